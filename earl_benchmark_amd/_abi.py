@@ -1,0 +1,78 @@
+"""ctypes view of include/earl_tabletop.h and the loader of the HIP shared library.
+
+The product path is GPU-only: if `csrc/libearl_hip.so` is missing or cannot be loaded this module
+raises -- there is no CPU fallback (the CPU oracle under oracle/ is test infrastructure and is never
+imported from here).
+"""
+import ctypes as C
+import os
+
+EARL_OK = 0
+REWARD_SPARSE, REWARD_DENSE = 0, 1
+REWARD_TYPES = {'sparse': REWARD_SPARSE, 'dense': REWARD_DENSE}
+
+
+class TabletopCfg(C.Structure):
+  _fields_ = [('n', C.c_int32), ('env_offset', C.c_int32), ('reward_type', C.c_int32), ('wide_init', C.c_int32),
+              ('reset_at_goal', C.c_int32), ('horizon', C.c_int32), ('goal_change_frequency', C.c_int32),
+              ('auto_reset', C.c_int32), ('n_goals', C.c_int32), ('n_sample_goals', C.c_int32),
+              ('seed', C.c_uint64), ('counter', C.c_uint64)]
+
+
+class TabletopState(C.Structure):
+  _fields_ = [('qpos', C.c_void_p), ('attached', C.c_void_p), ('goal_idx', C.c_void_p), ('goal_table', C.c_void_p),
+              ('steps_since_reset', C.c_void_p), ('num_interventions', C.c_void_p),
+              ('steps_since_goal_change', C.c_void_p), ('lifelong_return', C.c_void_p)]
+
+
+class TabletopOut(C.Structure):
+  _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p)]
+
+
+_P = C.POINTER
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/earl_tabletop.h one to one
+SIGNATURES = {
+    'earl_tabletop_step': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, _P(TabletopOut), C.c_void_p],
+    'earl_tabletop_rollout': [_P(TabletopCfg), _P(TabletopState), C.c_int32, C.c_void_p, _P(TabletopOut), C.c_void_p],
+    'earl_tabletop_reset': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_tabletop_observe': [_P(TabletopCfg), _P(TabletopState), _P(TabletopOut), C.c_void_p],
+    'earl_tabletop_reward': [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_tabletop_valid_init': [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_tabletop3_step': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, _P(TabletopOut), C.c_void_p],
+    'earl_tabletop3_rollout': [_P(TabletopCfg), _P(TabletopState), C.c_int32, C.c_void_p, _P(TabletopOut), C.c_void_p],
+    'earl_tabletop3_reset': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_tabletop3_reward': [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_version': [],
+    'earl_last_error': [],
+    'earl_device_count': [],
+}
+_RESTYPES = {'earl_version': C.c_char_p, 'earl_last_error': C.c_char_p}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libearl_hip.so')
+_lib = None
+
+
+class EarlHipError(RuntimeError):
+  pass
+
+
+def load():
+  """Load csrc/libearl_hip.so (built by `__graft_entry__.build()` / `make -C earl_benchmark_amd/csrc`)."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise EarlHipError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                         '(or `make -C earl_benchmark_amd/csrc`). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+      fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+      fn.argtypes = argtypes
+      fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+  return _lib
+
+
+def check(rc, what):
+  if rc != EARL_OK:
+    msg = load().earl_last_error()
+    raise EarlHipError(f'{what} failed with code {rc}: {msg.decode() if msg else "?"}')
