@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the tabletop_manipulation hot path on MI355X (BASELINE.json configs[1]).
+
+One bench "step" = one evaluation rollout of the whole batch: reset() + T = 200 wrapped env steps (the reference's
+eval horizon) of N = 4096 sparse-reward envs per GPU, executed by the reset kernel + ONE fused rollout kernel.
+Actions are synthetic U(-1,1) (pre-generated, resident in HBM); every step's obs / reward / done / success is
+written to HBM exactly as T step() calls would.  value = env-steps of all ranks / max-over-ranks wall time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--horizon 200] [--sweep] [--no-cpu]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Extra keys: "roofline" (fused rollout kernel: algorithmic bytes / HIP-event time
+vs 8 TB/s), "cpu_baseline" (the C oracle on the host cores, bounded sample), "step_api" (the same workload
+through per-step launches of the gym-style step()), and with --sweep "sweep" (throughput vs N).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BYTES_PER_ENV_STEP_ROLLOUT = 66  # act 12 B in; obs 48 + reward 4 + done 1 + success 1 B out
+BYTES_PER_ENV_STEP_STEP = 144    # + fp64 state in/out per launch: qpos 2x32, attached 2x1, goal_idx 4, steps 2x4
+STATE_BYTES_PER_ENV_LAUNCH = 2 * (32 + 1 + 4) + 4   # rollout: state read+written once per launch
+
+
+def parse():
+  p = argparse.ArgumentParser()
+  p.add_argument('--gpus', type=int, default=1)
+  p.add_argument('--steps', type=int, default=200)
+  p.add_argument('--warmup', type=int, default=20)
+  p.add_argument('--envs', type=int, default=4096, help='envs per GPU')
+  p.add_argument('--horizon', type=int, default=200)
+  p.add_argument('--reward', default='sparse')
+  p.add_argument('--sweep', action='store_true', help='also report throughput vs N (rank 0, single GPU)')
+  p.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+  p.add_argument('--cpu-seconds', type=float, default=10.0)
+  p.add_argument('--no-step-api', action='store_true')
+  return p.parse_args()
+
+
+def make_env(torch, n, horizon, reward, rank, device):
+  import earl_benchmark_amd as eb
+  loader = eb.EARLEnvs('tabletop_manipulation', reward_type=reward, num_envs=n, device=device, seed=0,
+                       env_offset=rank * n, eval_horizon=horizon, scalar_api=False)
+  _, env = loader.get_envs()
+  return env
+
+
+def synth_actions(torch, T, n, rank, device):
+  g = torch.Generator(device=device)
+  g.manual_seed(1234 + rank)
+  return (torch.rand(T, n, 3, generator=g, device=device) * 2 - 1).contiguous()
+
+
+def alloc_out(torch, T, n, device):
+  return (torch.empty(T, n, 12, dtype=torch.float32, device=device), torch.empty(T, n, dtype=torch.float32, device=device),
+          torch.empty(T, n, dtype=torch.bool, device=device), torch.empty(T, n, dtype=torch.bool, device=device))
+
+
+def time_rollouts(torch, dist, env, acts, out, steps, warmup, world):
+  """K x (reset + fused rollout), barrier + synchronize on both sides; HIP events around every rollout launch."""
+  for _ in range(warmup):
+    env.reset()
+    env.rollout(acts, out=out)
+  ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for k in range(steps):
+    env.reset()
+    ev[k][0].record()           # torch's current stream == the stream the kernels are launched on
+    env.rollout(acts, out=out)
+    ev[k][1].record()
+  gathered = None
+  if world > 1:                 # the one collective of the job: evaluation result of the last rollout -> every rank
+    summary = torch.stack([out[1].sum(0), out[3][-1].float()], 1).contiguous()      # [n, 2] return, final success
+    gathered = torch.empty(world * summary.shape[0], 2, dtype=summary.dtype, device=summary.device)
+    dist.all_gather_into_tensor(gathered, summary)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+  return dt, kern_ms, gathered
+
+
+def time_step_api(torch, env, acts, steps, warmup):
+  """the same workload through the gym-style API: one step() launch per env step (eager, no graph)."""
+  T = acts.shape[0]
+  for _ in range(max(1, warmup // 4)):
+    env.reset()
+    for t in range(T):
+      env.step(acts[t])
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(steps):
+    env.reset()
+    for t in range(T):
+      env.step(acts[t])
+  e1.record()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  return dt, e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline(n, T, reward, seconds):
+  """oracle/ (C restatement of the reference, OpenMP over envs) on the host cores: bounded sample of the same workload."""
+  import numpy as np
+  from oracle import tabletop_oracle as orc
+  o = orc.OracleTabletop(n, reward_type=reward, horizon=T, seed=0)
+  rng = np.random.default_rng(1234)
+  acts = rng.uniform(-1, 1, size=(T, n, 3)).astype(np.float32)
+  cores = os.cpu_count() or 1
+  o.reset(); o.rollout(acts)      # warm-up (thread pool, page faults)
+  reps, t0 = 0, time.perf_counter()
+  while time.perf_counter() - t0 < seconds:
+    o.reset()
+    o.rollout(acts)
+    reps += 1
+  dt = time.perf_counter() - t0
+  return {'value': reps * n * T / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+          'sample': f'{reps} rollouts of {n} envs x {T} steps ({reps * n * T} env-steps, {dt:.1f} s) through oracle/tabletop_oracle.c, '
+                    f'OpenMP static over envs, {cores} threads'}
+
+
+def main():
+  a = parse()
+  import torch
+  import torch.distributed as dist
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != a.gpus:
+    if world == 1 and a.gpus > 1:
+      sys.exit(f'--gpus {a.gpus} needs the torch.distributed.run launcher (one process per GPU)')
+    a.gpus = world
+  if not torch.cuda.is_available():
+    sys.exit('bench.py needs an MI355X (the hot path has no CPU fallback)')
+  torch.cuda.set_device(local_rank)
+  device = f'cuda:{local_rank}'
+  if world > 1:
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', device_id=torch.device(device))
+  n, T = a.envs, a.horizon
+
+  env = make_env(torch, n, T, a.reward, rank, device)
+  acts = synth_actions(torch, T, n, rank, device)
+  out = alloc_out(torch, T, n, device)
+  dt, kern_ms, gathered = time_rollouts(torch, dist, env, acts, out, a.steps, a.warmup, world)
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  total_env_steps = a.steps * n * T * world
+  value = total_env_steps / dt
+  assert bool(out[2][-1].all()) and not bool(out[2][:-1].any())     # done fires exactly at the horizon
+
+  res = None
+  if rank == 0:
+    kmean = sum(kern_ms) / len(kern_ms)
+    kmed = kern_ms[len(kern_ms) // 2]
+    bytes_per_launch = n * (T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH)
+    achieved = bytes_per_launch / (kmean * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+    if os.path.exists(tpath):
+      tj = json.load(open(tpath))
+      key = f'rollout_n{n}_T{T}'
+      traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
+    res = {
+        'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': value, 'unit': 'env-steps/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': f'tabletop_manipulation {a.reward} reward, {n} batched envs per MI355X, '
+                               f'reset + fused {T}-step rollout per bench step', 'envs_per_gpu': n,
+                   'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': n * T * world,
+                   'parallelism': f'env-range shard x{world}, no per-step collective'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'rollout_kernel<1>',
+                     'kernel_ms_mean': kmean, 'kernel_ms_median': kmed, 'algorithmic_bytes_per_launch': bytes_per_launch,
+                     'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT},
+    }
+    if not a.no_step_api:
+      env2 = make_env(torch, n, T, a.reward, rank, device)
+      ks = max(1, a.steps // 20)
+      sdt, sgpu = time_step_api(torch, env2, acts, ks, a.warmup)
+      res['step_api'] = {'value': ks * n * T / sdt, 'unit': 'env-steps/s', 'launches': ks * T,
+                         'us_per_step_call_wall': sdt / (ks * T) * 1e6, 'us_per_step_call_gpu': sgpu / (ks * T) * 1e6,
+                         'note': 'same workload, one eager step() launch per env step (host-launch bound at N=4096)',
+                         'achieved_GBs': n * BYTES_PER_ENV_STEP_STEP / (sgpu / (ks * T)) / 1e9}
+    if a.sweep:
+      sw = []
+      for ns in (64, 1024, 4096, 16384, 65536, 262144, 1048576):
+        Ts = T if ns * T * 66 < 12e9 else max(8, int(12e9 // (ns * 66)))
+        e = make_env(torch, ns, Ts, a.reward, 0, device)
+        ac = synth_actions(torch, Ts, ns, 0, device)
+        o = alloc_out(torch, Ts, ns, device)
+        k = max(3, min(a.steps, int(2e9 // (ns * Ts * 66)) + 3))
+        d, km, _ = time_rollouts(torch, dist, e, ac, o, k, 3, 1)
+        kmn = sum(km) / len(km)
+        sw.append({'envs': ns, 'T': Ts, 'env_steps_per_s': k * ns * Ts / d, 'kernel_ms': kmn,
+                   'GBs': ns * (Ts * 66 + STATE_BYTES_PER_ENV_LAUNCH) / (kmn * 1e-3) / 1e9})
+        del e, ac, o
+        torch.cuda.empty_cache()
+      res['sweep'] = sw
+    if not a.no_cpu:
+      res['cpu_baseline'] = cpu_baseline(n, T, a.reward, a.cpu_seconds)
+    else:
+      res['cpu_baseline'] = None
+    print(json.dumps(res), flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

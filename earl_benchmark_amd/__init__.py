@@ -1,0 +1,141 @@
+"""earl_benchmark_amd -- MI355X-native drop-in for the step()/reset() hot path of EARL.
+
+Public surface mirrors the reference's loader (reference: earl_benchmark/__init__.py):
+
+    import earl_benchmark_amd as earl_benchmark
+    loader = earl_benchmark.EARLEnvs('tabletop_manipulation', reward_type='sparse', num_envs=4096)
+    train_env, eval_env = loader.get_envs()
+    initial_states, goal_states = loader.get_initial_states(), loader.get_goal_states()
+    forward_demos, reverse_demos = loader.get_demonstrations()
+
+Extra keyword arguments of this build: `num_envs` (batch of independent env instances stepped by one HIP
+kernel launch), `device`, `seed`, `env_offset` (global id of env 0 when sharding over GPUs), `auto_reset`.
+Environment arithmetic runs only in the HIP library (csrc/); there is no CPU fallback.
+"""
+import os
+
+import numpy as np
+
+from . import tables
+
+__version__ = '0.1.0'
+
+# reference: earl_benchmark/__init__.py:16-47
+deployment_eval_config = {
+    'tabletop_manipulation': {'num_initial_state_samples': 1, 'num_goals': 4, 'train_horizon': int(2e5), 'eval_horizon': 200},
+    'sawyer_door': {'num_initial_state_samples': 1, 'num_goals': 1, 'train_horizon': int(2e5), 'eval_horizon': 300},
+    'sawyer_peg': {'num_initial_state_samples': 15, 'num_goals': 1, 'train_horizon': int(1e5), 'eval_horizon': 200},
+    'kitchen': {'num_initial_state_samples': 1, 'train_horizon': int(1e5), 'eval_horizon': 400, 'task': 'all_pairs'},
+    'minitaur': {'num_initial_state_samples': 1, 'num_goals': 4, 'train_horizon': int(1e5), 'eval_horizon': 1000},
+}
+# reference: earl_benchmark/__init__.py:50-81
+continuing_eval_config = {
+    'tabletop_manipulation': {'num_initial_state_samples': 1, 'num_goals': 4, 'train_horizon': int(5e4), 'goal_change_frequency': 400},
+    'sawyer_door': {'num_initial_state_samples': 1, 'num_goals': 1, 'train_horizon': int(5e4), 'goal_change_frequency': 600},
+    'sawyer_peg': {'num_initial_state_samples': 15, 'num_goals': 1, 'train_horizon': int(5e4), 'goal_change_frequency': 400},
+    'kitchen': {'num_initial_state_samples': 1, 'train_horizon': int(5e4), 'goal_change_frequency': 800, 'task': 'all_pairs'},
+    'minitaur': {'num_initial_state_samples': 1, 'num_goals': 4, 'train_horizon': int(1e5), 'goal_change_frequency': 2000},
+}
+
+_NOT_BUILT = ('{name}: the physics-backed envs (MuJoCo / Bullet dynamics) are not built in this round; '
+              'only their initial/goal-state tables and demonstrations are available. See DESIGN.md "out of scope".')
+
+
+class EARLEnvs(object):
+  """Same constructor and methods as the reference's EARLEnvs (earl_benchmark/__init__.py:83-247)."""
+
+  def __init__(self, env_name, reward_type='sparse', reset_train_env_at_goal=False, setup_as_lifelong_learning=False,
+               **kwargs):
+    if env_name not in deployment_eval_config:
+      raise KeyError(env_name)
+    self._env_name = env_name
+    self._reward_type = reward_type
+    self._reset_train_env_at_goal = reset_train_env_at_goal
+    self._setup_as_lifelong_learning = setup_as_lifelong_learning
+    self._kwargs = kwargs
+    self._batch_kwargs = {k: kwargs[k] for k in ('num_envs', 'device', 'seed', 'env_offset', 'scalar_api', 'auto_reset') if k in kwargs}
+
+    if not self._setup_as_lifelong_learning:
+      cfg = deployment_eval_config[env_name]
+      self._train_horizon = kwargs.get('train_horizon', cfg['train_horizon'])
+      self._eval_horizon = kwargs.get('eval_horizon', cfg['eval_horizon'])
+      self._num_initial_state_samples = kwargs.get('num_initial_state_samples', cfg['num_initial_state_samples'])
+      self._train_env = self.get_train_env()
+      self._eval_env = self.get_eval_env()
+    else:
+      cfg = continuing_eval_config[env_name]
+      self._train_horizon = kwargs.get('train_horizon', cfg['train_horizon'])
+      self._num_initial_state_samples = kwargs.get('num_initial_state_samples', cfg['num_initial_state_samples'])
+      self._goal_change_frequency = kwargs.get('goal_change_frequency', cfg['goal_change_frequency'])
+      self._train_env = self.get_train_env(lifelong=True)
+
+  def _make_env(self, reset_at_goal, seed_salt):
+    from . import wrappers  # noqa: F401  (imports torch lazily: tables/demos work without a GPU)
+    if self._env_name == 'tabletop_manipulation':
+      from .envs import tabletop
+      kw = dict(self._batch_kwargs)
+      kw['seed'] = int(kw.get('seed', 0)) + seed_salt   # train and eval envs draw from different streams
+      return tabletop.TabletopManipulation(task_list='rc_r-rc_k-rc_g-rc_b', reward_type=self._reward_type,
+                                           reset_at_goal=reset_at_goal,
+                                           wide_init_distr=self._kwargs.get('wide_init_distr', False), **kw)
+    if self._env_name == 'kitchen' and self._reward_type != 'dense':
+      raise ValueError('Kitchen environment only supports dense rewards.')  # reference: envs/kitchen.py:91-92
+    raise NotImplementedError(_NOT_BUILT.format(name=self._env_name))
+
+  def get_train_env(self, lifelong=False):
+    from . import wrappers
+    train_env = self._make_env(self._reset_train_env_at_goal, seed_salt=0)
+    train_env = wrappers.PersistentStateWrapper(train_env, episode_horizon=self._train_horizon)
+    if not lifelong:
+      return train_env
+    return wrappers.LifelongWrapper(train_env, self._goal_change_frequency)
+
+  def get_eval_env(self):
+    from . import wrappers
+    eval_env = self._make_env(False, seed_salt=0x9E3779B9)
+    return wrappers.PersistentStateWrapper(eval_env, episode_horizon=self._eval_horizon)
+
+  def has_demos(self):
+    return self._env_name in ['tabletop_manipulation', 'sawyer_door', 'sawyer_peg']
+
+  def get_envs(self):
+    if not self._setup_as_lifelong_learning:
+      return self._train_env, self._eval_env
+    return self._train_env
+
+  def get_initial_states(self, num_samples=None):
+    """Always returns initial states of shape N x state_dim (reference :185-219)."""
+    del num_samples
+    if self._env_name == 'minitaur':
+      # the reference builds these from env.reset() observations and crashes (`set` of ndarrays, :213-217)
+      raise NotImplementedError(_NOT_BUILT.format(name='minitaur'))
+    return tables.initial_states(self._env_name)
+
+  def get_goal_states(self):
+    if self._env_name == 'minitaur':
+      return None  # the reference falls off the end of the function (:221-236)
+    return tables.goal_states(self._env_name)
+
+  def get_demonstrations(self):
+    """(forward_demos, reverse_demos): dicts with observations, actions, rewards, terminals, next_observations,
+    infos -- the reference's pickle layout (:238-247), stored here as .npz (a demo_data.pkl next to it is also read)."""
+    demo_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'demonstrations')
+    try:
+      return tuple(load_demo(os.path.join(demo_dir, self._env_name, d)) for d in ('forward', 'reverse'))
+    except Exception:
+      print('please download the demonstrations corresponding to ', self._env_name)
+
+
+DEMO_KEYS = ('observations', 'actions', 'rewards', 'terminals', 'next_observations', 'infos')
+
+
+def load_demo(directory):
+  """Read one demonstration set: demo_data.npz (this build) or demo_data.pkl (the reference's format)."""
+  npz = os.path.join(directory, 'demo_data.npz')
+  if os.path.exists(npz):
+    with np.load(npz) as z:
+      return {k: z[k] for k in DEMO_KEYS}
+  import pickle
+  with open(os.path.join(directory, 'demo_data.pkl'), 'rb') as f:
+    demo = pickle.load(f)
+  return {k: np.asarray(demo[k]) for k in DEMO_KEYS}

@@ -1,0 +1,421 @@
+// tabletop.hip -- HIP kernels (gfx950) + the C ABI of include/earl_tabletop.h.
+//
+// Kernels (all one lane per env, 256-thread workgroups = 4 wavefronts of 64 envs):
+//   step_kernel<NOBJ>     one wrapped env step: act -> move -> obs -> reward/success -> horizon -> lifelong
+//   rollout_kernel<NOBJ>  T steps per launch, state held in VGPRs, only act in / obs,reward,flags out per step
+//   reset_kernel<NOBJ>    masked reset + observation of every env
+//   observe/reward/valid_init kernels: the pure functions of the reference API
+// HBM-bound streaming work: no MFMA, nothing GEMM-shaped.  See DESIGN.md for bytes/env-step and rooflines.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "tabletop_device.h"
+
+using namespace earl;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct KArgs {
+  earl_tabletop_cfg cfg;
+  earl_tabletop_state st;
+  earl_tabletop_out out;
+  const float* act;
+  const int32_t* next_goal_idx;
+  const uint8_t* mask;
+  float* obs_only;
+  int32_t T;
+  Thresholds th;
+};
+
+// ------------------------------------------------------------------------------------------------
+// per-lane state I/O
+// ------------------------------------------------------------------------------------------------
+template <int NOBJ>
+struct Lane {
+  Env<NOBJ> e;
+  int goal_idx;
+  int steps;
+  int sgc;      // steps since goal change (lifelong)
+  double lret;  // lifelong return
+  int resets;   // resets performed inside this launch (auto_reset)
+};
+
+template <int NOBJ>
+__device__ __forceinline__ void load_lane(const KArgs& a, int i, Lane<NOBJ>& L) {
+  constexpr int NQ = Dims<NOBJ>::NQ;
+  const double2* q2 = reinterpret_cast<const double2*>(a.st.qpos + (size_t)i * NQ);
+#pragma unroll
+  for (int k = 0; k < NQ / 2; ++k) {
+    const double2 v = q2[k];
+    L.e.q[2 * k] = v.x;
+    L.e.q[2 * k + 1] = v.y;
+  }
+  L.e.attached = a.st.attached[i];
+  L.goal_idx = a.st.goal_idx[i];
+  L.steps = a.st.steps_since_reset[i];
+  L.resets = 0;
+  if (a.cfg.goal_change_frequency > 0) {
+    L.sgc = a.st.steps_since_goal_change[i];
+    L.lret = a.st.lifelong_return[i];
+  } else {
+    L.sgc = 0;
+    L.lret = 0.0;
+  }
+}
+
+template <int NOBJ>
+__device__ __forceinline__ void store_lane(const KArgs& a, int i, const Lane<NOBJ>& L) {
+  constexpr int NQ = Dims<NOBJ>::NQ;
+  double2* q2 = reinterpret_cast<double2*>(a.st.qpos + (size_t)i * NQ);
+#pragma unroll
+  for (int k = 0; k < NQ / 2; ++k) q2[k] = double2{L.e.q[2 * k], L.e.q[2 * k + 1]};
+  a.st.attached[i] = (int8_t)L.e.attached;
+  a.st.steps_since_reset[i] = L.steps;
+  if (a.cfg.goal_change_frequency > 0) {
+    a.st.steps_since_goal_change[i] = L.sgc;
+    a.st.lifelong_return[i] = L.lret;
+    a.st.goal_idx[i] = L.goal_idx;
+  }
+  if (L.resets) {
+    a.st.goal_idx[i] = L.goal_idx;
+    a.st.num_interventions[i] += L.resets;
+  }
+}
+
+template <int NOBJ>
+__device__ __forceinline__ void store_obs(float* __restrict__ dst, const float (&o)[Dims<NOBJ>::NOBS]) {
+  float4* d4 = reinterpret_cast<float4*>(dst);  // rows are 48 B / 80 B: 16-byte aligned
+#pragma unroll
+  for (int k = 0; k < Dims<NOBJ>::NOBS / 4; ++k) d4[k] = float4{o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]};
+}
+
+// One wrapped step on register state.  `counter` is the Philox counter of THIS step.
+template <int NOBJ>
+__device__ __forceinline__ void wrapped_step(const KArgs& a, int i, uint64_t counter, Lane<NOBJ>& L,
+                                             float (&g)[Dims<NOBJ>::NG], float a0, float a1, float a2,
+                                             float (&o)[Dims<NOBJ>::NOBS], float& reward, bool& done, bool& succ) {
+  move<NOBJ>(L.e, rescale_action(a0), rescale_action(a1), rescale_action(a2), a.th);
+  make_obs<NOBJ>(L.e, g, o);
+  double r;
+  reward_success<NOBJ>(o, a.cfg.reward_type, a.cfg.wide_init, a.th, r, succ);
+  reward = (float)r;
+  L.steps += 1;                       // persistent_state_wrapper.py:25-26
+  done = L.steps >= a.cfg.horizon;    // :28-29
+  if constexpr (NOBJ == 1) {
+    if (a.cfg.goal_change_frequency > 0) {  // lifelong_wrapper.py:30-44
+      L.sgc += 1;
+      L.lret += r;
+      if (L.sgc >= a.cfg.goal_change_frequency) {
+        L.sgc = 0;
+        L.goal_idx = sample_goal(a.cfg, counter, i, a.next_goal_idx);
+        load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
+#pragma unroll
+        for (int k = 0; k < Dims<NOBJ>::NG; ++k) o[Dims<NOBJ>::NQ + 2 + k] = g[k];  // obs re-read with the new goal
+      }
+    }
+  }
+  if (done && a.cfg.auto_reset) {  // batched-only extension; the outputs above stay the terminal ones
+    L.goal_idx = reset_env<NOBJ>(L.e, a.cfg, counter, i, a.st.goal_table, a.next_goal_idx, a.th);
+    load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
+    L.steps = 0;
+    L.sgc = 0;
+    L.resets += 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+template <int NOBJ>
+__global__ __launch_bounds__(kBlock) void step_kernel(const KArgs a) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.cfg.n) return;
+  Lane<NOBJ> L;
+  load_lane<NOBJ>(a, i, L);
+  float g[Dims<NOBJ>::NG];
+  load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
+  const float* ap = a.act + (size_t)i * 3;
+  float o[Dims<NOBJ>::NOBS];
+  float reward;
+  bool done, succ;
+  wrapped_step<NOBJ>(a, i, a.cfg.counter, L, g, ap[0], ap[1], ap[2], o, reward, done, succ);
+  if (a.out.obs) store_obs<NOBJ>(a.out.obs + (size_t)i * Dims<NOBJ>::NOBS, o);
+  if (a.out.reward) a.out.reward[i] = reward;
+  if (a.out.done) a.out.done[i] = done;
+  if (a.out.success) a.out.success[i] = succ;
+  store_lane<NOBJ>(a, i, L);
+}
+
+template <int NOBJ>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(const KArgs a) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int n = a.cfg.n;
+  if (i >= n) return;
+  Lane<NOBJ> L;
+  load_lane<NOBJ>(a, i, L);
+  float g[Dims<NOBJ>::NG];
+  load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
+  constexpr int PF = 8;  // actions are state-independent: fetch PF steps ahead to keep loads in flight
+  for (int t0 = 0; t0 < a.T; t0 += PF) {
+    float av[PF][3];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int t = t0 + k < a.T ? t0 + k : a.T - 1;
+      const float* ap = a.act + ((size_t)t * n + i) * 3;
+      av[k][0] = ap[0];
+      av[k][1] = ap[1];
+      av[k][2] = ap[2];
+    }
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int t = t0 + k;
+      if (t < a.T) {
+        float o[Dims<NOBJ>::NOBS];
+        float reward;
+        bool done, succ;
+        wrapped_step<NOBJ>(a, i, a.cfg.counter + (uint64_t)t, L, g, av[k][0], av[k][1], av[k][2], o, reward, done, succ);
+        const size_t row = (size_t)t * n + i;
+        if (a.out.obs) store_obs<NOBJ>(a.out.obs + row * Dims<NOBJ>::NOBS, o);
+        if (a.out.reward) a.out.reward[row] = reward;
+        if (a.out.done) a.out.done[row] = done;
+        if (a.out.success) a.out.success[row] = succ;
+      }
+    }
+  }
+  store_lane<NOBJ>(a, i, L);
+}
+
+template <int NOBJ>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs a) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.cfg.n) return;
+  Lane<NOBJ> L;
+  load_lane<NOBJ>(a, i, L);
+  if (!a.mask || a.mask[i]) {
+    L.goal_idx = reset_env<NOBJ>(L.e, a.cfg, a.cfg.counter, i, a.st.goal_table, a.next_goal_idx, a.th);
+    L.steps = 0;   // persistent_state_wrapper.py:18-19
+    L.sgc = 0;     // lifelong_wrapper.py:26-27
+    L.resets = 1;
+    store_lane<NOBJ>(a, i, L);
+  }
+  if (a.obs_only) {
+    float g[Dims<NOBJ>::NG], o[Dims<NOBJ>::NOBS];
+    load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
+    make_obs<NOBJ>(L.e, g, o);
+    store_obs<NOBJ>(a.obs_only + (size_t)i * Dims<NOBJ>::NOBS, o);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void observe_kernel(const KArgs a) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.cfg.n) return;
+  Lane<1> L;
+  load_lane<1>(a, i, L);
+  float g[6], o[12];
+  load_goal<1>(a.st.goal_table, L.goal_idx, g);
+  make_obs<1>(L.e, g, o);
+  double r;
+  bool succ;
+  reward_success<1>(o, a.cfg.reward_type, a.cfg.wide_init, a.th, r, succ);
+  if (a.out.obs) store_obs<1>(a.out.obs + (size_t)i * 12, o);
+  if (a.out.reward) a.out.reward[i] = (float)r;
+  if (a.out.success) a.out.success[i] = succ;
+  if (a.out.done) a.out.done[i] = L.steps >= a.cfg.horizon;
+}
+
+template <int NOBJ>
+__global__ __launch_bounds__(kBlock) void reward_kernel(int n, const float* __restrict__ obs, int reward_type, int wide,
+                                                        float* __restrict__ reward, uint8_t* __restrict__ success,
+                                                        const Thresholds th) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  constexpr int NOBS = Dims<NOBJ>::NOBS;
+  float o[NOBS];
+  const float4* s4 = reinterpret_cast<const float4*>(obs + (size_t)i * NOBS);
+#pragma unroll
+  for (int k = 0; k < NOBS / 4; ++k) {
+    const float4 v = s4[k];
+    o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+  }
+  double r;
+  bool succ;
+  reward_success<NOBJ>(o, reward_type, wide, th, r, succ);
+  if (reward) reward[i] = (float)r;
+  if (success) success[i] = succ;
+}
+
+__global__ __launch_bounds__(kBlock) void valid_init_kernel(int n, const double* __restrict__ cand,
+                                                            uint8_t* __restrict__ valid, const Thresholds th) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const double2* c2 = reinterpret_cast<const double2*>(cand + (size_t)i * 4);
+  const double2 u = c2[0], v = c2[1];
+  const double s[4] = {u.x, u.y, v.x, v.y};
+  valid[i] = valid_init(s, th);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// smallest double s with sqrt(s) >= c  (so that  sqrt(d2) < c  <=>  d2 < s)
+double lt_threshold_f64(double c) {
+  double s = c * c;
+  while (std::sqrt(s) >= c) s = std::nextafter(s, 0.0);
+  while (std::sqrt(s) < c) s = std::nextafter(s, INFINITY);
+  return s;
+}
+// largest float s with (double)sqrtf(s) <= c  (so that  (double)sqrtf(x) <= c  <=>  x <= s)
+float le_threshold_f32(double c) {
+  float s = (float)(c * c);
+  while ((double)std::sqrt(s) <= c) s = std::nextafterf(s, INFINITY);
+  while ((double)std::sqrt(s) > c) s = std::nextafterf(s, 0.0f);
+  return s;
+}
+const Thresholds& thresholds() {
+  static const Thresholds th = {lt_threshold_f64(0.4), lt_threshold_f64(1.0), le_threshold_f32(0.2), le_threshold_f32(0.4)};
+  return th;
+}
+
+int check_common(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int nobj) {
+  if (!cfg || !st) return fail(EARL_ERR_ARG, "cfg/state is NULL");
+  if (cfg->n < 0) return fail(EARL_ERR_ARG, "n = %d < 0", cfg->n);
+  if (!st->qpos || !st->attached || !st->goal_idx || !st->goal_table || !st->steps_since_reset || !st->num_interventions)
+    return fail(EARL_ERR_ARG, "state has a NULL array");
+  if (cfg->n_goals < 1 || cfg->n_sample_goals < 1 || cfg->n_sample_goals > cfg->n_goals)
+    return fail(EARL_ERR_ARG, "bad goal table sizes n_goals=%d n_sample_goals=%d", cfg->n_goals, cfg->n_sample_goals);
+  if (cfg->reward_type != EARL_REWARD_SPARSE && cfg->reward_type != EARL_REWARD_DENSE)
+    return fail(EARL_ERR_ARG, "reward_type = %d", cfg->reward_type);
+  if (cfg->goal_change_frequency < 0 || cfg->horizon < 0) return fail(EARL_ERR_ARG, "negative horizon/frequency");
+  if (cfg->goal_change_frequency > 0 && (!st->steps_since_goal_change || !st->lifelong_return))
+    return fail(EARL_ERR_ARG, "lifelong mode needs steps_since_goal_change and lifelong_return");
+  if (nobj == 3 && (cfg->wide_init || cfg->reset_at_goal || cfg->goal_change_frequency))
+    return fail(EARL_ERR_ARG, "3-object variant: wide_init / reset_at_goal / lifelong are not supported");
+  return EARL_OK;
+}
+
+int launched(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(EARL_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return EARL_OK;
+}
+
+inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+template <int NOBJ>
+int do_step(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const float* act, const int32_t* ngi,
+            const earl_tabletop_out* out, earl_stream_t stream) {
+  if (int rc = check_common(cfg, st, NOBJ)) return rc;
+  if (!act || !out) return fail(EARL_ERR_ARG, "act/out is NULL");
+  if (cfg->n == 0) return EARL_OK;
+  KArgs a{*cfg, *st, *out, act, ngi, nullptr, nullptr, 1, thresholds()};
+  step_kernel<NOBJ><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
+  return launched("step_kernel");
+}
+
+template <int NOBJ>
+int do_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act,
+               const earl_tabletop_out* out, earl_stream_t stream) {
+  if (int rc = check_common(cfg, st, NOBJ)) return rc;
+  if (!act || !out) return fail(EARL_ERR_ARG, "act/out is NULL");
+  if (T < 0) return fail(EARL_ERR_ARG, "T = %d < 0", T);
+  if (cfg->n == 0 || T == 0) return EARL_OK;
+  KArgs a{*cfg, *st, *out, act, nullptr, nullptr, nullptr, T, thresholds()};
+  rollout_kernel<NOBJ><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
+  return launched("rollout_kernel");
+}
+
+template <int NOBJ>
+int do_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const uint8_t* mask, const int32_t* ngi,
+             float* obs, earl_stream_t stream) {
+  if (int rc = check_common(cfg, st, NOBJ)) return rc;
+  if (cfg->n == 0) return EARL_OK;
+  KArgs a{*cfg, *st, earl_tabletop_out{nullptr, nullptr, nullptr, nullptr}, nullptr, ngi, mask, obs, 0, thresholds()};
+  reset_kernel<NOBJ><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
+  return launched("reset_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+int earl_tabletop_step(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const float* act,
+                       const int32_t* next_goal_idx, const earl_tabletop_out* out, earl_stream_t stream) {
+  return do_step<1>(cfg, st, act, next_goal_idx, out, stream);
+}
+int earl_tabletop_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act,
+                          const earl_tabletop_out* out, earl_stream_t stream) {
+  return do_rollout<1>(cfg, st, T, act, out, stream);
+}
+int earl_tabletop_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const uint8_t* mask,
+                        const int32_t* next_goal_idx, float* obs, earl_stream_t stream) {
+  return do_reset<1>(cfg, st, mask, next_goal_idx, obs, stream);
+}
+int earl_tabletop_observe(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const earl_tabletop_out* out,
+                          earl_stream_t stream) {
+  if (int rc = check_common(cfg, st, 1)) return rc;
+  if (!out) return fail(EARL_ERR_ARG, "out is NULL");
+  if (cfg->n == 0) return EARL_OK;
+  KArgs a{*cfg, *st, *out, nullptr, nullptr, nullptr, nullptr, 0, thresholds()};
+  observe_kernel<<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
+  return launched("observe_kernel");
+}
+int earl_tabletop_reward(int32_t n, const float* obs, int32_t reward_type, int32_t wide_init, float* reward,
+                         uint8_t* success, earl_stream_t stream) {
+  if (n < 0 || !obs) return fail(EARL_ERR_ARG, "bad n/obs");
+  if (reward_type != EARL_REWARD_SPARSE && reward_type != EARL_REWARD_DENSE) return fail(EARL_ERR_ARG, "reward_type = %d", reward_type);
+  if (n == 0) return EARL_OK;
+  reward_kernel<1><<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(n, obs, reward_type, wide_init, reward, success, thresholds());
+  return launched("reward_kernel");
+}
+int earl_tabletop_valid_init(int32_t n, const double* cand, uint8_t* valid, earl_stream_t stream) {
+  if (n < 0 || !cand || !valid) return fail(EARL_ERR_ARG, "bad n/cand/valid");
+  if (n == 0) return EARL_OK;
+  valid_init_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(n, cand, valid, thresholds());
+  return launched("valid_init_kernel");
+}
+
+int earl_tabletop3_step(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const float* act,
+                        const earl_tabletop_out* out, earl_stream_t stream) {
+  return do_step<3>(cfg, st, act, nullptr, out, stream);
+}
+int earl_tabletop3_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act,
+                           const earl_tabletop_out* out, earl_stream_t stream) {
+  return do_rollout<3>(cfg, st, T, act, out, stream);
+}
+int earl_tabletop3_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const uint8_t* mask, float* obs,
+                         earl_stream_t stream) {
+  return do_reset<3>(cfg, st, mask, nullptr, obs, stream);
+}
+int earl_tabletop3_reward(int32_t n, const float* obs, int32_t reward_type, float* reward, uint8_t* success,
+                          earl_stream_t stream) {
+  if (n < 0 || !obs) return fail(EARL_ERR_ARG, "bad n/obs");
+  if (reward_type != EARL_REWARD_SPARSE && reward_type != EARL_REWARD_DENSE) return fail(EARL_ERR_ARG, "reward_type = %d", reward_type);
+  if (n == 0) return EARL_OK;
+  reward_kernel<3><<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(n, obs, reward_type, 0, reward, success, thresholds());
+  return launched("reward_kernel3");
+}
+
+const char* earl_version(void) { return "earl-hip 0.1 (gfx950)"; }
+const char* earl_last_error(void) { return g_err; }
+int earl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+}  // extern "C"

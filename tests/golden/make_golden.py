@@ -295,14 +295,47 @@ def gen_demos():
 # --------------------------------------------------------------------------------------
 # F. loader constants
 # --------------------------------------------------------------------------------------
+def _module_constants(relpath, names, start=None, stop=None):
+  """Evaluate module-level numeric tables of a reference file whose imports (metaworld, mujoco_py) are absent here:
+  only the top-level assignments / helper defs between `start` and `stop` are executed, with numpy in scope."""
+  import ast
+  src = open(os.path.join(REF, 'earl_benchmark', relpath)).read()
+  tree = ast.parse(src)
+  ns = {'np': np}
+  for node in tree.body:
+    if isinstance(node, ast.ClassDef):
+      break
+    if isinstance(node, (ast.Assign, ast.FunctionDef)):
+      seg = ast.get_source_segment(src, node)
+      if isinstance(node, ast.Assign) and 'os.path' in seg:
+        continue
+      exec(compile(ast.Module([node], []), relpath, 'exec'), ns)
+  return {k: ns[k] for k in names}
+
+
 def gen_loader_tables():
+  """initial/goal-state tables the loader returns (get_initial_states / get_goal_states, __init__.py:185-236).
+  Written twice: as a golden (tests) and as the product's data file earl_benchmark_amd/tables.npz."""
   out = {}
-  for name in ('tabletop_manipulation',):
-    L = ref_pkg.EARLEnvs(name, 'sparse')
-    out[f'{name}_initial_states'] = np.asarray(L.get_initial_states())
-    out[f'{name}_goal_states'] = np.asarray(L.get_goal_states())
+  L = ref_pkg.EARLEnvs('tabletop_manipulation', 'sparse')
+  out['tabletop_manipulation_initial_states'] = np.asarray(L.get_initial_states())
+  out['tabletop_manipulation_goal_states'] = np.asarray(L.get_goal_states())
   out['tabletop_3obj_initial_states'] = ref_t3.initial_states
   out['tabletop_3obj_goal_states'] = ref_t3.goal_states
+  c = _module_constants('envs/sawyer_door.py', ['initial_states', 'goal_states'])
+  out['sawyer_door_initial_states'], out['sawyer_door_goal_states'] = c['initial_states'], c['goal_states']
+  c = _module_constants('envs/sawyer_peg.py', ['initial_states', 'goal_states', 'wide_initial_states'])
+  out['sawyer_peg_initial_states'], out['sawyer_peg_goal_states'] = c['initial_states'], c['goal_states']
+  out['sawyer_peg_wide_initial_states'] = c['wide_initial_states']
+  c = _module_constants('envs/kitchen.py', ['initial_states', 'goal_states'])
+  out['kitchen_initial_states'] = c['initial_states']['all_pairs']      # Kitchen.get_init_states() (kitchen.py:103-104)
+  out['kitchen_goal_states'] = c['goal_states']
+  for k, v in c['initial_states'].items():
+    out[f'kitchen_task_{k}'] = np.atleast_2d(v)
+  shapes = {k: v.shape for k, v in out.items()}
+  assert shapes['sawyer_door_initial_states'] == (1, 7) and shapes['sawyer_peg_initial_states'] == (15, 7)
+  assert shapes['kitchen_initial_states'] == (6, 23) and shapes['kitchen_goal_states'] == (1, 23)
+  np.savez_compressed(os.path.join(REPO, 'earl_benchmark_amd', 'tables.npz'), **out)
   return out
 
 

@@ -1,0 +1,146 @@
+"""Drives csrc/libearl_hip.so through the C ABI (ctypes + raw device pointers) with the same call sequence and
+host-side (numpy) inputs/outputs as oracle.tabletop_oracle.OracleTabletop, so parity tests read the same on both."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from earl_benchmark_amd import _abi
+from oracle.tabletop_oracle import GOAL_TABLE, GOAL_TABLE3
+
+
+def _ptr(t):
+  return None if t is None else t.data_ptr()
+
+
+class HipTabletop:
+  def __init__(self, n, reward_type='sparse', wide_init=False, reset_at_goal=False, horizon=200,
+               goal_change_frequency=0, auto_reset=False, seed=0, env_offset=0, goal_table=None, nobj=1,
+               n_sample_goals=None, device='cuda:0'):
+    self.lib = _abi.load()
+    self.dev = torch.device(device)
+    self.n, self.nobj = n, nobj
+    self.nq = 2 + 2 * nobj
+    self.obs_dim = 2 * self.nq + 4
+    gt = goal_table if goal_table is not None else (GOAL_TABLE if nobj == 1 else GOAL_TABLE3)
+    kw = dict(device=self.dev)
+    self.goal_table = torch.tensor(np.ascontiguousarray(gt, np.float64), **kw)
+    self.cfg = _abi.TabletopCfg(n=n, env_offset=env_offset, reward_type={'sparse': 0, 'dense': 1}[reward_type],
+                                wide_init=int(wide_init), reset_at_goal=int(reset_at_goal), horizon=horizon,
+                                goal_change_frequency=goal_change_frequency, auto_reset=int(auto_reset),
+                                n_goals=len(gt), n_sample_goals=n_sample_goals or (4 if nobj == 1 else 1),
+                                seed=seed, counter=0)
+    self.qpos = torch.zeros(n, self.nq, dtype=torch.float64, **kw)
+    self.attached = torch.full((n,), -1, dtype=torch.int8, **kw)
+    self.goal_idx = torch.zeros(n, dtype=torch.int32, **kw)
+    self.steps_since_reset = torch.zeros(n, dtype=torch.int32, **kw)
+    self.num_interventions = torch.zeros(n, dtype=torch.int32, **kw)
+    self.steps_since_goal_change = torch.zeros(n, dtype=torch.int32, **kw)
+    self.lifelong_return = torch.zeros(n, dtype=torch.float64, **kw)
+    self._pfx = 'earl_tabletop_' if nobj == 1 else 'earl_tabletop3_'
+    self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+
+  STATE = ('qpos', 'attached', 'goal_idx', 'steps_since_reset', 'num_interventions', 'steps_since_goal_change',
+           'lifelong_return')
+
+  def set_from(self, oracle):
+    """copy the oracle's host state (and goal table / counter) to the device"""
+    self.goal_table = torch.tensor(oracle.goal_table, device=self.dev)
+    self.cfg.n_goals = len(oracle.goal_table)
+    for k in self.STATE:
+      getattr(self, k).copy_(torch.from_numpy(getattr(oracle, k)))
+    self.cfg.counter = oracle.cfg.counter
+
+  def host(self, k):
+    return getattr(self, k).cpu().numpy()
+
+  def _state(self):
+    return _abi.TabletopState(_ptr(self.qpos), _ptr(self.attached), _ptr(self.goal_idx), _ptr(self.goal_table),
+                              _ptr(self.steps_since_reset), _ptr(self.num_interventions),
+                              _ptr(self.steps_since_goal_change), _ptr(self.lifelong_return))
+
+  def _outs(self, lead):
+    kw = dict(device=self.dev)
+    obs = torch.full(lead + (self.obs_dim,), float('nan'), dtype=torch.float32, **kw)
+    rew = torch.full(lead, float('nan'), dtype=torch.float32, **kw)
+    done = torch.full(lead, 7, dtype=torch.uint8, **kw)
+    succ = torch.full(lead, 7, dtype=torch.uint8, **kw)
+    return (obs, rew, done, succ), _abi.TabletopOut(_ptr(obs), _ptr(rew), _ptr(done), _ptr(succ))
+
+  def _dev(self, a, dtype):
+    return None if a is None else torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=self.dev)
+
+  def _ok(self, rc, what):
+    _abi.check(rc, what)
+    torch.cuda.synchronize(self.dev)
+
+  def reset(self, mask=None, next_goal_idx=None):
+    obs = torch.full((self.n, self.obs_dim), float('nan'), dtype=torch.float32, device=self.dev)
+    m, g = self._dev(mask, torch.uint8), self._dev(next_goal_idx, torch.int32)
+    st = self._state()
+    if self.nobj == 1:
+      rc = self.lib.earl_tabletop_reset(C.byref(self.cfg), C.byref(st), _ptr(m), _ptr(g), _ptr(obs), self.stream)
+    else:
+      rc = self.lib.earl_tabletop3_reset(C.byref(self.cfg), C.byref(st), _ptr(m), _ptr(obs), self.stream)
+    self._ok(rc, 'reset')
+    self.cfg.counter += 1
+    return obs.cpu().numpy()
+
+  def step(self, act, next_goal_idx=None):
+    a = self._dev(act, torch.float32)
+    assert a.shape == (self.n, 3)
+    arrs, out = self._outs((self.n,))
+    st = self._state()
+    if self.nobj == 1:
+      g = self._dev(next_goal_idx, torch.int32)
+      rc = self.lib.earl_tabletop_step(C.byref(self.cfg), C.byref(st), _ptr(a), _ptr(g), C.byref(out), self.stream)
+    else:
+      rc = self.lib.earl_tabletop3_step(C.byref(self.cfg), C.byref(st), _ptr(a), C.byref(out), self.stream)
+    self._ok(rc, 'step')
+    self.cfg.counter += 1
+    return tuple(x.cpu().numpy() for x in arrs)
+
+  def rollout(self, act):
+    a = self._dev(act, torch.float32)
+    T = a.shape[0]
+    assert a.shape == (T, self.n, 3)
+    arrs, out = self._outs((T, self.n))
+    st = self._state()
+    rc = getattr(self.lib, self._pfx + 'rollout')(C.byref(self.cfg), C.byref(st), T, _ptr(a), C.byref(out), self.stream)
+    self._ok(rc, 'rollout')
+    self.cfg.counter += T
+    return tuple(x.cpu().numpy() for x in arrs)
+
+  def observe(self):
+    arrs, out = self._outs((self.n,))
+    st = self._state()
+    self._ok(self.lib.earl_tabletop_observe(C.byref(self.cfg), C.byref(st), C.byref(out), self.stream), 'observe')
+    return tuple(x.cpu().numpy() for x in arrs)
+
+
+def hip_reward(obs, reward_type='sparse', wide_init=False, nobj=1, device='cuda:0'):
+  lib = _abi.load()
+  dev = torch.device(device)
+  o = torch.tensor(np.ascontiguousarray(obs, np.float32), device=dev)
+  n = len(o)
+  r = torch.full((n,), float('nan'), dtype=torch.float32, device=dev)
+  s = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+  rt = {'sparse': 0, 'dense': 1}[reward_type]
+  stream = torch.cuda.current_stream(dev).cuda_stream
+  if nobj == 1:
+    rc = lib.earl_tabletop_reward(n, o.data_ptr(), rt, int(wide_init), r.data_ptr(), s.data_ptr(), stream)
+  else:
+    rc = lib.earl_tabletop3_reward(n, o.data_ptr(), rt, r.data_ptr(), s.data_ptr(), stream)
+  _abi.check(rc, 'reward')
+  torch.cuda.synchronize(dev)
+  return r.cpu().numpy(), s.cpu().numpy()
+
+
+def hip_valid_init(cand, device='cuda:0'):
+  lib = _abi.load()
+  dev = torch.device(device)
+  c = torch.tensor(np.ascontiguousarray(cand, np.float64), device=dev)
+  v = torch.full((len(c),), 7, dtype=torch.uint8, device=dev)
+  _abi.check(lib.earl_tabletop_valid_init(len(c), c.data_ptr(), v.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), 'valid_init')
+  torch.cuda.synchronize(dev)
+  return v.cpu().numpy()

@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: the HIP library loads without a GPU and exports every symbol that
+include/earl_tabletop.h declares; the ctypes view matches the header; the product refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import REPO, has_gpu
+from earl_benchmark_amd import _abi
+
+HEADER = os.path.join(REPO, 'include', 'earl_tabletop.h')
+
+
+def declared_functions():
+  src = open(HEADER).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  return re.findall(r'^\s*(?:int|const char\*)\s+(earl_\w+)\s*\(', src, flags=re.M)
+
+
+def test_header_declares_what_the_binding_expects():
+  names = declared_functions()
+  assert len(names) == len(set(names)) >= 13
+  assert set(names) == set(_abi.SIGNATURES), set(names) ^ set(_abi.SIGNATURES)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+  lib = _abi.load()
+  for name in declared_functions():
+    assert hasattr(lib, name), name
+  assert lib.earl_version().startswith(b'earl-hip')
+
+
+def test_struct_layouts_match_the_header():
+  # sizes/offsets implied by the C declarations (int32 x10 + uint64 x2; 8 pointers; 4 pointers)
+  assert C.sizeof(_abi.TabletopCfg) == 56 and _abi.TabletopCfg.seed.offset == 40 and _abi.TabletopCfg.counter.offset == 48
+  assert C.sizeof(_abi.TabletopState) == 64 and C.sizeof(_abi.TabletopOut) == 32
+  src = open(HEADER).read()
+  cfg_fields = re.findall(r'^\s*(?:u?int\d+_t)\s+(\w+);', src[src.index('typedef struct earl_tabletop_cfg'):src.index('} earl_tabletop_cfg')], flags=re.M)
+  assert cfg_fields == [f[0] for f in _abi.TabletopCfg._fields_]
+  st_fields = re.findall(r'^\s*(?:const\s+)?\w+\*\s+(\w+);', src[src.index('typedef struct earl_tabletop_state'):src.index('} earl_tabletop_state')], flags=re.M)
+  assert st_fields == [f[0] for f in _abi.TabletopState._fields_]
+  out_fields = re.findall(r'^\s*\w+\*\s+(\w+);', src[src.index('typedef struct earl_tabletop_out'):src.index('} earl_tabletop_out')], flags=re.M)
+  assert out_fields == [f[0] for f in _abi.TabletopOut._fields_]
+
+
+def test_argument_validation_needs_no_gpu():
+  lib = _abi.load()
+  assert lib.earl_tabletop_step(None, None, None, None, None, None) == -1
+  assert b'NULL' in lib.earl_last_error()
+  assert lib.earl_tabletop_reward(-1, None, 0, 0, None, None, None) == -1
+
+
+@pytest.mark.skipif(has_gpu(), reason='this container check is for GPU-less hosts')
+def test_product_fails_loudly_without_a_gpu():
+  from earl_benchmark_amd.envs import tabletop
+  with pytest.raises(_abi.EarlHipError):
+    tabletop.TabletopManipulation(num_envs=4)
+  with pytest.raises(_abi.EarlHipError):
+    tabletop.TabletopManipulation(num_envs=4, device='cpu')
+  import earl_benchmark_amd
+  with pytest.raises(_abi.EarlHipError):
+    earl_benchmark_amd.EARLEnvs('tabletop_manipulation', num_envs=8)
+
+
+def test_product_never_imports_the_oracle():
+  """oracle/ is test infrastructure: nothing under earl_benchmark_amd/ may reference it."""
+  for root, _, files in os.walk(os.path.join(REPO, 'earl_benchmark_amd')):
+    for f in files:
+      if f.endswith(('.py', '.hip', '.h', '.cpp')):
+        txt = open(os.path.join(root, f)).read()
+        for line in txt.splitlines():
+          if re.search(r'^\s*(from|import)\s+oracle\b|libearl_oracle|#include\s+"[^"]*oracle', line):
+            raise AssertionError(f'{f}: {line}')
