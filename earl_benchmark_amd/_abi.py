@@ -42,6 +42,7 @@ SIGNATURES = {
     'earl_tabletop3_rollout': [_P(TabletopCfg), _P(TabletopState), C.c_int32, C.c_void_p, _P(TabletopOut), C.c_void_p],
     'earl_tabletop3_reset': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_tabletop3_reward': [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_debug_set_rollout_impl': [C.c_int],
     'earl_version': [],
     'earl_last_error': [],
     'earl_device_count': [],
@@ -63,6 +64,10 @@ def load():
     if not os.path.exists(LIB_PATH):
       raise EarlHipError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                          '(or `make -C earl_benchmark_amd/csrc`). There is no CPU fallback.')
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It must be the one
+    # already mapped when our library's NEEDED libamdhip64.so.7 is resolved, otherwise the process ends up with two
+    # HIP runtimes and kernels launched from here see "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
       fn = getattr(lib, name)  # AttributeError here = header/library mismatch

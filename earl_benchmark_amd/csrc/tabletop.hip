@@ -13,6 +13,7 @@
 #include <cstdio>
 
 #include "tabletop_device.h"
+#include "tabletop_rollout_ws.h"
 
 using namespace earl;
 
@@ -95,7 +96,8 @@ __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float (
 }
 
 // One wrapped step on register state.  `counter` is the Philox counter of THIS step.
-template <int NOBJ>
+// GENERAL = lifelong goal switching and auto-reset compiled in (they drag the Philox generator into the loop).
+template <int NOBJ, bool GENERAL>
 __device__ __forceinline__ void wrapped_step(const KArgs& a, int i, uint64_t counter, Lane<NOBJ>& L,
                                              float (&g)[Dims<NOBJ>::NG], float a0, float a1, float a2,
                                              float (&o)[Dims<NOBJ>::NOBS], float& reward, bool& done, bool& succ) {
@@ -106,7 +108,7 @@ __device__ __forceinline__ void wrapped_step(const KArgs& a, int i, uint64_t cou
   reward = (float)r;
   L.steps += 1;                       // persistent_state_wrapper.py:25-26
   done = L.steps >= a.cfg.horizon;    // :28-29
-  if constexpr (NOBJ == 1) {
+  if constexpr (NOBJ == 1 && GENERAL) {
     if (a.cfg.goal_change_frequency > 0) {  // lifelong_wrapper.py:30-44
       L.sgc += 1;
       L.lret += r;
@@ -119,6 +121,7 @@ __device__ __forceinline__ void wrapped_step(const KArgs& a, int i, uint64_t cou
       }
     }
   }
+  if constexpr (GENERAL)
   if (done && a.cfg.auto_reset) {  // batched-only extension; the outputs above stay the terminal ones
     L.goal_idx = reset_env<NOBJ>(L.e, a.cfg, counter, i, a.st.goal_table, a.next_goal_idx, a.th);
     load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
@@ -131,7 +134,7 @@ __device__ __forceinline__ void wrapped_step(const KArgs& a, int i, uint64_t cou
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-template <int NOBJ>
+template <int NOBJ, bool GENERAL>
 __global__ __launch_bounds__(kBlock) void step_kernel(const KArgs a) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.cfg.n) return;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const KArgs a) {
   float o[Dims<NOBJ>::NOBS];
   float reward;
   bool done, succ;
-  wrapped_step<NOBJ>(a, i, a.cfg.counter, L, g, ap[0], ap[1], ap[2], o, reward, done, succ);
+  wrapped_step<NOBJ, GENERAL>(a, i, a.cfg.counter, L, g, ap[0], ap[1], ap[2], o, reward, done, succ);
   if (a.out.obs) store_obs<NOBJ>(a.out.obs + (size_t)i * Dims<NOBJ>::NOBS, o);
   if (a.out.reward) a.out.reward[i] = reward;
   if (a.out.done) a.out.done[i] = done;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const KArgs a) {
   store_lane<NOBJ>(a, i, L);
 }
 
-template <int NOBJ>
+template <int NOBJ, bool GENERAL>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const KArgs a) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int n = a.cfg.n;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const KArgs a) {
         float o[Dims<NOBJ>::NOBS];
         float reward;
         bool done, succ;
-        wrapped_step<NOBJ>(a, i, a.cfg.counter + (uint64_t)t, L, g, av[k][0], av[k][1], av[k][2], o, reward, done, succ);
+        wrapped_step<NOBJ, GENERAL>(a, i, a.cfg.counter + (uint64_t)t, L, g, av[k][0], av[k][1], av[k][2], o, reward, done, succ);
         const size_t row = (size_t)t * n + i;
         if (a.out.obs) store_obs<NOBJ>(a.out.obs + row * Dims<NOBJ>::NOBS, o);
         if (a.out.reward) a.out.reward[row] = reward;
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void valid_init_kernel(int n, const double*
 // host side
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[512] = "";
+int g_rollout_impl = 0;  // 0 = auto (wave-specialised when applicable), 1 = force the plain one-lane-per-env kernel
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -323,7 +327,10 @@ int do_step(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const f
   if (!act || !out) return fail(EARL_ERR_ARG, "act/out is NULL");
   if (cfg->n == 0) return EARL_OK;
   KArgs a{*cfg, *st, *out, act, ngi, nullptr, nullptr, 1, thresholds()};
-  step_kernel<NOBJ><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
+  if (cfg->goal_change_frequency > 0 || cfg->auto_reset)
+    step_kernel<NOBJ, true><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
+  else
+    step_kernel<NOBJ, false><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
   return launched("step_kernel");
 }
 
@@ -334,8 +341,25 @@ int do_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int3
   if (!act || !out) return fail(EARL_ERR_ARG, "act/out is NULL");
   if (T < 0) return fail(EARL_ERR_ARG, "T = %d < 0", T);
   if (cfg->n == 0 || T == 0) return EARL_OK;
+  const bool general = cfg->goal_change_frequency > 0 || cfg->auto_reset;
+  if constexpr (NOBJ == 1) {
+    // the common case (no lifelong switching, no auto-reset, all outputs requested): wave-specialised kernel
+    if (!general && out->obs && out->reward && out->done && out->success && g_rollout_impl != 1) {
+      WsArgs w{cfg->n, T, cfg->horizon, cfg->wide_init, act, st->qpos, st->attached, st->goal_idx, st->goal_table,
+               st->steps_since_reset, out->obs, out->reward, out->done, out->success, thresholds()};
+      const dim3 grid((unsigned)((cfg->n + 63) / 64));
+      if (cfg->reward_type == EARL_REWARD_SPARSE)
+        rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 6><<<grid, 64 * 4, 0, (hipStream_t)stream>>>(w);
+      else
+        rollout_ws_kernel<EARL_REWARD_DENSE, 4, 4, 6><<<grid, 64 * 6, 0, (hipStream_t)stream>>>(w);
+      return launched("rollout_ws_kernel");
+    }
+  }
   KArgs a{*cfg, *st, *out, act, nullptr, nullptr, nullptr, T, thresholds()};
-  rollout_kernel<NOBJ><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
+  if (general)
+    rollout_kernel<NOBJ, true><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
+  else
+    rollout_kernel<NOBJ, false><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
   return launched("rollout_kernel");
 }
 
@@ -408,6 +432,13 @@ int earl_tabletop3_reward(int32_t n, const float* obs, int32_t reward_type, floa
   if (n == 0) return EARL_OK;
   reward_kernel<3><<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(n, obs, reward_type, 0, reward, success, thresholds());
   return launched("reward_kernel3");
+}
+
+/* test/bench hook: choose the rollout kernel (0 auto, 1 plain); returns the previous value */
+int earl_debug_set_rollout_impl(int impl) {
+  const int prev = g_rollout_impl;
+  g_rollout_impl = impl;
+  return prev;
 }
 
 const char* earl_version(void) { return "earl-hip 0.1 (gfx950)"; }

@@ -129,6 +129,10 @@ class TabletopManipulation:
   def _task_rows(task_list):
     return task_goal_rows(task_list)
 
+  @property
+  def unwrapped(self):
+    return self
+
   # ------------------------------------------------------------------ plumbing
   def _sync_state_ptrs(self):
     s = self._st

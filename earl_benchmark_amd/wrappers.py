@@ -41,8 +41,8 @@ class PersistentStateWrapper(Wrapper):
   def step(self, action, **kwargs):
     return self.env.step(action, **kwargs)
 
-  def rollout(self, actions):
-    return self.env.rollout(actions)
+  def rollout(self, actions, **kwargs):
+    return self.env.rollout(actions, **kwargs)
 
   def is_successful(self, obs=None):
     return self.env.is_successful(obs)
@@ -75,8 +75,8 @@ class LifelongWrapper(Wrapper):
   def step(self, action, **kwargs):
     return self.env.step(action, **kwargs)
 
-  def rollout(self, actions):
-    return self.env.rollout(actions)
+  def rollout(self, actions, **kwargs):
+    return self.env.rollout(actions, **kwargs)
 
   @property
   def lifelong_return(self):

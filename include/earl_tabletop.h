@@ -122,6 +122,10 @@ int earl_tabletop3_reward(int32_t n, const float* obs, int32_t reward_type, floa
                           earl_stream_t stream);
 
 /* ---- library ---- */
+/* Test/bench hook: which kernel earl_tabletop_rollout uses. 0 = automatic (the wave-specialised kernel whenever
+ * lifelong switching and auto-reset are off and all four outputs are requested), 1 = always the plain
+ * one-lane-per-env kernel.  Both produce bit-identical outputs.  Returns the previous setting. */
+int earl_debug_set_rollout_impl(int impl);
 const char* earl_version(void);
 const char* earl_last_error(void);
 int earl_device_count(void); /* number of HIP devices visible, <= 0 when there is none */

@@ -109,11 +109,14 @@ class OracleTabletop:
     self._bump()
     return arrs
 
-  def rollout(self, act):
+  def rollout(self, act, out=None):
     act = np.ascontiguousarray(act, np.float32)
     T = act.shape[0]
     assert act.shape == (T, self.n, 3)
-    arrs, out = self._outs((T, self.n))
+    if out is None:
+      arrs, out = self._outs((T, self.n))
+    else:                                   # reuse caller-provided output arrays (CPU-baseline timing)
+      arrs, out = out, TabletopOut(*(_p(a) for a in out))
     st = self._state()
     getattr(lib(), self._pfx + 'rollout')(C.byref(self.cfg), C.byref(st), C.c_int32(T), _p(act), C.byref(out))
     self._bump(T)
@@ -153,3 +156,8 @@ def philox4x32_10(ctr, key):
   out = np.zeros(4, np.uint32)
   lib().oracle_philox4x32_10(_p(ctr), _p(key), _p(out))
   return out
+
+
+def set_threads(n):
+  """OpenMP threads used by the batched entry points (0 = query only); returns the current maximum."""
+  return int(lib().oracle_set_threads(C.c_int(int(n))))

@@ -1,0 +1,176 @@
+"""The reference's Python call surface (loader, gym-style env, wrappers) on the GPU, checked against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def torch():
+  import torch
+  return torch
+
+
+@pytest.fixture(scope='module')
+def orc():
+  from oracle import tabletop_oracle
+  return tabletop_oracle
+
+
+def mirror(orc, env, **kw):
+  """an oracle with the same configuration, state and RNG counter as `env`"""
+  u = env.unwrapped
+  c = u._cfg
+  o = orc.OracleTabletop(u.num_envs, reward_type=['sparse', 'dense'][c.reward_type], wide_init=bool(c.wide_init),
+                         reset_at_goal=bool(c.reset_at_goal), horizon=c.horizon, goal_change_frequency=c.goal_change_frequency,
+                         auto_reset=bool(c.auto_reset), seed=c.seed, env_offset=c.env_offset,
+                         goal_table=u.goal_table.cpu().numpy(), nobj=u.NOBJ, n_sample_goals=c.n_sample_goals)
+  o.qpos[:] = u.qpos.cpu().numpy(); o.attached[:] = u.attached.cpu().numpy(); o.goal_idx[:] = u.goal_idx.cpu().numpy()
+  o.steps_since_reset[:] = u.steps_since_reset.cpu().numpy(); o.num_interventions[:] = u.interventions.cpu().numpy()
+  o.steps_since_goal_change[:] = u.steps_since_goal_change.cpu().numpy(); o.lifelong_return[:] = u.lifelong_return_t.cpu().numpy()
+  o.cfg.counter = c.counter
+  return o
+
+
+def test_loader_batched_train_and_eval(torch, orc):
+  import earl_benchmark_amd as eb
+  n = 300
+  L = eb.EARLEnvs('tabletop_manipulation', reward_type='sparse', num_envs=n, seed=11)
+  train, evl = L.get_envs()
+  assert train.unwrapped._cfg.horizon == 200000 and evl.unwrapped._cfg.horizon == 200
+  assert evl.action_space.shape == (3,) and evl.observation_space.shape == (12,)
+  o = mirror(orc, evl)
+  obs = evl.reset()
+  assert obs.shape == (n, 12) and obs.dtype == torch.float32 and obs.is_cuda
+  np.testing.assert_array_equal(obs.cpu().numpy(), o.reset())
+  rng = np.random.default_rng(0)
+  for t in range(205):
+    a = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    ob, rw, dn, info = evl.step(torch.from_numpy(a).cuda())
+    r = o.step(a)
+    np.testing.assert_array_equal(ob.cpu().numpy(), r[0]); np.testing.assert_array_equal(rw.cpu().numpy(), r[1])
+    np.testing.assert_array_equal(dn.cpu().numpy(), r[2].astype(bool))
+    np.testing.assert_array_equal(info['success'].cpu().numpy(), r[3].astype(bool))
+    assert bool(dn.all()) == (t >= 199)
+  assert evl.total_steps == 205 and (evl.num_interventions.cpu().numpy() == 1).all()
+  # masked reset of the envs that are done + numpy actions are accepted
+  mask = torch.zeros(n, dtype=torch.bool, device='cuda'); mask[::2] = True
+  ob = evl.reset(mask=mask)
+  np.testing.assert_array_equal(ob.cpu().numpy(), o.reset(mask=mask.cpu().numpy()))
+  ob, rw, dn, _ = evl.step(np.zeros((n, 3), np.float32))
+  assert (dn.cpu().numpy() == np.tile([False, True], n // 2)).all()
+  assert L.get_initial_states().shape == (1, 6) and L.get_goal_states().shape == (4, 6) and L.has_demos()
+
+
+def test_scalar_api_is_the_reference_surface(torch, orc):
+  import earl_benchmark_amd as eb
+  L = eb.EARLEnvs('tabletop_manipulation', reward_type='dense', eval_horizon=5)
+  train, evl = L.get_envs()
+  obs = evl.reset()
+  assert isinstance(obs, np.ndarray) and obs.shape == (12,) and obs.dtype == np.float32
+  np.testing.assert_array_equal(obs[:6], [0, 0, 2.5, 0, -1, -1])
+  o = mirror(orc, evl)
+  out = evl.step(np.array([1.0, 0.0, 1.0]))
+  assert isinstance(out[0], np.ndarray) and isinstance(out[1], float) and isinstance(out[2], bool) and out[3] == {}
+  r = o.step(np.array([[1.0, 0.0, 1.0]], np.float32))
+  np.testing.assert_array_equal(out[0], r[0][0]); assert abs(out[1] - r[1][0]) < 1e-6
+  assert evl.attached_object == (-1, -1) and isinstance(evl.is_successful(), bool)
+  # reference-style injection hooks: set_state / attached / reset_goal(goal) / compute_reward(obs)
+  evl.set_state(np.array([0.1, 0.0, 0.2, 0.0, -10.0]))
+  evl.reset_goal(np.array([0.0, 0.0, 0.0, 2.0, -1.0, -1.0]))
+  ob, rw, dn, _ = evl.step(np.array([0.0, 0.0, 1.0]))
+  assert evl.attached_object == (0, 0) and ob[4] == 0 and tuple(ob[6:]) == (0, 0, 0, 2, -1, -1)
+  assert abs(evl.compute_reward(ob) - rw) < 1e-6
+  np.testing.assert_array_equal(evl.goal, [0, 0, 0, 2, -1, -1])
+  np.testing.assert_array_equal(evl.get_obs(), ob)
+  g = evl.get_next_goal()
+  assert g.shape == (6,) and any((g == row).all() for row in L.get_goal_states())
+  assert evl.num_interventions == 1 and evl.total_steps == 2
+
+
+def test_custom_goals_reward_and_checkpoint(torch, orc):
+  from earl_benchmark_amd.envs import tabletop
+  n = 64
+  env = tabletop.TabletopManipulation(reward_type='sparse', num_envs=n, seed=2)
+  rng = np.random.default_rng(2)
+  goals = np.concatenate([rng.uniform(-2, 2, size=(n, 4)), -np.ones((n, 2))], 1)
+  env.reset_goal(goals)
+  env.set_state(goals[:, :4] + 0.05)
+  o = mirror(orc, env)
+  a = np.zeros((n, 3), np.float32)
+  ob, rw, dn, info = env.step(a)
+  r = o.step(a)
+  np.testing.assert_array_equal(ob.cpu().numpy(), r[0]); np.testing.assert_array_equal(rw.cpu().numpy(), r[1])
+  np.testing.assert_array_equal(ob.cpu().numpy()[:, 6:], goals.astype(np.float32))
+  # pure functions on arbitrary obs batches
+  obs_batch = torch.cat([ob, ob * 0.5])
+  np.testing.assert_array_equal(env.is_successful(obs_batch).cpu().numpy(), orc.reward(obs_batch.cpu().numpy(), 'sparse')[2].astype(bool))
+  np.testing.assert_array_equal(env.compute_reward(obs_batch).cpu().numpy(), orc.reward(obs_batch.cpu().numpy(), 'sparse')[0])
+  # resample goals for half of the envs
+  m = torch.arange(n, device='cuda') % 2 == 0
+  env.reset_goal(mask=m)
+  gi = env.goal_idx.cpu().numpy()
+  assert (gi[::2] < 4).all() and (gi[1::2] >= 4).all()
+  # checkpoint / resume: identical continuation
+  sd = env.state_dict()
+  acts = torch.from_numpy(rng.uniform(-1, 1, size=(20, n, 3)).astype(np.float32)).cuda()
+  ref = env.rollout(acts)
+  env2 = tabletop.TabletopManipulation(reward_type='sparse', num_envs=n, seed=99)
+  env2.load_state_dict(sd)
+  got = env2.rollout(acts)
+  for x, y in zip(ref, got):
+    assert torch.equal(x, y)
+  assert torch.equal(env.qpos, env2.qpos)
+
+
+def test_lifelong_loader(torch, orc):
+  import earl_benchmark_amd as eb
+  n = 128
+  L = eb.EARLEnvs('tabletop_manipulation', reward_type='sparse', setup_as_lifelong_learning=True, num_envs=n,
+                  goal_change_frequency=9, train_horizon=50, seed=5)
+  env = L.get_envs()
+  from earl_benchmark_amd import wrappers
+  assert isinstance(env, wrappers.LifelongWrapper) and isinstance(env.env, wrappers.PersistentStateWrapper)
+  o = mirror(orc, env)
+  np.testing.assert_array_equal(env.reset().cpu().numpy(), o.reset())
+  rng = np.random.default_rng(3)
+  switched = 0
+  for t in range(60):
+    a = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    g_before = env.goal_idx.clone()
+    ob, rw, dn, _ = env.step(a)
+    r = o.step(a)
+    np.testing.assert_array_equal(ob.cpu().numpy(), r[0]); np.testing.assert_array_equal(rw.cpu().numpy(), r[1])
+    np.testing.assert_array_equal(dn.cpu().numpy(), r[2].astype(bool))
+    switched += int((env.goal_idx != g_before).sum())
+    assert ((t + 1) % 9 == 0) or bool((env.goal_idx == g_before).all())
+  assert switched > 0
+  np.testing.assert_array_equal(env.lifelong_return.cpu().numpy(), o.lifelong_return)
+  np.testing.assert_array_equal(env.steps_since_goal_change.cpu().numpy(), o.steps_since_goal_change)
+
+
+def test_3obj_env(torch, orc):
+  from earl_benchmark_amd.envs import tabletop_3obj
+  n = 200
+  env = tabletop_3obj.TabletopManipulation(reward_type='dense', num_envs=n, seed=1)
+  o = mirror(orc, env)
+  ob = env.reset()
+  assert ob.shape == (n, 20)
+  np.testing.assert_array_equal(ob.cpu().numpy(), o.reset())
+  rng = np.random.default_rng(4)
+  acts = rng.uniform(-1, 1, size=(50, n, 3)).astype(np.float32)
+  acts[..., 0] = np.abs(acts[..., 0]); acts[..., 2] = np.abs(acts[..., 2])
+  got = env.rollout(torch.from_numpy(acts).cuda())
+  want = o.rollout(acts)
+  np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+  np.testing.assert_allclose(got[1].cpu().numpy(), want[1], rtol=1e-6, atol=1e-6)
+  assert (env.attached.cpu().numpy() == o.attached).all() and (o.attached >= 0).any()
+  np.testing.assert_array_equal(env.get_obs().cpu().numpy(), want[0][-1])
+  np.testing.assert_array_equal(env.is_successful().cpu().numpy(), want[3][-1].astype(bool))
+
+
+def test_no_cpu_device():
+  from earl_benchmark_amd import _abi
+  from earl_benchmark_amd.envs import tabletop
+  with pytest.raises(_abi.EarlHipError):
+    tabletop.TabletopManipulation(num_envs=2, device='cpu')

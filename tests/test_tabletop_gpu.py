@@ -412,3 +412,43 @@ def test_full_size_properties(hx):
   out2 = h2.rollout(acts)
   for x, y in zip((obs, rew, done, succ), out2):
     np.testing.assert_array_equal(x, y)
+
+
+# ------------------------------------------------------------------------------------------------ kernel variants
+@pytest.mark.parametrize('rt,wide', [('sparse', False), ('dense', False), ('sparse', True)])
+@pytest.mark.parametrize('n,T', [(1, 1), (63, 5), (64, 4), (65, 13), (1000, 37), (4096, 200), (10001, 9)])
+def test_rollout_kernels_agree(hx, orc, rt, wide, n, T):
+  """The wave-specialised rollout kernel (default) == the plain one-lane-per-env kernel == the oracle, including
+  partial workgroups, n % 4 != 0 (byte-wise flag stores), T not a multiple of the chunk, NaN/inf actions."""
+  from earl_benchmark_amd import _abi
+  lib = _abi.load()
+  rng = np.random.default_rng(n * 1000 + T)
+  acts = rng.uniform(-1.3, 1.3, size=(T, n, 3)).astype(np.float32)
+  acts[..., 2] = np.where(rng.random((T, n)) < 0.7, np.abs(acts[..., 2]), acts[..., 2])
+  if n >= 63:
+    acts[T // 2, 5, 0] = np.nan          # poisons env 5 from step T//2 on (np.clip propagates NaN)
+    acts[0, 7, 1] = np.inf
+    acts[T - 1, 11, 2] = np.nan          # NaN grip -> release
+  o = orc.OracleTabletop(n, reward_type=rt, wide_init=wide, horizon=max(1, T - 2), seed=1)
+  random_state(rng, o)
+  o.steps_since_reset[:] = rng.integers(0, 3, size=n)
+  outs = {}
+  for impl in (0, 1):
+    h = hx.HipTabletop(n, reward_type=rt, wide_init=wide, horizon=max(1, T - 2), seed=1)
+    h.set_from(o)
+    prev = lib.earl_debug_set_rollout_impl(impl)
+    try:
+      outs[impl] = h.rollout(acts)
+    finally:
+      lib.earl_debug_set_rollout_impl(prev)
+    outs[impl, 'state'] = {k: h.host(k) for k in h.STATE}
+  for x, y in zip(outs[0], outs[1]):
+    np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+  for k in outs[0, 'state']:
+    np.testing.assert_array_equal(outs[0, 'state'][k], outs[1, 'state'][k], err_msg=k)
+  want = o.rollout(acts)
+  assert_same_out(outs[0], want, rt == 'dense')
+  for k, v in outs[0, 'state'].items():
+    np.testing.assert_array_equal(v, getattr(o, k), err_msg=k)
+  if n >= 63 and T >= 4:
+    assert np.isnan(outs[0][0][-1, 5, 0])
