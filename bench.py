@@ -204,7 +204,7 @@ def main():
                    'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': n * T * world,
                    'parallelism': f'env-range shard x{world}, no per-step collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'rollout_kernel<1>',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'rollout_ws_kernel',
                      'kernel_ms_mean': kmean, 'kernel_ms_median': kmed, 'algorithmic_bytes_per_launch': bytes_per_launch,
                      'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT},
     }

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 
 #include "tabletop_device.h"
 #include "tabletop_rollout_ws.h"
@@ -295,6 +296,29 @@ const Thresholds& thresholds() {
   return th;
 }
 
+// smallest float x with rescale_action(x) > 0: the grip test `rescaled a[2] > 0` (:144) on the RAW action.
+// rescale is monotone, so a bisection over the (ordered) non-negative float bit patterns finds it exactly.
+float grip_threshold() {
+  static const float thr = [] {
+    auto rescaled_positive = [](float x) {
+      const double c = x < -1.0f ? -1.0 : (x > 1.0f ? 1.0 : (double)x);
+      volatile double v = -0.2 + ((c + 1.) * 0.5) * (0.2 - -0.2);
+      return v > 0;
+    };
+    uint32_t lo = 0u, hi = 0x3f800000u;  // +0.0f (not positive) .. 1.0f (positive)
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      float f;
+      memcpy(&f, &mid, 4);
+      if (rescaled_positive(f)) hi = mid; else lo = mid;
+    }
+    float f;
+    memcpy(&f, &hi, 4);
+    return f;
+  }();
+  return thr;
+}
+
 int check_common(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int nobj) {
   if (!cfg || !st) return fail(EARL_ERR_ARG, "cfg/state is NULL");
   if (cfg->n < 0) return fail(EARL_ERR_ARG, "n = %d < 0", cfg->n);
@@ -346,12 +370,32 @@ int do_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int3
     // the common case (no lifelong switching, no auto-reset, all outputs requested): wave-specialised kernel
     if (!general && out->obs && out->reward && out->done && out->success && g_rollout_impl != 1) {
       WsArgs w{cfg->n, T, cfg->horizon, cfg->wide_init, act, st->qpos, st->attached, st->goal_idx, st->goal_table,
-               st->steps_since_reset, out->obs, out->reward, out->done, out->success, thresholds()};
+               st->steps_since_reset, out->obs, out->reward, out->done, out->success, thresholds(), grip_threshold()};
       const dim3 grid((unsigned)((cfg->n + 63) / 64));
-      if (cfg->reward_type == EARL_REWARD_SPARSE)
-        rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 6><<<grid, 64 * 4, 0, (hipStream_t)stream>>>(w);
-      else
-        rollout_ws_kernel<EARL_REWARD_DENSE, 4, 4, 6><<<grid, 64 * 6, 0, (hipStream_t)stream>>>(w);
+      const hipStream_t hs = (hipStream_t)stream;
+#define EARL_WS(RT, NC, NL, NS, K, LEAD) \
+  rollout_ws_kernel<RT, NC, NL, NS, K, LEAD><<<grid, 64 * (NC + NL + NS), 0, hs>>>(w)
+      if (cfg->reward_type == EARL_REWARD_SPARSE) {
+        switch (g_rollout_impl) {   // tuning variants (tools/tune_rollout.py); 0 = the shipped configuration
+          case 2: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 4, 6); break;
+          case 3: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 8, 3); break;
+          case 4: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 4, 6); break;
+          case 5: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 8, 3); break;
+          case 6: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 2, 4, 6); break;
+          case 7: EARL_WS(EARL_REWARD_SPARSE, 2, 1, 2, 4, 6); break;
+          case 8: EARL_WS(EARL_REWARD_SPARSE, 1, 1, 1, 4, 6); break;
+          case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 2, 4, 8, 3, true><<<grid, 64 * 8, 0, hs>>>(w); break;  // stamps
+          default:
+            // latency regime (one workgroup per CU): two x/y-split compute waves; throughput regime: fewer waves
+            if (cfg->n <= 32768) EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 8, 3);
+            else EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 8, 3);
+            break;
+        }
+      } else {
+        if (cfg->n <= 32768) EARL_WS(EARL_REWARD_DENSE, 2, 2, 4, 8, 3);
+        else EARL_WS(EARL_REWARD_DENSE, 1, 2, 4, 8, 3);
+      }
+#undef EARL_WS
       return launched("rollout_ws_kernel");
     }
   }
@@ -439,6 +483,14 @@ int earl_debug_set_rollout_impl(int impl) {
   const int prev = g_rollout_impl;
   g_rollout_impl = impl;
   return prev;
+}
+
+/* diagnostic: copy the per-workgroup s_memtime sums of the PROF rollout variant (impl 9) to host memory */
+int earl_debug_read_ws_profile(uint64_t* out, int32_t n_words) {
+  if (!out || n_words < 0 || n_words > 64 * 16) return fail(EARL_ERR_ARG, "bad profile buffer");
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(earl::g_ws_prof), (size_t)n_words * 8) != hipSuccess)
+    return fail(EARL_ERR_LAUNCH, "hipMemcpyFromSymbol failed");
+  return EARL_OK;
 }
 
 const char* earl_version(void) { return "earl-hip 0.1 (gfx950)"; }

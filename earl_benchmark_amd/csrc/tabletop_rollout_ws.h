@@ -6,17 +6,23 @@
 // partially-coalesced stores on that critical path, and because vmcnt retires in order every wait for
 // an action load also waits for all older stores.  Here a 64-env workgroup splits the step by ROLE:
 //
-//   wave 0        COMPUTE  the recurrence only (~30 VALU/step): reads rescaled actions from LDS, writes
-//                          the 4 f32 coordinates + attached flag into an LDS "row image" of the obs rows
-//   wave 1        LOADER   streams raw actions HBM -> VGPR ring (LEAD chunks ahead, coalesced dword loads, no
-//                          stores in this wave so its vmcnt waits never queue behind stores), transposes them
-//                          through LDS and rescales them to fp64 -> LDS
-//   waves 2..     STORERS  copy finished row images LDS -> HBM as fully coalesced float4 (the goal part of
-//                          each row is constant and pre-filled), evaluate success/reward, pack flags
+//   wave 0         COMPUTE  the recurrence only: reads rescaled actions from LDS, writes the 4 f32
+//                           coordinates + attached flag into an LDS "row image" of the obs rows
+//   waves 1..NL    LOADERS  stream raw actions HBM -> VGPRs a whole TRIP (LEAD chunks) ahead with coalesced
+//                           dword loads (no stores in these waves, so their vmcnt waits never queue behind
+//                           stores), transpose them through LDS and rescale them to fp64 -> LDS ring
+//   waves NL+1..   STORERS  copy finished row images LDS -> HBM as fully coalesced float4 (the goal part of
+//                           each row is constant and pre-filled), evaluate success/reward, pack flags
 //
 // One workgroup barrier per chunk of K steps; 3-deep action ring and 2-deep row-image ring in LDS.
 // Semantics are exactly those of rollout_kernel<1> without lifelong / auto-reset (the host picks the
 // kernel); outputs are bit-identical (tests/test_tabletop_gpu.py::test_rollout_kernels_agree).
+//
+// Measured (profiles/, tools/prof_ws.py): the first version of this kernel spent 318 cycles per step in
+// the compute wave although it issues < 40 instructions -- the attach test (sub, mul, fma, cmp, mask,
+// select) sat on the loop-carried path of the object position.  ws_step() below removes it from that
+// path: whenever the test matters the object has not moved during the previous step, so the test can
+// use the object position from ONE STEP EARLIER, which is ready long before.
 #pragma once
 #include <type_traits>
 
@@ -37,6 +43,7 @@ struct WsArgs {
   uint8_t* __restrict__ done;         // [T, n]
   uint8_t* __restrict__ success;      // [T, n]
   Thresholds th;
+  float grip_x;                       // smallest float x with rescale_action(x) > 0 (host: exact search)
 };
 
 // Lanes of ONE wave exchange data through LDS (loader staging).  Per thread the write and read addresses never
@@ -48,70 +55,208 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// fast clip for finite-or-inf values; NaN handling is done by the EXACT path
+// fast clip for values that are not NaN (v_max_f64 / v_min_f64); NaN handling is done by the EXACT path
 __device__ __forceinline__ double clip_fast(double x) { return fmin(fmax(x, -2.8), 2.8); }
 
+// One step of move :140-174 on register state.
+//   EXACT : np.clip NaN propagation and no range assumptions (compare+select, the textbook order).
+//   fast  : requires no NaN anywhere and |object| <= 2.8 (true after any clipped move; checked at kernel start):
+//           - the attach test reads (oxl, oyl) = the object position at the START OF THE PREVIOUS STEP.  If the mug
+//             was not attached during the previous step it did not move, so this is its current position; if it was
+//             attached, `att` is already true and the test result is ignored.  This takes the test off the
+//             loop-carried dependency of the object position (3 dependent fp64 ops per step remain).
+//           - a free object is "moved" by -0.0 and clipped: x + (-0.0) == x bit for bit, clip is the identity in range.
 template <bool EXACT>
-__device__ __forceinline__ void ws_step(double& fx, double& fy, double& ox, double& oy, bool& att, double a0,
-                                        double a1, bool grip, const Thresholds& th) {
-  // move :140-174 with the grasp test folded into mask logic; EXACT = np.clip NaN propagation (compare+select)
-  const double dx = fx - ox, dy = fy - oy;
-  const bool near = fma(dy, dy, dx * dx) < th.grasp_d2;
-  att = grip && (att || near);
-  double nfx, nfy;
+__device__ __forceinline__ void ws_step(double& fx, double& fy, double& ox, double& oy, double& oxl, double& oyl,
+                                        bool& att, double a0, double a1, bool grip, const Thresholds& th) {
   if constexpr (EXACT) {
-    nfx = clipd(fx + a0, -2.8, 2.8);
-    nfy = clipd(fy + a1, -2.8, 2.8);
+    const double dx = fx - ox, dy = fy - oy;
+    const bool near = fma(dy, dy, dx * dx) < th.grasp_d2;
+    att = grip && (att || near);
+    const double nfx = clipd(fx + a0, -2.8, 2.8), nfy = clipd(fy + a1, -2.8, 2.8);
+    if (att) {
+      ox = clipd(ox + (nfx - fx), -2.8, 2.8);
+      oy = clipd(oy + (nfy - fy), -2.8, 2.8);
+    }
+    fx = nfx;
+    fy = nfy;
+    oxl = ox;
+    oyl = oy;
   } else {
-    nfx = clip_fast(fx + a0);
-    nfy = clip_fast(fy + a1);
+    const double dx = fx - oxl, dy = fy - oyl;
+    const bool near = fma(dy, dy, dx * dx) < th.grasp_d2;
+    att = grip && (att || near);
+    oxl = ox;
+    oyl = oy;
+    const double nfx = clip_fast(fx + a0), nfy = clip_fast(fy + a1);
+    const double ddx = att ? nfx - fx : -0.0, ddy = att ? nfy - fy : -0.0;
+    ox = clip_fast(ox + ddx);
+    oy = clip_fast(oy + ddy);
+    fx = nfx;
+    fy = nfy;
   }
-  const double ddx = nfx - fx, ddy = nfy - fy;
-  double nox, noy;
-  if constexpr (EXACT) {
-    nox = clipd(ox + ddx, -2.8, 2.8);
-    noy = clipd(oy + ddy, -2.8, 2.8);
-  } else {
-    nox = clip_fast(ox + ddx);
-    noy = clip_fast(oy + ddy);
-  }
-  ox = att ? nox : ox;
-  oy = att ? noy : oy;
-  fx = nfx;
-  fy = nfy;
 }
 
-template <int RT, int NS, int K, int LEAD>
-__global__ __launch_bounds__(64 * (2 + NS)) void rollout_ws_kernel(const WsArgs a) {
-  constexpr int E = 64;
-  __shared__ double2 A[3][K][E];      // rescaled (a0, a1)
-  __shared__ uint8_t G[3][K][E];      // bit0: rescaled grip > 0, bit1: a0 or a1 is NaN
-  __shared__ int slow_flag[3];        // chunk contains a NaN action -> exact-NaN path
-  __shared__ float4 R[2][K][E * 3];   // row images: 64 obs rows of 48 B per step
-  __shared__ float S[K][E * 3];       // loader-private staging: raw actions of one chunk (coalesced -> per env)
+// The same step with the two coordinates of an env in two LANES (l: x, l+32: y) of a 32-env wave: every vector
+// instruction advances x and y at once, which halves the instructions a wave issues per step -- and a lone wave
+// issues one VALU per ~5.6 cycles (10.3 if it depends on the previous one; tools/ubench/issue.hip), fp32 and fp64
+// alike, so the instruction count IS the step latency.  Only the attach test couples the halves: the Y half needs
+// dx*dx (two v_permlane32_swap), and its compare mask is copied to the X half with scalar ops.
+//   f, o, ol: this lane's coordinate of gripper / mug / mug-one-step-ago; att64, grip64: lane masks, both halves equal.
+__device__ __forceinline__ double both_halves_from_lower(double v) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(r1[0], r0[0]);
+}
+template <bool EXACT>
+__device__ __forceinline__ void ws_step_xy(double& f, double& o, double& ol, unsigned long long& att64, double a,
+                                           unsigned long long grip64, const Thresholds& th) {
+  const double d = f - (EXACT ? o : ol);
+  const double d2 = fma(d, d, both_halves_from_lower(d * d));   // meaningful in the Y half: fma(dy, dy, dx*dx)
+  const unsigned near_y = (unsigned)(__ballot(d2 < th.grasp_d2) >> 32);
+  const unsigned long long near64 = ((unsigned long long)near_y << 32) | near_y;
+  att64 = grip64 & (att64 | near64);
+  const bool att = __builtin_amdgcn_inverse_ballot_w64(att64);
+  if constexpr (EXACT) {
+    const double nf = clipd(f + a, -2.8, 2.8);
+    if (att) o = clipd(o + (nf - f), -2.8, 2.8);
+    f = nf;
+    ol = o;
+  } else {
+    ol = o;
+    const double nf = clip_fast(f + a);
+    const double dd = att ? nf - f : -0.0;
+    o = clip_fast(o + dd);
+    f = nf;
+  }
+}
 
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// PROF = diagnostic build only (tools/prof_ws.py): s_memtime stamps per role, summed per workgroup into
+// g_ws_prof; never used by the shipped configuration and its timings are not quoted.
+__device__ unsigned long long g_ws_prof[64 * 16];
+__device__ __forceinline__ unsigned long long ws_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define WS_STAMP(acc)                                  \
+  if constexpr (PROF) {                                \
+    const unsigned long long t_ = ws_clock();          \
+    acc += t_ - p_x;                                   \
+    p_x = t_;                                          \
+  }
+
+// RT reward type; NC compute waves: 1 = one lane per env (64 envs), 2 = two 32-env waves with x / y in the two lane
+// halves; NL loader waves (steps of a chunk are dealt round-robin to them), NS storer waves (likewise), K steps per
+// chunk, LEAD chunks per loader trip.  K % NL == 0.
+template <int RT, int NC, int NL, int NS, int K, int LEAD, bool PROF = false>
+__global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const WsArgs a) {
+  constexpr int E = 64;
+  constexpr int KL = K / NL;          // steps of a chunk handled by one loader
+  static_assert(K % NL == 0, "K must be a multiple of NL");
+  static_assert(NC == 1 || NC == 2, "NC is 1 or 2");
+  // rescaled (a0, a1).  NC == 1: [2e], [2e+1] of env e.  NC == 2: wave cw reads [64cw + lane]: a0 of its 32 envs, then a1
+  __shared__ double A[3][K][2 * E];
+  __shared__ uint8_t G[3][K][E];      // rescaled grip > 0
+  __shared__ int slow_flag[3][NL];    // chunk contains a NaN action -> exact path (sticky in the compute wave)
+  __shared__ float4 R[2][K][E * 3];   // row images: 64 obs rows of 48 B per step
+  __shared__ float S[NL][KL][E * 3];  // loader-private staging: raw actions (coalesced order -> per env)
+
+  // readfirstlane: tell hipcc the role index is wave-uniform (otherwise every role test becomes exec-mask code)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = a.n, T = a.T;
   const int i0 = blockIdx.x * E;
   const int i = i0 + lane;
   const int valid = min(E, n - i0);   // live envs of this workgroup
   const bool live = lane < valid;
   const int nch = (T + K - 1) / K;
+  unsigned long long p_x = 0, p_t0 = 0;
 
   // ---- every thread: pre-fill the constant goal part of all row images (parts 1 and 2 of each row)
-  {
-    constexpr int per_buf = K * E;
-    for (int idx = threadIdx.x; idx < 2 * per_buf; idx += 64 * (2 + NS)) {
-      const int e = idx % E;
-      float g[6] = {0, 0, 0, 0, 0, 0};
-      if (e < valid) load_goal<1>(a.goal_table, a.goal_idx[i0 + e], g);
-      float4* row = &R[0][0][0] + (size_t)(idx / E) * (E * 3) + e * 3;
-      row[1] = float4{-1.0f, -1.0f, g[0], g[1]};
-      row[2] = float4{g[2], g[3], g[4], g[5]};
-    }
+  for (int idx = threadIdx.x; idx < 2 * K * E; idx += 64 * (NC + NL + NS)) {
+    const int e = idx % E;
+    float g[6] = {0, 0, 0, 0, 0, 0};
+    if (e < valid) load_goal<1>(a.goal_table, a.goal_idx[i0 + e], g);
+    float4* row = &R[0][0][0] + (size_t)(idx / E) * (E * 3) + e * 3;
+    row[1] = float4{-1.0f, -1.0f, g[0], g[1]};
+    row[2] = float4{g[2], g[3], g[4], g[5]};
   }
 
-  if (wave == 0) {
+  if (wave < NC) {
+   if constexpr (NC == 2) {
+    // ================================================================= COMPUTE, x / y in the two lane halves
+    const int h = lane >> 5, el = lane & 31, e = wave * 32 + el;   // coordinate, env within the wave / workgroup
+    const int ie = i0 + e;
+    const bool alive = e < valid;
+    double f = 0, o = 0;
+    bool att0 = false;
+    if (alive) {
+      f = a.qpos[(size_t)ie * 4 + h];
+      o = a.qpos[(size_t)ie * 4 + 2 + h];
+      att0 = a.attached[ie] >= 0;
+    }
+    double ol = o;
+    unsigned long long att64 = __ballot(att0);
+    bool slow = __any(!(fabs(f) <= 1e300) || !(fabs(o) <= 2.8));   // NaN / object outside the arena -> exact path
+    unsigned long long p_read = 0, p_comp = 0, p_bar = 0;
+    if constexpr (PROF) p_t0 = ws_clock();
+    __syncthreads();
+    if constexpr (PROF) p_x = ws_clock();
+    const unsigned long long p_first = p_x - p_t0;
+    double av[K], nv[K];
+    uint8_t gv[K], ng[K];
+    int nslow = 0;
+    auto fetch = [&](int c) {   // chunk c+1 is already published when chunk c starts: fetch it one chunk ahead
+      const int ab = c % 3;
+      nslow = 0;
+#pragma unroll
+      for (int w = 0; w < NL; ++w) nslow |= slow_flag[ab][w];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { nv[k] = A[ab][k][wave * 64 + lane]; ng[k] = G[ab][k][e]; }
+    };
+    fetch(0);
+    for (int c = 0; c < nch; ++c) {
+      const int rb = c & 1;
+      slow = slow || (nslow != 0);
+#pragma unroll
+      for (int k = 0; k < K; ++k) { av[k] = nv[k]; gv[k] = ng[k]; }
+      if (c + 1 < nch) fetch(c + 1);
+      if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WS_STAMP(p_read)
+      auto run = [&](auto exact) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (c * K + k >= T) break;      // tail chunk (wave-uniform)
+          ws_step_xy<decltype(exact)::value>(f, o, ol, att64, av[k], __ballot(gv[k] != 0), a.th);
+          float* rowf = reinterpret_cast<float*>(&R[rb][k][e * 3]);   // (fx, fy, ox, oy), (flag, flag, ..)
+          rowf[h] = (float)f;
+          rowf[2 + h] = (float)o;
+          rowf[4 + h] = __builtin_amdgcn_inverse_ballot_w64(att64) ? 0.0f : -1.0f;
+        }
+      };
+      if (__builtin_amdgcn_readfirstlane(slow ? 1 : 0)) run(std::true_type{});
+      else run(std::false_type{});
+      if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WS_STAMP(p_comp)
+      __syncthreads();
+      WS_STAMP(p_bar)
+    }
+    if constexpr (PROF) {
+      if (lane == 0 && blockIdx.x < 64 && wave == 0) {
+        unsigned long long* op = g_ws_prof + blockIdx.x * 16;
+        op[0] = p_first; op[1] = p_read; op[2] = p_comp; op[3] = p_bar; op[4] = p_x - p_t0;
+      }
+    }
+    if (alive) {
+      a.qpos[(size_t)ie * 4 + h] = f;
+      a.qpos[(size_t)ie * 4 + 2 + h] = o;
+      if (h == 0) {
+        a.attached[ie] = (att64 >> lane) & 1 ? 0 : -1;
+        a.steps_since_reset[ie] += T;
+      }
+    }
+   } else {
     // ================================================================= COMPUTE
     double fx = 0, fy = 0, ox = 0, oy = 0;
     bool att = false;
@@ -121,20 +266,41 @@ __global__ __launch_bounds__(64 * (2 + NS)) void rollout_ws_kernel(const WsArgs 
       fx = u.x; fy = u.y; ox = v.x; oy = v.y;
       att = a.attached[i] >= 0;
     }
-    bool slow = __any((fx != fx) || (fy != fy) || (ox != ox) || (oy != oy));   // sticky, wave-uniform
+    double oxl = ox, oyl = oy;
+    // exact path if the state holds a NaN or an object outside the arena (sticky, wave-uniform)
+    bool slow = __any(!(fabs(fx) <= 1e300) || !(fabs(fy) <= 1e300) || !(fabs(ox) <= 2.8) || !(fabs(oy) <= 2.8));
+    unsigned long long p_read = 0, p_comp = 0, p_bar = 0;
+    if constexpr (PROF) p_t0 = ws_clock();
     __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-      const int ab = c % 3, rb = c & 1;
-      slow = slow || (slow_flag[ab] != 0);
-      double2 av[K];
-      uint8_t gv[K];
+    if constexpr (PROF) p_x = ws_clock();
+    const unsigned long long p_first = p_x - p_t0;
+    // Chunk c+1 is already published when chunk c starts (the loaders run one barrier interval ahead and the ring
+    // is 3 deep), so its actions are fetched from LDS while chunk c is being computed: no LDS latency per chunk.
+    double2 av[K], nv[K];
+    uint8_t gv[K], ng[K];
+    int nslow = 0;
+    auto fetch = [&](int c) {
+      const int ab = c % 3;
+      nslow = 0;
 #pragma unroll
-      for (int k = 0; k < K; ++k) { av[k] = A[ab][k][lane]; gv[k] = G[ab][k][lane]; }
+      for (int w = 0; w < NL; ++w) nslow |= slow_flag[ab][w];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { nv[k] = reinterpret_cast<const double2*>(&A[ab][k][0])[lane]; ng[k] = G[ab][k][lane]; }
+    };
+    fetch(0);
+    for (int c = 0; c < nch; ++c) {
+      const int rb = c & 1;
+      slow = slow || (nslow != 0);
+#pragma unroll
+      for (int k = 0; k < K; ++k) { av[k] = nv[k]; gv[k] = ng[k]; }
+      if (c + 1 < nch) fetch(c + 1);
+      if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WS_STAMP(p_read)
       auto run = [&](auto exact) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           if (c * K + k >= T) break;      // tail chunk (wave-uniform)
-          ws_step<decltype(exact)::value>(fx, fy, ox, oy, att, av[k].x, av[k].y, (gv[k] & 1) != 0, a.th);
+          ws_step<decltype(exact)::value>(fx, fy, ox, oy, oxl, oyl, att, av[k].x, av[k].y, gv[k] != 0, a.th);
           float4* row = &R[rb][k][lane * 3];
           row[0] = float4{(float)fx, (float)fy, (float)ox, (float)oy};
           const float flag = att ? 0.0f : -1.0f;
@@ -143,7 +309,16 @@ __global__ __launch_bounds__(64 * (2 + NS)) void rollout_ws_kernel(const WsArgs 
       };
       if (__builtin_amdgcn_readfirstlane(slow ? 1 : 0)) run(std::true_type{});
       else run(std::false_type{});
+      if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WS_STAMP(p_comp)
       __syncthreads();
+      WS_STAMP(p_bar)
+    }
+    if constexpr (PROF) {
+      if (lane == 0 && blockIdx.x < 64) {
+        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+        o[0] = p_first; o[1] = p_read; o[2] = p_comp; o[3] = p_bar; o[4] = p_x - p_t0;
+      }
     }
     if (live) {
       double2* q2 = reinterpret_cast<double2*>(a.qpos + (size_t)i * 4);
@@ -152,72 +327,102 @@ __global__ __launch_bounds__(64 * (2 + NS)) void rollout_ws_kernel(const WsArgs 
       a.attached[i] = att ? 0 : -1;
       a.steps_since_reset[i] += T;
     }
-  } else if (wave == 1) {
-    // ================================================================= LOADER
+   }
+  } else if (wave < NC + NL) {
+    // ================================================================= LOADERS
     // The actions of one step for this workgroup are 192 consecutive floats.  Lane l loads floats l, l+64, l+128
-    // (three fully coalesced 256-B wave loads per step, each into its own VGPR so the ring below needs no
-    // register shuffling), LEAD chunks ahead of their use.  Loads are UNCONDITIONAL with clamped indices: a load
-    // under a branch, or a multi-dword load whose lanes are later split, makes hipcc wait vmcnt(0) right behind
-    // it, which serialises the prefetch ring (seen in the ISA of earlier versions).
-    float raw[LEAD][K][3];
+    // (three coalesced 256-B wave loads, each into its own VGPR).  A loader owns the steps k = w, w+NL, .. of every
+    // chunk and keeps TWO trips (LEAD chunks each) of raw actions in registers: at the start of a trip it first
+    // touches the trip loaded one whole trip ago (long since landed), then issues the loads of the next one.
+    // Loads are UNCONDITIONAL with clamped indices: a load under a branch makes hipcc wait vmcnt(0) right behind
+    // it.  Clamped duplicates are never consumed (compute stops at T, storers mask dead lanes).
+    const int w = wave - NC;
+    float rawA[LEAD][KL][3], rawB[LEAD][KL][3];
     const int last = max(valid * 3 - 1, 0);
     const int e0 = min(lane, last), e1 = min(lane + 64, last), e2 = min(lane + 128, last);
-    auto issue = [&](int d, int j) {   // raw[d] <- actions of chunk j
+    const float* const base = a.act + (size_t)i0 * 3;
+    const size_t step_stride = (size_t)n * 3;
+    auto issue_trip = [&](float (&raw)[LEAD][KL][3], int r) {   // raw <- my steps of trip r
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const int t = min(j * K + k, T - 1);
-        const float* p = a.act + ((size_t)t * n + i0) * 3;
-        raw[d][k][0] = p[e0]; raw[d][k][1] = p[e1]; raw[d][k][2] = p[e2];
-      }
+      for (int d = 0; d < LEAD; ++d)
+#pragma unroll
+        for (int q = 0; q < KL; ++q) {
+          const int t = __builtin_amdgcn_readfirstlane(min((r * LEAD + d) * K + q * NL + w, T - 1));
+          const float* p = base + (size_t)t * step_stride;
+          raw[d][q][0] = p[e0]; raw[d][q][1] = p[e1]; raw[d][q][2] = p[e2];
+        }
     };
-    auto process = [&](int d, int j) { // transpose through LDS, rescale, publish chunk j in slot j % 3
+    unsigned long long p_proc = 0, p_bar = 0;
+    auto process = [&](const float (&raw)[KL][3], int j) {  // transpose through LDS, rescale, publish chunk j
       const int ab = j % 3;
       bool any_nan = false;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        float* sk = &S[k][0];
-        sk[lane] = raw[d][k][0]; sk[lane + 64] = raw[d][k][1]; sk[lane + 128] = raw[d][k][2];
+      for (int q = 0; q < KL; ++q) {
+        float* sk = &S[w][q][0];
+        sk[lane] = raw[q][0]; sk[lane + 64] = raw[q][1]; sk[lane + 128] = raw[q][2];
       }
       wave_lds_fence();
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float* sk = &S[k][0];   // same wave wrote it: LDS operations of one wave execute in order
-        const double a0 = rescale_action(sk[lane * 3]), a1 = rescale_action(sk[lane * 3 + 1]);
-        const double a2 = rescale_action(sk[lane * 3 + 2]);
-        const bool nan = (a0 != a0) || (a1 != a1);
-        any_nan = any_nan || nan;
+      for (int q = 0; q < KL; ++q) {
+        const float* sk = &S[w][q][0];   // same wave wrote it: LDS operations of one wave execute in order
+        const float r0 = sk[lane * 3], r1 = sk[lane * 3 + 1], r2 = sk[lane * 3 + 2];
+        const double a0 = rescale_action(r0), a1 = rescale_action(r1);
+        any_nan = any_nan || (r0 != r0) || (r1 != r1);
         if (j < nch) {
-          A[ab][k][lane] = double2{a0, a1};
-          G[ab][k][lane] = (uint8_t)((a2 > 0 ? 1 : 0) | (nan ? 2 : 0));
+          if constexpr (NC == 2) {
+            A[ab][q * NL + w][(lane >> 5) * 64 + (lane & 31)] = a0;
+            A[ab][q * NL + w][(lane >> 5) * 64 + 32 + (lane & 31)] = a1;
+          } else {
+            reinterpret_cast<double2*>(&A[ab][q * NL + w][0])[lane] = double2{a0, a1};
+          }
+          G[ab][q * NL + w][lane] = (uint8_t)(r2 >= a.grip_x);   // == rescale_action(r2) > 0 (NaN -> release)
         }
       }
       const bool wave_nan = __any(any_nan);
-      if (lane == 0 && j < nch) slow_flag[ab] = wave_nan ? 1 : 0;
+      if (lane == 0 && j < nch) slow_flag[ab][w] = wave_nan ? 1 : 0;
       wave_lds_fence();   // the next chunk's staging writes must stay behind these reads
     };
-#pragma unroll
-    for (int d = 0; d < LEAD; ++d) issue(d, d);
-    for (int j0 = 0; j0 < nch + 2; j0 += LEAD) {
+    auto run_trip = [&](float (&cur)[LEAD][KL][3], float (&nxt)[LEAD][KL][3], int r) {
 #pragma unroll
       for (int d = 0; d < LEAD; ++d) {
-        const int j = j0 + d;
-        process(d, j);
-        issue(d, j + LEAD);
+        const int j = r * LEAD + d;
+        process(cur[d], j);
+        if (d == 0) {                       // `cur` has been touched (its wait is behind us): now prefetch trip r+1
+          __builtin_amdgcn_sched_barrier(0);
+          issue_trip(nxt, r + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        WS_STAMP(p_proc)
         if (j >= 1 && j < nch + 2) __syncthreads();
+        WS_STAMP(p_bar)
+      }
+    };
+    if constexpr (PROF) p_t0 = p_x = ws_clock();
+    issue_trip(rawA, 0);
+    for (int r = 0; r * LEAD < nch + 2; r += 2) {
+      run_trip(rawA, rawB, r);
+      if ((r + 1) * LEAD < nch + 2) run_trip(rawB, rawA, r + 1);
+    }
+    if constexpr (PROF) {
+      if (lane == 0 && blockIdx.x < 64 && w == 0) {
+        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+        o[5] = p_proc; o[6] = p_bar; o[7] = p_x - p_t0;
       }
     }
   } else {
     // ================================================================= STORERS
-    const int s = wave - 2;
+    const int s = wave - NC - NL;
     float g[6] = {0, 0, 0, 0, 0, 0};
-    int steps0 = 0;
+    int t_done = 0x7fffffff;           // done fires from step index t_done on (steps_since_reset + t + 1 >= horizon)
     if (live) {
       load_goal<1>(a.goal_table, a.goal_idx[i], g);
-      steps0 = a.steps_since_reset[i];
+      const long long td = (long long)a.horizon - 1 - a.steps_since_reset[i];
+      t_done = td < 0 ? 0 : (td > 0x7fffffff ? 0x7fffffff : (int)td);
     }
-    // steps0 must be in a register before the compute wave can possibly update steps_since_reset
+    // steps_since_reset must be in a register before the compute wave can possibly update it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool packed_flags = (valid == E) && ((n & 3) == 0);
+    const bool full = (valid == E) && ((n & 3) == 0);   // whole workgroup live and flag rows dword-aligned
+    unsigned long long p_st = 0, p_bar = 0;
     auto store_chunk = [&](int c) {
       const int rb = c & 1;
 #pragma unroll
@@ -226,43 +431,60 @@ __global__ __launch_bounds__(64 * (2 + NS)) void rollout_ws_kernel(const WsArgs 
         const int t = c * K + k;
         if (t >= T) continue;
         const size_t row0 = (size_t)t * n + i0;
-        // (1) the 64 obs rows of this step: 192 float4, contiguous in HBM and in LDS
         float4* dst = reinterpret_cast<float4*>(a.obs + row0 * 12);
         const float4* src = &R[rb][k][0];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const int idx = lane + 64 * m;
-          if (idx < valid * 3) dst[idx] = src[idx];
-        }
-        // (2) reward / success / done of env `lane`
+        // reward / success / done of env `lane` need the coordinates of its own row
         const float4 p = src[lane * 3];
-        float o[12] = {p.x, p.y, p.z, p.w, 0.f, 0.f, g[0], g[1], g[2], g[3], g[4], g[5]};
+        const float o[12] = {p.x, p.y, p.z, p.w, 0.f, 0.f, g[0], g[1], g[2], g[3], g[4], g[5]};
         const bool succ = success1(o, a.wide, a.th);
         float rew;
         if constexpr (RT == EARL_REWARD_SPARSE) rew = succ ? 1.0f : 0.0f;
         else rew = (float)dense1(o);
-        const bool dn = steps0 + t + 1 >= a.horizon;
-        if (live) a.reward[row0 + lane] = rew;
-        if (packed_flags) {   // 64 flag bytes of a step = 16 dwords: expand ballot nibbles to bytes
+        const bool dn = t >= t_done;
+        if (full) {
+          // (1) the 64 obs rows of this step: 192 float4, contiguous in HBM and in LDS
+          const float4 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128];
+          dst[lane] = v0; dst[lane + 64] = v1; dst[lane + 128] = v2;
+          a.reward[row0 + lane] = rew;
+          // (2) 64 flag bytes of a step = 16 dwords: expand ballot nibbles to bytes
           const unsigned long long ms = __ballot(succ), md = __ballot(dn);
           if (lane < 16) {
             const uint32_t ns = (uint32_t)(ms >> (4 * lane)) & 0xFu, nd = (uint32_t)(md >> (4 * lane)) & 0xFu;
             reinterpret_cast<uint32_t*>(a.success + row0)[lane] = (ns * 0x00204081u) & 0x01010101u;
             reinterpret_cast<uint32_t*>(a.done + row0)[lane] = (nd * 0x00204081u) & 0x01010101u;
           }
-        } else if (live) {
-          a.success[row0 + lane] = succ;
-          a.done[row0 + lane] = dn;
+        } else {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const int idx = lane + 64 * m;
+            if (idx < valid * 3) dst[idx] = src[idx];
+          }
+          if (live) {
+            a.reward[row0 + lane] = rew;
+            a.success[row0 + lane] = succ;
+            a.done[row0 + lane] = dn;
+          }
         }
       }
     };
+    if constexpr (PROF) p_t0 = ws_clock();
     __syncthreads();
+    if constexpr (PROF) p_x = ws_clock();
     for (int c = 0; c < nch; ++c) {
       if (c >= 1) store_chunk(c - 1);
+      WS_STAMP(p_st)
       __syncthreads();
+      WS_STAMP(p_bar)
     }
     store_chunk(nch - 1);
+    if constexpr (PROF) {
+      if (lane == 0 && blockIdx.x < 64 && s == 0) {
+        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+        o[8] = p_st; o[9] = p_bar; o[10] = ws_clock() - p_t0;
+      }
+    }
   }
 }
+#undef WS_STAMP
 
 }  // namespace earl
