@@ -34,6 +34,7 @@ _P = C.POINTER
 SIGNATURES = {
     'earl_tabletop_step': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, _P(TabletopOut), C.c_void_p],
     'earl_tabletop_rollout': [_P(TabletopCfg), _P(TabletopState), C.c_int32, C.c_void_p, _P(TabletopOut), C.c_void_p],
+    'earl_tabletop_reset_rollout': [_P(TabletopCfg), _P(TabletopState), C.c_int32, C.c_void_p, _P(TabletopOut), C.c_void_p],
     'earl_tabletop_reset': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_tabletop_observe': [_P(TabletopCfg), _P(TabletopState), _P(TabletopOut), C.c_void_p],
     'earl_tabletop_reward': [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],

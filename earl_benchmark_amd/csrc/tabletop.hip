@@ -359,18 +359,26 @@ int do_step(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const f
 }
 
 template <int NOBJ>
-int do_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act,
-               const earl_tabletop_out* out, earl_stream_t stream) {
+int do_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const uint8_t* mask, const int32_t* ngi,
+             float* obs, earl_stream_t stream);
+
+// reset_first: perform the reset of all envs (counter cfg->counter) before the T steps (counters cfg->counter+1 ..)
+template <int NOBJ>
+int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, int32_t T, const float* act,
+               const earl_tabletop_out* out, earl_stream_t stream, bool reset_first = false) {
+  const earl_tabletop_cfg* cfg = cfg_in;
   if (int rc = check_common(cfg, st, NOBJ)) return rc;
   if (!act || !out) return fail(EARL_ERR_ARG, "act/out is NULL");
   if (T < 0) return fail(EARL_ERR_ARG, "T = %d < 0", T);
-  if (cfg->n == 0 || T == 0) return EARL_OK;
+  if (cfg->n == 0) return EARL_OK;
+  if (T == 0) return reset_first ? do_reset<NOBJ>(cfg, st, nullptr, nullptr, nullptr, stream) : EARL_OK;
   const bool general = cfg->goal_change_frequency > 0 || cfg->auto_reset;
   if constexpr (NOBJ == 1) {
     // the common case (no lifelong switching, no auto-reset, all outputs requested): wave-specialised kernel
     if (!general && out->obs && out->reward && out->done && out->success && g_rollout_impl != 1) {
       WsArgs w{cfg->n, T, cfg->horizon, cfg->wide_init, act, st->qpos, st->attached, st->goal_idx, st->goal_table,
-               st->steps_since_reset, out->obs, out->reward, out->done, out->success, thresholds(), grip_threshold()};
+               st->steps_since_reset, out->obs, out->reward, out->done, out->success, thresholds(), grip_threshold(),
+               reset_first ? 1 : 0, *cfg, st->goal_idx, st->num_interventions};
       const dim3 grid((unsigned)((cfg->n + 63) / 64));
       const hipStream_t hs = (hipStream_t)stream;
 #define EARL_WS(RT, NC, NL, NS, K, LEAD) \
@@ -399,7 +407,12 @@ int do_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int3
       return launched("rollout_ws_kernel");
     }
   }
-  KArgs a{*cfg, *st, *out, act, nullptr, nullptr, nullptr, T, thresholds()};
+  earl_tabletop_cfg c2 = *cfg;
+  if (reset_first) {   // no fused variant of the general kernel: reset launch, then the steps with the next counters
+    if (int rc = do_reset<NOBJ>(cfg, st, nullptr, nullptr, nullptr, stream)) return rc;
+    c2.counter += 1;
+  }
+  KArgs a{c2, *st, *out, act, nullptr, nullptr, nullptr, T, thresholds()};
   if (general)
     rollout_kernel<NOBJ, true><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
   else
@@ -432,6 +445,10 @@ int earl_tabletop_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_stat
 int earl_tabletop_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const uint8_t* mask,
                         const int32_t* next_goal_idx, float* obs, earl_stream_t stream) {
   return do_reset<1>(cfg, st, mask, next_goal_idx, obs, stream);
+}
+int earl_tabletop_reset_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act,
+                                const earl_tabletop_out* out, earl_stream_t stream) {
+  return do_rollout<1>(cfg, st, T, act, out, stream, true);
 }
 int earl_tabletop_observe(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const earl_tabletop_out* out,
                           earl_stream_t stream) {

@@ -44,7 +44,20 @@ struct WsArgs {
   uint8_t* __restrict__ success;      // [T, n]
   Thresholds th;
   float grip_x;                       // smallest float x with rescale_action(x) > 0 (host: exact search)
+  // fused reset: reset_first != 0 performs earl_tabletop_reset (all envs, counter cfg.counter) in the prologue and
+  // runs the steps with counters cfg.counter + 1 ..; cfg carries seed / env_offset / reset mode / n_sample_goals
+  int32_t reset_first;
+  earl_tabletop_cfg cfg;
+  int32_t* __restrict__ goal_idx_w;         // same array as goal_idx (written by the fused reset)
+  int32_t* __restrict__ num_interventions;
 };
+
+// goal row of env `e` for this launch: the stored one, or the one the fused reset samples (every wave that needs it
+// recomputes the same Philox draw instead of waiting for another wave to publish it)
+__device__ __forceinline__ int ws_goal_row(const WsArgs& a, int env) {
+  if (a.reset_first) return sample_goal(a.cfg, a.cfg.counter, env, nullptr);
+  return a.goal_idx[env];
+}
 
 // Lanes of ONE wave exchange data through LDS (loader staging).  Per thread the write and read addresses never
 // alias, so without a fence hipcc reorders them freely (it did: seen in the ISA); a wavefront-scope fence costs no
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
   for (int idx = threadIdx.x; idx < 2 * K * E; idx += 64 * (NC + NL + NS)) {
     const int e = idx % E;
     float g[6] = {0, 0, 0, 0, 0, 0};
-    if (e < valid) load_goal<1>(a.goal_table, a.goal_idx[i0 + e], g);
+    if (e < valid) load_goal<1>(a.goal_table, ws_goal_row(a, i0 + e), g);
     float4* row = &R[0][0][0] + (size_t)(idx / E) * (E * 3) + e * 3;
     row[1] = float4{-1.0f, -1.0f, g[0], g[1]};
     row[2] = float4{g[2], g[3], g[4], g[5]};
@@ -192,9 +205,20 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
     double f = 0, o = 0;
     bool att0 = false;
     if (alive) {
-      f = a.qpos[(size_t)ie * 4 + h];
-      o = a.qpos[(size_t)ie * 4 + 2 + h];
-      att0 = a.attached[ie] >= 0;
+      if (a.reset_first) {   // PersistentStateWrapper.reset + TabletopManipulation.reset, both lanes of the env alike
+        Env<1> ev;
+        const int gi = reset_env<1>(ev, a.cfg, a.cfg.counter, ie, a.goal_table, nullptr, a.th);
+        f = ev.q[h];
+        o = ev.q[2 + h];
+        if (h == 0) {
+          a.goal_idx_w[ie] = gi;
+          a.num_interventions[ie] += 1;
+        }
+      } else {
+        f = a.qpos[(size_t)ie * 4 + h];
+        o = a.qpos[(size_t)ie * 4 + 2 + h];
+        att0 = a.attached[ie] >= 0;
+      }
     }
     double ol = o;
     unsigned long long att64 = __ballot(att0);
@@ -253,7 +277,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       a.qpos[(size_t)ie * 4 + 2 + h] = o;
       if (h == 0) {
         a.attached[ie] = (att64 >> lane) & 1 ? 0 : -1;
-        a.steps_since_reset[ie] += T;
+        a.steps_since_reset[ie] = (a.reset_first ? 0 : a.steps_since_reset[ie]) + T;
       }
     }
    } else {
@@ -261,10 +285,18 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
     double fx = 0, fy = 0, ox = 0, oy = 0;
     bool att = false;
     if (live) {
-      const double2* q2 = reinterpret_cast<const double2*>(a.qpos + (size_t)i * 4);
-      const double2 u = q2[0], v = q2[1];
-      fx = u.x; fy = u.y; ox = v.x; oy = v.y;
-      att = a.attached[i] >= 0;
+      if (a.reset_first) {
+        Env<1> ev;
+        const int gi = reset_env<1>(ev, a.cfg, a.cfg.counter, i, a.goal_table, nullptr, a.th);
+        fx = ev.q[0]; fy = ev.q[1]; ox = ev.q[2]; oy = ev.q[3];
+        a.goal_idx_w[i] = gi;
+        a.num_interventions[i] += 1;
+      } else {
+        const double2* q2 = reinterpret_cast<const double2*>(a.qpos + (size_t)i * 4);
+        const double2 u = q2[0], v = q2[1];
+        fx = u.x; fy = u.y; ox = v.x; oy = v.y;
+        att = a.attached[i] >= 0;
+      }
     }
     double oxl = ox, oyl = oy;
     // exact path if the state holds a NaN or an object outside the arena (sticky, wave-uniform)
@@ -325,7 +357,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       q2[0] = double2{fx, fy};
       q2[1] = double2{ox, oy};
       a.attached[i] = att ? 0 : -1;
-      a.steps_since_reset[i] += T;
+      a.steps_since_reset[i] = (a.reset_first ? 0 : a.steps_since_reset[i]) + T;
     }
    }
   } else if (wave < NC + NL) {
@@ -415,8 +447,8 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
     float g[6] = {0, 0, 0, 0, 0, 0};
     int t_done = 0x7fffffff;           // done fires from step index t_done on (steps_since_reset + t + 1 >= horizon)
     if (live) {
-      load_goal<1>(a.goal_table, a.goal_idx[i], g);
-      const long long td = (long long)a.horizon - 1 - a.steps_since_reset[i];
+      load_goal<1>(a.goal_table, ws_goal_row(a, i), g);
+      const long long td = (long long)a.horizon - 1 - (a.reset_first ? 0 : a.steps_since_reset[i]);
       t_done = td < 0 ? 0 : (td > 0x7fffffff ? 0x7fffffff : (int)td);
     }
     // steps_since_reset must be in a register before the compute wave can possibly update it

@@ -206,9 +206,10 @@ class TabletopManipulation:
       return obs[0].cpu().numpy(), float(rew[0]), bool(done[0]), {}
     return obs, rew, done, {'success': succ}
 
-  def rollout(self, actions, out=None):
+  def rollout(self, actions, out=None, reset_first=False):
     """T steps in one kernel launch: actions [T, N, 3] -> (obs [T,N,D], reward [T,N], done [T,N], success [T,N]).
-    Bit-identical to T calls of step().  `out`: optional tuple of preallocated output tensors to write into."""
+    Bit-identical to T calls of step().  `out`: optional tuple of preallocated output tensors to write into.
+    `reset_first=True` folds a reset() of every env into the same launch (one evaluation episode per call)."""
     with torch.cuda.device(self.device):
       a = torch.as_tensor(actions, device=self.device)
       T = a.shape[0]
@@ -223,10 +224,15 @@ class TabletopManipulation:
           if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
             raise ValueError(f'out tensor must be contiguous {dt} {shape} on {self.device}')
         out = _abi.TabletopOut(*(t.data_ptr() for t in outs))
-      fn = self._lib.earl_tabletop_rollout if self.NOBJ == 1 else self._lib.earl_tabletop3_rollout
+      if reset_first and self.NOBJ == 1:
+        fn = self._lib.earl_tabletop_reset_rollout
+      else:
+        if reset_first:
+          self._reset_kernel(None, None, want_obs=False)
+        fn = self._lib.earl_tabletop_rollout if self.NOBJ == 1 else self._lib.earl_tabletop3_rollout
       rc = fn(C.byref(self._cfg), C.byref(self._st), T, act.data_ptr(), C.byref(out), self._stream())
     _abi.check(rc, 'rollout')
-    self._cfg.counter += T          # step t of the rollout used counter + t
+    self._cfg.counter += T + (1 if reset_first and self.NOBJ == 1 else 0)   # step t used counter (+1 after a fused reset) + t
     self.total_step_count += T
     self._last_success = outs[3][-1]
     return outs

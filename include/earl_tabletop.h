@@ -90,6 +90,12 @@ int earl_tabletop_step(const earl_tabletop_cfg* cfg, const earl_tabletop_state* 
 int earl_tabletop_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T,
                           const float* act, const earl_tabletop_out* out, earl_stream_t stream);
 
+/* One evaluation episode per env in ONE launch: earl_tabletop_reset (all envs, Philox counter cfg->counter) followed by
+ * earl_tabletop_rollout of T steps (counters cfg->counter + 1 ...).  Bit-identical to the two calls; the caller advances
+ * its counter by T + 1.  (With lifelong switching / auto-reset enabled it is executed as the two launches.) */
+int earl_tabletop_reset_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T,
+                                const float* act, const earl_tabletop_out* out, earl_stream_t stream);
+
 /* PersistentStateWrapper.reset() + TabletopManipulation.reset() for the envs with mask[i] != 0
  * (mask == NULL: all).  Replaces wrappers/persistent_state_wrapper.py:17-20 and
  * envs/tabletop_manipulation.py:105-126 (incl. is_valid_init :89-97, get_next_goal :62-76).

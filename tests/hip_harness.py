@@ -100,15 +100,16 @@ class HipTabletop:
     self.cfg.counter += 1
     return tuple(x.cpu().numpy() for x in arrs)
 
-  def rollout(self, act):
+  def rollout(self, act, reset_first=False):
     a = self._dev(act, torch.float32)
     T = a.shape[0]
     assert a.shape == (T, self.n, 3)
     arrs, out = self._outs((T, self.n))
     st = self._state()
-    rc = getattr(self.lib, self._pfx + 'rollout')(C.byref(self.cfg), C.byref(st), T, _ptr(a), C.byref(out), self.stream)
-    self._ok(rc, 'rollout')
-    self.cfg.counter += T
+    name = self._pfx + ('reset_rollout' if reset_first else 'rollout')
+    rc = getattr(self.lib, name)(C.byref(self.cfg), C.byref(st), T, _ptr(a), C.byref(out), self.stream)
+    self._ok(rc, name)
+    self.cfg.counter += T + (1 if reset_first else 0)
     return tuple(x.cpu().numpy() for x in arrs)
 
   def observe(self):

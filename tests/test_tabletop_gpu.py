@@ -452,3 +452,31 @@ def test_rollout_kernels_agree(hx, orc, rt, wide, n, T):
     np.testing.assert_array_equal(v, getattr(o, k), err_msg=k)
   if n >= 63 and T >= 4:
     assert np.isnan(outs[0][0][-1, 5, 0])
+
+
+@pytest.mark.parametrize('mode', ['fixed', 'at_goal', 'wide'])
+@pytest.mark.parametrize('impl', [0, 1])
+def test_fused_reset_rollout_equals_reset_then_rollout(hx, orc, mode, impl):
+  """earl_tabletop_reset_rollout (one launch) == reset + rollout (two launches) == the oracle, for every reset mode,
+  for both rollout kernels, twice in a row (second episode starts from a dirty state)."""
+  from earl_benchmark_amd import _abi
+  lib = _abi.load()
+  n, T = 1000, 21
+  kw = dict(reset_at_goal=mode == 'at_goal', wide_init=mode == 'wide', seed=77, env_offset=5, horizon=T)
+  rng = np.random.default_rng(2)
+  o = orc.OracleTabletop(n, **kw)
+  h = hx.HipTabletop(n, **kw)
+  prev = lib.earl_debug_set_rollout_impl(impl)
+  try:
+    for rep in range(2):
+      acts = rng.uniform(-1, 1, size=(T, n, 3)).astype(np.float32)
+      acts[..., 2] = np.abs(acts[..., 2])
+      got = h.rollout(acts, reset_first=True)
+      o.reset()
+      want = o.rollout(acts)
+      assert_same_out(got, want, False)
+      assert_same_state(o, h)
+      assert h.cfg.counter == o.cfg.counter
+  finally:
+    lib.earl_debug_set_rollout_impl(prev)
+  assert (o.num_interventions == 2).all() and (o.steps_since_reset == T).all()

@@ -19,11 +19,11 @@ for n in sizes:
     lib.earl_debug_set_rollout_impl(impl)
     reps = max(5, min(200, int(3e9 // (n * T * 66))))
     for _ in range(3):
-      env.reset(); env.rollout(acts, out=out)
+      env.rollout(acts, out=out, reset_first=True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     torch.cuda.synchronize()
     for a, b in ev:
-      env.reset(); a.record(); env.rollout(acts, out=out); b.record()
+      a.record(); env.rollout(acts, out=out, reset_first=True); b.record()
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in ev)
     med = ms[len(ms) // 2]
