@@ -389,19 +389,23 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 3: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 8, 3); break;
           case 4: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 4, 6); break;
           case 5: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 8, 3); break;
-          case 6: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 2, 4, 6); break;
-          case 7: EARL_WS(EARL_REWARD_SPARSE, 2, 1, 2, 4, 6); break;
+          case 6: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 8, 8, 3); break;
+          case 7: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 8, 8, 3); break;
+          case 10: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 8, 3); break;
+          case 11: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 8, 3); break;
+          case 12: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 4, 6); break;
+          case 13: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 2, 4, 6); break;
+          case 14: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 2, 4, 6); break;
           case 8: EARL_WS(EARL_REWARD_SPARSE, 1, 1, 1, 4, 6); break;
           case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 2, 4, 8, 3, true><<<grid, 64 * 8, 0, hs>>>(w); break;  // stamps
           default:
-            // latency regime (one workgroup per CU): two x/y-split compute waves; throughput regime: fewer waves
-            if (cfg->n <= 32768) EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 8, 3);
-            else EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 8, 3);
+            // 2 x/y-split compute waves + 4 loaders + 4 storers, 8-step chunks: fastest of the variants above at
+            // every N measured (tools/tune_rollout.py; profiles/r01_tune_rollout.txt)
+            EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 8, 3);
             break;
         }
       } else {
-        if (cfg->n <= 32768) EARL_WS(EARL_REWARD_DENSE, 2, 2, 4, 8, 3);
-        else EARL_WS(EARL_REWARD_DENSE, 1, 2, 4, 8, 3);
+        EARL_WS(EARL_REWARD_DENSE, 2, 4, 4, 8, 3);
       }
 #undef EARL_WS
       return launched("rollout_ws_kernel");

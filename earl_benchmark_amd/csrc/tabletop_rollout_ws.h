@@ -145,6 +145,27 @@ __device__ __forceinline__ void ws_step_xy(double& f, double& o, double& ol, uns
   }
 }
 
+// Fast path of ws_step_xy, software-pipelined by one step: `nm` is the attach-test mask of the step being executed,
+// computed during the PREVIOUS step from (gripper after that step, mug before that step) -- by the argument above
+// that is the mug position whenever the test matters -- so the 10-instruction test chain (sub, mul, 2x swap, fma,
+// cmp, mask ops) runs beside the object update and the output conversion instead of in front of them.
+__device__ __forceinline__ unsigned long long ws_near_mask_xy(double f, double o, const Thresholds& th) {
+  const double d = f - o;
+  const double d2 = fma(d, d, both_halves_from_lower(d * d));   // meaningful in the Y half: fma(dy, dy, dx*dx)
+  const unsigned near_y = (unsigned)(__ballot(d2 < th.grasp_d2) >> 32);
+  return ((unsigned long long)near_y << 32) | near_y;
+}
+__device__ __forceinline__ void ws_step_xy_pipe(double& f, double& o, unsigned long long& nm, unsigned long long& att64,
+                                                double a, unsigned long long grip64, const Thresholds& th) {
+  att64 = grip64 & (att64 | nm);
+  const bool att = __builtin_amdgcn_inverse_ballot_w64(att64);
+  const double nf = clip_fast(f + a);
+  nm = ws_near_mask_xy(nf, o, th);          // for the NEXT step: o is still the mug position before this step's move
+  const double dd = att ? nf - f : -0.0;
+  o = clip_fast(o + dd);
+  f = nf;
+}
+
 // PROF = diagnostic build only (tools/prof_ws.py): s_memtime stamps per role, summed per workgroup into
 // g_ws_prof; never used by the shipped configuration and its timings are not quoted.
 __device__ unsigned long long g_ws_prof[64 * 16];
@@ -197,6 +218,9 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
   }
 
   if (wave < NC) {
+   // the recurrence is the critical path: its wave wins issue arbitration against the loader/storer wave that shares
+   // its SIMD (MI355X_MICROARCH.md, "two waves per SIMD": priority, then age)
+   __builtin_amdgcn_s_setprio(3);
    if constexpr (NC == 2) {
     // ================================================================= COMPUTE, x / y in the two lane halves
     const int h = lane >> 5, el = lane & 31, e = wave * 32 + el;   // coordinate, env within the wave / workgroup
@@ -222,6 +246,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
     }
     double ol = o;
     unsigned long long att64 = __ballot(att0);
+    unsigned long long nm = ws_near_mask_xy(f, o, a.th);   // attach test of the first step (true positions)
     bool slow = __any(!(fabs(f) <= 1e300) || !(fabs(o) <= 2.8));   // NaN / object outside the arena -> exact path
     unsigned long long p_read = 0, p_comp = 0, p_bar = 0;
     if constexpr (PROF) p_t0 = ws_clock();
@@ -248,19 +273,25 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       if (c + 1 < nch) fetch(c + 1);
       if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       WS_STAMP(p_read)
-      auto run = [&](auto exact) {
+      auto run = [&](auto exact, auto full) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          if (c * K + k >= T) break;      // tail chunk (wave-uniform)
-          ws_step_xy<decltype(exact)::value>(f, o, ol, att64, av[k], __ballot(gv[k] != 0), a.th);
+          if constexpr (!decltype(full)::value)
+            if (c * K + k >= T) break;      // tail chunk only (wave-uniform)
+          if constexpr (decltype(exact)::value) ws_step_xy<true>(f, o, ol, att64, av[k], __ballot(gv[k] != 0), a.th);
+          else ws_step_xy_pipe(f, o, nm, att64, av[k], __ballot(gv[k] != 0), a.th);
           float* rowf = reinterpret_cast<float*>(&R[rb][k][e * 3]);   // (fx, fy, ox, oy), (flag, flag, ..)
           rowf[h] = (float)f;
           rowf[2 + h] = (float)o;
           rowf[4 + h] = __builtin_amdgcn_inverse_ballot_w64(att64) ? 0.0f : -1.0f;
         }
       };
-      if (__builtin_amdgcn_readfirstlane(slow ? 1 : 0)) run(std::true_type{});
-      else run(std::false_type{});
+      const bool whole = (c + 1) * K <= T;   // every step of the chunk exists: no per-step tail test
+      if (__builtin_amdgcn_readfirstlane(slow ? 1 : 0)) {
+        if (whole) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+      } else {
+        if (whole) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
+      }
       if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       WS_STAMP(p_comp)
       __syncthreads();
@@ -328,10 +359,11 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       if (c + 1 < nch) fetch(c + 1);
       if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       WS_STAMP(p_read)
-      auto run = [&](auto exact) {
+      auto run = [&](auto exact, auto full) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          if (c * K + k >= T) break;      // tail chunk (wave-uniform)
+          if constexpr (!decltype(full)::value)
+            if (c * K + k >= T) break;      // tail chunk only (wave-uniform)
           ws_step<decltype(exact)::value>(fx, fy, ox, oy, oxl, oyl, att, av[k].x, av[k].y, gv[k] != 0, a.th);
           float4* row = &R[rb][k][lane * 3];
           row[0] = float4{(float)fx, (float)fy, (float)ox, (float)oy};
@@ -339,8 +371,12 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
           *reinterpret_cast<float2*>(&row[1]) = float2{flag, flag};
         }
       };
-      if (__builtin_amdgcn_readfirstlane(slow ? 1 : 0)) run(std::true_type{});
-      else run(std::false_type{});
+      const bool whole = (c + 1) * K <= T;   // every step of the chunk exists: no per-step tail test
+      if (__builtin_amdgcn_readfirstlane(slow ? 1 : 0)) {
+        if (whole) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+      } else {
+        if (whole) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
+      }
       if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       WS_STAMP(p_comp)
       __syncthreads();

@@ -21,6 +21,6 @@ for n in [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['64
   b = buf.reshape(64, 16)[:min(64, (n + 63) // 64)].astype(np.float64)
   m = np.median(b, axis=0)
   names = ['C.first_barrier', 'C.lds_read', 'C.compute', 'C.barrier', 'C.total', 'L.process+issue', 'L.barrier', 'L.total', 'S0.store', 'S0.barrier', 'S0.total']
-  print(f'n={n}: median cycles over {len(b)} workgroups (T={T}, 50 chunks of 4 steps)')
+  print(f'n={n}: median cycles over {len(b)} workgroups (T={T}, K=8: 25 chunks)')
   for k, nm in enumerate(names):
-    print(f'   {nm:18s} {m[k]:10.0f}  per chunk {m[k] / 50:8.1f}')
+    print(f'   {nm:18s} {m[k]:10.0f}  per step {m[k] / 200:8.1f}')
