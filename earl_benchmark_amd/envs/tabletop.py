@@ -107,6 +107,7 @@ class TabletopManipulation:
                                  n_goals=len(self._base_goals), n_sample_goals=self._n_sample_goals,
                                  seed=int(seed) & (2**64 - 1), counter=0)
     self._st = _abi.TabletopState()
+    self._cfg_ref, self._st_ref = C.byref(self._cfg), C.byref(self._st)   # reused by the hot calls
     self._sync_state_ptrs()
 
     self.action_space = Box(-1.0, 1.0, (3,), np.float32)           # three ctrlrange=[-1,1] motors of the model
@@ -189,18 +190,48 @@ class TabletopManipulation:
       obs = self._reset_kernel(mask, goal_idx)
     return obs[0].cpu().numpy() if self.scalar_api else obs
 
-  def step(self, action, next_goal_idx=None):
-    with torch.cuda.device(self.device):
-      act = self._actions(action, (self.num_envs,))
-      (obs, rew, done, succ), out = self._new_out((self.num_envs,))
+  def _out_struct(self, outs, lead):
+    """validate caller-provided output tensors (obs, reward, done, success) and wrap their pointers"""
+    want = [(lead + (self.OBS_DIM,), torch.float32), (lead, torch.float32), (lead, torch.bool), (lead, torch.bool)]
+    if len(outs) != 4:
+      raise ValueError('out must be (obs, reward, done, success)')
+    for t, (shape, dt) in zip(outs, want):
+      if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+        raise ValueError(f'out tensor must be contiguous {dt} {shape} on {self.device}')
+    return _abi.TabletopOut(*(t.data_ptr() for t in outs))
+
+  def step(self, action, next_goal_idx=None, out=None):
+    """step(action) of the wrapped reference env for every env: action [N, 3] -> (obs [N, D], reward [N], done [N],
+    {'success': [N]}).  Fresh output tensors per call like the reference (callers may keep them); pass
+    `out=(obs, reward, done, success)` to write into preallocated tensors instead."""
+    n = self.num_envs
+    if (torch.is_tensor(action) and action.dtype == torch.float32 and action.device == self.device
+        and action.shape == (n, 3) and action.is_contiguous()):
+      act = action
+    else:
+      act = self._actions(action, (n,))
+    if out is None:
+      outs, ostruct = self._new_out((n,))
+    else:
+      outs, ostruct = tuple(out), self._out_struct(tuple(out), (n,))
+    ctx = None
+    if torch.cuda.current_device() != self.device.index:   # launches go to the current device's runtime context
+      ctx = torch.cuda.device(self.device)
+      ctx.__enter__()
+    try:
       if self.NOBJ == 1:
         g = self._as_i32(next_goal_idx)
-        rc = self._lib.earl_tabletop_step(C.byref(self._cfg), C.byref(self._st), act.data_ptr(), _ptr(g), C.byref(out), self._stream())
+        rc = self._lib.earl_tabletop_step(self._cfg_ref, self._st_ref, act.data_ptr(), _ptr(g), C.byref(ostruct), self._stream())
       else:
-        rc = self._lib.earl_tabletop3_step(C.byref(self._cfg), C.byref(self._st), act.data_ptr(), C.byref(out), self._stream())
-    _abi.check(rc, 'step')
+        rc = self._lib.earl_tabletop3_step(self._cfg_ref, self._st_ref, act.data_ptr(), C.byref(ostruct), self._stream())
+    finally:
+      if ctx is not None:
+        ctx.__exit__(None, None, None)
+    if rc:
+      _abi.check(rc, 'step')
     self._cfg.counter += 1          # every call uses the current Philox counter, then advances it
     self.total_step_count += 1
+    obs, rew, done, succ = outs
     self._last_success = succ
     if self.scalar_api:
       return obs[0].cpu().numpy(), float(rew[0]), bool(done[0]), {}
@@ -218,12 +249,7 @@ class TabletopManipulation:
         outs, out = self._new_out((T, self.num_envs))
       else:
         outs = tuple(out)
-        want = [((T, self.num_envs, self.OBS_DIM), torch.float32), ((T, self.num_envs), torch.float32),
-                ((T, self.num_envs), torch.bool), ((T, self.num_envs), torch.bool)]
-        for t, (shape, dt) in zip(outs, want):
-          if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
-            raise ValueError(f'out tensor must be contiguous {dt} {shape} on {self.device}')
-        out = _abi.TabletopOut(*(t.data_ptr() for t in outs))
+        out = self._out_struct(outs, (T, self.num_envs))
       if reset_first and self.NOBJ == 1:
         fn = self._lib.earl_tabletop_reset_rollout
       else:

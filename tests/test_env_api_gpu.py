@@ -174,3 +174,38 @@ def test_no_cpu_device():
   from earl_benchmark_amd.envs import tabletop
   with pytest.raises(_abi.EarlHipError):
     tabletop.TabletopManipulation(num_envs=2, device='cpu')
+
+
+def test_launches_are_graph_capturable(torch, orc):
+  """The launch functions allocate nothing and never synchronise, so an evaluation episode (fused reset + rollout) can
+  be captured into a HIP graph on a side stream and replayed; replays reproduce the eager result."""
+  from earl_benchmark_amd.envs import tabletop
+  n, T = 512, 40
+  env = tabletop.TabletopManipulation(reward_type='sparse', num_envs=n, seed=3)
+  env._cfg.horizon = T
+  rng = np.random.default_rng(9)
+  acts = torch.from_numpy(rng.uniform(-1, 1, size=(T, n, 3)).astype(np.float32)).cuda()
+  out = (torch.empty(T, n, 12, device='cuda'), torch.empty(T, n, device='cuda'),
+         torch.empty(T, n, dtype=torch.bool, device='cuda'), torch.empty(T, n, dtype=torch.bool, device='cuda'))
+  counter0 = int(env._cfg.counter)
+  ref = [x.clone() for x in env.rollout(acts, out=out, reset_first=True)]
+  qpos_ref = env.qpos.clone()
+  env._cfg.counter = counter0                      # the graph freezes the kernel arguments, incl. the Philox counter
+  for t in out:
+    t.zero_()
+  g = torch.cuda.CUDAGraph()
+  s = torch.cuda.Stream()
+  s.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(s):
+    with torch.cuda.graph(g, stream=s):
+      env.rollout(acts, out=out, reset_first=True)
+  torch.cuda.current_stream().wait_stream(s)
+  for _ in range(3):
+    for t in out:
+      t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(out, ref):
+      assert torch.equal(x, y)
+    assert torch.equal(env.qpos, qpos_ref)
+  assert int(env.interventions[0]) == 1 + 3        # one eager episode + three replays (capture itself executes nothing)
