@@ -80,9 +80,8 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world):
   e1.record()
   gathered = None
   if world > 1:                 # the one collective of the job: evaluation result of the last rollout -> every rank
-    summary = torch.stack([out[1].sum(0), out[3][-1].float()], 1).contiguous()      # [n, 2] return, final success
-    gathered = torch.empty(world * summary.shape[0], 2, dtype=summary.dtype, device=summary.device)
-    dist.all_gather_into_tensor(gathered, summary)
+    from earl_benchmark_amd import sharding
+    gathered = sharding.gather_summary(sharding.rollout_summary(out[1], out[3]))    # [N_global, 2] return, success
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
@@ -145,10 +144,22 @@ def cpu_baseline(n, T, reward, seconds):
       trials[th] = reps * n * T / dt
   best = max(trials, key=trials.get)
   reps, dt = run(best, seconds)
+  # reference-shaped scalar loop: ONE env object, one step() call per env step from Python (the reference itself
+  # spends >= 49 us per step in its Python/numpy layer alone)
+  orc.set_threads(1)
+  o1 = orc.OracleTabletop(1, reward_type=reward, horizon=T, seed=0)
+  o1.reset()
+  a1 = acts[:, :1].copy()
+  k, t0 = 0, time.perf_counter()
+  while time.perf_counter() - t0 < 1.0:
+    o1.step(a1[k % T])
+    k += 1
+  scalar_rate = k / (time.perf_counter() - t0)
   return {'value': reps * n * T / dt, 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
           'sample': f'{reps} rollouts of {n} envs x {T} steps ({reps * n * T} env-steps, {dt:.1f} s) through oracle/tabletop_oracle.c, '
                     f'OpenMP static over envs, {best} threads (fastest of {sorted(trials)}; host exposes {avail} CPUs)',
-          'single_thread': trials[1], 'by_threads': {str(k): v for k, v in trials.items()}}
+          'single_thread': trials[1], 'by_threads': {str(k): v for k, v in trials.items()},
+          'scalar_python_loop_1env': scalar_rate}
 
 
 def main():

@@ -331,8 +331,8 @@ int check_common(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, in
   if (cfg->goal_change_frequency < 0 || cfg->horizon < 0) return fail(EARL_ERR_ARG, "negative horizon/frequency");
   if (cfg->goal_change_frequency > 0 && (!st->steps_since_goal_change || !st->lifelong_return))
     return fail(EARL_ERR_ARG, "lifelong mode needs steps_since_goal_change and lifelong_return");
-  if (nobj == 3 && (cfg->wide_init || cfg->reset_at_goal || cfg->goal_change_frequency))
-    return fail(EARL_ERR_ARG, "3-object variant: wide_init / reset_at_goal / lifelong are not supported");
+  if (nobj == 3 && (cfg->wide_init || cfg->goal_change_frequency))
+    return fail(EARL_ERR_ARG, "3-object variant: wide_init / lifelong do not exist in the reference class");
   return EARL_OK;
 }
 

@@ -247,6 +247,17 @@ __device__ __forceinline__ int reset_env(Env<NOBJ>& e, const earl_tabletop_cfg& 
     }
     gi = sample_goal(cfg, counter, env, next_goal_idx);
   } else {
+    if (cfg.reset_at_goal) {  // 3obj reset :64-69: goal + U(-0.3, 0.3)^8 (np.random.uniform = low + (high - low) u)
+      gi = sample_goal(cfg, counter, env, nullptr);
+      const double* row = goal_table + (size_t)gi * 10;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const U4 b = draw_block(cfg, counter, env, 1 + j);
+        e.q[2 * j] = row[2 * j] + (-0.3 + 0.6 * u01(b.x, b.y));
+        e.q[2 * j + 1] = row[2 * j + 1] + (-0.3 + 0.6 * u01(b.z, b.w));
+      }
+      return gi;
+    }
     const double init[8] = {0.0, 0.0, 2.5, 0.0, 2.5, -1.0, 2.5, 1.0};  // 3obj initial_states :11
 #pragma unroll
     for (int k = 0; k < 8; ++k) e.q[k] = init[k];

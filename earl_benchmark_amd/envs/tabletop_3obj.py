@@ -21,9 +21,7 @@ class TabletopManipulation(_Base):
 
   def __init__(self, reward_type='dense', reset_at_goal=False, num_envs=1, device='cuda', seed=0, env_offset=0,
                scalar_api=None, auto_reset=False):
-    if reset_at_goal:
-      raise NotImplementedError('3obj reset_at_goal (goal + U(-0.3, 0.3) noise, :64-69) is not built yet')
-    super().__init__(task_list='', reward_type=reward_type, reset_at_goal=False, wide_init_distr=False,
+    super().__init__(task_list='', reward_type=reward_type, reset_at_goal=reset_at_goal, wide_init_distr=False,
                      num_envs=num_envs, device=device, seed=seed, env_offset=env_offset, scalar_api=scalar_api,
                      auto_reset=auto_reset)
 

@@ -117,7 +117,8 @@ int earl_tabletop_valid_init(int32_t n, const double* cand, uint8_t* valid, earl
 
 /* ---- 3-object variant (envs/tabletop_manipulation_3obj.py; not wired into the reference's loader) ----
  * qpos [n,8], attached in {-1,0,1,2} (object index; the reference encodes it as (0,0)/(.5,.5)/(1,1)),
- * goal_table [n_goals,10], obs [n,20].  Same structs; wide_init / reset_at_goal must be 0. */
+ * goal_table [n_goals,10], obs [n,20].  Same structs; reset_at_goal = goal + U(-0.3,0.3)^8 (:64-69); wide_init and
+ * goal_change_frequency must be 0 (the reference class has neither). */
 int earl_tabletop3_step(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const float* act,
                         const earl_tabletop_out* out, earl_stream_t stream);
 int earl_tabletop3_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T,

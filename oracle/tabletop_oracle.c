@@ -327,8 +327,19 @@ static void reset_env3(const earl_tabletop_cfg* cfg, const earl_tabletop_state* 
   static const double init[8] = {0.0, 0.0, 2.5, 0.0, 2.5, -1.0, 2.5, 1.0}; /* 3obj initial_states :11 */
   double* q = st->qpos + 8 * (size_t)i;
   st->attached[i] = -1;
-  for (int k = 0; k < 8; ++k) q[k] = init[k];
-  st->goal_idx[i] = sample_goal(cfg, i, 0); /* np.random.randint(len(goal_list)) :52-56 */
+  if (cfg->reset_at_goal) { /* :64-69: qpos[:8] = goal[:8] + np.random.uniform(-0.3, 0.3, size=8) */
+    st->goal_idx[i] = sample_goal(cfg, i, 0);
+    const double* g = st->goal_table + 10 * (size_t)st->goal_idx[i];
+    for (int j = 0; j < 4; ++j) {
+      uint32_t b[4];
+      draw_block(cfg, i, 1 + (uint32_t)j, b);
+      q[2 * j] = g[2 * j] + (-0.3 + 0.6 * u01(b[0], b[1]));
+      q[2 * j + 1] = g[2 * j + 1] + (-0.3 + 0.6 * u01(b[2], b[3]));
+    }
+  } else {
+    for (int k = 0; k < 8; ++k) q[k] = init[k];
+    st->goal_idx[i] = sample_goal(cfg, i, 0); /* np.random.randint(len(goal_list)) :52-56 */
+  }
   st->steps_since_reset[i] = 0;
   st->num_interventions[i] += 1;
 }

@@ -480,3 +480,18 @@ def test_fused_reset_rollout_equals_reset_then_rollout(hx, orc, mode, impl):
   finally:
     lib.earl_debug_set_rollout_impl(prev)
   assert (o.num_interventions == 2).all() and (o.steps_since_reset == T).all()
+
+
+def test_3obj_reset_at_goal(hx, orc):
+  """3obj reset_at_goal (:64-69): goal + U(-0.3, 0.3)^8 -- HIP == oracle bit for bit, noise inside the box."""
+  n = 3000
+  kw = dict(reset_at_goal=True, nobj=3, seed=21, env_offset=9, horizon=50)
+  o = orc.OracleTabletop(n, **kw)
+  h = hx.HipTabletop(n, **kw)
+  np.testing.assert_array_equal(h.reset(), o.reset())
+  assert_same_state(o, h)
+  d = o.qpos - orc.GOAL_TABLE3[0, :8]
+  assert (np.abs(d) <= 0.3).all() and d.std() > 0.15 and abs(d.mean()) < 0.01
+  m = (np.arange(n) % 3 == 0).astype(np.uint8)
+  np.testing.assert_array_equal(h.reset(mask=m), o.reset(mask=m))
+  assert_same_state(o, h)
