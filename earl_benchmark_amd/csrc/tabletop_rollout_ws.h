@@ -195,7 +195,10 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
   __shared__ uint8_t G[3][K][E];      // rescaled grip > 0
   __shared__ int slow_flag[3][NL];    // chunk contains a NaN action -> exact path (sticky in the compute wave)
   __shared__ float4 R[2][K][E * 3];   // row images: 64 obs rows of 48 B per step
-  __shared__ float S[NL][KL][E * 3];  // loader-private staging: raw actions (coalesced order -> per env)
+  // loader-private staging: raw actions of SQ steps (coalesced order -> per env).  SQ = 1 for 8-step chunks keeps a
+  // workgroup under 80 KiB of LDS, so two of them fit on a CU and overlap each other's pipeline fill and drain.
+  constexpr int SQ = K >= 8 ? 1 : KL;
+  __shared__ float S[NL][SQ][E * 3];
 
   // readfirstlane: tell hipcc the role index is wave-uniform (otherwise every role test becomes exec-mask code)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -425,30 +428,33 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       const int ab = j % 3;
       bool any_nan = false;
 #pragma unroll
-      for (int q = 0; q < KL; ++q) {
-        float* sk = &S[w][q][0];
-        sk[lane] = raw[q][0]; sk[lane + 64] = raw[q][1]; sk[lane + 128] = raw[q][2];
-      }
-      wave_lds_fence();
+      for (int q0 = 0; q0 < KL; q0 += SQ) {
 #pragma unroll
-      for (int q = 0; q < KL; ++q) {
-        const float* sk = &S[w][q][0];   // same wave wrote it: LDS operations of one wave execute in order
-        const float r0 = sk[lane * 3], r1 = sk[lane * 3 + 1], r2 = sk[lane * 3 + 2];
-        const double a0 = rescale_action(r0), a1 = rescale_action(r1);
-        any_nan = any_nan || (r0 != r0) || (r1 != r1);
-        if (j < nch) {
-          if constexpr (NC == 2) {
-            A[ab][q * NL + w][(lane >> 5) * 64 + (lane & 31)] = a0;
-            A[ab][q * NL + w][(lane >> 5) * 64 + 32 + (lane & 31)] = a1;
-          } else {
-            reinterpret_cast<double2*>(&A[ab][q * NL + w][0])[lane] = double2{a0, a1};
-          }
-          G[ab][q * NL + w][lane] = (uint8_t)(r2 >= a.grip_x);   // == rescale_action(r2) > 0 (NaN -> release)
+        for (int q = q0; q < q0 + SQ; ++q) {
+          float* sk = &S[w][q - q0][0];
+          sk[lane] = raw[q][0]; sk[lane + 64] = raw[q][1]; sk[lane + 128] = raw[q][2];
         }
+        wave_lds_fence();
+#pragma unroll
+        for (int q = q0; q < q0 + SQ; ++q) {
+          const float* sk = &S[w][q - q0][0];   // same wave wrote it: LDS operations of one wave execute in order
+          const float r0 = sk[lane * 3], r1 = sk[lane * 3 + 1], r2 = sk[lane * 3 + 2];
+          const double a0 = rescale_action(r0), a1 = rescale_action(r1);
+          any_nan = any_nan || (r0 != r0) || (r1 != r1);
+          if (j < nch) {
+            if constexpr (NC == 2) {
+              A[ab][q * NL + w][(lane >> 5) * 64 + (lane & 31)] = a0;
+              A[ab][q * NL + w][(lane >> 5) * 64 + 32 + (lane & 31)] = a1;
+            } else {
+              reinterpret_cast<double2*>(&A[ab][q * NL + w][0])[lane] = double2{a0, a1};
+            }
+            G[ab][q * NL + w][lane] = (uint8_t)(r2 >= a.grip_x);   // == rescale_action(r2) > 0 (NaN -> release)
+          }
+        }
+        wave_lds_fence();   // the next staging writes must stay behind these reads
       }
       const bool wave_nan = __any(any_nan);
       if (lane == 0 && j < nch) slow_flag[ab][w] = wave_nan ? 1 : 0;
-      wave_lds_fence();   // the next chunk's staging writes must stay behind these reads
     };
     auto run_trip = [&](float (&cur)[LEAD][KL][3], float (&nxt)[LEAD][KL][3], int r) {
 #pragma unroll

@@ -20,14 +20,15 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 n, T = 4096, 200
 os.makedirs(PROF, exist_ok=True)
 
-stats = glob.glob(os.path.join(OUT, 'prof_stats', '*', '*_kernel_stats.csv'))[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+stats = newest(os.path.join(OUT, 'prof_stats', '*', '*_kernel_stats.csv'))
 shutil.copy(stats, os.path.join(PROF, f'{tag}_bench_n{n}_T{T}_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats)))
 kern = [r for r in rows if 'rollout' in r['Name']][0]
 
 pmc = {}
 for name in ('fetch', 'write'):
-  f = glob.glob(os.path.join(OUT, f'prof_{name}', '*', '*_counter_collection.csv'))[0]
+  f = newest(os.path.join(OUT, f'prof_{name}', '*', '*_counter_collection.csv'))
   agg = collections.defaultdict(list)
   for r in csv.DictReader(open(f)):
     agg[(r['Kernel_Name'], r['Counter_Name'])].append(float(r['Counter_Value']))
