@@ -29,6 +29,11 @@ class TabletopOut(C.Structure):
   _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p)]
 
 
+class MotorParams(C.Structure):   # struct earl_motor_params (include/earl_glue.h)
+  _fields_ = [('kp', C.c_double), ('kd', C.c_double), ('voltage', C.c_double), ('viscous_damping', C.c_double),
+              ('torque_control', C.c_int32)]
+
+
 _P = C.POINTER
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/earl_tabletop.h one to one
 SIGNATURES = {
@@ -45,6 +50,12 @@ SIGNATURES = {
     'earl_tabletop3_reward': [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_debug_set_rollout_impl': [C.c_int],
     'earl_debug_read_ws_profile': [C.c_void_p, C.c_int32],
+    # include/earl_glue.h
+    'earl_sawyer_sparse_f64': [C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_sawyer_sparse_f32': [C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_minitaur_leg_to_motor': [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_minitaur_motor_torque': [C.c_int32, _P(MotorParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_minitaur_reward': [C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_version': [],
     'earl_last_error': [],
     'earl_device_count': [],

@@ -1,0 +1,135 @@
+// glue.hip -- HIP kernels + C ABI of include/earl_glue.h: the pure-numpy glue of the physics-backed envs
+// (Sawyer sparse success rule, minitaur leg model / DC-motor model / reward).  One lane per row, fp64 like the
+// reference, -ffp-contract=off (explicit fma() only where numpy's BLAS dot fuses).  Elementwise, launch-bound at the
+// sizes of the BASELINE configs; they exist so that the glue around a future rigid-body stepper is already at parity.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "../../include/earl_glue.h"
+
+namespace {
+constexpr int kB = 256;
+
+__device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+template <typename T>
+__global__ __launch_bounds__(kB) void sawyer_sparse_kernel(int n, const T* __restrict__ obs, double radius,
+                                                           float* __restrict__ reward, uint8_t* __restrict__ success) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const T* o = obs + (size_t)i * 14;
+  bool s;
+  if constexpr (sizeof(T) == 8) {   // sawyer_door.py:173-177: float64 obs, numpy dot = FMA chain
+    const double d0 = o[4] - o[11], d1 = o[5] - o[12], d2 = o[6] - o[13];
+    s = sqrt(fma(d2, d2, fma(d1, d1, d0 * d0))) <= radius;
+  } else {                          // float32 rows (demonstrations): products rounded to float, summed in double
+    const float d0 = o[4] - o[11], d1 = o[5] - o[12], d2 = o[6] - o[13];
+    const double dot = ((double)(d0 * d0) + (double)(d1 * d1)) + (double)(d2 * d2);
+    s = (double)sqrtf((float)dot) <= radius;
+  }
+  if (success) success[i] = s;
+  if (reward) reward[i] = s ? 1.0f : 0.0f;
+}
+
+// minitaur.py:434-457
+__global__ __launch_bounds__(kB) void leg_to_motor_kernel(int n, const double* __restrict__ action, double* __restrict__ out) {
+  const int t = blockIdx.x * kB + threadIdx.x;   // one lane per motor
+  if (t >= n * 8) return;
+  const int r = t >> 3, i = t & 7, idx = i >> 1;
+  const double pi = 3.141592653589793, quater_pi = pi / 4;
+  const double* a = action + (size_t)r * 8;
+  const double fb = (-1 * quater_pi) * (a[idx + 4] + 1.5);
+  double ext = ((i & 1) ? -1.0 : 1.0) * quater_pi * a[idx];
+  if (i >= 4) ext = -ext;
+  out[t] = (pi + fb) + ext;
+}
+
+__device__ __forceinline__ double interp7(double x) {   // np.interp on motor.py's current/torque table
+  const double xp[7] = {0, 10, 20, 30, 40, 50, 60}, fp[7] = {0, 1, 1.9, 2.45, 3.0, 3.25, 3.5};
+  if (x >= 60.0) return 3.5;
+  double x0 = 0, f0 = 0, x1 = 10, f1 = 1;
+#pragma unroll
+  for (int j = 1; j < 6; ++j)
+    if (x >= xp[j]) { x0 = xp[j]; f0 = fp[j]; x1 = xp[j + 1]; f1 = fp[j + 1]; }
+  const double slope = (f1 - f0) / (x1 - x0);
+  return slope * (x - x0) + f0;
+}
+// motor.py:49-94
+__global__ __launch_bounds__(kB) void motor_kernel(int m, earl_motor_params p, const double* __restrict__ command,
+                                                   const double* __restrict__ angle, const double* __restrict__ velocity,
+                                                   double* __restrict__ actual, double* __restrict__ observed) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= m) return;
+  const double R = 0.186, Kt = 0.0954;
+  double pwm = p.torque_control ? command[i] : (-p.kp * (angle[i] - command[i]) - p.kd * velocity[i]);
+  pwm = clipd(pwm, -1.0, 1.0);
+  const double obs = clipd(Kt * (pwm * p.voltage / R), -5.7, 5.7);
+  const double vnet = clipd(pwm * p.voltage - (Kt + p.viscous_damping) * velocity[i], -50.0, 50.0);
+  const double current = vnet / R;
+  const double sign = current > 0 ? 1.0 : (current < 0 ? -1.0 : (current == 0 ? 0.0 : current));
+  if (actual) actual[i] = sign * interp7(fabs(current));
+  if (observed) observed[i] = obs;
+}
+
+// minitaur_gym_env.py:529-535, :495-503
+__global__ __launch_bounds__(kB) void minitaur_reward_kernel(int n, const double* __restrict__ obs, double dw, double ew,
+                                                             double dt, double* __restrict__ reward,
+                                                             uint8_t* __restrict__ success) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const double* o = obs + (size_t)i * 32;
+  const double xd = o[28] - o[30], yd = o[29] - o[31];
+  const double distance_reward = -fabs(xd) - fabs(yd);
+  double dot = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dot = fma(o[16 + k], o[8 + k], dot);
+  if (reward) reward[i] = dw * distance_reward - ew * (fabs(dot) * dt);
+  if (success) success[i] = sqrt(xd * xd + yd * yd) < 0.1;
+}
+
+int done(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "earl_glue: %s: %s\n", what, hipGetErrorString(e));
+    return EARL_ERR_LAUNCH;
+  }
+  return EARL_OK;
+}
+inline unsigned blocks(long long n) { return (unsigned)((n + kB - 1) / kB); }
+}  // namespace
+
+extern "C" {
+int earl_sawyer_sparse_f64(int32_t n, const double* obs, double radius, float* reward, uint8_t* success, earl_stream_t s) {
+  if (n < 0 || !obs) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  sawyer_sparse_kernel<double><<<blocks(n), kB, 0, (hipStream_t)s>>>(n, obs, radius, reward, success);
+  return done("sawyer_sparse_f64");
+}
+int earl_sawyer_sparse_f32(int32_t n, const float* obs, double radius, float* reward, uint8_t* success, earl_stream_t s) {
+  if (n < 0 || !obs) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  sawyer_sparse_kernel<float><<<blocks(n), kB, 0, (hipStream_t)s>>>(n, obs, radius, reward, success);
+  return done("sawyer_sparse_f32");
+}
+int earl_minitaur_leg_to_motor(int32_t n, const double* action, double* motor_angle, earl_stream_t s) {
+  if (n < 0 || !action || !motor_angle) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  leg_to_motor_kernel<<<blocks((long long)n * 8), kB, 0, (hipStream_t)s>>>(n, action, motor_angle);
+  return done("leg_to_motor");
+}
+int earl_minitaur_motor_torque(int32_t m, const earl_motor_params* p, const double* command, const double* angle,
+                               const double* velocity, double* actual_torque, double* observed_torque, earl_stream_t s) {
+  if (m < 0 || !p || !command || !angle || !velocity) return EARL_ERR_ARG;
+  if (m == 0) return EARL_OK;
+  motor_kernel<<<blocks(m), kB, 0, (hipStream_t)s>>>(m, *p, command, angle, velocity, actual_torque, observed_torque);
+  return done("motor_torque");
+}
+int earl_minitaur_reward(int32_t n, const double* obs, double distance_weight, double energy_weight, double time_step,
+                         double* reward, uint8_t* success, earl_stream_t s) {
+  if (n < 0 || !obs) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  minitaur_reward_kernel<<<blocks(n), kB, 0, (hipStream_t)s>>>(n, obs, distance_weight, energy_weight, time_step, reward, success);
+  return done("minitaur_reward");
+}
+}

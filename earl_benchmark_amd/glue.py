@@ -1,0 +1,84 @@
+"""Batched (GPU) versions of the pure-numpy glue of EARL's physics-backed envs -- include/earl_glue.h.
+
+The dynamics of sawyer_door / sawyer_peg / minitaur are MuJoCo / Bullet and are NOT built; these are
+the functions the reference itself evaluates in numpy around them, at parity with the reference
+(tests/test_glue.py, tests/test_glue_gpu.py):
+  sawyer_sparse_reward  SawyerDoorV2 / SawyerPegV2 .is_successful and the sparse compute_reward branch
+  leg_to_motor          Minitaur.ConvertFromLegModel
+  motor_torque          MotorModel.convert_to_torque
+  minitaur_reward       GoalConditionedMinitaurBulletEnv.compute_reward / is_successful
+All take and return torch tensors on a HIP device.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+
+SAWYER_RADIUS = {'sawyer_door': 0.02, 'sawyer_peg': 0.05}   # sawyer_door.py:177, sawyer_peg.py:63 (TARGET_RADIUS)
+
+
+def _stream(t):
+  return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _cuda(t, dtype=None):
+  t = torch.as_tensor(t)
+  if not t.is_cuda:
+    raise _abi.EarlHipError('glue functions run on MI355X only: pass tensors on a HIP device')
+  if dtype is not None and t.dtype != dtype:
+    t = t.to(dtype)
+  return t.contiguous()
+
+
+def sawyer_sparse_reward(obs, env_name='sawyer_door', radius=None):
+  """obs [n, 14] float64 (env) or float32 (demonstration layout) -> (reward [n] float32, success [n] bool)."""
+  lib = _abi.load()
+  obs = _cuda(obs)
+  if obs.dtype not in (torch.float32, torch.float64) or obs.ndim != 2 or obs.shape[1] != 14:
+    raise ValueError('obs must be [n, 14] float32/float64')
+  r = SAWYER_RADIUS[env_name] if radius is None else float(radius)
+  n = obs.shape[0]
+  rew = torch.empty(n, dtype=torch.float32, device=obs.device)
+  suc = torch.empty(n, dtype=torch.bool, device=obs.device)
+  fn = lib.earl_sawyer_sparse_f64 if obs.dtype == torch.float64 else lib.earl_sawyer_sparse_f32
+  with torch.cuda.device(obs.device):
+    _abi.check(fn(n, obs.data_ptr(), r, rew.data_ptr(), suc.data_ptr(), _stream(obs)), 'sawyer_sparse')
+  return rew, suc
+
+
+def leg_to_motor(action):
+  """action [n, 8] -> desired motor angles [n, 8] float64."""
+  lib = _abi.load()
+  a = _cuda(action, torch.float64).reshape(-1, 8)
+  out = torch.empty_like(a)
+  with torch.cuda.device(a.device):
+    _abi.check(lib.earl_minitaur_leg_to_motor(a.shape[0], a.data_ptr(), out.data_ptr(), _stream(a)), 'leg_to_motor')
+  return out
+
+
+def motor_torque(command, angle, velocity, kp=1.2, kd=0.0, voltage=16.0, viscous_damping=0.0, torque_control=False):
+  """-> (actual_torque, observed_torque), same shape as `command` (float64)."""
+  lib = _abi.load()
+  c, a, v = _cuda(command, torch.float64), _cuda(angle, torch.float64), _cuda(velocity, torch.float64)
+  if not (c.shape == a.shape == v.shape):
+    raise ValueError('command, angle, velocity must have the same shape')
+  act, obs = torch.empty_like(c), torch.empty_like(c)
+  p = _abi.MotorParams(kp, kd, voltage, viscous_damping, int(bool(torque_control)))
+  with torch.cuda.device(c.device):
+    _abi.check(lib.earl_minitaur_motor_torque(c.numel(), C.byref(p), c.data_ptr(), a.data_ptr(), v.data_ptr(),
+                                              act.data_ptr(), obs.data_ptr(), _stream(c)), 'motor_torque')
+  return act, obs
+
+
+def minitaur_reward(obs, distance_weight=2.0, energy_weight=0.005, time_step=0.01):
+  """obs [n, 32] -> (reward [n] float64, success [n] bool)."""
+  lib = _abi.load()
+  o = _cuda(obs, torch.float64).reshape(-1, 32)
+  n = o.shape[0]
+  rew = torch.empty(n, dtype=torch.float64, device=o.device)
+  suc = torch.empty(n, dtype=torch.bool, device=o.device)
+  with torch.cuda.device(o.device):
+    _abi.check(lib.earl_minitaur_reward(n, o.data_ptr(), distance_weight, energy_weight, time_step, rew.data_ptr(),
+                                        suc.data_ptr(), _stream(o)), 'minitaur_reward')
+  return rew, suc

@@ -1,0 +1,52 @@
+/* earl_glue.h -- C ABI of the pure-numpy glue of EARL's physics-backed envs.
+ *
+ * The DYNAMICS of sawyer_door / sawyer_peg / minitaur live in MuJoCo / Bullet and are out of scope;
+ * what the reference itself computes in numpy around them is restated here for batches in HBM, with the same
+ * conventions as earl_tabletop.h (device pointers, caller's stream, negative error codes, no allocation):
+ *
+ *   earl_sawyer_sparse_*      SawyerDoorV2.is_successful (envs/sawyer_door.py:173-177, radius 0.02) and
+ *                             SawyerPegV2.is_successful (envs/sawyer_peg.py:301-305, radius 0.05), and the sparse branch
+ *                             of compute_reward (:168-169 / :296-297): ||obs[4:7] - obs[11:14]|| <= radius
+ *   earl_minitaur_leg_to_motor   Minitaur.ConvertFromLegModel (envs/minitaur.py:434-457)
+ *   earl_minitaur_motor_torque   MotorModel.convert_to_torque (envs/motor.py:49-94)
+ *   earl_minitaur_reward         GoalConditionedMinitaurBulletEnv.compute_reward / is_successful
+ *                                (envs/minitaur_gym_env.py:529-535, :495-503)
+ * All fp64 like the reference's numpy code; tested bit-exact against goldens recorded from the reference's own
+ * functions (tests/golden/make_golden.py: gen_glue) and against the 2,910 Sawyer demonstration rows.
+ */
+#ifndef EARL_GLUE_H
+#define EARL_GLUE_H
+#include <stdint.h>
+
+#include "earl_tabletop.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* obs [n,14] float64 (what the env holds): success [n] 0/1, reward [n] = (float)success; either may be NULL */
+int earl_sawyer_sparse_f64(int32_t n, const double* obs, double radius, float* reward, uint8_t* success, earl_stream_t stream);
+/* obs [n,14] float32 (the demonstration layout): numpy float32 semantics of the same expression */
+int earl_sawyer_sparse_f32(int32_t n, const float* obs, double radius, float* reward, uint8_t* success, earl_stream_t stream);
+
+/* action [n,8] (4 extension + 4 swing components of the leg model) -> desired motor angles [n,8] */
+int earl_minitaur_leg_to_motor(int32_t n, const double* action, double* motor_angle, earl_stream_t stream);
+
+typedef struct earl_motor_params {
+  double kp, kd;             /* MotorModel(kp=1.2, kd=0) */
+  double voltage;            /* MOTOR_VOLTAGE 16.0 (set_voltage) */
+  double viscous_damping;    /* MOTOR_VISCOUS_DAMPING 0 (set_viscous_damping) */
+  int32_t torque_control;    /* torque_control_enabled: command is the pwm itself */
+} earl_motor_params;
+/* m motors (any shape flattened): command, angle, velocity -> actual_torque, observed_torque */
+int earl_minitaur_motor_torque(int32_t m, const earl_motor_params* p, const double* command, const double* angle,
+                               const double* velocity, double* actual_torque, double* observed_torque, earl_stream_t stream);
+
+/* obs [n,32] -> reward [n] (distance_weight * distance_reward - energy_weight * energy_reward), success [n] 0/1 */
+int earl_minitaur_reward(int32_t n, const double* obs, double distance_weight, double energy_weight, double time_step,
+                         double* reward, uint8_t* success, earl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

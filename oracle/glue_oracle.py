@@ -1,0 +1,44 @@
+"""numpy/ctypes front-end of oracle/glue_oracle.c (TEST INFRASTRUCTURE, NOT PRODUCT)."""
+import ctypes as C
+
+import numpy as np
+
+from oracle.tabletop_oracle import lib, _p
+
+
+class MotorParams(C.Structure):
+  _fields_ = [('kp', C.c_double), ('kd', C.c_double), ('voltage', C.c_double), ('viscous_damping', C.c_double),
+              ('torque_control', C.c_int32)]
+
+
+def sawyer_sparse(obs, radius):
+  obs = np.ascontiguousarray(obs)
+  n = len(obs)
+  r, s = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+  fn = lib().oracle_sawyer_sparse_f64 if obs.dtype == np.float64 else lib().oracle_sawyer_sparse_f32
+  assert obs.dtype in (np.float64, np.float32) and obs.shape == (n, 14)
+  fn(C.c_int32(n), _p(obs), C.c_double(radius), _p(r), _p(s))
+  return r, s
+
+
+def leg_to_motor(action):
+  a = np.ascontiguousarray(action, np.float64)
+  out = np.zeros_like(a)
+  lib().oracle_minitaur_leg_to_motor(C.c_int32(len(a)), _p(a), _p(out))
+  return out
+
+
+def motor_torque(command, angle, velocity, kp=1.2, kd=0.0, voltage=16.0, viscous_damping=0.0, torque_control=False):
+  c, a, v = (np.ascontiguousarray(x, np.float64) for x in (command, angle, velocity))
+  act, obs = np.zeros_like(c), np.zeros_like(c)
+  p = MotorParams(kp, kd, voltage, viscous_damping, int(torque_control))
+  lib().oracle_minitaur_motor_torque(C.c_int32(c.size), C.byref(p), _p(c), _p(a), _p(v), _p(act), _p(obs))
+  return act, obs
+
+
+def minitaur_reward(obs, distance_weight=2.0, energy_weight=0.005, time_step=0.01):
+  o = np.ascontiguousarray(obs, np.float64)
+  r, s = np.zeros(len(o)), np.zeros(len(o), np.uint8)
+  lib().oracle_minitaur_reward(C.c_int32(len(o)), _p(o), C.c_double(distance_weight), C.c_double(energy_weight),
+                               C.c_double(time_step), _p(r), _p(s))
+  return r, s

@@ -18,9 +18,9 @@ _lib = None
 
 
 def build(force=False):
-  src = os.path.join(HERE, 'tabletop_oracle.c')
-  hdr = os.path.join(HERE, '..', 'include', 'earl_tabletop.h')
-  stale = (not os.path.exists(SO)) or any(os.path.getmtime(p) > os.path.getmtime(SO) for p in (src, hdr))
+  deps = [os.path.join(HERE, 'tabletop_oracle.c'), os.path.join(HERE, 'glue_oracle.c'),
+          os.path.join(HERE, '..', 'include', 'earl_tabletop.h'), os.path.join(HERE, '..', 'include', 'earl_glue.h')]
+  stale = (not os.path.exists(SO)) or any(os.path.getmtime(p) > os.path.getmtime(SO) for p in deps)
   if force or stale:
     subprocess.run(['make', '-C', HERE, '-B', 'libearl_oracle.so'], check=True, capture_output=True)
   return SO

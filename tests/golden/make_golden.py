@@ -399,6 +399,76 @@ def gen_3obj(rng, m=8192, T=200):
   return o
 
 
+# --------------------------------------------------------------------------------------
+# H. glue of the physics-backed envs that is pure numpy in the reference (the dynamics themselves are MuJoCo / Bullet)
+# --------------------------------------------------------------------------------------
+def _method(relpath, cls, name):
+  """Compile ONE method of a reference class whose module cannot be imported here (pybullet / metaworld / mujoco_py
+  missing) and return it as a plain function; numpy is the only global it gets."""
+  import ast
+  import math
+  src = open(os.path.join(REF, 'earl_benchmark', relpath)).read()
+  for node in ast.parse(src).body:
+    if isinstance(node, ast.ClassDef) and node.name == cls:
+      for item in node.body:
+        if isinstance(item, ast.FunctionDef) and item.name == name:
+          item.decorator_list = []
+          ns = {'np': np, 'math': math}
+          exec(compile(ast.Module([item], []), relpath, 'exec'), ns)
+          return ns[name]
+  raise KeyError((relpath, cls, name))
+
+
+def gen_glue(rng, m=1024):
+  import types
+  from earl_benchmark.envs import minitaur as ref_minitaur   # imports only numpy + motor
+  from earl_benchmark.envs import motor as ref_motor
+  out = {}
+  # -- Sawyer sparse success rule (sawyer_door.py:173-177 radius 0.02, sawyer_peg.py:301-305 radius 0.05) on f64 obs
+  door_succ = _method('envs/sawyer_door.py', 'SawyerDoorV2', 'is_successful')
+  peg_succ = _method('envs/sawyer_peg.py', 'SawyerPegV2', 'is_successful')
+  obs = rng.uniform(-0.5, 1.0, size=(m, 14))
+  r = np.abs(rng.normal(size=m)) * 0.04
+  d = rng.normal(size=(m, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+  obs[:, 11:14] = obs[:, 4:7] + d * r[:, None]               # straddles both radii
+  peg_self = types.SimpleNamespace(TARGET_RADIUS=0.05)
+  out['sawyer_obs'] = obs
+  out['sawyer_door_success'] = np.array([bool(door_succ(None, obs=o)) for o in obs])
+  out['sawyer_peg_success'] = np.array([bool(peg_succ(peg_self, obs=o)) for o in obs])
+  out['sawyer_norm'] = np.array([np.linalg.norm(o[4:7] - o[11:14]) for o in obs])
+  # -- minitaur: leg model -> motor angles (minitaur.py:434-457)
+  fake = types.SimpleNamespace(num_motors=8)
+  acts = rng.uniform(-1, 1, size=(m, 8))
+  out['leg_actions'] = acts
+  out['leg_motor_angles'] = np.stack([ref_minitaur.Minitaur.ConvertFromLegModel(fake, a.copy()) for a in acts])
+  acts32 = acts.astype(np.float32)   # what a float32 policy hands over: the result array inherits float32
+  out['leg_motor_angles_f32in'] = np.stack([ref_minitaur.Minitaur.ConvertFromLegModel(fake, a.copy()) for a in acts32])
+  # -- minitaur: DC motor model (motor.py:49-94), position control (default kp 1.2, kd 0) and torque control
+  cmd = rng.uniform(-2, 4, size=(m, 8)); ang = rng.uniform(-2, 4, size=(m, 8)); vel = rng.uniform(-120, 120, size=(m, 8))
+  cmd[:64] = ang[:64]; vel[:32] = 0.0                         # zero pwm / zero current corner
+  vel[64:128] = rng.uniform(-600, 600, size=(64, 8))          # diode clipping at 50 V
+  out.update(motor_cmd=cmd, motor_angle=ang, motor_vel=vel)
+  for tag, kw, visc, volt in (('pos', dict(kp=1.2, kd=0), 0.0, 16.0), ('pd', dict(kp=0.9, kd=0.02), 0.0013, 14.5),
+                              ('torque', dict(torque_control_enabled=True), 0.0, 16.0)):
+    mm = ref_motor.MotorModel(**kw)
+    mm.set_viscous_damping(visc); mm.set_voltage(volt)
+    c = np.clip(cmd, -1.5, 1.5) if tag == 'torque' else cmd
+    act, obsd = zip(*[mm.convert_to_torque(c[i], ang[i], vel[i]) for i in range(m)])
+    out[f'motor_{tag}_actual'] = np.stack(act); out[f'motor_{tag}_observed'] = np.stack(obsd)
+    out[f'motor_{tag}_params'] = np.array([kw.get('kp', 1.2), kw.get('kd', 0.0), float(kw.get('torque_control_enabled', False)), volt, visc])
+  out['motor_torque_cmd'] = np.clip(cmd, -1.5, 1.5)
+  # -- minitaur: compute_reward(obs) (minitaur_gym_env.py:529-535) and is_successful(obs) (:495-503) on 32-d observations
+  rew = _method('envs/minitaur_gym_env.py', 'GoalConditionedMinitaurBulletEnv', 'compute_reward')
+  suc = _method('envs/minitaur_gym_env.py', 'GoalConditionedMinitaurBulletEnv', 'is_successful')
+  envself = types.SimpleNamespace(_distance_weight=2, _energy_weight=0.005, _time_step=0.01)   # :458, :70, :126
+  mobs = rng.normal(size=(m, 32))
+  mobs[:, 28:30] = mobs[:, 30:32] + rng.normal(size=(m, 2)) * 0.08
+  out['minitaur_obs'] = mobs
+  out['minitaur_reward'] = np.array([rew(envself, list(o)) for o in mobs])
+  out['minitaur_success'] = np.array([suc(envself, list(o)) for o in mobs])
+  return out
+
+
 def main():
   rng = np.random.default_rng(20221002)
   random.seed(7)
@@ -410,7 +480,8 @@ def main():
           ('tabletop_lifelong', lambda: gen_lifelong(rng)),
           ('tabletop_demo_replay', gen_demos),
           ('loader_tables', gen_loader_tables),
-          ('tabletop3_onestep', lambda: gen_3obj(rng))]
+          ('tabletop3_onestep', lambda: gen_3obj(rng)),
+          ('physics_glue', lambda: gen_glue(rng))]
   for name, fn in jobs:
     data = fn()
     path = os.path.join(HERE, name + '.npz')

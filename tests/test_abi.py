@@ -10,17 +10,18 @@ from conftest import REPO, has_gpu
 from earl_benchmark_amd import _abi
 
 HEADER = os.path.join(REPO, 'include', 'earl_tabletop.h')
+HEADERS = [HEADER, os.path.join(REPO, 'include', 'earl_glue.h')]
 
 
 def declared_functions():
-  src = open(HEADER).read()
+  src = ''.join(open(h).read() for h in HEADERS)
   src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
   return re.findall(r'^\s*(?:int|const char\*)\s+(earl_\w+)\s*\(', src, flags=re.M)
 
 
 def test_header_declares_what_the_binding_expects():
   names = declared_functions()
-  assert len(names) == len(set(names)) >= 13
+  assert len(names) == len(set(names)) >= 20
   assert set(names) == set(_abi.SIGNATURES), set(names) ^ set(_abi.SIGNATURES)
 
 
