@@ -394,10 +394,11 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 10: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 8, 3); break;
           case 11: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 8, 3); break;
           case 12: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 4, 6); break;
-          case 13: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 2, 4, 6); break;
+          case 13: EARL_WS(EARL_REWARD_SPARSE, 1, 4, 4, 8, 3); break;
           case 14: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 2, 4, 6); break;
           case 8: EARL_WS(EARL_REWARD_SPARSE, 1, 1, 1, 4, 6); break;
-          case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 2, 4, 8, 3, true><<<grid, 64 * 8, 0, hs>>>(w); break;  // stamps
+          case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 4, 8, 3, true><<<grid, 64 * 10, 0, hs>>>(w); break;  // stamps
+          case 19: rollout_ws_kernel<EARL_REWARD_SPARSE, 1, 4, 4, 8, 3, true><<<grid, 64 * 9, 0, hs>>>(w); break;  // stamps
           default:
             // 2 x/y-split compute waves + 4 loaders + 4 storers, 8-step chunks: fastest of the variants above at
             // every N measured (tools/tune_rollout.py; profiles/r01_tune_rollout.txt)

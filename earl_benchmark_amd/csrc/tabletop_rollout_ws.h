@@ -110,6 +110,32 @@ __device__ __forceinline__ void ws_step(double& fx, double& fy, double& ox, doub
   }
 }
 
+// Fast step in the form the hardware likes.  Measured on MI355X (tools/ubench/cu_issue*.hip), ticks per instruction of
+// ONE wave / instructions per tick a whole CU sustains:   VALU with VGPR or inline operands 5.3 / 1.5-1.8;
+// ANY instruction that reads or writes an SGPR (SALU, v_cmp, v_cndmask with a mask, v_readfirstlane, a VALU with a
+// scalar source operand such as the clip bounds) 8.3 / 1.0 -- the scalar side is one shared pipe per CU;
+// v_cvt_f32_f64 8.3; v_permlane32_swap 20.  So this version keeps every operand in VGPRs: predicates are int lane
+// masks built from sign bits (d2 < thr  <=>  sign(d2 - thr), exact for non-NaN), selections are and / bfi on the halves
+// of the doubles, the clip bounds and the threshold are pinned in VGPRs.  Same arithmetic, bit for bit.
+struct WsConst { double lo, hi, thr; int nz; };   // clip bounds, attach threshold, high word of -0.0
+__device__ __forceinline__ void ws_step_v(double& fx, double& fy, double& ox, double& oy, double& oxl, double& oyl,
+                                          int& att, double a0, double a1, int grip, const WsConst& k) {
+  const double dx = fx - oxl, dy = fy - oyl;
+  const int near = __double2hiint(fma(dy, dy, dx * dx) - k.thr) >> 31;   // all ones iff d2 < thr
+  att = grip & (att | near);
+  oxl = ox;
+  oyl = oy;
+  const double nfx = fmin(fmax(fx + a0, k.lo), k.hi), nfy = fmin(fmax(fy + a1, k.lo), k.hi);
+  const double ddx = nfx - fx, ddy = nfy - fy;
+  // att ? dd : -0.0, on the two halves of the double
+  const double sx = __hiloint2double((att & __double2hiint(ddx)) | (~att & k.nz), att & __double2loint(ddx));
+  const double sy = __hiloint2double((att & __double2hiint(ddy)) | (~att & k.nz), att & __double2loint(ddy));
+  ox = fmin(fmax(ox + sx, k.lo), k.hi);
+  oy = fmin(fmax(oy + sy, k.lo), k.hi);
+  fx = nfx;
+  fy = nfy;
+}
+
 // The same step with the two coordinates of an env in two LANES (l: x, l+32: y) of a 32-env wave: every vector
 // instruction advances x and y at once, which halves the instructions a wave issues per step -- and a lone wave
 // issues one VALU per ~5.6 cycles (10.3 if it depends on the previous one; tools/ubench/issue.hip), fp32 and fp64
@@ -333,6 +359,9 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       }
     }
     double oxl = ox, oyl = oy;
+    int attm = att ? -1 : 0;            // lane mask form of `att` for the VGPR-only fast step
+    WsConst kc{-2.8, 2.8, a.th.grasp_d2, (int)0x80000000};
+    asm volatile("" : "+v"(kc.lo), "+v"(kc.hi), "+v"(kc.thr), "+v"(kc.nz));   // keep them in VGPRs (a scalar operand costs 8.3 vs 5.3)
     // exact path if the state holds a NaN or an object outside the arena (sticky, wave-uniform)
     bool slow = __any(!(fabs(fx) <= 1e300) || !(fabs(fy) <= 1e300) || !(fabs(ox) <= 2.8) || !(fabs(oy) <= 2.8));
     unsigned long long p_read = 0, p_comp = 0, p_bar = 0;
@@ -343,7 +372,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
     // Chunk c+1 is already published when chunk c starts (the loaders run one barrier interval ahead and the ring
     // is 3 deep), so its actions are fetched from LDS while chunk c is being computed: no LDS latency per chunk.
     double2 av[K], nv[K];
-    uint8_t gv[K], ng[K];
+    int gv[K], ng[K];     // grip as a lane mask: the loaders store 0xFF / 0x00, read back sign-extended
     int nslow = 0;
     auto fetch = [&](int c) {
       const int ab = c % 3;
@@ -351,7 +380,10 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
 #pragma unroll
       for (int w = 0; w < NL; ++w) nslow |= slow_flag[ab][w];
 #pragma unroll
-      for (int k = 0; k < K; ++k) { nv[k] = reinterpret_cast<const double2*>(&A[ab][k][0])[lane]; ng[k] = G[ab][k][lane]; }
+      for (int k = 0; k < K; ++k) {
+        nv[k] = reinterpret_cast<const double2*>(&A[ab][k][0])[lane];
+        ng[k] = reinterpret_cast<const int8_t*>(&G[ab][k][0])[lane];
+      }
     };
     fetch(0);
     for (int c = 0; c < nch; ++c) {
@@ -367,10 +399,16 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
         for (int k = 0; k < K; ++k) {
           if constexpr (!decltype(full)::value)
             if (c * K + k >= T) break;      // tail chunk only (wave-uniform)
-          ws_step<decltype(exact)::value>(fx, fy, ox, oy, oxl, oyl, att, av[k].x, av[k].y, gv[k] != 0, a.th);
+          if constexpr (decltype(exact)::value) {
+            bool attb = attm != 0;
+            ws_step<true>(fx, fy, ox, oy, oxl, oyl, attb, av[k].x, av[k].y, gv[k] != 0, a.th);
+            attm = attb ? -1 : 0;
+          } else {
+            ws_step_v(fx, fy, ox, oy, oxl, oyl, attm, av[k].x, av[k].y, gv[k], kc);
+          }
           float4* row = &R[rb][k][lane * 3];
           row[0] = float4{(float)fx, (float)fy, (float)ox, (float)oy};
-          const float flag = att ? 0.0f : -1.0f;
+          const float flag = __int_as_float(~attm & (int)0xBF800000);   // attached ? 0.0f : -1.0f
           *reinterpret_cast<float2*>(&row[1]) = float2{flag, flag};
         }
       };
@@ -395,7 +433,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       double2* q2 = reinterpret_cast<double2*>(a.qpos + (size_t)i * 4);
       q2[0] = double2{fx, fy};
       q2[1] = double2{ox, oy};
-      a.attached[i] = att ? 0 : -1;
+      a.attached[i] = attm ? 0 : -1;
       a.steps_since_reset[i] = (a.reset_first ? 0 : a.steps_since_reset[i]) + T;
     }
    }
@@ -448,7 +486,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
             } else {
               reinterpret_cast<double2*>(&A[ab][q * NL + w][0])[lane] = double2{a0, a1};
             }
-            G[ab][q * NL + w][lane] = (uint8_t)(r2 >= a.grip_x);   // == rescale_action(r2) > 0 (NaN -> release)
+            G[ab][q * NL + w][lane] = (uint8_t)(r2 >= a.grip_x ? 0xFF : 0);   // == rescale_action(r2) > 0 (NaN -> release)
           }
         }
         wave_lds_fence();   // the next staging writes must stay behind these reads
@@ -541,16 +579,53 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
         }
       }
     };
+    // Fast form for whole chunks of a full workgroup (K % NS == 0): this storer owns steps s, s+NS, .. of the chunk.
+    // All LDS reads of those steps are issued first (one round trip instead of two per step), then the HBM stores and
+    // the success arithmetic run on registers.
+    constexpr int Q = (K % NS == 0) ? K / NS : 0;
+    auto store_chunk_fast = [&](int c) {
+      const int rb = c & 1;
+      float4 p[Q > 0 ? Q : 1], v0[Q > 0 ? Q : 1], v1[Q > 0 ? Q : 1], v2[Q > 0 ? Q : 1];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float4* src = &R[rb][s + NS * q][0];
+        v0[q] = src[lane]; v1[q] = src[lane + 64]; v2[q] = src[lane + 128];
+        p[q] = src[lane * 3];
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int t = c * K + s + NS * q;
+        const size_t row0 = (size_t)t * n + i0;
+        float4* dst = reinterpret_cast<float4*>(a.obs + row0 * 12);
+        dst[lane] = v0[q]; dst[lane + 64] = v1[q]; dst[lane + 128] = v2[q];
+        const float o[12] = {p[q].x, p[q].y, p[q].z, p[q].w, 0.f, 0.f, g[0], g[1], g[2], g[3], g[4], g[5]};
+        const bool succ = success1(o, a.wide, a.th);
+        float rew;
+        if constexpr (RT == EARL_REWARD_SPARSE) rew = succ ? 1.0f : 0.0f;
+        else rew = (float)dense1(o);
+        a.reward[row0 + lane] = rew;
+        const unsigned long long ms = __ballot(succ), md = __ballot(t >= t_done);
+        if (lane < 16) {
+          const uint32_t ns = (uint32_t)(ms >> (4 * lane)) & 0xFu, nd = (uint32_t)(md >> (4 * lane)) & 0xFu;
+          reinterpret_cast<uint32_t*>(a.success + row0)[lane] = (ns * 0x00204081u) & 0x01010101u;
+          reinterpret_cast<uint32_t*>(a.done + row0)[lane] = (nd * 0x00204081u) & 0x01010101u;
+        }
+      }
+    };
+    auto store = [&](int c) {
+      if (Q > 0 && full && (c + 1) * K <= T) store_chunk_fast(c);
+      else store_chunk(c);
+    };
     if constexpr (PROF) p_t0 = ws_clock();
     __syncthreads();
     if constexpr (PROF) p_x = ws_clock();
     for (int c = 0; c < nch; ++c) {
-      if (c >= 1) store_chunk(c - 1);
+      if (c >= 1) store(c - 1);
       WS_STAMP(p_st)
       __syncthreads();
       WS_STAMP(p_bar)
     }
-    store_chunk(nch - 1);
+    store(nch - 1);
     if constexpr (PROF) {
       if (lane == 0 && blockIdx.x < 64 && s == 0) {
         unsigned long long* o = g_ws_prof + blockIdx.x * 16;

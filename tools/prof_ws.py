@@ -11,7 +11,7 @@ for n in [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['64
   L = eb.EARLEnvs('tabletop_manipulation', reward_type='sparse', num_envs=n, eval_horizon=T, scalar_api=False)
   _, env = L.get_envs()
   acts = (torch.rand(T, n, 3, device='cuda') * 2 - 1).contiguous()
-  lib.earl_debug_set_rollout_impl(9)
+  lib.earl_debug_set_rollout_impl(int(os.environ.get('PROF_IMPL', '9')))
   for _ in range(5):
     env.reset(); env.rollout(acts)
   torch.cuda.synchronize()

@@ -1,0 +1,42 @@
+// CU-level issue capacity (gfx950): W waves in ONE workgroup (one CU), each running independent chains (ILP 4) of one
+// instruction type; reports aggregate wave-instructions per cycle (s_memtime ticks) of the CU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define N 512
+template <int MODE>
+__global__ void k(unsigned long long* out, double seed) {
+  double x[4] = {seed, seed + 1, seed + 2, seed + 3};
+  float y[4] = {(float)seed, 1.f, 2.f, 3.f};
+  __syncthreads();
+  unsigned long long t0, t1;
+  asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (MODE == 0) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[j]) : "v"(seed));
+      if (MODE == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(y[j]) : "v"(y[3]));
+      if (MODE == 2) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(x[j]) : "v"(seed));
+      if (MODE == 3) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
+      if (MODE == 4) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(y[j]) : "v"(y[3]));
+    }
+  }
+  asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
+  if (x[0] + x[1] + x[2] + x[3] + y[0] + y[1] + y[2] == 12345.678) out[63] = 1;
+}
+template <int MODE>
+void run(const char* name, unsigned long long* d) {
+  for (int W : {1, 2, 4, 8, 12, 16}) {
+    unsigned long long h[16] = {0};
+    for (int r = 0; r < 3; ++r) { k<MODE><<<1, 64 * W>>>(d, 1.0); hipDeviceSynchronize(); }
+    hipMemcpy(h, d, 8 * W, hipMemcpyDeviceToHost);
+    unsigned long long mx = 0; for (int w = 0; w < W; ++w) mx = h[w] > mx ? h[w] : mx;
+    printf("%-10s waves/CU=%2d : per-wave %5.2f ticks/instr, CU aggregate %5.2f instr/tick\n", name, W, (double)mx / (N * 4), (double)W * N * 4 / mx);
+  }
+}
+int main() {
+  unsigned long long* d; hipMalloc(&d, 1024);
+  run<0>("v_add_f64", d); run<2>("v_fma_f64", d); run<1>("v_add_f32", d); run<4>("v_cndmask", d); run<3>("s_add_u32", d);
+  return 0;
+}
