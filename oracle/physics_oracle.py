@@ -1,0 +1,514 @@
+"""CPU reference of the articulated-body stepper (numpy, fp64) for the models compiled by tools/mjcf_compile.py.
+
+TEST INFRASTRUCTURE, NOT PRODUCT.  It is also used by tools/mjcf_compile.py at model-compile time (inverse weights at
+qpos0).  **Parity with MuJoCo is UNPINNED**: MuJoCo 2.1 / metaworld are not in /root/reference and cannot be run here
+(SURVEY.md section 8c).  The algorithm follows MuJoCo's documented pipeline (Computation chapter):
+
+  kinematics -> composite-rigid-body mass matrix (+ armature) -> RNE bias forces (gravity, Coriolis) -> passive joint
+  damping -> position actuators -> soft constraints (weld to the mocap body, joint limits; contacts: NOT YET) with
+  solref / solimp impedance and the dual problem (A + R) f = aref - J a0 solved by projected Gauss-Seidel ->
+  semi-implicit Euler with implicit joint damping.
+
+What IS pinned by the reference's own data: the model tables + forward kinematics reproduce the two door-handle
+positions recorded in envs/sawyer_door.py:46-47 to 1e-8 (tests/test_physics.py).
+All joints are 1-dof (hinge / slide), so nq == nv.
+"""
+import numpy as np
+
+
+# ------------------------------------------------------------------ quaternions / rotations
+def quat_mul(a, b):
+  w1, x1, y1, z1 = a
+  w2, x2, y2, z2 = b
+  return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                   w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def quat_conj(q):
+  return np.array([q[0], -q[1], -q[2], -q[3]])
+
+
+def quat_mat(q):
+  w, x, y, z = q
+  return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                   [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def skew(v):
+  return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+class Model:
+  """tables of one compiled model (earl_benchmark_amd/models/<name>.npz)"""
+
+  def __init__(self, path_or_dict):
+    d = np.load(path_or_dict, allow_pickle=False) if isinstance(path_or_dict, str) else path_or_dict
+    for k in d.files if hasattr(d, 'files') else d:
+      setattr(self, k, np.array(d[k]))
+    self.nb, self.nv = len(self.body_parent), len(self.jnt_body)
+    self.dt = float(self.timestep)
+    # ancestors of each dof (dofs whose motion moves the dof's body), incl. itself
+    self.body_dofs = [[] for _ in range(self.nb)]
+    for j in range(self.nv):
+      self.body_dofs[self.jnt_body[j]].append(j)
+    self.dof_anc = []                      # dofs that move dof j's body: those of its ancestors and, on its own body, j and earlier
+    for j in range(self.nv):
+      anc, b = [a for a in self.body_dofs[self.jnt_body[j]] if a <= j], self.body_parent[self.jnt_body[j]]
+      while b != 0:
+        anc = self.body_dofs[b] + anc
+        b = self.body_parent[b]
+      self.dof_anc.append(anc)
+
+  def body_id(self, name):
+    return list(self.body_names).index(name)
+
+  def geom_id(self, name):
+    return list(self.geom_names).index(name)
+
+  def site_id(self, name):
+    return list(self.site_names).index(name)
+
+
+# ------------------------------------------------------------------ kinematics
+def kinematics(m, qpos, body_pos=None):
+  """-> dict(xpos [nb,3], xquat [nb,4], xmat [nb,3,3], xipos, ximat, axis [nv,3] world, anchor [nv,3] world)"""
+  bp = m.body_pos if body_pos is None else body_pos
+  xpos, xquat = np.zeros((m.nb, 3)), np.tile([1.0, 0, 0, 0], (m.nb, 1))
+  axis, anchor = np.zeros((m.nv, 3)), np.zeros((m.nv, 3))
+  for b in range(1, m.nb):
+    p = m.body_parent[b]
+    R = quat_mat(xquat[p])
+    xpos[b] = xpos[p] + R @ bp[b]
+    xquat[b] = quat_mul(xquat[p], m.body_quat[b])
+    for j in m.body_dofs[b]:
+      Rb = quat_mat(xquat[b])
+      anchor[j] = xpos[b] + Rb @ m.jnt_pos[j]
+      axis[j] = Rb @ m.jnt_axis[j]
+      if m.jnt_type[j] == 0:   # hinge: rotate about the axis through the anchor
+        h = 0.5 * qpos[j]
+        xquat[b] = quat_mul(xquat[b], np.concatenate([[np.cos(h)], np.sin(h) * m.jnt_axis[j]]))
+        xpos[b] = anchor[j] - quat_mat(xquat[b]) @ m.jnt_pos[j]
+      else:                    # slide
+        xpos[b] = xpos[b] + axis[j] * qpos[j]
+  xmat = np.stack([quat_mat(q) for q in xquat])
+  xipos = xpos + np.einsum('bij,bj->bi', xmat, m.body_ipos)
+  ximat = np.stack([xmat[b] @ quat_mat(m.body_iquat[b]) for b in range(m.nb)])
+  return dict(xpos=xpos, xquat=xquat, xmat=xmat, xipos=xipos, ximat=ximat, axis=axis, anchor=anchor)
+
+
+def motion_subspace(m, kin):
+  """S [nv,6]: spatial velocity (omega, v of the point at the world origin) per unit joint velocity"""
+  S = np.zeros((m.nv, 6))
+  for j in range(m.nv):
+    if m.jnt_type[j] == 0:
+      S[j, :3] = kin['axis'][j]
+      S[j, 3:] = np.cross(kin['anchor'][j], kin['axis'][j])
+    else:
+      S[j, 3:] = kin['axis'][j]
+  return S
+
+
+def spatial_inertia(mass, c, Ic):
+  """6x6 inertia about the world origin of a body with COM c and rotational inertia Ic (world axes)"""
+  cx = skew(c)
+  I = np.zeros((6, 6))
+  I[:3, :3] = Ic + mass * cx @ cx.T
+  I[:3, 3:] = mass * cx
+  I[3:, :3] = mass * cx.T
+  I[3:, 3:] = mass * np.eye(3)
+  return I
+
+
+def crossm(v):  # spatial motion cross product  v x .
+  w, u = v[:3], v[3:]
+  X = np.zeros((6, 6))
+  X[:3, :3] = skew(w); X[3:, :3] = skew(u); X[3:, 3:] = skew(w)
+  return X
+
+
+def crossf(v):  # spatial force cross product  v x* .
+  return -crossm(v).T
+
+
+def body_inertias(m, kin):
+  return [spatial_inertia(m.body_mass[b], kin['xipos'][b], kin['ximat'][b] @ np.diag(m.body_inertia[b]) @ kin['ximat'][b].T)
+          for b in range(m.nb)]
+
+
+def mass_matrix(m, kin, S=None, I=None):
+  S = motion_subspace(m, kin) if S is None else S
+  Ic = [x.copy() for x in (body_inertias(m, kin) if I is None else I)]
+  for b in range(m.nb - 1, 0, -1):
+    Ic[m.body_parent[b]] += Ic[b]
+  M = np.zeros((m.nv, m.nv))
+  for i in range(m.nv):
+    F = Ic[m.jnt_body[i]] @ S[i]
+    for j in m.dof_anc[i]:
+      M[i, j] = M[j, i] = S[j] @ F
+  M[np.arange(m.nv), np.arange(m.nv)] += m.jnt_armature
+  return M
+
+
+def bias_forces(m, kin, qvel, S=None, I=None):
+  """RNE with zero acceleration: Coriolis / centrifugal + gravity generalized forces (qfrc_bias)"""
+  S = motion_subspace(m, kin) if S is None else S
+  I = body_inertias(m, kin) if I is None else I
+  V = np.zeros((m.nb, 6)); A = np.zeros((m.nb, 6))
+  A[0, 3:] = -m.gravity                   # fictitious base acceleration
+  F = np.zeros((m.nb, 6))
+  for b in range(1, m.nb):
+    p = m.body_parent[b]
+    V[b], A[b] = V[p], A[p].copy()
+    for j in m.body_dofs[b]:
+      A[b] = A[b] + crossm(V[b]) @ S[j] * qvel[j]
+      V[b] = V[b] + S[j] * qvel[j]
+    F[b] = I[b] @ A[b] + crossf(V[b]) @ (I[b] @ V[b])
+  for b in range(m.nb - 1, 0, -1):
+    F[m.body_parent[b]] += F[b]
+  return np.array([S[j] @ F[m.jnt_body[j]] for j in range(m.nv)])
+
+
+def body_jacobian(m, S, b, point):
+  """6 x nv: (omega, velocity of `point` rigidly attached to body b)"""
+  J = np.zeros((6, m.nv))
+  bb = b
+  while bb != 0:
+    for j in m.body_dofs[bb]:
+      J[:3, j] = S[j, :3]
+      J[3:, j] = S[j, 3:] + np.cross(S[j, :3], point)
+    bb = m.body_parent[bb]
+  return J
+
+
+# ------------------------------------------------------------------ soft constraints (MuJoCo solref / solimp)
+def impedance(solimp, r):
+  d0, dw, width, mid, power = solimp
+  x = min(abs(r) / width, 1.0) if width > 0 else 1.0
+  if power == 1 or d0 == dw:
+    y = x
+  elif x <= mid:
+    y = x ** power / mid ** (power - 1)
+  else:
+    y = 1 - (1 - x) ** power / (1 - mid) ** (power - 1)
+  return d0 + y * (dw - d0)
+
+
+def kbimp(solref, solimp, r, dt):
+  tc, dr = max(solref[0], 2 * dt), solref[1]
+  dmax = solimp[1]
+  d = impedance(solimp, r)
+  k = 1.0 / (dmax * dmax * tc * tc * dr * dr)
+  b = 2.0 / (dmax * tc)
+  return k, b, d
+
+
+def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
+  """rows: J [nc,nv], r [nc], aref [nc], R [nc], is_equality [nc]"""
+  rows = []
+  for w in range(len(m.weld_body1)):
+    b1, b2 = int(m.weld_body1[w]), int(m.weld_body2[w])
+    assert m.body_mocap[b1], 'weld body1 is the mocap body in these models'
+    p1, q1 = mocap_pos, mocap_quat / np.linalg.norm(mocap_quat)
+    p2, q2 = kin['xpos'][b2], kin['xquat'][b2]
+    Jb = body_jacobian(m, S, b2, p2)
+    rpos = p2 - p1                                            # relpose = identity (metaworld's reset_mocap_welds)
+    qe = quat_mul(quat_conj(q1), q2)                          # orientation of body2 in body1's frame
+    if qe[0] < 0:
+      qe = -qe
+    rrot = quat_mat(q1) @ qe[1:]                              # ~ half the rotation vector, world axes
+    for a in range(3):
+      rows.append((Jb[3 + a], rpos[a], m.weld_solref[w], m.weld_solimp[w], m.body_invweight0[b2, 0], True))
+    for a in range(3):
+      rows.append((0.5 * Jb[a], rrot[a], m.weld_solref[w], m.weld_solimp[w], m.body_invweight0[b2, 1], True))
+  for j in range(m.nv):
+    if m.jnt_limited[j]:
+      lo, hi = m.jnt_range[j]
+      e = np.zeros(m.nv); e[j] = 1.0
+      if qpos[j] - lo < 0:
+        rows.append((e, qpos[j] - lo, m.jnt_solref[j], m.jnt_solimp[j], m.dof_invweight0[j], False))
+      if hi - qpos[j] < 0:
+        rows.append((-e, hi - qpos[j], m.jnt_solref[j], m.jnt_solimp[j], m.dof_invweight0[j], False))
+  if not rows:
+    return np.zeros((0, m.nv)), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0, bool)
+  J = np.stack([r[0] for r in rows])
+  res = np.array([r[1] for r in rows])
+  aref, R = np.zeros(len(rows)), np.zeros(len(rows))
+  for i, (Ji, ri, solref, solimp, invw, _) in enumerate(rows):
+    k, b, d = kbimp(solref, solimp, ri, m.dt)
+    aref[i] = -b * (Ji @ qvel) - k * d * ri
+    R[i] = max((1 - d) / d * invw, 1e-15)
+  return J, res, aref, R, np.array([r[5] for r in rows])
+
+
+def solve_constraints(A, R, rhs, is_eq, iters=50):
+  """(A + R) f = rhs with f >= 0 on the inequality rows: projected Gauss-Seidel"""
+  n = len(rhs)
+  f = np.zeros(n)
+  AR = A + np.diag(R)
+  for _ in range(iters):
+    for i in range(n):
+      f[i] += (rhs[i] - AR[i] @ f) / AR[i, i]
+      if not is_eq[i] and f[i] < 0:
+        f[i] = 0.0
+  return f
+
+
+class State:
+  def __init__(self, m):
+    self.qpos = np.zeros(m.nv); self.qvel = np.zeros(m.nv)
+    self.mocap_pos = np.zeros(3); self.mocap_quat = np.array([1.0, 0, 0, 0])
+    self.ctrl = np.zeros(len(m.act_joint))
+
+
+def forward(m, s, body_pos=None):
+  """accelerations of one state -> dict with qacc (before the integrator's implicit damping), M, forces, kinematics"""
+  kin = kinematics(m, s.qpos, body_pos)
+  S = motion_subspace(m, kin)
+  I = body_inertias(m, kin)
+  M = mass_matrix(m, kin, S, I)
+  bias = bias_forces(m, kin, s.qvel, S, I)
+  passive = -m.jnt_damping * s.qvel
+  act = np.zeros(m.nv)
+  for a in range(len(m.act_joint)):
+    j = m.act_joint[a]
+    c = np.clip(s.ctrl[a], *m.act_ctrlrange[a])
+    act[j] += m.act_kp[a] * (c - s.qpos[j])
+  tau = passive + act - bias
+  Minv = np.linalg.inv(M)
+  a0 = Minv @ tau
+  J, res, aref, R, is_eq = constraints(m, kin, S, s.qpos, s.qvel, s.mocap_pos, s.mocap_quat)
+  f = np.zeros(0)
+  qfrc_c = np.zeros(m.nv)
+  if len(res):
+    A = J @ Minv @ J.T
+    f = solve_constraints(A, R, aref - J @ a0, is_eq)
+    qfrc_c = J.T @ f
+  qacc = a0 + Minv @ qfrc_c
+  return dict(kin=kin, M=M, qacc=qacc, tau=tau, qfrc_constraint=qfrc_c, efc_force=f, efc_pos=res)
+
+
+def step(m, s, body_pos=None):
+  """one timestep: semi-implicit Euler, joint damping integrated implicitly"""
+  out = forward(m, s, body_pos)
+  M = out['M']
+  Mh = M + m.dt * np.diag(m.jnt_damping)
+  qacc = np.linalg.solve(Mh, M @ out['qacc'])
+  s.qvel = s.qvel + m.dt * qacc
+  s.qpos = s.qpos + m.dt * s.qvel
+  return out
+
+
+def inverse_weights(m):
+  """body_invweight0 [nb,2] (translational, rotational) and dof_invweight0 [nv] at qpos0 = 0 (MuJoCo compiles these
+  into the model; the constraint regularizer uses them as the diagonal approximation of J M^-1 J^T)"""
+  kin = kinematics(m, np.zeros(m.nv))
+  S = motion_subspace(m, kin)
+  Minv = np.linalg.inv(mass_matrix(m, kin, S))
+  bw = np.zeros((m.nb, 2))
+  for b in range(1, m.nb):
+    J = body_jacobian(m, S, b, kin['xipos'][b])
+    A = J @ Minv @ J.T
+    bw[b] = [np.trace(A[3:, 3:]) / 3, np.trace(A[:3, :3]) / 3]
+  return bw, np.diag(Minv).copy()
+
+
+# ======================================================================================================================
+# Reduced ("link") model: one link per dof = the jointed body merged with its fixed descendants.  This is the form
+# the HIP stepper consumes (earl_benchmark_amd/csrc/physics.hip); `LinkModel.step` is its line-by-line reference.
+# ======================================================================================================================
+def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geoms=()):
+  """-> dict of arrays: links in an order where parents precede children (the dof order of these models)"""
+  bp = m.body_pos if body_pos is None else body_pos
+  link_of_body = np.full(m.nb, -1)          # nearest moving ancestor-or-self link of each body (-1: world-fixed)
+  for b in range(1, m.nb):
+    if m.body_dofs[b]:
+      assert len(m.body_dofs[b]) == 1
+      link_of_body[b] = m.body_dofs[b][0]
+    else:
+      link_of_body[b] = link_of_body[m.body_parent[b]]
+  # pose of every body in the frame of its link's jointed body (or world), with all joints at zero
+  rel_pos, rel_quat = np.zeros((m.nb, 3)), np.tile([1.0, 0, 0, 0], (m.nb, 1))
+  for b in range(1, m.nb):
+    p = m.body_parent[b]
+    if m.body_dofs[b]:
+      continue                              # the jointed body itself is the link frame
+    rel_pos[b] = rel_pos[p] + quat_mat(rel_quat[p]) @ bp[b]
+    rel_quat[b] = quat_mul(rel_quat[p], m.body_quat[b])
+  nv = m.nv
+  out = dict(parent=np.full(nv, -1, np.int32), tpos=np.zeros((nv, 3)), tquat=np.zeros((nv, 4)), jtype=m.jnt_type.astype(np.int32),
+             jaxis=m.jnt_axis.copy(), jpos=m.jnt_pos.copy(), mass=np.zeros(nv), com=np.zeros((nv, 3)), inertia=np.zeros((nv, 6)))
+  for l in range(nv):
+    b = int(m.jnt_body[l]); p = int(m.body_parent[b])
+    out['parent'][l] = link_of_body[p]
+    out['tpos'][l] = rel_pos[p] + quat_mat(rel_quat[p]) @ bp[b]      # jointed body's frame in its parent link's frame
+    out['tquat'][l] = quat_mul(rel_quat[p], m.body_quat[b])
+    members = [bb for bb in range(1, m.nb) if link_of_body[bb] == l]
+    M = sum(m.body_mass[bb] for bb in members)
+    c = sum(m.body_mass[bb] * (rel_pos[bb] + quat_mat(rel_quat[bb]) @ m.body_ipos[bb]) for bb in members) / M
+    I = np.zeros((3, 3))
+    for bb in members:
+      R = quat_mat(rel_quat[bb]) @ quat_mat(m.body_iquat[bb])
+      r = rel_pos[bb] + quat_mat(rel_quat[bb]) @ m.body_ipos[bb] - c
+      I += R @ np.diag(m.body_inertia[bb]) @ R.T + m.body_mass[bb] * (r @ r * np.eye(3) - np.outer(r, r))
+    out['mass'][l], out['com'][l] = M, c
+    out['inertia'][l] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+  assert all(out['parent'][l] < l for l in range(nv)), 'links must be ordered parents first'
+  att = []                                   # named points/frames rigidly attached to links
+  for name in attach_bodies:
+    b = m.body_id(name); att.append((name, link_of_body[b], rel_pos[b], rel_quat[b]))
+  for name in attach_sites:
+    s = m.site_id(name); b = int(m.site_body[s])
+    att.append((name, link_of_body[b], rel_pos[b] + quat_mat(rel_quat[b]) @ m.site_pos[s], rel_quat[b]))
+  for name in attach_geoms:
+    g = m.geom_id(name); b = int(m.geom_body[g])
+    att.append((name, link_of_body[b], rel_pos[b] + quat_mat(rel_quat[b]) @ m.geom_pos[g], rel_quat[b]))
+  out['att_link'] = np.array([a[1] for a in att], np.int32)
+  out['att_pos'] = np.stack([a[2] for a in att]); out['att_quat'] = np.stack([a[3] for a in att])
+  out['att_names'] = np.array([a[0] for a in att])
+  for k in ('jnt_limited', 'jnt_range', 'jnt_damping', 'jnt_armature', 'jnt_solref', 'jnt_solimp', 'dof_invweight0',
+            'act_joint', 'act_kp', 'act_ctrlrange', 'weld_solref', 'weld_solimp', 'gravity', 'timestep'):
+    out[k] = np.array(getattr(m, k))
+  wb = int(m.weld_body2[0])
+  out['weld_att'] = np.int32(list(out['att_names']).index(str(m.body_names[wb])))
+  out['weld_invweight'] = m.body_invweight0[wb].copy()
+  return out
+
+
+def sym6(v):
+  return np.array([[v[0], v[3], v[4]], [v[3], v[1], v[5]], [v[4], v[5], v[2]]])
+
+
+class LinkModel:
+  """the reduced tables + the reference of the HIP stepper (same phases, same order of operations where it matters)"""
+
+  def __init__(self, path_or_dict):
+    d = np.load(path_or_dict, allow_pickle=False) if isinstance(path_or_dict, str) else path_or_dict
+    for k in (d.files if hasattr(d, 'files') else d):
+      setattr(self, k, np.array(d[k]))
+    self.nv = len(self.parent)
+    self.dt = float(self.timestep)
+    self.anc = []
+    for l in range(self.nv):
+      a, p = [l], self.parent[l]
+      while p >= 0:
+        a = [int(p)] + a
+        p = self.parent[p]
+      self.anc.append(a)
+
+  def kinematics(self, qpos):
+    nv = self.nv
+    pos, quat = np.zeros((nv, 3)), np.zeros((nv, 4))
+    S = np.zeros((nv, 6))
+    for l in range(nv):
+      p = self.parent[l]
+      pp, pq = (pos[p], quat[p]) if p >= 0 else (np.zeros(3), np.array([1.0, 0, 0, 0]))
+      x = pp + quat_mat(pq) @ self.tpos[l]
+      q = quat_mul(pq, self.tquat[l])
+      R = quat_mat(q)
+      anchor, axis = x + R @ self.jpos[l], R @ self.jaxis[l]
+      if self.jtype[l] == 0:
+        h = 0.5 * qpos[l]
+        q = quat_mul(q, np.concatenate([[np.cos(h)], np.sin(h) * self.jaxis[l]]))
+        x = anchor - quat_mat(q) @ self.jpos[l]
+        S[l, :3], S[l, 3:] = axis, np.cross(anchor, axis)
+      else:
+        x = x + axis * qpos[l]
+        S[l, 3:] = axis
+      pos[l], quat[l] = x, q
+    return pos, quat, S
+
+  def attachment(self, pos, quat, k):
+    l = self.att_link[k]
+    if l < 0:
+      return self.att_pos[k].copy(), self.att_quat[k].copy()
+    return pos[l] + quat_mat(quat[l]) @ self.att_pos[k], quat_mul(quat[l], self.att_quat[k])
+
+  def forward(self, qpos, qvel, ctrl, mocap_pos, mocap_quat):
+    nv = self.nv
+    pos, quat, S = self.kinematics(qpos)
+    I6 = []
+    for l in range(nv):
+      R = quat_mat(quat[l])
+      I6.append(spatial_inertia(self.mass[l], pos[l] + R @ self.com[l], R @ sym6(self.inertia[l]) @ R.T))
+    Ic = [x.copy() for x in I6]
+    for l in range(nv - 1, -1, -1):
+      if self.parent[l] >= 0:
+        Ic[self.parent[l]] += Ic[l]
+    M = np.zeros((nv, nv))
+    for i in range(nv):
+      F = Ic[i] @ S[i]
+      for j in self.anc[i]:
+        M[i, j] = M[j, i] = S[j] @ F
+    M[np.arange(nv), np.arange(nv)] += self.jnt_armature
+    V, A, F = np.zeros((nv, 6)), np.zeros((nv, 6)), np.zeros((nv, 6))
+    a_base = np.concatenate([np.zeros(3), -self.gravity])
+    for l in range(nv):
+      p = self.parent[l]
+      Vp, Ap = (V[p], A[p]) if p >= 0 else (np.zeros(6), a_base)
+      A[l] = Ap + crossm(Vp) @ S[l] * qvel[l]
+      V[l] = Vp + S[l] * qvel[l]
+      F[l] = I6[l] @ A[l] + crossf(V[l]) @ (I6[l] @ V[l])
+    for l in range(nv - 1, -1, -1):
+      if self.parent[l] >= 0:
+        F[self.parent[l]] += F[l]
+    bias = np.array([S[l] @ F[l] for l in range(nv)])
+    tau = -self.jnt_damping * qvel - bias
+    for a in range(len(self.act_joint)):
+      j = self.act_joint[a]
+      tau[j] += self.act_kp[a] * (np.clip(ctrl[a], *self.act_ctrlrange[a]) - qpos[j])
+    L = np.linalg.cholesky(M)
+    a0 = np.linalg.solve(L.T, np.linalg.solve(L, tau))
+    # constraint rows: 6 weld rows, then lower / upper limit of every dof (inactive rows carry zero force)
+    k = int(self.weld_att)
+    hp, hq = self.attachment(pos, quat, k)
+    J = np.zeros((6 + 2 * nv, nv)); res = np.zeros(6 + 2 * nv); active = np.zeros(6 + 2 * nv, bool)
+    solref = [self.weld_solref[0]] * 6; solimp = [self.weld_solimp[0]] * 6
+    invw = [self.weld_invweight[0]] * 3 + [self.weld_invweight[1]] * 3
+    for j in self.anc[self.att_link[k]]:
+      J[0:3, j] = S[j, 3:] + np.cross(S[j, :3], hp)
+      J[3:6, j] = 0.5 * S[j, :3]
+    q1 = mocap_quat / np.linalg.norm(mocap_quat)
+    qe = quat_mul(quat_conj(q1), hq)
+    if qe[0] < 0:
+      qe = -qe
+    res[0:3] = hp - mocap_pos
+    res[3:6] = quat_mat(q1) @ qe[1:]
+    active[:6] = True
+    for j in range(nv):
+      J[6 + 2 * j, j], J[7 + 2 * j, j] = 1.0, -1.0
+      res[6 + 2 * j], res[7 + 2 * j] = qpos[j] - self.jnt_range[j, 0], self.jnt_range[j, 1] - qpos[j]
+      active[6 + 2 * j] = bool(self.jnt_limited[j]) and res[6 + 2 * j] < 0
+      active[7 + 2 * j] = bool(self.jnt_limited[j]) and res[7 + 2 * j] < 0
+      solref += [self.jnt_solref[j]] * 2; solimp += [self.jnt_solimp[j]] * 2; invw += [self.dof_invweight0[j]] * 2
+    nc = len(res)
+    aref, Rg = np.zeros(nc), np.zeros(nc)
+    Jv = J @ qvel
+    for i in range(nc):
+      kk, bb, dd = kbimp(solref[i], solimp[i], res[i], self.dt)
+      aref[i] = -bb * Jv[i] - kk * dd * res[i]
+      Rg[i] = max((1 - dd) / dd * invw[i], 1e-15)
+    Y = np.linalg.solve(L, J.T)                      # nv x nc
+    AR = Y.T @ Y + np.diag(Rg)
+    rhs = aref - J @ a0
+    f = np.zeros(nc)
+    act = active.copy()
+    for _ in range(4):                               # active-set: drop inequality rows that would pull
+      idx = np.nonzero(act)[0]
+      f[:] = 0.0
+      f[idx] = np.linalg.solve(AR[np.ix_(idx, idx)], rhs[idx])
+      bad = act & (np.arange(nc) >= 6) & (f < 0)
+      if not bad.any():
+        break
+      act &= ~bad
+    f[~act] = 0.0
+    qacc = a0 + np.linalg.solve(L.T, Y @ f)
+    return dict(pos=pos, quat=quat, M=M, qacc=qacc, f=f, res=res, active=act)
+
+  def step(self, qpos, qvel, ctrl, mocap_pos, mocap_quat):
+    out = self.forward(qpos, qvel, ctrl, mocap_pos, mocap_quat)
+    M = out['M']
+    qacc = np.linalg.solve(M + self.dt * np.diag(self.jnt_damping), M @ out['qacc'])
+    qvel = qvel + self.dt * qacc
+    qpos = qpos + self.dt * qvel
+    return qpos, qvel, out

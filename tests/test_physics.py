@@ -1,0 +1,104 @@
+"""Articulated-body reference (oracle/physics_oracle.py) and the compiled Sawyer-door model tables.
+
+Pinned by the reference's own data: forward kinematics of the compiled model reproduces the two door-handle positions
+recorded in envs/sawyer_door.py:46-47 (and initial_states / goal_states :13-16).  Dynamics vs MuJoCo: UNPINNED (no
+simulator here); checked by first principles (symmetry / positive definiteness, Jacobian vs finite differences, energy
+conservation) and by the reduced link model == full body model."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from oracle import physics_oracle as po
+
+MODEL = os.path.join(REPO, 'earl_benchmark_amd', 'models', 'sawyer_door.npz')
+LINKS = os.path.join(REPO, 'earl_benchmark_amd', 'models', 'sawyer_door_links.npz')
+
+
+@pytest.fixture(scope='module')
+def m():
+  return po.Model(MODEL)
+
+
+def door_body_pos(m):
+  bp = m.body_pos.copy()
+  bp[m.body_id('door')] = np.array([0.1, 0.95, 0.1], np.float32).astype(float)   # obj_init_pos (sawyer_door.py:36)
+  return bp
+
+
+def test_model_facts(m):
+  assert (m.nb, m.nv, len(m.geom_body)) == (36, 10, 52)
+  assert float(m.timestep) == 0.0025 and list(m.act_kp) == [400.0, 400.0]
+  assert list(m.joint_names[:7]) == [f'right_j{i}' for i in range(7)] and list(m.joint_names[7:]) == ['r_close', 'l_close', 'doorjoint']
+  np.testing.assert_array_equal(m.jnt_damping, [10] * 7 + [1000, 1000, 2])
+  np.testing.assert_array_equal(m.jnt_armature, [0.001] * 7 + [100, 100, 0.001])
+
+
+def test_handle_position_matches_the_reference_constants(m):
+  """(end effector pos, handle pos) comments of the reference: -pi/3 -> handle [0.01007495, 0.47104556, 0.10003595],
+  0 -> [0.29072163, 0.74286009, 0.10003595]; the same numbers are initial_states[0][4:7] / goal_states[0][4:7]."""
+  import earl_benchmark_amd.tables as tables
+  g = m.geom_id('handle')
+  for ang, want in ((0.0, tables.goal_states('sawyer_door')[0, 4:7]), (-np.pi / 3, tables.initial_states('sawyer_door')[0, 4:7])):
+    q = np.zeros(m.nv); q[9] = ang
+    kin = po.kinematics(m, q, door_body_pos(m))
+    b = m.geom_body[g]
+    got = kin['xpos'][b] + kin['xmat'][b] @ m.geom_pos[g]
+    np.testing.assert_allclose(got, want, atol=2e-8, rtol=0)
+
+
+def test_dynamics_first_principles(m):
+  rng = np.random.default_rng(0)
+  q = rng.uniform(-1, 1, m.nv) * 0.5; q[1] = -1.5; q[7] = 0.02; q[8] = -0.01; q[9] = -0.5
+  kin = po.kinematics(m, q); S = po.motion_subspace(m, kin)
+  M = po.mass_matrix(m, kin, S)
+  assert np.abs(M - M.T).max() == 0 and np.linalg.eigvalsh(M).min() > 1e-3
+  b = m.body_id('hand'); eps = 1e-6
+  J = po.body_jacobian(m, S, b, kin['xpos'][b])
+  Jn = np.stack([(po.kinematics(m, q + eps * np.eye(m.nv)[j])['xpos'][b] - kin['xpos'][b]) / eps for j in range(m.nv)], 1)
+  assert np.abs(J[3:] - Jn).max() < 5e-6
+  # energy is conserved by the unforced, undamped, unconstrained system
+  m2 = po.Model(MODEL)
+  m2.jnt_damping = np.zeros(m.nv); m2.jnt_limited = np.zeros(m.nv, int); m2.weld_body1 = np.zeros(0, int); m2.act_joint = np.zeros(0, int)
+  m2.dt = 2e-4
+
+  def energy(s):
+    k = po.kinematics(m2, s.qpos)
+    return 0.5 * s.qvel @ po.mass_matrix(m2, k) @ s.qvel - sum(m2.body_mass[i] * (m2.gravity @ k['xipos'][i]) for i in range(m2.nb))
+  s = po.State(m2); s.qpos = q.copy(); s.qvel = rng.normal(size=m.nv) * 0.3; s.qvel[7:9] = 0
+  e0 = energy(s)
+  for _ in range(200):
+    po.step(m2, s)
+  assert abs(energy(s) - e0) / abs(e0) < 1e-6
+
+
+def test_link_model_equals_body_model(m):
+  lm = po.LinkModel(LINKS)
+  assert list(lm.parent) == [-1, 0, 1, 2, 3, 4, 5, 6, 6, -1]
+  rng = np.random.default_rng(1)
+  s = po.State(m)
+  s.qpos = rng.uniform(-1, 1, 10) * 0.4; s.qpos[1] = -1.2; s.qpos[7] = 0.01; s.qpos[8] = -0.01; s.qpos[9] = -0.6
+  s.qvel = rng.normal(size=10) * 0.2
+  s.mocap_pos = np.array([0.1, 0.5, 0.3]); s.mocap_quat = np.array([1.0, 0, 1, 0]); s.ctrl = np.array([-1.0, 1.0])
+  full = po.forward(m, s, door_body_pos(m))
+  red = lm.forward(s.qpos, s.qvel, s.ctrl, s.mocap_pos, s.mocap_quat)
+  np.testing.assert_allclose(red['M'], full['M'], atol=1e-13)
+  hp, _ = lm.attachment(red['pos'], red['quat'], 0)
+  np.testing.assert_allclose(hp, full['kin']['xpos'][m.body_id('hand')], atol=1e-14)
+  np.testing.assert_allclose(red['qacc'], full['qacc'], rtol=5e-3)     # exact active-set solve vs 50 PGS sweeps
+
+
+def test_reset_hand_settles_near_the_recorded_pose(m):
+  """metaworld's _reset_hand: 50 x (mocap at hand_init_pos, 5 substeps).  The reference records the settled hand at
+  [0.00592, 0.39968, 0.19493] (initial_states, demos); this stepper settles within 6 mm of it (soft weld + gravity sag;
+  the exact figure depends on MuJoCo internals that cannot be pinned here)."""
+  lm = po.LinkModel(LINKS)
+  qpos, qvel = np.zeros(10), np.zeros(10)
+  qpos[9] = -np.pi / 3
+  mp, mq, ctrl = np.array([0, 0.4, 0.2], np.float32).astype(float), np.array([1.0, 0, 1, 0]), np.array([-1.0, 1.0])
+  for _ in range(250):
+    qpos, qvel, out = lm.step(qpos, qvel, ctrl, mp, mq)
+  hp, _ = lm.attachment(out['pos'], out['quat'], 0)
+  assert np.abs(hp - [0.00591636, 0.39968333, 0.19493164]).max() < 6e-3
+  assert (qpos[1] <= -0.5 + 1e-3) and abs(qpos[7]) < 1e-3       # joint limit respected, claw held at its stop

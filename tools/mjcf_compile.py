@@ -1,0 +1,375 @@
+#!/usr/bin/env python3
+"""Compile the FACTS of a reference MJCF model into this build's own table format (numeric arrays in an .npz).
+
+Runs only in the build container (the MJCF files live under /root/reference).  What travels is numbers: kinematic tree,
+frames, inertias, joint / actuator / equality parameters, collision primitives -- no XML, no meshes.
+
+    python tools/mjcf_compile.py sawyer_door     -> earl_benchmark_amd/models/sawyer_door.npz
+
+Implements the subset of MuJoCo's model compiler these files use (MuJoCo 2.1 semantics, from its documentation):
+<include>, nested <default class> + childclass, <compiler angle/inertiafromgeom/inertiagrouprange>, <body> with
+pos/quat/euler, <inertial>, <joint> (hinge/slide), <geom> (box/sphere/cylinder/capsule/plane/mesh), <site>,
+<position> actuators, <weld> equality, mocap bodies, <option>.  Bodies without <inertial> get mass / inertia from their
+geoms in the inertia group range (primitive shapes only; mesh geoms are outside the range in these models).  Mesh geoms
+keep their authored frame (MuJoCo re-centres them on the mesh centroid: see `mesh_center` below, needed for the one mesh
+geom an observation reads, "handle").
+"""
+import os
+import struct
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+REF_ENVS = '/root/reference/earl_benchmark/envs'
+MODELS = {
+    'sawyer_door': 'metaworld_assets/sawyer_xyz/sawyer_door_pull.xml',
+    'sawyer_peg': 'metaworld_assets/sawyer_xyz/sawyer_peg_insertion_side.xml',
+}
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'earl_benchmark_amd', 'models')
+
+
+# ------------------------------------------------------------------ small math
+def quat_mul(a, b):
+  w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+  return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                   w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def quat_norm(q):
+  q = np.asarray(q, float)
+  return q / np.linalg.norm(q)
+
+
+def quat_mat(q):
+  w, x, y, z = q
+  return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                   [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def euler_quat(e):  # MuJoCo default eulerseq "xyz": intrinsic rotations about x, then y, then z
+  q = np.array([1.0, 0, 0, 0])
+  for ang, ax in zip(e, np.eye(3)):
+    q = quat_mul(q, np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax]))
+  return q
+
+
+def mat_quat(R):
+  t = np.trace(R)
+  if t > 0:
+    s = np.sqrt(t + 1) * 2
+    q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+  else:
+    i = int(np.argmax(np.diag(R))); j, k = (i + 1) % 3, (i + 2) % 3
+    s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1) * 2
+    q = [0, 0, 0, 0]
+    q[0] = (R[k, j] - R[j, k]) / s; q[1 + i] = 0.25 * s
+    q[1 + j] = (R[j, i] + R[i, j]) / s; q[1 + k] = (R[k, i] + R[i, k]) / s
+  return quat_norm(q)
+
+
+def vec(s, n=None, default=None):
+  if s is None:
+    return None if default is None else np.array(default, float)
+  v = np.array([float(x) for x in s.split()], float)
+  if n is not None and len(v) != n:
+    v = np.concatenate([v, np.zeros(n - len(v))])
+  return v
+
+
+# ------------------------------------------------------------------ XML loading (includes + defaults)
+def load(path):
+  root = ET.parse(path).getroot()
+  base = os.path.dirname(path)
+
+  def expand(node):
+    out = []
+    for ch in list(node):
+      if ch.tag == 'include':
+        inc = ET.parse(os.path.join(base, ch.get('file'))).getroot()
+        expand(inc)
+        out.extend(list(inc))
+      else:
+        expand(ch)
+        out.append(ch)
+    for ch in list(node):
+      node.remove(ch)
+    node.extend(out)
+  expand(root)
+  return root
+
+
+class Defaults:
+  """<default class=...> tree: attribute dicts per element tag, inherited from the parent class."""
+
+  def __init__(self, root):
+    self.cls = {'main': {}}
+    for d in root.findall('default'):
+      self._walk(d, 'main', top=True)
+
+  def _walk(self, node, parent, top=False):
+    name = node.get('class') or 'main'
+    if name not in self.cls:
+      self.cls[name] = {k: dict(v) for k, v in self.cls[parent].items()}
+    cur = self.cls[name]
+    for ch in node:
+      if ch.tag == 'default':
+        self._walk(ch, name)
+      else:
+        cur.setdefault(ch.tag, {}).update(ch.attrib)
+
+  def attrs(self, el, active):
+    cls = el.get('class') or active or 'main'
+    a = dict(self.cls.get(cls, self.cls['main']).get(el.tag, {}))
+    a.update(el.attrib)
+    return a
+
+
+# ------------------------------------------------------------------ inertia of primitives (MuJoCo: uniform density)
+def geom_frame(a):
+  pos = vec(a.get('pos'), 3, [0, 0, 0])
+  if a.get('quat') is not None:
+    q = quat_norm(vec(a['quat']))
+  elif a.get('euler') is not None:
+    q = euler_quat(vec(a['euler']))
+  else:
+    q = np.array([1.0, 0, 0, 0])
+  if a.get('fromto') is not None:
+    raise NotImplementedError('fromto geoms')
+  return pos, q
+
+
+def primitive_inertia(gtype, size, density, mass):
+  """mass, principal inertia (about the geom centre, geom axes)"""
+  if gtype == 'box':
+    x, y, z = size[:3]
+    vol = 8 * x * y * z
+    m = mass if mass is not None else density * vol
+    return m, m / 3 * np.array([y * y + z * z, x * x + z * z, x * x + y * y])
+  if gtype == 'sphere':
+    r = size[0]
+    m = mass if mass is not None else density * 4 / 3 * np.pi * r ** 3
+    return m, np.full(3, 0.4 * m * r * r)
+  if gtype == 'cylinder':
+    r, h = size[0], size[1]
+    m = mass if mass is not None else density * np.pi * r * r * 2 * h
+    ixy = m * (3 * r * r + (2 * h) ** 2) / 12
+    return m, np.array([ixy, ixy, 0.5 * m * r * r])
+  if gtype == 'capsule':
+    r, h = size[0], size[1]
+    vc, vs = np.pi * r * r * 2 * h, 4 / 3 * np.pi * r ** 3
+    dens = density if mass is None else mass / (vc + vs)
+    mc, ms = dens * vc, dens * vs
+    izz = 0.5 * mc * r * r + 0.4 * ms * r * r
+    ixx = mc * (3 * r * r + (2 * h) ** 2) / 12 + ms * (0.4 * r * r + 0.375 * r * (2 * h) / 1 * 1 + h * h) if False else \
+        mc * (r * r / 4 + (2 * h) ** 2 / 12) + ms * (0.4 * r * r + h * h + 0.75 * r * h)
+    return mc + ms, np.array([ixx, ixx, izz])
+  raise NotImplementedError(gtype)
+
+
+def combine_inertia(parts):
+  """parts: (mass, com[3], R[3,3] of principal axes, diag[3]) in the body frame -> mass, com, quat, diag"""
+  M = sum(p[0] for p in parts)
+  if M <= 0:
+    return 0.0, np.zeros(3), np.array([1.0, 0, 0, 0]), np.zeros(3)
+  com = sum(p[0] * p[1] for p in parts) / M
+  I = np.zeros((3, 3))
+  for m, c, R, d in parts:
+    I += R @ np.diag(d) @ R.T
+    r = c - com
+    I += m * (r @ r * np.eye(3) - np.outer(r, r))
+  w, V = np.linalg.eigh(I)
+  order = np.argsort(-w)           # MuJoCo sorts principal inertias in decreasing order
+  w, V = w[order], V[:, order]
+  if np.linalg.det(V) < 0:
+    V[:, 2] = -V[:, 2]
+  return M, com, mat_quat(V), w
+
+
+# ------------------------------------------------------------------ STL centroid (MuJoCo re-centres mesh geoms on it)
+def mesh_center(path):
+  """Centre MuJoCo 2.1 gives a mesh: volume-weighted centroid of the pyramids spanned by each face and the mean of the
+  face centroids (|volume| weights), see mesh processing in the MuJoCo docs ("Mesh")."""
+  data = open(path, 'rb').read()
+  n = struct.unpack('<I', data[80:84])[0]
+  tri = np.frombuffer(data, dtype=np.dtype([('n', '<f4', 3), ('v', '<f4', (3, 3)), ('a', '<u2')]), count=n, offset=84)['v'].astype(float)
+  fc = tri.mean(1)
+  area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+  c0 = (fc * area[:, None]).sum(0) / area.sum()
+  a, b, c = tri[:, 0] - c0, tri[:, 1] - c0, tri[:, 2] - c0
+  vol = np.abs(np.einsum('ij,ij->i', a, np.cross(b, c))) / 6
+  cen = (tri.sum(1) + c0) / 4
+  return (cen * vol[:, None]).sum(0) / vol.sum(), c0, tri
+
+
+# ------------------------------------------------------------------ the compiler
+def compile_model(name):
+  path = os.path.join(REF_ENVS, MODELS[name])
+  root = load(path)
+  dfl = Defaults(root)
+  comp = {}
+  for c in root.findall('compiler'):
+    comp.update(c.attrib)
+  assert comp.get('angle', 'degree') == 'radian'
+  grp_lo, grp_hi = [int(x) for x in comp.get('inertiagrouprange', '0 5').split()]
+  opt = {}
+  for o in root.findall('option'):
+    opt.update(o.attrib)
+  meshes = {}
+  for a in root.findall('asset'):
+    for m in a.findall('mesh'):
+      meshes[m.get('name')] = os.path.normpath(os.path.join(os.path.dirname(path), m.get('file')))
+
+  bodies, joints, geoms, sites = [], [], [], []
+  names = {'body': ['world'], 'joint': [], 'geom': [], 'site': []}
+  bodies.append(dict(parent=0, pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]), mocap=0, inertial=None, geoms=[]))
+
+  def add_geom(el, bid, active):
+    a = dfl.attrs(el, active)
+    gtype = a.get('type', 'sphere')
+    pos, q = geom_frame(a)
+    size = vec(a.get('size'), 3, [0, 0, 0])
+    g = dict(body=bid, type=gtype, pos=pos, quat=q, size=size, group=int(a.get('group', 0)),
+             contype=int(a.get('contype', 1)), conaffinity=int(a.get('conaffinity', 1)), condim=int(a.get('condim', 3)),
+             density=float(a.get('density', 1000)), mass=(float(a['mass']) if 'mass' in a else None),
+             friction=vec(a.get('friction'), 3, [1, 0.005, 0.0001]), solref=vec(a.get('solref'), 2, [0.02, 1]),
+             solimp=vec(a.get('solimp'), 5, [0.9, 0.95, 0.001, 0.5, 2]), margin=float(a.get('margin', 0)),
+             mesh=a.get('mesh'))
+    if gtype == 'mesh':   # MuJoCo moves the geom frame to the mesh centre (orientation: principal axes, not needed here)
+      cen, _, _ = mesh_center(meshes[a['mesh']])
+      g['pos'] = pos + quat_mat(q) @ cen
+    names['geom'].append(a.get('name', ''))
+    geoms.append(g)
+    bodies[bid]['geoms'].append(len(geoms) - 1)
+
+  def walk(el, parent, active):
+    for ch in el:
+      if ch.tag == 'body':
+        cls = ch.get('childclass') or active
+        pos = vec(ch.get('pos'), 3, [0, 0, 0])
+        q = quat_norm(vec(ch.get('quat'))) if ch.get('quat') else (euler_quat(vec(ch.get('euler'))) if ch.get('euler') else np.array([1.0, 0, 0, 0]))
+        bid = len(bodies)
+        bodies.append(dict(parent=parent, pos=pos, quat=q, mocap=int(ch.get('mocap', 'false') == 'true'), inertial=None, geoms=[]))
+        names['body'].append(ch.get('name', ''))
+        for sub in ch:
+          if sub.tag == 'inertial':
+            iq = quat_norm(vec(sub.get('quat'))) if sub.get('quat') else np.array([1.0, 0, 0, 0])
+            bodies[bid]['inertial'] = (float(sub.get('mass')), vec(sub.get('pos'), 3), iq, vec(sub.get('diaginertia'), 3))
+          elif sub.tag == 'joint':
+            a = dfl.attrs(sub, cls)
+            joints.append(dict(body=bid, type=a.get('type', 'hinge'), axis=quat_norm(vec(a.get('axis'), 3, [0, 0, 1])) if True else None,
+                               pos=vec(a.get('pos'), 3, [0, 0, 0]), limited=int(a.get('limited', 'false') == 'true'),
+                               range=vec(a.get('range'), 2, [0, 0]), damping=float(a.get('damping', 0)),
+                               armature=float(a.get('armature', 0)), solref=vec(a.get('solreflimit'), 2, [0.02, 1]),
+                               solimp=vec(a.get('solimplimit'), 5, [0.9, 0.95, 0.001, 0.5, 2]), margin=float(a.get('margin', 0))))
+            joints[-1]['axis'] = vec(a.get('axis'), 3, [0, 0, 1]) / np.linalg.norm(vec(a.get('axis'), 3, [0, 0, 1]))
+            names['joint'].append(a.get('name', ''))
+          elif sub.tag == 'geom':
+            add_geom(sub, bid, cls)
+          elif sub.tag == 'site':
+            a = dfl.attrs(sub, cls)
+            pos, q = geom_frame(a)
+            sites.append(dict(body=bid, pos=pos, quat=q))
+            names['site'].append(a.get('name', ''))
+        walk(ch, bid, cls)
+      elif ch.tag == 'geom' and el.tag == 'worldbody':
+        add_geom(ch, 0, active)
+      elif ch.tag == 'site' and el.tag == 'worldbody':
+        a = dfl.attrs(ch, active)
+        pos, q = geom_frame(a)
+        sites.append(dict(body=0, pos=pos, quat=q))
+        names['site'].append(a.get('name', ''))
+
+  for wb in root.findall('worldbody'):
+    walk(wb, 0, None)
+
+  # inertia: explicit <inertial>, else from geoms in the inertia group range
+  nb = len(bodies)
+  mass, ipos, iquat, inertia = np.zeros(nb), np.zeros((nb, 3)), np.tile([1.0, 0, 0, 0], (nb, 1)), np.zeros((nb, 3))
+  for b, bd in enumerate(bodies):
+    if bd['inertial'] is not None:
+      mass[b], ipos[b], iquat[b], inertia[b] = bd['inertial']
+    else:
+      parts = []
+      for gi in bd['geoms']:
+        g = geoms[gi]
+        if grp_lo <= g['group'] <= grp_hi and g['type'] not in ('plane', 'mesh'):
+          m, d = primitive_inertia(g['type'], g['size'], g['density'], g['mass'])
+          parts.append((m, g['pos'], quat_mat(g['quat']), d))
+      if parts:
+        mass[b], ipos[b], iquat[b], inertia[b] = combine_inertia(parts)
+
+  jtype = {'hinge': 0, 'slide': 1}
+  gtype = {'plane': 0, 'sphere': 1, 'capsule': 2, 'cylinder': 3, 'box': 4, 'mesh': 5}
+  acts = []
+  for ac in root.findall('actuator'):
+    for el in ac:
+      a = dfl.attrs(el, None)
+      assert el.tag == 'position'
+      acts.append(dict(joint=names['joint'].index(a['joint']), kp=float(a.get('kp', 1)), ctrlrange=vec(a.get('ctrlrange'), 2, [0, 0]),
+                       ctrllimited=int(a.get('ctrllimited', 'false') == 'true')))
+  welds = []
+  for eq in root.findall('equality'):
+    for el in eq:
+      assert el.tag == 'weld'
+      welds.append(dict(body1=names['body'].index(el.get('body1')), body2=names['body'].index(el.get('body2')),
+                        solref=vec(el.get('solref'), 2, [0.02, 1]), solimp=vec(el.get('solimp'), 5, [0.9, 0.95, 0.001, 0.5, 2])))
+
+  out = dict(
+      name=np.array(name), timestep=np.float64(opt.get('timestep', 0.002)), gravity=vec(opt.get('gravity'), 3, [0, 0, -9.81]),
+      body_parent=np.array([b['parent'] for b in bodies], np.int32), body_pos=np.stack([b['pos'] for b in bodies]),
+      body_quat=np.stack([b['quat'] for b in bodies]), body_mocap=np.array([b['mocap'] for b in bodies], np.int32),
+      body_mass=mass, body_ipos=ipos, body_iquat=iquat, body_inertia=inertia,
+      jnt_body=np.array([j['body'] for j in joints], np.int32), jnt_type=np.array([jtype[j['type']] for j in joints], np.int32),
+      jnt_axis=np.stack([j['axis'] for j in joints]), jnt_pos=np.stack([j['pos'] for j in joints]),
+      jnt_limited=np.array([j['limited'] for j in joints], np.int32), jnt_range=np.stack([j['range'] for j in joints]),
+      jnt_damping=np.array([j['damping'] for j in joints]), jnt_armature=np.array([j['armature'] for j in joints]),
+      jnt_solref=np.stack([j['solref'] for j in joints]), jnt_solimp=np.stack([j['solimp'] for j in joints]),
+      geom_body=np.array([g['body'] for g in geoms], np.int32), geom_type=np.array([gtype[g['type']] for g in geoms], np.int32),
+      geom_pos=np.stack([g['pos'] for g in geoms]), geom_quat=np.stack([g['quat'] for g in geoms]),
+      geom_size=np.stack([g['size'] for g in geoms]), geom_contype=np.array([g['contype'] for g in geoms], np.int32),
+      geom_conaffinity=np.array([g['conaffinity'] for g in geoms], np.int32), geom_condim=np.array([g['condim'] for g in geoms], np.int32),
+      geom_friction=np.stack([g['friction'] for g in geoms]), geom_solref=np.stack([g['solref'] for g in geoms]),
+      geom_solimp=np.stack([g['solimp'] for g in geoms]), geom_margin=np.array([g['margin'] for g in geoms]),
+      site_body=np.array([s['body'] for s in sites], np.int32), site_pos=np.stack([s['pos'] for s in sites]),
+      act_joint=np.array([a['joint'] for a in acts], np.int32), act_kp=np.array([a['kp'] for a in acts]),
+      act_ctrlrange=np.stack([a['ctrlrange'] for a in acts]),
+      weld_body1=np.array([w['body1'] for w in welds], np.int32), weld_body2=np.array([w['body2'] for w in welds], np.int32),
+      weld_solref=np.stack([w['solref'] for w in welds]), weld_solimp=np.stack([w['solimp'] for w in welds]),
+      body_names=np.array(names['body']), joint_names=np.array(names['joint']), geom_names=np.array(names['geom']),
+      site_names=np.array(names['site']),
+  )
+  return out
+
+
+def main():
+  name = sys.argv[1] if len(sys.argv) > 1 else 'sawyer_door'
+  m = compile_model(name)
+  # constants MuJoCo's compiler derives at qpos0: inverse inertia weights used by the constraint regularizer
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  from oracle import physics_oracle as po
+  bw, dw = po.inverse_weights(po.Model(m))
+  m['body_invweight0'], m['dof_invweight0'] = bw, dw
+  os.makedirs(OUT, exist_ok=True)
+  np.savez_compressed(os.path.join(OUT, name + '.npz'), **m)
+  if name == 'sawyer_door':
+    # link form consumed by the HIP stepper; the env moves the door body to obj_init_pos at construction
+    # (envs/sawyer_door.py:36, :111-113) -- baked in here
+    pm = po.Model(m)
+    bp = pm.body_pos.copy()
+    bp[pm.body_id('door')] = np.array([0.1, 0.95, 0.1], np.float32).astype(float)
+    red = po.reduce_model(pm, bp, attach_bodies=['hand'], attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector'],
+                          attach_geoms=['handle'])
+    np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
+  nb, nj, ng = len(m['body_parent']), len(m['jnt_body']), len(m['geom_body'])
+  col = int(((m['geom_contype'] != 0) | (m['geom_conaffinity'] != 0)).sum())
+  print(f'{name}: {nb} bodies, {nj} joints (nv={nj}), {ng} geoms ({col} colliding), {len(m["act_joint"])} actuators, '
+        f'{len(m["weld_body1"])} welds, dt={float(m["timestep"])}, total mass {m["body_mass"].sum():.3f}')
+  for j in range(nj):
+    print(f'  joint {j} {m["joint_names"][j]:12s} body {m["body_names"][m["jnt_body"][j]]:12s} type {m["jnt_type"][j]} '
+          f'range {m["jnt_range"][j]} damping {m["jnt_damping"][j]} armature {m["jnt_armature"][j]}')
+
+
+if __name__ == '__main__':
+  main()
