@@ -10,7 +10,7 @@ from conftest import REPO, has_gpu
 from earl_benchmark_amd import _abi
 
 HEADER = os.path.join(REPO, 'include', 'earl_tabletop.h')
-HEADERS = [HEADER, os.path.join(REPO, 'include', 'earl_glue.h')]
+HEADERS = [HEADER, os.path.join(REPO, 'include', 'earl_glue.h'), os.path.join(REPO, 'include', 'earl_physics.h')]
 
 
 def declared_functions():
