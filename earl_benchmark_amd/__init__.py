@@ -78,6 +78,13 @@ class EARLEnvs(object):
       return tabletop.TabletopManipulation(task_list='rc_r-rc_k-rc_g-rc_b', reward_type=self._reward_type,
                                            reset_at_goal=reset_at_goal,
                                            wide_init_distr=self._kwargs.get('wide_init_distr', False), **kw)
+    if self._env_name == 'sawyer_door':
+      # reference: earl_benchmark/__init__.py (sawyer_door.SawyerDoorV2(reward_type=..., reset_at_goal=...)); dynamics: this
+      # build's own stepper -- no contacts yet, parity with MuJoCo unpinned
+      from .envs import sawyer_door
+      kw = dict(self._batch_kwargs)
+      kw['seed'] = int(kw.get('seed', 0)) + seed_salt
+      return sawyer_door.SawyerDoor(reward_type=self._reward_type, reset_at_goal=reset_at_goal, **kw)
     if self._env_name == 'kitchen' and self._reward_type != 'dense':
       raise ValueError('Kitchen environment only supports dense rewards.')  # reference: envs/kitchen.py:91-92
     raise NotImplementedError(_NOT_BUILT.format(name=self._env_name))

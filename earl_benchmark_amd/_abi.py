@@ -34,6 +34,24 @@ class MotorParams(C.Structure):   # struct earl_motor_params (include/earl_glue.
               ('torque_control', C.c_int32)]
 
 
+class SawyerCfg(C.Structure):   # struct earl_sawyer_cfg (include/earl_physics.h)
+  _fields_ = [('n', C.c_int32), ('env_offset', C.c_int32), ('reward_type', C.c_int32), ('horizon', C.c_int32),
+              ('frame_skip', C.c_int32), ('att_hand', C.c_int32), ('att_right', C.c_int32), ('att_left', C.c_int32),
+              ('att_obj', C.c_int32), ('obj_dof', C.c_int32), ('action_scale', C.c_double),
+              ('mocap_low', C.c_double * 3), ('mocap_high', C.c_double * 3), ('mocap_quat', C.c_double * 4),
+              ('success_radius', C.c_double), ('hand_init_pos', C.c_double * 3), ('obj_init_pos', C.c_double * 3),
+              ('obj_init_angle', C.c_double), ('angle_noise', C.c_double * 2), ('seed', C.c_uint64), ('counter', C.c_uint64)]
+
+
+class SawyerState(C.Structure):
+  _fields_ = [('qpos', C.c_void_p), ('qvel', C.c_void_p), ('mocap_pos', C.c_void_p), ('goal', C.c_void_p),
+              ('steps_since_reset', C.c_void_p)]
+
+
+class SawyerOut(C.Structure):
+  _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p)]
+
+
 _P = C.POINTER
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/earl_tabletop.h one to one
 SIGNATURES = {
@@ -60,6 +78,10 @@ SIGNATURES = {
     'earl_physics_step': [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7,
     'earl_physics_forward': [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9,
     'earl_physics_model_size': [],
+    'earl_sawyer_rollout': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_int32, _P(SawyerOut), C.c_void_p],
+    'earl_sawyer_reset': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState)] + [C.c_void_p] * 5,
+    'earl_sawyer_observe': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_void_p],
+    'earl_sawyer_door_reward': [_P(SawyerCfg), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_version': [],
     'earl_last_error': [],
     'earl_device_count': [],

@@ -17,6 +17,7 @@
 #include <cstdio>
 
 #include "../../include/earl_physics.h"
+#include "philox.h"
 
 namespace {
 
@@ -81,6 +82,7 @@ struct Shared {
   double J[NC][NV], Y[NV][NC], AR[NC][NC], C[NC][NC];
   double rhs[NC], f[NC], bz[NC];
   int idx[NC];
+  double att[4][3];
 };
 
 struct PArgs {
@@ -132,28 +134,13 @@ __device__ __forceinline__ void bwd_regs(const double (&L)[NV * (NV + 1) / 2], d
   }
 }
 
+// One timestep of one env (the whole wave).  INTEGRATE=false stops after qacc (mj_forward); qacc_out / efc_out may be NULL.
 template <int NV, bool INTEGRATE>
-__global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
-  using SH = Shared<NV>;
-  constexpr int NC = SH::NC;
-  __shared__ SH s;
-  const earl_link_model* __restrict__ m = a.m;
-  const int env = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model* __restrict__ m, const int lane, const V3 mpos, const Q4 mq,
+                                        const double (&ctrl)[EARL_MAXACT], double* qacc_out, double* efc_out) {
+  constexpr int NC = Shared<NV>::NC;
   const double dt = m->dt;
-
-  if (lane < NV) {
-    s.qp[lane] = a.qpos[(size_t)env * NV + lane];
-    s.qv[lane] = a.qvel[(size_t)env * NV + lane];
-  }
-  fence();
-  const V3 mpos = ld3(a.mocap_pos + (size_t)env * 3);
-  Q4 mq{a.mocap_quat[(size_t)env * 4], a.mocap_quat[(size_t)env * 4 + 1], a.mocap_quat[(size_t)env * 4 + 2], a.mocap_quat[(size_t)env * 4 + 3]};
   {
-    const double nrm = 1.0 / sqrt(mq.w * mq.w + mq.x * mq.x + mq.y * mq.y + mq.z * mq.z);
-    mq = {mq.w * nrm, mq.x * nrm, mq.y * nrm, mq.z * nrm};
-  }
-
-  for (int ts = 0; ts < a.nsub; ++ts) {
     // ---------------------------------------------------------------- P0: half-angle sin / cos of the hinges
     if (lane < NV) {
       double sn = 0, cs = 1;
@@ -292,7 +279,7 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
       double t = -m->damping[l] * s.qv[l] - bias;
       for (int ac = 0; ac < m->n_act; ++ac)
         if (m->act_joint[ac] == l) {
-          const double c = fmin(fmax(a.ctrl[(size_t)env * m->n_act + ac], m->act_ctrlrange[ac][0]), m->act_ctrlrange[ac][1]);
+          const double c = fmin(fmax(ctrl[ac], m->act_ctrlrange[ac][0]), m->act_ctrlrange[ac][1]);
           t += m->act_kp[ac] * (c - s.qp[l]);
         }
       s.tau[l] = t;
@@ -319,12 +306,15 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
       qmat(ql, R);
       const V3 hp = add(ld3(s.pos[la]), mulv(R, ld3(m->att_pos[k])));
       const Q4 hq = qmul(ql, Q4{m->att_quat[k][0], m->att_quat[k][1], m->att_quat[k][2], m->att_quat[k][3]});
-      Q4 qe = qmul(Q4{mq.w, -mq.x, -mq.y, -mq.z}, hq);
-      if (qe.w < 0) qe = {-qe.w, -qe.x, -qe.y, -qe.z};
-      double R1[3][3];
-      qmat(mq, R1);
-      const V3 rrot = mulv(R1, V3{qe.x, qe.y, qe.z});
-      const V3 rpos = sub(hp, mpos);
+      // weld rows as mj_instantiateEqual builds them (body1 = mocap, body2 = hand, relpose = identity): position error
+      // mocap - hand; orientation error = vector part of e = conj(q_hand) * q_mocap with the exact Jacobian of that vector
+      // part, -0.5 * (e_w a + a x e_v), a = R_hand^T w_j (no sign flip for e_w < 0)
+      const Q4 qe = qmul(Q4{hq.w, -hq.x, -hq.y, -hq.z}, mq);
+      const V3 ev{qe.x, qe.y, qe.z};
+      double Rh[3][3];
+      qmat(hq, Rh);
+      const V3 rrot = ev;
+      const V3 rpos = sub(mpos, hp);
       if (lane < NC) {
         const int r = lane;
         double Jr[NV];
@@ -341,9 +331,12 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
               const V3 sw = ld3(&s.S[j][0]), sv = ld3(&s.S[j][3]);
               if (r < 3) {
                 const V3 pv = add(sv, cross(sw, hp));
-                Jr[j] = c == 0 ? pv.x : (c == 1 ? pv.y : pv.z);
+                Jr[j] = -(c == 0 ? pv.x : (c == 1 ? pv.y : pv.z));
               } else {
-                Jr[j] = 0.5 * (c == 0 ? sw.x : (c == 1 ? sw.y : sw.z));
+                const V3 aa{Rh[0][0] * sw.x + Rh[1][0] * sw.y + Rh[2][0] * sw.z, Rh[0][1] * sw.x + Rh[1][1] * sw.y + Rh[2][1] * sw.z,
+                            Rh[0][2] * sw.x + Rh[1][2] * sw.y + Rh[2][2] * sw.z};
+                const V3 jq = add(scl(aa, qe.w), cross(aa, ev));
+                Jr[j] = -0.5 * (c == 0 ? jq.x : (c == 1 ? jq.y : jq.z));
               }
             }
           res = r < 3 ? (c == 0 ? rpos.x : (c == 1 ? rpos.y : rpos.z)) : (c == 0 ? rrot.x : (c == 1 ? rrot.y : rrot.z));
@@ -446,9 +439,9 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
         double v = 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) v = lane == i ? qacc[i] : v;
-        a.qacc_out[(size_t)env * NV + lane] = v;
+        if (qacc_out) qacc_out[lane] = v;
       }
-      if (a.efc_out && lane < NC) a.efc_out[(size_t)env * NC + lane] = s.f[lane];
+      if (efc_out && lane < NC) efc_out[lane] = s.f[lane];
     } else {
       // -------------------------------------------------------------- P11: Euler, joint damping implicit
       if (lane < NV) {
@@ -480,6 +473,43 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
       fence();
     }
   }
+}
+
+// world position of attachment k from the kinematics currently in LDS
+template <int NV>
+__device__ __forceinline__ V3 attachment(const Shared<NV>& s, const earl_link_model* __restrict__ m, const int k) {
+  const int la = m->att_link[k];
+  V3 p = ld3(m->att_pos[k]);
+  if (la >= 0) {
+    double R[3][3];
+    qmat(Q4{s.quat[la][0], s.quat[la][1], s.quat[la][2], s.quat[la][3]}, R);
+    p = add(ld3(s.pos[la]), mulv(R, p));
+  }
+  return p;
+}
+
+__device__ __forceinline__ Q4 qnormalize(const Q4& q) {
+  const double nrm = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  return {q.w * nrm, q.x * nrm, q.y * nrm, q.z * nrm};
+}
+
+template <int NV, bool INTEGRATE>
+__global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
+  __shared__ Shared<NV> s;
+  const earl_link_model* __restrict__ m = a.m;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (lane < NV) {
+    s.qp[lane] = a.qpos[(size_t)env * NV + lane];
+    s.qv[lane] = a.qvel[(size_t)env * NV + lane];
+  }
+  fence();
+  const V3 mpos = ld3(a.mocap_pos + (size_t)env * 3);
+  const Q4 mq = qnormalize(Q4{a.mocap_quat[(size_t)env * 4], a.mocap_quat[(size_t)env * 4 + 1], a.mocap_quat[(size_t)env * 4 + 2], a.mocap_quat[(size_t)env * 4 + 3]});
+  double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
+  for (int ac = 0; ac < m->n_act; ++ac) ctrl[ac] = a.ctrl[(size_t)env * m->n_act + ac];
+  for (int ts = 0; ts < a.nsub; ++ts)
+    substep<NV, INTEGRATE>(s, m, lane, mpos, mq, ctrl, a.qacc_out ? a.qacc_out + (size_t)env * NV : nullptr,
+                           a.efc_out ? a.efc_out + (size_t)env * Shared<NV>::NC : nullptr);
   if constexpr (INTEGRATE) {
     if (lane < NV) {
       a.qpos[(size_t)env * NV + lane] = s.qp[lane];
@@ -488,16 +518,175 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
   }
   // attachments at the kinematics of the LAST timestep's start (what mj_step leaves in data.xpos / site_xpos)
   if (a.att_xpos && lane < m->n_att) {
-    const int la = m->att_link[lane];
-    V3 p = ld3(m->att_pos[lane]);
-    if (la >= 0) {
-      double R[3][3];
-      qmat(Q4{s.quat[la][0], s.quat[la][1], s.quat[la][2], s.quat[la][3]}, R);
-      p = add(ld3(s.pos[la]), mulv(R, p));
-    }
+    const V3 p = attachment<NV>(s, m, lane);
     double* o = a.att_xpos + ((size_t)env * m->n_att + lane) * 3;
     o[0] = p.x; o[1] = p.y; o[2] = p.z;
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------ Sawyer env kernels
+struct SawyerArgs {
+  const earl_link_model* m;
+  earl_sawyer_cfg cfg;
+  earl_sawyer_state st;
+  const float* action; int T;
+  earl_sawyer_out out;
+  const double* reset_qpos; const double* reset_qvel; const uint8_t* mask; double* reset_obs;
+  int observe_only;
+};
+
+// metaworld reward_utils.tolerance(x, bounds=(0, hi), margin, sigmoid='gaussian') [UPSTREAM, dm_control semantics; unpinned]
+__device__ __forceinline__ double tolerance_gaussian(double x, double hi, double margin) {
+  if (0.0 <= x && x <= hi) return 1.0;
+  if (margin == 0) return 0.0;
+  const double d = (x < 0.0 ? -x : x - hi) / margin;
+  const double scale = sqrt(-2.0 * log(0.1));
+  return exp(-0.5 * (d * scale) * (d * scale));
+}
+
+// obs[14] + reward + flags of one env from the kinematics in LDS (sawyer_door.py:86-94, :141-177); all lanes call it
+template <int NV>
+__device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model* __restrict__ m, const earl_sawyer_cfg& cfg,
+                                            const int lane, const double* __restrict__ goal, double* __restrict__ obs,
+                                            float* reward, uint8_t* success) {
+  if (lane < 4) {
+    const int k = lane == 0 ? cfg.att_hand : (lane == 1 ? cfg.att_right : (lane == 2 ? cfg.att_left : cfg.att_obj));
+    const V3 p = attachment<NV>(s, m, k);
+    s.att[lane][0] = p.x; s.att[lane][1] = p.y; s.att[lane][2] = p.z;
+  }
+  fence();
+  if (lane < 14) {
+    double v;
+    if (lane < 3) v = s.att[0][lane];
+    else if (lane == 3) {
+      const V3 d = sub(ld3(s.att[1]), ld3(s.att[2]));
+      v = fmin(fmax(sqrt(dot(d, d)) / 0.1, 0.0), 1.0);
+    } else if (lane < 7) v = s.att[3][lane - 4];
+    else v = goal[lane - 7];
+    obs[lane] = v;
+  }
+  if (lane == 0) {
+    const V3 tcp = ld3(s.att[0]), obj = ld3(s.att[3]), target = ld3(goal + 4);
+    const V3 d = sub(obj, target);
+    const double obj_to_target = sqrt(dot(d, d));                 // np.linalg.norm in f64
+    const bool ok = obj_to_target <= cfg.success_radius;
+    double r = ok ? 1.0 : 0.0;
+    if (cfg.reward_type != 0) {
+      const V3 e = sub(tcp, obj);
+      const double tcp_to_obj = sqrt(dot(e, e));
+      const V3 oi = sub(ld3(cfg.obj_init_pos), target), hi = sub(ld3(cfg.hand_init_pos), obj);
+      const double in_place = tolerance_gaussian(obj_to_target, 0.05, sqrt(dot(oi, oi)));
+      const double hand_in_place = tolerance_gaussian(tcp_to_obj, 0.25 * 0.05, sqrt(dot(hi, hi)) + 0.1);
+      r = 3 * hand_in_place + 6 * in_place;
+      if (obj_to_target < 0.05) r = 10;
+    }
+    if (reward) *reward = (float)r;
+    if (success) *success = ok ? 1 : 0;
+  }
+  fence();
+}
+
+template <int NV>
+__global__ __launch_bounds__(64) void sawyer_rollout_kernel(const SawyerArgs a) {
+  __shared__ Shared<NV> s;
+  const earl_link_model* __restrict__ m = a.m;
+  const earl_sawyer_cfg& cfg = a.cfg;
+  const int env = blockIdx.x, lane = threadIdx.x, n = cfg.n;
+  if (lane < NV) {
+    s.qp[lane] = a.st.qpos[(size_t)env * NV + lane];
+    s.qv[lane] = a.st.qvel[(size_t)env * NV + lane];
+  }
+  fence();
+  V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
+  const Q4 mq = qnormalize(Q4{cfg.mocap_quat[0], cfg.mocap_quat[1], cfg.mocap_quat[2], cfg.mocap_quat[3]});
+  int steps = a.st.steps_since_reset ? a.st.steps_since_reset[env] : 0;
+  const float scale = (float)cfg.action_scale;
+  for (int t = 0; t < a.T; ++t) {
+    const float4 act = *reinterpret_cast<const float4*>(a.action + ((size_t)t * n + env) * 4);
+    // set_xyz_action [UPSTREAM]: clip, float32 product with the scale, float64 add, box clip
+    const float cx = fminf(fmaxf(act.x, -1.f), 1.f) * scale, cy = fminf(fmaxf(act.y, -1.f), 1.f) * scale, cz = fminf(fmaxf(act.z, -1.f), 1.f) * scale;
+    mpos.x = fmin(fmax(mpos.x + (double)cx, cfg.mocap_low[0]), cfg.mocap_high[0]);
+    mpos.y = fmin(fmax(mpos.y + (double)cy, cfg.mocap_low[1]), cfg.mocap_high[1]);
+    mpos.z = fmin(fmax(mpos.z + (double)cz, cfg.mocap_low[2]), cfg.mocap_high[2]);
+    const double ctrl[EARL_MAXACT] = {(double)act.w, -(double)act.w, 0, 0};
+    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, true>(s, m, lane, mpos, mq, ctrl, nullptr, nullptr);
+    const size_t row = (size_t)t * n + env;
+    sawyer_emit<NV>(s, m, cfg, lane, a.st.goal + (size_t)env * 7, a.out.obs + row * 14, a.out.reward ? a.out.reward + row : nullptr,
+                    a.out.success ? a.out.success + row : nullptr);
+    ++steps;
+    if (lane == 0 && a.out.done) a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
+  }
+  if (lane < NV) {
+    a.st.qpos[(size_t)env * NV + lane] = s.qp[lane];
+    a.st.qvel[(size_t)env * NV + lane] = s.qv[lane];
+  }
+  if (lane < 3) a.st.mocap_pos[(size_t)env * 3 + lane] = lane == 0 ? mpos.x : (lane == 1 ? mpos.y : mpos.z);
+  if (lane == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
+}
+
+template <int NV>
+__global__ __launch_bounds__(64) void sawyer_reset_kernel(const SawyerArgs a) {
+  __shared__ Shared<NV> s;
+  const earl_link_model* __restrict__ m = a.m;
+  const earl_sawyer_cfg& cfg = a.cfg;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (a.observe_only) {
+    if (lane < NV) {
+      s.qp[lane] = a.st.qpos[(size_t)env * NV + lane];
+      s.qv[lane] = a.st.qvel[(size_t)env * NV + lane];
+    }
+    fence();
+    const Q4 mq = qnormalize(Q4{cfg.mocap_quat[0], cfg.mocap_quat[1], cfg.mocap_quat[2], cfg.mocap_quat[3]});
+    const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
+    substep<NV, false>(s, m, lane, ld3(a.st.mocap_pos + (size_t)env * 3), mq, ctrl, nullptr, nullptr);
+    sawyer_emit<NV>(s, m, cfg, lane, a.st.goal + (size_t)env * 7, a.reset_obs + (size_t)env * 14, nullptr, nullptr);
+    return;
+  }
+  if (a.mask && !a.mask[env]) return;
+  const earl::U4 b = earl::philox4x32_10(earl::U4{0u, (uint32_t)(cfg.env_offset + env), (uint32_t)cfg.counter, (uint32_t)(cfg.counter >> 32)},
+                                         (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
+  // np.random.uniform(lo, hi) = lo + (hi - lo) * u   (sawyer_door.py:116-118)
+  const double angle = cfg.obj_init_angle + (cfg.angle_noise[0] + (cfg.angle_noise[1] - cfg.angle_noise[0]) * earl::u01(b.x, b.y));
+  if (lane < NV) {
+    s.qp[lane] = lane == cfg.obj_dof ? angle : a.reset_qpos[lane];
+    s.qv[lane] = lane == cfg.obj_dof ? 0.0 : a.reset_qvel[lane];
+    a.st.qpos[(size_t)env * NV + lane] = s.qp[lane];
+    a.st.qvel[(size_t)env * NV + lane] = s.qv[lane];
+  }
+  if (lane < 3) a.st.mocap_pos[(size_t)env * 3 + lane] = cfg.hand_init_pos[lane];
+  if (lane == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
+  fence();
+  if (a.reset_obs) {
+    // set_state -> sim.forward(): kinematics of the state just written
+    const Q4 mq = qnormalize(Q4{cfg.mocap_quat[0], cfg.mocap_quat[1], cfg.mocap_quat[2], cfg.mocap_quat[3]});
+    const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
+    substep<NV, false>(s, m, lane, ld3(cfg.hand_init_pos), mq, ctrl, nullptr, nullptr);
+    sawyer_emit<NV>(s, m, cfg, lane, a.st.goal + (size_t)env * 7, a.reset_obs + (size_t)env * 14, nullptr, nullptr);
+  }
+}
+
+// compute_reward / is_successful on given observations (sawyer_door.py:141-177), one lane per row
+__global__ void sawyer_door_reward_kernel(const int n, const double* __restrict__ obs, const earl_sawyer_cfg cfg, float* __restrict__ reward,
+                                          uint8_t* __restrict__ success) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* o = obs + (size_t)i * 14;
+  const V3 tcp = ld3(o), obj = ld3(o + 4), target = ld3(o + 11);
+  const V3 d = sub(obj, target);
+  const double obj_to_target = sqrt(dot(d, d));
+  const bool ok = obj_to_target <= cfg.success_radius;
+  double r = ok ? 1.0 : 0.0;
+  if (cfg.reward_type != 0) {
+    const V3 e = sub(tcp, obj);
+    const V3 oi = sub(ld3(cfg.obj_init_pos), target), hi = sub(ld3(cfg.hand_init_pos), obj);
+    const double in_place = tolerance_gaussian(obj_to_target, 0.05, sqrt(dot(oi, oi)));
+    const double hand_in_place = tolerance_gaussian(sqrt(dot(e, e)), 0.25 * 0.05, sqrt(dot(hi, hi)) + 0.1);
+    r = 3 * hand_in_place + 6 * in_place;
+    if (obj_to_target < 0.05) r = 10;
+  }
+  if (reward) reward[i] = (float)r;
+  if (success) success[i] = ok ? 1 : 0;
 }
 
 int launched(const char* what) {
@@ -533,6 +722,50 @@ int earl_physics_forward(const earl_link_model* model, int32_t nv, int32_t n, co
   if (nv == 10) physics_kernel<10, false><<<n, 64, 0, (hipStream_t)stream>>>(a);
   else return EARL_ERR_ARG;
   return launched("physics_forward");
+}
+
+int earl_sawyer_rollout(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+                        const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream) {
+  if (!model || !cfg || !st || !out || !action || T < 0 || cfg->n < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !out->obs) return EARL_ERR_ARG;
+  if (cfg->frame_skip < 0 || cfg->att_hand < 0 || cfg->att_right < 0 || cfg->att_left < 0 || cfg->att_obj < 0) return EARL_ERR_ARG;
+  if (cfg->n == 0 || T == 0) return EARL_OK;
+  SawyerArgs a{model, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
+  if (nv == 10) sawyer_rollout_kernel<10><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
+  else return EARL_ERR_ARG;
+  return launched("sawyer_rollout");
+}
+
+int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+                      const double* reset_qpos, const double* reset_qvel, const uint8_t* mask, double* obs,
+                      earl_stream_t stream) {
+  if (!model || !cfg || !st || !reset_qpos || !reset_qvel || cfg->n < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
+  if (cfg->obj_dof < 0 || cfg->obj_dof >= nv) return EARL_ERR_ARG;
+  if (cfg->n == 0) return EARL_OK;
+  SawyerArgs a{model, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, reset_qpos, reset_qvel, mask, obs, 0};
+  if (nv == 10) sawyer_reset_kernel<10><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
+  else return EARL_ERR_ARG;
+  return launched("sawyer_reset");
+}
+
+int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st, double* obs,
+                        earl_stream_t stream) {
+  if (!model || !cfg || !st || !obs || cfg->n < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
+  if (cfg->n == 0) return EARL_OK;
+  SawyerArgs a{model, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, obs, 1};
+  if (nv == 10) sawyer_reset_kernel<10><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
+  else return EARL_ERR_ARG;
+  return launched("sawyer_observe");
+}
+
+int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, float* reward, uint8_t* success,
+                            earl_stream_t stream) {
+  if (!cfg || n < 0 || !obs) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  sawyer_door_reward_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, obs, *cfg, reward, success);
+  return launched("sawyer_door_reward");
 }
 
 int earl_physics_model_size(void) { return (int)sizeof(earl_link_model); }

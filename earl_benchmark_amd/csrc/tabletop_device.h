@@ -9,6 +9,7 @@
 // function), envs/tabletop_manipulation_3obj.py, wrappers/persistent_state_wrapper.py,
 // wrappers/lifelong_wrapper.py.
 #pragma once
+#include "philox.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,26 +35,10 @@ struct Dims {
   static constexpr int NOBS = NQ + 2 + NG;  // 12 / 20
 };
 
-// ---------------------------------------------------------------- Philox4x32-10 (counter-based RNG)
-struct U4 { uint32_t x, y, z, w; };
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return c;
-}
 // draw layout (shared with the oracle): ctr = {draw, global env id, counter lo, counter hi}, key = seed
 __device__ __forceinline__ U4 draw_block(const earl_tabletop_cfg& cfg, uint64_t counter, int env, uint32_t draw) {
   return philox4x32_10(U4{draw, (uint32_t)(cfg.env_offset + env), (uint32_t)counter, (uint32_t)(counter >> 32)},
                        (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
-}
-__device__ __forceinline__ double u01(uint32_t lo, uint32_t hi) {
-  return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
 }
 __device__ __forceinline__ int sample_goal(const earl_tabletop_cfg& cfg, uint64_t counter, int env,
                                            const int32_t* __restrict__ next_goal_idx) {

@@ -1,0 +1,249 @@
+"""Batched, GPU-resident counterpart of the reference's Sawyer door env (BASELINE config 3).
+
+Mirrors `SawyerDoorV2` (reference: earl_benchmark/envs/sawyer_door.py) -- constructor arguments, `reset`, `step`,
+`reset_goal`, `get_next_goal`, `compute_reward`, `is_successful`, `_get_obs`, observation layout
+(hand xyz, gripper opening, handle xyz, goal[7]) -- for `num_envs` independent instances stepped by ONE kernel launch
+(one wavefront per env, csrc/physics.hip behind include/earl_physics.h).
+
+STATUS: the dynamics are this build's own articulated-body stepper: smooth dynamics + mocap weld + joint limits, NO
+contacts yet (the gripper passes through the door handle), and parity with MuJoCo is UNPINNED.  What is
+pinned: the sparse success rule (bit-exact on the reference's demonstrations), the model tables and forward kinematics
+(the reference's recorded handle / hand positions), the reset pose (6 mm).  `SawyerXYZEnv.step` semantics are upstream
+metaworld behaviour restated from SURVEY.md Appendix D.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _abi, physics
+from ..spaces import Box
+
+INT32_MAX = 2**31 - 1
+
+# reference: sawyer_door.py:13-16
+initial_states = np.array([[0.00591636, 0.39968333, 0.19493164, 1.0, 0.01007495, 0.47104556, 0.10003595]])
+goal_states = np.array([[0.29072163, 0.74286009, 0.10003595, 1.0, 0.29072163, 0.74286009, 0.10003595]])
+
+RESET_HAND_STEPS = 50       # SawyerXYZEnv._reset_hand(steps=50) [UPSTREAM]
+FRAME_SKIP = 5              # SawyerXYZEnv(frame_skip=5) [UPSTREAM]
+
+
+def _ptr(t):
+  return None if t is None else t.data_ptr()
+
+
+class SawyerDoor:
+  """N independent Sawyer door envs; state (qpos, qvel, mocap) lives in HBM, every call is one kernel launch."""
+
+  OBS_DIM = 14
+  MODEL = 'sawyer_door'
+
+  def __init__(self, reward_type='sparse', reset_at_goal=False, num_envs=1, device='cuda', seed=0, env_offset=0,
+               scalar_api=None, auto_reset=False):
+    if auto_reset:
+      raise NotImplementedError('auto_reset is not built for the Sawyer envs')
+    self._lib = _abi.load()
+    dev = torch.device(device)
+    if dev.type != 'cuda' or not torch.cuda.is_available():
+      raise _abi.EarlHipError(f'device={device!r}: the Sawyer envs run on MI355X only (no CPU fallback)')
+    if dev.index is None:
+      dev = torch.device('cuda', torch.cuda.current_device())
+    if reward_type not in _abi.REWARD_TYPES:
+      raise ValueError(f'reward_type must be sparse|dense, got {reward_type!r}')
+    self.device = dev
+    self.num_envs = n = int(num_envs)
+    self.scalar_api = (n == 1) if scalar_api is None else bool(scalar_api)
+    if self.scalar_api and n != 1:
+      raise ValueError('scalar_api needs num_envs == 1')
+    self._reward_type = reward_type
+    self._reset_at_goal = bool(reset_at_goal)
+    # sawyer_door.py:32-41
+    self.obj_init_angle = 0.0 if self._reset_at_goal else -np.pi / 3
+    self.obj_init_pos = np.array([0.1, 0.95, 0.1], dtype=np.float32)
+    self.hand_init_pos = np.array([0.29, 0.74, 0.1] if self._reset_at_goal else [0, 0.4, 0.2], dtype=np.float32)
+    self.goal_states = goal_states.copy()
+    self.max_path_length = int(1e8)
+
+    with torch.cuda.device(dev):
+      self.model = physics.DeviceModel(self.MODEL, device=dev)
+    nv = self.nv = self.model.nv
+    names = self.model.att_names
+    kw = dict(device=dev)
+    self.qpos = torch.zeros(n, nv, dtype=torch.float64, **kw)
+    self.qvel = torch.zeros(n, nv, dtype=torch.float64, **kw)
+    self.mocap_pos = torch.zeros(n, 3, dtype=torch.float64, **kw)
+    self.goal_t = torch.tensor(goal_states[0], dtype=torch.float64, **kw).repeat(n, 1).contiguous()
+    self.steps_since_reset = torch.zeros(n, dtype=torch.int32, **kw)
+    self.interventions = torch.zeros(n, dtype=torch.int32, **kw)
+    self.steps_since_goal_change = torch.zeros(n, dtype=torch.int32, **kw)
+    self.lifelong_return_t = torch.zeros(n, dtype=torch.float64, **kw)
+    self.total_step_count = 0
+
+    lo, hi = (-np.pi / 20, 0.0) if self._reset_at_goal else (0.0, np.pi / 20)          # :116-118
+    cfg = _abi.SawyerCfg(n=n, env_offset=int(env_offset), reward_type=_abi.REWARD_TYPES[reward_type], horizon=INT32_MAX,
+                         frame_skip=FRAME_SKIP, att_hand=names.index('hand'), att_right=names.index('rightEndEffector'),
+                         att_left=names.index('leftEndEffector'), att_obj=names.index('handle'),
+                         obj_dof=int(self.model.tables.get('obj_dof', nv - 1)), action_scale=1.0 / 100,
+                         success_radius=0.02, obj_init_angle=float(self.obj_init_angle), seed=int(seed) & (2**64 - 1), counter=0)
+    cfg.mocap_low[:] = (-0.5, 0.40, 0.05)      # SawyerDoorCloseEnvV2 hand_low / hand_high [UPSTREAM]; sawyer_door.py:25-26
+    cfg.mocap_high[:] = (0.5, 1.0, 0.5)
+    cfg.mocap_quat[:] = (1.0, 0.0, 1.0, 0.0)
+    cfg.hand_init_pos[:] = [float(x) for x in self.hand_init_pos]
+    cfg.obj_init_pos[:] = [float(x) for x in self.obj_init_pos]
+    cfg.angle_noise[:] = (lo, hi)
+    cfg.goal_change_frequency = 0               # python-side only (LifelongWrapper)
+    self._cfg = cfg
+    self._st = _abi.SawyerState(qpos=self.qpos.data_ptr(), qvel=self.qvel.data_ptr(), mocap_pos=self.mocap_pos.data_ptr(),
+                                goal=self.goal_t.data_ptr(), steps_since_reset=self.steps_since_reset.data_ptr())
+    self._cfg_ref, self._st_ref = C.byref(self._cfg), C.byref(self._st)
+
+    self.action_space = Box(-1.0, 1.0, (4,), np.float32)
+    self.observation_space = Box(-np.inf, np.inf, (self.OBS_DIM,), np.float64)
+    with torch.cuda.device(dev):
+      self._reset_state = self._settle_reset_hand()
+      self.reset()
+    self.interventions.zero_()
+
+  # ------------------------------------------------------------------ internals
+  @property
+  def unwrapped(self):
+    return self
+
+  def _stream(self):
+    return torch.cuda.current_stream(self.device).cuda_stream
+
+  def _settle_reset_hand(self):
+    """sim.reset() + _reset_hand: 50 x (mocap <- hand_init_pos, ctrl <- [-1, 1], frame_skip timesteps) from qpos0.
+    Deterministic and identical for every env, so it is run once on a single instance and cached."""
+    kw = dict(dtype=torch.float64, device=self.device)
+    q, v = torch.zeros(1, self.nv, **kw), torch.zeros(1, self.nv, **kw)
+    mp = torch.tensor([[float(x) for x in self.hand_init_pos]], **kw)
+    mq = torch.tensor([[1.0, 0.0, 1.0, 0.0]], **kw)
+    ctrl = torch.tensor([[-1.0, 1.0]], **kw)
+    self.model.step(q, v, mp, mq, ctrl, nsub=RESET_HAND_STEPS * FRAME_SKIP)
+    return q[0].contiguous(), v[0].contiguous()
+
+  def _new_out(self, lead):
+    kw = dict(device=self.device)
+    return {'obs': torch.empty(*lead, self.num_envs, self.OBS_DIM, dtype=torch.float64, **kw),
+            'reward': torch.empty(*lead, self.num_envs, dtype=torch.float32, **kw),
+            'done': torch.empty(*lead, self.num_envs, dtype=torch.bool, **kw),
+            'success': torch.empty(*lead, self.num_envs, dtype=torch.bool, **kw)}
+
+  def _launch_rollout(self, actions, T, out):
+    o = _abi.SawyerOut(obs=out['obs'].data_ptr(), reward=_ptr(out.get('reward')), done=_ptr(out.get('done')),
+                       success=_ptr(out.get('success')))
+    with torch.cuda.device(self.device):
+      _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),
+                                               T, C.byref(o), self._stream()), 'earl_sawyer_rollout')
+    self.total_step_count += T
+    if self._cfg.goal_change_frequency:
+      self.lifelong_return_t += out['reward'].reshape(T, -1).sum(0, dtype=torch.float64)
+    self._last_success = out['success'][-1] if out['success'].dim() == 2 else out['success']
+
+  def _actions(self, action, lead):
+    a = torch.as_tensor(np.asarray(action, dtype=np.float32) if not torch.is_tensor(action) else action, device=self.device)
+    a = a.to(torch.float32).reshape(*lead, self.num_envs, 4).contiguous()
+    return a
+
+  # ------------------------------------------------------------------ gym-style API
+  def reset(self, mask=None):
+    """reset (masked) envs; returns obs [N,14] (numpy [14] with scalar_api)."""
+    obs = torch.empty(self.num_envs, self.OBS_DIM, dtype=torch.float64, device=self.device)
+    if mask is not None:
+      mask = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+      obs_prev = self._get_obs_t()
+    with torch.cuda.device(self.device):
+      _abi.check(self._lib.earl_sawyer_reset(self.model.buf.data_ptr(), self.nv, self._cfg_ref, self._st_ref,
+                                             self._reset_state[0].data_ptr(), self._reset_state[1].data_ptr(), _ptr(mask),
+                                             obs.data_ptr(), self._stream()), 'earl_sawyer_reset')
+    self._cfg.counter += 1
+    if mask is None:
+      self.interventions += 1
+    else:
+      self.interventions += mask.to(torch.int32)
+      obs = torch.where(mask.bool()[:, None], obs, obs_prev)
+    self.steps_since_goal_change.zero_()
+    return obs[0].cpu().numpy() if self.scalar_api else obs
+
+  def step(self, action, out=None):
+    out = out if out is not None else self._new_out(())
+    self._launch_rollout(self._actions(action, ()), 1, out)
+    if self.scalar_api:
+      return out['obs'][0].cpu().numpy(), float(out['reward'][0]), bool(out['done'][0]), {}
+    return out['obs'], out['reward'], out['done'], {'success': out['success']}
+
+  def rollout(self, actions, out=None):
+    """T steps in one launch: actions [T,N,4] -> dict of obs [T,N,14] f64, reward [T,N] f32, done / success [T,N] bool."""
+    a = torch.as_tensor(actions, device=self.device)
+    T = a.shape[0]
+    out = out if out is not None else self._new_out((T,))
+    self._launch_rollout(self._actions(a, (T,)), T, out)
+    return out
+
+  def _get_obs_t(self):
+    obs = torch.empty(self.num_envs, self.OBS_DIM, dtype=torch.float64, device=self.device)
+    with torch.cuda.device(self.device):
+      _abi.check(self._lib.earl_sawyer_observe(self.model.buf.data_ptr(), self.nv, self._cfg_ref, self._st_ref, obs.data_ptr(),
+                                               self._stream()), 'earl_sawyer_observe')
+    return obs
+
+  def _get_obs(self):
+    obs = self._get_obs_t()
+    return obs[0].cpu().numpy() if self.scalar_api else obs
+
+  get_obs = _get_obs
+
+  def _reward(self, obs):
+    o = torch.as_tensor(obs, device=self.device).to(torch.float64).reshape(-1, self.OBS_DIM).contiguous()
+    r = torch.empty(o.shape[0], dtype=torch.float32, device=self.device)
+    s = torch.empty(o.shape[0], dtype=torch.bool, device=self.device)
+    with torch.cuda.device(self.device):
+      _abi.check(self._lib.earl_sawyer_door_reward(self._cfg_ref, o.shape[0], o.data_ptr(), r.data_ptr(), s.data_ptr(), self._stream()),
+                 'earl_sawyer_door_reward')
+    return r, s
+
+  def compute_reward(self, obs, actions=None):
+    """reward of the given observation(s) (sawyer_door.py:141-171); batched: tensor [B]."""
+    del actions
+    r, _ = self._reward(obs)
+    return float(r[0]) if self.scalar_api and np.ndim(obs) == 1 else r
+
+  def is_successful(self, obs=None):
+    _, s = self._reward(self._get_obs_t() if obs is None else obs)
+    return bool(s[0]) if self.scalar_api and (obs is None or np.ndim(obs) == 1) else s
+
+  # ------------------------------------------------------------------ goals (sawyer_door.py:96-109)
+  def get_next_goal(self):
+    return self.goal_states[0]
+
+  def reset_goal(self, goal=None, mask=None):
+    g = torch.as_tensor(self.get_next_goal() if goal is None else goal, dtype=torch.float64, device=self.device)
+    g = g.expand(self.num_envs, 7)
+    if mask is None:
+      self.goal_t.copy_(g)
+    else:
+      m = torch.as_tensor(mask, device=self.device).bool()
+      self.goal_t[m] = g[m]
+
+  @property
+  def goal(self):
+    return self.goal_t[0].cpu().numpy() if self.scalar_api else self.goal_t
+
+  # ------------------------------------------------------------------ state access
+  def set_state(self, qpos, qvel):
+    self.qpos.copy_(torch.as_tensor(qpos, dtype=torch.float64, device=self.device).reshape(self.num_envs, self.nv))
+    self.qvel.copy_(torch.as_tensor(qvel, dtype=torch.float64, device=self.device).reshape(self.num_envs, self.nv))
+
+  def state_dict(self):
+    return {k: getattr(self, k).clone() for k in ('qpos', 'qvel', 'mocap_pos', 'goal_t', 'steps_since_reset', 'interventions',
+                                                  'steps_since_goal_change', 'lifelong_return_t')} | {
+                                                      'counter': int(self._cfg.counter), 'total_step_count': self.total_step_count}
+
+  def load_state_dict(self, sd):
+    for k in ('qpos', 'qvel', 'mocap_pos', 'goal_t', 'steps_since_reset', 'interventions', 'steps_since_goal_change',
+              'lifelong_return_t'):
+      getattr(self, k).copy_(sd[k])
+    self._cfg.counter = int(sd['counter'])
+    self.total_step_count = int(sd['total_step_count'])

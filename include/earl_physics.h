@@ -57,6 +57,65 @@ int earl_physics_forward(const earl_link_model* model, int32_t nv, int32_t n, co
                          const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc,
                          double* efc_force, double* att_xpos, earl_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Sawyer envs on the stepper.  Replaces, per env instance:
+ *   SawyerXYZEnv.step [UPSTREAM metaworld, not in the reference tree; behaviour per SURVEY.md Appendix D]:
+ *     mocap += clip(a[:3], -1, 1) * action_scale (float32 product), clipped to [mocap_low, mocap_high], mocap quat fixed;
+ *     ctrl = [a[3], -a[3]]; frame_skip timesteps;
+ *   SawyerDoorV2._get_obs          earl_benchmark/envs/sawyer_door.py:86-94   obs[14] = hand xyz, gripper opening, object xyz, goal[7]
+ *   SawyerDoorV2.compute_reward    earl_benchmark/envs/sawyer_door.py:141-171 (sparse: is_successful :173-177, radius 0.02)
+ *   PersistentStateWrapper.step    earl_benchmark/wrappers/persistent_state_wrapper.py:17-31  (done = steps_since_reset >= horizon)
+ *   SawyerDoorV2.reset_model       earl_benchmark/envs/sawyer_door.py:111-125 (settled hand pose, object angle init + U(lo, hi))
+ * obs is float64 like the reference's (the demonstrations store it as float32). */
+typedef struct earl_sawyer_cfg {
+  int32_t n, env_offset;
+  int32_t reward_type;                     /* 0 sparse, 1 dense (dense uses metaworld's tolerance(): unpinned) */
+  int32_t horizon;                         /* <= 0: never done */
+  int32_t frame_skip;
+  int32_t att_hand, att_right, att_left, att_obj;   /* attachment indices the observation reads */
+  int32_t obj_dof;                         /* dof re-initialised by reset (door hinge) */
+  double action_scale;
+  double mocap_low[3], mocap_high[3], mocap_quat[4];
+  double success_radius;
+  double hand_init_pos[3], obj_init_pos[3];
+  double obj_init_angle, angle_noise[2];
+  uint64_t seed, counter;                  /* reset draws: Philox(seed; global env id, counter) */
+} earl_sawyer_cfg;
+
+typedef struct earl_sawyer_state {
+  double* qpos;                 /* [n, nv] */
+  double* qvel;                 /* [n, nv] */
+  double* mocap_pos;            /* [n, 3] */
+  double* goal;                 /* [n, 7] */
+  int32_t* steps_since_reset;   /* [n] */
+} earl_sawyer_state;
+
+typedef struct earl_sawyer_out {
+  double* obs;        /* [T, n, 14] */
+  float* reward;      /* [T, n] */
+  uint8_t* done;      /* [T, n] */
+  uint8_t* success;   /* [T, n] is_successful(obs) */
+} earl_sawyer_out;
+
+/* T env steps of every env in ONE launch (state stays in LDS between steps).  action: float32 [T, n, 4]. */
+int earl_sawyer_rollout(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+                        const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream);
+
+/* reset the envs with mask[i] != 0 (mask NULL = all): state <- the settled post-_reset_hand state (reset_qpos / reset_qvel,
+ * [nv] each, device), object dof <- obj_init_angle + U(angle_noise), mocap <- hand_init_pos, counters cleared; obs [n,14]
+ * (may be NULL) is written for the reset envs only. */
+int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+                      const double* reset_qpos, const double* reset_qvel, const uint8_t* mask, double* obs,
+                      earl_stream_t stream);
+
+/* obs [n,14] of the CURRENT state (kinematics recomputed, nothing integrated): SawyerDoorV2._get_obs sawyer_door.py:86-94 */
+int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+                        double* obs, earl_stream_t stream);
+
+/* compute_reward / is_successful on caller-supplied observations [n,14] (sawyer_door.py:141-177); reward / success may be NULL */
+int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, float* reward, uint8_t* success,
+                            earl_stream_t stream);
+
 /* sizeof(earl_link_model) as compiled into the library (bindings check their struct layout against it) */
 int earl_physics_model_size(void);
 

@@ -212,15 +212,17 @@ def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
     p1, q1 = mocap_pos, mocap_quat / np.linalg.norm(mocap_quat)
     p2, q2 = kin['xpos'][b2], kin['xquat'][b2]
     Jb = body_jacobian(m, S, b2, p2)
-    rpos = p2 - p1                                            # relpose = identity (metaworld's reset_mocap_welds)
-    qe = quat_mul(quat_conj(q1), q2)                          # orientation of body2 in body1's frame
-    if qe[0] < 0:
-      qe = -qe
-    rrot = quat_mat(q1) @ qe[1:]                              # ~ half the rotation vector, world axes
+    # mj_instantiateEqual, weld with relpose = identity (metaworld's reset_mocap_welds): position error body1 - body2;
+    # orientation error = vec(conj(q2) * q1) with its exact Jacobian -0.5 (e_w a + a x e_v), a = R2^T w_j
+    rpos = p1 - p2
+    e = quat_mul(quat_conj(q2), q1)
+    R2 = quat_mat(q2)
     for a in range(3):
-      rows.append((Jb[3 + a], rpos[a], m.weld_solref[w], m.weld_solimp[w], m.body_invweight0[b2, 0], True))
+      rows.append((-Jb[3 + a], rpos[a], m.weld_solref[w], m.weld_solimp[w], m.body_invweight0[b2, 0], True))
+    A = R2.T @ Jb[0:3]                                        # 3 x nv, angular Jacobian in body2 axes
+    Jq = -0.5 * (e[0] * A + np.cross(A.T, e[1:]).T)
     for a in range(3):
-      rows.append((0.5 * Jb[a], rrot[a], m.weld_solref[w], m.weld_solimp[w], m.body_invweight0[b2, 1], True))
+      rows.append((Jq[a], e[1 + a], m.weld_solref[w], m.weld_solimp[w], m.body_invweight0[b2, 1], True))
   for j in range(m.nv):
     if m.jnt_limited[j]:
       lo, hi = m.jnt_range[j]
@@ -465,15 +467,19 @@ class LinkModel:
     J = np.zeros((6 + 2 * nv, nv)); res = np.zeros(6 + 2 * nv); active = np.zeros(6 + 2 * nv, bool)
     solref = [self.weld_solref[0]] * 6; solimp = [self.weld_solimp[0]] * 6
     invw = [self.weld_invweight[0]] * 3 + [self.weld_invweight[1]] * 3
-    for j in self.anc[self.att_link[k]]:
-      J[0:3, j] = S[j, 3:] + np.cross(S[j, :3], hp)
-      J[3:6, j] = 0.5 * S[j, :3]
+    # weld rows as mj_instantiateEqual builds them (body1 = mocap, body2 = hand, relpose = identity after metaworld's
+    # reset_mocap_welds): position error mocap - hand; orientation error = vector part of e = conj(q_hand) * q_mocap with
+    # the EXACT Jacobian of that vector part, 0.5 * vec(conj(q_hand) * [0, -w_j] * q_mocap) = -0.5 * (e_w a + a x e_v),
+    # a = R_hand^T w_j.  No sign flip for e_w < 0 (MuJoCo has none).
     q1 = mocap_quat / np.linalg.norm(mocap_quat)
-    qe = quat_mul(quat_conj(q1), hq)
-    if qe[0] < 0:
-      qe = -qe
-    res[0:3] = hp - mocap_pos
-    res[3:6] = quat_mat(q1) @ qe[1:]
+    e = quat_mul(quat_conj(hq), q1)
+    Rh = quat_mat(hq)
+    for j in self.anc[self.att_link[k]]:
+      J[0:3, j] = -(S[j, 3:] + np.cross(S[j, :3], hp))
+      a = Rh.T @ S[j, :3]
+      J[3:6, j] = -0.5 * (e[0] * a + np.cross(a, e[1:]))
+    res[0:3] = mocap_pos - hp
+    res[3:6] = e[1:]
     active[:6] = True
     for j in range(nv):
       J[6 + 2 * j, j], J[7 + 2 * j, j] = 1.0, -1.0

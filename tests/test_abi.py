@@ -45,6 +45,33 @@ def test_struct_layouts_match_the_header():
   assert out_fields == [f[0] for f in _abi.TabletopOut._fields_]
 
 
+def test_every_struct_layout_matches_what_gcc_sees(tmp_path):
+  """compile a probe against the public headers (plain C, as a foreign-language binding would) and compare sizeof /
+  offsetof of every struct with the ctypes mirrors"""
+  import subprocess
+  from earl_benchmark_amd.physics import LinkModelStruct
+  mirrors = {'earl_tabletop_cfg': _abi.TabletopCfg, 'earl_tabletop_state': _abi.TabletopState, 'earl_tabletop_out': _abi.TabletopOut,
+             'earl_motor_params': _abi.MotorParams, 'earl_link_model': LinkModelStruct, 'earl_sawyer_cfg': _abi.SawyerCfg,
+             'earl_sawyer_state': _abi.SawyerState, 'earl_sawyer_out': _abi.SawyerOut}
+  lines = []
+  for cname, cls in mirrors.items():
+    lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+    lines += [f'printf(" %zu", offsetof({cname}, {f[0]}));' for f in cls._fields_]
+    lines.append('printf("\\n");')
+  src = ('#include <stdio.h>\n#include <stddef.h>\n#include "earl_tabletop.h"\n#include "earl_glue.h"\n#include "earl_physics.h"\n'
+         'int main(void) {\n' + '\n'.join(lines) + '\nreturn 0; }\n')
+  c = tmp_path / 'probe.c'
+  c.write_text(src)
+  exe = tmp_path / 'probe'
+  subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(REPO, 'include'), '-o', str(exe), str(c)], check=True)
+  out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+  assert len(out) == len(mirrors)
+  for line, (cname, cls) in zip(out, mirrors.items()):
+    tok = line.split()
+    assert tok[0] == cname and int(tok[1]) == C.sizeof(cls), (cname, tok[1], C.sizeof(cls))
+    assert [int(x) for x in tok[2:]] == [getattr(cls, f[0]).offset for f in cls._fields_], cname
+
+
 def test_argument_validation_needs_no_gpu():
   lib = _abi.load()
   assert lib.earl_tabletop_step(None, None, None, None, None, None) == -1

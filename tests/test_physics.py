@@ -102,3 +102,25 @@ def test_reset_hand_settles_near_the_recorded_pose(m):
   hp, _ = lm.attachment(out['pos'], out['quat'], 0)
   assert np.abs(hp - [0.00591636, 0.39968333, 0.19493164]).max() < 6e-3
   assert (qpos[1] <= -0.5 + 1e-3) and abs(qpos[7]) < 1e-3       # joint limit respected, claw held at its stop
+
+
+def test_gripper_opening_of_the_demonstrations_pins_the_claw_dynamics():
+  """The first 12 env steps of each demonstration episode happen before the gripper touches the handle, so the recorded
+  gripper opening obs[3] depends only on smooth dynamics: position actuators (kp 400), armature 100, damping 1000 integrated
+  implicitly, joint limits, frame_skip 5 and the one-timestep lag of mj_step's kinematics.  The restatement reproduces
+  those MuJoCo outputs to 1e-4 (float32 storage of the demos: 6e-8); the hand path only loosely (transient-sensitive)."""
+  from oracle.sawyer_oracle import SawyerDoorOracle
+  lm = po.LinkModel(LINKS)
+  z = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'demonstrations', 'sawyer_door', 'forward', 'demo_data.npz'))
+  ends = np.nonzero(z['terminals'].ravel())[0]
+  env = SawyerDoorOracle(lm)
+  obs0 = env.reset()
+  assert np.abs(obs0[:3] - z['observations'][0][:3]).max() < 6e-3 and obs0[3] == 1.0
+  for s in (0, int(ends[0]) + 1):
+    env.reset()
+    for t in range(12):
+      o, r, done, ok = env.step(z['actions'][s + t])
+      want = z['next_observations'][s + t]
+      assert abs(o[3] - want[3]) < 1e-4, (s, t, o[3], want[3])
+      assert np.abs(o[:3] - want[:3]).max() < 2.5e-2
+      assert float(r) == float(z['rewards'][s + t, 0])
