@@ -18,6 +18,7 @@ MODEL_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 
 class LinkModelStruct(C.Structure):   # struct earl_link_model
   _fields_ = [('nv', C.c_int32), ('n_att', C.c_int32), ('n_act', C.c_int32), ('weld_att', C.c_int32),
+              ('n_jump', C.c_int32), ('pad_', C.c_int32 * 3), ('jump', C.c_int32 * MAXV * 4),
               ('parent', C.c_int32 * MAXV), ('jtype', C.c_int32 * MAXV), ('limited', C.c_int32 * MAXV),
               ('anc_mask', C.c_uint32 * MAXV), ('desc_mask', C.c_uint32 * MAXV), ('att_link', C.c_int32 * MAXATT),
               ('act_joint', C.c_int32 * MAXACT),
@@ -52,6 +53,22 @@ def load_link_model(name):
       anc[l] |= np.uint32(1 << p)
       p = int(d['parent'][p])
   desc = np.array([sum(1 << i for i in range(nv) if (anc[i] >> l) & 1) for l in range(nv)], np.uint32)
+  # ancestor doubling tables for the log-depth kinematics
+  par = [int(x) for x in d['parent']]
+  depth = [bin(int(a)).count('1') for a in anc]
+  s.n_jump = max(1, int(np.ceil(np.log2(max(depth)))))
+  assert s.n_jump <= 4
+  jump = np.full((4, MAXV), -1, np.int32)
+  for l in range(nv):
+    chain = []
+    p = par[l]
+    while p >= 0:
+      chain.append(p)
+      p = par[p]
+    for r in range(4):
+      if len(chain) >= (1 << r):
+        jump[r, l] = chain[(1 << r) - 1]
+  _fill(s.jump, jump)
   for dst, src in ((s.parent, d['parent']), (s.jtype, d['jtype']), (s.limited, d['jnt_limited']), (s.anc_mask, anc),
                    (s.desc_mask, desc), (s.att_link, d['att_link']), (s.act_joint, d['act_joint']), (s.tpos, d['tpos']),
                    (s.tquat, d['tquat']), (s.jaxis, d['jaxis']), (s.jpos, d['jpos']), (s.mass, d['mass']), (s.com, d['com']),

@@ -27,6 +27,8 @@ extern "C" {
 
 typedef struct earl_link_model {
   int32_t nv, n_att, n_act, weld_att;      /* weld_att: attachment welded to the mocap body */
+  int32_t n_jump, pad_[3];                 /* rounds of ancestor doubling the kinematics needs: ceil(log2(max depth)) */
+  int32_t jump[4][EARL_MAXV];              /* jump[r][l]: ancestor of link l at distance 2^r, -1 if none */
   int32_t parent[EARL_MAXV];               /* -1 = world */
   int32_t jtype[EARL_MAXV];                /* 0 hinge, 1 slide */
   int32_t limited[EARL_MAXV];
@@ -115,6 +117,10 @@ int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_saw
 /* compute_reward / is_successful on caller-supplied observations [n,14] (sawyer_door.py:141-177); reward / success may be NULL */
 int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, float* reward, uint8_t* success,
                             earl_stream_t stream);
+
+/* measurement switch: lanes of a wavefront that work on one env instance -- 16 (default: four envs per wavefront) or 64 (one
+ * wavefront per env).  Results are identical; DESIGN.md quotes both timings. */
+int earl_debug_set_physics_lanes(int lanes_per_env);
 
 /* sizeof(earl_link_model) as compiled into the library (bindings check their struct layout against it) */
 int earl_physics_model_size(void);

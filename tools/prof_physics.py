@@ -1,0 +1,51 @@
+"""Per-phase cycle counts of one timestep of the articulated-body stepper (wave 0, lane 0; s_memtime-class counter).
+Build (here or on the GPU box):  python tools/prof_physics.py --build     Run (GPU): python tools/prof_physics.py [N]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'tools', 'ubench', 'libearl_physprof.so')
+FLAGS = '--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -DEARL_PHYS_PROF'
+NAMES = ['K1-2 joint + world transforms', 'K3 subspace + inertia', '-', 'K4 composite inertia', 'K5 mass matrix', 'K6-7 RNE + tau', 'K8 constraint rows', '-',
+         'K9 Hessian + active-set Newton', '-', '-', 'K10 Euler']
+
+
+def build():
+  src = os.path.join(ROOT, 'earl_benchmark_amd', 'csrc', 'physics.hip')
+  subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-o', LIB, src], check=True)
+
+
+def main():
+  if '--build' in sys.argv:
+    return build()
+  import numpy as np
+  import torch
+  sys.path.insert(0, ROOT)
+  from earl_benchmark_amd import physics
+  n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+  nsub = 5
+  lib = C.CDLL(LIB)
+  s, _ = physics.load_link_model('sawyer_door')
+  buf = torch.from_numpy(np.frombuffer(bytes(s), dtype=np.uint8).copy()).cuda()
+  rng = np.random.default_rng(0)
+  qpos = rng.uniform(-0.3, 0.3, size=(n, 10)); qpos[:, 1] = -1.0; qpos[:, 7] = 0.02; qpos[:, 8] = -0.02; qpos[:, 9] = -1.0
+  t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+  dq, dv = t(qpos), torch.zeros(n, 10, dtype=torch.float64, device='cuda')
+  mp = t(np.tile([0.0, 0.6, 0.2], (n, 1))); mq = t(np.tile([1.0, 0, 1, 0], (n, 1))); ctrl = t(rng.uniform(-1, 1, size=(n, 2)))
+  args = [C.c_void_p(buf.data_ptr()), C.c_int32(10), C.c_int32(n), C.c_int32(nsub)] + [C.c_void_p(x.data_ptr()) for x in (dq, dv, mp, mq, ctrl)] + [None, None]
+  out = (C.c_ulonglong * 32)()
+  for rep in range(3):
+    lib.earl_physics_step(*args)
+    torch.cuda.synchronize()
+    lib.earl_debug_read_phys_profile(out, 1)
+  tot = sum(out[:12])
+  print(f'N={n}: cycles per timestep of wave 0 (= 4 envs at 16 lanes per env), total {tot / nsub:.0f}')
+  for i, nm in enumerate(NAMES):
+    if nm != '-':
+      print(f'  {nm:32s} {out[i] / nsub:9.0f}  {100.0 * out[i] / tot:5.1f} %')
+
+
+if __name__ == '__main__':
+  main()
