@@ -40,6 +40,8 @@ def parse():
   p.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
   p.add_argument('--cpu-seconds', type=float, default=10.0)
   p.add_argument('--no-step-api', action='store_true')
+  p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door'],
+                 help='tabletop = BASELINE configs[1] (the default, the quoted metric); sawyer_door = configs[2] shape, N=8192 (next row)')
   return p.parse_args()
 
 
@@ -162,6 +164,89 @@ def cpu_baseline(n, T, reward, seconds):
           'scalar_python_loop_1env': scalar_rate}
 
 
+def sawyer_cpu_baseline(T_sample, seconds):
+  """the numpy restatement of the same stepper (oracle/sawyer_oracle.py), one env, one thread, bounded sample"""
+  import numpy as np
+  from oracle import physics_oracle as po
+  from oracle.sawyer_oracle import SawyerDoorOracle
+  lm = po.LinkModel(os.path.join(REPO, 'earl_benchmark_amd', 'models', 'sawyer_door_links.npz'))
+  env = SawyerDoorOracle(lm)
+  env.reset()
+  rng = np.random.default_rng(0)
+  acts = rng.uniform(-1, 1, size=(T_sample, 4)).astype(np.float32)
+  t0 = time.perf_counter()
+  k = 0
+  while k < T_sample and time.perf_counter() - t0 < seconds:
+    env.step(acts[k])
+    k += 1
+  dt = time.perf_counter() - t0
+  return {'value': k / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+          'sample': f'{k} env steps (5 timesteps each) of one env through the numpy restatement of the same stepper '
+                    '(oracle/sawyer_oracle.py); MuJoCo itself is not available on this host'}
+
+
+def main_sawyer(a, torch, dist, world, rank, device):
+  """BASELINE configs[2] shape (Sawyer door half): N envs per GPU, reset + one fused T-step rollout per bench step.
+  The dynamics are this build's own stepper (no contacts yet, parity with MuJoCo unpinned) -- see DESIGN.md."""
+  from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
+  from earl_benchmark_amd.wrappers import PersistentStateWrapper
+  from earl_benchmark_amd import sharding
+  n = a.envs if a.envs != 4096 else 8192
+  T = a.horizon if a.horizon != 200 else 300
+  kw = sharding.shard_kwargs(n * world, rank, world) if world > 1 else {}
+  env = PersistentStateWrapper(SawyerDoor(reward_type=a.reward, num_envs=n, seed=1234, env_offset=kw.get('env_offset', rank * n)), T)
+  g = torch.Generator(device=device).manual_seed(99 + rank)
+  acts = (torch.rand(T, n, 4, generator=g, device=device) * 2 - 1).to(torch.float32)
+  out = env.unwrapped._new_out((T,))
+  stream = torch.cuda.current_stream()
+
+  def step():
+    env.reset()
+    env.rollout(acts, out=out)
+  for _ in range(a.warmup):
+    step()
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  e0.record(stream)
+  for _ in range(a.steps):
+    step()
+  e1.record(stream)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  dt = time.perf_counter() - t0
+  gpu_ms = e0.elapsed_time(e1) / a.steps
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  assert bool(out['done'][-1].all()) and not bool(out['done'][:-1].any()) and bool(torch.isfinite(out['obs']).all())
+  if rank == 0:
+    bytes_per_env_step = 16 + 14 * 8 + 4 + 1 + 1          # action + obs (f64) + reward + done + success
+    per_launch = n * (T * bytes_per_env_step + 2 * (2 * 10 * 8 + 3 * 8) + 7 * 8 + 4 * 2)
+    achieved = per_launch / (gpu_ms * 1e-3) / 1e9
+    res = {'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': a.steps * n * T * world / dt, 'unit': 'env-steps/s',
+           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': f'sawyer_door {a.reward} reward, {n} batched envs per MI355X, reset + fused {T}-step rollout '
+                                  f'(5 timesteps per env step) per bench step; own stepper: weld + joint limits, NO contacts yet',
+                      'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
+                      'parallelism': f'env-range shard x{world}, no per-step collective'},
+           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                        'traffic': None, 'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
+                        'algorithmic_bytes_per_launch': per_launch, 'bytes_per_env_step': bytes_per_env_step,
+                        'note': 'not HBM-bound: fp64 VALU issue bound (about 26k cycles per timestep per wavefront of 4 envs, '
+                                'tools/prof_physics.py); the HBM figure is reported because the schema asks for it'},
+           'cpu_baseline': None if a.no_cpu else sawyer_cpu_baseline(200, a.cpu_seconds)}
+    print(json.dumps(res), flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
   a = parse()
   import torch
@@ -180,6 +265,8 @@ def main():
   if world > 1:
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group('nccl', device_id=torch.device(device))
+  if a.workload == 'sawyer_door':
+    return main_sawyer(a, torch, dist, world, rank, device)
   n, T = a.envs, a.horizon
 
   env = make_env(torch, n, T, a.reward, rank, device)
