@@ -75,11 +75,12 @@ SIGNATURES = {
     'earl_minitaur_motor_torque': [C.c_int32, _P(MotorParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_minitaur_reward': [C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
     # include/earl_physics.h
-    'earl_physics_step': [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7,
-    'earl_physics_forward': [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9,
+    'earl_physics_step': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7,
+    'earl_physics_forward': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9,
     'earl_physics_model_size': [],
+    'earl_collision_model_size': [],
     'earl_debug_set_physics_lanes': [C.c_int],
-    'earl_sawyer_rollout': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_int32, _P(SawyerOut), C.c_void_p],
+    'earl_sawyer_rollout': [C.c_void_p, C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_int32, _P(SawyerOut), C.c_void_p],
     'earl_sawyer_reset': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState)] + [C.c_void_p] * 5,
     'earl_sawyer_observe': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_void_p],
     'earl_sawyer_door_reward': [_P(SawyerCfg), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],

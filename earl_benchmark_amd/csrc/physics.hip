@@ -43,7 +43,9 @@ __device__ unsigned long long g_phys_prof[32];
     p_last = t_;                                                                           \
   } while (0)
 #define PSTART() unsigned long long p_last = __builtin_readcyclecounter()
+#define PCOUNT(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phys_prof[i] += (v); } while (0)
 #else
+#define PCOUNT(i, v) do {} while (0)
 #define PSTAMP(i) do {} while (0)
 #define PSTART() do {} while (0)
 #endif
@@ -152,6 +154,7 @@ struct Shared {
   double M[NV][NV];
   double tau[NV];
   double att[4][3];
+  double ct[EARL_MAXCON][10];        // contact records: dist, normal (3), point (3), class, sphere link, box link
   union {
     struct { double Xq1[NV][4], Xp1[NV][4]; } k2;                    // second buffer of the doubling
     struct {
@@ -161,7 +164,12 @@ struct Shared {
         struct { double V[NV][6], Cc[NV][6], F[NV][6]; } rne;
       };
     } dyn;
-    struct { double J6[6][NV], wD[8], war[8], Hw[NV][NV], rw[NV], dl[NV], rl[NV], rhs2[NV]; } con;
+    struct {
+      double J6[6][NV], wD[8], war[8], Hw[NV][NV], rw[NV], dl[NV], rl[NV], rhs2[NV];
+      double CJ[EARL_MAXCON][3][NV];   // contact Jacobians: normal, tangent 1, tangent 2
+      double cw[EARL_MAXCON][8];       // per-iteration weights of the active pyramid edges
+      double Hc[NV][NV], rc[NV];
+    } con;
   };
 };
 
@@ -202,11 +210,32 @@ __device__ __forceinline__ void solve_regs(const double (&L)[NV * (NV + 1) / 2],
   }
 }
 
+// block table of the collision model (bounding tests), staged once per workgroup
+struct BlkTable {
+  int n_blk, pad_;
+  int begin[EARL_MAXBLK], end[EARL_MAXBLK], box[EARL_MAXBLK], link[EARL_MAXBLK], box_link[EARL_MAXBLK];
+  double center[EARL_MAXBLK][3], reach[EARL_MAXBLK], box_pos[EARL_MAXBLK][3], box_quat[EARL_MAXBLK][4], box_half[EARL_MAXBLK][3];
+};
+__device__ __forceinline__ void stage_blocks(BlkTable& t, const earl_collision_model* __restrict__ col) {
+  const int i = threadIdx.x;
+  if (i == 0) t.n_blk = col ? col->n_blk : 0;
+  if (col && i < col->n_blk) {
+    const int b = col->blk_box[i];
+    t.begin[i] = col->blk_begin[i]; t.end[i] = col->blk_end[i]; t.box[i] = b; t.link[i] = col->blk_link[i];
+    t.box_link[i] = col->box_link[b]; t.reach[i] = col->blk_reach[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { t.center[i][k] = col->blk_center[i][k]; t.box_pos[i][k] = col->box_pos[b][k]; t.box_half[i][k] = col->box_half[b][k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t.box_quat[i][k] = col->box_quat[b][k];
+  }
+}
+
 // One timestep of one env by its LPE-lane group (`sub` = lane within the group; every lane of the wave runs this, the
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
 template <int NV, int LPE, bool INTEGRATE>
-__device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m, const int sub, const V3 mpos, const Q4 mq,
-                                        const double (&ctrl)[EARL_MAXACT], double* qacc_out, double* efc_out) {
+__device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m, const BlkTable& bt, const earl_collision_model* __restrict__ col, const int sub,
+                                        const int grp, const V3 mpos, const Q4 mq, const double (&ctrl)[EARL_MAXACT], double* qacc_out,
+                                        double* efc_out) {
   static_assert(NV <= LPE, "one lane per link");
   const double dt = m.dt;
   const bool isl = sub < NV;
@@ -256,6 +285,49 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       }
       fence();
     }
+  }
+  // ------------------------------------------------------------------ C0: collision bounding tests (world frames are final)
+  unsigned int nearw = 0;                              // blocks with a near bounding test in ANY env of the wave
+  unsigned int nearg = 0;                              // ... in this env
+  if (bt.n_blk > 0) {
+    // C0: bounding test per block, lane = block
+    const int b = sub < bt.n_blk ? sub : 0;
+    const int bl = bt.link[b], xl = bt.box_link[b];
+    V3 cs = ld3(bt.center[b]), cb = ld3(bt.box_pos[b]);
+    Q4 qb = ldq(bt.box_quat[b]);
+    {
+      double R[3][3];
+      qmat(ldq(s.Xq[bl < 0 ? 0 : bl]), R);
+      const V3 w = add(ld3(s.Xp[bl < 0 ? 0 : bl]), mulv(R, cs));
+      cs = bl < 0 ? cs : w;
+      const Q4 ql = ldq(s.Xq[xl < 0 ? 0 : xl]);
+      qmat(ql, R);
+      const V3 w2 = add(ld3(s.Xp[xl < 0 ? 0 : xl]), mulv(R, cb));
+      const Q4 q2 = qmul(ql, qb);
+      cb = xl < 0 ? cb : w2;
+      qb = xl < 0 ? qb : q2;
+    }
+    // distance from the set's bounding-sphere centre to the box (in the box frame) against the set radius + margin
+    double Rb[3][3];
+    qmat(qb, Rb);
+    const V3 x = mulvT(Rb, vsub(cs, cb)), h = ld3(bt.box_half[b]);
+    const V3 d{x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z)};
+    const bool nearb = sub < bt.n_blk && dot(d, d) < bt.reach[b] * bt.reach[b];
+    const unsigned long long bal = __ballot(nearb);
+    nearg = LPE == 64 ? (unsigned int)bal : (unsigned int)((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull));
+    nearw = LPE == 64 ? (unsigned int)bal : (unsigned int)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+  }
+  // prefetch this lane's pair record of the first near block: its latency hides behind K3-K7
+  int pf_blk = -1, pf_link = -1, pf_cls = 0;
+  double pf_r = 0, pf_margin = 0;
+  V3 pf_pos{0, 0, 0};
+  if (nearw) {
+    pf_blk = __builtin_ctz(nearw);
+    const int pend = bt.end[pf_blk], pi0 = bt.begin[pf_blk] + sub;
+    const int pi = pi0 < pend ? pi0 : pend - 1;
+    pf_link = col->pair_rec[pi].sph_link; pf_cls = col->pair_rec[pi].cls;
+    pf_r = col->pair_rec[pi].r; pf_margin = col->pair_rec[pi].margin;
+    pf_pos = ld3(col->pair_rec[pi].pos);
   }
   PSTAMP(0);
   // ------------------------------------------------------------------ K3: motion subspace + compact spatial inertia
@@ -381,8 +453,91 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       }
     if (isl) s.tau[l] = t;
   }
-  fence();                                             // dyn.* is dead from here on; con.* takes its place
+  fence();                                             // dyn.* is dead from here on; col.* then con.* take its place
   PSTAMP(5);
+  // ------------------------------------------------------------------ C1-C2: collision (reference: LinkModel.collide)
+  int nct = 0;                                         // contacts of this env (same value in every lane of the group)
+  if (nearw) {
+    // C2: pair tests of the near blocks, in pair order; the box frame once per block, the sphere centre per test
+    for (unsigned int rest = nearw; rest; rest &= rest - 1u) {
+      const int b = __builtin_ctz(rest);
+      const bool mine = (nearg >> b) & 1u;
+      const int pend = bt.end[b], xl = bt.box_link[b];
+      V3 pb = ld3(bt.box_pos[b]);
+      Q4 qb = ldq(bt.box_quat[b]);
+      if (xl >= 0) {                                    // uniform over the wave
+        const Q4 ql = ldq(s.Xq[xl]);
+        double R[3][3];
+        qmat(ql, R);
+        pb = add(ld3(s.Xp[xl]), mulv(R, pb));
+        qb = qmul(ql, qb);
+      }
+      double Rb[3][3];
+      qmat(qb, Rb);
+      const V3 h = ld3(bt.box_half[b]);
+      for (int base = bt.begin[b]; base < pend; base += LPE) {
+        const int pi = base + sub < pend ? base + sub : pend - 1;
+        const bool valid = mine && base + sub < pend;
+        int lk, cls;
+        double r, margin;
+        V3 c;
+        if (b == pf_blk && base == bt.begin[b]) {       // uniform: the record prefetched after C0
+          lk = pf_link; cls = pf_cls; r = pf_r; margin = pf_margin; c = pf_pos;
+        } else {
+          lk = col->pair_rec[pi].sph_link; cls = col->pair_rec[pi].cls;
+          r = col->pair_rec[pi].r; margin = col->pair_rec[pi].margin;
+          c = ld3(col->pair_rec[pi].pos);
+        }
+        {
+          double R[3][3];
+          qmat(ldq(s.Xq[lk < 0 ? 0 : lk]), R);
+          const V3 w = add(ld3(s.Xp[lk < 0 ? 0 : lk]), mulv(R, c));
+          c = lk < 0 ? c : w;
+        }
+        const V3 x = mulvT(Rb, vsub(c, pb));
+        V3 q{fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z)};
+        const bool outside = fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z;
+        double dist;
+        V3 nl;
+        {
+          const V3 d = vsub(x, q);
+          const double d2 = dot(d, d);
+          const double inv = rsq_nr(outside ? d2 : 1.0);
+          // inside: leave through the nearest face (first minimum of h - |x|)
+          const double gx = h.x - fabs(x.x), gy = h.y - fabs(x.y), gz = h.z - fabs(x.z);
+          const int ax = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
+          const double xa = pick3(x, ax), ha = pick3(h, ax), sg = xa >= 0 ? 1.0 : -1.0;
+          const V3 ni{ax == 0 ? sg : 0.0, ax == 1 ? sg : 0.0, ax == 2 ? sg : 0.0};
+          const V3 qi{ax == 0 ? sg * ha : x.x, ax == 1 ? sg * ha : x.y, ax == 2 ? sg * ha : x.z};
+          dist = outside ? d2 * inv - r : -(ha - fabs(xa)) - r;
+          nl = outside ? scl(d, inv) : ni;
+          q = outside ? q : qi;
+        }
+        const bool hit = valid && dist < margin;
+        const unsigned long long bal = __ballot(hit);
+        const unsigned int gb = LPE == 64 ? 0u : (unsigned int)((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull));
+        const int before = LPE == 64 ? __popcll(bal & ((1ull << sub) - 1ull)) : __popc(gb & ((1u << sub) - 1u));
+        const int total = LPE == 64 ? __popcll(bal) : __popc(gb);
+        const int slot = nct + before;
+        if (hit && slot < EARL_MAXCON) {
+          const V3 n = mulv(Rb, nl);
+          const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
+          double* o = s.ct[slot];
+          o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
+          o[7] = (double)cls; o[8] = (double)lk; o[9] = (double)xl;
+        }
+        nct = nct + total < EARL_MAXCON ? nct + total : EARL_MAXCON;
+      }
+    }
+    fence();
+  }
+  // most over the wave (uniform loop bound for the contact phases)
+  PCOUNT(20, 1); PCOUNT(21, nearw ? 1 : 0); PCOUNT(22, __popc(nearw));
+  int ncmax = 0;
+  if (nearw && __any(nct > 0)) {
+#pragma unroll
+    for (int k = 0; k < EARL_MAXCON; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
+  }
   // ------------------------------------------------------------------ K8: constraint rows
   double Jc[6];                                        // this lane's column of the weld Jacobian
   V3 rpos, rrot;
@@ -440,6 +595,54 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     lim_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
     lim_aref = -bb * (lim_side * s.qv[l]) - kk * dd * res;
   }
+  // ------------------------------------------------------------------ C3: contact rows (reference: LinkModel.contact_rows)
+  double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};       // lane c (< nct) owns contact c: edge weights and reference accelerations
+  unsigned int cact = 0;                               // active pyramid edges of that contact (bits 0..3)
+  if (ncmax > 0) {
+    for (int c = 0; c < ncmax; ++c) {
+      const double* rec = s.ct[c];
+      const bool cv = c < nct;
+      const V3 n = cv ? ld3(rec + 1) : V3{0, 0, 1}, p = cv ? ld3(rec + 4) : V3{0, 0, 0};
+      const int ls = cv ? (int)rec[8] : -1, lb = cv ? (int)rec[9] : -1;
+      // tangents: n x (the coordinate axis least aligned with n), normalised, then n x t1
+      const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
+      const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
+      const V3 e{ia == 0 ? 1.0 : 0.0, ia == 1 ? 1.0 : 0.0, ia == 2 ? 1.0 : 0.0};
+      V3 t1 = cross(n, e);
+      t1 = scl(t1, rsq_nr(dot(t1, t1)));
+      const V3 t2 = cross(n, t1);
+      const double w = ((ls >= 0 && ((m.anc_mask[ls < 0 ? 0 : ls] >> l) & 1u)) ? 1.0 : 0.0) - ((lb >= 0 && ((m.anc_mask[lb < 0 ? 0 : lb] >> l) & 1u)) ? 1.0 : 0.0);
+      const V3 Jp = scl(add(Sv, cross(Sw, p)), w);
+      if (isl && cv) {
+        s.con.CJ[c][0][l] = dot(n, Jp);
+        s.con.CJ[c][1][l] = dot(t1, Jp);
+        s.con.CJ[c][2][l] = dot(t2, Jp);
+      }
+    }
+    fence();
+    {
+      const int c = sub < EARL_MAXCON ? sub : EARL_MAXCON - 1;
+      const bool cv = sub < nct;
+      double vn = 0, vt1 = 0, vt2 = 0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const double qd = s.qv[j];
+        vn = fma(s.con.CJ[c][0][j], qd, vn); vt1 = fma(s.con.CJ[c][1][j], qd, vt1); vt2 = fma(s.con.CJ[c][2][j], qd, vt2);
+      }
+      const double* rec = s.ct[c];
+      const int cls = cv ? (int)rec[7] : 0;
+      const double margin = col->cls_margin[cls];
+      cmu = col->cls_mu[cls];
+      double kk, bb, dd;
+      kbimp(col->cls_solref[cls], col->cls_solimp[cls], rec[0] - margin, dt, kk, bb, dd);
+      const double R0 = fmax((1 - dd) * col->cls_invw[cls] * rcp_nr(dd), 1e-15);
+      cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
+      const double basea = -kk * dd * (rec[0] - margin);
+      car[0] = -bb * (vn + cmu * vt1) + basea; car[1] = -bb * (vn - cmu * vt1) + basea;
+      car[2] = -bb * (vn + cmu * vt2) + basea; car[3] = -bb * (vn - cmu * vt2) + basea;
+      cact = cv ? 0xFu : 0u;
+    }
+  }
   fence();
   PSTAMP(6);
   // ------------------------------------------------------------------ K9: Hessian of the equality part, then the active-set Newton
@@ -455,25 +658,58 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       double h = s.M[i][l];
 #pragma unroll
       for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
+      if (i == l) h += m.drag_G[l];                     // soft velocity row of a permanent dragging contact
       if (isl) s.con.Hw[i][l] = h;
     }
+    g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
     if (isl) s.con.rw[l] = g;
   }
   bool act = lim_inst;
   double a[NV];
   double L[NV * (NV + 1) / 2];
+  PCOUNT(23, ncmax > 0 ? 1 : 0); PCOUNT(24, ncmax);
   for (int it = 0; it < 8; ++it) {
+    PCOUNT(25, 1);
     if (isl) {
       s.con.dl[l] = act ? lim_D : 0.0;
       s.con.rl[l] = act ? lim_D * lim_aref * lim_side : 0.0;
+    }
+    if (ncmax > 0 && sub < EARL_MAXCON) {
+      // edges (n + mu t1, n - mu t1, n + mu t2, n - mu t2): sum_e D a_e u_e u_e' on (Jn, Jt1, Jt2) and sum_e D a_e aref_e u_e
+      const double a1 = (cact & 1u) ? cD : 0.0, a2 = (cact & 2u) ? cD : 0.0, a3 = (cact & 4u) ? cD : 0.0, a4 = (cact & 8u) ? cD : 0.0;
+      double* w = s.con.cw[sub];
+      w[0] = a1 + a2 + a3 + a4; w[1] = cmu * (a1 - a2); w[2] = cmu * (a3 - a4); w[3] = cmu * cmu * (a1 + a2); w[4] = cmu * cmu * (a3 + a4);
+      w[5] = a1 * car[0] + a2 * car[1] + a3 * car[2] + a4 * car[3];
+      w[6] = cmu * (a1 * car[0] - a2 * car[1]);
+      w[7] = cmu * (a3 * car[2] - a4 * car[3]);
+    }
+    fence();
+    {
+      double hcol[NV], rr = s.con.rw[l];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) hcol[i] = s.con.Hw[i][l];
+      for (int c = 0; c < ncmax; ++c) {
+        const double* w = s.con.cw[c];
+        const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
+        const bool cv = c < nct;
+        const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+        rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+      }
+      if (isl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s.con.Hc[i][l] = hcol[i];
+        s.con.rc[l] = rr;
+      }
     }
     fence();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
 #pragma unroll
-      for (int j = 0; j < i; ++j) L[i * (i + 1) / 2 + j] = s.con.Hw[i][j];
-      L[i * (i + 1) / 2 + i] = s.con.Hw[i][i] + s.con.dl[i];
-      a[i] = s.con.rw[i] + s.con.rl[i];
+      for (int j = 0; j < i; ++j) L[i * (i + 1) / 2 + j] = s.con.Hc[i][j];
+      L[i * (i + 1) / 2 + i] = s.con.Hc[i][i] + s.con.dl[i];
+      a[i] = s.con.rc[i] + s.con.rl[i];
     }
     chol_regs<NV>(L);
     solve_regs<NV>(L, a);
@@ -481,8 +717,24 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
 #pragma unroll
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
     const bool want = lim_inst && (lim_side * al - lim_aref < 0);
-    const bool changed = want != act;
+    bool changed = want != act;
     act = want;
+    if (ncmax > 0) {
+      const int c = sub < EARL_MAXCON ? sub : EARL_MAXCON - 1;
+      double an = 0, at1 = 0, at2 = 0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        an = fma(s.con.CJ[c][0][j], a[j], an); at1 = fma(s.con.CJ[c][1][j], a[j], at1); at2 = fma(s.con.CJ[c][2][j], a[j], at2);
+      }
+      unsigned int nb = 0;
+      nb |= (an + cmu * at1 - car[0] < 0) ? 1u : 0u;
+      nb |= (an - cmu * at1 - car[1] < 0) ? 2u : 0u;
+      nb |= (an + cmu * at2 - car[2] < 0) ? 4u : 0u;
+      nb |= (an - cmu * at2 - car[3] < 0) ? 8u : 0u;
+      nb = sub < nct ? nb : 0u;
+      changed = changed || nb != cact;
+      cact = nb;
+    }
     fence();
     if (!__any(changed)) break;
   }
@@ -566,6 +818,7 @@ __device__ __forceinline__ void stage_model(earl_link_model& dst, const earl_lin
 
 struct PArgs {
   const earl_link_model* m;
+  const earl_collision_model* col;
   int n, nsub;
   double* qpos; double* qvel;
   const double* mocap_pos; const double* mocap_quat; const double* ctrl;
@@ -576,7 +829,9 @@ template <int NV, int LPE, bool INTEGRATE>
 __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
   constexpr int EPW = 64 / LPE;
   __shared__ earl_link_model m;
+  __shared__ BlkTable bt;
   __shared__ Shared<NV> sh[EPW];
+  stage_blocks(bt, a.col);
   stage_model(m, a.m);
   const int lane = threadIdx.x, sub = lane % LPE, grp = lane / LPE;
   const int env_raw = blockIdx.x * EPW + grp;
@@ -594,7 +849,7 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
   for (int ac = 0; ac < m.n_act; ++ac) ctrl[ac] = a.ctrl[(size_t)env * m.n_act + ac];
   constexpr int NC = 6 + 2 * NV;
   for (int ts = 0; ts < a.nsub; ++ts)
-    substep<NV, LPE, INTEGRATE>(s, m, sub, mpos, mq, ctrl, (a.qacc_out && live) ? a.qacc_out + (size_t)env * NV : nullptr,
+    substep<NV, LPE, INTEGRATE>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, (a.qacc_out && live) ? a.qacc_out + (size_t)env * NV : nullptr,
                                 (a.efc_out && live) ? a.efc_out + (size_t)env * NC : nullptr);
   if constexpr (INTEGRATE) {
     if (sub < NV && live) {
@@ -613,6 +868,7 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
 // ------------------------------------------------------------------------------------------------ Sawyer env kernels
 struct SawyerArgs {
   const earl_link_model* m;
+  const earl_collision_model* col;
   earl_sawyer_cfg cfg;
   earl_sawyer_state st;
   const float* action; int T;
@@ -683,7 +939,9 @@ __global__ __launch_bounds__(64) void sawyer_rollout_kernel(const SawyerArgs a) 
   static_assert(LPE >= 14, "the observation is written by 14 lanes");
   constexpr int EPW = 64 / LPE;
   __shared__ earl_link_model m;
+  __shared__ BlkTable bt;
   __shared__ Shared<NV> sh[EPW];
+  stage_blocks(bt, a.col);
   stage_model(m, a.m);
   const earl_sawyer_cfg& cfg = a.cfg;
   const int lane = threadIdx.x, sub = lane % LPE, grp = lane / LPE, n = cfg.n;
@@ -708,7 +966,7 @@ __global__ __launch_bounds__(64) void sawyer_rollout_kernel(const SawyerArgs a) 
     mpos.y = fmin(fmax(mpos.y + (double)cy, cfg.mocap_low[1]), cfg.mocap_high[1]);
     mpos.z = fmin(fmax(mpos.z + (double)cz, cfg.mocap_low[2]), cfg.mocap_high[2]);
     const double ctrl[EARL_MAXACT] = {(double)act.w, -(double)act.w, 0, 0};
-    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, sub, mpos, mq, ctrl, nullptr, nullptr);
+    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
     const size_t row = (size_t)t * n + env;
     sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.out.obs + row * 14, a.out.reward ? a.out.reward + row : nullptr,
                     a.out.success ? a.out.success + row : nullptr);
@@ -729,7 +987,9 @@ template <int NV, int LPE>
 __global__ __launch_bounds__(64) void sawyer_reset_kernel(const SawyerArgs a) {
   constexpr int EPW = 64 / LPE;
   __shared__ earl_link_model m;
+  __shared__ BlkTable bt;
   __shared__ Shared<NV> sh[EPW];
+  stage_blocks(bt, a.col);
   stage_model(m, a.m);
   const earl_sawyer_cfg& cfg = a.cfg;
   const int lane = threadIdx.x, sub = lane % LPE, grp = lane / LPE;
@@ -766,7 +1026,7 @@ __global__ __launch_bounds__(64) void sawyer_reset_kernel(const SawyerArgs a) {
   // set_state -> sim.forward(): kinematics of the state just written
   const Q4 mq = qnormalize(ldq(cfg.mocap_quat));
   const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
-  substep<NV, LPE, false>(s, m, sub, mpos, mq, ctrl, nullptr, nullptr);
+  substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
   sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.reset_obs + (size_t)env * 14, nullptr, nullptr);
 }
 
@@ -803,35 +1063,35 @@ void launch_physics(const PArgs& a, hipStream_t st) {
 
 extern "C" {
 
-int earl_physics_step(const earl_link_model* model, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
+int earl_physics_step(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
                       earl_stream_t stream) {
   if (!model || n < 0 || nsub < 0 || !qpos || !qvel || !mocap_pos || !mocap_quat || !ctrl) return EARL_ERR_ARG;
   if (n == 0 || nsub == 0) return EARL_OK;
-  PArgs a{model, n, nsub, qpos, qvel, mocap_pos, mocap_quat, ctrl, att_xpos, nullptr, nullptr};
+  PArgs a{model, col, n, nsub, qpos, qvel, mocap_pos, mocap_quat, ctrl, att_xpos, nullptr, nullptr};
   if (nv == 10) launch_physics<10, true>(a, (hipStream_t)stream);
   else return EARL_ERR_ARG;
   return launched("physics_step");
 }
 
-int earl_physics_forward(const earl_link_model* model, int32_t nv, int32_t n, const double* qpos, const double* qvel,
+int earl_physics_forward(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, const double* qpos, const double* qvel,
                          const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc,
                          double* efc_force, double* att_xpos, earl_stream_t stream) {
   if (!model || n < 0 || !qpos || !qvel || !mocap_pos || !mocap_quat || !ctrl || !qacc) return EARL_ERR_ARG;
   if (n == 0) return EARL_OK;
-  PArgs a{model, n, 1, const_cast<double*>(qpos), const_cast<double*>(qvel), mocap_pos, mocap_quat, ctrl, att_xpos, qacc, efc_force};
+  PArgs a{model, col, n, 1, const_cast<double*>(qpos), const_cast<double*>(qvel), mocap_pos, mocap_quat, ctrl, att_xpos, qacc, efc_force};
   if (nv == 10) launch_physics<10, false>(a, (hipStream_t)stream);
   else return EARL_ERR_ARG;
   return launched("physics_forward");
 }
 
-int earl_sawyer_rollout(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model* col, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                         const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream) {
   if (!model || !cfg || !st || !out || !action || T < 0 || cfg->n < 0) return EARL_ERR_ARG;
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !out->obs) return EARL_ERR_ARG;
   if (cfg->frame_skip < 0 || cfg->att_hand < 0 || cfg->att_right < 0 || cfg->att_left < 0 || cfg->att_obj < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
-  SawyerArgs a{model, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
+  SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
   if (nv != 10) return EARL_ERR_ARG;
   if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
   else sawyer_rollout_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
@@ -845,7 +1105,7 @@ int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawye
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
   if (cfg->obj_dof < 0 || cfg->obj_dof >= nv) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
-  SawyerArgs a{model, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, reset_qpos, reset_qvel, mask, obs, 0};
+  SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, reset_qpos, reset_qvel, mask, obs, 0};
   if (nv != 10) return EARL_ERR_ARG;
   sawyer_reset_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
   return launched("sawyer_reset");
@@ -856,7 +1116,7 @@ int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_saw
   if (!model || !cfg || !st || !obs || cfg->n < 0) return EARL_ERR_ARG;
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
-  SawyerArgs a{model, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, obs, 1};
+  SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, obs, 1};
   if (nv != 10) return EARL_ERR_ARG;
   sawyer_reset_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
   return launched("sawyer_observe");
@@ -888,5 +1148,6 @@ int earl_debug_read_phys_profile(unsigned long long* out, int reset) {
 #endif
 
 int earl_physics_model_size(void) { return (int)sizeof(earl_link_model); }
+int earl_collision_model_size(void) { return (int)sizeof(earl_collision_model); }
 
 }  // extern "C"

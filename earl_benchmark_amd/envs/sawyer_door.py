@@ -40,7 +40,7 @@ class SawyerDoor:
   MODEL = 'sawyer_door'
 
   def __init__(self, reward_type='sparse', reset_at_goal=False, num_envs=1, device='cuda', seed=0, env_offset=0,
-               scalar_api=None, auto_reset=False):
+               scalar_api=None, auto_reset=False, contacts=True):
     if auto_reset:
       raise NotImplementedError('auto_reset is not built for the Sawyer envs')
     self._lib = _abi.load()
@@ -66,7 +66,7 @@ class SawyerDoor:
     self.max_path_length = int(1e8)
 
     with torch.cuda.device(dev):
-      self.model = physics.DeviceModel(self.MODEL, device=dev)
+      self.model = physics.DeviceModel(self.MODEL, device=dev, contacts=contacts)
     nv = self.nv = self.model.nv
     names = self.model.att_names
     kw = dict(device=dev)
@@ -135,7 +135,7 @@ class SawyerDoor:
     o = _abi.SawyerOut(obs=out['obs'].data_ptr(), reward=_ptr(out.get('reward')), done=_ptr(out.get('done')),
                        success=_ptr(out.get('success')))
     with torch.cuda.device(self.device):
-      _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),
+      _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.model.col_ptr, self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),
                                                T, C.byref(o), self._stream()), 'earl_sawyer_rollout')
     self.total_step_count += T
     if self._cfg.goal_change_frequency:

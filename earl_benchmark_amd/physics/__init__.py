@@ -13,6 +13,7 @@ import torch
 from .. import _abi
 
 MAXV, MAXATT, MAXACT = 16, 8, 4
+MAXSPH, MAXBOX, MAXPAIR, MAXCLS, MAXCON, MAXBLK = 64, 16, 256, 16, 8, 16
 MODEL_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'models')
 
 
@@ -29,7 +30,25 @@ class LinkModelStruct(C.Structure):   # struct earl_link_model
               ('dof_invweight', C.c_double * MAXV), ('att_pos', C.c_double * 3 * MAXATT), ('att_quat', C.c_double * 4 * MAXATT),
               ('act_kp', C.c_double * MAXACT), ('act_ctrlrange', C.c_double * 2 * MAXACT),
               ('weld_solref', C.c_double * 2), ('weld_solimp', C.c_double * 5), ('weld_invweight', C.c_double * 2),
-              ('gravity', C.c_double * 3), ('dt', C.c_double)]
+              ('gravity', C.c_double * 3), ('dt', C.c_double), ('drag_G', C.c_double * MAXV), ('drag_b', C.c_double * MAXV)]
+
+
+class PairRec(C.Structure):
+  _fields_ = [('sph_link', C.c_int32), ('cls', C.c_int32), ('pos', C.c_double * 3), ('r', C.c_double), ('margin', C.c_double)]
+
+
+class CollisionModelStruct(C.Structure):   # struct earl_collision_model
+  _fields_ = [('n_sph', C.c_int32), ('n_box', C.c_int32), ('n_pair', C.c_int32), ('n_cls', C.c_int32),
+              ('n_blk', C.c_int32), ('pad_', C.c_int32 * 3), ('blk_begin', C.c_int32 * MAXBLK), ('blk_end', C.c_int32 * MAXBLK),
+              ('blk_box', C.c_int32 * MAXBLK), ('blk_link', C.c_int32 * MAXBLK), ('blk_center', C.c_double * 3 * MAXBLK),
+              ('blk_reach', C.c_double * MAXBLK),
+              ('sph_link', C.c_int32 * MAXSPH), ('box_link', C.c_int32 * MAXBOX),
+              ('sph_pos', C.c_double * 3 * MAXSPH), ('sph_r', C.c_double * MAXSPH),
+              ('box_pos', C.c_double * 3 * MAXBOX), ('box_quat', C.c_double * 4 * MAXBOX), ('box_half', C.c_double * 3 * MAXBOX),
+              ('pair_sph', C.c_uint8 * MAXPAIR), ('pair_box', C.c_uint8 * MAXPAIR), ('pair_cls', C.c_uint8 * MAXPAIR),
+              ('pad2_', C.c_uint8 * MAXPAIR), ('pair_rec', PairRec * MAXPAIR),
+              ('cls_mu', C.c_double * MAXCLS), ('cls_solref', C.c_double * 2 * MAXCLS), ('cls_solimp', C.c_double * 5 * MAXCLS),
+              ('cls_margin', C.c_double * MAXCLS), ('cls_invw', C.c_double * MAXCLS)]
 
 
 def _fill(dst, src):
@@ -79,28 +98,66 @@ def load_link_model(name):
                    (s.weld_solimp, d['weld_solimp'][0]), (s.weld_invweight, d['weld_invweight']), (s.gravity, d['gravity'])):
     _fill(dst, src)
   s.dt = float(d['timestep'])
+  if 'dof_drag_G' in d:
+    _fill(s.drag_G, d['dof_drag_G'])
+    _fill(s.drag_b, d['dof_drag_b'])
   return s, d
+
+
+def load_collision_model(d):
+  """tables dict (from load_link_model) -> CollisionModelStruct, or None if the model has no collision geometry"""
+  if 'col_pair' not in d or len(d['col_pair']) == 0:
+    return None
+  c = CollisionModelStruct()
+  c.n_sph, c.n_box, c.n_pair, c.n_cls = len(d['col_sph_link']), len(d['col_box_link']), len(d['col_pair']), len(d['col_cls_mu'])
+  c.n_blk = len(d['col_blk_begin'])
+  assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS and c.n_blk <= MAXBLK
+  for dst, src in ((c.blk_begin, d['col_blk_begin']), (c.blk_end, d['col_blk_end']), (c.blk_box, d['col_blk_box']),
+                   (c.blk_link, d['col_blk_link']), (c.blk_center, d['col_blk_center']), (c.blk_reach, d['col_blk_reach'])):
+    _fill(dst, src)
+  for dst, src in ((c.sph_link, d['col_sph_link']), (c.box_link, d['col_box_link']), (c.sph_pos, d['col_sph_pos']), (c.sph_r, d['col_sph_r']),
+                   (c.box_pos, d['col_box_pos']), (c.box_quat, d['col_box_quat']), (c.box_half, d['col_box_half']),
+                   (c.pair_sph, d['col_pair'][:, 0].astype(np.uint8)), (c.pair_box, d['col_pair'][:, 1].astype(np.uint8)),
+                   (c.pair_cls, d['col_pair_cls'].astype(np.uint8)), (c.cls_mu, d['col_cls_mu']), (c.cls_solref, d['col_cls_solref']),
+                   (c.cls_solimp, d['col_cls_solimp']), (c.cls_margin, d['col_cls_margin']), (c.cls_invw, d['col_cls_invw'])):
+    _fill(dst, src)
+  for i, (si, bi) in enumerate(d['col_pair']):
+    r = c.pair_rec[i]
+    r.sph_link, r.cls, r.r = int(d['col_sph_link'][si]), int(d['col_pair_cls'][i]), float(d['col_sph_r'][si])
+    r.pos[:] = [float(x) for x in d['col_sph_pos'][si]]
+    r.margin = float(d['col_cls_margin'][r.cls])
+  return c
 
 
 class DeviceModel:
   """a link model resident in HBM"""
 
-  def __init__(self, name, device='cuda'):
+  def __init__(self, name, device='cuda', contacts=True):
     self.lib = _abi.load()
     self.struct, self.tables = load_link_model(name)
+    self.col_struct = load_collision_model(self.tables) if contacts else None
+    if not contacts:
+      _fill(self.struct.drag_G, np.zeros(self.struct.nv))
     self.nv, self.n_att, self.n_act = self.struct.nv, self.struct.n_att, self.struct.n_act
     self.device = torch.device(device)
     raw = np.frombuffer(bytes(self.struct), dtype=np.uint8).copy()
     self.buf = torch.from_numpy(raw).to(self.device)
+    self.col_buf = None
+    if self.col_struct is not None:
+      self.col_buf = torch.from_numpy(np.frombuffer(bytes(self.col_struct), dtype=np.uint8).copy()).to(self.device)
     self.att_names = [str(x) for x in self.tables['att_names']]
 
   def _stream(self):
     return torch.cuda.current_stream(self.device).cuda_stream
 
+  @property
+  def col_ptr(self):
+    return None if self.col_buf is None else self.col_buf.data_ptr()
+
   def step(self, qpos, qvel, mocap_pos, mocap_quat, ctrl, nsub=1, att_xpos=None):
     n = qpos.shape[0]
     with torch.cuda.device(self.device):
-      rc = self.lib.earl_physics_step(self.buf.data_ptr(), self.nv, n, nsub, qpos.data_ptr(), qvel.data_ptr(), mocap_pos.data_ptr(),
+      rc = self.lib.earl_physics_step(self.buf.data_ptr(), self.col_ptr, self.nv, n, nsub, qpos.data_ptr(), qvel.data_ptr(), mocap_pos.data_ptr(),
                                       mocap_quat.data_ptr(), ctrl.data_ptr(), None if att_xpos is None else att_xpos.data_ptr(),
                                       self._stream())
     _abi.check(rc, 'physics_step')
@@ -112,7 +169,7 @@ class DeviceModel:
     efc = torch.empty(n, 6 + 2 * self.nv, **kw)
     att = torch.empty(n, self.n_att, 3, **kw)
     with torch.cuda.device(self.device):
-      rc = self.lib.earl_physics_forward(self.buf.data_ptr(), self.nv, n, qpos.data_ptr(), qvel.data_ptr(), mocap_pos.data_ptr(),
+      rc = self.lib.earl_physics_forward(self.buf.data_ptr(), self.col_ptr, self.nv, n, qpos.data_ptr(), qvel.data_ptr(), mocap_pos.data_ptr(),
                                          mocap_quat.data_ptr(), ctrl.data_ptr(), qacc.data_ptr(), efc.data_ptr(), att.data_ptr(),
                                          self._stream())
     _abi.check(rc, 'physics_forward')

@@ -45,17 +45,47 @@ typedef struct earl_link_model {
   double act_kp[EARL_MAXACT], act_ctrlrange[EARL_MAXACT][2];
   double weld_solref[2], weld_solimp[5], weld_invweight[2];
   double gravity[3], dt;
+  double drag_G[EARL_MAXV], drag_b[EARL_MAXV];   /* soft velocity row per dof, cost 1/2 G (a + b v)^2: a permanent deep contact reduced at
+                                                    model-compile time (the door panel standing in the table top), 0 = none */
 } earl_link_model;
 
-/* nsub timesteps of every env.  model: DEVICE copy of an earl_link_model.  State (updated in place):
+/* Collision geometry of a link model: SPHERES (cylinders are chains of spheres; box corners are spheres of radius 0)
+ * tested against BOXES over a fixed pair list; per-pair solver parameters by class (MuJoCo's geom mixing rules applied
+ * at model-compile time).  At most EARL_MAXCON contacts per env and timestep: the first active pairs in list order. */
+#define EARL_MAXSPH 64
+#define EARL_MAXBOX 16
+#define EARL_MAXPAIR 256
+#define EARL_MAXCLS 16
+#define EARL_MAXCON 8
+#define EARL_MAXBLK 16
+typedef struct earl_collision_model {
+  int32_t n_sph, n_box, n_pair, n_cls;
+  /* pairs are stored box-major in blocks (one box x one set of spheres); a block is skipped when the bounding sphere of its
+   * set (centre given in the frame of blk_link, -1 = world) is farther than blk_reach from the box centre */
+  int32_t n_blk, pad_[3];
+  int32_t blk_begin[EARL_MAXBLK], blk_end[EARL_MAXBLK], blk_box[EARL_MAXBLK], blk_link[EARL_MAXBLK];
+  double blk_center[EARL_MAXBLK][3], blk_reach[EARL_MAXBLK];
+  int32_t sph_link[EARL_MAXSPH];             /* -1 = fixed to the world */
+  int32_t box_link[EARL_MAXBOX];
+  double sph_pos[EARL_MAXSPH][3], sph_r[EARL_MAXSPH];
+  double box_pos[EARL_MAXBOX][3], box_quat[EARL_MAXBOX][4], box_half[EARL_MAXBOX][3];
+  uint8_t pair_sph[EARL_MAXPAIR], pair_box[EARL_MAXPAIR], pair_cls[EARL_MAXPAIR];
+  uint8_t pad2_[EARL_MAXPAIR];
+  /* the same pairs, self-contained (one load per test): sphere link, class, local centre, radius, class margin */
+  struct { int32_t sph_link, cls; double pos[3], r, margin; } pair_rec[EARL_MAXPAIR];
+  double cls_mu[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS];
+} earl_collision_model;
+
+/* nsub timesteps of every env.  model: DEVICE copy of an earl_link_model; col: DEVICE copy of its earl_collision_model or
+ * NULL (no contacts).  State (updated in place):
  * qpos, qvel [n, nv]; inputs mocap_pos [n,3], mocap_quat [n,4] (normalised internally), ctrl [n, n_act];
  * att_xpos (may be NULL) [n, n_att, 3]: world positions of the attachments after the last timestep. */
-int earl_physics_step(const earl_link_model* model, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
+int earl_physics_step(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
                       earl_stream_t stream);
 
 /* Forward quantities of the CURRENT state without integrating (tests): qacc [n,nv], efc_force [n, 6+2nv] (may be NULL) */
-int earl_physics_forward(const earl_link_model* model, int32_t nv, int32_t n, const double* qpos, const double* qvel,
+int earl_physics_forward(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, const double* qpos, const double* qvel,
                          const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc,
                          double* efc_force, double* att_xpos, earl_stream_t stream);
 
@@ -100,7 +130,7 @@ typedef struct earl_sawyer_out {
 } earl_sawyer_out;
 
 /* T env steps of every env in ONE launch (state stays in LDS between steps).  action: float32 [T, n, 4]. */
-int earl_sawyer_rollout(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model* col, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                         const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream);
 
 /* reset the envs with mask[i] != 0 (mask NULL = all): state <- the settled post-_reset_hand state (reset_qpos / reset_qvel,
@@ -124,6 +154,7 @@ int earl_debug_set_physics_lanes(int lanes_per_env);
 
 /* sizeof(earl_link_model) as compiled into the library (bindings check their struct layout against it) */
 int earl_physics_model_size(void);
+int earl_collision_model_size(void);
 
 #ifdef __cplusplus
 }

@@ -319,7 +319,7 @@ def inverse_weights(m):
 # Reduced ("link") model: one link per dof = the jointed body merged with its fixed descendants.  This is the form
 # the HIP stepper consumes (earl_benchmark_amd/csrc/physics.hip); `LinkModel.step` is its line-by-line reference.
 # ======================================================================================================================
-def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geoms=()):
+def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geoms=(), collision=None):
   """-> dict of arrays: links in an order where parents precede children (the dof order of these models)"""
   bp = m.body_pos if body_pos is None else body_pos
   link_of_body = np.full(m.nb, -1)          # nearest moving ancestor-or-self link of each body (-1: world-fixed)
@@ -374,7 +374,138 @@ def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geo
   wb = int(m.weld_body2[0])
   out['weld_att'] = np.int32(list(out['att_names']).index(str(m.body_names[wb])))
   out['weld_invweight'] = m.body_invweight0[wb].copy()
+  if collision is not None:
+    out.update(collision_primitives(m, link_of_body, rel_pos, rel_quat, collision, bp))
   return out
+
+
+def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=None):
+  """Collision geometry of the link model: SPHERES (cylinders become chains of spheres along their axis at spacing
+  <= 0.75 r, hemispherical ends inside the cylinder; box corner POINTS are spheres of radius 0) tested against BOXES.
+  spec: dict(plates=[geom names], chains=[geom ids], corner_sets=[[geom names merged into one box]], big_boxes=[geom ids]).
+  Pairs: chain spheres x plates, corner points x big boxes.  Per-primitive solver parameters are the geoms' own."""
+  sph, box = [], []
+
+  def gframe(g):
+    b = int(m.geom_body[g])
+    return (int(link_of_body[b]), rel_pos[b] + quat_mat(rel_quat[b]) @ m.geom_pos[g], quat_mul(rel_quat[b], m.geom_quat[g]))
+
+  def params(g):
+    si = np.array(m.geom_solimp[g], float)
+    if si[3] == 0 and si[4] == 0:                 # three-number solimp in the MJCF: midpoint / power keep their defaults
+      si[3:] = [0.5, 2.0]
+    return dict(mu=float(m.geom_friction[g][0]), solref=np.array(m.geom_solref[g], float), solimp=si,
+                margin=float(m.geom_margin[g]), invw=float(m.body_invweight0[int(m.geom_body[g])][0]))
+
+  def union_box(names):
+    """the (parallel) boxes `names` merged into one box in the first one's axes -> link, centre, quat, half sizes"""
+    gs = [m.geom_id(n) for n in names]
+    l, _, q = gframe(gs[0])
+    Rq = quat_mat(q)
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for g in gs:
+      l2, p2, q2 = gframe(g)
+      assert l2 == l and np.allclose(q2, q)
+      c = Rq.T @ p2
+      lo, hi = np.minimum(lo, c - m.geom_size[g][:3]), np.maximum(hi, c + m.geom_size[g][:3])
+    return l, Rq @ (0.5 * (lo + hi)), q, 0.5 * (hi - lo), lo, hi, Rq
+
+  # gripper plates: a finger is a claw box and a pad box (same size, 3 mm apart) -> ONE box per finger with the pad's
+  # contact parameters (the pad is the gripping face); otherwise every touching sphere would produce two contacts
+  for names in spec.get('plates', ()):
+    l, p, q, half, _, _, _ = union_box(names)
+    box.append(dict(link=l, pos=p, quat=q, half=half, kind=0, **params(m.geom_id(names[-1]))))
+  n_plates = len(box)
+  for g in spec.get('big_boxes', ()):
+    l, p, q = gframe(g)
+    box.append(dict(link=l, pos=p, quat=q, half=np.array(m.geom_size[g][:3], float), kind=1, **params(g)))
+  for g in spec.get('chains', ()):
+    l, p, q = gframe(g)
+    r, h = float(m.geom_size[g][0]), float(m.geom_size[g][1])
+    span = max(h - r, 0.0)
+    k = 1 if span == 0 else int(np.ceil(2 * span / (0.75 * r))) + 1
+    for t in (np.linspace(-span, span, k) if k > 1 else [0.0]):
+      sph.append(dict(link=l, pos=p + quat_mat(q) @ np.array([0, 0, t]), r=r, kind=0, **params(g)))
+  for names in spec.get('corner_sets', ()):
+    l, _, q, _, lo, hi, Rq = union_box(names)
+    gs = [m.geom_id(names[0])]
+    for sx in (0, 1):
+      for sy in (0, 1):
+        for sz in (0, 1):
+          c = np.array([hi[0] if sx else lo[0], hi[1] if sy else lo[1], hi[2] if sz else lo[2]])
+          sph.append(dict(link=l, pos=Rq @ c, r=0.0, kind=1, **params(gs[0])))
+  # Permanent deep box-in-box contacts (the door panel stands 2.3 cm inside the table top: obj_init_pos z = 0.1, panel
+  # half height 0.123).  Such a contact has all four pyramid edges active and a constant depth, and the moving box has
+  # one dof, so its 4 x 4 edges reduce EXACTLY to one soft velocity row on that dof (tests/test_physics.py checks the
+  # reduction against the explicit contacts):  cost 1/2 G (a_j + b v_j)^2,  G = sum_k rho_k^2 / R0.
+  nv = len(m.jnt_body)
+  drag_G, drag_b = np.zeros(nv), np.zeros(nv)
+  for g_mov, g_fix, depth in spec.get('drag', ()):
+    l, p, q = gframe(g_mov)
+    a, b = params(g_mov), params(g_fix)
+    solref, solimp, margin = 0.5 * (a['solref'] + b['solref']), 0.5 * (a['solimp'] + b['solimp']), max(a['margin'], b['margin'])
+    kk, bb, dd = kbimp(solref, solimp, -depth - margin, float(m.timestep))
+    R0 = max((1 - dd) / dd * (a['invw'] + b['invw']), 1e-15)
+    h = np.array(m.geom_size[g_mov][:3], float)
+    axis = m.jnt_axis[l]; anchor = m.jnt_pos[l]
+    assert m.jnt_type[l] == 0 and abs(abs(quat_mat(q)[:, 2] @ axis) - 1) < 1e-9, 'drag reduction: hinge parallel to the box z axis'
+    for sx in (-1, 1):
+      for sy in (-1, 1):
+        c = p + quat_mat(q) @ np.array([sx * h[0], sy * h[1], -h[2]]) - anchor
+        rho2 = c @ c - (c @ axis) ** 2
+        drag_G[l] += rho2 / R0
+    drag_b[l] = bb
+  # pairs in BOX-MAJOR order, cut into blocks (one box x one set of spheres) that carry a bounding test: the kernel skips
+  # a whole block when the set's bounding sphere is clear of the box's.  Chain spheres ride on one link; the corner
+  # points of both gripper plates are bounded together in the frame of their common parent (the claws slide: slack).
+  pairs, blocks = [], []
+  parent = [int(link_of_body[m.body_parent[int(m.jnt_body[l])]]) for l in range(nv)]
+  for j, bx in enumerate(box):
+    members = [i for i, sp in enumerate(sph) if sp['kind'] == bx['kind'] and sp['link'] != bx['link']]
+    if not members:
+      continue
+    links = sorted(set(sph[i]['link'] for i in members))
+    if len(links) == 1:
+      bl, slack = links[0], 0.0
+      pts = np.array([sph[i]['pos'] for i in members])
+    else:                                         # sets on sibling slide links: bound them in the parent's frame at mid range
+      bl = parent[links[0]]
+      assert all(parent[l] == bl and m.jnt_type[l] == 1 for l in links)
+      slack = max(0.5 * (m.jnt_range[l][1] - m.jnt_range[l][0]) for l in links)
+      pts = []
+      for i in members:
+        l = sph[i]['link']
+        jb = int(m.jnt_body[l]); pb = int(m.body_parent[jb])
+        tp = rel_pos[pb] + quat_mat(rel_quat[pb]) @ (m.body_pos if body_pos_ is None else body_pos_)[jb]
+        tq = quat_mul(rel_quat[pb], m.body_quat[jb])
+        mid = 0.5 * (m.jnt_range[l][0] + m.jnt_range[l][1])
+        pts.append(tp + quat_mat(tq) @ (sph[i]['pos'] + m.jnt_axis[l] * mid))
+      pts = np.array(pts)
+    ctr = pts.mean(0)
+    rad = max(np.sqrt(((pts[k] - ctr) ** 2).sum()) + sph[i]['r'] for k, i in enumerate(members)) + slack
+    mmax = max(max(sph[i]['margin'], bx['margin']) for i in members)
+    blocks.append(dict(begin=len(pairs), end=len(pairs) + len(members), box=j, link=bl, center=ctr,
+                       reach=rad + mmax + 1e-6))
+    pairs += [(i, j) for i in members]
+  cls, pair_cls = [], []
+  for i, j in pairs:                             # contact parameters: MuJoCo mixes the two geoms (max friction / margin, mean solref / solimp)
+    a, b = sph[i], box[j]
+    key = (max(a['mu'], b['mu']), tuple(0.5 * (a['solref'] + b['solref'])), tuple(0.5 * (a['solimp'] + b['solimp'])),
+           max(a['margin'], b['margin']), a['invw'] + b['invw'])
+    if key not in cls:
+      cls.append(key)
+    pair_cls.append(cls.index(key))
+  return dict(col_sph_link=np.array([x['link'] for x in sph], np.int32), col_sph_pos=np.array([x['pos'] for x in sph]),
+              col_sph_r=np.array([x['r'] for x in sph]),
+              col_box_link=np.array([x['link'] for x in box], np.int32), col_box_pos=np.array([x['pos'] for x in box]),
+              col_box_quat=np.array([x['quat'] for x in box]), col_box_half=np.array([x['half'] for x in box]),
+              col_pair=np.array(pairs, np.int32).reshape(-1, 2), col_pair_cls=np.array(pair_cls, np.int32),
+              col_cls_mu=np.array([c[0] for c in cls]), col_cls_solref=np.array([c[1] for c in cls]),
+              col_cls_solimp=np.array([c[2] for c in cls]), col_cls_margin=np.array([c[3] for c in cls]),
+              col_cls_invw=np.array([c[4] for c in cls]), dof_drag_G=drag_G, dof_drag_b=drag_b,
+              col_blk_begin=np.array([b['begin'] for b in blocks], np.int32), col_blk_end=np.array([b['end'] for b in blocks], np.int32),
+              col_blk_box=np.array([b['box'] for b in blocks], np.int32), col_blk_link=np.array([b['link'] for b in blocks], np.int32),
+              col_blk_center=np.array([b['center'] for b in blocks]), col_blk_reach=np.array([b['reach'] for b in blocks]))
 
 
 def sym6(v):
@@ -459,12 +590,12 @@ class LinkModel:
     for a in range(len(self.act_joint)):
       j = self.act_joint[a]
       tau[j] += self.act_kp[a] * (np.clip(ctrl[a], *self.act_ctrlrange[a]) - qpos[j])
-    L = np.linalg.cholesky(M)
-    a0 = np.linalg.solve(L.T, np.linalg.solve(L, tau))
-    # constraint rows: 6 weld rows, then lower / upper limit of every dof (inactive rows carry zero force)
+    a0 = np.linalg.solve(M, tau)
+    # constraint rows: 6 weld rows (equalities), then lower / upper limit of every dof, then 4 pyramid edges per contact
     k = int(self.weld_att)
     hp, hq = self.attachment(pos, quat, k)
-    J = np.zeros((6 + 2 * nv, nv)); res = np.zeros(6 + 2 * nv); active = np.zeros(6 + 2 * nv, bool)
+    nlim = 6 + 2 * nv
+    J = np.zeros((nlim, nv)); res = np.zeros(nlim); inst = np.zeros(nlim, bool)
     solref = [self.weld_solref[0]] * 6; solimp = [self.weld_solimp[0]] * 6
     invw = [self.weld_invweight[0]] * 3 + [self.weld_invweight[1]] * 3
     # weld rows as mj_instantiateEqual builds them (body1 = mocap, body2 = hand, relpose = identity after metaworld's
@@ -480,36 +611,136 @@ class LinkModel:
       J[3:6, j] = -0.5 * (e[0] * a + np.cross(a, e[1:]))
     res[0:3] = mocap_pos - hp
     res[3:6] = e[1:]
-    active[:6] = True
+    inst[:6] = True
     for j in range(nv):
       J[6 + 2 * j, j], J[7 + 2 * j, j] = 1.0, -1.0
       res[6 + 2 * j], res[7 + 2 * j] = qpos[j] - self.jnt_range[j, 0], self.jnt_range[j, 1] - qpos[j]
-      active[6 + 2 * j] = bool(self.jnt_limited[j]) and res[6 + 2 * j] < 0
-      active[7 + 2 * j] = bool(self.jnt_limited[j]) and res[7 + 2 * j] < 0
+      inst[6 + 2 * j] = bool(self.jnt_limited[j]) and res[6 + 2 * j] < 0
+      inst[7 + 2 * j] = bool(self.jnt_limited[j]) and res[7 + 2 * j] < 0
       solref += [self.jnt_solref[j]] * 2; solimp += [self.jnt_solimp[j]] * 2; invw += [self.dof_invweight0[j]] * 2
-    nc = len(res)
-    aref, Rg = np.zeros(nc), np.zeros(nc)
+    aref, Rg = np.zeros(nlim), np.zeros(nlim)
     Jv = J @ qvel
-    for i in range(nc):
+    for i in range(nlim):
       kk, bb, dd = kbimp(solref[i], solimp[i], res[i], self.dt)
       aref[i] = -bb * Jv[i] - kk * dd * res[i]
       Rg[i] = max((1 - dd) / dd * invw[i], 1e-15)
-    Y = np.linalg.solve(L, J.T)                      # nv x nc
-    AR = Y.T @ Y + np.diag(Rg)
-    rhs = aref - J @ a0
-    f = np.zeros(nc)
-    act = active.copy()
-    for _ in range(4):                               # active-set: drop inequality rows that would pull
-      idx = np.nonzero(act)[0]
-      f[:] = 0.0
-      f[idx] = np.linalg.solve(AR[np.ix_(idx, idx)], rhs[idx])
-      bad = act & (np.arange(nc) >= 6) & (f < 0)
-      if not bad.any():
+    if self.contacts and hasattr(self, 'dof_drag_G'):
+      for j in np.nonzero(self.dof_drag_G)[0]:   # soft velocity row of a permanent dragging contact: 1/2 G (a_j + b v_j)^2
+        row = np.zeros(nv); row[j] = 1.0
+        J = np.vstack([J, row]); aref = np.append(aref, -self.dof_drag_b[j] * qvel[j]); Rg = np.append(Rg, 1.0 / self.dof_drag_G[j])
+        inst = np.append(inst, True); res = np.append(res, 0.0)
+    n_eq_extra = len(aref) - nlim
+    contacts = self.collide(pos, quat) if (self.contacts and hasattr(self, 'col_pair')) else []
+    if contacts:
+      Jc, arc, Rc = self.contact_rows(contacts, S, qvel)
+      J, aref, Rg = np.vstack([J, Jc]), np.concatenate([aref, arc]), np.concatenate([Rg, Rc])
+      inst = np.concatenate([inst, np.ones(len(arc), bool)])
+    is_eq = np.zeros(len(aref), bool); is_eq[:6] = True; is_eq[nlim:nlim + n_eq_extra] = True
+    qacc, act = self.solve_primal(M, tau, J[inst], aref[inst], 1.0 / Rg[inst], is_eq[inst])
+    f = np.zeros(len(aref)); active = np.zeros(len(aref), bool)
+    idx = np.nonzero(inst)[0]
+    f[idx] = np.where(act, -(J[idx] @ qacc - aref[idx]) / Rg[idx], 0.0)
+    active[idx] = act
+    return dict(pos=pos, quat=quat, M=M, qacc=qacc, f=f, res=res, active=active, contacts=contacts, a0=a0)
+
+  block_cull = True        # False: test every pair (tests check that the cull never drops a contact)
+  contacts = True          # class-level switch: LinkModel.contacts = False gives the contact-free stepper
+  max_contacts = 8         # the kernel's cap: the first max_contacts active pairs in pair order
+
+  def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8):
+    """MuJoCo's primal problem  min_a 1/2 (a-a0)' M (a-a0) + sum_r 1/2 D_r [J_r a - aref_r]_-^2  (equalities: both signs)
+    by the active-set Newton iteration the kernel runs: rows start active, then active <=> J_r a < aref_r."""
+    act = np.ones(len(aref), bool)
+    a = None
+    for _ in range(iters):
+      Ja = J[act]
+      H = M + Ja.T @ (D[act, None] * Ja)
+      a = np.linalg.solve(H, tau + Ja.T @ (D[act] * aref[act]))
+      want = is_eq | (J @ a - aref < 0)
+      if (want == act).all():
         break
-      act &= ~bad
-    f[~act] = 0.0
-    qacc = a0 + np.linalg.solve(L.T, Y @ f)
-    return dict(pos=pos, quat=quat, M=M, qacc=qacc, f=f, res=res, active=act)
+      act = want
+    return a, act
+
+  def collide(self, pos, quat):
+    """sphere / point vs box tests over the model's pair list -> contacts (dist < margin), at most max_contacts"""
+    out = []
+    near = np.ones(len(self.col_pair), bool)
+    if self.block_cull and hasattr(self, 'col_blk_begin'):            # the kernel's block cull, restated so that a wrong bound shows up as a parity failure
+      near[:] = False
+      for b in range(len(self.col_blk_begin)):
+        bl, bi = int(self.col_blk_link[b]), int(self.col_blk_box[b])
+        cs = self.col_blk_center[b] if bl < 0 else pos[bl] + quat_mat(quat[bl]) @ self.col_blk_center[b]
+        lb = int(self.col_box_link[bi])
+        if lb < 0:
+          cb, Rb = self.col_box_pos[bi], quat_mat(self.col_box_quat[bi])
+        else:
+          cb, Rb = pos[lb] + quat_mat(quat[lb]) @ self.col_box_pos[bi], quat_mat(quat_mul(quat[lb], self.col_box_quat[bi]))
+        x = Rb.T @ (cs - cb)
+        dd = x - np.clip(x, -self.col_box_half[bi], self.col_box_half[bi])
+        if (dd ** 2).sum() < self.col_blk_reach[b] ** 2:
+          near[self.col_blk_begin[b]:self.col_blk_end[b]] = True
+    for pi, (si, bi) in enumerate(self.col_pair):
+      if not near[pi]:
+        continue
+      cls = int(self.col_pair_cls[pi])
+      ls, lb = int(self.col_sph_link[si]), int(self.col_box_link[bi])
+      c = self.col_sph_pos[si] if ls < 0 else pos[ls] + quat_mat(quat[ls]) @ self.col_sph_pos[si]
+      if lb < 0:
+        pb, Rb = self.col_box_pos[bi], quat_mat(self.col_box_quat[bi])
+      else:
+        pb, Rb = pos[lb] + quat_mat(quat[lb]) @ self.col_box_pos[bi], quat_mat(quat_mul(quat[lb], self.col_box_quat[bi]))
+      h, r = self.col_box_half[bi], float(self.col_sph_r[si])
+      x = Rb.T @ (c - pb)
+      q = np.clip(x, -h, h)
+      if (np.abs(x) > h).any():
+        d = x - q
+        nd = np.sqrt(d @ d)
+        dist, nl = nd - r, d / nd
+      else:                                      # centre inside the box: leave through the nearest face
+        i = int(np.argmin(h - np.abs(x)))
+        sg = 1.0 if x[i] >= 0 else -1.0
+        nl = np.zeros(3); nl[i] = sg
+        dist = -(h[i] - abs(x[i])) - r
+        q = x.copy(); q[i] = sg * h[i]
+      margin = float(self.col_cls_margin[cls])
+      if dist < margin:
+        n = Rb @ nl
+        p = pb + Rb @ q + n * (0.5 * dist)
+        out.append(dict(pair=pi, cls=cls, ls=ls, lb=lb, dist=dist, n=n, p=p))
+        if len(out) == self.max_contacts:
+          break
+    return out
+
+  @staticmethod
+  def tangents(n):
+    i = int(np.argmin(np.abs(n)))                # the coordinate axis least aligned with the normal
+    e = np.zeros(3); e[i] = 1.0
+    t1 = np.cross(n, e); t1 /= np.sqrt(t1 @ t1)
+    return t1, np.cross(n, t1)
+
+  def contact_rows(self, contacts, S, qvel):
+    """4 pyramid edges per contact: (n +- mu t1, n +- mu t2) . (v_sphere_point - v_box_point)"""
+    nv = self.nv
+    J, aref, R = [], [], []
+    for c in contacts:
+      cls = c['cls']
+      mu = float(self.col_cls_mu[cls])
+      Jp = np.zeros((3, nv))
+      for l, sgn in ((c['ls'], 1.0), (c['lb'], -1.0)):
+        if l >= 0:
+          for j in self.anc[l]:
+            Jp[:, j] += sgn * (S[j, 3:] + np.cross(S[j, :3], c['p']))
+      t1, t2 = self.tangents(c['n'])
+      margin = float(self.col_cls_margin[cls])
+      kk, bb, dd = kbimp(self.col_cls_solref[cls], self.col_cls_solimp[cls], c['dist'] - margin, self.dt)
+      R0 = max((1 - dd) / dd * float(self.col_cls_invw[cls]), 1e-15)
+      for d in (c['n'] + mu * t1, c['n'] - mu * t1, c['n'] + mu * t2, c['n'] - mu * t2):
+        row = d @ Jp
+        J.append(row)
+        aref.append(-bb * (row @ qvel) - kk * dd * (c['dist'] - margin))
+        R.append(2 * mu * mu * R0)
+    return np.array(J), np.array(aref), np.array(R)
 
   def step(self, qpos, qvel, ctrl, mocap_pos, mocap_quat):
     out = self.forward(qpos, qvel, ctrl, mocap_pos, mocap_quat)

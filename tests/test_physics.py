@@ -75,6 +75,7 @@ def test_dynamics_first_principles(m):
 
 def test_link_model_equals_body_model(m):
   lm = po.LinkModel(LINKS)
+  lm.contacts = False                     # the body-level model has no contact / drag rows
   assert list(lm.parent) == [-1, 0, 1, 2, 3, 4, 5, 6, 6, -1]
   rng = np.random.default_rng(1)
   s = po.State(m)
@@ -124,3 +125,60 @@ def test_gripper_opening_of_the_demonstrations_pins_the_claw_dynamics():
       assert abs(o[3] - want[3]) < 1e-4, (s, t, o[3], want[3])
       assert np.abs(o[:3] - want[:3]).max() < 2.5e-2
       assert float(r) == float(z['rewards'][s + t, 0])
+
+
+def test_drag_row_is_the_exact_reduction_of_the_door_panel_standing_in_the_table():
+  """the model compiler replaces the four permanent corner contacts of the door panel with the table top (depth 2.3 cm,
+  all pyramid edges active) by one soft velocity row on the door hinge; here the explicit contacts are rebuilt and
+  both formulations must give the same accelerations"""
+  z = dict(np.load(LINKS))
+  lm = po.LinkModel(dict(z))
+  bi_panel = [i for i in range(len(z['col_box_link'])) if z['col_box_link'][i] == 9][0]
+  bi_table = [i for i in range(len(z['col_box_link'])) if z['col_box_link'][i] == -1 and z['col_box_half'][i][0] == 0.7][0]
+  h, p0, q0 = z['col_box_half'][bi_panel], z['col_box_pos'][bi_panel], z['col_box_quat'][bi_panel]
+  pts = [p0 + po.quat_mat(q0) @ np.array([sx * h[0], sy * h[1], -h[2]]) for sx in (-1, 1) for sy in (-1, 1)]
+  ns, ncls = len(z['col_sph_link']), len(z['col_cls_mu'])
+  e = dict(z)
+  e['col_sph_link'] = np.concatenate([z['col_sph_link'], [9] * 4]).astype(np.int32)
+  e['col_sph_pos'] = np.vstack([z['col_sph_pos'], pts]); e['col_sph_r'] = np.concatenate([z['col_sph_r'], [0] * 4])
+  # class of the pair (door panel, table): MuJoCo's mixing of the two geoms' parameters, as the compiler computes it for the drag row
+  m = po.Model(MODEL)
+  gp = [g for g in range(len(m.geom_body)) if m.geom_body[g] == m.body_id('door_link') and m.geom_type[g] == 4 and m.geom_contype[g]][0]
+  gt = [g for g in range(len(m.geom_body)) if m.geom_body[g] == m.body_id('tablelink') and m.geom_conaffinity[g]][0]
+  si = np.array(m.geom_solimp[gp], float); si[3:] = [0.5, 2.0]
+  e['col_cls_mu'] = np.append(z['col_cls_mu'], 1.0)
+  e['col_cls_solref'] = np.vstack([z['col_cls_solref'], 0.5 * (m.geom_solref[gp] + m.geom_solref[gt])])
+  e['col_cls_solimp'] = np.vstack([z['col_cls_solimp'], 0.5 * (si + m.geom_solimp[gt])])
+  e['col_cls_margin'] = np.append(z['col_cls_margin'], 0.0)
+  e['col_cls_invw'] = np.append(z['col_cls_invw'], m.body_invweight0[m.body_id('door_link')][0])
+  e['col_pair'] = np.vstack([[[ns + i, bi_table] for i in range(4)], z['col_pair']]).astype(np.int32)
+  e['col_pair_cls'] = np.concatenate([[ncls] * 4, z['col_pair_cls']]).astype(np.int32)
+  e['dof_drag_G'] = np.zeros(10)
+  ex = po.LinkModel(e); ex.max_contacts = 12; ex.block_cull = False
+  rng = np.random.default_rng(5)
+  for _ in range(4):
+    q = rng.uniform(-0.4, 0.4, 10); q[1] = -1.2; q[7], q[8] = 0.01, -0.01; q[9] = rng.uniform(-1.2, -0.2)
+    v = rng.normal(size=10) * 0.3
+    args = (q, v, np.array([-1.0, 1.0]), np.array([0.1, 0.5, 0.3]), np.array([1.0, 0, 1, 0]))
+    a, b = lm.forward(*args), ex.forward(*args)
+    assert len(a['contacts']) == 0 and len(b['contacts']) == 4
+    np.testing.assert_allclose(a['qacc'], b['qacc'], rtol=1e-9, atol=1e-9 * np.abs(b['qacc']).max())
+
+
+def test_block_cull_never_drops_a_contact():
+  from oracle.sawyer_oracle import SawyerDoorOracle
+  lm = po.LinkModel(LINKS)
+  env = SawyerDoorOracle(lm)
+  env.reset()
+  rng = np.random.default_rng(7)
+  found = 0
+  for t in range(60):
+    a = rng.uniform(-1, 1, 4); a[:3] = [0.9, 0.6, -0.9] if t < 30 else a[:3]
+    env.step(a.astype(np.float32))
+    pos, quat, _ = lm.kinematics(env.qpos)
+    lm.block_cull = True; c1 = [c['pair'] for c in lm.collide(pos, quat)]
+    lm.block_cull = False; c2 = [c['pair'] for c in lm.collide(pos, quat)]
+    lm.block_cull = True
+    assert c1 == c2
+    found += len(c1)
+  assert found > 10

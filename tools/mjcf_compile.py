@@ -359,8 +359,20 @@ def main():
     pm = po.Model(m)
     bp = pm.body_pos.copy()
     bp[pm.body_id('door')] = np.array([0.1, 0.95, 0.1], np.float32).astype(float)
+    # collision set of the door task: gripper plates vs handle bars (cylinders on door_link), plate corners vs the door
+    # panel, the door frame and the table top.  Left out: the two mesh hulls on the wrist (l6, eGripperBase), walls, floor.
+    dl, frame, table = pm.body_id('door_link'), pm.body_id('doorlockB'), pm.body_id('tablelink')
+    colliding = lambda g: bool(m['geom_contype'][g] or m['geom_conaffinity'][g])
+    chains = [g for g in range(len(m['geom_body'])) if m['geom_body'][g] == dl and m['geom_type'][g] == 3 and colliding(g)
+              and m['geom_size'][g][1] > m['geom_size'][g][0]]
+    big = [g for g in range(len(m['geom_body'])) if m['geom_body'][g] in (dl, frame, table) and m['geom_type'][g] == 4 and colliding(g)]
+    panel = [g for g in big if m['geom_body'][g] == dl][0]
+    tbl = [g for g in big if m['geom_body'][g] == table][0]
     red = po.reduce_model(pm, bp, attach_bodies=['hand'], attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector'],
-                          attach_geoms=['handle'])
+                          attach_geoms=['handle'],
+                          collision=dict(plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], chains=chains,
+                                         corner_sets=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], big_boxes=big,
+                                         drag=[(panel, tbl, -(bp[pm.body_id('door')][2] - m['geom_size'][panel][2]))]))
     np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
   nb, nj, ng = len(m['body_parent']), len(m['jnt_body']), len(m['geom_body'])
   col = int(((m['geom_contype'] != 0) | (m['geom_conaffinity'] != 0)).sum())

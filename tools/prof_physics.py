@@ -8,23 +8,50 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, 'tools', 'ubench', 'libearl_physprof.so')
 FLAGS = '--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -DEARL_PHYS_PROF'
-NAMES = ['K1-2 joint + world transforms', 'K3 subspace + inertia', '-', 'K4 composite inertia', 'K5 mass matrix', 'K6-7 RNE + tau', 'K8 constraint rows', '-',
+NAMES = ['K1-2 joint + world transforms', 'K3 subspace + inertia', '-', 'K4 composite inertia', 'K5 mass matrix', 'K6-7 RNE + tau', 'C0-2 collision + K8 rows + C3', '-',
          'K9 Hessian + active-set Newton', '-', '-', 'K10 Euler']
 
 
 def build():
-  src = os.path.join(ROOT, 'earl_benchmark_amd', 'csrc', 'physics.hip')
-  subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-o', LIB, src], check=True)
+  srcs = [os.path.join(ROOT, 'earl_benchmark_amd', 'csrc', f) for f in ('physics.hip', 'tabletop.hip', 'glue.hip')]
+  subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-o', LIB] + srcs, check=True)
+
+
+def rollout_counters(n, T):
+  """event counters of wave 0 over a random-action rollout of the Sawyer door env (profiling build of the whole library)"""
+  import torch
+  sys.path.insert(0, ROOT)
+  from earl_benchmark_amd import _abi
+  _abi.LIB_PATH = LIB
+  _abi.SIGNATURES['earl_debug_read_phys_profile'] = [C.c_void_p, C.c_int]
+  from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
+  env = SawyerDoor(num_envs=n)
+  lib = _abi.load()
+  out = (C.c_ulonglong * 32)()
+  acts = torch.rand(T, n, 4, device='cuda') * 2 - 1
+  env.reset()
+  torch.cuda.synchronize()
+  lib.earl_debug_read_phys_profile(out, 1)
+  env.rollout(acts)
+  torch.cuda.synchronize()
+  lib.earl_debug_read_phys_profile(out, 1)
+  ts = max(1, out[20])
+  print(f'rollout N={n} T={T}: timesteps of wave 0: {out[20]}; with a near block {out[21] / ts:.3f} (blocks per timestep {out[22] / ts:.2f}); '
+        f'with contacts {out[23] / ts:.3f} (max contacts per env, mean {out[24] / ts:.2f}); Newton iterations per timestep {out[25] / ts:.2f}')
+  tot = sum(out[:12])
+  print(f'  cycles per timestep {tot / ts:.0f}: ' + ', '.join(f'{NAMES[i].split()[0]} {out[i] / ts:.0f}' for i in range(12) if NAMES[i] != '-'))
 
 
 def main():
   if '--build' in sys.argv:
     return build()
+  if '--rollout' in sys.argv:
+    return rollout_counters(1024, 300)
   import numpy as np
   import torch
   sys.path.insert(0, ROOT)
   from earl_benchmark_amd import physics
-  n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+  n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
   nsub = 5
   lib = C.CDLL(LIB)
   s, _ = physics.load_link_model('sawyer_door')
@@ -34,7 +61,9 @@ def main():
   t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
   dq, dv = t(qpos), torch.zeros(n, 10, dtype=torch.float64, device='cuda')
   mp = t(np.tile([0.0, 0.6, 0.2], (n, 1))); mq = t(np.tile([1.0, 0, 1, 0], (n, 1))); ctrl = t(rng.uniform(-1, 1, size=(n, 2)))
-  args = [C.c_void_p(buf.data_ptr()), C.c_int32(10), C.c_int32(n), C.c_int32(nsub)] + [C.c_void_p(x.data_ptr()) for x in (dq, dv, mp, mq, ctrl)] + [None, None]
+  col = physics.load_collision_model(_) if '--nocol' not in sys.argv else None
+  cbuf = torch.from_numpy(np.frombuffer(bytes(col), dtype=np.uint8).copy()).cuda() if col is not None else None
+  args = [C.c_void_p(buf.data_ptr()), C.c_void_p(cbuf.data_ptr() if cbuf is not None else None), C.c_int32(10), C.c_int32(n), C.c_int32(nsub)] + [C.c_void_p(x.data_ptr()) for x in (dq, dv, mp, mq, ctrl)] + [None, None]
   out = (C.c_ulonglong * 32)()
   for rep in range(3):
     lib.earl_physics_step(*args)
