@@ -187,7 +187,7 @@ def sawyer_cpu_baseline(T_sample, seconds):
 
 def main_sawyer(a, torch, dist, world, rank, device):
   """BASELINE configs[2] shape (Sawyer door half): N envs per GPU, reset + one fused T-step rollout per bench step.
-  The dynamics are this build's own stepper (no contacts yet, parity with MuJoCo unpinned) -- see DESIGN.md."""
+  The dynamics are this build's own stepper (own contact model, parity with MuJoCo unpinned) -- see DESIGN.md."""
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
   from earl_benchmark_amd.wrappers import PersistentStateWrapper
   from earl_benchmark_amd import sharding
@@ -232,14 +232,15 @@ def main_sawyer(a, torch, dist, world, rank, device):
            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
            'config': {'workload': f'sawyer_door {a.reward} reward, {n} batched envs per MI355X, reset + fused {T}-step rollout '
-                                  f'(5 timesteps per env step) per bench step; own stepper: weld + joint limits, NO contacts yet',
+                                  f'(5 timesteps per env step) per bench step; own stepper incl. contacts, parity with MuJoCo unpinned',
                       'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
                       'parallelism': f'env-range shard x{world}, no per-step collective'},
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': None, 'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
                         'algorithmic_bytes_per_launch': per_launch, 'bytes_per_env_step': bytes_per_env_step,
-                        'note': 'not HBM-bound: fp64 VALU issue bound (about 26k cycles per timestep per wavefront of 4 envs, '
-                                'tools/prof_physics.py); the HBM figure is reported because the schema asks for it'},
+                        'note': 'not HBM-bound: fp64 VALU issue bound (26k cycles per timestep per wavefront of 4 envs without contacts, '
+                                '43k on average under random actions, tools/prof_physics.py); the HBM figure is reported because the '
+                                'schema asks for it'},
            'cpu_baseline': None if a.no_cpu else sawyer_cpu_baseline(200, a.cpu_seconds)}
     print(json.dumps(res), flush=True)
   if world > 1:

@@ -80,7 +80,7 @@ class EARLEnvs(object):
                                            wide_init_distr=self._kwargs.get('wide_init_distr', False), **kw)
     if self._env_name == 'sawyer_door':
       # reference: earl_benchmark/__init__.py (sawyer_door.SawyerDoorV2(reward_type=..., reset_at_goal=...)); dynamics: this
-      # build's own stepper -- no contacts yet, parity with MuJoCo unpinned
+      # build's own stepper and contact model -- parity with MuJoCo unpinned
       from .envs import sawyer_door
       kw = dict(self._batch_kwargs)
       kw['seed'] = int(kw.get('seed', 0)) + seed_salt

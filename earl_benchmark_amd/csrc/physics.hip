@@ -18,7 +18,9 @@
 //      over active rows; the Hessian M + J' D J is nv x nv; the unilateral rows enter by an active-set iteration
 //      (Cholesky in registers, redundantly per lane: NV is a compile-time constant)
 //   K10 semi-implicit Euler with implicit joint damping: (M + dt B) a' = M a.
-// NO contacts yet.  Parity vs MuJoCo is unpinned; parity vs the reference above is tested to 1e-8.
+//   C0-C3 contacts: block bounding tests (lane = block) -> sphere / point vs box tests of the near blocks (lane = pair,
+//      ballot compaction into <= EARL_MAXCON contact records) -> 4 pyramid edges per contact as unilateral rows of K9.
+// Parity vs MuJoCo is unpinned; parity vs the reference above is tested to 1e-8 (1e-6 through contacts).
 //
 // Floating point: this file allows FMA contraction in the dynamics (nothing here is a bit-exact contract); the
 // observation / reward epilogue switches it off again so the success flag is the rule applied to the emitted numbers.

@@ -5,8 +5,9 @@ Mirrors `SawyerDoorV2` (reference: earl_benchmark/envs/sawyer_door.py) -- constr
 (hand xyz, gripper opening, handle xyz, goal[7]) -- for `num_envs` independent instances stepped by ONE kernel launch
 (one wavefront per env, csrc/physics.hip behind include/earl_physics.h).
 
-STATUS: the dynamics are this build's own articulated-body stepper: smooth dynamics + mocap weld + joint limits, NO
-contacts yet (the gripper passes through the door handle), and parity with MuJoCo is UNPINNED.  What is
+STATUS: the dynamics are this build's own articulated-body stepper: smooth dynamics, mocap weld, joint limits and a
+contact model of its own (gripper plates vs handle bars / door panel / frame / table; `contacts=False` switches it off);
+parity with MuJoCo is UNPINNED.  What is
 pinned: the sparse success rule (bit-exact on the reference's demonstrations), the model tables and forward kinematics
 (the reference's recorded handle / hand positions), the reset pose (6 mm).  `SawyerXYZEnv.step` semantics are upstream
 metaworld behaviour restated from SURVEY.md Appendix D.

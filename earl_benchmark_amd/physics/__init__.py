@@ -1,6 +1,6 @@
 """Batched articulated-body stepper (include/earl_physics.h): model tables -> device, raw step / forward calls.
 
-STATUS (round 1): smooth dynamics + weld / joint-limit constraints for the Sawyer-door model; NO contacts yet, parity with
+STATUS (round 1): smooth dynamics, weld / joint-limit constraints and frictional contacts for the Sawyer-door model; parity with
 MuJoCo unpinned.  The model tables are numeric facts compiled from the reference's MJCF by
 tools/mjcf_compile.py into earl_benchmark_amd/models/*.npz.
 """

@@ -1,6 +1,7 @@
 /* earl_physics.h -- C ABI of the batched articulated-body stepper (BASELINE config 3).
  *
- * STATUS: smooth dynamics + weld / joint-limit constraints; NO contacts yet.  Parity with MuJoCo is UNPINNED (the
+ * STATUS: smooth dynamics, weld / joint-limit constraints, frictional contacts (spheres / points vs boxes, pyramidal
+ * friction).  Parity with MuJoCo is UNPINNED (the
  * simulator is not available to this build): the kernel is tested against this build's own CPU reference
  * (oracle/physics_oracle.py: LinkModel) which follows MuJoCo's documented pipeline and is checked by first principles;
  * the model tables and forward kinematics ARE pinned by numbers recorded in the reference (tests/test_physics.py).

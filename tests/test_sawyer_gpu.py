@@ -158,3 +158,51 @@ def test_contact_dynamics_match_oracle_through_a_grasp(lm):
   assert ncon_steps >= 15
   assert ref.qpos[9] > ang + 0.3                       # the door was dragged towards closed
   assert bool((env.qpos[0] == env.qpos[1]).all())      # identical envs in one wavefront stay identical
+
+
+def test_all_demo_episodes_open_loop_loose():
+  """the 10 demonstration episodes replayed OPEN LOOP from their recorded start (door angle inverted from
+  the first recorded handle position).  The demonstrations come from MuJoCo with a feedback policy; this build's
+  stepper is a different simulator (sphere-chain handle, pyramidal friction, 8-contact cap), so only loose agreement is
+  asserted -- the bounds are what round 1 measures plus margin, and DESIGN.md quotes the measured values:
+  forward (close the door): every episode reaches the goal, handle path RMS < 13 cm;
+  reverse (pull the door open): the door is pulled every time (handle path RMS < 15 cm), not always to the goal."""
+  import torch
+  from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
+  eps = []
+  for d in ('forward', 'reverse'):
+    z = np.load(os.path.join(DEMOS, d, 'demo_data.npz'))
+    ends = np.nonzero(z['terminals'].ravel())[0] + 1
+    for s0, e0 in zip([0] + list(ends[:-1]), ends):
+      eps.append((d, z['observations'][s0], z['actions'][s0:e0], z['next_observations'][s0:e0]))
+  n, T = len(eps), max(len(e[2]) for e in eps)
+  assert n == 10
+  env = SawyerDoor(num_envs=n)
+  env.reset()
+  want_handle = np.stack([e[1][4:7] for e in eps]).astype(np.float64)
+  best, err = np.zeros(n), np.full(n, 1e9)
+  for a in np.linspace(-1.5, 0.1, 801):
+    env.qpos[:, 9] = a
+    e2 = ((env._get_obs()[:, 4:7].cpu().numpy() - want_handle) ** 2).sum(1)
+    m = e2 < err
+    best[m], err[m] = a, e2[m]
+  assert np.sqrt(err.max()) < 1e-3
+  env.qpos[:, 9] = torch.from_numpy(best).cuda()
+  env.goal_t[:] = torch.from_numpy(np.stack([e[1][7:] for e in eps]).astype(np.float64)).cuda()
+  acts = np.zeros((T, n, 4), np.float32)
+  for i, e in enumerate(eps):
+    acts[:len(e[2]), i] = e[2]
+  out = env.rollout(torch.from_numpy(acts).cuda())
+  obs, suc = out['obs'].cpu().numpy(), out['success'].cpu().numpy()
+  assert np.isfinite(obs).all()
+  for i, e in enumerate(eps):
+    L = len(e[2])
+    o, w = obs[:L, i], e[3]
+    handle_rms = np.sqrt(((o[:, 4:7] - w[:, 4:7]) ** 2).sum(1).mean())
+    start = np.linalg.norm(w[0, 4:7] - w[0, 11:14])
+    closest = np.linalg.norm(o[:, 4:7] - o[:, 11:14], axis=1).min()
+    if e[0] == 'forward':
+      assert suc[:L, i].any() and handle_rms < 0.13, (i, handle_rms)
+    else:
+      assert handle_rms < 0.15 and closest < 0.95 * start, (i, handle_rms, closest, start)
+    assert (o[:, 9 - 9 + 3] >= 0).all() and (np.abs(o[:, 6] - 0.10003595) < 1e-6).all()     # handle height never changes (hinge about z)
