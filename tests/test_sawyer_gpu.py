@@ -206,3 +206,63 @@ def test_all_demo_episodes_open_loop_loose():
     else:
       assert handle_rms < 0.15 and closest < 0.95 * start, (i, handle_rms, closest, start)
     assert (o[:, 9 - 9 + 3] >= 0).all() and (np.abs(o[:, 6] - 0.10003595) < 1e-6).all()     # handle height never changes (hinge about z)
+
+
+def test_shards_equal_one_batch_and_both_lane_layouts_agree():
+  """env-range sharding: two half shards (env_offset) reproduce one batch bit for bit, resets included (Philox streams are
+  keyed by the global env id); and one-wavefront-per-env (64 lanes) gives the same numbers as four envs per wavefront"""
+  import torch
+  from earl_benchmark_amd import _abi
+  from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
+  lib = _abi.load()
+  n, T = 10, 12
+  g = torch.Generator().manual_seed(5)
+  acts = (torch.rand(T, n, 4, generator=g) * 2 - 1).cuda()
+  acts[:, :, :3] = torch.tensor([0.9, 0.6, -0.9]).cuda()        # head for the table / door: contacts appear
+  runs = {}
+  try:
+    for lanes in (16, 64):
+      _abi.check(lib.earl_debug_set_physics_lanes(lanes), 'lanes')
+      full = SawyerDoor(num_envs=n, seed=3)
+      o0 = full.reset()
+      out = full.rollout(acts)
+      runs[lanes] = (o0.clone(), out['obs'].clone(), out['reward'].clone(), full.qpos.clone())
+      if lanes == 16:
+        a, b = SawyerDoor(num_envs=6, seed=3, env_offset=0), SawyerDoor(num_envs=4, seed=3, env_offset=6)
+        oa, ob = a.reset(), b.reset()
+        assert torch.equal(torch.cat([oa, ob]), o0)
+        ra, rb = a.rollout(acts[:, :6].contiguous()), b.rollout(acts[:, 6:].contiguous())
+        assert torch.equal(torch.cat([ra['obs'], rb['obs']], 1), out['obs'])
+        assert torch.equal(torch.cat([a.qpos, b.qpos]), full.qpos)
+  finally:
+    _abi.check(lib.earl_debug_set_physics_lanes(16), 'lanes')
+  for x, y in zip(runs[16], runs[64]):
+    assert torch.equal(x, y)
+  assert len(torch.unique(runs[16][0][:, 4])) == n              # every env drew its own door angle
+
+
+def test_masked_reset_state_dict_and_lifelong_loader():
+  import earl_benchmark_amd as eb
+  import torch
+  loader = eb.EARLEnvs('sawyer_door', reward_type='dense', setup_as_lifelong_learning=True, num_envs=5, train_horizon=7,
+                       goal_change_frequency=3)
+  env = loader.get_envs()
+  o = env.reset()
+  u = env.unwrapped
+  acts = torch.zeros(4, 5, 4).cuda(); acts[..., 2] = -1.0
+  out = env.rollout(acts)
+  np.testing.assert_allclose(env.lifelong_return.cpu().numpy(), out['reward'].double().sum(0).cpu().numpy(), rtol=1e-12)
+  sd = u.state_dict()
+  before = u.qpos.clone()
+  mask = torch.tensor([1, 0, 0, 1, 0], dtype=torch.bool).cuda()
+  o2 = env.reset(mask=mask)
+  assert torch.equal(u.qpos[~mask], before[~mask]) and not torch.equal(u.qpos[mask], before[mask])
+  assert u.steps_since_reset.tolist() == [0, 4, 4, 0, 4] and env.num_interventions.tolist() == [2, 1, 1, 2, 1]
+  np.testing.assert_allclose(o2[~mask].cpu().numpy(), u._get_obs()[~mask].cpu().numpy(), atol=0)
+  u.load_state_dict(sd)
+  assert torch.equal(u.qpos, before) and u.steps_since_reset.tolist() == [4] * 5
+  o3, r3, d3, _ = env.step(acts[0])
+  assert d3.tolist() == [False] * 5
+  for _ in range(2):
+    o3, r3, d3, _ = env.step(acts[0])
+  assert d3.tolist() == [True] * 5                                # horizon 7 reached
