@@ -182,3 +182,34 @@ def test_block_cull_never_drops_a_contact():
     assert c1 == c2
     found += len(c1)
   assert found > 10
+
+
+def test_active_set_newton_converges_to_the_kkt_point_through_a_grasp():
+  """forward demonstration 0 (grasp, drag, release): every constraint solve of the replay reaches a fixed active set
+  within the kernel's 8 iterations, i.e. the exact minimiser of the convex primal problem: active unilateral rows pull
+  (J a < aref, force > 0), inactive ones are satisfied (J a >= aref)"""
+  from oracle.sawyer_oracle import SawyerDoorOracle
+  lm = po.LinkModel(LINKS)
+  seen = []
+  orig = po.LinkModel.solve_primal
+
+  def checked(self, M, tau, J, aref, D, is_eq, iters=8):
+    a, act = orig(self, M, tau, J, aref, D, is_eq, iters)
+    x = J @ a - aref
+    want = is_eq | (x < 0)
+    seen.append(((want == act).all(), len(aref), int((~is_eq & act).sum())))
+    g = M @ a - tau + J[act].T @ (D[act] * x[act])             # gradient of the primal cost at the returned point
+    assert np.abs(g).max() < 1e-6 * (1 + np.abs(tau).max())
+    return a, act
+  po.LinkModel.solve_primal = checked
+  try:
+    z = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'demonstrations', 'sawyer_door', 'forward', 'demo_data.npz'))
+    env = SawyerDoorOracle(lm)
+    env.reset()
+    env.qpos[9] = -0.894                                       # the recorded start of this episode (handle [0.0667, 0.49, 0.1])
+    for t in range(60):
+      env.step(z['actions'][t])
+  finally:
+    po.LinkModel.solve_primal = orig
+  seen = np.array(seen)
+  assert seen[:, 0].all() and seen[:, 1].max() > 30 and seen[:, 2].max() >= 8      # converged every time; contact rows were in play
