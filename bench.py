@@ -238,9 +238,9 @@ def main_sawyer(a, torch, dist, world, rank, device):
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': None, 'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
                         'algorithmic_bytes_per_launch': per_launch, 'bytes_per_env_step': bytes_per_env_step,
-                        'note': 'not HBM-bound: fp64 VALU issue bound (26k cycles per timestep per wavefront of 4 envs without contacts, '
-                                '43k on average under random actions, tools/prof_physics.py); the HBM figure is reported because the '
-                                'schema asks for it'},
+                        'note': 'not HBM-bound: 46 % of wave cycles issue instructions (32 % fp64 VALU, 7.5 % LDS), 49 % wait on '
+                                'LDS / memory counters at one wave per SIMD (profiles/r01_sawyer_rollout_pmc.json); 43k cycles per '
+                                'timestep per wavefront of 4 envs; the HBM figure is reported because the schema asks for it'},
            'cpu_baseline': None if a.no_cpu else sawyer_cpu_baseline(200, a.cpu_seconds)}
     print(json.dumps(res), flush=True)
   if world > 1:
