@@ -267,6 +267,7 @@ __global__ __launch_bounds__(kBlock) void valid_init_kernel(int n, const double*
 // host side
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[512] = "";
+int g_rollout_lds_pad = 0;  // extra dynamic LDS per workgroup of the wave-specialised kernel (limits co-residency; tuning)
 int g_rollout_impl = 0;  // 0 = auto (wave-specialised when applicable), 1 = force the plain one-lane-per-env kernel
 
 int fail(int code, const char* fmt, ...) {
@@ -382,7 +383,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
       const dim3 grid((unsigned)((cfg->n + 63) / 64));
       const hipStream_t hs = (hipStream_t)stream;
 #define EARL_WS(RT, NC, NL, NS, K, LEAD) \
-  rollout_ws_kernel<RT, NC, NL, NS, K, LEAD><<<grid, 64 * (NC + NL + NS), 0, hs>>>(w)
+  rollout_ws_kernel<RT, NC, NL, NS, K, LEAD><<<grid, 64 * (NC + NL + NS), g_rollout_lds_pad, hs>>>(w)
       if (cfg->reward_type == EARL_REWARD_SPARSE) {
         switch (g_rollout_impl) {   // tuning variants (tools/tune_rollout.py); 0 = the shipped configuration
           case 2: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 4, 6); break;
@@ -502,8 +503,9 @@ int earl_tabletop3_reward(int32_t n, const float* obs, int32_t reward_type, floa
 
 /* test/bench hook: choose the rollout kernel (0 auto, 1 plain); returns the previous value */
 int earl_debug_set_rollout_impl(int impl) {
-  const int prev = g_rollout_impl;
-  g_rollout_impl = impl;
+  const int prev = g_rollout_impl + 1000 * (g_rollout_lds_pad / 1024);
+  g_rollout_lds_pad = (impl / 1000) * 1024;        // thousands digit and up: KiB of LDS padding per workgroup
+  g_rollout_impl = impl % 1000;
   return prev;
 }
 
