@@ -83,7 +83,7 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world):
   gathered = None
   if world > 1:                 # the one collective of the job: evaluation result of the last rollout -> every rank
     from earl_benchmark_amd import sharding
-    gathered = sharding.gather_summary(sharding.rollout_summary(out[1], out[3]))    # [N_global, 2] return, success
+    gathered = sharding.gather_summary(sharding.rollout_summary(out[1], out[3]), sizes=[acts.shape[1]] * world)   # [N_global, 2]
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()

@@ -33,15 +33,18 @@ def rollout_summary(reward, success):
   return torch.stack([reward.sum(0), success[-1].to(reward.dtype)], 1).contiguous()
 
 
-def gather_summary(summary, group=None):
+def gather_summary(summary, group=None, sizes=None):
   """The single collective of an evaluation job: every rank receives the [N_global, 2] table (rank order = env order).
-  One all_gather_into_tensor of the (padded, if the shards are ragged) per-rank tables."""
+  One all_gather_into_tensor of the (padded, if the shards are ragged) per-rank tables.  `sizes` (rows per rank), when
+  the caller knows them -- shard_range is deterministic -- saves the size exchange and its host synchronisation."""
   if not dist.is_initialized() or dist.get_world_size(group) == 1:
     return summary
   world = dist.get_world_size(group)
-  sizes = [torch.zeros(1, dtype=torch.int64, device=summary.device) for _ in range(world)]
-  dist.all_gather(sizes, torch.tensor([summary.shape[0]], dtype=torch.int64, device=summary.device), group=group)
-  sizes = [int(s.item()) for s in sizes]
+  if sizes is None:
+    sizes = [torch.zeros(1, dtype=torch.int64, device=summary.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([summary.shape[0]], dtype=torch.int64, device=summary.device), group=group)
+    sizes = [int(s.item()) for s in sizes]
+  assert len(sizes) == world and sizes[dist.get_rank(group)] == summary.shape[0]
   if len(set(sizes)) == 1:
     out = torch.empty(world * sizes[0], *summary.shape[1:], dtype=summary.dtype, device=summary.device)
     dist.all_gather_into_tensor(out, summary.contiguous(), group=group)

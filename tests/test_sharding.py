@@ -47,6 +47,9 @@ def _worker(rank, world, port, n_global, T, ragged, out_dir):
     obs, rew, done, succ = o.rollout(np.ascontiguousarray(acts_global[:, lo:lo + n]))
     summary = sh.rollout_summary(torch.from_numpy(rew), torch.from_numpy(succ.astype(bool)))
     table = sh.gather_summary(summary)
+    # the same gather when the caller supplies the (deterministic) shard sizes: no size exchange
+    known = [b - a for a, b in (sh.shard_range(n_global + (1 if ragged else 0), r, world) for r in range(world))]
+    assert torch.equal(sh.gather_summary(summary, sizes=known), table)
     # max-over-ranks timing plumbing of bench.py: all_reduce(MAX)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
