@@ -157,6 +157,8 @@ struct Shared {
   double tau[NV];
   double att[4][3];
   double ct[EARL_MAXCON][10];        // contact records: dist, normal (3), point (3), class, sphere link, box link
+  double bank_pad[8];                // sizeof(Shared<10>) would be 31 * 256 B: the four env blocks of a wave would sit on the same LDS
+                                     // banks and every broadcast access would conflict 4 ways; +64 B staggers them by 16 banks
   union {
     struct { double Xq1[NV][4], Xp1[NV][4]; } k2;                    // second buffer of the doubling
     struct {
