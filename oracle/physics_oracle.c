@@ -1,0 +1,471 @@
+/* physics_oracle.c -- plain C restatement of the articulated-body stepper, one env at a time (scalar loops).
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  It restates oracle/physics_oracle.py (LinkModel.forward / step / collide /
+ * contact_rows / solve_primal), which remains the readable statement; this file exists (a) as a third implementation to
+ * cross-check the numpy one and the HIP kernels, (b) as the CPU baseline of `bench.py --workload sawyer_door` (OpenMP over
+ * envs).  PARITY WITH MUJOCO IS UNPINNED, exactly as for the numpy statement (see its header and DESIGN.md section 9);
+ * the env glue follows oracle/sawyer_oracle.py (reference: earl_benchmark/envs/sawyer_door.py:86-177, metaworld upstream).
+ * The structs are the public ones of include/earl_physics.h (host copies).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/earl_physics.h"
+
+#define NVMAX EARL_MAXV
+#define NROWMAX (6 + 2 * EARL_MAXV + 4 * EARL_MAXCON)
+
+typedef struct { double w, x, y, z; } Q4;
+typedef struct { double x, y, z; } V3;
+
+static Q4 qmul(Q4 a, Q4 b) {
+  Q4 r = {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+  return r;
+}
+static void qmat(Q4 q, double R[3][3]) {
+  R[0][0] = 1 - 2 * (q.y * q.y + q.z * q.z); R[0][1] = 2 * (q.x * q.y - q.w * q.z); R[0][2] = 2 * (q.x * q.z + q.w * q.y);
+  R[1][0] = 2 * (q.x * q.y + q.w * q.z); R[1][1] = 1 - 2 * (q.x * q.x + q.z * q.z); R[1][2] = 2 * (q.y * q.z - q.w * q.x);
+  R[2][0] = 2 * (q.x * q.z - q.w * q.y); R[2][1] = 2 * (q.y * q.z + q.w * q.x); R[2][2] = 1 - 2 * (q.x * q.x + q.y * q.y);
+}
+static V3 v3(double x, double y, double z) { V3 r = {x, y, z}; return r; }
+static V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
+static Q4 ldq(const double* p) { Q4 r = {p[0], p[1], p[2], p[3]}; return r; }
+static V3 mulv(double R[3][3], V3 v) { return v3(R[0][0] * v.x + R[0][1] * v.y + R[0][2] * v.z, R[1][0] * v.x + R[1][1] * v.y + R[1][2] * v.z, R[2][0] * v.x + R[2][1] * v.y + R[2][2] * v.z); }
+static V3 mulvT(double R[3][3], V3 v) { return v3(R[0][0] * v.x + R[1][0] * v.y + R[2][0] * v.z, R[0][1] * v.x + R[1][1] * v.y + R[2][1] * v.z, R[0][2] * v.x + R[1][2] * v.y + R[2][2] * v.z); }
+static V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static V3 scl(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+static double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static double pick(V3 v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
+
+/* compact spatial inertia about the world origin: {m, m c (3), Io xx yy zz xy xz yz}; I [w; v] = [n; f] */
+static void iapply(const double* I, V3 w, V3 v, V3* n, V3* f) {
+  V3 h = ld3(I + 1);
+  *n = add(v3(I[4] * w.x + I[7] * w.y + I[8] * w.z, I[7] * w.x + I[5] * w.y + I[9] * w.z, I[8] * w.x + I[9] * w.y + I[6] * w.z), cross(h, v));
+  *f = sub(scl(v, I[0]), cross(h, w));
+}
+
+static void kbimp(const double* solref, const double* solimp, double r, double dt, double* k, double* b, double* d) {
+  const double tc = fmax(solref[0], 2 * dt), dr = solref[1];
+  const double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  const double x = width > 0 ? fmin(fabs(r) / width, 1.0) : 1.0;
+  double y;
+  if (power == 1 || d0 == dw) y = x;
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  *d = d0 + y * (dw - d0);
+  *k = 1.0 / (dw * dw * tc * tc * dr * dr);
+  *b = 2.0 / (dw * tc);
+}
+
+/* dense Cholesky solve of an SPD system, n <= NVMAX; A is destroyed */
+static void chol_solve(int n, double A[NVMAX][NVMAX], double* x) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[j][j];
+    for (int p = 0; p < j; ++p) d -= A[j][p] * A[j][p];
+    d = sqrt(d);
+    A[j][j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[i][j];
+      for (int p = 0; p < j; ++p) s -= A[i][p] * A[j][p];
+      A[i][j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    double s = x[i];
+    for (int p = 0; p < i; ++p) s -= A[i][p] * x[p];
+    x[i] = s / A[i][i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = x[i];
+    for (int p = i + 1; p < n; ++p) s -= A[p][i] * x[p];
+    x[i] = s / A[i][i];
+  }
+}
+
+typedef struct {
+  double Xq[NVMAX][4], Xp[NVMAX][3];      /* world frames of the links at the start of the last timestep */
+  double qacc[NVMAX];
+  double efc[6 + 2 * NVMAX];
+  int ncon;
+} StepOut;
+
+/* one timestep (integrate != 0) or the forward quantities only; reference: LinkModel.forward / step */
+static void substep(const earl_link_model* m, const earl_collision_model* col, double* qp, double* qv, V3 mpos, Q4 mq, const double* ctrl,
+                    int integrate, StepOut* o) {
+  const int nv = m->nv;
+  const double dt = m->dt;
+  double S[NVMAX][6], I10[NVMAX][10], Ic[NVMAX][10], M[NVMAX][NVMAX], tau[NVMAX];
+  /* kinematics (parents precede children) */
+  for (int l = 0; l < nv; ++l) {
+    const int p = m->parent[l];
+    Q4 pq = {1, 0, 0, 0};
+    V3 pp = {0, 0, 0};
+    if (p >= 0) { pq = ldq(o->Xq[p]); pp = ld3(o->Xp[p]); }
+    double Rp[3][3], R[3][3];
+    qmat(pq, Rp);
+    V3 x = add(pp, mulv(Rp, ld3(m->tpos[l])));
+    Q4 q = qmul(pq, ldq(m->tquat[l]));
+    qmat(q, R);
+    const V3 ax = ld3(m->jaxis[l]);
+    const V3 anchor = add(x, mulv(R, ld3(m->jpos[l]))), axw = mulv(R, ax);
+    if (m->jtype[l] == 0) {
+      const double h = 0.5 * qp[l], sn = sin(h), cs = cos(h);
+      Q4 qj = {cs, sn * ax.x, sn * ax.y, sn * ax.z};
+      q = qmul(q, qj);
+      qmat(q, R);
+      x = sub(anchor, mulv(R, ld3(m->jpos[l])));
+      const V3 sv = cross(anchor, axw);
+      S[l][0] = axw.x; S[l][1] = axw.y; S[l][2] = axw.z; S[l][3] = sv.x; S[l][4] = sv.y; S[l][5] = sv.z;
+    } else {
+      x = add(x, scl(axw, qp[l]));
+      S[l][0] = S[l][1] = S[l][2] = 0; S[l][3] = axw.x; S[l][4] = axw.y; S[l][5] = axw.z;
+    }
+    o->Xq[l][0] = q.w; o->Xq[l][1] = q.x; o->Xq[l][2] = q.y; o->Xq[l][3] = q.z;
+    o->Xp[l][0] = x.x; o->Xp[l][1] = x.y; o->Xp[l][2] = x.z;
+    /* spatial inertia */
+    const double mass = m->mass[l];
+    const V3 c = add(x, mulv(R, ld3(m->com[l])));
+    const double* in = m->inertia[l];
+    const double I[3][3] = {{in[0], in[3], in[4]}, {in[3], in[1], in[5]}, {in[4], in[5], in[2]}};
+    double T[3][3], W[3][3];
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) T[r][cc] = R[r][0] * I[0][cc] + R[r][1] * I[1][cc] + R[r][2] * I[2][cc];
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) W[r][cc] = T[r][0] * R[cc][0] + T[r][1] * R[cc][1] + T[r][2] * R[cc][2];
+    const double c2 = dot(c, c);
+    double* i10 = I10[l];
+    i10[0] = mass; i10[1] = mass * c.x; i10[2] = mass * c.y; i10[3] = mass * c.z;
+    i10[4] = W[0][0] + mass * (c2 - c.x * c.x); i10[5] = W[1][1] + mass * (c2 - c.y * c.y); i10[6] = W[2][2] + mass * (c2 - c.z * c.z);
+    i10[7] = W[0][1] - mass * c.x * c.y; i10[8] = W[0][2] - mass * c.x * c.z; i10[9] = W[1][2] - mass * c.y * c.z;
+  }
+  /* composite inertias, mass matrix */
+  memcpy(Ic, I10, sizeof(Ic));
+  for (int l = nv - 1; l >= 0; --l)
+    if (m->parent[l] >= 0) for (int e = 0; e < 10; ++e) Ic[m->parent[l]][e] += Ic[l][e];
+  memset(M, 0, sizeof(M));
+  for (int i = 0; i < nv; ++i) {
+    V3 n, f;
+    iapply(Ic[i], ld3(S[i]), ld3(S[i] + 3), &n, &f);
+    for (int j = i; j >= 0; j = m->parent[j]) {
+      const double v = dot(ld3(S[j]), n) + dot(ld3(S[j] + 3), f);
+      M[i][j] = M[j][i] = v;
+    }
+    M[i][i] += m->armature[i];
+  }
+  /* bias forces (RNE) */
+  {
+    double Vw[NVMAX][6], Aw[NVMAX][6], F[NVMAX][6];
+    for (int l = 0; l < nv; ++l) {
+      const int p = m->parent[l];
+      V3 wp = {0, 0, 0}, vp = {0, 0, 0}, awp = {0, 0, 0}, avp = {-m->gravity[0], -m->gravity[1], -m->gravity[2]};
+      if (p >= 0) { wp = ld3(Vw[p]); vp = ld3(Vw[p] + 3); awp = ld3(Aw[p]); avp = ld3(Aw[p] + 3); }
+      const V3 sw = ld3(S[l]), sv = ld3(S[l] + 3);
+      const double qd = qv[l];
+      const V3 aw = add(awp, scl(cross(wp, sw), qd)), av = add(avp, scl(add(cross(vp, sw), cross(wp, sv)), qd));
+      const V3 w = add(wp, scl(sw, qd)), v = add(vp, scl(sv, qd));
+      V3 n1, f1, n2, f2;
+      iapply(I10[l], aw, av, &n1, &f1);
+      iapply(I10[l], w, v, &n2, &f2);
+      const V3 n = add(n1, add(cross(w, n2), cross(v, f2))), f = add(f1, cross(w, f2));
+      Vw[l][0] = w.x; Vw[l][1] = w.y; Vw[l][2] = w.z; Vw[l][3] = v.x; Vw[l][4] = v.y; Vw[l][5] = v.z;
+      Aw[l][0] = aw.x; Aw[l][1] = aw.y; Aw[l][2] = aw.z; Aw[l][3] = av.x; Aw[l][4] = av.y; Aw[l][5] = av.z;
+      F[l][0] = n.x; F[l][1] = n.y; F[l][2] = n.z; F[l][3] = f.x; F[l][4] = f.y; F[l][5] = f.z;
+    }
+    for (int l = nv - 1; l >= 0; --l)
+      if (m->parent[l] >= 0) for (int e = 0; e < 6; ++e) F[m->parent[l]][e] += F[l][e];
+    for (int l = 0; l < nv; ++l) {
+      double bias = 0;
+      for (int e = 0; e < 6; ++e) bias += S[l][e] * F[l][e];
+      tau[l] = -m->damping[l] * qv[l] - bias;
+    }
+    for (int ac = 0; ac < m->n_act; ++ac) {
+      const int j = m->act_joint[ac];
+      const double c = fmin(fmax(ctrl[ac], m->act_ctrlrange[ac][0]), m->act_ctrlrange[ac][1]);
+      tau[j] += m->act_kp[ac] * (c - qp[j]);
+    }
+  }
+  /* constraint rows */
+  double J[NROWMAX][NVMAX], aref[NROWMAX], D[NROWMAX];
+  int iseq[NROWMAX], rowid[NROWMAX], nr = 0;       /* rowid: position in the efc output (weld 0..5, limits 6 + 2 j + side), -1 otherwise */
+  memset(J, 0, sizeof(J));
+  {
+    const int k = m->weld_att, la = m->att_link[k];
+    double R[3][3], Rh[3][3];
+    const Q4 ql = ldq(o->Xq[la]);
+    qmat(ql, R);
+    const V3 hp = add(ld3(o->Xp[la]), mulv(R, ld3(m->att_pos[k])));
+    const Q4 hq = qmul(ql, ldq(m->att_quat[k]));
+    const Q4 hc = {hq.w, -hq.x, -hq.y, -hq.z};
+    const Q4 e = qmul(hc, mq);
+    const V3 ev = {e.x, e.y, e.z};
+    qmat(hq, Rh);
+    const V3 rpos = sub(mpos, hp);
+    for (int j = la; j >= 0; j = m->parent[j]) {
+      const V3 sw = ld3(S[j]), sv = ld3(S[j] + 3);
+      const V3 pv = add(sv, cross(sw, hp));
+      const V3 a = mulvT(Rh, sw);
+      const V3 jq = add(scl(a, e.w), cross(a, ev));
+      J[0][j] = -pv.x; J[1][j] = -pv.y; J[2][j] = -pv.z;
+      J[3][j] = -0.5 * jq.x; J[4][j] = -0.5 * jq.y; J[5][j] = -0.5 * jq.z;
+    }
+    for (int r = 0; r < 6; ++r) {
+      const double res = r < 3 ? pick(rpos, r) : pick(ev, r - 3);
+      double Jv = 0, kk, bb, dd;
+      for (int j = 0; j < nv; ++j) Jv += J[r][j] * qv[j];
+      kbimp(m->weld_solref, m->weld_solimp, res, dt, &kk, &bb, &dd);
+      aref[r] = -bb * Jv - kk * dd * res;
+      D[r] = 1.0 / fmax((1 - dd) / dd * m->weld_invweight[r < 3 ? 0 : 1], 1e-15);
+      iseq[r] = 1; rowid[r] = r;
+    }
+    nr = 6;
+  }
+  for (int j = 0; j < nv; ++j) {
+    if (!m->limited[j]) continue;
+    for (int side = 0; side < 2; ++side) {
+      const double res = side == 0 ? qp[j] - m->range[j][0] : m->range[j][1] - qp[j];
+      if (!(res < 0)) continue;
+      const double sg = side == 0 ? 1.0 : -1.0;
+      double kk, bb, dd;
+      kbimp(m->jsolref[j], m->jsolimp[j], res, dt, &kk, &bb, &dd);
+      J[nr][j] = sg;
+      aref[nr] = -bb * (sg * qv[j]) - kk * dd * res;
+      D[nr] = 1.0 / fmax((1 - dd) / dd * m->dof_invweight[j], 1e-15);
+      iseq[nr] = 0; rowid[nr] = 6 + 2 * j + side;
+      ++nr;
+    }
+  }
+  for (int j = 0; j < nv; ++j)
+    if (m->drag_G[j] != 0) {                        /* soft velocity row of a permanent dragging contact */
+      J[nr][j] = 1.0; aref[nr] = -m->drag_b[j] * qv[j]; D[nr] = m->drag_G[j]; iseq[nr] = 1; rowid[nr] = -1;
+      ++nr;
+    }
+  o->ncon = 0;
+  if (col) {
+    int ncon = 0;
+    for (int b = 0; b < col->n_blk && ncon < EARL_MAXCON; ++b) {
+      const int bi = col->blk_box[b], bl = col->blk_link[b], xl = col->box_link[bi];
+      V3 cs = ld3(col->blk_center[b]), pb = ld3(col->box_pos[bi]);
+      Q4 qb = ldq(col->box_quat[bi]);
+      double R[3][3], Rb[3][3];
+      if (bl >= 0) { qmat(ldq(o->Xq[bl]), R); cs = add(ld3(o->Xp[bl]), mulv(R, cs)); }
+      if (xl >= 0) { const Q4 ql = ldq(o->Xq[xl]); qmat(ql, R); pb = add(ld3(o->Xp[xl]), mulv(R, pb)); qb = qmul(ql, qb); }
+      qmat(qb, Rb);
+      const V3 h = ld3(col->box_half[bi]);
+      {
+        const V3 x = mulvT(Rb, sub(cs, pb));
+        const V3 d = v3(x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z));
+        if (!(dot(d, d) < col->blk_reach[b] * col->blk_reach[b])) continue;
+      }
+      for (int pi = col->blk_begin[b]; pi < col->blk_end[b] && ncon < EARL_MAXCON; ++pi) {
+        const int lk = col->pair_rec[pi].sph_link, cls = col->pair_rec[pi].cls;
+        const double r = col->pair_rec[pi].r, margin = col->pair_rec[pi].margin;
+        V3 c = ld3(col->pair_rec[pi].pos);
+        if (lk >= 0) { qmat(ldq(o->Xq[lk]), R); c = add(ld3(o->Xp[lk]), mulv(R, c)); }
+        const V3 x = mulvT(Rb, sub(c, pb));
+        V3 q = v3(fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z));
+        double dist;
+        V3 nl;
+        if (fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z) {
+          const V3 d = sub(x, q);
+          const double nd = sqrt(dot(d, d));
+          dist = nd - r; nl = scl(d, 1.0 / nd);
+        } else {
+          const double gx = h.x - fabs(x.x), gy = h.y - fabs(x.y), gz = h.z - fabs(x.z);
+          const int ax = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
+          const double xa = pick(x, ax), ha = pick(h, ax), sg = xa >= 0 ? 1.0 : -1.0;
+          nl = v3(ax == 0 ? sg : 0, ax == 1 ? sg : 0, ax == 2 ? sg : 0);
+          q = v3(ax == 0 ? sg * ha : x.x, ax == 1 ? sg * ha : x.y, ax == 2 ? sg * ha : x.z);
+          dist = -(ha - fabs(xa)) - r;
+        }
+        if (!(dist < margin)) continue;
+        const V3 n = mulv(Rb, nl);
+        const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
+        /* tangents: n x (the coordinate axis least aligned with n) */
+        const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
+        const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
+        V3 t1 = cross(n, v3(ia == 0, ia == 1, ia == 2));
+        t1 = scl(t1, 1.0 / sqrt(dot(t1, t1)));
+        const V3 t2 = cross(n, t1);
+        double Jn[NVMAX] = {0}, Jt1[NVMAX] = {0}, Jt2[NVMAX] = {0};
+        for (int pass = 0; pass < 2; ++pass) {
+          const double sgn = pass == 0 ? 1.0 : -1.0;
+          for (int j = pass == 0 ? lk : xl; j >= 0; j = m->parent[j]) {
+            const V3 Jp = scl(add(ld3(S[j] + 3), cross(ld3(S[j]), p)), sgn);
+            Jn[j] += dot(n, Jp); Jt1[j] += dot(t1, Jp); Jt2[j] += dot(t2, Jp);
+          }
+        }
+        const double mu = col->cls_mu[cls];
+        double kk, bb, dd;
+        kbimp(col->cls_solref[cls], col->cls_solimp[cls], dist - margin, dt, &kk, &bb, &dd);
+        const double R0 = fmax((1 - dd) / dd * col->cls_invw[cls], 1e-15);
+        for (int e = 0; e < 4; ++e) {
+          const double s1 = e == 0 ? mu : (e == 1 ? -mu : 0.0), s2 = e == 2 ? mu : (e == 3 ? -mu : 0.0);
+          double vel = 0;
+          for (int j = 0; j < nv; ++j) { J[nr][j] = Jn[j] + s1 * Jt1[j] + s2 * Jt2[j]; vel += J[nr][j] * qv[j]; }
+          aref[nr] = -bb * vel - kk * dd * (dist - margin);
+          D[nr] = 1.0 / (2 * mu * mu * R0);
+          iseq[nr] = 0; rowid[nr] = -1;
+          ++nr;
+        }
+        ++ncon;
+      }
+    }
+    o->ncon = ncon;
+  }
+  /* primal active-set Newton (LinkModel.solve_primal) */
+  int act[NROWMAX];
+  double a[NVMAX];
+  for (int r = 0; r < nr; ++r) act[r] = 1;
+  for (int it = 0; it < 8; ++it) {
+    double H[NVMAX][NVMAX];
+    for (int i = 0; i < nv; ++i) { a[i] = tau[i]; for (int j = 0; j < nv; ++j) H[i][j] = M[i][j]; }
+    for (int r = 0; r < nr; ++r) {
+      if (!act[r]) continue;
+      for (int i = 0; i < nv; ++i) {
+        if (J[r][i] == 0) continue;
+        const double w = D[r] * J[r][i];
+        a[i] += w * aref[r];
+        for (int j = 0; j < nv; ++j) H[i][j] += w * J[r][j];
+      }
+    }
+    chol_solve(nv, H, a);
+    int changed = 0;
+    for (int r = 0; r < nr; ++r) {
+      double x = -aref[r];
+      for (int j = 0; j < nv; ++j) x += J[r][j] * a[j];
+      const int want = iseq[r] || x < 0;
+      changed |= want != act[r];
+      act[r] = want;
+    }
+    if (!changed) break;
+  }
+  for (int i = 0; i < nv; ++i) o->qacc[i] = a[i];
+  memset(o->efc, 0, sizeof(o->efc));
+  for (int r = 0; r < nr; ++r) {
+    if (rowid[r] < 0 || !act[r]) continue;
+    double x = -aref[r];
+    for (int j = 0; j < nv; ++j) x += J[r][j] * a[j];
+    o->efc[rowid[r]] = -D[r] * x;
+  }
+  if (integrate) {   /* semi-implicit Euler, joint damping implicit: (M + dt B) a' = M a */
+    double H[NVMAX][NVMAX], rhs[NVMAX];
+    for (int i = 0; i < nv; ++i) {
+      rhs[i] = 0;
+      for (int j = 0; j < nv; ++j) { rhs[i] += M[i][j] * a[j]; H[i][j] = M[i][j]; }
+      H[i][i] += dt * m->damping[i];
+    }
+    chol_solve(nv, H, rhs);
+    for (int i = 0; i < nv; ++i) { qv[i] += dt * rhs[i]; qp[i] += dt * qv[i]; }
+  }
+}
+
+static V3 attachment(const earl_link_model* m, const StepOut* o, int k) {
+  const int la = m->att_link[k];
+  V3 p = ld3(m->att_pos[k]);
+  if (la >= 0) { double R[3][3]; qmat(ldq(o->Xq[la]), R); p = add(ld3(o->Xp[la]), mulv(R, p)); }
+  return p;
+}
+static Q4 qnormalize(Q4 q) {
+  const double s = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  Q4 r = {q.w * s, q.x * s, q.y * s, q.z * s};
+  return r;
+}
+
+int oracle_set_physics_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
+/* earl_physics_step / earl_physics_forward on host arrays (integrate: 1 = step nsub times, 0 = forward quantities) */
+int oracle_physics(const earl_link_model* m, const earl_collision_model* col, int32_t n, int32_t nsub, int32_t integrate, double* qpos,
+                   double* qvel, const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc, double* efc,
+                   double* att_xpos, int32_t* ncon) {
+  const int nv = m->nv;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < n; ++e) {
+    StepOut o;
+    const V3 mpos = ld3(mocap_pos + 3 * (size_t)e);
+    const Q4 mq = qnormalize(ldq(mocap_quat + 4 * (size_t)e));
+    for (int ts = 0; ts < (integrate ? nsub : 1); ++ts)
+      substep(m, col, qpos + (size_t)e * nv, qvel + (size_t)e * nv, mpos, mq, ctrl + (size_t)e * m->n_act, integrate, &o);
+    if (qacc) memcpy(qacc + (size_t)e * nv, o.qacc, sizeof(double) * nv);
+    if (efc) memcpy(efc + (size_t)e * (6 + 2 * nv), o.efc, sizeof(double) * (6 + 2 * nv));
+    if (ncon) ncon[e] = o.ncon;
+    if (att_xpos)
+      for (int k = 0; k < m->n_att; ++k) {
+        const V3 p = attachment(m, &o, k);
+        double* d = att_xpos + ((size_t)e * m->n_att + k) * 3;
+        d[0] = p.x; d[1] = p.y; d[2] = p.z;
+      }
+  }
+  return 0;
+}
+
+static double tolerance_gaussian(double x, double hi, double margin) {
+  if (0.0 <= x && x <= hi) return 1.0;
+  if (margin == 0) return 0.0;
+  const double d = (x < 0.0 ? -x : x - hi) / margin, scale = sqrt(-2.0 * log(0.1));
+  return exp(-0.5 * (d * scale) * (d * scale));
+}
+
+/* earl_sawyer_rollout on host arrays (same cfg / state / out structs with host pointers); reference: oracle/sawyer_oracle.py */
+int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* col, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+                          const float* action, int32_t T, const earl_sawyer_out* out) {
+  const int nv = m->nv, n = cfg->n;
+  const float scale = (float)cfg->action_scale;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < n; ++e) {
+    StepOut o;
+    double* qp = st->qpos + (size_t)e * nv;
+    double* qv = st->qvel + (size_t)e * nv;
+    double* mp = st->mocap_pos + (size_t)e * 3;
+    const double* goal = st->goal + (size_t)e * 7;
+    const Q4 mq = qnormalize(ldq(cfg->mocap_quat));
+    int steps = st->steps_since_reset ? st->steps_since_reset[e] : 0;
+    for (int t = 0; t < T; ++t) {
+      const float* a = action + ((size_t)t * n + e) * 4;
+      for (int k = 0; k < 3; ++k) {
+        const float c = fminf(fmaxf(a[k], -1.f), 1.f) * scale;
+        mp[k] = fmin(fmax(mp[k] + (double)c, cfg->mocap_low[k]), cfg->mocap_high[k]);
+      }
+      const double ctrl[EARL_MAXACT] = {(double)a[3], -(double)a[3], 0, 0};
+      for (int ts = 0; ts < cfg->frame_skip; ++ts) substep(m, col, qp, qv, ld3(mp), mq, ctrl, 1, &o);
+      const size_t row = (size_t)t * n + e;
+      const V3 hand = attachment(m, &o, cfg->att_hand), rr = attachment(m, &o, cfg->att_right), ll = attachment(m, &o, cfg->att_left),
+               obj = attachment(m, &o, cfg->att_obj);
+      double* ob = out->obs + row * 14;
+      const V3 dg = sub(rr, ll);
+      ob[0] = hand.x; ob[1] = hand.y; ob[2] = hand.z;
+      ob[3] = fmin(fmax(sqrt(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z) / 0.1, 0.0), 1.0);
+      ob[4] = obj.x; ob[5] = obj.y; ob[6] = obj.z;
+      for (int k = 0; k < 7; ++k) ob[7 + k] = goal[k];
+      const V3 target = ld3(goal + 4), d = sub(obj, target);
+      const double obj_to_target = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+      const int ok = obj_to_target <= cfg->success_radius;
+      double r = ok ? 1.0 : 0.0;
+      if (cfg->reward_type != 0) {
+        const V3 e1 = sub(hand, obj), oi = sub(ld3(cfg->obj_init_pos), target), hi = sub(ld3(cfg->hand_init_pos), obj);
+        const double in_place = tolerance_gaussian(obj_to_target, 0.05, sqrt(oi.x * oi.x + oi.y * oi.y + oi.z * oi.z));
+        const double hand_in_place = tolerance_gaussian(sqrt(e1.x * e1.x + e1.y * e1.y + e1.z * e1.z), 0.25 * 0.05, sqrt(hi.x * hi.x + hi.y * hi.y + hi.z * hi.z) + 0.1);
+        r = 3 * hand_in_place + 6 * in_place;
+        if (obj_to_target < 0.05) r = 10;
+      }
+      ++steps;
+      if (out->reward) out->reward[row] = (float)r;
+      if (out->success) out->success[row] = (uint8_t)ok;
+      if (out->done) out->done[row] = (cfg->horizon > 0 && steps >= cfg->horizon) ? 1 : 0;
+    }
+    if (st->steps_since_reset) st->steps_since_reset[e] = steps;
+  }
+  return 0;
+}

@@ -213,3 +213,44 @@ def test_active_set_newton_converges_to_the_kkt_point_through_a_grasp():
     po.LinkModel.solve_primal = orig
   seen = np.array(seen)
   assert seen[:, 0].all() and seen[:, 1].max() > 30 and seen[:, 2].max() >= 8      # converged every time; contact rows were in play
+
+
+def test_c_restatement_equals_the_numpy_statement():
+  """oracle/physics_oracle.c (third implementation, the CPU baseline of the Sawyer bench) against LinkModel: forward
+  quantities on random states incl. violated limits, and the env loop through the grasp of forward demonstration 0"""
+  from oracle import physics_c
+  from oracle.sawyer_oracle import SawyerDoorOracle
+  lm = po.LinkModel(LINKS)
+  cm = physics_c.CModel('sawyer_door')
+  rng = np.random.default_rng(2)
+  n = 24
+  qpos = rng.uniform(-1, 1, size=(n, 10)) * 0.6
+  qpos[:, 1] = rng.uniform(-3.0, -0.3, n); qpos[:, 7] = rng.uniform(-0.005, 0.045, n); qpos[:, 8] = rng.uniform(-0.035, 0.005, n)
+  qpos[:, 9] = rng.uniform(-1.5, 0.1, n)
+  qvel = rng.normal(size=(n, 10)) * 0.3
+  mp = rng.uniform([-0.3, 0.4, 0.05], [0.3, 0.9, 0.45], size=(n, 3))
+  mq = np.tile([1.0, 0, 1, 0], (n, 1)) + rng.normal(size=(n, 4)) * 0.05
+  ctrl = rng.uniform(-1.3, 1.3, size=(n, 2))
+  got = cm.run(qpos, qvel, mp, mq, ctrl, integrate=False)
+  for i in range(n):
+    ref = lm.forward(qpos[i], qvel[i], ctrl[i], mp[i], mq[i])
+    np.testing.assert_allclose(got['qacc'][i], ref['qacc'], rtol=1e-9, atol=1e-9 * np.abs(ref['qacc']).max())
+    np.testing.assert_allclose(got['efc'][i], ref['f'][:26], rtol=1e-9, atol=1e-9 * (1 + np.abs(ref['f']).max()))
+    assert got['ncon'][i] == len(ref['contacts'])
+    for k in range(5):
+      np.testing.assert_allclose(got['att'][i, k], lm.attachment(ref['pos'], ref['quat'], k)[0], atol=1e-13)
+  # env loop through a grasp
+  z = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'demonstrations', 'sawyer_door', 'forward', 'demo_data.npz'))
+  env = SawyerDoorOracle(lm)
+  env.reset()
+  env.qpos[9] = -0.894
+  T = 36
+  q, v, mpos = env.qpos[None].copy(), env.qvel[None].copy(), env.mocap[None].copy()
+  goal, steps = env.goal[None].copy(), np.zeros(1, np.int32)
+  obs, rew, done, suc = cm.sawyer_rollout(physics_c.door_cfg(att_names=cm.att_names), q, v, mpos, goal, steps, z['actions'][:T, None, :])
+  for t in range(T):
+    o, r, d, ok = env.step(z['actions'][t])
+    np.testing.assert_allclose(obs[t, 0], o, rtol=0, atol=1e-7, err_msg=f'step {t}')
+    assert float(rew[t, 0]) == float(r) and bool(suc[t, 0]) == ok
+  np.testing.assert_allclose(q[0], env.qpos, atol=1e-7)
+  assert steps[0] == T
