@@ -74,6 +74,7 @@ SIGNATURES = {
     'earl_minitaur_leg_to_motor': [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_minitaur_motor_torque': [C.c_int32, _P(MotorParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_minitaur_reward': [C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_kitchen_reward': [C.c_int32] + [C.c_void_p] * 6,
     # include/earl_physics.h
     'earl_physics_step': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7,
     'earl_physics_forward': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9,

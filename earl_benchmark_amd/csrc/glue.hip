@@ -88,6 +88,39 @@ __global__ __launch_bounds__(kB) void minitaur_reward_kernel(int n, const double
   if (success) success[i] = sqrt(xd * xd + yd * yd) < 0.1;
 }
 
+// numpy's float64 norm = sqrt(ddot(x, x)); OpenBLAS runs vectors this short through its scalar tail loop, which the
+// compiler contracts: dot = fma(x_i, x_i, dot) in index order (probed in the build container, see oracle/glue_oracle.c)
+__device__ __forceinline__ double norm_diff(const double* a, const double* b, int n) {
+  double d = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double x = a[i] - b[i];
+    d = fma(x, x, d);
+  }
+  return sqrt(d);
+}
+
+// kitchen.py:141-183
+__global__ __launch_bounds__(kB) void kitchen_reward_kernel(int n, const double* __restrict__ obs, const double* __restrict__ mocap,
+                                                            const double* __restrict__ sites, double* __restrict__ reward,
+                                                            uint8_t* __restrict__ success) {
+  const int i = blockIdx.x * kB + threadIdx.x;
+  if (i >= n) return;
+  const double* o = obs + (size_t)i * 46;
+  const double dist = norm_diff(o + 9, o + 32, 14);
+  double r = -10 * dist;
+  const int start[8] = {9, 11, 13, 15, 17, 19, 20, 22}, len[8] = {2, 2, 2, 2, 2, 1, 2, 1};   // component_to_state_idx :15-25, minus 'arm'
+  bool reaching = false;
+  for (int c = 0; c < 8; ++c) {
+    if (norm_diff(o + start[c], o + start[c] + 23, len[c]) < len[c] * 0.01) r += 1;
+    else if (!reaching) {
+      reaching = true;
+      r += -0.5 * norm_diff(mocap + (size_t)i * 3, sites + ((size_t)i * 8 + c) * 3, 3);
+    }
+  }
+  if (reward) reward[i] = r;
+  if (success) success[i] = dist <= 0.3;
+}
+
 int done(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -131,5 +164,12 @@ int earl_minitaur_reward(int32_t n, const double* obs, double distance_weight, d
   if (n == 0) return EARL_OK;
   minitaur_reward_kernel<<<blocks(n), kB, 0, (hipStream_t)s>>>(n, obs, distance_weight, energy_weight, time_step, reward, success);
   return done("minitaur_reward");
+}
+int earl_kitchen_reward(int32_t n, const double* obs, const double* mocap_pos, const double* site_xpos, double* reward,
+                        uint8_t* success, earl_stream_t s) {
+  if (n < 0 || !obs || !mocap_pos || !site_xpos) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  kitchen_reward_kernel<<<blocks(n), kB, 0, (hipStream_t)s>>>(n, obs, mocap_pos, site_xpos, reward, success);
+  return done("kitchen_reward");
 }
 }

@@ -82,3 +82,22 @@ def minitaur_reward(obs, distance_weight=2.0, energy_weight=0.005, time_step=0.0
     _abi.check(lib.earl_minitaur_reward(n, o.data_ptr(), distance_weight, energy_weight, time_step, rew.data_ptr(),
                                         suc.data_ptr(), _stream(o)), 'minitaur_reward')
   return rew, suc
+
+
+KITCHEN_SITES = ('knob1_site', 'knob2_site', 'knob3_site', 'knob4_site', 'light_site', 'slide_site', 'hinge_site2', 'microhandle_site')
+
+
+def kitchen_reward(obs, mocap_pos, site_xpos):
+  """Kitchen.compute_reward / is_successful (kitchen.py:141-183): obs [n,46], mocap_pos [n,3], site_xpos [n,8,3] in
+  KITCHEN_SITES order -> (reward [n] float64, success [n] bool)."""
+  lib = _abi.load()
+  o = _cuda(obs, torch.float64).reshape(-1, 46)
+  n = o.shape[0]
+  mp = _cuda(mocap_pos, torch.float64).reshape(n, 3)
+  sx = _cuda(site_xpos, torch.float64).reshape(n, 8, 3)
+  rew = torch.empty(n, dtype=torch.float64, device=o.device)
+  suc = torch.empty(n, dtype=torch.bool, device=o.device)
+  with torch.cuda.device(o.device):
+    _abi.check(lib.earl_kitchen_reward(n, o.data_ptr(), mp.data_ptr(), sx.data_ptr(), rew.data_ptr(), suc.data_ptr(), _stream(o)),
+               'kitchen_reward')
+  return rew, suc

@@ -11,6 +11,9 @@
  *   earl_minitaur_motor_torque   MotorModel.convert_to_torque (envs/motor.py:49-94)
  *   earl_minitaur_reward         GoalConditionedMinitaurBulletEnv.compute_reward / is_successful
  *                                (envs/minitaur_gym_env.py:529-535, :495-503)
+ *   earl_kitchen_reward          Kitchen._get_reward_n_score / compute_reward / is_successful (envs/kitchen.py:141-183):
+ *                                the numpy part; what the reference reads from the simulator there (mocap position, the
+ *                                eight task-site positions) is an input
  * All fp64 like the reference's numpy code; tested bit-exact against goldens recorded from the reference's own
  * functions (tests/golden/make_golden.py: gen_glue) and against the 2,910 Sawyer demonstration rows.
  */
@@ -45,6 +48,13 @@ int earl_minitaur_motor_torque(int32_t m, const earl_motor_params* p, const doub
 /* obs [n,32] -> reward [n] (distance_weight * distance_reward - energy_weight * energy_reward), success [n] 0/1 */
 int earl_minitaur_reward(int32_t n, const double* obs, double distance_weight, double energy_weight, double time_step,
                          double* reward, uint8_t* success, earl_stream_t stream);
+
+/* obs [n,46] = qpos[23] + goal[23]; mocap_pos [n,3]; site_xpos [n,8,3] in the order the reward walks the components:
+ * knob1..knob4 (burner0..3), light_site, slide_site, hinge_site2, microhandle_site (kitchen.py:148-155, :15-25).
+ * reward [n] float64: -10 |obj - goal| + 1 per component within len * 0.01, - 0.5 |mocap - site| of the FIRST unsolved
+ * component; success [n]: |obj - goal| <= 0.3.  Either output may be NULL. */
+int earl_kitchen_reward(int32_t n, const double* obs, const double* mocap_pos, const double* site_xpos, double* reward,
+                        uint8_t* success, earl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -91,3 +91,34 @@ int oracle_minitaur_reward(int32_t n, const double* obs, double distance_weight,
   }
   return EARL_OK;
 }
+
+
+/* Kitchen._get_reward_n_score / is_successful (/root/reference/earl_benchmark/envs/kitchen.py:141-183), the numpy part.
+ * np.linalg.norm on float64 = sqrt(ddot(x, x)); OpenBLAS's ddot runs these short vectors through its scalar tail loop,
+ * which is compiled with FMA contraction: dot = fma(x_i, x_i, dot) in index order (pinned by tests/golden/kitchen_glue.npz). */
+static double norm_diff(const double* a, const double* b, int n) {
+  double d = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double x = a[i] - b[i];
+    d = fma(x, x, d);
+  }
+  return sqrt(d);
+}
+void oracle_kitchen_reward(int32_t n, const double* obs, const double* mocap, const double* sites, double* reward, uint8_t* success) {
+  static const int start[8] = {9, 11, 13, 15, 17, 19, 20, 22}, len[8] = {2, 2, 2, 2, 2, 1, 2, 1};   /* component_to_state_idx :15-25 */
+  for (int32_t i = 0; i < n; ++i) {
+    const double* o = obs + (size_t)i * 46;
+    const double dist = norm_diff(o + 9, o + 32, 14);
+    double r = -10 * dist;
+    int reaching = 0;
+    for (int c = 0; c < 8; ++c) {
+      if (norm_diff(o + start[c], o + start[c] + 23, len[c]) < len[c] * 0.01) r += 1;
+      else if (!reaching) {
+        reaching = 1;
+        r += -0.5 * norm_diff(mocap + (size_t)i * 3, sites + ((size_t)i * 8 + c) * 3, 3);
+      }
+    }
+    if (reward) reward[i] = r;
+    if (success) success[i] = dist <= 0.3;
+  }
+}

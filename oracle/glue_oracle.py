@@ -42,3 +42,12 @@ def minitaur_reward(obs, distance_weight=2.0, energy_weight=0.005, time_step=0.0
   lib().oracle_minitaur_reward(C.c_int32(len(o)), _p(o), C.c_double(distance_weight), C.c_double(energy_weight),
                                C.c_double(time_step), _p(r), _p(s))
   return r, s
+
+
+def kitchen_reward(obs, mocap_pos, site_xpos):
+  o, mp, sx = (np.ascontiguousarray(x, np.float64) for x in (obs, mocap_pos, site_xpos))
+  n = len(o)
+  assert o.shape == (n, 46) and mp.shape == (n, 3) and sx.shape == (n, 8, 3)
+  r, s = np.zeros(n), np.zeros(n, np.uint8)
+  lib().oracle_kitchen_reward(C.c_int32(n), _p(o), _p(mp), _p(sx), _p(r), _p(s))
+  return r, s.astype(bool)

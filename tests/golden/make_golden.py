@@ -402,7 +402,19 @@ def gen_3obj(rng, m=8192, T=200):
 # --------------------------------------------------------------------------------------
 # H. glue of the physics-backed envs that is pure numpy in the reference (the dynamics themselves are MuJoCo / Bullet)
 # --------------------------------------------------------------------------------------
-def _method(relpath, cls, name):
+def _module_constant(relpath, name):
+  """evaluate ONE top-level assignment (a literal table) of a reference module that cannot be imported here"""
+  import ast
+  src = open(os.path.join(REF, 'earl_benchmark', relpath)).read()
+  for node in ast.parse(src).body:
+    if isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id == name for t in node.targets):
+      ns = {'np': np}
+      exec(compile(ast.Module([node], []), relpath, 'exec'), ns)
+      return ns[name]
+  raise KeyError((relpath, name))
+
+
+def _method(relpath, cls, name, extra=None):
   """Compile ONE method of a reference class whose module cannot be imported here (pybullet / metaworld / mujoco_py
   missing) and return it as a plain function; numpy is the only global it gets."""
   import ast
@@ -414,6 +426,7 @@ def _method(relpath, cls, name):
         if isinstance(item, ast.FunctionDef) and item.name == name:
           item.decorator_list = []
           ns = {'np': np, 'math': math}
+          ns.update(extra or {})
           exec(compile(ast.Module([item], []), relpath, 'exec'), ns)
           return ns[name]
   raise KeyError((relpath, cls, name))
@@ -469,7 +482,51 @@ def gen_glue(rng, m=1024):
   return out
 
 
+def gen_kitchen(rng, m=2048):
+  """Kitchen._get_reward_n_score / compute_reward / is_successful (envs/kitchen.py:141-183) called on synthetic
+  observations with a stand-in for `self.sim` (mocap position + the eight task sites): the numpy part of the kitchen
+  reward is the reference's own code; what it reads from the simulator is an input here."""
+  import types
+  c2s = _module_constant('envs/kitchen.py', 'component_to_state_idx')
+  goal = _module_constant('envs/kitchen.py', 'goal_states')[0]
+  fn = _method('envs/kitchen.py', 'Kitchen', '_get_reward_n_score', extra={'component_to_state_idx': c2s})
+  succ = _method('envs/kitchen.py', 'Kitchen', 'is_successful')
+  sites = ['knob1_site', 'knob2_site', 'knob3_site', 'knob4_site', 'light_site', 'slide_site', 'hinge_site2', 'microhandle_site']
+  keys = [k for k in c2s if k != 'arm']                      # dict order = the order the reward walks the components in
+  assert keys == ['burner0', 'burner1', 'burner2', 'burner3', 'light_switch', 'slide_cabinet', 'hinge_cabinet', 'microwave']
+  obs = np.zeros((m, 46)); mocap = rng.uniform(-1, 1, size=(m, 3)) + np.array([-0.4, 0.1, 2.2]); site_xpos = rng.uniform(-1, 1, size=(m, 8, 3)) + np.array([-0.3, 0.5, 2.0])
+  rew, ok = np.zeros(m), np.zeros(m, bool)
+  for i in range(m):
+    o = np.concatenate([rng.normal(size=23) * 0.5, goal])
+    for k in keys:                                            # some components solved (within n * 0.01), some near the edge, some far
+      idx = np.array(c2s[k]); mode = rng.integers(0, 4)
+      if mode == 0:
+        o[idx] = goal[idx] + rng.normal(size=len(idx)) * 0.002
+      elif mode == 1:
+        d = rng.normal(size=len(idx)); d /= np.linalg.norm(d)
+        o[idx] = goal[idx] + d * len(idx) * 0.01 * rng.uniform(0.9, 1.1)
+    if i % 5 == 0:                                            # near the success radius 0.3 of the 14 object coordinates
+      d = rng.normal(size=14); d /= np.linalg.norm(d)
+      o[9:23] = goal[9:23] + d * rng.uniform(0.25, 0.35)
+    obs[i] = o
+    data = types.SimpleNamespace(mocap_pos=mocap[i][None].copy(), get_site_xpos=lambda name, i=i: site_xpos[i, sites.index(name)])
+    fake = types.SimpleNamespace(sim=types.SimpleNamespace(data=data))
+    rd, _ = fn(fake, o.copy())
+    rew[i] = rd['r_total']
+    ok[i] = succ(fake, obs=o.copy())
+  return dict(kitchen_obs=obs, kitchen_mocap=mocap, kitchen_site_xpos=site_xpos, kitchen_reward=rew, kitchen_success=ok,
+              kitchen_site_names=np.array(sites), kitchen_component_names=np.array(keys),
+              kitchen_component_start=np.array([c2s[k][0] for k in keys]), kitchen_component_len=np.array([len(c2s[k]) for k in keys]))
+
+
 def main():
+  if len(sys.argv) > 1 and sys.argv[1] == 'kitchen_glue':      # added after the other files were recorded: own stream, nothing else rewritten
+    data = gen_kitchen(np.random.default_rng(20221003))
+    np.savez_compressed(os.path.join(HERE, 'kitchen_glue.npz'), **data)
+    print('kitchen_glue:', {k: getattr(v, 'shape', ()) for k, v in data.items()}, 'solved-component bonus rows:',
+          int((data['kitchen_reward'] > -10 * np.linalg.norm(data['kitchen_obs'][:, 9:23] - data['kitchen_obs'][:, 32:46], axis=1)).sum()),
+          'successes', int(data['kitchen_success'].sum()))
+    return
   rng = np.random.default_rng(20221002)
   random.seed(7)
   np.random.seed(7)

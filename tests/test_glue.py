@@ -53,3 +53,17 @@ def test_minitaur_reward_golden():
   r, s = go.minitaur_reward(g['minitaur_obs'])
   np.testing.assert_array_equal(r, g['minitaur_reward'])
   np.testing.assert_array_equal(s, g['minitaur_success'].astype(np.uint8))
+
+
+def test_kitchen_reward_and_success_match_the_reference_method_bit_for_bit():
+  """goldens: Kitchen._get_reward_n_score / is_successful (envs/kitchen.py:141-183) compiled from the reference source and
+  called on 2,048 synthetic observations with a stand-in for the simulator handles it reads (mocap, task sites)"""
+  from conftest import load_golden
+  from oracle import glue_oracle as go
+  z = load_golden('kitchen_glue')
+  r, s = go.kitchen_reward(z['kitchen_obs'], z['kitchen_mocap'], z['kitchen_site_xpos'])
+  assert (r == z['kitchen_reward']).all() and (s == z['kitchen_success']).all()
+  assert 100 < int(s.sum()) < 1000                                        # both outcomes are covered
+  base = -10 * np.linalg.norm(z['kitchen_obs'][:, 9:23] - z['kitchen_obs'][:, 32:46], axis=1)
+  assert (r > base + 0.5).sum() > 500 and (r < base).sum() > 200          # bonus and reaching branches
+  assert list(z['kitchen_component_start']) == [9, 11, 13, 15, 17, 19, 20, 22] and list(z['kitchen_component_len']) == [2, 2, 2, 2, 2, 1, 2, 1]

@@ -71,3 +71,11 @@ def test_glue_rejects_cpu_tensors(t):
   from earl_benchmark_amd import _abi, glue
   with pytest.raises(_abi.EarlHipError):
     glue.leg_to_motor(t.zeros(2, 8, dtype=t.float64))
+
+
+def test_kitchen_reward_hip_matches_the_reference_goldens(t):
+  from earl_benchmark_amd import glue
+  z = load_golden('kitchen_glue')
+  r, s = glue.kitchen_reward(dev(t, z['kitchen_obs']), dev(t, z['kitchen_mocap']), dev(t, z['kitchen_site_xpos']))
+  assert (r.cpu().numpy() == z['kitchen_reward']).all() and (s.cpu().numpy() == z['kitchen_success']).all()
+  assert list(glue.KITCHEN_SITES) == [str(x) for x in z['kitchen_site_names']]
