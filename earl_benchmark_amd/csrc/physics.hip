@@ -151,6 +151,7 @@ __device__ __forceinline__ void kbimp(const double* solref, const double* solimp
 template <int NV>
 struct Shared {
   double qp[NV], qv[NV];
+  double bq[4];                      // orientation of the free body (unit quaternion), identity if the model has none
   double Xq[NV][4], Xp[NV][4];       // world frame of every link (final buffer of the ancestor doubling)
   double S[NV][6];                   // motion subspace, world coordinates about the origin: [angular; linear]
   double M[NV][NV];
@@ -250,16 +251,19 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   {
     const Q4 tq = ldq(m.tquat[l]);
     const V3 ax = ld3(m.jaxis[l]), jp = ld3(m.jpos[l]);
-    const bool hinge = m.jtype[l] == 0;
+    const int jt = m.jtype[l];
+    const bool hinge = jt == 0;
     const double q = s.qp[l];
     double sn, cs;
     sincos_mod(hinge ? 0.5 * q : 0.0, sn, cs);
     double Rt[3][3], Rl[3][3];
     qmat(tq, Rt);
-    Q = qmul(tq, Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z});
+    // free body: link type 2 applies the orientation quaternion, the type-3 links behind it are rigid (sn = 0, cs = 1)
+    const Q4 jq = jt == 2 ? ldq(s.bq) : Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z};
+    Q = qmul(tq, jq);
     qmat(Q, Rl);
     // hinge: rotate about the anchor; slide: translate along the axis (Rl == Rt then)
-    P = add(add(ld3(m.tpos[l]), vsub(mulv(Rt, jp), mulv(Rl, jp))), scl(mulv(Rt, ax), hinge ? 0.0 : q));
+    P = add(add(ld3(m.tpos[l]), vsub(mulv(Rt, jp), mulv(Rl, jp))), scl(mulv(Rt, ax), jt == 1 ? q : 0.0));
   }
   // ------------------------------------------------------------------ K2: world frames by ancestor doubling
   {
@@ -293,11 +297,11 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   // ------------------------------------------------------------------ C0: collision bounding tests (world frames are final)
   unsigned int nearw = 0;                              // blocks with a near bounding test in ANY env of the wave
   unsigned int nearg = 0;                              // ... in this env
-  if (bt.n_blk > 0) {
-    // C0: bounding test per block, lane = block
-    const int b = sub < bt.n_blk ? sub : 0;
+  for (int cb = 0; cb < bt.n_blk; cb += LPE) {
+    // C0: bounding test per block, lane = block (LPE blocks per pass)
+    const int b = cb + sub < bt.n_blk ? cb + sub : 0;
     const int bl = bt.link[b], xl = bt.box_link[b];
-    V3 cs = ld3(bt.center[b]), cb = ld3(bt.box_pos[b]);
+    V3 cs = ld3(bt.center[b]), cb_ = ld3(bt.box_pos[b]);
     Q4 qb = ldq(bt.box_quat[b]);
     {
       double R[3][3];
@@ -306,20 +310,24 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       cs = bl < 0 ? cs : w;
       const Q4 ql = ldq(s.Xq[xl < 0 ? 0 : xl]);
       qmat(ql, R);
-      const V3 w2 = add(ld3(s.Xp[xl < 0 ? 0 : xl]), mulv(R, cb));
+      const V3 w2 = add(ld3(s.Xp[xl < 0 ? 0 : xl]), mulv(R, cb_));
       const Q4 q2 = qmul(ql, qb);
-      cb = xl < 0 ? cb : w2;
+      cb_ = xl < 0 ? cb_ : w2;
       qb = xl < 0 ? qb : q2;
     }
     // distance from the set's bounding-sphere centre to the box (in the box frame) against the set radius + margin
     double Rb[3][3];
     qmat(qb, Rb);
-    const V3 x = mulvT(Rb, vsub(cs, cb)), h = ld3(bt.box_half[b]);
+    const V3 x = mulvT(Rb, vsub(cs, cb_)), h = ld3(bt.box_half[b]);
     const V3 d{x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z)};
-    const bool nearb = sub < bt.n_blk && dot(d, d) < bt.reach[b] * bt.reach[b];
+    const bool nearb = cb + sub < bt.n_blk && dot(d, d) < bt.reach[b] * bt.reach[b];
     const unsigned long long bal = __ballot(nearb);
-    nearg = LPE == 64 ? (unsigned int)bal : (unsigned int)((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull));
-    nearw = LPE == 64 ? (unsigned int)bal : (unsigned int)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull);
+    if constexpr (LPE == 64) {
+      nearg |= (unsigned int)bal; nearw |= (unsigned int)bal;
+    } else {
+      nearg |= (unsigned int)((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull)) << cb;
+      nearw |= (unsigned int)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull) << cb;
+    }
   }
   // prefetch this lane's pair record of the first near block: its latency hides behind K3-K7
   int pf_blk = -1, pf_link = -1, pf_cls = 0;
@@ -341,7 +349,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     qmat(Q, R);
     const V3 aw = mulv(R, ld3(m.jaxis[l]));
     const V3 anchor = add(P, mulv(R, ld3(m.jpos[l])));
-    const bool hinge = m.jtype[l] == 0;
+    const bool hinge = m.jtype[l] != 1;               // rotation axes of a free body: body axes after the rotation, like a hinge's
     Sw = hinge ? aw : V3{0, 0, 0};
     Sv = hinge ? cross(anchor, aw) : aw;
     const double mass = m.mass[l];
@@ -416,7 +424,19 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     }
     // crossm(V_l) S_l qd_l = [w x sw ; v x sw + w x sv] qd   (V of the parent and V_l differ by S_l qd_l, whose cross with S_l is 0)
     const double qdl = s.qv[l];
-    const V3 cw = scl(cross(w, Sw), qdl), cv = scl(add(cross(v, Sw), cross(w, Sv)), qdl);
+    // d/dt of this link's axis uses the velocity of the links in cd_mask: all ancestors, except that the three rotation
+    // axes of a free body use the velocity before any of them (mj_comVel computes the three dofdots before updating cvel)
+    V3 wc = w, vc = v;
+    if (m.ball_dof >= 0) {
+      const uint32_t drop = amask & ~m.cd_mask[l];
+      for (int a = m.ball_dof; a < NV; ++a) {
+        const double qd = ((drop >> a) & 1u) ? s.qv[a] : 0.0;
+        const double* sa = s.S[a];
+        wc = vsub(wc, scl(ld3(sa), qd));
+        vc = vsub(vc, scl(ld3(sa + 3), qd));
+      }
+    }
+    const V3 cw = scl(cross(wc, Sw), qdl), cv = scl(add(cross(vc, Sw), cross(wc, Sv)), qdl);
     if (isl) {
       double* o = s.dyn.rne.Cc[l];
       o[0] = cw.x; o[1] = cw.y; o[2] = cw.z; o[3] = cv.x; o[4] = cv.y; o[5] = cv.z;
@@ -786,9 +806,27 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     if (isl) {
       const double nv_ = s.qv[l] + dt * al;
       s.qv[l] = nv_;
-      s.qp[l] = s.qp[l] + dt * nv_;
+      s.qp[l] = s.qp[l] + dt * nv_;                    // (unused for the rotation dofs of a free body)
     }
     fence();
+    if (m.ball_dof >= 0) {
+      // mju_quatIntegrate: q <- normalize(q) * quat(axis = w / |w|, angle = dt |w|), w = angular velocity in body axes; every lane
+      // computes it, lane 0 stores
+      const int bd = m.ball_dof;
+      const V3 wb{s.qv[bd], s.qv[bd + 1], s.qv[bd + 2]};
+      Q4 q0 = ldq(s.bq);
+      const double n0 = rsq_nr(q0.w * q0.w + q0.x * q0.x + q0.y * q0.y + q0.z * q0.z);
+      q0 = Q4{q0.w * n0, q0.x * n0, q0.y * n0, q0.z * n0};
+      const double w2 = dot(wb, wb);
+      const double iw = w2 > 0 ? rsq_nr(w2 > 0 ? w2 : 1.0) : 0.0;
+      double sn, cs;
+      sincos_mod(0.5 * dt * (w2 * iw), sn, cs);
+      Q4 q1 = qmul(q0, Q4{cs, sn * wb.x * iw, sn * wb.y * iw, sn * wb.z * iw});
+      const double n1 = rsq_nr(q1.w * q1.w + q1.x * q1.x + q1.y * q1.y + q1.z * q1.z);
+      fence();
+      if (sub == 0) { s.bq[0] = q1.w * n1; s.bq[1] = q1.x * n1; s.bq[2] = q1.y * n1; s.bq[3] = q1.z * n1; }
+      fence();
+    }
     PSTAMP(11);
   }
 }
@@ -820,6 +858,34 @@ __device__ __forceinline__ void stage_model(earl_link_model& dst, const earl_lin
   fence();
 }
 
+// state rows <-> LDS.  qpos rows are [nq]: one entry per dof, except that the free body's orientation quaternion sits at
+// [ball_dof, ball_dof + 4) (normalised on load, as mj_kinematics does)
+template <int NV>
+__device__ __forceinline__ void load_state(Shared<NV>& s, const earl_link_model& m, const double* __restrict__ qrow, const double* __restrict__ vrow, const int sub) {
+  const int bd = m.ball_dof;
+  if (sub < NV) {
+    s.qp[sub] = (bd < 0 || sub < bd) ? qrow[sub] : 0.0;
+    s.qv[sub] = vrow[sub];
+  }
+  if (sub < 4) {
+    double v = sub == 0 ? 1.0 : 0.0;
+    if (bd >= 0) {
+      const Q4 q = ldq(qrow + bd);
+      v = qrow[bd + sub] * rsq_nr(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    }
+    s.bq[sub] = v;
+  }
+}
+template <int NV>
+__device__ __forceinline__ void store_state(const Shared<NV>& s, const earl_link_model& m, double* __restrict__ qrow, double* __restrict__ vrow, const int sub) {
+  const int bd = m.ball_dof;
+  if (sub < NV) {
+    if (bd < 0 || sub < bd) qrow[sub] = s.qp[sub];
+    vrow[sub] = s.qv[sub];
+  }
+  if (bd >= 0 && sub < 4) qrow[bd + sub] = s.bq[sub];
+}
+
 struct PArgs {
   const earl_link_model* m;
   const earl_collision_model* col;
@@ -842,10 +908,7 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
   const bool live = env_raw < a.n;
   const int env = live ? env_raw : a.n - 1;            // idle groups shadow the last env and store nothing
   Shared<NV>& s = sh[grp];
-  if (sub < NV) {
-    s.qp[sub] = a.qpos[(size_t)env * NV + sub];
-    s.qv[sub] = a.qvel[(size_t)env * NV + sub];
-  }
+  load_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
   fence();
   const V3 mpos = ld3(a.mocap_pos + (size_t)env * 3);
   const Q4 mq = qnormalize(ldq(a.mocap_quat + (size_t)env * 4));
@@ -856,10 +919,7 @@ __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
     substep<NV, LPE, INTEGRATE>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, (a.qacc_out && live) ? a.qacc_out + (size_t)env * NV : nullptr,
                                 (a.efc_out && live) ? a.efc_out + (size_t)env * NC : nullptr);
   if constexpr (INTEGRATE) {
-    if (sub < NV && live) {
-      a.qpos[(size_t)env * NV + sub] = s.qp[sub];
-      a.qvel[(size_t)env * NV + sub] = s.qv[sub];
-    }
+    if (live) store_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
   }
   // attachments at the kinematics of the LAST timestep's start (what mj_step leaves in data.xpos / site_xpos)
   if (a.att_xpos && sub < m.n_att && live) {
@@ -953,10 +1013,7 @@ __global__ __launch_bounds__(64) void sawyer_rollout_kernel(const SawyerArgs a) 
   const bool live = env_raw < n;
   const int env = live ? env_raw : n - 1;
   Shared<NV>& s = sh[grp];
-  if (sub < NV) {
-    s.qp[sub] = a.st.qpos[(size_t)env * NV + sub];
-    s.qv[sub] = a.st.qvel[(size_t)env * NV + sub];
-  }
+  load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   fence();
   V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
   const Q4 mq = qnormalize(ldq(cfg.mocap_quat));
@@ -978,10 +1035,7 @@ __global__ __launch_bounds__(64) void sawyer_rollout_kernel(const SawyerArgs a) 
     if (sub == 0 && live && a.out.done) a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
   }
   if (!live) return;
-  if (sub < NV) {
-    a.st.qpos[(size_t)env * NV + sub] = s.qp[sub];
-    a.st.qvel[(size_t)env * NV + sub] = s.qv[sub];
-  }
+  store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = sub == 0 ? mpos.x : (sub == 1 ? mpos.y : mpos.z);
   if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
 }
@@ -1004,26 +1058,54 @@ __global__ __launch_bounds__(64) void sawyer_reset_kernel(const SawyerArgs a) {
   const bool live = env_raw < cfg.n && (a.observe_only || resetting);
   V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
   if (resetting) {
-    const earl::U4 b = earl::philox4x32_10(earl::U4{0u, (uint32_t)(cfg.env_offset + env), (uint32_t)cfg.counter, (uint32_t)(cfg.counter >> 32)},
-                                           (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
-    // np.random.uniform(lo, hi) = lo + (hi - lo) * u   (sawyer_door.py:116-118)
-    double angle;
-    {
+    const uint32_t gid = (uint32_t)(cfg.env_offset + env), c0 = (uint32_t)cfg.counter, c1 = (uint32_t)(cfg.counter >> 32);
+    const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
+    load_state<NV>(s, m, a.reset_qpos, a.reset_qvel, sub);
+    fence();
+    if (cfg.obj_kind == 0) {
+      const earl::U4 b = earl::philox4x32_10(earl::U4{0u, gid, c0, c1}, k0, k1);
+      // np.random.uniform(lo, hi) = lo + (hi - lo) * u   (sawyer_door.py:116-118)
+      double angle;
+      {
 #pragma clang fp contract(off)
-      angle = cfg.obj_init_angle + (cfg.angle_noise[0] + (cfg.angle_noise[1] - cfg.angle_noise[0]) * earl::u01(b.x, b.y));
+        angle = cfg.obj_init_angle + (cfg.angle_noise[0] + (cfg.angle_noise[1] - cfg.angle_noise[0]) * earl::u01(b.x, b.y));
+      }
+      if (sub == cfg.obj_dof) { s.qp[sub] = angle; s.qv[sub] = 0.0; }
+    } else {
+      // sawyer_peg.py:199-212 / :221-223: xyz ~ U(obj_low, obj_high), redrawn while the xy distance to the hole block is < 0.1;
+      // _set_obj_xyz [UPSTREAM]: qpos[9:12] <- xyz, qvel[9:15] <- 0 (the orientation is left as it is)
+      double px = 0, py = 0, pz = 0;
+      for (uint32_t attempt = 0; attempt < 16u; ++attempt) {
+#pragma clang fp contract(off)
+        const earl::U4 b0 = earl::philox4x32_10(earl::U4{2u * attempt, gid, c0, c1}, k0, k1);
+        const earl::U4 b1 = earl::philox4x32_10(earl::U4{2u * attempt + 1u, gid, c0, c1}, k0, k1);
+        px = cfg.obj_low[0] + (cfg.obj_high[0] - cfg.obj_low[0]) * earl::u01(b0.x, b0.y);
+        py = cfg.obj_low[1] + (cfg.obj_high[1] - cfg.obj_low[1]) * earl::u01(b0.z, b0.w);
+        pz = cfg.obj_low[2] + (cfg.obj_high[2] - cfg.obj_low[2]) * earl::u01(b1.x, b1.y);
+        const double dx = px - cfg.obj_reject_xy[0], dy = py - cfg.obj_reject_xy[1];
+        if (!(sqrt(dx * dx + dy * dy) < cfg.obj_reject_radius)) break;
+      }
+      const int k = sub - cfg.obj_dof;
+      if (k >= 0 && k < 6 && sub < NV) {
+        if (k < 3) s.qp[sub] = k == 0 ? px : (k == 1 ? py : pz);
+        s.qv[sub] = 0.0;
+      }
     }
-    if (sub < NV) {
-      s.qp[sub] = sub == cfg.obj_dof ? angle : a.reset_qpos[sub];
-      s.qv[sub] = sub == cfg.obj_dof ? 0.0 : a.reset_qvel[sub];
-      a.st.qpos[(size_t)env * NV + sub] = s.qp[sub];
-      a.st.qvel[(size_t)env * NV + sub] = s.qv[sub];
+    if (cfg.n_goal_rows > 0 && cfg.goal_table && sub < 7) {
+      // get_next_goal with reset_at_goal (sawyer_peg.py:149-152): np.random.randint(0, rows) -> own Philox draw
+      const earl::U4 b = earl::philox4x32_10(earl::U4{0xFFFFu, gid, c0, c1}, k0, k1);
+      int row = (int)(earl::u01(b.x, b.y) * (double)cfg.n_goal_rows);
+      row = row < cfg.n_goal_rows ? row : cfg.n_goal_rows - 1;
+      a.st.goal[(size_t)env * 7 + sub] = cfg.goal_table[(size_t)row * 7 + sub];
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");    // the observation below reads the goal row back through global memory
+    fence();
+    store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
     mpos = ld3(cfg.hand_init_pos);
     if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = cfg.hand_init_pos[sub];
     if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
-  } else if (sub < NV) {
-    s.qp[sub] = a.st.qpos[(size_t)env * NV + sub];
-    s.qv[sub] = a.st.qvel[(size_t)env * NV + sub];
+  } else {
+    load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   }
   fence();
   if (!a.reset_obs) return;
@@ -1074,6 +1156,7 @@ int earl_physics_step(const earl_link_model* model, const earl_collision_model* 
   if (n == 0 || nsub == 0) return EARL_OK;
   PArgs a{model, col, n, nsub, qpos, qvel, mocap_pos, mocap_quat, ctrl, att_xpos, nullptr, nullptr};
   if (nv == 10) launch_physics<10, true>(a, (hipStream_t)stream);
+  else if (nv == 15) launch_physics<15, true>(a, (hipStream_t)stream);
   else return EARL_ERR_ARG;
   return launched("physics_step");
 }
@@ -1085,6 +1168,7 @@ int earl_physics_forward(const earl_link_model* model, const earl_collision_mode
   if (n == 0) return EARL_OK;
   PArgs a{model, col, n, 1, const_cast<double*>(qpos), const_cast<double*>(qvel), mocap_pos, mocap_quat, ctrl, att_xpos, qacc, efc_force};
   if (nv == 10) launch_physics<10, false>(a, (hipStream_t)stream);
+  else if (nv == 15) launch_physics<15, false>(a, (hipStream_t)stream);
   else return EARL_ERR_ARG;
   return launched("physics_forward");
 }
@@ -1096,9 +1180,14 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
   if (cfg->frame_skip < 0 || cfg->att_hand < 0 || cfg->att_right < 0 || cfg->att_left < 0 || cfg->att_obj < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
   SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
-  if (nv != 10) return EARL_ERR_ARG;
-  if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
-  else sawyer_rollout_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  if (cfg->obj_kind == 1 && cfg->reward_type != 0) return EARL_ERR_ARG;   // the peg's dense reward (metaworld reward_utils, upstream) is not built
+  if (nv == 10) {
+    if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
+    else sawyer_rollout_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  } else if (nv == 15) {
+    if (g_lpe == 64) sawyer_rollout_kernel<15, 64><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
+    else sawyer_rollout_kernel<15, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  } else return EARL_ERR_ARG;
   return launched("sawyer_rollout");
 }
 
@@ -1107,11 +1196,13 @@ int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawye
                       earl_stream_t stream) {
   if (!model || !cfg || !st || !reset_qpos || !reset_qvel || cfg->n < 0) return EARL_ERR_ARG;
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
-  if (cfg->obj_dof < 0 || cfg->obj_dof >= nv) return EARL_ERR_ARG;
+  if (cfg->obj_dof < 0 || cfg->obj_dof >= nv || (cfg->obj_kind != 0 && cfg->obj_kind != 1)) return EARL_ERR_ARG;
+  if (cfg->obj_kind == 1 && cfg->obj_dof + 6 > nv) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
   SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, reset_qpos, reset_qvel, mask, obs, 0};
-  if (nv != 10) return EARL_ERR_ARG;
-  sawyer_reset_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  if (nv == 10) sawyer_reset_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  else if (nv == 15) sawyer_reset_kernel<15, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  else return EARL_ERR_ARG;
   return launched("sawyer_reset");
 }
 
@@ -1121,8 +1212,9 @@ int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_saw
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
   SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, obs, 1};
-  if (nv != 10) return EARL_ERR_ARG;
-  sawyer_reset_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  if (nv == 10) sawyer_reset_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  else if (nv == 15) sawyer_reset_kernel<15, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  else return EARL_ERR_ARG;
   return launched("sawyer_observe");
 }
 
@@ -1153,5 +1245,6 @@ int earl_debug_read_phys_profile(unsigned long long* out, int reset) {
 
 int earl_physics_model_size(void) { return (int)sizeof(earl_link_model); }
 int earl_collision_model_size(void) { return (int)sizeof(earl_collision_model); }
+int earl_sawyer_cfg_size(void) { return (int)sizeof(earl_sawyer_cfg); }
 
 }  // extern "C"

@@ -13,13 +13,13 @@ import torch
 from .. import _abi
 
 MAXV, MAXATT, MAXACT = 16, 8, 4
-MAXSPH, MAXBOX, MAXPAIR, MAXCLS, MAXCON, MAXBLK = 64, 16, 256, 16, 8, 16
+MAXSPH, MAXBOX, MAXPAIR, MAXCLS, MAXCON, MAXBLK = 64, 16, 512, 16, 12, 32
 MODEL_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'models')
 
 
 class LinkModelStruct(C.Structure):   # struct earl_link_model
   _fields_ = [('nv', C.c_int32), ('n_att', C.c_int32), ('n_act', C.c_int32), ('weld_att', C.c_int32),
-              ('n_jump', C.c_int32), ('pad_', C.c_int32 * 3), ('jump', C.c_int32 * MAXV * 4),
+              ('n_jump', C.c_int32), ('ball_dof', C.c_int32), ('nq', C.c_int32), ('pad_', C.c_int32), ('jump', C.c_int32 * MAXV * 4),
               ('parent', C.c_int32 * MAXV), ('jtype', C.c_int32 * MAXV), ('limited', C.c_int32 * MAXV),
               ('anc_mask', C.c_uint32 * MAXV), ('desc_mask', C.c_uint32 * MAXV), ('att_link', C.c_int32 * MAXATT),
               ('act_joint', C.c_int32 * MAXACT),
@@ -30,7 +30,8 @@ class LinkModelStruct(C.Structure):   # struct earl_link_model
               ('dof_invweight', C.c_double * MAXV), ('att_pos', C.c_double * 3 * MAXATT), ('att_quat', C.c_double * 4 * MAXATT),
               ('act_kp', C.c_double * MAXACT), ('act_ctrlrange', C.c_double * 2 * MAXACT),
               ('weld_solref', C.c_double * 2), ('weld_solimp', C.c_double * 5), ('weld_invweight', C.c_double * 2),
-              ('gravity', C.c_double * 3), ('dt', C.c_double), ('drag_G', C.c_double * MAXV), ('drag_b', C.c_double * MAXV)]
+              ('gravity', C.c_double * 3), ('dt', C.c_double), ('drag_G', C.c_double * MAXV), ('drag_b', C.c_double * MAXV),
+              ('cd_mask', C.c_uint32 * MAXV)]
 
 
 class PairRec(C.Structure):
@@ -65,6 +66,9 @@ def load_link_model(name):
   assert nv <= MAXV and natt <= MAXATT and nact <= MAXACT
   s = LinkModelStruct()
   s.nv, s.n_att, s.n_act, s.weld_att = nv, natt, nact, int(d['weld_att'])
+  s.ball_dof = int(d['ball_dof']) if 'ball_dof' in d else -1
+  s.nq = nv + (1 if s.ball_dof >= 0 else 0)
+  assert s.ball_dof < 0 or s.ball_dof == nv - 3
   anc = np.zeros(nv, np.uint32)
   for l in range(nv):
     p = l
@@ -72,6 +76,13 @@ def load_link_model(name):
       anc[l] |= np.uint32(1 << p)
       p = int(d['parent'][p])
   desc = np.array([sum(1 << i for i in range(nv) if (anc[i] >> l) & 1) for l in range(nv)], np.uint32)
+  # links whose velocity enters d/dt of a link's axis: its ancestors; the three rotation axes of a free body all use the velocity
+  # before any of them (oracle: LinkModel.forward, MuJoCo mj_comVel)
+  cd = anc.copy()
+  for l in range(nv):
+    if int(d['jtype'][l]) == 3:
+      pb = int(d['parent'][s.ball_dof])
+      cd[l] = anc[pb] if pb >= 0 else 0
   # ancestor doubling tables for the log-depth kinematics
   par = [int(x) for x in d['parent']]
   depth = [bin(int(a)).count('1') for a in anc]
@@ -89,7 +100,7 @@ def load_link_model(name):
         jump[r, l] = chain[(1 << r) - 1]
   _fill(s.jump, jump)
   for dst, src in ((s.parent, d['parent']), (s.jtype, d['jtype']), (s.limited, d['jnt_limited']), (s.anc_mask, anc),
-                   (s.desc_mask, desc), (s.att_link, d['att_link']), (s.act_joint, d['act_joint']), (s.tpos, d['tpos']),
+                   (s.desc_mask, desc), (s.cd_mask, cd), (s.att_link, d['att_link']), (s.act_joint, d['act_joint']), (s.tpos, d['tpos']),
                    (s.tquat, d['tquat']), (s.jaxis, d['jaxis']), (s.jpos, d['jpos']), (s.mass, d['mass']), (s.com, d['com']),
                    (s.inertia, d['inertia']), (s.range, d['jnt_range']), (s.damping, d['jnt_damping']),
                    (s.armature, d['jnt_armature']), (s.jsolref, d['jnt_solref']), (s.jsolimp, d['jnt_solimp']),
@@ -138,7 +149,7 @@ class DeviceModel:
     self.col_struct = load_collision_model(self.tables) if contacts else None
     if not contacts:
       _fill(self.struct.drag_G, np.zeros(self.struct.nv))
-    self.nv, self.n_att, self.n_act = self.struct.nv, self.struct.n_att, self.struct.n_act
+    self.nv, self.n_att, self.n_act, self.nq = self.struct.nv, self.struct.n_att, self.struct.n_act, self.struct.nq
     self.device = torch.device(device)
     raw = np.frombuffer(bytes(self.struct), dtype=np.uint8).copy()
     self.buf = torch.from_numpy(raw).to(self.device)

@@ -1,4 +1,5 @@
-/* earl_physics.h -- C ABI of the batched articulated-body stepper (BASELINE config 3).
+/* earl_physics.h -- C ABI of the batched articulated-body stepper (BASELINE config 3:
+ * sawyer_door and sawyer_peg).
  *
  * STATUS: smooth dynamics, weld / joint-limit constraints, frictional contacts (spheres / points vs boxes, pyramidal
  * friction).  Parity with MuJoCo is UNPINNED (the
@@ -28,10 +29,15 @@ extern "C" {
 
 typedef struct earl_link_model {
   int32_t nv, n_att, n_act, weld_att;      /* weld_att: attachment welded to the mocap body */
-  int32_t n_jump, pad_[3];                 /* rounds of ancestor doubling the kinematics needs: ceil(log2(max depth)) */
+  int32_t n_jump;                          /* rounds of ancestor doubling the kinematics needs: ceil(log2(max depth)) */
+  int32_t ball_dof;                        /* first of the three rotation dofs of the free body (always the last three dofs), -1 = none */
+  int32_t nq, pad_;                        /* length of a qpos row: nv, or nv + 1 with a free body (its orientation is a unit quaternion
+                                              stored at qpos[ball_dof .. ball_dof + 3], MuJoCo's layout) */
   int32_t jump[4][EARL_MAXV];              /* jump[r][l]: ancestor of link l at distance 2^r, -1 if none */
   int32_t parent[EARL_MAXV];               /* -1 = world */
-  int32_t jtype[EARL_MAXV];                /* 0 hinge, 1 slide */
+  int32_t jtype[EARL_MAXV];                /* 0 hinge, 1 slide; a free joint is six links: three slides along the world axes, then
+                                              2 = applies the orientation quaternion, axis = body x; 3, 3 = rigid, axes = body y, z
+                                              (MuJoCo: angular velocity of a free body in body axes) */
   int32_t limited[EARL_MAXV];
   uint32_t anc_mask[EARL_MAXV];            /* bit i: link i is an ancestor of (or is) this link */
   uint32_t desc_mask[EARL_MAXV];           /* bit i: link i is in the subtree of this link (incl. itself) */
@@ -48,6 +54,8 @@ typedef struct earl_link_model {
   double gravity[3], dt;
   double drag_G[EARL_MAXV], drag_b[EARL_MAXV];   /* soft velocity row per dof, cost 1/2 G (a + b v)^2: a permanent deep contact reduced at
                                                     model-compile time (the door panel standing in the table top), 0 = none */
+  uint32_t cd_mask[EARL_MAXV];             /* links whose velocity enters d/dt of this link's axis: anc_mask, except that the three rotation
+                                              axes of a free body all use the velocity before any of them (mj_comVel) */
 } earl_link_model;
 
 /* Collision geometry of a link model: SPHERES (cylinders are chains of spheres; box corners are spheres of radius 0)
@@ -55,10 +63,10 @@ typedef struct earl_link_model {
  * at model-compile time).  At most EARL_MAXCON contacts per env and timestep: the first active pairs in list order. */
 #define EARL_MAXSPH 64
 #define EARL_MAXBOX 16
-#define EARL_MAXPAIR 256
+#define EARL_MAXPAIR 512
 #define EARL_MAXCLS 16
-#define EARL_MAXCON 8
-#define EARL_MAXBLK 16
+#define EARL_MAXCON 12
+#define EARL_MAXBLK 32
 typedef struct earl_collision_model {
   int32_t n_sph, n_box, n_pair, n_cls;
   /* pairs are stored box-major in blocks (one box x one set of spheres); a block is skipped when the bounding sphere of its
@@ -79,7 +87,7 @@ typedef struct earl_collision_model {
 
 /* nsub timesteps of every env.  model: DEVICE copy of an earl_link_model; col: DEVICE copy of its earl_collision_model or
  * NULL (no contacts).  State (updated in place):
- * qpos, qvel [n, nv]; inputs mocap_pos [n,3], mocap_quat [n,4] (normalised internally), ctrl [n, n_act];
+ * qpos [n, nq], qvel [n, nv]; inputs mocap_pos [n,3], mocap_quat [n,4] (normalised internally), ctrl [n, n_act];
  * att_xpos (may be NULL) [n, n_att, 3]: world positions of the attachments after the last timestep. */
 int earl_physics_step(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
@@ -99,6 +107,9 @@ int earl_physics_forward(const earl_link_model* model, const earl_collision_mode
  *   SawyerDoorV2.compute_reward    earl_benchmark/envs/sawyer_door.py:141-171 (sparse: is_successful :173-177, radius 0.02)
  *   PersistentStateWrapper.step    earl_benchmark/wrappers/persistent_state_wrapper.py:17-31  (done = steps_since_reset >= horizon)
  *   SawyerDoorV2.reset_model       earl_benchmark/envs/sawyer_door.py:111-125 (settled hand pose, object angle init + U(lo, hi))
+ *   SawyerPegV2._get_obs           earl_benchmark/envs/sawyer_peg.py:134-142, _get_pos_objects :186-187 (object xyz = site pegHead)
+ *   SawyerPegV2.compute_reward     earl_benchmark/envs/sawyer_peg.py:231-299 -- sparse only: is_successful :301-305, radius 0.05
+ *   SawyerPegV2.reset_model        earl_benchmark/envs/sawyer_peg.py:192-229, get_next_goal / reset_goal :144-163
  * obs is float64 like the reference's (the demonstrations store it as float32). */
 typedef struct earl_sawyer_cfg {
   int32_t n, env_offset;
@@ -106,17 +117,24 @@ typedef struct earl_sawyer_cfg {
   int32_t horizon;                         /* <= 0: never done */
   int32_t frame_skip;
   int32_t att_hand, att_right, att_left, att_obj;   /* attachment indices the observation reads */
-  int32_t obj_dof;                         /* dof re-initialised by reset (door hinge) */
+  int32_t obj_dof;                         /* dof re-initialised by reset: the door hinge, or the first of the peg's three translations */
+  int32_t obj_kind;                        /* 0: hinge angle <- obj_init_angle + U(angle_noise)   (SawyerDoorV2.reset_model, sawyer_door.py:111-125)
+                                              1: free body, xyz <- U(obj_low, obj_high) redrawn while its xy is within obj_reject_radius of
+                                                 obj_reject_xy, orientation kept, zero velocity  (SawyerPegV2.reset_model, sawyer_peg.py:192-229) */
+  int32_t n_goal_rows;                     /* > 0: reset draws the goal uniformly from goal_table [n_goal_rows, 7] (SawyerPegV2.get_next_goal
+                                              with reset_at_goal, sawyer_peg.py:144-152); 0: goals are left as they are */
   double action_scale;
   double mocap_low[3], mocap_high[3], mocap_quat[4];
   double success_radius;
   double hand_init_pos[3], obj_init_pos[3];
   double obj_init_angle, angle_noise[2];
+  double obj_low[3], obj_high[3], obj_reject_xy[2], obj_reject_radius;
+  const double* goal_table;                /* device, [n_goal_rows, 7] or NULL */
   uint64_t seed, counter;                  /* reset draws: Philox(seed; global env id, counter) */
 } earl_sawyer_cfg;
 
 typedef struct earl_sawyer_state {
-  double* qpos;                 /* [n, nv] */
+  double* qpos;                 /* [n, nq] */
   double* qvel;                 /* [n, nv] */
   double* mocap_pos;            /* [n, 3] */
   double* goal;                 /* [n, 7] */
@@ -134,8 +152,8 @@ typedef struct earl_sawyer_out {
 int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model* col, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                         const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream);
 
-/* reset the envs with mask[i] != 0 (mask NULL = all): state <- the settled post-_reset_hand state (reset_qpos / reset_qvel,
- * [nv] each, device), object dof <- obj_init_angle + U(angle_noise), mocap <- hand_init_pos, counters cleared; obs [n,14]
+/* reset the envs with mask[i] != 0 (mask NULL = all): state <- the settled post-_reset_hand state (reset_qpos [nq], reset_qvel
+ * [nv], device), object re-initialised as cfg.obj_kind says, mocap <- hand_init_pos, counters cleared; obs [n,14]
  * (may be NULL) is written for the reset envs only. */
 int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                       const double* reset_qpos, const double* reset_qvel, const uint8_t* mask, double* obs,
@@ -145,7 +163,8 @@ int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawye
 int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                         double* obs, earl_stream_t stream);
 
-/* compute_reward / is_successful on caller-supplied observations [n,14] (sawyer_door.py:141-177); reward / success may be NULL */
+/* compute_reward / is_successful on caller-supplied observations [n,14] (sawyer_door.py:141-177); reward / success may be NULL.
+ * With reward_type sparse this is also SawyerPegV2's rule (sawyer_peg.py:295-305: radius 0.05 in cfg.success_radius). */
 int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, float* reward, uint8_t* success,
                             earl_stream_t stream);
 
@@ -156,6 +175,7 @@ int earl_debug_set_physics_lanes(int lanes_per_env);
 /* sizeof(earl_link_model) as compiled into the library (bindings check their struct layout against it) */
 int earl_physics_model_size(void);
 int earl_collision_model_size(void);
+int earl_sawyer_cfg_size(void);
 
 #ifdef __cplusplus
 }

@@ -96,7 +96,14 @@ typedef struct {
   int ncon;
 } StepOut;
 
-/* one timestep (integrate != 0) or the forward quantities only; reference: LinkModel.forward / step */
+static Q4 qnormalize(Q4 q) {
+  const double s = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  Q4 r = {q.w * s, q.x * s, q.y * s, q.z * s};
+  return r;
+}
+
+/* one timestep (integrate != 0) or the forward quantities only; reference: LinkModel.forward / step.
+ * qp is a qpos row [nq] (the free body's quaternion at [ball_dof, ball_dof + 4)), qv a qvel row [nv]. */
 static void substep(const earl_link_model* m, const earl_collision_model* col, double* qp, double* qv, V3 mpos, Q4 mq, const double* ctrl,
                     int integrate, StepOut* o) {
   const int nv = m->nv;
@@ -123,6 +130,18 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
       x = sub(anchor, mulv(R, ld3(m->jpos[l])));
       const V3 sv = cross(anchor, axw);
       S[l][0] = axw.x; S[l][1] = axw.y; S[l][2] = axw.z; S[l][3] = sv.x; S[l][4] = sv.y; S[l][5] = sv.z;
+    } else if (m->jtype[l] >= 2) {
+      /* rotation of a free body (LinkModel.kinematics): type 2 applies the orientation quaternion (normalised, as mj_kinematics
+       * does) and its axis is the rotated body x axis; the type-3 links behind it are rigid and carry the body y / z axes */
+      V3 a2 = axw;
+      if (m->jtype[l] == 2) {
+        q = qmul(q, qnormalize(ldq(qp + l)));
+        qmat(q, R);
+        x = sub(anchor, mulv(R, ld3(m->jpos[l])));
+        a2 = mulv(R, ax);
+      }
+      const V3 sv = cross(anchor, a2);
+      S[l][0] = a2.x; S[l][1] = a2.y; S[l][2] = a2.z; S[l][3] = sv.x; S[l][4] = sv.y; S[l][5] = sv.z;
     } else {
       x = add(x, scl(axw, qp[l]));
       S[l][0] = S[l][1] = S[l][2] = 0; S[l][3] = axw.x; S[l][4] = axw.y; S[l][5] = axw.z;
@@ -166,7 +185,13 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
       if (p >= 0) { wp = ld3(Vw[p]); vp = ld3(Vw[p] + 3); awp = ld3(Aw[p]); avp = ld3(Aw[p] + 3); }
       const V3 sw = ld3(S[l]), sv = ld3(S[l] + 3);
       const double qd = qv[l];
-      const V3 aw = add(awp, scl(cross(wp, sw), qd)), av = add(avp, scl(add(cross(vp, sw), cross(wp, sv)), qd));
+      /* d/dt of the axis: the three rotation axes of a free body all use the velocity before any of them (mj_comVel) */
+      V3 wc = wp, vc = vp;
+      if (m->jtype[l] == 3) {
+        const int pc = m->parent[m->ball_dof];
+        wc = pc >= 0 ? ld3(Vw[pc]) : v3(0, 0, 0); vc = pc >= 0 ? ld3(Vw[pc] + 3) : v3(0, 0, 0);
+      }
+      const V3 aw = add(awp, scl(cross(wc, sw), qd)), av = add(avp, scl(add(cross(vc, sw), cross(wc, sv)), qd));
       const V3 w = add(wp, scl(sw, qd)), v = add(vp, scl(sv, qd));
       V3 n1, f1, n2, f2;
       iapply(I10[l], aw, av, &n1, &f1);
@@ -360,7 +385,19 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
       H[i][i] += dt * m->damping[i];
     }
     chol_solve(nv, H, rhs);
-    for (int i = 0; i < nv; ++i) { qv[i] += dt * rhs[i]; qp[i] += dt * qv[i]; }
+    const int bd = m->ball_dof;
+    for (int i = 0; i < nv; ++i) { qv[i] += dt * rhs[i]; if (bd < 0 || i < bd) qp[i] += dt * qv[i]; }
+    if (bd >= 0) {   /* mju_quatIntegrate (LinkModel.integrate_pos) */
+      const V3 w = ld3(qv + bd);
+      const double nw = sqrt(dot(w, w));
+      Q4 q = qnormalize(ldq(qp + bd));
+      if (nw > 0) {
+        const double ang = dt * nw, sn = sin(0.5 * ang) / nw;
+        const Q4 r = {cos(0.5 * ang), sn * w.x, sn * w.y, sn * w.z};
+        q = qnormalize(qmul(q, r));
+      }
+      qp[bd] = q.w; qp[bd + 1] = q.x; qp[bd + 2] = q.y; qp[bd + 3] = q.z;
+    }
   }
 }
 
@@ -369,11 +406,6 @@ static V3 attachment(const earl_link_model* m, const StepOut* o, int k) {
   V3 p = ld3(m->att_pos[k]);
   if (la >= 0) { double R[3][3]; qmat(ldq(o->Xq[la]), R); p = add(ld3(o->Xp[la]), mulv(R, p)); }
   return p;
-}
-static Q4 qnormalize(Q4 q) {
-  const double s = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  Q4 r = {q.w * s, q.x * s, q.y * s, q.z * s};
-  return r;
 }
 
 int oracle_set_physics_threads(int n) {
@@ -397,7 +429,7 @@ int oracle_physics(const earl_link_model* m, const earl_collision_model* col, in
     const V3 mpos = ld3(mocap_pos + 3 * (size_t)e);
     const Q4 mq = qnormalize(ldq(mocap_quat + 4 * (size_t)e));
     for (int ts = 0; ts < (integrate ? nsub : 1); ++ts)
-      substep(m, col, qpos + (size_t)e * nv, qvel + (size_t)e * nv, mpos, mq, ctrl + (size_t)e * m->n_act, integrate, &o);
+      substep(m, col, qpos + (size_t)e * m->nq, qvel + (size_t)e * nv, mpos, mq, ctrl + (size_t)e * m->n_act, integrate, &o);
     if (qacc) memcpy(qacc + (size_t)e * nv, o.qacc, sizeof(double) * nv);
     if (efc) memcpy(efc + (size_t)e * (6 + 2 * nv), o.efc, sizeof(double) * (6 + 2 * nv));
     if (ncon) ncon[e] = o.ncon;
@@ -426,7 +458,7 @@ int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* 
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < n; ++e) {
     StepOut o;
-    double* qp = st->qpos + (size_t)e * nv;
+    double* qp = st->qpos + (size_t)e * m->nq;
     double* qv = st->qvel + (size_t)e * nv;
     double* mp = st->mocap_pos + (size_t)e * 3;
     const double* goal = st->goal + (size_t)e * 7;

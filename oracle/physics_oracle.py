@@ -85,7 +85,8 @@ def kinematics(m, qpos, body_pos=None):
       Rb = quat_mat(xquat[b])
       anchor[j] = xpos[b] + Rb @ m.jnt_pos[j]
       axis[j] = Rb @ m.jnt_axis[j]
-      if m.jnt_type[j] == 0:   # hinge: rotate about the axis through the anchor
+      if m.jnt_type[j] != 1:   # hinge: rotate about the axis through the anchor (the components of a free joint's rotation
+                               # count as hinges here: exact at zero rotation, which is all this full-body form is used at)
         h = 0.5 * qpos[j]
         xquat[b] = quat_mul(xquat[b], np.concatenate([[np.cos(h)], np.sin(h) * m.jnt_axis[j]]))
         xpos[b] = anchor[j] - quat_mat(xquat[b]) @ m.jnt_pos[j]
@@ -101,7 +102,7 @@ def motion_subspace(m, kin):
   """S [nv,6]: spatial velocity (omega, v of the point at the world origin) per unit joint velocity"""
   S = np.zeros((m.nv, 6))
   for j in range(m.nv):
-    if m.jnt_type[j] == 0:
+    if m.jnt_type[j] != 1:
       S[j, :3] = kin['axis'][j]
       S[j, 3:] = np.cross(kin['anchor'][j], kin['axis'][j])
     else:
@@ -301,10 +302,19 @@ def step(m, s, body_pos=None):
   return out
 
 
+def dof_qpos0(m):
+  """per-dof coordinates of the reference configuration: 0, except the translation of a free body (its qpos0 = body pos)"""
+  q = np.zeros(m.nv)
+  if hasattr(m, 'body_free'):
+    for b in np.nonzero(m.body_free)[0]:
+      q[m.body_dofs[b][:3]] = m.body_qpos0[b][:3]
+  return q
+
+
 def inverse_weights(m):
   """body_invweight0 [nb,2] (translational, rotational) and dof_invweight0 [nv] at qpos0 = 0 (MuJoCo compiles these
   into the model; the constraint regularizer uses them as the diagonal approximation of J M^-1 J^T)"""
-  kin = kinematics(m, np.zeros(m.nv))
+  kin = kinematics(m, dof_qpos0(m))
   S = motion_subspace(m, kin)
   Minv = np.linalg.inv(mass_matrix(m, kin, S))
   bw = np.zeros((m.nb, 2))
@@ -325,8 +335,7 @@ def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geo
   link_of_body = np.full(m.nb, -1)          # nearest moving ancestor-or-self link of each body (-1: world-fixed)
   for b in range(1, m.nb):
     if m.body_dofs[b]:
-      assert len(m.body_dofs[b]) == 1
-      link_of_body[b] = m.body_dofs[b][0]
+      link_of_body[b] = m.body_dofs[b][-1]  # a body with several dofs (free joint) is a chain of links; the LAST carries the body
     else:
       link_of_body[b] = link_of_body[m.body_parent[b]]
   # pose of every body in the frame of its link's jointed body (or world), with all joints at zero
@@ -338,13 +347,18 @@ def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geo
     rel_pos[b] = rel_pos[p] + quat_mat(rel_quat[p]) @ bp[b]
     rel_quat[b] = quat_mul(rel_quat[p], m.body_quat[b])
   nv = m.nv
-  out = dict(parent=np.full(nv, -1, np.int32), tpos=np.zeros((nv, 3)), tquat=np.zeros((nv, 4)), jtype=m.jnt_type.astype(np.int32),
+  out = dict(parent=np.full(nv, -1, np.int32), tpos=np.zeros((nv, 3)), tquat=np.tile([1.0, 0, 0, 0], (nv, 1)), jtype=m.jnt_type.astype(np.int32),
              jaxis=m.jnt_axis.copy(), jpos=m.jnt_pos.copy(), mass=np.zeros(nv), com=np.zeros((nv, 3)), inertia=np.zeros((nv, 6)))
   for l in range(nv):
     b = int(m.jnt_body[l]); p = int(m.body_parent[b])
-    out['parent'][l] = link_of_body[p]
-    out['tpos'][l] = rel_pos[p] + quat_mat(rel_quat[p]) @ bp[b]      # jointed body's frame in its parent link's frame
-    out['tquat'][l] = quat_mul(rel_quat[p], m.body_quat[b])
+    if l != m.body_dofs[b][0]:              # later dof of a multi-dof body: rides on the previous one, same frame, no mass
+      out['parent'][l] = l - 1
+    else:
+      out['parent'][l] = link_of_body[p]
+      out['tpos'][l] = rel_pos[p] + quat_mat(rel_quat[p]) @ bp[b]      # jointed body's frame in its parent link's frame
+      out['tquat'][l] = quat_mul(rel_quat[p], m.body_quat[b])
+    if l != m.body_dofs[b][-1]:
+      continue
     members = [bb for bb in range(1, m.nb) if link_of_body[bb] == l]
     M = sum(m.body_mass[bb] for bb in members)
     c = sum(m.body_mass[bb] * (rel_pos[bb] + quat_mat(rel_quat[bb]) @ m.body_ipos[bb]) for bb in members) / M
@@ -374,6 +388,12 @@ def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geo
   wb = int(m.weld_body2[0])
   out['weld_att'] = np.int32(list(out['att_names']).index(str(m.body_names[wb])))
   out['weld_invweight'] = m.body_invweight0[wb].copy()
+  # generalized coordinates: qpos has one entry per dof, except that a free body's orientation is a unit quaternion
+  # stored where MuJoCo stores it (after the body's three translations): nq = nv + 1 per free body
+  ball = [l for l in range(nv) if m.jnt_type[l] == 2]
+  assert len(ball) <= 1 and (not ball or ball[0] == nv - 3), 'one free body, last in the dof order'
+  out['ball_dof'] = np.int32(ball[0] if ball else -1)
+  out['qpos0'] = np.concatenate([dof_qpos0(m)[:ball[0]], m.body_qpos0[m.jnt_body[ball[0]]][3:]]) if ball else dof_qpos0(m)
   if collision is not None:
     out.update(collision_primitives(m, link_of_body, rel_pos, rel_quat, collision, bp))
   return out
@@ -412,28 +432,38 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
 
   # gripper plates: a finger is a claw box and a pad box (same size, 3 mm apart) -> ONE box per finger with the pad's
   # contact parameters (the pad is the gripping face); otherwise every touching sphere would produce two contacts
+  # Which spheres meet which boxes: every sphere belongs to a named SET, every box ACCEPTS a tuple of sets.  Defaults
+  # (the door task): cylinder chains are set 'chain' and meet the plates; box corners are set 'corner' and meet the big boxes.
   for names in spec.get('plates', ()):
     l, p, q, half, _, _, _ = union_box(names)
-    box.append(dict(link=l, pos=p, quat=q, half=half, kind=0, **params(m.geom_id(names[-1]))))
-  n_plates = len(box)
-  for g in spec.get('big_boxes', ()):
+    box.append(dict(link=l, pos=p, quat=q, half=half, accept=tuple(spec.get('plates_accept', ('chain',))), **params(m.geom_id(names[-1]))))
+  for e in spec.get('big_boxes', ()):
+    g, accept = (e['geom'], tuple(e['accept'])) if isinstance(e, dict) else (e, ('corner',))
     l, p, q = gframe(g)
-    box.append(dict(link=l, pos=p, quat=q, half=np.array(m.geom_size[g][:3], float), kind=1, **params(g)))
-  for g in spec.get('chains', ()):
+    box.append(dict(link=l, pos=p, quat=q, half=np.array(m.geom_size[g][:3], float), accept=accept, **params(g)))
+  for e in spec.get('chains', ()):
+    g, sname, spacing = (e['geom'], e.get('set', 'chain'), e.get('spacing', 0.75)) if isinstance(e, dict) else (e, 'chain', 0.75)
     l, p, q = gframe(g)
-    r, h = float(m.geom_size[g][0]), float(m.geom_size[g][1])
+    if m.geom_type[g] == 4:                        # a long box stood in for by the chain of its inscribed spheres along its longest axis
+      sz = np.array(m.geom_size[g][:3], float)
+      ax = int(np.argmax(sz))
+      r, h = float(np.min(np.delete(sz, ax))), float(sz[ax])
+      d = np.eye(3)[ax]
+    else:                                          # cylinder: axis z, size = (radius, half length)
+      r, h, d = float(m.geom_size[g][0]), float(m.geom_size[g][1]), np.array([0.0, 0, 1])
     span = max(h - r, 0.0)
-    k = 1 if span == 0 else int(np.ceil(2 * span / (0.75 * r))) + 1
+    k = 1 if span == 0 else int(np.ceil(2 * span / (spacing * r))) + 1
     for t in (np.linspace(-span, span, k) if k > 1 else [0.0]):
-      sph.append(dict(link=l, pos=p + quat_mat(q) @ np.array([0, 0, t]), r=r, kind=0, **params(g)))
-  for names in spec.get('corner_sets', ()):
+      sph.append(dict(link=l, pos=p + quat_mat(q) @ (d * t), r=r, set=sname, **params(g)))
+  for e in spec.get('corner_sets', ()):
+    names, sname = (e['names'], e.get('set', 'corner')) if isinstance(e, dict) else (e, 'corner')
     l, _, q, _, lo, hi, Rq = union_box(names)
     gs = [m.geom_id(names[0])]
     for sx in (0, 1):
       for sy in (0, 1):
         for sz in (0, 1):
           c = np.array([hi[0] if sx else lo[0], hi[1] if sy else lo[1], hi[2] if sz else lo[2]])
-          sph.append(dict(link=l, pos=Rq @ c, r=0.0, kind=1, **params(gs[0])))
+          sph.append(dict(link=l, pos=Rq @ c, r=0.0, set=sname, **params(gs[0])))
   # Permanent deep box-in-box contacts (the door panel stands 2.3 cm inside the table top: obj_init_pos z = 0.1, panel
   # half height 0.123).  Such a contact has all four pyramid edges active and a constant depth, and the moving box has
   # one dof, so its 4 x 4 edges reduce EXACTLY to one soft velocity row on that dof (tests/test_physics.py checks the
@@ -461,7 +491,8 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
   pairs, blocks = [], []
   parent = [int(link_of_body[m.body_parent[int(m.jnt_body[l])]]) for l in range(nv)]
   for j, bx in enumerate(box):
-    members = [i for i, sp in enumerate(sph) if sp['kind'] == bx['kind'] and sp['link'] != bx['link']]
+   for sname in bx['accept']:
+    members = [i for i, sp in enumerate(sph) if sp['set'] == sname and sp['link'] != bx['link']]
     if not members:
       continue
     links = sorted(set(sph[i]['link'] for i in members))
@@ -530,6 +561,9 @@ class LinkModel:
       self.anc.append(a)
 
   def kinematics(self, qpos):
+    """joint types: 0 hinge, 1 slide, 2 / 3 the rotation of a free body (MuJoCo: angular velocity in BODY axes, orientation a
+    unit quaternion in qpos): link type 2 applies the quaternion and its axis is the rotated body x axis, the two type-3
+    links that follow do not move and contribute the body y and z axes."""
     nv = self.nv
     pos, quat = np.zeros((nv, 3)), np.zeros((nv, 4))
     S = np.zeros((nv, 6))
@@ -545,11 +579,34 @@ class LinkModel:
         q = quat_mul(q, np.concatenate([[np.cos(h)], np.sin(h) * self.jaxis[l]]))
         x = anchor - quat_mat(q) @ self.jpos[l]
         S[l, :3], S[l, 3:] = axis, np.cross(anchor, axis)
-      else:
+      elif self.jtype[l] == 1:
         x = x + axis * qpos[l]
         S[l, 3:] = axis
+      else:
+        if self.jtype[l] == 2:
+          qb = np.asarray(qpos[l:l + 4], float)
+          q = quat_mul(q, qb / np.sqrt(qb @ qb))         # normalised, as mj_kinematics does
+          x = anchor - quat_mat(q) @ self.jpos[l]
+          axis = quat_mat(q) @ self.jaxis[l]
+        S[l, :3], S[l, 3:] = axis, np.cross(anchor, axis)
       pos[l], quat[l] = x, q
     return pos, quat, S
+
+  def integrate_pos(self, qpos, qvel):
+    """qpos <- qpos (+) dt qvel: per-dof addition; a free body's quaternion by mju_quatIntegrate (q * exp(dt w / 2), w in body axes)"""
+    bd = int(getattr(self, 'ball_dof', -1))
+    if bd < 0:
+      return qpos + self.dt * qvel
+    out = np.array(qpos, float)
+    out[:bd] = qpos[:bd] + self.dt * qvel[:bd]
+    w = qvel[bd:bd + 3]
+    nw = np.sqrt(w @ w)
+    qn = qpos[bd:bd + 4] / np.sqrt(qpos[bd:bd + 4] @ qpos[bd:bd + 4])
+    if nw > 0:
+      ang = self.dt * nw
+      qn = quat_mul(qn, np.concatenate([[np.cos(0.5 * ang)], np.sin(0.5 * ang) * w / nw]))
+    out[bd:bd + 4] = qn / np.sqrt(qn @ qn)
+    return out
 
   def attachment(self, pos, quat, k):
     l = self.att_link[k]
@@ -579,7 +636,11 @@ class LinkModel:
     for l in range(nv):
       p = self.parent[l]
       Vp, Ap = (V[p], A[p]) if p >= 0 else (np.zeros(6), a_base)
-      A[l] = Ap + crossm(Vp) @ S[l] * qvel[l]
+      # d/dt of the axis: V_parent x S_l; the three rotation axes of a free body all use the velocity BEFORE any of the
+      # three (mj_comVel: "compute all 3 dofdots before updating the velocity")
+      pc = p if self.jtype[l] != 3 else self.parent[l - 1 if self.jtype[l - 1] == 2 else l - 2]
+      Vc = V[pc] if pc >= 0 else np.zeros(6)
+      A[l] = Ap + crossm(Vc) @ S[l] * qvel[l]
       V[l] = Vp + S[l] * qvel[l]
       F[l] = I6[l] @ A[l] + crossf(V[l]) @ (I6[l] @ V[l])
     for l in range(nv - 1, -1, -1):
@@ -645,7 +706,7 @@ class LinkModel:
 
   block_cull = True        # False: test every pair (tests check that the cull never drops a contact)
   contacts = True          # class-level switch: LinkModel.contacts = False gives the contact-free stepper
-  max_contacts = 8         # the kernel's cap: the first max_contacts active pairs in pair order
+  max_contacts = 12        # the kernel's cap (EARL_MAXCON): the first max_contacts active pairs in pair order
 
   def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8):
     """MuJoCo's primal problem  min_a 1/2 (a-a0)' M (a-a0) + sum_r 1/2 D_r [J_r a - aref_r]_-^2  (equalities: both signs)
@@ -747,5 +808,5 @@ class LinkModel:
     M = out['M']
     qacc = np.linalg.solve(M + self.dt * np.diag(self.jnt_damping), M @ out['qacc'])
     qvel = qvel + self.dt * qacc
-    qpos = qpos + self.dt * qvel
+    qpos = self.integrate_pos(qpos, qvel)
     return qpos, qvel, out

@@ -258,13 +258,26 @@ def compile_model(name):
             bodies[bid]['inertial'] = (float(sub.get('mass')), vec(sub.get('pos'), 3), iq, vec(sub.get('diaginertia'), 3))
           elif sub.tag == 'joint':
             a = dfl.attrs(sub, cls)
-            joints.append(dict(body=bid, type=a.get('type', 'hinge'), axis=quat_norm(vec(a.get('axis'), 3, [0, 0, 1])) if True else None,
-                               pos=vec(a.get('pos'), 3, [0, 0, 0]), limited=int(a.get('limited', 'false') == 'true'),
-                               range=vec(a.get('range'), 2, [0, 0]), damping=float(a.get('damping', 0)),
-                               armature=float(a.get('armature', 0)), solref=vec(a.get('solreflimit'), 2, [0.02, 1]),
-                               solimp=vec(a.get('solimplimit'), 5, [0.9, 0.95, 0.001, 0.5, 2]), margin=float(a.get('margin', 0))))
-            joints[-1]['axis'] = vec(a.get('axis'), 3, [0, 0, 1]) / np.linalg.norm(vec(a.get('axis'), 3, [0, 0, 1]))
-            names['joint'].append(a.get('name', ''))
+            base = dict(body=bid, pos=vec(a.get('pos'), 3, [0, 0, 0]), limited=int(a.get('limited', 'false') == 'true'),
+                        range=vec(a.get('range'), 2, [0, 0]), damping=float(a.get('damping', 0)),
+                        armature=float(a.get('armature', 0)), solref=vec(a.get('solreflimit'), 2, [0.02, 1]),
+                        solimp=vec(a.get('solimplimit'), 5, [0.9, 0.95, 0.001, 0.5, 2]), margin=float(a.get('margin', 0)))
+            if a.get('type', 'hinge') == 'free':
+              # A free joint becomes six 1-dof entries on the same body, in MuJoCo's dof order: three translations along the
+              # WORLD axes ('slide'), then the rotation about the three BODY axes: 'ball0' carries the orientation quaternion
+              # (qpos keeps MuJoCo's layout: xyz + wxyz), 'ball1' / 'ball2' only contribute their axis.  The body's own pos /
+              # quat are the joint's qpos0 (MuJoCo semantics), so the body frame itself is zeroed.
+              assert parent == 0 and not base['limited']
+              bodies[bid]['free'] = 1
+              bodies[bid]['qpos0'] = np.concatenate([bodies[bid]['pos'], bodies[bid]['quat']])
+              bodies[bid]['pos'], bodies[bid]['quat'] = np.zeros(3), np.array([1.0, 0, 0, 0])
+              for k, t in enumerate(('slide', 'slide', 'slide', 'ball0', 'ball1', 'ball2')):
+                joints.append(dict(base, type=t, axis=np.eye(3)[k % 3], pos=np.zeros(3)))
+                names['joint'].append(a.get('name', names['body'][bid]) + '_' + 'xyz'[k % 3] + ('t' if k < 3 else 'r'))
+            else:
+              ax = vec(a.get('axis'), 3, [0, 0, 1])
+              joints.append(dict(base, type=a.get('type', 'hinge'), axis=ax / np.linalg.norm(ax)))
+              names['joint'].append(a.get('name', ''))
           elif sub.tag == 'geom':
             add_geom(sub, bid, cls)
           elif sub.tag == 'site':
@@ -300,7 +313,7 @@ def compile_model(name):
       if parts:
         mass[b], ipos[b], iquat[b], inertia[b] = combine_inertia(parts)
 
-  jtype = {'hinge': 0, 'slide': 1}
+  jtype = {'hinge': 0, 'slide': 1, 'ball0': 2, 'ball1': 3, 'ball2': 3}
   gtype = {'plane': 0, 'sphere': 1, 'capsule': 2, 'cylinder': 3, 'box': 4, 'mesh': 5}
   acts = []
   for ac in root.findall('actuator'):
@@ -320,6 +333,8 @@ def compile_model(name):
       name=np.array(name), timestep=np.float64(opt.get('timestep', 0.002)), gravity=vec(opt.get('gravity'), 3, [0, 0, -9.81]),
       body_parent=np.array([b['parent'] for b in bodies], np.int32), body_pos=np.stack([b['pos'] for b in bodies]),
       body_quat=np.stack([b['quat'] for b in bodies]), body_mocap=np.array([b['mocap'] for b in bodies], np.int32),
+      body_free=np.array([b.get('free', 0) for b in bodies], np.int32),
+      body_qpos0=np.stack([b.get('qpos0', np.array([0, 0, 0, 1.0, 0, 0, 0])) for b in bodies]),
       body_mass=mass, body_ipos=ipos, body_iquat=iquat, body_inertia=inertia,
       jnt_body=np.array([j['body'] for j in joints], np.int32), jnt_type=np.array([jtype[j['type']] for j in joints], np.int32),
       jnt_axis=np.stack([j['axis'] for j in joints]), jnt_pos=np.stack([j['pos'] for j in joints]),
@@ -374,6 +389,26 @@ def main():
                                          corner_sets=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], big_boxes=big,
                                          drag=[(panel, tbl, -(bp[pm.body_id('door')][2] - m['geom_size'][panel][2]))]))
     np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
+  if name == 'sawyer_peg':
+    # link form of the peg task.  reset_model puts body 'box' at goal - (0.03, 0, 0.13) = its MJCF position (sawyer_peg.py:196-197).
+    # Collision set: the peg (a 3 x 3 x 24 cm box) is a chain of inscribed spheres against the gripper plates and the
+    # seven boxes of the hole block, and its 8 corners are points against the table top and the block; the plate corners
+    # are points against the table top and the block.  Left out: wrist mesh hulls, retaining walls, floor.
+    pm = po.Model(m)
+    table = pm.body_id('tablelink')
+    blockb = [b for b in range(len(m['body_parent'])) if m['body_parent'][b] == pm.body_id('box')][0]
+    colliding = lambda g: bool(m['geom_contype'][g] or m['geom_conaffinity'][g])
+    boxes = lambda body: [g for g in range(len(m['geom_body'])) if m['geom_body'][g] == body and m['geom_type'][g] == 4 and colliding(g)]
+    peg = pm.geom_id('peg')
+    red = po.reduce_model(pm, None, attach_bodies=['hand'], attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector', 'pegHead', 'pegGrasp'],
+                          collision=dict(plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], plates_accept=('peg',),
+                                         chains=[dict(geom=peg, set='peg', spacing=1.0)],
+                                         corner_sets=[dict(names=['peg'], set='pegcorner'), ['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']],
+                                         big_boxes=[dict(geom=g, accept=('peg', 'pegcorner', 'corner')) for g in boxes(blockb)] +
+                                                   [dict(geom=g, accept=('pegcorner', 'corner')) for g in boxes(table)]))
+    np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
+    print('links:', len(red['parent']), 'spheres', len(red['col_sph_link']), 'boxes', len(red['col_box_link']), 'pairs', len(red['col_pair']),
+          'blocks', len(red['col_blk_begin']), 'classes', len(red['col_cls_mu']))
   nb, nj, ng = len(m['body_parent']), len(m['jnt_body']), len(m['geom_body'])
   col = int(((m['geom_contype'] != 0) | (m['geom_conaffinity'] != 0)).sum())
   print(f'{name}: {nb} bodies, {nj} joints (nv={nj}), {ng} geoms ({col} colliding), {len(m["act_joint"])} actuators, '
