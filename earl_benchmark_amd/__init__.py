@@ -85,6 +85,12 @@ class EARLEnvs(object):
       kw = dict(self._batch_kwargs)
       kw['seed'] = int(kw.get('seed', 0)) + seed_salt
       return sawyer_door.SawyerDoor(reward_type=self._reward_type, reset_at_goal=reset_at_goal, **kw)
+    if self._env_name == 'sawyer_peg':
+      # reference: earl_benchmark/__init__.py:119-122, :146-148 (sawyer_peg.SawyerPegV2(reward_type=..., reset_at_goal=...))
+      from .envs import sawyer_peg
+      kw = dict(self._batch_kwargs)
+      kw['seed'] = int(kw.get('seed', 0)) + seed_salt
+      return sawyer_peg.SawyerPeg(reward_type=self._reward_type, reset_at_goal=reset_at_goal, **kw)
     if self._env_name == 'kitchen' and self._reward_type != 'dense':
       raise ValueError('Kitchen environment only supports dense rewards.')  # reference: envs/kitchen.py:91-92
     raise NotImplementedError(_NOT_BUILT.format(name=self._env_name))

@@ -147,22 +147,33 @@ __device__ __forceinline__ void kbimp(const double* solref, const double* solimp
   b = 2.0 * rcp_nr(dw * tc);
 }
 
+// Static bounds by model size: the door model (nv 10) keeps 8 contact slots and 16 collision blocks, which keeps its workgroup
+// under 40 KB of LDS (four workgroups per CU, one wave per SIMD); the peg model (nv 15) needs 12 / 32.
+template <int NV> struct Lim {
+  static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
+  static constexpr int MB = NV <= 10 ? 16 : EARL_MAXBLK;    // collision blocks
+  static constexpr int NA = NV <= 10 ? NV : 9;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
+                                                            // and free peg are separate trees (checked by the host side); the door model
+                                                            // (9 + 1) is factorised densely -- the split did not pay there
+};
+
 // Per-env LDS block.  The three phase groups of the union are live at disjoint times.
 template <int NV>
 struct Shared {
+  static constexpr int MC = Lim<NV>::MC;
   double qp[NV], qv[NV];
   double bq[4];                      // orientation of the free body (unit quaternion), identity if the model has none
   double Xq[NV][4], Xp[NV][4];       // world frame of every link (final buffer of the ancestor doubling)
-  double S[NV][6];                   // motion subspace, world coordinates about the origin: [angular; linear]
   double M[NV][NV];
   double tau[NV];
   double att[4][3];
-  double ct[EARL_MAXCON][10];        // contact records: dist, normal (3), point (3), class, sphere link, box link
+  double ct[MC][10];                 // contact records: dist, normal (3), point (3), class, sphere link, box link
   double bank_pad[8];                // sizeof(Shared<10>) would be 31 * 256 B: the four env blocks of a wave would sit on the same LDS
                                      // banks and every broadcast access would conflict 4 ways; +64 B staggers them by 16 banks
   union {
     struct { double Xq1[NV][4], Xp1[NV][4]; } k2;                    // second buffer of the doubling
     struct {
+      double S[NV][6];                 // motion subspace, world coordinates about the origin: [angular; linear] (every lane keeps its own column in registers)
       double I10[NV][10];
       union {
         struct { double Ic[NV][10], FS[NV][6]; } crb;
@@ -171,60 +182,78 @@ struct Shared {
     } dyn;
     struct {
       double J6[6][NV], wD[8], war[8], Hw[NV][NV], rw[NV], dl[NV], rl[NV], rhs2[NV];
-      double CJ[EARL_MAXCON][3][NV];   // contact Jacobians: normal, tangent 1, tangent 2
-      double cw[EARL_MAXCON][8];       // per-iteration weights of the active pyramid edges
+      double CJ[MC][3][NV];            // contact Jacobians: normal, tangent 1, tangent 2
+      double cw[MC][8];                // per-iteration weights of the active pyramid edges
       double Hc[NV][NV], rc[NV];
     } con;
   };
 };
 
-// Cholesky of a dense SPD matrix held in registers (lower triangle, row-major packed); the diagonal is left INVERTED
-template <int NV>
+// Cholesky of an SPD matrix held in registers (lower triangle, row-major packed); the diagonal is left INVERTED.
+// NA < NV: the matrix is block diagonal, rows / columns [0, NA) and [NA, NV) -- the arm and the free object are separate
+// trees, so the mass matrix always is, and the Hessian is unless a contact joins the two.  The entries of the off-diagonal block
+// are then never read or written (their registers are dead on that path).
+template <int NV, int NA>
 __device__ __forceinline__ void chol_regs(double (&L)[NV * (NV + 1) / 2]) {
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
+    const int p0 = j >= NA ? NA : 0;                  // first column of row j's block
     double d = L[j * (j + 1) / 2 + j];
 #pragma unroll
-    for (int p = 0; p < j; ++p) d -= L[j * (j + 1) / 2 + p] * L[j * (j + 1) / 2 + p];
+    for (int p = p0; p < j; ++p) d -= L[j * (j + 1) / 2 + p] * L[j * (j + 1) / 2 + p];
     const double inv = rsq_nr(d);
     L[j * (j + 1) / 2 + j] = inv;
 #pragma unroll
-    for (int i = j + 1; i < NV; ++i) {
+    for (int i = j + 1; i < (j < NA ? NA : NV); ++i) {
       double s = L[i * (i + 1) / 2 + j];
 #pragma unroll
-      for (int p = 0; p < j; ++p) s -= L[i * (i + 1) / 2 + p] * L[j * (j + 1) / 2 + p];
+      for (int p = p0; p < j; ++p) s -= L[i * (i + 1) / 2 + p] * L[j * (j + 1) / 2 + p];
       L[i * (i + 1) / 2 + j] = s * inv;
     }
   }
 }
-template <int NV>
+template <int NV, int NA>
 __device__ __forceinline__ void solve_regs(const double (&L)[NV * (NV + 1) / 2], double (&x)[NV]) {   // (L L') x' = x
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     double s = x[i];
 #pragma unroll
-    for (int p = 0; p < i; ++p) s -= L[i * (i + 1) / 2 + p] * x[p];
+    for (int p = (i >= NA ? NA : 0); p < i; ++p) s -= L[i * (i + 1) / 2 + p] * x[p];
     x[i] = s * L[i * (i + 1) / 2 + i];
   }
 #pragma unroll
   for (int i = NV - 1; i >= 0; --i) {
     double s = x[i];
 #pragma unroll
-    for (int p = i + 1; p < NV; ++p) s -= L[p * (p + 1) / 2 + i] * x[p];
+    for (int p = i + 1; p < (i < NA ? NA : NV); ++p) s -= L[p * (p + 1) / 2 + i] * x[p];
     x[i] = s * L[i * (i + 1) / 2 + i];
+  }
+}
+// the lower triangle of an LDS matrix (+ a diagonal term) into the packed register form, skipping the off-diagonal block when NA < NV
+template <int NV, int NA, typename D>
+__device__ __forceinline__ void load_tri(double (&L)[NV * (NV + 1) / 2], const double (&H)[NV][NV], D diag) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int j = (i >= NA ? NA : 0); j < i; ++j) L[i * (i + 1) / 2 + j] = H[i][j];
+    L[i * (i + 1) / 2 + i] = H[i][i] + diag(i);
   }
 }
 
 // block table of the collision model (bounding tests), staged once per workgroup
+template <int MB>
 struct BlkTable {
-  int n_blk, pad_;
-  int begin[EARL_MAXBLK], end[EARL_MAXBLK], box[EARL_MAXBLK], link[EARL_MAXBLK], box_link[EARL_MAXBLK];
-  double center[EARL_MAXBLK][3], reach[EARL_MAXBLK], box_pos[EARL_MAXBLK][3], box_quat[EARL_MAXBLK][4], box_half[EARL_MAXBLK][3];
+  int n_blk, max_con;
+  int begin[MB], end[MB], box[MB], link[MB], box_link[MB];
+  double center[MB][3], reach[MB], box_pos[MB][3], box_quat[MB][4], box_half[MB][3];
 };
-__device__ __forceinline__ void stage_blocks(BlkTable& t, const earl_collision_model* __restrict__ col) {
+template <int MB>
+__device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collision_model* __restrict__ col) {
   const int i = threadIdx.x;
-  if (i == 0) t.n_blk = col ? col->n_blk : 0;
-  if (col && i < col->n_blk) {
+  // (bounds are clamped here; the Python / C front ends refuse models that exceed them)
+  const int nb = col ? (col->n_blk < MB ? col->n_blk : MB) : 0;
+  if (i == 0) { t.n_blk = nb; t.max_con = col ? col->max_con : 0; }
+  if (i < nb) {
     const int b = col->blk_box[i];
     t.begin[i] = col->blk_begin[i]; t.end[i] = col->blk_end[i]; t.box[i] = b; t.link[i] = col->blk_link[i];
     t.box_link[i] = col->box_link[b]; t.reach[i] = col->blk_reach[i];
@@ -238,10 +267,13 @@ __device__ __forceinline__ void stage_blocks(BlkTable& t, const earl_collision_m
 // One timestep of one env by its LPE-lane group (`sub` = lane within the group; every lane of the wave runs this, the
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
 template <int NV, int LPE, bool INTEGRATE>
-__device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m, const BlkTable& bt, const earl_collision_model* __restrict__ col, const int sub,
+__device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m, const BlkTable<Lim<NV>::MB>& bt, const earl_collision_model* __restrict__ col, const int sub,
                                         const int grp, const V3 mpos, const Q4 mq, const double (&ctrl)[EARL_MAXACT], double* qacc_out,
                                         double* efc_out) {
   static_assert(NV <= LPE, "one lane per link");
+  constexpr int MC = Lim<NV>::MC, NA = Lim<NV>::NA;
+  static_assert(MC <= LPE, "one lane per contact");
+  const int maxcon = bt.max_con < MC ? bt.max_con : MC;
   const double dt = m.dt;
   const bool isl = sub < NV;
   const int l = isl ? sub : NV - 1;
@@ -367,7 +399,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       for (int cc = r; cc < 3; ++cc) W[r][cc] = T[r][0] * R[cc][0] + T[r][1] * R[cc][1] + T[r][2] * R[cc][2];
     const double c2 = dot(c, c);
     if (isl) {
-      double* o = s.S[l];
+      double* o = s.dyn.S[l];
       o[0] = Sw.x; o[1] = Sw.y; o[2] = Sw.z; o[3] = Sv.x; o[4] = Sv.y; o[5] = Sv.z;
       double* i10 = s.dyn.I10[l];
       i10[0] = mass;
@@ -418,7 +450,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
 #pragma unroll
     for (int a = 0; a < NV; ++a) {
       const double qd = ((amask >> a) & 1u) ? s.qv[a] : 0.0;
-      const double* sa = s.S[a];
+      const double* sa = s.dyn.S[a];
       w = add(w, scl(ld3(sa), qd));
       v = add(v, scl(ld3(sa + 3), qd));
     }
@@ -431,7 +463,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       const uint32_t drop = amask & ~m.cd_mask[l];
       for (int a = m.ball_dof; a < NV; ++a) {
         const double qd = ((drop >> a) & 1u) ? s.qv[a] : 0.0;
-        const double* sa = s.S[a];
+        const double* sa = s.dyn.S[a];
         wc = vsub(wc, scl(ld3(sa), qd));
         vc = vsub(vc, scl(ld3(sa + 3), qd));
       }
@@ -543,14 +575,14 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
         const int before = LPE == 64 ? __popcll(bal & ((1ull << sub) - 1ull)) : __popc(gb & ((1u << sub) - 1u));
         const int total = LPE == 64 ? __popcll(bal) : __popc(gb);
         const int slot = nct + before;
-        if (hit && slot < EARL_MAXCON) {
+        if (hit && slot < maxcon) {
           const V3 n = mulv(Rb, nl);
           const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
           double* o = s.ct[slot];
           o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
           o[7] = (double)cls; o[8] = (double)lk; o[9] = (double)xl;
         }
-        nct = nct + total < EARL_MAXCON ? nct + total : EARL_MAXCON;
+        nct = nct + total < maxcon ? nct + total : maxcon;
       }
     }
     fence();
@@ -560,7 +592,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   int ncmax = 0;
   if (nearw && __any(nct > 0)) {
 #pragma unroll
-    for (int k = 0; k < EARL_MAXCON; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
+    for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
   }
   // ------------------------------------------------------------------ K8: constraint rows
   double Jc[6];                                        // this lane's column of the weld Jacobian
@@ -622,12 +654,14 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   // ------------------------------------------------------------------ C3: contact rows (reference: LinkModel.contact_rows)
   double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};       // lane c (< nct) owns contact c: edge weights and reference accelerations
   unsigned int cact = 0;                               // active pyramid edges of that contact (bits 0..3)
+  bool coupled = false;                                // some contact of some env of the wave joins the two trees (arm / object)
   if (ncmax > 0) {
     for (int c = 0; c < ncmax; ++c) {
       const double* rec = s.ct[c];
       const bool cv = c < nct;
       const V3 n = cv ? ld3(rec + 1) : V3{0, 0, 1}, p = cv ? ld3(rec + 4) : V3{0, 0, 0};
       const int ls = cv ? (int)rec[8] : -1, lb = cv ? (int)rec[9] : -1;
+      coupled = coupled || (ls >= 0 && lb >= 0 && ((ls < NA) != (lb < NA)));
       // tangents: n x (the coordinate axis least aligned with n), normalised, then n x t1
       const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
       const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
@@ -645,7 +679,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     }
     fence();
     {
-      const int c = sub < EARL_MAXCON ? sub : EARL_MAXCON - 1;
+      const int c = sub < MC ? sub : MC - 1;
       const bool cv = sub < nct;
       double vn = 0, vt1 = 0, vt2 = 0;
 #pragma unroll
@@ -688,6 +722,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
     if (isl) s.con.rw[l] = g;
   }
+  coupled = __any(coupled);
   bool act = lim_inst;
   double a[NV];
   double L[NV * (NV + 1) / 2];
@@ -698,7 +733,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       s.con.dl[l] = act ? lim_D : 0.0;
       s.con.rl[l] = act ? lim_D * lim_aref * lim_side : 0.0;
     }
-    if (ncmax > 0 && sub < EARL_MAXCON) {
+    if (ncmax > 0 && sub < MC) {
       // edges (n + mu t1, n - mu t1, n + mu t2, n - mu t2): sum_e D a_e u_e u_e' on (Jn, Jt1, Jt2) and sum_e D a_e aref_e u_e
       const double a1 = (cact & 1u) ? cD : 0.0, a2 = (cact & 2u) ? cD : 0.0, a3 = (cact & 4u) ? cD : 0.0, a4 = (cact & 8u) ? cD : 0.0;
       double* w = s.con.cw[sub];
@@ -729,14 +764,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     }
     fence();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-#pragma unroll
-      for (int j = 0; j < i; ++j) L[i * (i + 1) / 2 + j] = s.con.Hc[i][j];
-      L[i * (i + 1) / 2 + i] = s.con.Hc[i][i] + s.con.dl[i];
-      a[i] = s.con.rc[i] + s.con.rl[i];
+    for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
+    if (NA == NV || coupled) {                         // a contact joins the arm and the object: dense factorisation (uniform over the wave)
+      load_tri<NV, NV>(L, s.con.Hc, [&](int i) { return s.con.dl[i]; });
+      chol_regs<NV, NV>(L);
+      solve_regs<NV, NV>(L, a);
+    } else {
+      load_tri<NV, NA>(L, s.con.Hc, [&](int i) { return s.con.dl[i]; });
+      chol_regs<NV, NA>(L);
+      solve_regs<NV, NA>(L, a);
     }
-    chol_regs<NV>(L);
-    solve_regs<NV>(L, a);
     double al = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
@@ -744,7 +781,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     bool changed = want != act;
     act = want;
     if (ncmax > 0) {
-      const int c = sub < EARL_MAXCON ? sub : EARL_MAXCON - 1;
+      const int c = sub < MC ? sub : MC - 1;
       double an = 0, at1 = 0, at2 = 0;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
@@ -791,14 +828,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     }
     fence();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-#pragma unroll
-      for (int j = 0; j < i; ++j) L[i * (i + 1) / 2 + j] = s.M[i][j];
-      L[i * (i + 1) / 2 + i] = s.M[i][i] + dt * m.damping[i];
-      a[i] = s.con.rhs2[i];
-    }
-    chol_regs<NV>(L);
-    solve_regs<NV>(L, a);
+    for (int i = 0; i < NV; ++i) a[i] = s.con.rhs2[i];
+    load_tri<NV, NA>(L, s.M, [&](int i) { return dt * m.damping[i]; });       // the mass matrix is block diagonal: two trees
+    chol_regs<NV, NA>(L);
+    solve_regs<NV, NA>(L, a);
     double al = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
@@ -899,7 +932,7 @@ template <int NV, int LPE, bool INTEGRATE>
 __global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
   constexpr int EPW = 64 / LPE;
   __shared__ earl_link_model m;
-  __shared__ BlkTable bt;
+  __shared__ BlkTable<Lim<NV>::MB> bt;
   __shared__ Shared<NV> sh[EPW];
   stage_blocks(bt, a.col);
   stage_model(m, a.m);
@@ -1003,7 +1036,7 @@ __global__ __launch_bounds__(64) void sawyer_rollout_kernel(const SawyerArgs a) 
   static_assert(LPE >= 14, "the observation is written by 14 lanes");
   constexpr int EPW = 64 / LPE;
   __shared__ earl_link_model m;
-  __shared__ BlkTable bt;
+  __shared__ BlkTable<Lim<NV>::MB> bt;
   __shared__ Shared<NV> sh[EPW];
   stage_blocks(bt, a.col);
   stage_model(m, a.m);
@@ -1045,7 +1078,7 @@ template <int NV, int LPE>
 __global__ __launch_bounds__(64) void sawyer_reset_kernel(const SawyerArgs a) {
   constexpr int EPW = 64 / LPE;
   __shared__ earl_link_model m;
-  __shared__ BlkTable bt;
+  __shared__ BlkTable<Lim<NV>::MB> bt;
   __shared__ Shared<NV> sh[EPW];
   stage_blocks(bt, a.col);
   stage_model(m, a.m);

@@ -59,11 +59,7 @@ class SawyerDoor:
       raise ValueError('scalar_api needs num_envs == 1')
     self._reward_type = reward_type
     self._reset_at_goal = bool(reset_at_goal)
-    # sawyer_door.py:32-41
-    self.obj_init_angle = 0.0 if self._reset_at_goal else -np.pi / 3
-    self.obj_init_pos = np.array([0.1, 0.95, 0.1], dtype=np.float32)
-    self.hand_init_pos = np.array([0.29, 0.74, 0.1] if self._reset_at_goal else [0, 0.4, 0.2], dtype=np.float32)
-    self.goal_states = goal_states.copy()
+    self._task_constants()
     self.max_path_length = int(1e8)
 
     with torch.cuda.device(dev):
@@ -71,28 +67,26 @@ class SawyerDoor:
     nv = self.nv = self.model.nv
     names = self.model.att_names
     kw = dict(device=dev)
-    self.qpos = torch.zeros(n, nv, dtype=torch.float64, **kw)
+    self.nq = self.model.nq
+    self.qpos = torch.zeros(n, self.nq, dtype=torch.float64, **kw)
     self.qvel = torch.zeros(n, nv, dtype=torch.float64, **kw)
     self.mocap_pos = torch.zeros(n, 3, dtype=torch.float64, **kw)
-    self.goal_t = torch.tensor(goal_states[0], dtype=torch.float64, **kw).repeat(n, 1).contiguous()
+    self.goal_t = torch.tensor(self.goal_states[0], dtype=torch.float64, **kw).repeat(n, 1).contiguous()
     self.steps_since_reset = torch.zeros(n, dtype=torch.int32, **kw)
     self.interventions = torch.zeros(n, dtype=torch.int32, **kw)
     self.steps_since_goal_change = torch.zeros(n, dtype=torch.int32, **kw)
     self.lifelong_return_t = torch.zeros(n, dtype=torch.float64, **kw)
     self.total_step_count = 0
 
-    lo, hi = (-np.pi / 20, 0.0) if self._reset_at_goal else (0.0, np.pi / 20)          # :116-118
     cfg = _abi.SawyerCfg(n=n, env_offset=int(env_offset), reward_type=_abi.REWARD_TYPES[reward_type], horizon=INT32_MAX,
                          frame_skip=FRAME_SKIP, att_hand=names.index('hand'), att_right=names.index('rightEndEffector'),
-                         att_left=names.index('leftEndEffector'), att_obj=names.index('handle'),
-                         obj_dof=int(self.model.tables.get('obj_dof', nv - 1)), action_scale=1.0 / 100,
-                         success_radius=0.02, obj_init_angle=float(self.obj_init_angle), seed=int(seed) & (2**64 - 1), counter=0)
-    cfg.mocap_low[:] = (-0.5, 0.40, 0.05)      # SawyerDoorCloseEnvV2 hand_low / hand_high [UPSTREAM]; sawyer_door.py:25-26
+                         att_left=names.index('leftEndEffector'), action_scale=1.0 / 100, seed=int(seed) & (2**64 - 1), counter=0)
+    cfg.mocap_low[:] = (-0.5, 0.40, 0.05)      # hand_low / hand_high: sawyer_door.py:25-26, sawyer_peg.py:67-68 (mocap bounds = hand bounds [UPSTREAM])
     cfg.mocap_high[:] = (0.5, 1.0, 0.5)
     cfg.mocap_quat[:] = (1.0, 0.0, 1.0, 0.0)
     cfg.hand_init_pos[:] = [float(x) for x in self.hand_init_pos]
     cfg.obj_init_pos[:] = [float(x) for x in self.obj_init_pos]
-    cfg.angle_noise[:] = (lo, hi)
+    self._task_cfg(cfg, names)
     cfg.goal_change_frequency = 0               # python-side only (LifelongWrapper)
     self._cfg = cfg
     self._st = _abi.SawyerState(qpos=self.qpos.data_ptr(), qvel=self.qvel.data_ptr(), mocap_pos=self.mocap_pos.data_ptr(),
@@ -106,6 +100,22 @@ class SawyerDoor:
       self.reset()
     self.interventions.zero_()
 
+  # ------------------------------------------------------------------ task specifics (overridden by envs/sawyer_peg.py)
+  def _task_constants(self):
+    # sawyer_door.py:32-41
+    self.obj_init_angle = 0.0 if self._reset_at_goal else -np.pi / 3
+    self.obj_init_pos = np.array([0.1, 0.95, 0.1], dtype=np.float32)
+    self.hand_init_pos = np.array([0.29, 0.74, 0.1] if self._reset_at_goal else [0, 0.4, 0.2], dtype=np.float32)
+    self.goal_states = goal_states.copy()
+
+  def _task_cfg(self, cfg, names):
+    lo, hi = (-np.pi / 20, 0.0) if self._reset_at_goal else (0.0, np.pi / 20)          # :116-118
+    cfg.att_obj = names.index('handle')
+    cfg.obj_dof, cfg.obj_kind = self.model.nv - 1, 0
+    cfg.success_radius = 0.02
+    cfg.obj_init_angle = float(self.obj_init_angle)
+    cfg.angle_noise[:] = (lo, hi)
+
   # ------------------------------------------------------------------ internals
   @property
   def unwrapped(self):
@@ -118,7 +128,7 @@ class SawyerDoor:
     """sim.reset() + _reset_hand: 50 x (mocap <- hand_init_pos, ctrl <- [-1, 1], frame_skip timesteps) from qpos0.
     Deterministic and identical for every env, so it is run once on a single instance and cached."""
     kw = dict(dtype=torch.float64, device=self.device)
-    q, v = torch.zeros(1, self.nv, **kw), torch.zeros(1, self.nv, **kw)
+    q, v = torch.tensor(self.model.tables['qpos0'], **kw).reshape(1, self.nq).contiguous(), torch.zeros(1, self.nv, **kw)
     mp = torch.tensor([[float(x) for x in self.hand_init_pos]], **kw)
     mq = torch.tensor([[1.0, 0.0, 1.0, 0.0]], **kw)
     ctrl = torch.tensor([[-1.0, 1.0]], **kw)
@@ -234,7 +244,7 @@ class SawyerDoor:
 
   # ------------------------------------------------------------------ state access
   def set_state(self, qpos, qvel):
-    self.qpos.copy_(torch.as_tensor(qpos, dtype=torch.float64, device=self.device).reshape(self.num_envs, self.nv))
+    self.qpos.copy_(torch.as_tensor(qpos, dtype=torch.float64, device=self.device).reshape(self.num_envs, self.nq))
     self.qvel.copy_(torch.as_tensor(qvel, dtype=torch.float64, device=self.device).reshape(self.num_envs, self.nv))
 
   def state_dict(self):

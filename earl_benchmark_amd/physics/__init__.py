@@ -40,7 +40,7 @@ class PairRec(C.Structure):
 
 class CollisionModelStruct(C.Structure):   # struct earl_collision_model
   _fields_ = [('n_sph', C.c_int32), ('n_box', C.c_int32), ('n_pair', C.c_int32), ('n_cls', C.c_int32),
-              ('n_blk', C.c_int32), ('pad_', C.c_int32 * 3), ('blk_begin', C.c_int32 * MAXBLK), ('blk_end', C.c_int32 * MAXBLK),
+              ('n_blk', C.c_int32), ('max_con', C.c_int32), ('pad_', C.c_int32 * 2), ('blk_begin', C.c_int32 * MAXBLK), ('blk_end', C.c_int32 * MAXBLK),
               ('blk_box', C.c_int32 * MAXBLK), ('blk_link', C.c_int32 * MAXBLK), ('blk_center', C.c_double * 3 * MAXBLK),
               ('blk_reach', C.c_double * MAXBLK),
               ('sph_link', C.c_int32 * MAXSPH), ('box_link', C.c_int32 * MAXBOX),
@@ -122,7 +122,10 @@ def load_collision_model(d):
   c = CollisionModelStruct()
   c.n_sph, c.n_box, c.n_pair, c.n_cls = len(d['col_sph_link']), len(d['col_box_link']), len(d['col_pair']), len(d['col_cls_mu'])
   c.n_blk = len(d['col_blk_begin'])
-  assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS and c.n_blk <= MAXBLK
+  c.max_con = int(d['max_contacts']) if 'max_contacts' in d else 8
+  small = len(d['parent']) <= 10                # csrc/physics.hip Lim<NV>: 8 contact slots / 16 blocks for nv <= 10
+  assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS
+  assert c.n_blk <= (16 if small else MAXBLK) and 0 < c.max_con <= (8 if small else MAXCON)
   for dst, src in ((c.blk_begin, d['col_blk_begin']), (c.blk_end, d['col_blk_end']), (c.blk_box, d['col_blk_box']),
                    (c.blk_link, d['col_blk_link']), (c.blk_center, d['col_blk_center']), (c.blk_reach, d['col_blk_reach'])):
     _fill(dst, src)

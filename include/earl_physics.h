@@ -60,7 +60,8 @@ typedef struct earl_link_model {
 
 /* Collision geometry of a link model: SPHERES (cylinders are chains of spheres; box corners are spheres of radius 0)
  * tested against BOXES over a fixed pair list; per-pair solver parameters by class (MuJoCo's geom mixing rules applied
- * at model-compile time).  At most EARL_MAXCON contacts per env and timestep: the first active pairs in list order. */
+ * at model-compile time).  At most max_con (<= EARL_MAXCON) contacts per env and timestep: the first active pairs in list order.
+ * Models with nv <= 10 are limited to 8 contact slots and 16 blocks (their workgroup then fits four times into a CU's LDS). */
 #define EARL_MAXSPH 64
 #define EARL_MAXBOX 16
 #define EARL_MAXPAIR 512
@@ -71,7 +72,9 @@ typedef struct earl_collision_model {
   int32_t n_sph, n_box, n_pair, n_cls;
   /* pairs are stored box-major in blocks (one box x one set of spheres); a block is skipped when the bounding sphere of its
    * set (centre given in the frame of blk_link, -1 = world) is farther than blk_reach from the box centre */
-  int32_t n_blk, pad_[3];
+  int32_t n_blk;
+  int32_t max_con;                           /* contacts kept per env and timestep (<= EARL_MAXCON; <= 8 for models with nv <= 10): the first active pairs */
+  int32_t pad_[2];
   int32_t blk_begin[EARL_MAXBLK], blk_end[EARL_MAXBLK], blk_box[EARL_MAXBLK], blk_link[EARL_MAXBLK];
   double blk_center[EARL_MAXBLK][3], blk_reach[EARL_MAXBLK];
   int32_t sph_link[EARL_MAXSPH];             /* -1 = fixed to the world */

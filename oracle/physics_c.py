@@ -64,3 +64,13 @@ def door_cfg(reward_type='sparse', reset_at_goal=False, horizon=0, att_names=Non
               action_scale=1.0 / 100, mocap_low=(-0.5, 0.40, 0.05), mocap_high=(0.5, 1.0, 0.5), mocap_quat=(1.0, 0.0, 1.0, 0.0),
               success_radius=0.02, hand_init_pos=hand_init, obj_init_pos=np.array([0.1, 0.95, 0.1], np.float32).astype(np.float64),
               obj_init_angle=0.0, angle_noise=(0.0, 0.0), seed=0, counter=0)
+
+
+def peg_cfg(horizon=0, att_names=None):
+  """earl_sawyer_cfg fields of the sawyer_peg task (sparse reward, reset ranges of the default reset_model)"""
+  names = att_names
+  return dict(env_offset=0, reward_type=0, horizon=horizon, frame_skip=5, att_hand=names.index('hand'), att_right=names.index('rightEndEffector'),
+              att_left=names.index('leftEndEffector'), att_obj=names.index('pegHead'), obj_dof=9, obj_kind=1, n_goal_rows=0,
+              action_scale=1.0 / 100, mocap_low=(-0.5, 0.40, 0.05), mocap_high=(0.5, 1.0, 0.5), mocap_quat=(1.0, 0.0, 1.0, 0.0),
+              success_radius=0.05, hand_init_pos=(0.0, 0.6, 0.2), obj_init_pos=(0.0, 0.6, 0.02), obj_low=(0.0, 0.5, 0.02),
+              obj_high=(0.2, 0.7, 0.02), obj_reject_xy=(-0.3, 0.6), obj_reject_radius=0.1, seed=0, counter=0)

@@ -272,7 +272,7 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
   o->ncon = 0;
   if (col) {
     int ncon = 0;
-    for (int b = 0; b < col->n_blk && ncon < EARL_MAXCON; ++b) {
+    for (int b = 0; b < col->n_blk && ncon < col->max_con; ++b) {
       const int bi = col->blk_box[b], bl = col->blk_link[b], xl = col->box_link[bi];
       V3 cs = ld3(col->blk_center[b]), pb = ld3(col->box_pos[bi]);
       Q4 qb = ldq(col->box_quat[bi]);
@@ -286,7 +286,7 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
         const V3 d = v3(x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z));
         if (!(dot(d, d) < col->blk_reach[b] * col->blk_reach[b])) continue;
       }
-      for (int pi = col->blk_begin[b]; pi < col->blk_end[b] && ncon < EARL_MAXCON; ++pi) {
+      for (int pi = col->blk_begin[b]; pi < col->blk_end[b] && ncon < col->max_con; ++pi) {
         const int lk = col->pair_rec[pi].sph_link, cls = col->pair_rec[pi].cls;
         const double r = col->pair_rec[pi].r, margin = col->pair_rec[pi].margin;
         V3 c = ld3(col->pair_rec[pi].pos);

@@ -536,7 +536,8 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
               col_cls_invw=np.array([c[4] for c in cls]), dof_drag_G=drag_G, dof_drag_b=drag_b,
               col_blk_begin=np.array([b['begin'] for b in blocks], np.int32), col_blk_end=np.array([b['end'] for b in blocks], np.int32),
               col_blk_box=np.array([b['box'] for b in blocks], np.int32), col_blk_link=np.array([b['link'] for b in blocks], np.int32),
-              col_blk_center=np.array([b['center'] for b in blocks]), col_blk_reach=np.array([b['reach'] for b in blocks]))
+              col_blk_center=np.array([b['center'] for b in blocks]), col_blk_reach=np.array([b['reach'] for b in blocks]),
+              max_contacts=np.int32(spec.get('max_contacts', 8)))
 
 
 def sym6(v):
@@ -552,6 +553,7 @@ class LinkModel:
       setattr(self, k, np.array(d[k]))
     self.nv = len(self.parent)
     self.dt = float(self.timestep)
+    self.max_contacts = int(self.max_contacts)
     self.anc = []
     for l in range(self.nv):
       a, p = [l], self.parent[l]
@@ -706,7 +708,7 @@ class LinkModel:
 
   block_cull = True        # False: test every pair (tests check that the cull never drops a contact)
   contacts = True          # class-level switch: LinkModel.contacts = False gives the contact-free stepper
-  max_contacts = 12        # the kernel's cap (EARL_MAXCON): the first max_contacts active pairs in pair order
+  max_contacts = 8         # the kernel's cap (tables: 'max_contacts' = earl_collision_model.max_con): the first max_contacts active pairs in pair order
 
   def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8):
     """MuJoCo's primal problem  min_a 1/2 (a-a0)' M (a-a0) + sum_r 1/2 D_r [J_r a - aref_r]_-^2  (equalities: both signs)

@@ -98,3 +98,80 @@ class SawyerDoorOracle:
     r, ok = compute_reward(obs, self.reward_type, self.hand_init_pos)
     self.steps += 1
     return obs, np.float32(r), bool(self.horizon > 0 and self.steps >= self.horizon), bool(ok)
+
+
+# ---------------------------------------------------------------------------------------------------- sawyer_peg
+PEG_GOAL = np.array([0.0, 0.6, 0.2, 1.0, -0.3 + 0.03, 0.6, 0.0 + 0.13])                            # sawyer_peg.py:52
+PEG_INITIAL_XY = np.array([(0.00313463, 0.68326396), (-0.04035005, 0.67949003), (0.02531051, 0.6074387), (0.05957219, 0.6271171),
+                           (-0.07566337, 0.62575287), (-0.01177235, 0.55206996), (0.02779735, 0.54707706), (0.01835314, 0.5329686),
+                           (0.02690855, 0.6263067), (0.01766127, 0.59630984), (0.0560186, 0.6634998), (-0.03950658, 0.6323736),
+                           (-0.03216827, 0.5247563), (0.01265727, 0.69466716), (0.05076993, 0.6025737)])            # :18-48
+PEG_INITIAL_STATES = np.array([[0.00615235, 0.6001898, 0.19430117, 1.0, x, y, 0.02] for x, y in PEG_INITIAL_XY])
+
+
+class SawyerPegOracle(SawyerDoorOracle):
+  """SawyerPegV2 (sparse reward) around LinkModel: reference earl_benchmark/envs/sawyer_peg.py
+     _get_obs :134-142 (object = site pegHead :186-187), reset_model :192-229, get_next_goal / reset_goal :144-163,
+     is_successful :301-305 (radius 0.05); SawyerXYZEnv.step / _reset_hand / _set_obj_xyz are upstream metaworld."""
+
+  def __init__(self, link_model, reward_type='sparse', reset_at_goal=False, seed=0, env_id=0, horizon=0, frame_skip=5):
+    assert reward_type == 'sparse'
+    self.lm, self.reward_type, self.seed, self.env_id, self.horizon, self.frame_skip = link_model, reward_type, seed, env_id, horizon, frame_skip
+    names = [str(x) for x in link_model.att_names]
+    self.k_hand, self.k_right, self.k_left, self.k_obj = (names.index(x) for x in ('hand', 'rightEndEffector', 'leftEndEffector', 'pegHead'))
+    self.obj_dof = int(link_model.ball_dof) - 3
+    self.hand_init_pos = np.array([0, 0.6, 0.2], dtype=np.float64)
+    self.reset_at_goal = reset_at_goal
+    pos_box = PEG_GOAL[4:] - np.array([0.03, 0.0, 0.13])
+    if not reset_at_goal:
+      self.obj_low, self.obj_high = np.array([0.0, 0.5, 0.02]), np.array([0.2, 0.7, 0.02])
+      self.reject_xy, self.reject_radius = pos_box[:2], 0.1
+    else:
+      goal_pos = PEG_GOAL[4:] - np.array([-0.1, 0.0, 0.0])
+      self.obj_low, self.obj_high = goal_pos - 0.02, goal_pos + 0.02
+      self.reject_xy, self.reject_radius = pos_box[:2], 0.0
+    self.goal = PEG_GOAL.copy()
+    self.counter = 0
+    self._settled = None
+
+  def settle(self):
+    if self._settled is None:
+      q, v = self.lm.qpos0.copy(), np.zeros(self.lm.nv)
+      for _ in range(50 * self.frame_skip):
+        q, v, _ = self.lm.step(q, v, np.array([-1.0, 1.0]), self.hand_init_pos, MOCAP_QUAT)
+      self._settled = (q, v)
+    return self._settled
+
+  def _draw(self, d):
+    return philox4x32_10((d, self.env_id, self.counter & 0xFFFFFFFF, self.counter >> 32), (self.seed & 0xFFFFFFFF, self.seed >> 32))
+
+  def reset(self):
+    q, v = (x.copy() for x in self.settle())
+    for attempt in range(16):
+      b0, b1 = self._draw(2 * attempt), self._draw(2 * attempt + 1)
+      u = np.array([u01(b0[0], b0[1]), u01(b0[2], b0[3]), u01(b1[0], b1[1])])
+      pos = self.obj_low + (self.obj_high - self.obj_low) * u
+      if not np.sqrt(np.sum((pos[:2] - self.reject_xy) ** 2)) < self.reject_radius:
+        break
+    if self.reset_at_goal:
+      b = self._draw(0xFFFF)
+      self.goal = PEG_INITIAL_STATES[min(int(u01(b[0], b[1]) * len(PEG_INITIAL_STATES)), len(PEG_INITIAL_STATES) - 1)].copy()
+    self.counter += 1
+    q[self.obj_dof:self.obj_dof + 3] = pos          # _set_obj_xyz [UPSTREAM]: qpos[9:12] <- pos, qvel[9:15] <- 0
+    v[self.obj_dof:self.obj_dof + 6] = 0.0
+    self.qpos, self.qvel, self.mocap, self.steps = q, v, self.hand_init_pos.copy(), 0
+    pos_, quat_, _ = self.lm.kinematics(q)
+    return self.obs_from(pos_, quat_)
+
+  def step(self, action):
+    a = np.asarray(action, dtype=np.float32)
+    delta = (np.clip(a[:3], np.float32(-1), np.float32(1)) * np.float32(1.0 / 100)).astype(np.float64)
+    self.mocap = np.clip(self.mocap + delta, MOCAP_LOW, MOCAP_HIGH)
+    ctrl = np.array([float(a[3]), -float(a[3])])
+    out = None
+    for _ in range(self.frame_skip):
+      self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl, self.mocap, MOCAP_QUAT)
+    obs = self.obs_from(out['pos'], out['quat'])
+    ok = bool(np.sqrt(np.sum((obs[4:7] - obs[11:14]) ** 2)) <= 0.05)             # is_successful :301-305
+    self.steps += 1
+    return obs, np.float32(float(ok)), bool(self.horizon > 0 and self.steps >= self.horizon), ok

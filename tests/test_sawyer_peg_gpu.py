@@ -1,0 +1,236 @@
+"""Sawyer peg-insertion env on the HIP stepper vs the CPU restatement (oracle/sawyer_oracle.SawyerPegOracle on
+oracle/physics_oracle.LinkModel, and the C restatement for the long runs), and vs the reference's recorded demonstrations
+where those constrain it.
+
+Dynamics parity with MuJoCo is UNPINNED (no simulator here).  Pinned by the reference's data: the sparse rule (bit-exact on
+all 1,815 demonstration rows), the reset observation (hand within 8 mm, gripper 1.0, pegHead z = 0.02 and xy inside the
+reset box), the reverse-task reset (peg in the hole, goal = one of the 15 initial states).  Loose: the 10 forward
+demonstrations replayed open loop (grasp, lift, insert)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+LINKS = os.path.join(REPO, 'earl_benchmark_amd', 'models', 'sawyer_peg_links.npz')
+DEMOS = os.path.join(REPO, 'earl_benchmark_amd', 'demonstrations', 'sawyer_peg')
+
+
+@pytest.fixture(scope='module')
+def lm():
+  from oracle import physics_oracle as po
+  return po.LinkModel(LINKS)
+
+
+def episodes(direction):
+  z = np.load(os.path.join(DEMOS, direction, 'demo_data.npz'))
+  ends = np.nonzero(z['terminals'].ravel())[0] + 1
+  return [(z['observations'][s], z['actions'][s:e], z['next_observations'][s:e], z['rewards'][s:e].ravel())
+          for s, e in zip([0] + list(ends[:-1]), ends)]
+
+
+@pytest.mark.parametrize('reset_at_goal', [False, True])
+def test_reset_and_rollout_match_oracle(lm, reset_at_goal):
+  import torch
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  from earl_benchmark_amd.wrappers import PersistentStateWrapper
+  from oracle.sawyer_oracle import PEG_INITIAL_STATES, SawyerPegOracle
+  n, T, off = 6, 7, 40
+  env = PersistentStateWrapper(SawyerPeg(reset_at_goal=reset_at_goal, num_envs=n, seed=11, env_offset=off), 5)
+  obs0 = env.reset().cpu().numpy()
+  refs = [SawyerPegOracle(lm, 'sparse', reset_at_goal, seed=11, env_id=off + i, horizon=5) for i in range(n)]
+  for r in refs:
+    r._settled = refs[0].settle()
+    r.counter = 1                       # the env constructor consumed draw 0
+  ref0 = np.stack([r.reset() for r in refs])
+  np.testing.assert_allclose(obs0, ref0, rtol=0, atol=1e-8)
+  u = env.unwrapped
+  np.testing.assert_allclose(u.qpos.cpu().numpy(), np.stack([r.qpos for r in refs]), atol=1e-9)
+  assert (u.qvel[:, 9:] == 0).all()
+  if reset_at_goal:                     # peg in the hole, goal drawn from the initial-state table (sawyer_peg.py:149-152, :216-227)
+    assert (np.abs(obs0[:, 4:7] - [-0.27, 0.6, 0.13]) <= 0.02 + 1e-12).all()
+    assert all((np.abs(PEG_INITIAL_STATES - g).max(1) == 0).any() for g in obs0[:, 7:])
+    assert len(np.unique(obs0[:, 11])) > 1
+  else:
+    assert (obs0[:, 4] >= -0.1).all() and (obs0[:, 4] <= 0.1).all() and (obs0[:, 5] >= 0.5).all() and (obs0[:, 5] <= 0.7).all()
+    np.testing.assert_allclose(obs0[:, 6], 0.02, atol=1e-6)      # _set_obj_xyz keeps the settled orientation: 0.1 m x a 2e-7 rad pitch
+    assert len(np.unique(obs0[:, 4])) == n
+  rng = np.random.default_rng(3)
+  acts = rng.uniform(-1.3, 1.3, size=(T, n, 4)).astype(np.float32)
+  acts[:, :, 2] = -np.abs(acts[:, :, 2])            # head down, towards the peg / the table
+  out = env.rollout(torch.from_numpy(acts).cuda())
+  for t in range(T):
+    for i, r in enumerate(refs):
+      o, rew, done, ok = r.step(acts[t, i])
+      np.testing.assert_allclose(out['obs'][t, i].cpu().numpy(), o, rtol=0, atol=1e-7)
+      assert float(out['reward'][t, i]) == float(rew)
+      assert bool(out['done'][t, i]) == done and bool(out['success'][t, i]) == ok
+  assert bool(out['done'][4].all()) and not bool(out['done'][3].any())
+  o, rew, done, info = env.step(torch.from_numpy(acts[0]).cuda())
+  ref = np.stack([r.step(acts[0, i])[0] for i, r in enumerate(refs)])
+  np.testing.assert_allclose(o.cpu().numpy(), ref, rtol=0, atol=2e-7)
+
+
+def test_reset_observation_against_the_demonstrations():
+  """every recorded episode starts with the reference's own reset observation"""
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg, goal_states, initial_states
+  fwd, rev = episodes('forward'), episodes('reverse')
+  env = SawyerPeg(num_envs=16, seed=1)
+  o = env.reset().cpu().numpy()
+  first = np.stack([e[0] for e in fwd]).astype(np.float64)
+  assert np.abs(o[:, :3] - first[0, :3]).max() < 8e-3            # hand after _reset_hand: a 250-timestep transient, within 8 mm
+  assert np.abs(o[:, 3] - 1.0).max() < 1e-9 and (first[:, 3] == 1.0).all()
+  np.testing.assert_allclose(o[:, 7:], np.repeat(goal_states, 16, 0), atol=0)
+  np.testing.assert_allclose(first[:, 7:], np.repeat(goal_states, len(first), 0), atol=1e-7)
+  assert (np.abs(first[:, 6] - 0.02) < 1e-7).all() and (np.abs(o[:, 6] - 0.02) < 1e-6).all()
+  for x in (o, first):                                           # pegHead = peg - (0.1, 0, 0), peg ~ U([0, 0.2] x [0.5, 0.7])
+    assert (x[:, 4] >= -0.1 - 1e-7).all() and (x[:, 4] <= 0.1).all() and (x[:, 5] >= 0.5).all() and (x[:, 5] <= 0.7).all()
+  env_r = SawyerPeg(num_envs=16, seed=1, reset_at_goal=True)
+  o_r = env_r.reset().cpu().numpy()
+  first_r = np.stack([e[0] for e in rev]).astype(np.float64)
+  for x, tol in ((o_r, 1e-12), (first_r, 1e-6)):                 # the reverse task starts in the hole, its goal is an initial state
+    assert (np.abs(x[:, 4:7] - [-0.27, 0.6, 0.13]) <= 0.02 + tol).all()
+    assert all((np.abs(initial_states - g).max(1) < 1e-6).any() for g in x[:, 7:])
+
+
+def test_sparse_rule_on_demo_rows():
+  import torch
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  env = SawyerPeg(num_envs=2)
+  rows = 0
+  for d in ('forward', 'reverse'):
+    z = np.load(os.path.join(DEMOS, d, 'demo_data.npz'))
+    o = torch.from_numpy(z['next_observations'].astype(np.float64)).cuda()
+    assert (env.compute_reward(o).cpu().numpy() == z['rewards'].ravel()).all()     # the reference's recorded sparse rewards, bit-exact
+    assert (env.is_successful(o).cpu().numpy() == (z['rewards'].ravel() == 1)).all()
+    rows += len(z['rewards'])
+  assert rows == 1815
+  with pytest.raises(NotImplementedError):
+    SawyerPeg(reward_type='dense')
+
+
+def place_pegs(env, heads):
+  import torch
+  env.qpos[:, 9:12] = torch.from_numpy(heads + np.array([0.1, 0.0, 0.0])).cuda()
+  env.qvel[:, 9:] = 0
+
+
+def test_grasp_and_lift_match_the_cpu_statement():
+  """forward demonstration 4 (grasp, lift, carry, insert) from its recorded start: HIP env vs the C restatement of the same
+  algorithm, resynchronised every step so that each env step is an independent comparison through plate / peg / table /
+  hole-block contacts; and the outcome of the open-loop replay itself."""
+  import torch
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  from oracle import physics_c
+  obs0, acts, nobs, rew = episodes('forward')[4]
+  T = len(acts)
+  env = SawyerPeg(num_envs=3)
+  env.reset()
+  place_pegs(env, np.tile(obs0[4:7].astype(np.float64), (3, 1)))
+  cm = physics_c.CModel('sawyer_peg')
+  cfg = physics_c.peg_cfg(att_names=cm.att_names)
+  q, v, mp = env.qpos[:1].cpu().numpy().copy(), env.qvel[:1].cpu().numpy().copy(), env.mocap_pos[:1].cpu().numpy().copy()
+  goal, st = env.goal_t[:1].cpu().numpy().copy(), np.zeros(1, np.int32)
+  lifted, ncon_steps = 0.0, 0
+  for t in range(T):
+    ob, r_ref, _, ok_ref = cm.sawyer_rollout(cfg, q, v, mp, goal, st, acts[t][None, None, :])
+    o, r, done, info = env.step(torch.from_numpy(np.tile(acts[t], (3, 1))).cuda())
+    np.testing.assert_allclose(o[0].cpu().numpy(), ob[0, 0], rtol=0, atol=1e-6, err_msg=f'step {t}')
+    np.testing.assert_allclose(env.qpos[0].cpu().numpy(), q[0], rtol=0, atol=1e-6, err_msg=f'step {t}')
+    assert float(r[0]) == float(r_ref[0, 0]) and bool(info['success'][0]) == bool(ok_ref[0, 0])
+    ncon_steps += int(cm.run(q, v, mp, [1.0, 0, 1, 0], [0.0, 0.0], integrate=False)['ncon'][0] > 2)
+    lifted = max(lifted, ob[0, 0, 6])
+    env.qpos[:] = torch.from_numpy(q).cuda(); env.qvel[:] = torch.from_numpy(v).cuda(); env.mocap_pos[:] = torch.from_numpy(mp).cuda()
+  assert ncon_steps >= 15                              # the plates held the peg for a good part of the episode
+  assert lifted > 0.12 and abs(lifted - nobs[:, 6].max()) < 0.02      # lifted as high as MuJoCo's recording (13.6 cm)
+  assert bool(info['success'][0]) and rew[-1] == 1.0   # ... and inserted: the open-loop replay ends in the hole, like the demonstration
+  assert bool((env.qpos[0] == env.qpos[1]).all())      # identical envs in one wavefront stay identical
+
+
+def test_forward_demos_open_loop_loose():
+  """the 10 forward demonstrations (MuJoCo, feedback policy) replayed OPEN LOOP in this build's stepper (sphere-chain
+  peg, pyramidal friction, 12-contact cap).  Only loose agreement is asserted; the bounds are what this round measures plus
+  margin (DESIGN.md quotes the measured values): the hand follows the recorded path (RMS < 3 cm), at least half of the episodes
+  lift the peg above 10 cm, at least 3 end inserted."""
+  import torch
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  eps = episodes('forward')
+  n, T = len(eps), max(len(e[1]) for e in eps)
+  assert n == 10
+  env = SawyerPeg(num_envs=n)
+  env.reset()
+  place_pegs(env, np.stack([e[0][4:7] for e in eps]).astype(np.float64))
+  acts = np.zeros((T, n, 4), np.float32)
+  for i, e in enumerate(eps):
+    acts[:len(e[1]), i] = e[1]
+  out = env.rollout(torch.from_numpy(acts).cuda())
+  obs, suc = out['obs'].cpu().numpy(), out['success'].cpu().numpy()
+  assert np.isfinite(obs).all()
+  lifted = inserted = 0
+  for i, e in enumerate(eps):
+    L = len(e[1])
+    o, w = obs[:L, i], e[2]
+    assert np.sqrt(((o[:, :3] - w[:, :3]) ** 2).sum(1).mean()) < 0.03, i
+    assert (o[:, 6] > 0.004).all()                      # the peg is pressed into the soft table top by the plates at most ~1 cm, never through it
+    lifted += o[:, 6].max() > 0.10
+    inserted += bool(suc[L - 1, i])
+  assert lifted >= 5 and inserted >= 3, (lifted, inserted)
+
+
+def test_shards_equal_one_batch_and_both_lane_layouts_agree():
+  import torch
+  from earl_benchmark_amd import _abi
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  lib = _abi.load()
+  n, T = 10, 10
+  g = torch.Generator().manual_seed(5)
+  acts = (torch.rand(T, n, 4, generator=g) * 2 - 1).cuda()
+  acts[:, :, 2] = -0.9                                           # down onto the table / the pegs
+  runs = {}
+  try:
+    for lanes in (16, 64):
+      _abi.check(lib.earl_debug_set_physics_lanes(lanes), 'lanes')
+      full = SawyerPeg(num_envs=n, seed=3)
+      o0 = full.reset()
+      out = full.rollout(acts)
+      runs[lanes] = (o0.clone(), out['obs'].clone(), out['reward'].clone(), full.qpos.clone())
+      if lanes == 16:
+        a, b = SawyerPeg(num_envs=6, seed=3, env_offset=0), SawyerPeg(num_envs=4, seed=3, env_offset=6)
+        oa, ob = a.reset(), b.reset()
+        assert torch.equal(torch.cat([oa, ob]), o0)
+        ra, rb = a.rollout(acts[:, :6].contiguous()), b.rollout(acts[:, 6:].contiguous())
+        assert torch.equal(torch.cat([ra['obs'], rb['obs']], 1), out['obs'])
+        assert torch.equal(torch.cat([a.qpos, b.qpos]), full.qpos)
+  finally:
+    _abi.check(lib.earl_debug_set_physics_lanes(16), 'lanes')
+  for x, y in zip(runs[16], runs[64]):
+    assert torch.equal(x, y)
+
+
+def test_loader_masked_reset_and_lifelong():
+  import earl_benchmark_amd as eb
+  import torch
+  loader = eb.EARLEnvs('sawyer_peg', reward_type='sparse', num_envs=5, eval_horizon=3)
+  train, ev = loader.get_envs()
+  o = ev.reset()
+  assert o.shape == (5, 14) and o.dtype == torch.float64
+  for t in range(3):
+    o, r, done, info = ev.step(torch.zeros(5, 4))
+  assert bool(done.all()) and int(ev.num_interventions[0]) == 1
+  assert loader.get_initial_states().shape == (15, 7) and loader.get_goal_states().shape == (1, 7)
+  np.testing.assert_allclose(o[:, 7:].cpu().numpy(), np.repeat(loader.get_goal_states(), 5, 0), atol=0)
+  u = ev.unwrapped
+  before = u.qpos.clone()
+  mask = torch.tensor([1, 0, 0, 1, 0], dtype=torch.bool).cuda()
+  ev.reset(mask=mask)
+  assert torch.equal(u.qpos[~mask], before[~mask]) and not torch.equal(u.qpos[mask], before[mask])
+  assert u.steps_since_reset.tolist() == [0, 3, 3, 0, 3]
+  life = eb.EARLEnvs('sawyer_peg', reward_type='sparse', setup_as_lifelong_learning=True, reset_train_env_at_goal=True, num_envs=4,
+                     train_horizon=6, goal_change_frequency=2).get_envs()
+  o = life.reset()
+  out = life.rollout(torch.zeros(3, 4, 4).cuda())
+  assert out['obs'].shape == (3, 4, 14)
+  with pytest.raises(NotImplementedError):
+    eb.EARLEnvs('sawyer_peg', reward_type='dense', num_envs=2)

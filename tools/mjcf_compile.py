@@ -401,7 +401,7 @@ def main():
     boxes = lambda body: [g for g in range(len(m['geom_body'])) if m['geom_body'][g] == body and m['geom_type'][g] == 4 and colliding(g)]
     peg = pm.geom_id('peg')
     red = po.reduce_model(pm, None, attach_bodies=['hand'], attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector', 'pegHead', 'pegGrasp'],
-                          collision=dict(plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], plates_accept=('peg',),
+                          collision=dict(max_contacts=12, plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], plates_accept=('peg',),
                                          chains=[dict(geom=peg, set='peg', spacing=1.0)],
                                          corner_sets=[dict(names=['peg'], set='pegcorner'), ['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']],
                                          big_boxes=[dict(geom=g, accept=('peg', 'pegcorner', 'corner')) for g in boxes(blockb)] +

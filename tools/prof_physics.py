@@ -18,14 +18,15 @@ def build():
 
 
 def rollout_counters(n, T):
-  """event counters of wave 0 over a random-action rollout of the Sawyer door env (profiling build of the whole library)"""
+  """event counters of wave 0 over a random-action rollout of the Sawyer door (or, with --peg, peg) env (profiling build of the whole library)"""
   import torch
   sys.path.insert(0, ROOT)
   from earl_benchmark_amd import _abi
   _abi.LIB_PATH = LIB
   _abi.SIGNATURES['earl_debug_read_phys_profile'] = [C.c_void_p, C.c_int]
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
-  env = SawyerDoor(num_envs=n)
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  env = (SawyerPeg if '--peg' in sys.argv else SawyerDoor)(num_envs=n)
   lib = _abi.load()
   out = (C.c_ulonglong * 32)()
   acts = torch.rand(T, n, 4, device='cuda') * 2 - 1
@@ -46,7 +47,7 @@ def main():
   if '--build' in sys.argv:
     return build()
   if '--rollout' in sys.argv:
-    return rollout_counters(1024, 300)
+    return rollout_counters(1024, 200 if '--peg' in sys.argv else 300)
   import numpy as np
   import torch
   sys.path.insert(0, ROOT)
