@@ -152,6 +152,9 @@ __device__ __forceinline__ void kbimp(const double* solref, const double* solimp
 template <int NV> struct Lim {
   static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
   static constexpr int MB = NV <= 10 ? 16 : EARL_MAXBLK;    // collision blocks
+  static constexpr int WPB = NV <= 10 ? 1 : 3;              // wavefronts per workgroup.  nv 10: 38 KB per single-wave workgroup, four per CU.  nv 15: one
+                                                            // env block is 11.7 KB; a three-wave workgroup (12 envs + the tables once = 151 KB) puts three
+                                                            // waves on a CU where single-wave workgroups (57 KB) would fit two
   static constexpr int NA = NV <= 10 ? NV : 9;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
                                                             // and free peg are separate trees (checked by the host side); the door model
                                                             // (9 + 1) is factorised densely -- the split did not pay there
@@ -167,7 +170,6 @@ struct Shared {
   double M[NV][NV];
   double tau[NV];
   double att[4][3];
-  double ct[MC][10];                 // contact records: dist, normal (3), point (3), class, sphere link, box link
   double bank_pad[8];                // sizeof(Shared<10>) would be 31 * 256 B: the four env blocks of a wave would sit on the same LDS
                                      // banks and every broadcast access would conflict 4 ways; +64 B staggers them by 16 banks
   union {
@@ -181,9 +183,12 @@ struct Shared {
       };
     } dyn;
     struct {
-      double J6[6][NV], wD[8], war[8], Hw[NV][NV], rw[NV], dl[NV], rl[NV], rhs2[NV];
+      double J6[6][NV], wD[8], war[8], dl[NV], rl[NV], rhs2[NV];
       double CJ[MC][3][NV];            // contact Jacobians: normal, tangent 1, tangent 2
-      double cw[MC][8];                // per-iteration weights of the active pyramid edges
+      union {
+        double ct[MC][10];             // contact records (C2 -> C3): dist, normal (3), point (3), class, sphere link, box link
+        double cw[MC][8];              // per-iteration weights of the active pyramid edges (K9)
+      };
       double Hc[NV][NV], rc[NV];
     } con;
   };
@@ -240,6 +245,51 @@ __device__ __forceinline__ void load_tri(double (&L)[NV * (NV + 1) / 2], const d
   }
 }
 
+// Dense factorisation for the rare timesteps in which a contact joins the two trees of a big model (gripper plates on the
+// peg): a register-resident 15 x 15 factor would need 240 VGPRs and spills the whole kernel into scratch memory.  Instead the
+// lanes share the work, lane = row, the factor overwrites the lower triangle of H in LDS (diagonal INVERTED): left-looking
+// by columns, every lane recomputes the pivot redundantly from the pivot row it has just read, so a column costs one LDS
+// round trip.  The two triangular solves then read L back from LDS, redundantly per lane (no exchange).
+template <int NV>
+__device__ __forceinline__ void chol_coop(double (&H)[NV][NV], const double (&dl)[NV], const int l, const bool isl) {
+  double r[NV];                                        // row l of H, then of L (entries j <= l)
+#pragma unroll
+  for (int j = 0; j < NV; ++j) r[j] = H[l][j];
+  if (isl) H[l][l] = H[l][l] + dl[l];
+  fence();
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    double sj = H[j][j], si = r[j] + (l == j ? dl[l] : 0.0);
+#pragma unroll
+    for (int p = 0; p < j; ++p) {
+      const double pj = H[j][p];
+      sj = fma(-pj, pj, sj);
+      si = fma(-r[p], pj, si);
+    }
+    const double inv = rsq_nr(sj);
+    r[j] = si * inv;
+    if (isl && l >= j) H[l][j] = l == j ? inv : r[j];
+    fence();
+  }
+}
+template <int NV>
+__device__ __forceinline__ void solve_lds(const double (&H)[NV][NV], double (&x)[NV]) {   // (L L') x' = x, L in LDS as chol_coop leaves it
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s = x[i];
+#pragma unroll
+    for (int p = 0; p < i; ++p) s = fma(-H[i][p], x[p], s);
+    x[i] = s * H[i][i];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; --i) {
+    double s = x[i];
+#pragma unroll
+    for (int p = i + 1; p < NV; ++p) s = fma(-H[p][i], x[p], s);
+    x[i] = s * H[i][i];
+  }
+}
+
 // block table of the collision model (bounding tests), staged once per workgroup
 template <int MB>
 struct BlkTable {
@@ -249,7 +299,7 @@ struct BlkTable {
 };
 template <int MB>
 __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collision_model* __restrict__ col) {
-  const int i = threadIdx.x;
+  const int i = threadIdx.x;                           // n_blk <= 32 < one wavefront
   // (bounds are clamped here; the Python / C front ends refuse models that exceed them)
   const int nb = col ? (col->n_blk < MB ? col->n_blk : MB) : 0;
   if (i == 0) { t.n_blk = nb; t.max_con = col ? col->max_con : 0; }
@@ -438,7 +488,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   for (int i = 0; i < NV; ++i) {
     const double* fs = s.dyn.crb.FS[i];
     double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
-    v = ((m.anc_mask[i] >> l) & 1u) ? v : 0.0;          // j = l is an ancestor of (or is) i
+    v = ((dmask >> i) & 1u) ? v : 0.0;                  // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
     if (i == l) v += m.armature[l];
     if (isl && l <= i) { s.M[i][l] = v; s.M[l][i] = v; }
   }
@@ -578,7 +628,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
         if (hit && slot < maxcon) {
           const V3 n = mulv(Rb, nl);
           const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
-          double* o = s.ct[slot];
+          double* o = s.con.ct[slot];
           o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
           o[7] = (double)cls; o[8] = (double)lk; o[9] = (double)xl;
         }
@@ -657,7 +707,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   bool coupled = false;                                // some contact of some env of the wave joins the two trees (arm / object)
   if (ncmax > 0) {
     for (int c = 0; c < ncmax; ++c) {
-      const double* rec = s.ct[c];
+      const double* rec = s.con.ct[c];
       const bool cv = c < nct;
       const V3 n = cv ? ld3(rec + 1) : V3{0, 0, 1}, p = cv ? ld3(rec + 4) : V3{0, 0, 0};
       const int ls = cv ? (int)rec[8] : -1, lb = cv ? (int)rec[9] : -1;
@@ -687,7 +737,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
         const double qd = s.qv[j];
         vn = fma(s.con.CJ[c][0][j], qd, vn); vt1 = fma(s.con.CJ[c][1][j], qd, vt1); vt2 = fma(s.con.CJ[c][2][j], qd, vt2);
       }
-      const double* rec = s.ct[c];
+      const double* rec = s.con.ct[c];
       const int cls = cv ? (int)rec[7] : 0;
       const double margin = col->cls_margin[cls];
       cmu = col->cls_mu[cls];
@@ -704,6 +754,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   fence();
   PSTAMP(6);
   // ------------------------------------------------------------------ K9: Hessian of the equality part, then the active-set Newton
+  double hw[NV], rw;                                   // this lane's column of M + J6' D J6 (+ drag) and its right-hand side: registers, all iterations
   {
     double DJ[6], g = s.tau[l];
 #pragma unroll
@@ -717,10 +768,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
 #pragma unroll
       for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
       if (i == l) h += m.drag_G[l];                     // soft velocity row of a permanent dragging contact
-      if (isl) s.con.Hw[i][l] = h;
+      hw[i] = h;
     }
     g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
-    if (isl) s.con.rw[l] = g;
+    rw = g;
   }
   coupled = __any(coupled);
   bool act = lim_inst;
@@ -744,9 +795,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     }
     fence();
     {
-      double hcol[NV], rr = s.con.rw[l];
+      double hcol[NV], rr = rw;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) hcol[i] = s.con.Hw[i][l];
+      for (int i = 0; i < NV; ++i) hcol[i] = hw[i];
       for (int c = 0; c < ncmax; ++c) {
         const double* w = s.con.cw[c];
         const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
@@ -765,10 +816,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     fence();
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
-    if (NA == NV || coupled) {                         // a contact joins the arm and the object: dense factorisation (uniform over the wave)
+    if constexpr (NA == NV) {                          // small model: dense, in registers
       load_tri<NV, NV>(L, s.con.Hc, [&](int i) { return s.con.dl[i]; });
       chol_regs<NV, NV>(L);
       solve_regs<NV, NV>(L, a);
+    } else if (coupled) {                              // a contact joins the arm and the object (uniform over the wave): shared dense factorisation in LDS
+      chol_coop<NV>(s.con.Hc, s.con.dl, l, isl);
+      solve_lds<NV>(s.con.Hc, a);
     } else {
       load_tri<NV, NA>(L, s.con.Hc, [&](int i) { return s.con.dl[i]; });
       chol_regs<NV, NA>(L);
@@ -887,8 +941,8 @@ __device__ __forceinline__ void stage_model(earl_link_model& dst, const earl_lin
   static_assert(sizeof(earl_link_model) % 8 == 0, "copied as 8-byte words");
   const unsigned long long* g = reinterpret_cast<const unsigned long long*>(src);
   unsigned long long* d = reinterpret_cast<unsigned long long*>(&dst);
-  for (int i = threadIdx.x; i < (int)(sizeof(earl_link_model) / 8); i += 64) d[i] = g[i];
-  fence();
+  for (int i = threadIdx.x; i < (int)(sizeof(earl_link_model) / 8); i += blockDim.x) d[i] = g[i];
+  __syncthreads();                                     // the only workgroup barrier: afterwards every wave works on its own LDS blocks
 }
 
 // state rows <-> LDS.  qpos rows are [nq]: one entry per dof, except that the free body's orientation quaternion sits at
@@ -929,18 +983,18 @@ struct PArgs {
 };
 
 template <int NV, int LPE, bool INTEGRATE>
-__global__ __launch_bounds__(64) void physics_kernel(const PArgs a) {
-  constexpr int EPW = 64 / LPE;
+__global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs a) {
+  constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
   __shared__ earl_link_model m;
   __shared__ BlkTable<Lim<NV>::MB> bt;
-  __shared__ Shared<NV> sh[EPW];
+  __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
   stage_model(m, a.m);
-  const int lane = threadIdx.x, sub = lane % LPE, grp = lane / LPE;
-  const int env_raw = blockIdx.x * EPW + grp;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE;
+  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
   const bool live = env_raw < a.n;
   const int env = live ? env_raw : a.n - 1;            // idle groups shadow the last env and store nothing
-  Shared<NV>& s = sh[grp];
+  Shared<NV>& s = sh[wave * EPW + grp];
   load_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
   fence();
   const V3 mpos = ld3(a.mocap_pos + (size_t)env * 3);
@@ -1032,20 +1086,20 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model
 }
 
 template <int NV, int LPE>
-__global__ __launch_bounds__(64) void sawyer_rollout_kernel(const SawyerArgs a) {
+__global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_rollout_kernel(const SawyerArgs a) {
   static_assert(LPE >= 14, "the observation is written by 14 lanes");
-  constexpr int EPW = 64 / LPE;
+  constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
   __shared__ earl_link_model m;
   __shared__ BlkTable<Lim<NV>::MB> bt;
-  __shared__ Shared<NV> sh[EPW];
+  __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
   stage_model(m, a.m);
   const earl_sawyer_cfg& cfg = a.cfg;
-  const int lane = threadIdx.x, sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-  const int env_raw = blockIdx.x * EPW + grp;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
+  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
   const bool live = env_raw < n;
   const int env = live ? env_raw : n - 1;
-  Shared<NV>& s = sh[grp];
+  Shared<NV>& s = sh[wave * EPW + grp];
   load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   fence();
   V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
@@ -1075,18 +1129,18 @@ __global__ __launch_bounds__(64) void sawyer_rollout_kernel(const SawyerArgs a) 
 
 // reset (masked) / observe: both end with the kinematics of the current state and the observation
 template <int NV, int LPE>
-__global__ __launch_bounds__(64) void sawyer_reset_kernel(const SawyerArgs a) {
-  constexpr int EPW = 64 / LPE;
+__global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const SawyerArgs a) {
+  constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
   __shared__ earl_link_model m;
   __shared__ BlkTable<Lim<NV>::MB> bt;
-  __shared__ Shared<NV> sh[EPW];
+  __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
   stage_model(m, a.m);
   const earl_sawyer_cfg& cfg = a.cfg;
-  const int lane = threadIdx.x, sub = lane % LPE, grp = lane / LPE;
-  const int env_raw = blockIdx.x * EPW + grp;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE;
+  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
   const int env = env_raw < cfg.n ? env_raw : cfg.n - 1;
-  Shared<NV>& s = sh[grp];
+  Shared<NV>& s = sh[wave * EPW + grp];
   const bool resetting = !a.observe_only && env_raw < cfg.n && (!a.mask || a.mask[env]);
   const bool live = env_raw < cfg.n && (a.observe_only || resetting);
   V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
@@ -1172,10 +1226,14 @@ int launched(const char* what) {
 
 int g_lpe = 16;   // lanes per env (earl_debug_set_physics_lanes): 16 = four envs per wavefront, 64 = one wavefront per env
 
+// launch geometry: Lim<NV>::WPB wavefronts per workgroup, 64 / LPE envs per wavefront
+template <int NV, int LPE> int grid_for(int n) { constexpr int epb = (64 / LPE) * Lim<NV>::WPB; return (n + epb - 1) / epb; }
+template <int NV> constexpr int block_for() { return 64 * Lim<NV>::WPB; }
+
 template <int NV, bool INTEGRATE>
 void launch_physics(const PArgs& a, hipStream_t st) {
-  if (g_lpe == 64) physics_kernel<NV, 64, INTEGRATE><<<a.n, 64, 0, st>>>(a);
-  else physics_kernel<NV, 16, INTEGRATE><<<(a.n + 3) / 4, 64, 0, st>>>(a);
+  if (g_lpe == 64) physics_kernel<NV, 64, INTEGRATE><<<grid_for<NV, 64>(a.n), block_for<NV>(), 0, st>>>(a);
+  else physics_kernel<NV, 16, INTEGRATE><<<grid_for<NV, 16>(a.n), block_for<NV>(), 0, st>>>(a);
 }
 
 }  // namespace
@@ -1215,11 +1273,11 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
   SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
   if (cfg->obj_kind == 1 && cfg->reward_type != 0) return EARL_ERR_ARG;   // the peg's dense reward (metaworld reward_utils, upstream) is not built
   if (nv == 10) {
-    if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
-    else sawyer_rollout_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+    if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<grid_for<10, 64>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
+    else sawyer_rollout_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
   } else if (nv == 15) {
-    if (g_lpe == 64) sawyer_rollout_kernel<15, 64><<<cfg->n, 64, 0, (hipStream_t)stream>>>(a);
-    else sawyer_rollout_kernel<15, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+    if (g_lpe == 64) sawyer_rollout_kernel<15, 64><<<grid_for<15, 64>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
+    else sawyer_rollout_kernel<15, 16><<<grid_for<15, 16>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
   } else return EARL_ERR_ARG;
   return launched("sawyer_rollout");
 }
@@ -1233,8 +1291,8 @@ int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawye
   if (cfg->obj_kind == 1 && cfg->obj_dof + 6 > nv) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
   SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, reset_qpos, reset_qvel, mask, obs, 0};
-  if (nv == 10) sawyer_reset_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
-  else if (nv == 15) sawyer_reset_kernel<15, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  if (nv == 10) sawyer_reset_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
+  else if (nv == 15) sawyer_reset_kernel<15, 16><<<grid_for<15, 16>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
   else return EARL_ERR_ARG;
   return launched("sawyer_reset");
 }
@@ -1245,8 +1303,8 @@ int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_saw
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
   SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, obs, 1};
-  if (nv == 10) sawyer_reset_kernel<10, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
-  else if (nv == 15) sawyer_reset_kernel<15, 16><<<(cfg->n + 3) / 4, 64, 0, (hipStream_t)stream>>>(a);
+  if (nv == 10) sawyer_reset_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
+  else if (nv == 15) sawyer_reset_kernel<15, 16><<<grid_for<15, 16>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
   else return EARL_ERR_ARG;
   return launched("sawyer_observe");
 }
