@@ -85,6 +85,10 @@ __device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b
 __device__ __forceinline__ V3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
 __device__ __forceinline__ Q4 ldq(const double* p) { return {p[0], p[1], p[2], p[3]}; }
 __device__ __forceinline__ double pick3(const V3& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
+// selects of whole vectors, component by component: a `cond ? V3 : V3` on the structs is lowered by hipcc to a select of two
+// stack ADDRESSES and a load through scratch memory (store both, wait, load one) -- seen in the ISA of every phase that had one
+__device__ __forceinline__ V3 selv(const bool c, const V3& a, const V3& b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+__device__ __forceinline__ Q4 selq(const bool c, const Q4& a, const Q4& b) { return {c ? a.w : b.w, c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 
 // reciprocal / reciprocal square root: hardware seed + Newton steps (about 1 ulp; not correctly rounded -- fine here)
 __device__ __forceinline__ double rcp_nr(double x) {
@@ -341,7 +345,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     double Rt[3][3], Rl[3][3];
     qmat(tq, Rt);
     // free body: link type 2 applies the orientation quaternion, the type-3 links behind it are rigid (sn = 0, cs = 1)
-    const Q4 jq = jt == 2 ? ldq(s.bq) : Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z};
+    const Q4 jq = selq(jt == 2, ldq(s.bq), Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z});
     Q = qmul(tq, jq);
     qmat(Q, Rl);
     // hinge: rotate about the anchor; slide: translate along the axis (Rl == Rt then)
@@ -366,7 +370,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       qmat(qa, Ra);
       const V3 xn = add(xa, mulv(Ra, P));
       const Q4 qn = qmul(qa, Q);
-      if (a >= 0) { P = xn; Q = qn; }
+      P = selv(a >= 0, xn, P); Q = selq(a >= 0, qn, Q);
       buf ^= 1;
       if (isl) {
         double* oq = buf ? s.k2.Xq1[l] : s.Xq[l];
@@ -389,13 +393,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       double R[3][3];
       qmat(ldq(s.Xq[bl < 0 ? 0 : bl]), R);
       const V3 w = add(ld3(s.Xp[bl < 0 ? 0 : bl]), mulv(R, cs));
-      cs = bl < 0 ? cs : w;
+      cs = selv(bl < 0, cs, w);
       const Q4 ql = ldq(s.Xq[xl < 0 ? 0 : xl]);
       qmat(ql, R);
       const V3 w2 = add(ld3(s.Xp[xl < 0 ? 0 : xl]), mulv(R, cb_));
       const Q4 q2 = qmul(ql, qb);
-      cb_ = xl < 0 ? cb_ : w2;
-      qb = xl < 0 ? qb : q2;
+      cb_ = selv(xl < 0, cb_, w2);
+      qb = selq(xl < 0, qb, q2);
     }
     // distance from the set's bounding-sphere centre to the box (in the box frame) against the set radius + margin
     double Rb[3][3];
@@ -432,8 +436,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     const V3 aw = mulv(R, ld3(m.jaxis[l]));
     const V3 anchor = add(P, mulv(R, ld3(m.jpos[l])));
     const bool hinge = m.jtype[l] != 1;               // rotation axes of a free body: body axes after the rotation, like a hinge's
-    Sw = hinge ? aw : V3{0, 0, 0};
-    Sv = hinge ? cross(anchor, aw) : aw;
+    Sw = selv(hinge, aw, V3{0, 0, 0});
+    Sv = selv(hinge, cross(anchor, aw), aw);
     const double mass = m.mass[l];
     const V3 c = add(P, mulv(R, ld3(m.com[l])));
     const double* in = m.inertia[l];
@@ -598,7 +602,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
           double R[3][3];
           qmat(ldq(s.Xq[lk < 0 ? 0 : lk]), R);
           const V3 w = add(ld3(s.Xp[lk < 0 ? 0 : lk]), mulv(R, c));
-          c = lk < 0 ? c : w;
+          c = selv(lk < 0, c, w);
         }
         const V3 x = mulvT(Rb, vsub(c, pb));
         V3 q{fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z)};
@@ -616,8 +620,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
           const V3 ni{ax == 0 ? sg : 0.0, ax == 1 ? sg : 0.0, ax == 2 ? sg : 0.0};
           const V3 qi{ax == 0 ? sg * ha : x.x, ax == 1 ? sg * ha : x.y, ax == 2 ? sg * ha : x.z};
           dist = outside ? d2 * inv - r : -(ha - fabs(xa)) - r;
-          nl = outside ? scl(d, inv) : ni;
-          q = outside ? q : qi;
+          nl = selv(outside, scl(d, inv), ni);
+          q = selv(outside, q, qi);
         }
         const bool hit = valid && dist < margin;
         const unsigned long long bal = __ballot(hit);
@@ -709,7 +713,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     for (int c = 0; c < ncmax; ++c) {
       const double* rec = s.con.ct[c];
       const bool cv = c < nct;
-      const V3 n = cv ? ld3(rec + 1) : V3{0, 0, 1}, p = cv ? ld3(rec + 4) : V3{0, 0, 0};
+      const V3 n = selv(cv, ld3(rec + 1), V3{0, 0, 1}), p = selv(cv, ld3(rec + 4), V3{0, 0, 0});
       const int ls = cv ? (int)rec[8] : -1, lb = cv ? (int)rec[9] : -1;
       coupled = coupled || (ls >= 0 && lb >= 0 && ((ls < NA) != (lb < NA)));
       // tangents: n x (the coordinate axis least aligned with n), normalised, then n x t1
