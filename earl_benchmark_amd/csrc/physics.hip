@@ -300,6 +300,7 @@ struct BlkTable {
   int n_blk, max_con;
   int begin[MB], end[MB], box[MB], link[MB], box_link[MB];
   double center[MB][3], reach[MB], box_pos[MB][3], box_quat[MB][4], box_half[MB][3];
+  double cls_mu[EARL_MAXCLS], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5];   // contact classes
 };
 template <int MB>
 __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collision_model* __restrict__ col) {
@@ -307,6 +308,12 @@ __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collisi
   // (bounds are clamped here; the Python / C front ends refuse models that exceed them)
   const int nb = col ? (col->n_blk < MB ? col->n_blk : MB) : 0;
   if (i == 0) { t.n_blk = nb; t.max_con = col ? col->max_con : 0; }
+  if (col && i < EARL_MAXCLS) {
+    t.cls_mu[i] = col->cls_mu[i]; t.cls_margin[i] = col->cls_margin[i]; t.cls_invw[i] = col->cls_invw[i];
+    t.cls_solref[i][0] = col->cls_solref[i][0]; t.cls_solref[i][1] = col->cls_solref[i][1];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t.cls_solimp[i][k] = col->cls_solimp[i][k];
+  }
   if (i < nb) {
     const int b = col->blk_box[i];
     t.begin[i] = col->blk_begin[i]; t.end[i] = col->blk_end[i]; t.box[i] = b; t.link[i] = col->blk_link[i];
@@ -641,6 +648,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     }
     fence();
   }
+  PSTAMP(2);
   // most over the wave (uniform loop bound for the contact phases)
   PCOUNT(20, 1); PCOUNT(21, nearw ? 1 : 0); PCOUNT(22, __popc(nearw));
   int ncmax = 0;
@@ -705,6 +713,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     lim_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
     lim_aref = -bb * (lim_side * s.qv[l]) - kk * dd * res;
   }
+  PSTAMP(7);
   // ------------------------------------------------------------------ C3: contact rows (reference: LinkModel.contact_rows)
   double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};       // lane c (< nct) owns contact c: edge weights and reference accelerations
   unsigned int cact = 0;                               // active pyramid edges of that contact (bits 0..3)
@@ -743,11 +752,11 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       }
       const double* rec = s.con.ct[c];
       const int cls = cv ? (int)rec[7] : 0;
-      const double margin = col->cls_margin[cls];
-      cmu = col->cls_mu[cls];
+      const double margin = bt.cls_margin[cls];
+      cmu = bt.cls_mu[cls];
       double kk, bb, dd;
-      kbimp(col->cls_solref[cls], col->cls_solimp[cls], rec[0] - margin, dt, kk, bb, dd);
-      const double R0 = fmax((1 - dd) * col->cls_invw[cls] * rcp_nr(dd), 1e-15);
+      kbimp(bt.cls_solref[cls], bt.cls_solimp[cls], rec[0] - margin, dt, kk, bb, dd);
+      const double R0 = fmax((1 - dd) * bt.cls_invw[cls] * rcp_nr(dd), 1e-15);
       cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
       const double basea = -kk * dd * (rec[0] - margin);
       car[0] = -bb * (vn + cmu * vt1) + basea; car[1] = -bb * (vn - cmu * vt1) + basea;
@@ -777,6 +786,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
     rw = g;
   }
+  PSTAMP(9);
   coupled = __any(coupled);
   bool act = lim_inst;
   double a[NV];

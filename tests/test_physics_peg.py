@@ -1,0 +1,165 @@
+"""Free-joint support of the articulated-body reference (oracle/physics_oracle.py, oracle/physics_oracle.c) and the compiled
+Sawyer-peg model tables (peg half).
+
+Dynamics vs MuJoCo: UNPINNED (no simulator here).  Checked here by first principles -- the free body obeys Euler's rigid-body
+equations exactly, momenta are conserved in free flight -- by a third implementation (C vs numpy), and against what the
+reference's demonstrations record: the reset observation, and the ten forward episodes replayed open loop (grasp, lift,
+insert)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from oracle import physics_oracle as po
+
+MODEL = os.path.join(REPO, 'earl_benchmark_amd', 'models', 'sawyer_peg.npz')
+LINKS = os.path.join(REPO, 'earl_benchmark_amd', 'models', 'sawyer_peg_links.npz')
+DEMOS = os.path.join(REPO, 'earl_benchmark_amd', 'demonstrations', 'sawyer_peg')
+MP, MQ = np.array([0.0, 0.6, 0.2]), np.array([1.0, 0, 1, 0])
+
+
+def tables():
+  with np.load(LINKS) as z:
+    return {k: z[k] for k in z.files}
+
+
+def episodes(direction):
+  z = np.load(os.path.join(DEMOS, direction, 'demo_data.npz'))
+  ends = np.nonzero(z['terminals'].ravel())[0] + 1
+  return [(z['observations'][s], z['actions'][s:e], z['next_observations'][s:e], z['rewards'][s:e].ravel())
+          for s, e in zip([0] + list(ends[:-1]), ends)]
+
+
+def test_model_facts():
+  """sawyer_peg_insertion_side.xml: 7 arm hinges + 2 claw slides + the peg's free joint (reference: metaworld_assets/sawyer_xyz/
+  sawyer_peg_insertion_side.xml:10-17: mass 0.1, diaginertia 1e5, damping 0.005, sites pegHead / pegGrasp)"""
+  m = po.Model(MODEL)
+  assert (m.nv, m.nb) == (15, 36) and abs(m.dt - 0.0025) < 1e-15
+  assert list(m.jnt_type) == [0] * 7 + [1] * 5 + [2, 3, 3]
+  peg = m.body_id('peg')
+  assert m.body_free[peg] == 1 and m.body_mass[peg] == 0.1 and (m.body_inertia[peg] == 1e5).all()
+  np.testing.assert_allclose(m.body_qpos0[peg], [0, 0.6, 0.03, 1, 0, 0, 0])
+  assert (m.jnt_damping[9:] == 0.005).all() and not m.jnt_limited[9:].any()
+  d = tables()
+  lm = po.LinkModel(d)
+  assert (lm.nv, int(lm.ball_dof), len(lm.qpos0), lm.max_contacts) == (15, 12, 16, 12)
+  assert list(lm.parent) == [-1, 0, 1, 2, 3, 4, 5, 6, 6, -1, 9, 10, 11, 12, 13]         # two trees: arm (+ claws), peg
+  assert (lm.mass[9:14] == 0).all() and lm.mass[14] == 0.1                                # the last link of the chain carries the body
+  pos, quat, _ = lm.kinematics(lm.qpos0)
+  names = [str(x) for x in lm.att_names]
+  np.testing.assert_allclose(lm.attachment(pos, quat, names.index('pegHead'))[0], [-0.1, 0.6, 0.03], atol=1e-15)
+  np.testing.assert_allclose(lm.attachment(pos, quat, names.index('pegGrasp'))[0], [0.03, 0.6, 0.04], atol=1e-15)
+  # the observation's object slot is pegHead = peg - (0.1, 0, 0): the 15 recorded initial states put the peg inside the reset box
+  from oracle.sawyer_oracle import PEG_INITIAL_STATES
+  peg_xy = PEG_INITIAL_STATES[:, 4:6] + [0.1, 0.0]
+  assert (peg_xy >= [0.0, 0.5]).all() and (peg_xy <= [0.2, 0.7]).all() and (PEG_INITIAL_STATES[:, 6] == 0.02).all()
+  assert len(d['col_pair']) == 327 and len(d['col_blk_begin']) == 25 and len(d['col_sph_link']) == 39 and len(d['col_box_link']) == 10
+
+
+def test_free_body_obeys_eulers_equations_and_conserves_momentum():
+  """a free body with a non-spherical inertia and an offset centre of mass, no gravity, no damping: qacc of the six free-joint
+  dofs against the closed form (body-frame Euler equations; the frame origin's acceleration from the COM being unaccelerated),
+  then linear / angular momentum and energy over 400 timesteps of tumbling"""
+  d = tables()
+  d['inertia'] = d['inertia'].copy(); d['inertia'][14] = [0.02, 0.05, 0.03, 0.004, -0.003, 0.002]
+  d['com'] = d['com'].copy(); d['com'][14] = [0.03, -0.02, 0.05]
+  d['gravity'] = np.zeros(3); d['jnt_damping'] = d['jnt_damping'].copy(); d['jnt_damping'][9:] = 0
+  lm = po.LinkModel(d); lm.contacts = False
+  rng = np.random.default_rng(0)
+  q = lm.qpos0.copy(); b = rng.normal(size=4); q[12:16] = b / np.linalg.norm(b); q[9:12] = [0.1, 0.5, 0.4]
+  v = np.zeros(15); v[9:15] = rng.normal(size=6)
+  a = lm.forward(q, v, np.zeros(2), MP, MQ)['qacc'][9:]
+  R, Ic, c, wb = po.quat_mat(q[12:16]), po.sym6(d['inertia'][14]), d['com'][14], v[12:15]
+  dwb = np.linalg.solve(Ic, -np.cross(wb, Ic @ wb))
+  ww, alpha, r = R @ wb, R @ dwb, R @ c
+  np.testing.assert_allclose(a, np.concatenate([-(np.cross(alpha, r) + np.cross(ww, np.cross(ww, r))), dwb]), atol=1e-13)
+
+  def momenta(q, v):
+    R = po.quat_mat(q[12:16]); w = R @ v[12:15]; r = R @ c; vc = v[9:12] + np.cross(w, r)
+    return 0.1 * vc, R @ Ic @ R.T @ w + np.cross(q[9:12] + r, 0.1 * vc), 0.05 * vc @ vc + 0.5 * w @ (R @ Ic @ R.T @ w)
+  p0 = momenta(q, v)
+  for _ in range(400):
+    q, v, _ = lm.step(q, v, np.zeros(2), MP, MQ)
+  p1 = momenta(q, v)
+  np.testing.assert_allclose(p1[0], p0[0], atol=1e-4); np.testing.assert_allclose(p1[1], p0[1], atol=2e-4)     # first-order integrator
+  assert abs(p1[2] - p0[2]) < 1e-3 * p0[2] and abs(np.linalg.norm(q[12:16]) - 1) < 1e-14
+
+
+def test_c_restatement_equals_the_numpy_statement_on_the_peg_model():
+  from oracle import physics_c
+  lm = po.LinkModel(LINKS)
+  cm = physics_c.CModel('sawyer_peg')
+  rng = np.random.default_rng(1)
+  n = 16
+  qpos = np.tile(lm.qpos0, (n, 1))
+  qpos[:, :7] += rng.normal(size=(n, 7)) * 0.1; qpos[:, 7] = 0.02; qpos[:, 8] = -0.015
+  b = rng.normal(size=(n, 4)); qpos[:, 12:16] = b / np.linalg.norm(b, axis=1, keepdims=True) * 1.05          # normalised inside
+  qpos[:, 9:12] = rng.uniform([-0.35, 0.4, 0.0], [0.3, 0.9, 0.4], size=(n, 3))
+  qpos[::2, 11] = 0.014; qpos[::2, 12:16] = [1, 0, 0, 0]                                                    # half of them in the table top
+  qvel = rng.normal(size=(n, 15)) * 0.5
+  ctrl = rng.uniform(-1.3, 1.3, size=(n, 2))
+  got = cm.run(qpos, qvel, MP, MQ, ctrl, integrate=False)
+  ncon = 0
+  for i in range(n):
+    ref = lm.forward(qpos[i], qvel[i], ctrl[i], MP, MQ)
+    np.testing.assert_allclose(got['qacc'][i], ref['qacc'], rtol=1e-9, atol=1e-9 * np.abs(ref['qacc']).max())
+    assert got['ncon'][i] == len(ref['contacts'])
+    ncon += len(ref['contacts'])
+  assert ncon > 8
+  q, v = lm.qpos0.copy(), np.zeros(15)
+  q[9:12] = [0.1, 0.6, 0.02]
+  r = cm.run(q, v, MP, MQ, [-1.0, 1.0], nsub=100)
+  for _ in range(100):
+    q, v, out = lm.step(q, v, np.array([-1.0, 1.0]), MP, MQ)
+  np.testing.assert_allclose(r['qpos'][0], q, atol=1e-12); np.testing.assert_allclose(r['qvel'][0], v, atol=1e-11)
+  assert abs(q[11] - 0.015) < 1e-4 and r['ncon'][0] >= 2                                 # the dropped peg rests on the table top
+
+
+def test_block_cull_never_drops_a_contact_on_the_peg_model():
+  from oracle.sawyer_oracle import SawyerPegOracle
+  lm = po.LinkModel(LINKS)
+  env = SawyerPegOracle(lm, seed=2)
+  env._settled = (lm.qpos0.copy(), np.zeros(15))          # skip the 250-timestep settle: any state will do here
+  env.reset()
+  _, acts, _, _ = episodes('forward')[5]
+  env.qpos[9:12] = episodes('forward')[5][0][4:7] + np.array([0.1, 0, 0])
+  found = 0
+  for t in range(30):
+    env.step(acts[t])
+    pos, quat, _ = lm.kinematics(env.qpos)
+    lm.block_cull = True; c1 = [c['pair'] for c in lm.collide(pos, quat)]
+    lm.block_cull = False; c2 = [c['pair'] for c in lm.collide(pos, quat)]
+    lm.block_cull = True
+    assert c1 == c2
+    found += len(c1)
+  assert found > 30
+
+
+def test_reset_pose_and_forward_demonstrations_open_loop():
+  """_reset_hand from qpos0 lands within 8 mm of the hand pose every recorded episode starts with (a 250-timestep transient);
+  the ten forward demonstrations (MuJoCo + a feedback policy) replayed OPEN LOOP through the C restatement: the hand follows
+  the recorded path, most episodes grasp and lift the peg to the recorded height, several end inserted in the hole.
+  Measured this round: 6 / 10 lifted, 4 / 10 inserted, hand RMS 1.0-2.4 cm."""
+  from oracle import physics_c
+  cm = physics_c.CModel('sawyer_peg')
+  lm = po.LinkModel(LINKS)
+  r = cm.run(lm.qpos0, np.zeros(15), MP, MQ, [-1.0, 1.0], nsub=250)            # sim.reset() + _reset_hand [UPSTREAM]
+  q0, v0 = r['qpos'][0], r['qvel'][0]
+  names = cm.att_names
+  eps = episodes('forward')
+  np.testing.assert_allclose(r['att'][0, names.index('hand')], eps[0][0][:3], atol=8e-3)
+  grip = np.linalg.norm(r['att'][0, names.index('rightEndEffector')] - r['att'][0, names.index('leftEndEffector')]) / 0.1
+  assert grip >= 1.0 and all(e[0][3] == 1.0 for e in eps)                      # the observation clips the opening to 1.0
+  cfg = physics_c.peg_cfg(att_names=names)
+  lifted = inserted = 0
+  for obs0, acts, nxt, rew in eps:
+    q, v = q0[None].copy(), v0[None].copy()
+    q[0, 9:12] = obs0[4:7] + np.array([0.1, 0, 0]); v[0, 9:] = 0
+    ob, _, _, suc = cm.sawyer_rollout(cfg, q, v, MP[None].copy(), obs0[7:][None].astype(np.float64), np.zeros(1, np.int32), acts[:, None, :])
+    ob = ob[:, 0]
+    assert np.sqrt(((ob[:, :3] - nxt[:, :3]) ** 2).sum(1).mean()) < 0.03
+    lifted += abs(ob[:, 6].max() - nxt[:, 6].max()) < 0.02
+    inserted += bool(suc[-1, 0])
+    assert rew[-1] == 1.0
+  assert lifted >= 5 and inserted >= 3, (lifted, inserted)

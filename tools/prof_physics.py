@@ -8,8 +8,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, 'tools', 'ubench', 'libearl_physprof.so')
 FLAGS = '--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -DEARL_PHYS_PROF'
-NAMES = ['K1-2 joint + world transforms', 'K3 subspace + inertia', '-', 'K4 composite inertia', 'K5 mass matrix', 'K6-7 RNE + tau', 'C0-2 collision + K8 rows + C3', '-',
-         'K9 Hessian + active-set Newton', '-', '-', 'K10 Euler']
+NAMES = ['K1-2 joint + world transforms + C0 bounding tests', 'K3 subspace + inertia', 'C1-2 pair tests', 'K4 composite inertia', 'K5 mass matrix', 'K6-7 RNE + tau',
+         'C3 contact rows', 'K8 weld / limit rows', 'K9b active-set Newton', 'K9a equality Hessian', '-', 'K10 Euler']
 
 
 def build():
