@@ -156,9 +156,16 @@ __device__ __forceinline__ void kbimp(const double* solref, const double* solimp
 template <int NV> struct Lim {
   static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
   static constexpr int MB = NV <= 10 ? 16 : EARL_MAXBLK;    // collision blocks
-  static constexpr int WPB = NV <= 10 ? 1 : 3;              // wavefronts per workgroup.  nv 10: 38 KB per single-wave workgroup, four per CU.  nv 15: one
+#ifndef EARL_DOOR_WPB
+#define EARL_DOOR_WPB 1
+#endif
+  static constexpr int WPB = NV <= 10 ? EARL_DOOR_WPB : 3;              // wavefronts per workgroup.  nv 10: 38 KB per single-wave workgroup, four per CU.  nv 15: one
                                                             // env block is 11.7 KB; a three-wave workgroup (12 envs + the tables once = 151 KB) puts three
                                                             // waves on a CU where single-wave workgroups (57 KB) would fit two
+#ifndef EARL_DOOR_COOP
+#define EARL_DOOR_COOP 0
+#endif
+  static constexpr bool COOP = NV <= 10 && EARL_DOOR_COOP;  // small model: every factorisation shared in LDS instead of per lane in registers (experiment)
   static constexpr int NA = NV <= 10 ? NV : 9;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
                                                             // and free peg are separate trees (checked by the host side); the door model
                                                             // (9 + 1) is factorised densely -- the split did not pay there
@@ -830,7 +837,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     fence();
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
-    if constexpr (NA == NV) {                          // small model: dense, in registers
+    if constexpr (Lim<NV>::COOP) {
+      chol_coop<NV>(s.con.Hc, s.con.dl, l, isl);
+      solve_lds<NV>(s.con.Hc, a);
+    } else if constexpr (NA == NV) {                   // small model: dense, in registers
       load_tri<NV, NV>(L, s.con.Hc, [&](int i) { return s.con.dl[i]; });
       chol_regs<NV, NV>(L);
       solve_regs<NV, NV>(L, a);
@@ -897,9 +907,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     fence();
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rhs2[i];
-    load_tri<NV, NA>(L, s.M, [&](int i) { return dt * m.damping[i]; });       // the mass matrix is block diagonal: two trees
-    chol_regs<NV, NA>(L);
-    solve_regs<NV, NA>(L, a);
+    if constexpr (Lim<NV>::COOP) {                     // M is rebuilt next timestep: factorise it in place
+      if (isl) s.con.dl[l] = dt * m.damping[l];
+      fence();
+      chol_coop<NV>(s.M, s.con.dl, l, isl);
+      solve_lds<NV>(s.M, a);
+    } else {
+      load_tri<NV, NA>(L, s.M, [&](int i) { return dt * m.damping[i]; });     // the mass matrix is block diagonal: two trees
+      chol_regs<NV, NA>(L);
+      solve_regs<NV, NA>(L, a);
+    }
     double al = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
@@ -1099,8 +1116,11 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model
   fence();
 }
 
+#ifndef EARL_WAVES_PER_EU
+#define EARL_WAVES_PER_EU 1
+#endif
 template <int NV, int LPE>
-__global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_rollout_kernel(const SawyerArgs a) {
+__global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_rollout_kernel(const SawyerArgs a) {
   static_assert(LPE >= 14, "the observation is written by 14 lanes");
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
   __shared__ earl_link_model m;
@@ -1119,6 +1139,8 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_rollout_kernel(const
   V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
   const Q4 mq = qnormalize(ldq(cfg.mocap_quat));
   int steps = a.st.steps_since_reset ? a.st.steps_since_reset[env] : 0;
+  const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
+  int sgc = gcf > 0 ? a.st.steps_since_goal_change[env] : 0;
   const float scale = (float)cfg.action_scale;
   for (int t = 0; t < a.T; ++t) {
     const float4 act = *reinterpret_cast<const float4*>(a.action + ((size_t)t * n + env) * 4);
@@ -1134,11 +1156,28 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_rollout_kernel(const
                     a.out.success ? a.out.success + row : nullptr);
     ++steps;
     if (sub == 0 && live && a.out.done) a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
+    if (gcf > 0 && ++sgc >= gcf) {
+      // LifelongWrapper.step (lifelong_wrapper.py:36-42): reset_goal() -> get_next_goal(), then the observation is re-read with the new
+      // goal (same simulator state: only the goal block changes); the reward above used the old goal
+      sgc = 0;
+      if (cfg.n_goal_rows > 0 && cfg.goal_table && sub >= 7 && sub < 14 && live) {      // the lanes that wrote the goal block of this row
+        const uint64_t ev = cfg.step_counter + (uint64_t)t;
+        const earl::U4 b = earl::philox4x32_10(earl::U4{0xFFFEu, (uint32_t)(cfg.env_offset + env), (uint32_t)ev, (uint32_t)(ev >> 32)},
+                                               (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
+        int grow = (int)(earl::u01(b.x, b.y) * (double)cfg.n_goal_rows);
+        grow = grow < cfg.n_goal_rows ? grow : cfg.n_goal_rows - 1;
+        const double gv = cfg.goal_table[(size_t)grow * 7 + (sub - 7)];
+        a.st.goal[(size_t)env * 7 + (sub - 7)] = gv;
+        a.out.obs[row * 14 + sub] = gv;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next step's observation reads the goal row back through global memory
+    }
   }
   if (!live) return;
   store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = sub == 0 ? mpos.x : (sub == 1 ? mpos.y : mpos.z);
   if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
+  if (sub == 0 && gcf > 0) a.st.steps_since_goal_change[env] = sgc;
 }
 
 // reset (masked) / observe: both end with the kinematics of the current state and the observation
@@ -1176,7 +1215,23 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
       // sawyer_peg.py:199-212 / :221-223: xyz ~ U(obj_low, obj_high), redrawn while the xy distance to the hole block is < 0.1;
       // _set_obj_xyz [UPSTREAM]: qpos[9:12] <- xyz, qvel[9:15] <- 0 (the orientation is left as it is)
       double px = 0, py = 0, pz = 0;
-      for (uint32_t attempt = 0; attempt < 16u; ++attempt) {
+      bool wide = false;
+      if (cfg.obj_kind == 2 && cfg.n_wide > 0 && cfg.wide_table) {
+        // wide_init (sawyer_peg.py:200-209): np.random.uniform() < 0.5 keeps the default draw below; otherwise a row of the wide table
+        // (shifted by +0.1 in x: "- np.array([-0.1, 0, 0])") plus U(-0.02, 0.02)^3
+#pragma clang fp contract(off)
+        const earl::U4 c0_ = earl::philox4x32_10(earl::U4{0xFFF0u, gid, c0, c1}, k0, k1);
+        const earl::U4 c1_ = earl::philox4x32_10(earl::U4{0xFFF1u, gid, c0, c1}, k0, k1);
+        wide = !(earl::u01(c0_.x, c0_.y) < 0.5);
+        int wr = (int)(earl::u01(c0_.z, c0_.w) * (double)cfg.n_wide);
+        wr = wr < cfg.n_wide ? wr : cfg.n_wide - 1;
+        const double lo = -cfg.wide_noise, hi = cfg.wide_noise;
+        px = (cfg.wide_table[wr * 3 + 0] + cfg.wide_shift[0]) + (lo + (hi - lo) * earl::u01(c1_.x, c1_.y));
+        py = (cfg.wide_table[wr * 3 + 1] + cfg.wide_shift[1]) + (lo + (hi - lo) * earl::u01(c1_.z, c1_.w));
+        const earl::U4 c2_ = earl::philox4x32_10(earl::U4{0xFFF2u, gid, c0, c1}, k0, k1);
+        pz = (cfg.wide_table[wr * 3 + 2] + cfg.wide_shift[2]) + (lo + (hi - lo) * earl::u01(c2_.x, c2_.y));
+      }
+      for (uint32_t attempt = 0; attempt < 16u && !wide; ++attempt) {
 #pragma clang fp contract(off)
         const earl::U4 b0 = earl::philox4x32_10(earl::U4{2u * attempt, gid, c0, c1}, k0, k1);
         const earl::U4 b1 = earl::philox4x32_10(earl::U4{2u * attempt + 1u, gid, c0, c1}, k0, k1);
@@ -1205,6 +1260,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
     mpos = ld3(cfg.hand_init_pos);
     if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = cfg.hand_init_pos[sub];
     if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
+    if (sub == 0 && a.st.steps_since_goal_change) a.st.steps_since_goal_change[env] = 0;     // LifelongWrapper.reset (lifelong_wrapper.py:25-28)
   } else {
     load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   }
@@ -1285,7 +1341,7 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
   if (cfg->frame_skip < 0 || cfg->att_hand < 0 || cfg->att_right < 0 || cfg->att_left < 0 || cfg->att_obj < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
   SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
-  if (cfg->obj_kind == 1 && cfg->reward_type != 0) return EARL_ERR_ARG;   // the peg's dense reward (metaworld reward_utils, upstream) is not built
+  if (cfg->obj_kind >= 1 && cfg->reward_type != 0) return EARL_ERR_ARG;   // the peg's dense reward (metaworld reward_utils, upstream) is not built
   if (nv == 10) {
     if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<grid_for<10, 64>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
     else sawyer_rollout_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
@@ -1301,8 +1357,9 @@ int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawye
                       earl_stream_t stream) {
   if (!model || !cfg || !st || !reset_qpos || !reset_qvel || cfg->n < 0) return EARL_ERR_ARG;
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
-  if (cfg->obj_dof < 0 || cfg->obj_dof >= nv || (cfg->obj_kind != 0 && cfg->obj_kind != 1)) return EARL_ERR_ARG;
-  if (cfg->obj_kind == 1 && cfg->obj_dof + 6 > nv) return EARL_ERR_ARG;
+  if (cfg->obj_dof < 0 || cfg->obj_dof >= nv || cfg->obj_kind < 0 || cfg->obj_kind > 2) return EARL_ERR_ARG;
+  if (cfg->obj_kind >= 1 && cfg->obj_dof + 6 > nv) return EARL_ERR_ARG;
+  if (cfg->obj_kind == 2 && (cfg->n_wide <= 0 || !cfg->wide_table)) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
   SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, reset_qpos, reset_qvel, mask, obs, 0};
   if (nv == 10) sawyer_reset_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);

@@ -87,10 +87,11 @@ class SawyerDoor:
     cfg.hand_init_pos[:] = [float(x) for x in self.hand_init_pos]
     cfg.obj_init_pos[:] = [float(x) for x in self.obj_init_pos]
     self._task_cfg(cfg, names)
-    cfg.goal_change_frequency = 0               # python-side only (LifelongWrapper)
+    cfg.goal_change_frequency = 0               # set by LifelongWrapper
     self._cfg = cfg
     self._st = _abi.SawyerState(qpos=self.qpos.data_ptr(), qvel=self.qvel.data_ptr(), mocap_pos=self.mocap_pos.data_ptr(),
-                                goal=self.goal_t.data_ptr(), steps_since_reset=self.steps_since_reset.data_ptr())
+                                goal=self.goal_t.data_ptr(), steps_since_reset=self.steps_since_reset.data_ptr(),
+                                steps_since_goal_change=self.steps_since_goal_change.data_ptr())
     self._cfg_ref, self._st_ref = C.byref(self._cfg), C.byref(self._st)
 
     self.action_space = Box(-1.0, 1.0, (4,), np.float32)
@@ -145,6 +146,7 @@ class SawyerDoor:
   def _launch_rollout(self, actions, T, out):
     o = _abi.SawyerOut(obs=out['obs'].data_ptr(), reward=_ptr(out.get('reward')), done=_ptr(out.get('done')),
                        success=_ptr(out.get('success')))
+    self._cfg.step_counter = self.total_step_count
     with torch.cuda.device(self.device):
       _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.model.col_ptr, self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),
                                                T, C.byref(o), self._stream()), 'earl_sawyer_rollout')
@@ -175,7 +177,6 @@ class SawyerDoor:
     else:
       self.interventions += mask.to(torch.int32)
       obs = torch.where(mask.bool()[:, None], obs, obs_prev)
-    self.steps_since_goal_change.zero_()
     return obs[0].cpu().numpy() if self.scalar_api else obs
 
   def step(self, action, out=None):

@@ -10,7 +10,7 @@ STATUS: the dynamics are this build's own stepper and contact model (the peg as 
 gripper plates and the hole block, its corners as points against the table and the block); parity with MuJoCo is UNPINNED
 (DESIGN.md section 9).  Pinned by the reference's data: the sparse success rule (bit-exact on the 1,815 demonstration rows), the
 reset observation (hand pose, gripper opening 1.0, pegHead at z = 0.02), initial / goal tables.  Not built: the dense reward
-(metaworld's reward_utils and _gripper_caging_reward are upstream code absent from the reference tree) and `wide_init`.
+(metaworld's reward_utils and _gripper_caging_reward are upstream code absent from the reference tree).
 """
 import numpy as np
 import torch
@@ -23,6 +23,11 @@ initial_states = np.array([[0.00615235, 0.6001898, 0.19430117, 1.0, x, y, 0.02] 
     (-0.01177235, 0.55206996), (0.02779735, 0.54707706), (0.01835314, 0.5329686), (0.02690855, 0.6263067), (0.01766127, 0.59630984),
     (0.0560186, 0.6634998), (-0.03950658, 0.6323736), (-0.03216827, 0.5247563), (0.01265727, 0.69466716), (0.05076993, 0.6025737))])
 goal_states = np.array([[0.0, 0.6, 0.2, 1.0, -0.3 + 0.03, 0.6, 0.0 + 0.13]])
+# reference: sawyer_peg.py:55-60 (peg positions only)
+wide_initial_states = np.array([[-0.3, 0.8, 0.02], [-0.4, 0.8, 0.02], [-0.3, 0.9, 0.02], [-0.4, 0.9, 0.02], [-0.2, 0.8, 0.02], [-0.2, 0.75, 0.02],
+                                [-0.2, 0.9, 0.02], [-0.1, 0.77, 0.02], [0.0, 0.9, 0.02], [0.1, 0.8, 0.02], [0.15, 0.75, 0.02], [-0.3, 0.4, 0.02],
+                                [-0.4, 0.4, 0.02], [-0.3, 0.45, 0.02], [-0.4, 0.45, 0.02], [-0.2, 0.4, 0.02], [-0.2, 0.45, 0.02], [-0.2, 0.38, 0.02],
+                                [-0.1, 0.42, 0.02], [0.0, 0.45, 0.02], [0.1, 0.36, 0.02], [0.15, 0.44, 0.02]])
 
 
 class SawyerPeg(SawyerDoor):
@@ -35,8 +40,7 @@ class SawyerPeg(SawyerDoor):
     if reward_type != 'sparse':
       raise NotImplementedError('sawyer_peg: only the sparse reward is built (the dense one needs metaworld reward_utils / '
                                 '_gripper_caging_reward, which are not in the reference tree)')
-    if wide_init:
-      raise NotImplementedError('sawyer_peg: wide_init is not built')
+    self.wide_init = bool(wide_init)
     super().__init__(reward_type=reward_type, reset_at_goal=reset_at_goal, **kw)
 
   def _task_constants(self):
@@ -60,6 +64,12 @@ class SawyerPeg(SawyerDoor):
       cfg.obj_reject_xy[:] = [float(pos_box[0]), float(pos_box[1])]
       cfg.obj_reject_radius = 0.1
       cfg.n_goal_rows, cfg.goal_table = 0, None
+      if self.wide_init:
+        # :200-209: with probability 1/2 the draw above, otherwise a row of wide_initial_states - (-0.1, 0, 0) + U(-0.02, 0.02)^3
+        self._wide_table = torch.tensor(wide_initial_states, dtype=torch.float64, device=self.device).contiguous()
+        cfg.obj_kind, cfg.n_wide, cfg.wide_table = 2, len(wide_initial_states), self._wide_table.data_ptr()
+        cfg.wide_shift[:] = (0.1, 0.0, 0.0)
+        cfg.wide_noise = 0.02
     else:
       # :216-227: the peg starts in the hole, goal_pos + U(-0.02, 0.02)^3 with goal_pos = goal - (-0.1, 0, 0); the goal is one of
       # the initial states (get_next_goal :149-152)

@@ -123,9 +123,15 @@ typedef struct earl_sawyer_cfg {
   int32_t obj_dof;                         /* dof re-initialised by reset: the door hinge, or the first of the peg's three translations */
   int32_t obj_kind;                        /* 0: hinge angle <- obj_init_angle + U(angle_noise)   (SawyerDoorV2.reset_model, sawyer_door.py:111-125)
                                               1: free body, xyz <- U(obj_low, obj_high) redrawn while its xy is within obj_reject_radius of
-                                                 obj_reject_xy, orientation kept, zero velocity  (SawyerPegV2.reset_model, sawyer_peg.py:192-229) */
+                                                 obj_reject_xy, orientation kept, zero velocity  (SawyerPegV2.reset_model, sawyer_peg.py:192-229)
+                                              2: as 1 with probability 1/2, otherwise xyz <- wide_table[randint(n_wide)] + wide_shift +
+                                                 U(-wide_noise, wide_noise)^3  (wide_init, sawyer_peg.py:200-209) */
   int32_t n_goal_rows;                     /* > 0: reset draws the goal uniformly from goal_table [n_goal_rows, 7] (SawyerPegV2.get_next_goal
                                               with reset_at_goal, sawyer_peg.py:144-152); 0: goals are left as they are */
+  int32_t goal_change_frequency;           /* > 0: LifelongWrapper.step (lifelong_wrapper.py:30-44): every that many steps since the last reset /
+                                              switch the goal is redrawn (from goal_table if n_goal_rows > 0, else kept) and the goal block of the
+                                              observation returned by that step is the NEW goal; the reward of that step used the old one */
+  int32_t n_wide;                          /* rows of wide_table (obj_kind 2) */
   double action_scale;
   double mocap_low[3], mocap_high[3], mocap_quat[4];
   double success_radius;
@@ -133,7 +139,10 @@ typedef struct earl_sawyer_cfg {
   double obj_init_angle, angle_noise[2];
   double obj_low[3], obj_high[3], obj_reject_xy[2], obj_reject_radius;
   const double* goal_table;                /* device, [n_goal_rows, 7] or NULL */
-  uint64_t seed, counter;                  /* reset draws: Philox(seed; global env id, counter) */
+  const double* wide_table;                /* device, [n_wide, 3] or NULL */
+  double wide_shift[3], wide_noise;
+  uint64_t seed, counter;                  /* reset draws: Philox(seed; draw, global env id, counter) */
+  uint64_t step_counter;                   /* env steps taken before this launch (goal-switch draws: Philox(seed; 0xFFFE, global env id, step)) */
 } earl_sawyer_cfg;
 
 typedef struct earl_sawyer_state {
@@ -142,6 +151,7 @@ typedef struct earl_sawyer_state {
   double* mocap_pos;            /* [n, 3] */
   double* goal;                 /* [n, 7] */
   int32_t* steps_since_reset;   /* [n] */
+  int32_t* steps_since_goal_change;   /* [n]; may be NULL when cfg.goal_change_frequency == 0 */
 } earl_sawyer_state;
 
 typedef struct earl_sawyer_out {

@@ -34,7 +34,7 @@ class CModel:
                          _p(mq), _p(ct), _p(qacc), _p(efc), _p(att), _p(ncon))
     return dict(qpos=q, qvel=v, qacc=qacc, efc=efc, att=att, ncon=ncon)
 
-  def sawyer_rollout(self, cfg_kwargs, qpos, qvel, mocap_pos, goal, steps_since_reset, actions):
+  def sawyer_rollout(self, cfg_kwargs, qpos, qvel, mocap_pos, goal, steps_since_reset, actions, steps_since_goal_change=None, goal_table=None):
     """the env loop of oracle/sawyer_oracle.py for a batch; arrays are updated in place; -> obs, reward, done, success"""
     a = self._abi
     T, n = actions.shape[:2]
@@ -43,7 +43,11 @@ class CModel:
       if isinstance(v, (tuple, list, np.ndarray)):
         getattr(cfg, k)[:] = [float(x) for x in v]
     st = a.SawyerState(qpos=qpos.ctypes.data, qvel=qvel.ctypes.data, mocap_pos=mocap_pos.ctypes.data, goal=goal.ctypes.data,
-                       steps_since_reset=steps_since_reset.ctypes.data)
+                       steps_since_reset=steps_since_reset.ctypes.data,
+                       steps_since_goal_change=None if steps_since_goal_change is None else steps_since_goal_change.ctypes.data)
+    if goal_table is not None:
+      self._gt = np.ascontiguousarray(goal_table, np.float64)
+      cfg.goal_table, cfg.n_goal_rows = self._gt.ctypes.data, len(self._gt)
     obs, rew = np.zeros((T, n, 14)), np.zeros((T, n), np.float32)
     done, suc = np.zeros((T, n), np.uint8), np.zeros((T, n), np.uint8)
     out = a.SawyerOut(obs=obs.ctypes.data, reward=rew.ctypes.data, done=done.ctypes.data, success=suc.ctypes.data)

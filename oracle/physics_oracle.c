@@ -450,6 +450,9 @@ static double tolerance_gaussian(double x, double hi, double margin) {
   return exp(-0.5 * (d * scale) * (d * scale));
 }
 
+void oracle_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out);   /* tabletop_oracle.c */
+static double u01_(uint32_t lo, uint32_t hi) { return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0); }
+
 /* earl_sawyer_rollout on host arrays (same cfg / state / out structs with host pointers); reference: oracle/sawyer_oracle.py */
 int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* col, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                           const float* action, int32_t T, const earl_sawyer_out* out) {
@@ -461,9 +464,11 @@ int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* 
     double* qp = st->qpos + (size_t)e * m->nq;
     double* qv = st->qvel + (size_t)e * nv;
     double* mp = st->mocap_pos + (size_t)e * 3;
-    const double* goal = st->goal + (size_t)e * 7;
+    double* goal = st->goal + (size_t)e * 7;
     const Q4 mq = qnormalize(ldq(cfg->mocap_quat));
     int steps = st->steps_since_reset ? st->steps_since_reset[e] : 0;
+    const int gcf = st->steps_since_goal_change ? cfg->goal_change_frequency : 0;
+    int sgc = gcf > 0 ? st->steps_since_goal_change[e] : 0;
     for (int t = 0; t < T; ++t) {
       const float* a = action + ((size_t)t * n + e) * 4;
       for (int k = 0; k < 3; ++k) {
@@ -496,8 +501,22 @@ int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* 
       if (out->reward) out->reward[row] = (float)r;
       if (out->success) out->success[row] = (uint8_t)ok;
       if (out->done) out->done[row] = (cfg->horizon > 0 && steps >= cfg->horizon) ? 1 : 0;
+      if (gcf > 0 && ++sgc >= gcf) {   /* LifelongWrapper.step, lifelong_wrapper.py:36-42: new goal, observation re-read with it */
+        sgc = 0;
+        if (cfg->n_goal_rows > 0 && cfg->goal_table) {
+          const uint64_t ev = cfg->step_counter + (uint64_t)t;
+          const uint32_t ctr[4] = {0xFFFEu, (uint32_t)(cfg->env_offset + e), (uint32_t)ev, (uint32_t)(ev >> 32)};
+          const uint32_t key[2] = {(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
+          uint32_t b[4];
+          oracle_philox4x32_10(ctr, key, b);
+          int grow = (int)(u01_(b[0], b[1]) * (double)cfg->n_goal_rows);
+          if (grow >= cfg->n_goal_rows) grow = cfg->n_goal_rows - 1;
+          for (int k = 0; k < 7; ++k) { goal[k] = cfg->goal_table[(size_t)grow * 7 + k]; ob[7 + k] = goal[k]; }
+        }
+      }
     }
     if (st->steps_since_reset) st->steps_since_reset[e] = steps;
+    if (gcf > 0) st->steps_since_goal_change[e] = sgc;
   }
   return 0;
 }

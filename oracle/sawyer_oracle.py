@@ -106,6 +106,10 @@ PEG_INITIAL_XY = np.array([(0.00313463, 0.68326396), (-0.04035005, 0.67949003), 
                            (-0.07566337, 0.62575287), (-0.01177235, 0.55206996), (0.02779735, 0.54707706), (0.01835314, 0.5329686),
                            (0.02690855, 0.6263067), (0.01766127, 0.59630984), (0.0560186, 0.6634998), (-0.03950658, 0.6323736),
                            (-0.03216827, 0.5247563), (0.01265727, 0.69466716), (0.05076993, 0.6025737)])            # :18-48
+PEG_WIDE_INITIAL = np.array([[-0.3, 0.8, 0.02], [-0.4, 0.8, 0.02], [-0.3, 0.9, 0.02], [-0.4, 0.9, 0.02], [-0.2, 0.8, 0.02], [-0.2, 0.75, 0.02],
+                             [-0.2, 0.9, 0.02], [-0.1, 0.77, 0.02], [0.0, 0.9, 0.02], [0.1, 0.8, 0.02], [0.15, 0.75, 0.02], [-0.3, 0.4, 0.02],
+                             [-0.4, 0.4, 0.02], [-0.3, 0.45, 0.02], [-0.4, 0.45, 0.02], [-0.2, 0.4, 0.02], [-0.2, 0.45, 0.02], [-0.2, 0.38, 0.02],
+                             [-0.1, 0.42, 0.02], [0.0, 0.45, 0.02], [0.1, 0.36, 0.02], [0.15, 0.44, 0.02]])                    # :55-60
 PEG_INITIAL_STATES = np.array([[0.00615235, 0.6001898, 0.19430117, 1.0, x, y, 0.02] for x, y in PEG_INITIAL_XY])
 
 
@@ -114,8 +118,10 @@ class SawyerPegOracle(SawyerDoorOracle):
      _get_obs :134-142 (object = site pegHead :186-187), reset_model :192-229, get_next_goal / reset_goal :144-163,
      is_successful :301-305 (radius 0.05); SawyerXYZEnv.step / _reset_hand / _set_obj_xyz are upstream metaworld."""
 
-  def __init__(self, link_model, reward_type='sparse', reset_at_goal=False, seed=0, env_id=0, horizon=0, frame_skip=5):
+  def __init__(self, link_model, reward_type='sparse', reset_at_goal=False, seed=0, env_id=0, horizon=0, frame_skip=5, wide_init=False,
+               goal_change_frequency=0):
     assert reward_type == 'sparse'
+    self.wide_init, self.gcf, self.sgc, self.total_steps = wide_init, goal_change_frequency, 0, 0
     self.lm, self.reward_type, self.seed, self.env_id, self.horizon, self.frame_skip = link_model, reward_type, seed, env_id, horizon, frame_skip
     names = [str(x) for x in link_model.att_names]
     self.k_hand, self.k_right, self.k_left, self.k_obj = (names.index(x) for x in ('hand', 'rightEndEffector', 'leftEndEffector', 'pegHead'))
@@ -147,7 +153,14 @@ class SawyerPegOracle(SawyerDoorOracle):
 
   def reset(self):
     q, v = (x.copy() for x in self.settle())
-    for attempt in range(16):
+    wide = False
+    if self.wide_init and not self.reset_at_goal:       # sawyer_peg.py:200-209
+      c0, c1, c2 = self._draw(0xFFF0), self._draw(0xFFF1), self._draw(0xFFF2)
+      wide = not (u01(c0[0], c0[1]) < 0.5)
+      row = PEG_WIDE_INITIAL[min(int(u01(c0[2], c0[3]) * len(PEG_WIDE_INITIAL)), len(PEG_WIDE_INITIAL) - 1)]
+      un = np.array([u01(c1[0], c1[1]), u01(c1[2], c1[3]), u01(c2[0], c2[1])])
+      pos = (row + np.array([0.1, 0.0, 0.0])) + (-0.02 + (0.02 - -0.02) * un)
+    for attempt in range(0 if wide else 16):
       b0, b1 = self._draw(2 * attempt), self._draw(2 * attempt + 1)
       u = np.array([u01(b0[0], b0[1]), u01(b0[2], b0[3]), u01(b1[0], b1[1])])
       pos = self.obj_low + (self.obj_high - self.obj_low) * u
@@ -159,7 +172,7 @@ class SawyerPegOracle(SawyerDoorOracle):
     self.counter += 1
     q[self.obj_dof:self.obj_dof + 3] = pos          # _set_obj_xyz [UPSTREAM]: qpos[9:12] <- pos, qvel[9:15] <- 0
     v[self.obj_dof:self.obj_dof + 6] = 0.0
-    self.qpos, self.qvel, self.mocap, self.steps = q, v, self.hand_init_pos.copy(), 0
+    self.qpos, self.qvel, self.mocap, self.steps, self.sgc = q, v, self.hand_init_pos.copy(), 0, 0
     pos_, quat_, _ = self.lm.kinematics(q)
     return self.obs_from(pos_, quat_)
 
@@ -174,4 +187,13 @@ class SawyerPegOracle(SawyerDoorOracle):
     obs = self.obs_from(out['pos'], out['quat'])
     ok = bool(np.sqrt(np.sum((obs[4:7] - obs[11:14]) ** 2)) <= 0.05)             # is_successful :301-305
     self.steps += 1
+    if self.gcf > 0:                                    # LifelongWrapper.step (lifelong_wrapper.py:30-44)
+      self.sgc += 1
+      if self.sgc >= self.gcf:
+        self.sgc = 0
+        if self.reset_at_goal:
+          b = philox4x32_10((0xFFFE, self.env_id, self.total_steps & 0xFFFFFFFF, self.total_steps >> 32), (self.seed & 0xFFFFFFFF, self.seed >> 32))
+          self.goal = PEG_INITIAL_STATES[min(int(u01(b[0], b[1]) * len(PEG_INITIAL_STATES)), len(PEG_INITIAL_STATES) - 1)].copy()
+          obs = np.concatenate([obs[:7], self.goal])
+    self.total_steps += 1
     return obs, np.float32(float(ok)), bool(self.horizon > 0 and self.steps >= self.horizon), ok

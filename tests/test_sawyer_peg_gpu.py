@@ -234,3 +234,57 @@ def test_loader_masked_reset_and_lifelong():
   assert out['obs'].shape == (3, 4, 14)
   with pytest.raises(NotImplementedError):
     eb.EARLEnvs('sawyer_peg', reward_type='dense', num_envs=2)
+
+
+def test_wide_init_reset_matches_oracle(lm):
+  """wide_init (sawyer_peg.py:200-209): half of the resets use the default reset box, the other half a row of the wide table + noise"""
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg, wide_initial_states
+  from oracle.sawyer_oracle import SawyerPegOracle
+  n = 48
+  env = SawyerPeg(num_envs=n, seed=21, wide_init=True)
+  obs0 = env.reset().cpu().numpy()
+  refs = [SawyerPegOracle(lm, seed=21, env_id=i, wide_init=True) for i in range(n)]
+  for r in refs:
+    r._settled = refs[0].settle()
+    r.counter = 1
+  ref0 = np.stack([r.reset() for r in refs])
+  np.testing.assert_allclose(obs0, ref0, rtol=0, atol=1e-8)
+  peg = obs0[:, 4:7] + [0.1, 0, 0]
+  default = (peg[:, 0] >= 0) & (peg[:, 0] <= 0.2) & (peg[:, 1] >= 0.5) & (peg[:, 1] <= 0.7) & (np.abs(peg[:, 2] - 0.02) < 1e-6)
+  near_table = np.array([np.abs(wide_initial_states + [0.1, 0, 0] - p).max(1).min() <= 0.02 + 1e-9 for p in peg])
+  assert (default | near_table).all() and 12 <= default.sum() <= 36 and 12 <= near_table.sum() <= 36
+
+
+def test_lifelong_goal_switch_matches_oracle(lm):
+  """LifelongWrapper on the reverse task (reset_at_goal: goals are the 15 initial states): every goal_change_frequency steps the goal
+  is redrawn, the returned observation carries the NEW goal, the reward of that step was computed with the old one"""
+  import earl_benchmark_amd as eb
+  import torch
+  from oracle.sawyer_oracle import SawyerPegOracle
+  n, T, f = 5, 8, 3
+  env = eb.EARLEnvs('sawyer_peg', reward_type='sparse', setup_as_lifelong_learning=True, reset_train_env_at_goal=True, num_envs=n, seed=4,
+                    train_horizon=100, goal_change_frequency=f).get_envs()
+  obs0 = env.reset().cpu().numpy()
+  refs = [SawyerPegOracle(lm, 'sparse', True, seed=4, env_id=i, goal_change_frequency=f) for i in range(n)]
+  for r in refs:
+    r._settled = refs[0].settle()
+    r.counter = 1
+  np.testing.assert_allclose(obs0, np.stack([r.reset() for r in refs]), rtol=0, atol=1e-8)
+  acts = np.random.default_rng(9).uniform(-1, 1, size=(T, n, 4)).astype(np.float32)
+  out = env.rollout(torch.from_numpy(acts[:5]).cuda())
+  rest = [env.step(torch.from_numpy(acts[t]).cuda()) for t in range(5, T)]                 # the counter carries across launches
+  obs = np.concatenate([out['obs'].cpu().numpy()] + [o[0].cpu().numpy()[None] for o in rest])
+  rew = np.concatenate([out['reward'].cpu().numpy()] + [o[1].cpu().numpy()[None] for o in rest])
+  goals = [obs0[:, 7:]]
+  for t in range(T):
+    for i, r in enumerate(refs):
+      o, rw, _, _ = r.step(acts[t, i])
+      np.testing.assert_allclose(obs[t, i], o, rtol=0, atol=1e-7, err_msg=f'step {t} env {i}')
+      assert float(rew[t, i]) == float(rw)
+    goals.append(obs[t][:, 7:])
+  changed = [bool((goals[t + 1] != goals[t]).any()) for t in range(T)]
+  assert changed[2] and changed[5] and not any(changed[t] for t in (0, 1, 3, 4, 6, 7))       # switches on steps 3 and 6 only
+  u = env.unwrapped
+  assert u.steps_since_goal_change.tolist() == [2] * n
+  np.testing.assert_allclose(u.goal_t.cpu().numpy(), goals[-1], atol=0)
+  np.testing.assert_allclose(env.lifelong_return.cpu().numpy(), rew.sum(0), atol=1e-12)
