@@ -288,3 +288,23 @@ def test_lifelong_goal_switch_matches_oracle(lm):
   assert u.steps_since_goal_change.tolist() == [2] * n
   np.testing.assert_allclose(u.goal_t.cpu().numpy(), goals[-1], atol=0)
   np.testing.assert_allclose(env.lifelong_return.cpu().numpy(), rew.sum(0), atol=1e-12)
+
+
+def test_demo_prefixes_peg_drop_and_gripper():
+  """first 12 steps of the 10 forward demonstrations from their recorded start (before the gripper reaches the peg): the peg is set
+  down 5 mm above the table by reset_model and settles on it -- MuJoCo's recorded pegHead path is reproduced within 1.5 mm (free fall,
+  soft table contact, friction), the gripper opening exactly (clipped at 1.0), the hand within 1.5 cm"""
+  import torch
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  eps = episodes('forward')
+  n, K = len(eps), 12
+  env = SawyerPeg(num_envs=n)
+  env.reset()
+  place_pegs(env, np.stack([e[0][4:7] for e in eps]).astype(np.float64))
+  acts = np.stack([e[1][:K] for e in eps], axis=1)
+  got = env.rollout(torch.from_numpy(acts).cuda())['obs'].cpu().numpy()
+  want = np.stack([e[2][:K] for e in eps], axis=1)
+  assert np.abs(got[..., 3] - want[..., 3]).max() < 1e-6
+  assert np.abs(got[..., 4:7] - want[..., 4:7]).max() < 1.5e-3
+  assert np.abs(got[..., :3] - want[..., :3]).max() < 1.5e-2
+  assert abs(got[-1, :, 6].mean() - 0.015) < 1e-3 and abs(want[-1, :, 6].mean() - 0.015) < 1e-3       # both rest on the table top
