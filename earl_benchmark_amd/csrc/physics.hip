@@ -151,15 +151,26 @@ __device__ __forceinline__ void kbimp(const double* solref, const double* solimp
   b = 2.0 * rcp_nr(dw * tc);
 }
 
+// Symmetric NV x NV matrix in LDS, lower triangle packed row-major (row i, column j <= i at i (i + 1) / 2 + j): half the
+// LDS of a square array -- the env block is what limits the number of waves on a CU
+template <int NV>
+struct SymLds {
+  double v[NV * (NV + 1) / 2];
+  __device__ __forceinline__ double& lo(const int i, const int j) { return v[i * (i + 1) / 2 + j]; }               // i >= j
+  __device__ __forceinline__ const double& lo(const int i, const int j) const { return v[i * (i + 1) / 2 + j]; }
+  // entry (i, l) in either order; ltri = l (l + 1) / 2 is kept per lane (i is a compile-time index at every call site)
+  __device__ __forceinline__ double sym(const int i, const int l, const int ltri) const { return v[i >= l ? i * (i + 1) / 2 + l : ltri + i]; }
+};
+
 // Static bounds by model size: the door model (nv 10) keeps 8 contact slots and 16 collision blocks, which keeps its workgroup
 // under 40 KB of LDS (four workgroups per CU, one wave per SIMD); the peg model (nv 15) needs 12 / 32.
 template <int NV> struct Lim {
   static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
-  static constexpr int MB = NV <= 10 ? 16 : EARL_MAXBLK;    // collision blocks
+  static constexpr int MB = NV <= 10 ? 16 : 28;             // collision blocks (<= EARL_MAXBLK; the peg model has 25)
 #ifndef EARL_DOOR_WPB
 #define EARL_DOOR_WPB 1
 #endif
-  static constexpr int WPB = NV <= 10 ? EARL_DOOR_WPB : 3;              // wavefronts per workgroup.  nv 10: 38 KB per single-wave workgroup, four per CU.  nv 15: one
+  static constexpr int WPB = NV <= 10 ? EARL_DOOR_WPB : 4;              // wavefronts per workgroup.  nv 10: 38 KB per single-wave workgroup, four per CU.  nv 15: one
                                                             // env block is 11.7 KB; a three-wave workgroup (12 envs + the tables once = 151 KB) puts three
                                                             // waves on a CU where single-wave workgroups (57 KB) would fit two
 #ifndef EARL_DOOR_COOP
@@ -173,18 +184,15 @@ template <int NV> struct Lim {
 
 // Per-env LDS block.  The three phase groups of the union are live at disjoint times.
 template <int NV>
-struct Shared {
+struct SharedData {
   static constexpr int MC = Lim<NV>::MC;
   double qp[NV], qv[NV];
   double bq[4];                      // orientation of the free body (unit quaternion), identity if the model has none
-  double Xq[NV][4], Xp[NV][4];       // world frame of every link (final buffer of the ancestor doubling)
-  double M[NV][NV];
-  double tau[NV];
-  double att[4][3];
-  double bank_pad[8];                // sizeof(Shared<10>) would be 31 * 256 B: the four env blocks of a wave would sit on the same LDS
-                                     // banks and every broadcast access would conflict 4 ways; +64 B staggers them by 16 banks
+  double Xq[NV][4], Xp[NV][3];       // world frame of every link (final buffer of the ancestor doubling)
+  SymLds<NV> M;                      // mass matrix
   union {
-    struct { double Xq1[NV][4], Xp1[NV][4]; } k2;                    // second buffer of the doubling
+    struct { double Xq1[NV][4], Xp1[NV][3]; } k2;                    // second buffer of the doubling
+    struct { double att[4][3]; } emit;                               // observation epilogue (after the last timestep of an env step)
     struct {
       double S[NV][6];                 // motion subspace, world coordinates about the origin: [angular; linear] (every lane keeps its own column in registers)
       double I10[NV][10];
@@ -194,15 +202,24 @@ struct Shared {
       };
     } dyn;
     struct {
-      double J6[6][NV], wD[8], war[8], dl[NV], rl[NV], rhs2[NV];
+      double J6[6][NV], wD[6], war[6], dl[NV], rl[NV];
       double CJ[MC][3][NV];            // contact Jacobians: normal, tangent 1, tangent 2
       union {
         double ct[MC][10];             // contact records (C2 -> C3): dist, normal (3), point (3), class, sphere link, box link
         double cw[MC][8];              // per-iteration weights of the active pyramid edges (K9)
       };
-      double Hc[NV][NV], rc[NV];
+      SymLds<NV> Hc;                   // Hessian of the iteration; the shared factorisation overwrites it with L
+      double rc[NV];                   // its right-hand side; then the right-hand side of K10
     } con;
   };
+};
+// The four env blocks of a wave must not start on the same LDS banks (every broadcast access would conflict 4 ways): the block
+// size is padded to 64 or 192 mod 256 bytes, whichever is nearer
+template <int NV>
+struct Shared : SharedData<NV> {
+  static constexpr int R = (int)(sizeof(SharedData<NV>) % 256);
+  static constexpr int PAD = R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R);
+  char bank_pad[PAD == 0 ? 8 : PAD];
 };
 
 // Cholesky of an SPD matrix held in registers (lower triangle, row-major packed); the diagonal is left INVERTED.
@@ -247,12 +264,12 @@ __device__ __forceinline__ void solve_regs(const double (&L)[NV * (NV + 1) / 2],
 }
 // the lower triangle of an LDS matrix (+ a diagonal term) into the packed register form, skipping the off-diagonal block when NA < NV
 template <int NV, int NA, typename D>
-__device__ __forceinline__ void load_tri(double (&L)[NV * (NV + 1) / 2], const double (&H)[NV][NV], D diag) {
+__device__ __forceinline__ void load_tri(double (&L)[NV * (NV + 1) / 2], const SymLds<NV>& H, D diag) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
 #pragma unroll
-    for (int j = (i >= NA ? NA : 0); j < i; ++j) L[i * (i + 1) / 2 + j] = H[i][j];
-    L[i * (i + 1) / 2 + i] = H[i][i] + diag(i);
+    for (int j = (i >= NA ? NA : 0); j < i; ++j) L[i * (i + 1) / 2 + j] = H.lo(i, j);
+    L[i * (i + 1) / 2 + i] = H.lo(i, i) + diag(i);
   }
 }
 
@@ -262,42 +279,43 @@ __device__ __forceinline__ void load_tri(double (&L)[NV * (NV + 1) / 2], const d
 // by columns, every lane recomputes the pivot redundantly from the pivot row it has just read, so a column costs one LDS
 // round trip.  The two triangular solves then read L back from LDS, redundantly per lane (no exchange).
 template <int NV>
-__device__ __forceinline__ void chol_coop(double (&H)[NV][NV], const double (&dl)[NV], const int l, const bool isl) {
-  double r[NV];                                        // row l of H, then of L (entries j <= l)
+__device__ __forceinline__ void chol_coop(SymLds<NV>& H, const double (&dl)[NV], const int l, const bool isl) {
+  const int ltri = l * (l + 1) / 2;
+  double r[NV];                                        // row l of H, then of L (entries j <= l; the others are never used)
 #pragma unroll
-  for (int j = 0; j < NV; ++j) r[j] = H[l][j];
-  if (isl) H[l][l] = H[l][l] + dl[l];
+  for (int j = 0; j < NV; ++j) r[j] = H.sym(j, l, ltri);
+  if (isl) H.v[ltri + l] = r[l] + dl[l];
   fence();
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    double sj = H[j][j], si = r[j] + (l == j ? dl[l] : 0.0);
+    double sj = H.lo(j, j), si = r[j] + (l == j ? dl[l] : 0.0);
 #pragma unroll
     for (int p = 0; p < j; ++p) {
-      const double pj = H[j][p];
+      const double pj = H.lo(j, p);
       sj = fma(-pj, pj, sj);
       si = fma(-r[p], pj, si);
     }
     const double inv = rsq_nr(sj);
     r[j] = si * inv;
-    if (isl && l >= j) H[l][j] = l == j ? inv : r[j];
+    if (isl && l >= j) H.v[ltri + j] = l == j ? inv : r[j];
     fence();
   }
 }
 template <int NV>
-__device__ __forceinline__ void solve_lds(const double (&H)[NV][NV], double (&x)[NV]) {   // (L L') x' = x, L in LDS as chol_coop leaves it
+__device__ __forceinline__ void solve_lds(const SymLds<NV>& H, double (&x)[NV]) {   // (L L') x' = x, L in LDS as chol_coop leaves it
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     double s = x[i];
 #pragma unroll
-    for (int p = 0; p < i; ++p) s = fma(-H[i][p], x[p], s);
-    x[i] = s * H[i][i];
+    for (int p = 0; p < i; ++p) s = fma(-H.lo(i, p), x[p], s);
+    x[i] = s * H.lo(i, i);
   }
 #pragma unroll
   for (int i = NV - 1; i >= 0; --i) {
     double s = x[i];
 #pragma unroll
-    for (int p = i + 1; p < NV; ++p) s = fma(-H[p][i], x[p], s);
-    x[i] = s * H[i][i];
+    for (int p = i + 1; p < NV; ++p) s = fma(-H.lo(p, i), x[p], s);
+    x[i] = s * H.lo(i, i);
   }
 }
 
@@ -345,6 +363,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   const double dt = m.dt;
   const bool isl = sub < NV;
   const int l = isl ? sub : NV - 1;
+  const int ltri = l * (l + 1) / 2;                    // row offset of this lane in the packed symmetric matrices
   PSTART();
   // ------------------------------------------------------------------ K1: joint transform in the parent's frame
   Q4 Q; V3 P;
@@ -508,11 +527,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
     v = ((dmask >> i) & 1u) ? v : 0.0;                  // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
     if (i == l) v += m.armature[l];
-    if (isl && l <= i) { s.M[i][l] = v; s.M[l][i] = v; }
+    if (isl && l <= i) s.M.lo(i, l) = v;
   }
   fence();
   PSTAMP(4);
   // ------------------------------------------------------------------ K6: bias forces (RNE by masked sums)
+  double tau_l;                                        // this lane's applied + passive - bias force
   {
     V3 w{0, 0, 0}, v{0, 0, 0};
 #pragma unroll
@@ -575,7 +595,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
         const double c = fmin(fmax(ctrl[ac], m.act_ctrlrange[ac][0]), m.act_ctrlrange[ac][1]);
         t += m.act_kp[ac] * (c - s.qp[l]);
       }
-    if (isl) s.tau[l] = t;
+    tau_l = t;
   }
   fence();                                             // dyn.* is dead from here on; col.* then con.* take its place
   PSTAMP(5);
@@ -776,7 +796,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   // ------------------------------------------------------------------ K9: Hessian of the equality part, then the active-set Newton
   double hw[NV], rw;                                   // this lane's column of M + J6' D J6 (+ drag) and its right-hand side: registers, all iterations
   {
-    double DJ[6], g = s.tau[l];
+    double DJ[6], g = tau_l;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       DJ[r] = s.con.wD[r] * Jc[r];
@@ -784,7 +804,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      double h = s.M[i][l];
+      double h = s.M.sym(i, l, ltri);
 #pragma unroll
       for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
       if (i == l) h += m.drag_G[l];                     // soft velocity row of a permanent dragging contact
@@ -830,7 +850,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       }
       if (isl) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) s.con.Hc[i][l] = hcol[i];
+        for (int i = 0; i < NV; ++i)
+          if (i >= l) s.con.Hc.lo(i, l) = hcol[i];    // lower part of column l
         s.con.rc[l] = rr;
       }
     }
@@ -901,12 +922,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     {
       double acc = 0;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) acc = fma(s.M[l][j], a[j], acc);
-      if (isl) s.con.rhs2[l] = acc;
+      for (int j = 0; j < NV; ++j) acc = fma(s.M.sym(j, l, ltri), a[j], acc);
+      if (isl) s.con.rc[l] = acc;
     }
     fence();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] = s.con.rhs2[i];
+    for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i];
     if constexpr (Lim<NV>::COOP) {                     // M is rebuilt next timestep: factorise it in place
       if (isl) s.con.dl[l] = dt * m.damping[l];
       fence();
@@ -1094,22 +1115,22 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model
   if (sub < 4) {
     const int k = sub == 0 ? cfg.att_hand : (sub == 1 ? cfg.att_right : (sub == 2 ? cfg.att_left : cfg.att_obj));
     const V3 p = attachment<NV>(s, m, k);
-    s.att[sub][0] = p.x; s.att[sub][1] = p.y; s.att[sub][2] = p.z;
+    s.emit.att[sub][0] = p.x; s.emit.att[sub][1] = p.y; s.emit.att[sub][2] = p.z;
   }
   fence();
   if (sub < 14 && live) {
     double v;
-    if (sub < 3) v = s.att[0][sub];
+    if (sub < 3) v = s.emit.att[0][sub];
     else if (sub == 3) {
-      const V3 d = vsub(ld3(s.att[1]), ld3(s.att[2]));
+      const V3 d = vsub(ld3(s.emit.att[1]), ld3(s.emit.att[2]));
       v = fmin(fmax(sqrt(d.x * d.x + d.y * d.y + d.z * d.z) / 0.1, 0.0), 1.0);
-    } else if (sub < 7) v = s.att[3][sub - 4];
+    } else if (sub < 7) v = s.emit.att[3][sub - 4];
     else v = goal[sub - 7];
     obs[sub] = v;
   }
   if (sub == 0 && live) {
     double r; bool ok;
-    door_reward(cfg, ld3(s.att[0]), ld3(s.att[3]), ld3(goal + 4), r, ok);
+    door_reward(cfg, ld3(s.emit.att[0]), ld3(s.emit.att[3]), ld3(goal + 4), r, ok);
     if (reward) *reward = (float)r;
     if (success) *success = ok ? 1 : 0;
   }
