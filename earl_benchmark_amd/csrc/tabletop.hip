@@ -383,7 +383,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
       const dim3 grid((unsigned)((cfg->n + 63) / 64));
       const hipStream_t hs = (hipStream_t)stream;
 #define EARL_WS(RT, NC, NL, NS, K, LEAD) \
-  rollout_ws_kernel<RT, NC, NL, NS, K, LEAD><<<grid, 64 * (NC + NL + NS), g_rollout_lds_pad, hs>>>(w)
+  rollout_ws_kernel<RT, NC, NL, NS, K, LEAD><<<grid, 64 * (((NC) == 3 ? 2 : (NC)) + NL + NS), g_rollout_lds_pad, hs>>>(w)
       if (cfg->reward_type == EARL_REWARD_SPARSE) {
         switch (g_rollout_impl) {   // tuning variants (tools/tune_rollout.py); 0 = the shipped configuration
           case 2: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 4, 6); break;
@@ -398,16 +398,32 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 13: EARL_WS(EARL_REWARD_SPARSE, 1, 4, 4, 8, 3); break;
           case 14: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 2, 4, 6); break;
           case 8: EARL_WS(EARL_REWARD_SPARSE, 1, 1, 1, 4, 6); break;
+          case 20: EARL_WS(EARL_REWARD_SPARSE, 3, 4, 4, 8, 3); break;    // x / y in adjacent lanes (DPP), VGPR-only masks
+          case 21: EARL_WS(EARL_REWARD_SPARSE, 3, 4, 8, 8, 3); break;
+          case 22: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3); break;    // = shipped for grids of up to 256 workgroups
+          case 23: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 8, 8, 3); break;
+          case 30: EARL_WS(EARL_REWARD_SPARSE, 3, 1, 8, 8, 3); break;
+          case 31: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 4, 8, 3); break;
+          case 32: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 4, 4, 6); break;
+          case 33: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2); break;    // = shipped for larger grids
+          case 34: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 4); break;
+          case 29: rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, 8, 3, true><<<grid, 64 * 12, 0, hs>>>(w); break;  // stamps
           case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 4, 8, 3, true><<<grid, 64 * 10, 0, hs>>>(w); break;  // stamps
           case 19: rollout_ws_kernel<EARL_REWARD_SPARSE, 1, 4, 4, 8, 3, true><<<grid, 64 * 9, 0, hs>>>(w); break;  // stamps
           default:
-            // 2 x/y-split compute waves + 4 loaders + 4 storers, 8-step chunks: fastest of the variants above at
-            // every N measured (tools/tune_rollout.py; profiles/r01_tune_rollout.txt)
-            EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 8, 3);
+            // 2 compute waves with x / y in adjacent lanes (DPP, VGPR-only masks) + 2 loaders + 8 storers, 8-step chunks:
+            // fastest of the variants above at N = 4096 and not slower at any larger N measured (tools/tune_rollout.py;
+            // profiles/r01_tune_rollout.txt).  Variant 11 is the previous default (lane-half layout, 4 storers).
+            // Two loaders, not four: fewer waves compete with the compute waves for issue slots (4 loaders: 30.4 us, 2: 29.0 us
+            // at N = 4096, T = 200).  Large grids (more than one workgroup per CU) prefer shorter loader trips (LEAD 2):
+            // 69.5 vs 65.0 G env-steps/s at N = 2^20.
+            if (grid.x <= 256) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
+            else EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
             break;
         }
       } else {
-        EARL_WS(EARL_REWARD_DENSE, 2, 4, 4, 8, 3);
+        if (grid.x <= 256) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
+        else EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
       }
 #undef EARL_WS
       return launched("rollout_ws_kernel");

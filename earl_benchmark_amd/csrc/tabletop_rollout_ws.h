@@ -192,6 +192,54 @@ __device__ __forceinline__ void ws_step_xy_pipe(double& f, double& o, unsigned l
   f = nf;
 }
 
+// Third layout (NC == 3): x and y of an env in ADJACENT lanes (2e, 2e+1) of a 32-env wave.  The cross-lane traffic of the attach
+// test is then a DPP quad permutation (v_mov_b32_dpp, an ordinary VALU slot) instead of v_permlane32_swap (20 cycles each),
+// and -- as in ws_step_v -- every predicate stays in a VGPR lane mask (sign bits, and / bfi), so no instruction of the step
+// touches an SGPR (8.3 cycles and one shared scalar pipe per CU): no ballot, no inverse ballot, no v_cndmask with a mask.
+// 25 instructions per step in the ISA (31 for the lane-half layout): add max min | sub mul dpp dpp fma sub ashr dpp | or and |
+// sub bfi and | add max min | cvt cvt bitop | address, ds_write2, ds_write.
+//   quad_perm [0,0,2,2] (0xA0): both lanes of a pair read the EVEN (x) lane;  [1,1,3,3] (0xF5): both read the ODD (y) lane.
+//   old = src in every update_dpp: all lanes are written, so no zero-initialised destination (saves a v_mov per DPP).
+__device__ __forceinline__ double dpp_from_x(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0xA0, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0xA0, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_swap_pair(double v) {   // quad_perm [1,0,3,2]
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0xB1, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0xB1, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// attach-test mask (all ones / zero, both lanes of the pair) of gripper coordinate f against mug coordinate o
+__device__ __forceinline__ int ws_near_mask_adj(double f, double o, const WsConst& k) {
+  const double d = f - o;
+  const double d2 = fma(d, d, dpp_from_x(d * d));          // meaningful in the y lane: fma(dy, dy, dx*dx)
+  const int m = __double2hiint(d2 - k.thr) >> 31;          // all ones iff d2 < thr (exact for non-NaN)
+  return __builtin_amdgcn_update_dpp(m, m, 0xF5, 0xF, 0xF, false);
+}
+// fast step, software-pipelined like ws_step_xy_pipe: `nm` is the mask of THIS step's test, computed during the previous step
+__device__ __forceinline__ void ws_step_adj(double& f, double& o, int& nm, int& attm, double a, int grip, const WsConst& k) {
+  attm = grip & (attm | nm);
+  const double nf = fmin(fmax(f + a, k.lo), k.hi);
+  nm = ws_near_mask_adj(nf, o, k);                         // for the NEXT step: o is still the mug position before this step's move
+  const double dd = nf - f;
+  // attm ? dd : -0.0 on the two halves of the double (v_bfi_b32, v_and_b32)
+  const double sd = __hiloint2double((attm & __double2hiint(dd)) | (~attm & k.nz), attm & __double2loint(dd));
+  o = fmin(fmax(o + sd, k.lo), k.hi);
+  f = nf;
+}
+// exact step (NaN actions / states: np.clip propagates NaN): both lanes of a pair gather the partner's coordinate and run the
+// one-lane-per-env reference step redundantly; each keeps its own coordinate
+__device__ __forceinline__ void ws_step_adj_exact(double& f, double& o, int& attm, double a, int grip, int c, const Thresholds& th) {
+  const double pf = dpp_swap_pair(f), po = dpp_swap_pair(o), pa = dpp_swap_pair(a);
+  double fx = c ? pf : f, fy = c ? f : pf, ox = c ? po : o, oy = c ? o : po, oxl = 0, oyl = 0;
+  bool att = attm != 0;
+  ws_step<true>(fx, fy, ox, oy, oxl, oyl, att, c ? pa : a, c ? a : pa, grip != 0, th);
+  f = c ? fy : fx;
+  o = c ? oy : ox;
+  attm = att ? -1 : 0;
+}
+
 // PROF = diagnostic build only (tools/prof_ws.py): s_memtime stamps per role, summed per workgroup into
 // g_ws_prof; never used by the shipped configuration and its timings are not quoted.
 __device__ unsigned long long g_ws_prof[64 * 16];
@@ -211,11 +259,12 @@ __device__ __forceinline__ unsigned long long ws_clock() {
 // halves; NL loader waves (steps of a chunk are dealt round-robin to them), NS storer waves (likewise), K steps per
 // chunk, LEAD chunks per loader trip.  K % NL == 0.
 template <int RT, int NC, int NL, int NS, int K, int LEAD, bool PROF = false>
-__global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const WsArgs a) {
+__global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_ws_kernel(const WsArgs a) {
   constexpr int E = 64;
+  constexpr int NCW = NC == 3 ? 2 : NC;     // compute WAVES (NC == 3: two, x / y in adjacent lanes)
   constexpr int KL = K / NL;          // steps of a chunk handled by one loader
   static_assert(K % NL == 0, "K must be a multiple of NL");
-  static_assert(NC == 1 || NC == 2, "NC is 1 or 2");
+  static_assert(NC == 1 || NC == 2 || NC == 3, "NC is 1, 2 or 3");
   // rescaled (a0, a1).  NC == 1: [2e], [2e+1] of env e.  NC == 2: wave cw reads [64cw + lane]: a0 of its 32 envs, then a1
   __shared__ double A[3][K][2 * E];
   __shared__ uint8_t G[3][K][E];      // rescaled grip > 0
@@ -236,21 +285,121 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
   const int nch = (T + K - 1) / K;
   unsigned long long p_x = 0, p_t0 = 0;
 
-  // ---- every thread: pre-fill the constant goal part of all row images (parts 1 and 2 of each row)
-  for (int idx = threadIdx.x; idx < 2 * K * E; idx += 64 * (NC + NL + NS)) {
-    const int e = idx % E;
+  // ---- compute and storer threads: pre-fill the constant goal part of all row images (parts 1 and 2 of each row).  The
+  // loaders skip this and issue their first loads at once (the launch's fixed cost is the chain prologue -> first loads
+  // land -> two chunks processed -> first barrier).  A thread serves ONE env column (the stride is a multiple of 64), so the
+  // goal row -- a Philox draw when the reset is fused -- is evaluated once per thread, not once per row.
+  if (wave < NCW || wave >= NCW + NL) {
+    const int tid = wave < NCW ? (int)threadIdx.x : (int)threadIdx.x - 64 * NL;
+    const int e = tid % E;
     float g[6] = {0, 0, 0, 0, 0, 0};
     if (e < valid) load_goal<1>(a.goal_table, ws_goal_row(a, i0 + e), g);
-    float4* row = &R[0][0][0] + (size_t)(idx / E) * (E * 3) + e * 3;
-    row[1] = float4{-1.0f, -1.0f, g[0], g[1]};
-    row[2] = float4{g[2], g[3], g[4], g[5]};
+    for (int rowi = tid / E; rowi < 2 * K; rowi += NCW + NS) {
+      float4* row = &R[0][0][0] + (size_t)rowi * (E * 3) + e * 3;
+      row[1] = float4{-1.0f, -1.0f, g[0], g[1]};
+      row[2] = float4{g[2], g[3], g[4], g[5]};
+    }
   }
 
-  if (wave < NC) {
+  if (wave < NCW) {
    // the recurrence is the critical path: its wave wins issue arbitration against the loader/storer wave that shares
    // its SIMD (MI355X_MICROARCH.md, "two waves per SIMD": priority, then age)
    __builtin_amdgcn_s_setprio(3);
-   if constexpr (NC == 2) {
+   if constexpr (NC == 3) {
+    // ================================================================= COMPUTE, x / y in adjacent lanes, VGPR-only masks
+    const int h = lane & 1, el = lane >> 1, e = wave * 32 + el;   // coordinate, env within the wave / workgroup
+    const int ie = i0 + e;
+    const bool alive = e < valid;
+    double f = 0, o = 0;
+    bool att0 = false;
+    if (alive) {
+      if (a.reset_first) {   // PersistentStateWrapper.reset + TabletopManipulation.reset, both lanes of the env alike
+        Env<1> ev;
+        const int gi = reset_env<1>(ev, a.cfg, a.cfg.counter, ie, a.goal_table, nullptr, a.th);
+        f = h ? ev.q[1] : ev.q[0];         // (selects, not ev.q[h]: a dynamic index would put the array into scratch memory)
+        o = h ? ev.q[3] : ev.q[2];
+        if (h == 0) {
+          a.goal_idx_w[ie] = gi;
+          a.num_interventions[ie] += 1;
+        }
+      } else {
+        f = a.qpos[(size_t)ie * 4 + h];
+        o = a.qpos[(size_t)ie * 4 + 2 + h];
+        att0 = a.attached[ie] >= 0;
+      }
+    }
+    int attm = att0 ? -1 : 0;
+    WsConst kc{-2.8, 2.8, a.th.grasp_d2, (int)0x80000000};
+    asm volatile("" : "+v"(kc.lo), "+v"(kc.hi), "+v"(kc.thr), "+v"(kc.nz));   // keep them in VGPRs (a scalar operand costs 8.3 vs 5.3)
+    int nm = ws_near_mask_adj(f, o, kc);                       // attach test of the first step (true positions)
+    bool slow = __any(!(fabs(f) <= 1e300) || !(fabs(o) <= 2.8));   // NaN / object outside the arena -> exact path
+    unsigned long long p_read = 0, p_comp = 0, p_bar = 0;
+    if constexpr (PROF) p_t0 = ws_clock();
+    __syncthreads();
+    if constexpr (PROF) p_x = ws_clock();
+    const unsigned long long p_first = p_x - p_t0;
+    double av[K], nv[K];
+    int gv[K], ng[K];           // grip as a lane mask: the loaders store 0xFF / 0x00, read back sign-extended
+    int nslow = 0;
+    auto fetch = [&](int c) {   // chunk c+1 is already published when chunk c starts: fetch it one chunk ahead
+      const int ab = c % 3;
+      nslow = 0;
+#pragma unroll
+      for (int w = 0; w < NL; ++w) nslow |= slow_flag[ab][w];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        nv[k] = A[ab][k][wave * 64 + lane];                    // [2e + h]: the loaders' double2 {a0, a1} of env e
+        ng[k] = reinterpret_cast<const int8_t*>(&G[ab][k][0])[e];
+      }
+    };
+    fetch(0);
+    for (int c = 0; c < nch; ++c) {
+      const int rb = c & 1;
+      slow = slow || (nslow != 0);
+#pragma unroll
+      for (int k = 0; k < K; ++k) { av[k] = nv[k]; gv[k] = ng[k]; }
+      if (c + 1 < nch) fetch(c + 1);
+      if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WS_STAMP(p_read)
+      auto run = [&](auto exact, auto full) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if constexpr (!decltype(full)::value)
+            if (c * K + k >= T) break;      // tail chunk only (wave-uniform)
+          if constexpr (decltype(exact)::value) ws_step_adj_exact(f, o, attm, av[k], gv[k], h, a.th);
+          else ws_step_adj(f, o, nm, attm, av[k], gv[k], kc);
+          float* rowf = reinterpret_cast<float*>(&R[rb][k][e * 3]);   // (fx, fy, ox, oy), (flag, flag, ..)
+          rowf[h] = (float)f;
+          rowf[2 + h] = (float)o;
+          rowf[4 + h] = __int_as_float(~attm & (int)0xBF800000);     // attached ? 0.0f : -1.0f
+        }
+      };
+      const bool whole = (c + 1) * K <= T;   // every step of the chunk exists: no per-step tail test
+      if (__builtin_amdgcn_readfirstlane(slow ? 1 : 0)) {
+        if (whole) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+      } else {
+        if (whole) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
+      }
+      if constexpr (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WS_STAMP(p_comp)
+      __syncthreads();
+      WS_STAMP(p_bar)
+    }
+    if constexpr (PROF) {
+      if (lane == 0 && blockIdx.x < 64 && wave == 0) {
+        unsigned long long* op = g_ws_prof + blockIdx.x * 16;
+        op[0] = p_first; op[1] = p_read; op[2] = p_comp; op[3] = p_bar; op[4] = p_x - p_t0;
+      }
+    }
+    if (alive) {
+      a.qpos[(size_t)ie * 4 + h] = f;
+      a.qpos[(size_t)ie * 4 + 2 + h] = o;
+      if (h == 0) {
+        a.attached[ie] = attm ? 0 : -1;
+        a.steps_since_reset[ie] = (a.reset_first ? 0 : a.steps_since_reset[ie]) + T;
+      }
+    }
+   } else if constexpr (NC == 2) {
     // ================================================================= COMPUTE, x / y in the two lane halves
     const int h = lane >> 5, el = lane & 31, e = wave * 32 + el;   // coordinate, env within the wave / workgroup
     const int ie = i0 + e;
@@ -261,8 +410,8 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       if (a.reset_first) {   // PersistentStateWrapper.reset + TabletopManipulation.reset, both lanes of the env alike
         Env<1> ev;
         const int gi = reset_env<1>(ev, a.cfg, a.cfg.counter, ie, a.goal_table, nullptr, a.th);
-        f = ev.q[h];
-        o = ev.q[2 + h];
+        f = h ? ev.q[1] : ev.q[0];         // (selects: a dynamic index puts the array into scratch memory)
+        o = h ? ev.q[3] : ev.q[2];
         if (h == 0) {
           a.goal_idx_w[ie] = gi;
           a.num_interventions[ie] += 1;
@@ -437,7 +586,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
       a.steps_since_reset[i] = (a.reset_first ? 0 : a.steps_since_reset[i]) + T;
     }
    }
-  } else if (wave < NC + NL) {
+  } else if (wave < NCW + NL) {
     // ================================================================= LOADERS
     // The actions of one step for this workgroup are 192 consecutive floats.  Lane l loads floats l, l+64, l+128
     // (three coalesced 256-B wave loads, each into its own VGPR).  A loader owns the steps k = w, w+NL, .. of every
@@ -445,7 +594,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
     // touches the trip loaded one whole trip ago (long since landed), then issues the loads of the next one.
     // Loads are UNCONDITIONAL with clamped indices: a load under a branch makes hipcc wait vmcnt(0) right behind
     // it.  Clamped duplicates are never consumed (compute stops at T, storers mask dead lanes).
-    const int w = wave - NC;
+    const int w = wave - NCW;
     float rawA[LEAD][KL][3], rawB[LEAD][KL][3];
     const int last = max(valid * 3 - 1, 0);
     const int e0 = min(lane, last), e1 = min(lane + 64, last), e2 = min(lane + 128, last);
@@ -523,7 +672,7 @@ __global__ __launch_bounds__(64 * (NC + NL + NS)) void rollout_ws_kernel(const W
     }
   } else {
     // ================================================================= STORERS
-    const int s = wave - NC - NL;
+    const int s = wave - NCW - NL;
     float g[6] = {0, 0, 0, 0, 0, 0};
     int t_done = 0x7fffffff;           // done fires from step index t_done on (steps_since_reset + t + 1 >= horizon)
     if (live) {

@@ -433,7 +433,10 @@ def test_rollout_kernels_agree(hx, orc, rt, wide, n, T):
   random_state(rng, o)
   o.steps_since_reset[:] = rng.integers(0, 3, size=n)
   outs = {}
-  for impl in (0, 1):
+  # 0 = shipped configuration, 1 = plain kernel; sparse only: 11 = x / y in the two lane halves (v_permlane32_swap), 13 = one lane per
+  # env with VGPR-only masks, 20 / 22 = x / y in adjacent lanes (DPP) with VGPR-only masks and other role counts
+  impls = (0, 1) + ((11, 13, 20, 22) if rt == 'sparse' else ())
+  for impl in impls:
     h = hx.HipTabletop(n, reward_type=rt, wide_init=wide, horizon=max(1, T - 2), seed=1)
     h.set_from(o)
     prev = lib.earl_debug_set_rollout_impl(impl)
@@ -442,10 +445,11 @@ def test_rollout_kernels_agree(hx, orc, rt, wide, n, T):
     finally:
       lib.earl_debug_set_rollout_impl(prev)
     outs[impl, 'state'] = {k: h.host(k) for k in h.STATE}
-  for x, y in zip(outs[0], outs[1]):
-    np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
-  for k in outs[0, 'state']:
-    np.testing.assert_array_equal(outs[0, 'state'][k], outs[1, 'state'][k], err_msg=k)
+  for impl in impls[1:]:
+    for x, y in zip(outs[0], outs[impl]):
+      np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8), err_msg=f'variant {impl}')
+    for k in outs[0, 'state']:
+      np.testing.assert_array_equal(outs[0, 'state'][k], outs[impl, 'state'][k], err_msg=f'{k} variant {impl}')
   want = o.rollout(acts)
   assert_same_out(outs[0], want, rt == 'dense')
   for k, v in outs[0, 'state'].items():

@@ -9,7 +9,7 @@ from earl_benchmark_amd import _abi
 lib = _abi.load()
 impls = [int(x) for x in (sys.argv[1].split(',') if len(sys.argv) > 1 else '0,1,2,3,4,5,6,7'.split(','))]
 sizes = [int(x) for x in (sys.argv[2].split(',') if len(sys.argv) > 2 else '64,4096,65536,262144'.split(','))]
-T = 200
+T = int(os.environ.get('TUNE_T', '200'))
 for n in sizes:
   L = eb.EARLEnvs('tabletop_manipulation', reward_type='sparse', num_envs=n, eval_horizon=T, scalar_api=False)
   _, env = L.get_envs()
