@@ -34,6 +34,13 @@ class MotorParams(C.Structure):   # struct earl_motor_params (include/earl_glue.
               ('torque_control', C.c_int32)]
 
 
+class KitchenParams(C.Structure):   # struct earl_kitchen_params (include/earl_glue.h)
+  _fields_ = [('pos_bound', C.c_double * 2 * 23), ('vel_bound', C.c_double * 2 * 23), ('pos_noise_amp', C.c_double * 23),
+              ('act_mid', C.c_double * 9), ('act_amp', C.c_double * 9), ('mocap_range', C.c_double * 3),
+              ('mocap_clip_lower', C.c_double * 3), ('mocap_clip_upper', C.c_double * 3), ('step_duration', C.c_double),
+              ('robot_noise_ratio', C.c_double)]
+
+
 class SawyerCfg(C.Structure):   # struct earl_sawyer_cfg (include/earl_physics.h)
   _fields_ = [('n', C.c_int32), ('env_offset', C.c_int32), ('reward_type', C.c_int32), ('horizon', C.c_int32),
               ('frame_skip', C.c_int32), ('att_hand', C.c_int32), ('att_right', C.c_int32), ('att_left', C.c_int32),
@@ -79,6 +86,9 @@ SIGNATURES = {
     'earl_minitaur_motor_torque': [C.c_int32, _P(MotorParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_minitaur_reward': [C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_kitchen_reward': [C.c_int32] + [C.c_void_p] * 6,
+    'earl_kitchen_default_params': [_P(KitchenParams)],
+    'earl_kitchen_action': [C.c_int32, _P(KitchenParams)] + [C.c_void_p] * 5,
+    'earl_kitchen_obs': [C.c_int32, _P(KitchenParams)] + [C.c_void_p] * 5,
     # include/earl_physics.h
     'earl_physics_step': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7,
     'earl_physics_forward': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9,

@@ -121,6 +121,48 @@ __global__ __launch_bounds__(kB) void kitchen_reward_kernel(int n, const double*
   if (success) success[i] = dist <= 0.3;
 }
 
+// KitchenV0.step (kitchen_multitask_v0.py:91-105) + Robot.step's limits (franka_robot.py:172-174, :259-264); one lane per env
+__global__ void kitchen_action_kernel(const int n, const earl_kitchen_params p, const double* __restrict__ action, double* __restrict__ mocap,
+                                      const double* __restrict__ last_qp, double* __restrict__ ctrl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double x = action[(size_t)i * 9 + k];
+    const double c = x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x);         // np.clip (NaN propagates)
+    a[k] = p.act_mid[k] + c * p.act_amp[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double x = mocap[(size_t)i * 3 + k] + a[k] * p.mocap_range[k];
+    mocap[(size_t)i * 3 + k] = x < p.mocap_clip_lower[k] ? p.mocap_clip_lower[k] : (x > p.mocap_clip_upper[k] ? p.mocap_clip_upper[k] : x);
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double v = a[k] < p.vel_bound[k][0] ? p.vel_bound[k][0] : (a[k] > p.vel_bound[k][1] ? p.vel_bound[k][1] : a[k]);
+    const double x = last_qp[(size_t)i * 9 + k] + v * p.step_duration;
+    ctrl[(size_t)i * 9 + k] = x < p.pos_bound[k][0] ? p.pos_bound[k][0] : (x > p.pos_bound[k][1] ? p.pos_bound[k][1] : x);
+  }
+}
+
+// Robot.get_obs + KitchenV0._get_obs (franka_robot.py:137-168, kitchen_multitask_v0.py:127-139); one lane per obs entry
+__global__ void kitchen_obs_kernel(const int n, const earl_kitchen_params p, const double* __restrict__ qpos, const double* __restrict__ goal,
+                                   const double* __restrict__ noise, double* __restrict__ obs) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * 46) return;
+  const int i = (int)(t / 46), k = (int)(t % 46);
+  double v;
+  if (k < 23) {
+    v = qpos[(size_t)i * 23 + k];
+    // qp += ratio * amp[:9] * u[0:9];  qp_obj += ratio * amp[-14:] * u[18:32]   (left to right)
+    if (noise) v = v + (p.robot_noise_ratio * p.pos_noise_amp[k]) * noise[(size_t)i * 46 + (k < 9 ? k : k + 9)];
+  } else {
+    v = goal[(size_t)i * 23 + (k - 23)];
+  }
+  obs[t] = v;
+}
+
 int done(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -164,6 +206,41 @@ int earl_minitaur_reward(int32_t n, const double* obs, double distance_weight, d
   if (n == 0) return EARL_OK;
   minitaur_reward_kernel<<<blocks(n), kB, 0, (hipStream_t)s>>>(n, obs, distance_weight, energy_weight, time_step, reward, success);
   return done("minitaur_reward");
+}
+int earl_kitchen_default_params(earl_kitchen_params* p) {
+  if (!p) return EARL_ERR_ARG;
+  // franka_config.xml:17-57 (qpos0 .. qpos22)
+  static const double pb[23][2] = {{-2.9, 2.9}, {-1.8, 1.8}, {-2.9, 2.9}, {-3.1, 0.0}, {-2.9, 2.9}, {0.0, 3.8}, {-2.9, 2.9}, {0.0, 0.04}, {0.0, 0.04},
+                                   {-.5, 0.0}, {-.5, 0.0}, {-.005, 0.0}, {-.005, 0.0}, {-.005, 0.0}, {-.005, 0.0}, {-.005, 0.0}, {-.005, 0.0},
+                                   {-1.5, 1.5}, {-1.5, 1.5}, {-1.5, 1.5}, {-10.57, 10.57}, {-10.57, 10.57}, {-10.57, 10.57}};
+  static const double amp[23] = {0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.005, 0.005, 0.0005, 0.0005, 0.0005, 0.0005, 0.0005, 0.0005,
+                                 0.005, 0.005, 0.005, 0.1, 0.1, 0.1};
+  for (int k = 0; k < 23; ++k) {
+    p->pos_bound[k][0] = pb[k][0]; p->pos_bound[k][1] = pb[k][1];
+    const double vb = k < 9 ? 10.0 : (k < 20 ? 5.0 : 0.5);
+    p->vel_bound[k][0] = -vb; p->vel_bound[k][1] = vb;
+    p->pos_noise_amp[k] = amp[k];
+  }
+  for (int k = 0; k < 9; ++k) { p->act_mid[k] = 0.0; p->act_amp[k] = 2.0; }            // kitchen_multitask_v0.py:78-79
+  const double lo[3] = {-0.7, -0.1, 1.8}, hi[3] = {0.4, 0.5, 2.6};                         // :49-50
+  for (int k = 0; k < 3; ++k) { p->mocap_range[k] = 0.01; p->mocap_clip_lower[k] = lo[k]; p->mocap_clip_upper[k] = hi[k]; }   // :47
+  p->step_duration = 40 * 0.002;                                                            // skip * model.opt.timestep (:104-105)
+  p->robot_noise_ratio = 0.1;                                                               // :42
+  return EARL_OK;
+}
+int earl_kitchen_action(int32_t n, const earl_kitchen_params* p, const double* action, double* mocap_pos, const double* last_qpos_robot,
+                        double* ctrl, earl_stream_t s) {
+  if (n < 0 || !p || !action || !mocap_pos || !last_qpos_robot || !ctrl) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  kitchen_action_kernel<<<blocks(n), kB, 0, (hipStream_t)s>>>(n, *p, action, mocap_pos, last_qpos_robot, ctrl);
+  return done("kitchen_action");
+}
+int earl_kitchen_obs(int32_t n, const earl_kitchen_params* p, const double* qpos, const double* goal, const double* noise, double* obs,
+                     earl_stream_t s) {
+  if (n < 0 || !p || !qpos || !goal || !obs) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  kitchen_obs_kernel<<<blocks((long long)n * 46), kB, 0, (hipStream_t)s>>>(n, *p, qpos, goal, noise, obs);
+  return done("kitchen_obs");
 }
 int earl_kitchen_reward(int32_t n, const double* obs, const double* mocap_pos, const double* site_xpos, double* reward,
                         uint8_t* success, earl_stream_t s) {

@@ -101,3 +101,41 @@ def kitchen_reward(obs, mocap_pos, site_xpos):
     _abi.check(lib.earl_kitchen_reward(n, o.data_ptr(), mp.data_ptr(), sx.data_ptr(), rew.data_ptr(), suc.data_ptr(), _stream(o)),
                'kitchen_reward')
   return rew, suc
+
+
+def kitchen_params():
+  """struct earl_kitchen_params with the reference's values (franka_config.xml joint table, KitchenV0 step constants)"""
+  p = _abi.KitchenParams()
+  _abi.check(_abi.load().earl_kitchen_default_params(C.byref(p)), 'kitchen_default_params')
+  return p
+
+
+def kitchen_action(action, mocap_pos, last_qpos_robot, params=None):
+  """KitchenV0.step up to do_simulation (kitchen_multitask_v0.py:91-105, franka_robot.py:172-207, :259-264): action [n,9], mocap_pos
+  [n,3] (updated IN PLACE), last_qpos_robot [n,9] -> ctrl [n,9] (the position targets handed to do_simulation)"""
+  lib = _abi.load()
+  p = params or kitchen_params()
+  a = _cuda(action, torch.float64).contiguous()
+  n = a.shape[0]
+  lq = _cuda(last_qpos_robot, torch.float64).contiguous()
+  assert a.shape == (n, 9) and lq.shape == (n, 9) and mocap_pos.shape == (n, 3) and mocap_pos.dtype == torch.float64 and mocap_pos.is_contiguous()
+  ctrl = torch.empty(n, 9, dtype=torch.float64, device=a.device)
+  with torch.cuda.device(a.device):
+    _abi.check(lib.earl_kitchen_action(n, C.byref(p), a.data_ptr(), mocap_pos.data_ptr(), lq.data_ptr(), ctrl.data_ptr(), _stream(a)), 'kitchen_action')
+  return ctrl
+
+
+def kitchen_obs(qpos, goal, noise=None, params=None):
+  """Robot.get_obs + KitchenV0._get_obs (franka_robot.py:137-168, kitchen_multitask_v0.py:127-139): qpos [n,23], goal [n,23], noise [n,46]
+  (the U(-1, 1) draws of one get_obs in call order) or None -> obs [n,46]"""
+  lib = _abi.load()
+  p = params or kitchen_params()
+  q, g = _cuda(qpos, torch.float64).contiguous(), _cuda(goal, torch.float64).contiguous()
+  n = q.shape[0]
+  u = None if noise is None else _cuda(noise, torch.float64).contiguous()
+  assert q.shape == (n, 23) and g.shape == (n, 23) and (u is None or u.shape == (n, 46))
+  obs = torch.empty(n, 46, dtype=torch.float64, device=q.device)
+  with torch.cuda.device(q.device):
+    _abi.check(lib.earl_kitchen_obs(n, C.byref(p), q.data_ptr(), g.data_ptr(), None if u is None else u.data_ptr(), obs.data_ptr(), _stream(q)),
+               'kitchen_obs')
+  return obs

@@ -14,6 +14,12 @@
  *   earl_kitchen_reward          Kitchen._get_reward_n_score / compute_reward / is_successful (envs/kitchen.py:141-183):
  *                                the numpy part; what the reference reads from the simulator there (mocap position, the
  *                                eight task-site positions) is an input
+ *   earl_kitchen_action          KitchenV0.step up to do_simulation (adept_envs/franka/kitchen_multitask_v0.py:91-105): action clip and
+ *                                scale, mocap update; Robot.step -> Robot_VelAct.ctrl_velocity_limits + Robot.ctrl_position_limits
+ *                                (adept_envs/franka/robot/franka_robot.py:172-207, :259-264): the position targets handed to
+ *                                do_simulation
+ *   earl_kitchen_obs             Robot.get_obs + KitchenV0._get_obs (franka_robot.py:137-168, kitchen_multitask_v0.py:127-139): the
+ *                                observation with sensor noise, the U(-1, 1) draws being an input (row a18)
  * All fp64 like the reference's numpy code; tested bit-exact against goldens recorded from the reference's own
  * functions (tests/golden/make_golden.py: gen_glue) and against the 2,910 Sawyer demonstration rows.
  */
@@ -55,6 +61,28 @@ int earl_minitaur_reward(int32_t n, const double* obs, double distance_weight, d
  * component; success [n]: |obj - goal| <= 0.3.  Either output may be NULL. */
 int earl_kitchen_reward(int32_t n, const double* obs, const double* mocap_pos, const double* site_xpos, double* reward,
                         uint8_t* success, earl_stream_t stream);
+
+/* Joint table of the kitchen robot config (adept_envs/franka/robot/franka_config.xml:17-57, as read by Robot._read_specs_from_config) and
+ * the step constants of KitchenV0 (kitchen_multitask_v0.py:40-53, :78-79): filled by earl_kitchen_default_params. */
+typedef struct earl_kitchen_params {
+  double pos_bound[23][2], vel_bound[23][2], pos_noise_amp[23];
+  double act_mid[9], act_amp[9];                 /* 0, 2.0 */
+  double mocap_range[3];                         /* 0.01 */
+  double mocap_clip_lower[3], mocap_clip_upper[3];
+  double step_duration;                          /* skip * timestep = 40 * 0.002 */
+  double robot_noise_ratio;                      /* 0.1 */
+} earl_kitchen_params;
+int earl_kitchen_default_params(earl_kitchen_params* p);   /* host call */
+
+/* action [n,9] float64 (a float32 action is promoted exactly as numpy does: the clip keeps float32, the scaling promotes),
+ * mocap_pos [n,3] updated in place, last_qpos_robot [n,9] = qpos_robot of the newest cached (noisy) observation,
+ * ctrl [n,9] = the targets passed to do_simulation (MuJoCo itself uses the first nu = 2 and clamps them to the actuators' ctrlrange). */
+int earl_kitchen_action(int32_t n, const earl_kitchen_params* p, const double* action, double* mocap_pos, const double* last_qpos_robot,
+                        double* ctrl, earl_stream_t stream);
+/* qpos [n,23], goal [n,23], noise [n,46] = the four env.np_random.uniform(-1, 1) calls of one get_obs in order (robot qpos 9, robot
+ * qvel 9, object qpos 14, object qvel 14), or NULL for no noise (env.initializing): obs [n,46] = noisy robot qpos, noisy object qpos, goal */
+int earl_kitchen_obs(int32_t n, const earl_kitchen_params* p, const double* qpos, const double* goal, const double* noise, double* obs,
+                     earl_stream_t stream);
 
 #ifdef __cplusplus
 }

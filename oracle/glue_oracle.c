@@ -122,3 +122,33 @@ void oracle_kitchen_reward(int32_t n, const double* obs, const double* mocap, co
     if (success) success[i] = dist <= 0.3;
   }
 }
+
+
+/* KitchenV0.step up to do_simulation (/root/reference/earl_benchmark/envs/kitchen_assets/adept_envs/adept_envs/franka/kitchen_multitask_v0.py:91-105)
+ * and Robot.step's limits (.../franka/robot/franka_robot.py:172-174 ctrl_position_limits, :259-264 Robot_VelAct.ctrl_velocity_limits);
+ * pinned by tests/golden/kitchen_step.npz (recorded from those methods).  The parameter struct is the public one of earl_glue.h. */
+static double clipd_(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+void oracle_kitchen_action(int32_t n, const earl_kitchen_params* p, const double* action, double* mocap, const double* last_qp, double* ctrl) {
+  for (int32_t i = 0; i < n; ++i) {
+    double a[9];
+    for (int k = 0; k < 9; ++k) a[k] = p->act_mid[k] + clipd_(action[(size_t)i * 9 + k], -1.0, 1.0) * p->act_amp[k];   /* :92-95 */
+    for (int k = 0; k < 3; ++k)                                                                                         /* :99-102 */
+      mocap[(size_t)i * 3 + k] = clipd_(mocap[(size_t)i * 3 + k] + a[k] * p->mocap_range[k], p->mocap_clip_lower[k], p->mocap_clip_upper[k]);
+    for (int k = 0; k < 9; ++k) {
+      const double v = clipd_(a[k], p->vel_bound[k][0], p->vel_bound[k][1]);                                            /* franka_robot.py:262 */
+      ctrl[(size_t)i * 9 + k] = clipd_(last_qp[(size_t)i * 9 + k] + v * p->step_duration, p->pos_bound[k][0], p->pos_bound[k][1]);   /* :263, :173 */
+    }
+  }
+}
+/* Robot.get_obs + KitchenV0._get_obs (franka_robot.py:137-168, kitchen_multitask_v0.py:127-139) */
+void oracle_kitchen_obs(int32_t n, const earl_kitchen_params* p, const double* qpos, const double* goal, const double* noise, double* obs) {
+  for (int32_t i = 0; i < n; ++i)
+    for (int k = 0; k < 46; ++k) {
+      double v;
+      if (k < 23) {
+        v = qpos[(size_t)i * 23 + k];
+        if (noise) v = v + (p->robot_noise_ratio * p->pos_noise_amp[k]) * noise[(size_t)i * 46 + (k < 9 ? k : k + 9)];
+      } else v = goal[(size_t)i * 23 + (k - 23)];
+      obs[(size_t)i * 46 + k] = v;
+    }
+}

@@ -548,5 +548,84 @@ def main():
       print('   exact-boundary rows (numpy 1.22 vs 2 compare hazard):', data['boundary_rows'])
 
 
+def gen_kitchen_step(rng, m=512):
+  """KitchenV0.step (kitchen_multitask_v0.py:91-105: action clip / scale, mocap update), Robot.step -> Robot_VelAct.ctrl_velocity_limits
+  + Robot.ctrl_position_limits (franka_robot.py:172-207, :259-264) and Robot.get_obs + KitchenV0._get_obs (franka_robot.py:137-168,
+  kitchen_multitask_v0.py:127-139) called on synthetic states with a stand-in for `self.sim` / `env`: the numpy part of one kitchen env
+  step around the 40 mj_step calls.  The joint table (bounds, noise amplitudes) is read by the reference's own
+  Robot._read_specs_from_config from its franka_config.xml."""
+  import collections
+  import types
+  A = 'envs/kitchen_assets/adept_envs/adept_envs/'
+  import importlib.util                        # the module by path: the adept_envs package itself imports gym's registry
+  spec = importlib.util.spec_from_file_location('ref_adept_config', os.path.join(REF, 'earl_benchmark', A, 'utils/config.py'))
+  cfgmod = importlib.util.module_from_spec(spec); spec.loader.exec_module(cfgmod)      # numpy + xml only
+  get_config_root_node, read_config_from_node = cfgmod.get_config_root_node, cfgmod.read_config_from_node
+  read_specs = _method(A + 'franka/robot/franka_robot.py', 'Robot', '_read_specs_from_config',
+                       extra={'get_config_root_node': get_config_root_node, 'read_config_from_node': read_config_from_node})
+  robot = types.SimpleNamespace(n_dofs=23, n_jnt=9, n_obj=14, has_obj=True, is_hardware=False, overlay=False)
+  read_specs(robot, os.path.join(REF, 'earl_benchmark', A, 'franka/robot/franka_config.xml'))
+  observation = collections.namedtuple('observation', ['time', 'qpos_robot', 'qvel_robot', 'qpos_object', 'qvel_object'])
+  robot.observation_cache = collections.deque([], maxlen=5)
+  fr = A + 'franka/robot/franka_robot.py'
+  robot.ctrl_velocity_limits = types.MethodType(_method(fr, 'Robot_VelAct', 'ctrl_velocity_limits'), robot)
+  robot.ctrl_position_limits = types.MethodType(_method(fr, 'Robot', 'ctrl_position_limits'), robot)
+  robot_step = _method(fr, 'Robot', 'step', extra={'time': __import__('time')})
+  robot_get_obs = _method(fr, 'Robot', 'get_obs', extra={'observation': observation})
+  kstep = _method(A + 'franka/kitchen_multitask_v0.py', 'KitchenV0', 'step')
+  kobs = _method(A + 'franka/kitchen_multitask_v0.py', 'KitchenV0', '_get_obs')
+
+  class Rng:                                   # env.np_random: hands out the recorded U(-1, 1) draws in call order
+    def __init__(self, u): self.u, self.i = u, 0
+    def uniform(self, low, high, size):
+      assert (low, high) == (-1.0, 1.0)
+      out = self.u[self.i:self.i + size].copy(); self.i += size
+      return out
+
+  act = rng.uniform(-1.4, 1.4, size=(m, 9))
+  act[::7] = rng.choice([-1.0, 1.0, 0.0, -0.999, 1e-9], size=act[::7].shape)
+  act32 = act.astype(np.float32)
+  mocap = rng.uniform([-0.75, -0.15, 1.75], [0.45, 0.55, 2.65], size=(m, 3))
+  mocap[::5] = rng.choice([-0.7, 0.4, -0.1, 0.5, 1.8, 2.6], size=mocap[::5].shape) + rng.normal(size=mocap[::5].shape) * 0.004
+  last_qp = rng.uniform(robot.robot_pos_bound[:9, 0] - 0.3, robot.robot_pos_bound[:9, 1] + 0.3, size=(m, 9))
+  qpos = rng.uniform(-1.5, 1.5, size=(m, 23)); qvel = rng.normal(size=(m, 23))
+  goal = rng.uniform(-1.5, 1.5, size=(m, 23))
+  u = rng.uniform(-1.0, 1.0, size=(m, 46))     # the 46 uniforms of one get_obs call: qp 9, qv 9, obj qp 14, obj qv 14
+  new_mocap, ctrl, new_mocap32, ctrl32, obs = (np.zeros((m, 3)), np.zeros((m, 9)), np.zeros((m, 3)), np.zeros((m, 9)), np.zeros((m, 46)))
+  for i in range(m):
+    for a_in, nm, ct in ((act[i], new_mocap, ctrl), (act32[i], new_mocap32, ctrl32)):
+      got = {}
+      env = types.SimpleNamespace(initializing=False, act_mid=np.zeros(9), act_amp=2.0 * np.ones(9), range=np.array([0.01, 0.01, 0.01]),
+                                  mocap_pos_clip_lower=np.array([-0.7, -0.1, 1.8]), mocap_pos_clip_upper=np.array([0.4, 0.5, 2.6]), skip=40,
+                                  model=types.SimpleNamespace(opt=types.SimpleNamespace(timestep=0.002)), obs_dict={'t': 0.0},
+                                  sim=types.SimpleNamespace(data=types.SimpleNamespace(mocap_pos=mocap[i:i + 1].copy()),
+                                                            model=types.SimpleNamespace(opt=types.SimpleNamespace(timestep=0.002))))
+      env.do_simulation = lambda c, nfr, got=got: got.update(ctrl=np.array(c, float), n_frames=nfr)
+      env._get_obs = lambda: None
+      env._get_reward_n_score = lambda d: ({'r_total': 0.0}, 0.0)
+      robot.observation_cache.clear()
+      robot.observation_cache.append(observation(0.0, last_qp[i].copy(), None, None, None))
+      env.robot = types.SimpleNamespace(step=lambda e, a, step_duration: robot_step(robot, e, a, step_duration))
+      kstep(env, a_in)
+      assert got['n_frames'] == 40
+      nm[i], ct[i] = env.sim.data.mocap_pos[0], got['ctrl']
+    env = types.SimpleNamespace(initializing=False, np_random=Rng(u[i]), robot_noise_ratio=0.1, goal_concat=True, goal=goal[i].copy(),
+                                sim=types.SimpleNamespace(data=types.SimpleNamespace(qpos=qpos[i].copy(), qvel=qvel[i].copy(), time=0.5)))
+    env.robot = types.SimpleNamespace(get_obs=lambda e, robot_noise_ratio: robot_get_obs(robot, e, robot_noise_ratio=robot_noise_ratio))
+    obs[i] = kobs(env)
+  return dict(kstep_action=act, kstep_mocap=mocap, kstep_last_qpos=last_qp, kstep_new_mocap=new_mocap, kstep_ctrl=ctrl,
+              kstep_new_mocap_f32act=new_mocap32, kstep_ctrl_f32act=ctrl32, kobs_qpos=qpos, kobs_goal=goal, kobs_uniform=u, kobs_obs=obs,
+              kitchen_pos_bound=robot.robot_pos_bound.copy(), kitchen_vel_bound=robot.robot_vel_bound.copy(),
+              kitchen_pos_noise_amp=robot.robot_pos_noise_amp.copy())
+
+
 if __name__ == '__main__':
+  if len(sys.argv) > 1 and sys.argv[1] == 'kitchen_step':      # added later: own stream, nothing else rewritten
+    data = gen_kitchen_step(np.random.default_rng(20221004))
+    np.savez_compressed(os.path.join(HERE, 'kitchen_step.npz'), **data)
+    print('kitchen_step:', {k: getattr(v, 'shape', ()) for k, v in data.items()})
+    print('  mocap rows clipped:', int((np.abs(data['kstep_new_mocap'] - (data['kstep_mocap'] + np.clip(data['kstep_action'][:, :3], -1, 1) * 2.0 * 0.01)) > 0).any(1).sum()),
+          ' ctrl entries at a position bound:', int(((data['kstep_ctrl'] == data['kitchen_pos_bound'][:9, 0]) | (data['kstep_ctrl'] == data['kitchen_pos_bound'][:9, 1])).sum()),
+          ' f32-action rows that differ from f64:', int((data['kstep_ctrl'] != data['kstep_ctrl_f32act']).any(1).sum()))
+    sys.exit(0)
   main()

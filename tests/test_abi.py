@@ -51,7 +51,7 @@ def test_every_struct_layout_matches_what_gcc_sees(tmp_path):
   import subprocess
   from earl_benchmark_amd.physics import CollisionModelStruct, LinkModelStruct
   mirrors = {'earl_tabletop_cfg': _abi.TabletopCfg, 'earl_tabletop_state': _abi.TabletopState, 'earl_tabletop_out': _abi.TabletopOut,
-             'earl_motor_params': _abi.MotorParams, 'earl_link_model': LinkModelStruct, 'earl_collision_model': CollisionModelStruct, 'earl_sawyer_cfg': _abi.SawyerCfg,
+             'earl_motor_params': _abi.MotorParams, 'earl_kitchen_params': _abi.KitchenParams, 'earl_link_model': LinkModelStruct, 'earl_collision_model': CollisionModelStruct, 'earl_sawyer_cfg': _abi.SawyerCfg,
              'earl_sawyer_state': _abi.SawyerState, 'earl_sawyer_out': _abi.SawyerOut}
   lines = []
   for cname, cls in mirrors.items():

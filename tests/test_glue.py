@@ -67,3 +67,24 @@ def test_kitchen_reward_and_success_match_the_reference_method_bit_for_bit():
   base = -10 * np.linalg.norm(z['kitchen_obs'][:, 9:23] - z['kitchen_obs'][:, 32:46], axis=1)
   assert (r > base + 0.5).sum() > 500 and (r < base).sum() > 200          # bonus and reaching branches
   assert list(z['kitchen_component_start']) == [9, 11, 13, 15, 17, 19, 20, 22] and list(z['kitchen_component_len']) == [2, 2, 2, 2, 2, 1, 2, 1]
+
+
+def test_kitchen_step_and_obs_glue_match_the_reference_methods_bit_for_bit():
+  """goldens (make_golden.py: gen_kitchen_step): KitchenV0.step / _get_obs, Robot.step / get_obs / ctrl_position_limits and
+  Robot_VelAct.ctrl_velocity_limits compiled from the reference source and run on synthetic states, the joint table read by the reference's
+  own Robot._read_specs_from_config"""
+  z = load_golden('kitchen_step')
+  p = go.kitchen_params(z['kitchen_pos_bound'], z['kitchen_vel_bound'], z['kitchen_pos_noise_amp'])
+  mp, ctrl = go.kitchen_action(p, z['kstep_action'], z['kstep_mocap'], z['kstep_last_qpos'])
+  assert (mp == z['kstep_new_mocap']).all() and (ctrl == z['kstep_ctrl']).all()
+  # float32 actions: np.clip keeps float32, the scaling promotes -- the same as promoting first (the clip bounds are exact in float32)
+  mp32, ctrl32 = go.kitchen_action(p, z['kstep_action'].astype(np.float32).astype(np.float64), z['kstep_mocap'], z['kstep_last_qpos'])
+  assert (mp32 == z['kstep_new_mocap_f32act']).all() and (ctrl32 == z['kstep_ctrl_f32act']).all()
+  obs = go.kitchen_obs(p, z['kobs_qpos'], z['kobs_goal'], z['kobs_uniform'])
+  assert (obs == z['kobs_obs']).all()
+  clean = go.kitchen_obs(p, z['kobs_qpos'], z['kobs_goal'], None)
+  assert (clean == np.concatenate([z['kobs_qpos'], z['kobs_goal']], 1)).all()
+  # the fixture exercises every clip: mocap box, velocity bounds (|a| up to 2 < 10: never), position bounds
+  assert ((mp == [-0.7, -0.1, 1.8]) | (mp == [0.4, 0.5, 2.6])).any(0).all()
+  assert (ctrl == z['kitchen_pos_bound'][:9, 0]).any() and (ctrl == z['kitchen_pos_bound'][:9, 1]).any()
+  assert np.abs(obs[:, :9] - z['kobs_qpos'][:, :9]).max() <= 0.1 * 0.1 + 1e-15 and np.abs(obs[:, 11:17] - z['kobs_qpos'][:, 11:17]).max() <= 0.1 * 0.0005 + 1e-15

@@ -79,3 +79,23 @@ def test_kitchen_reward_hip_matches_the_reference_goldens(t):
   r, s = glue.kitchen_reward(dev(t, z['kitchen_obs']), dev(t, z['kitchen_mocap']), dev(t, z['kitchen_site_xpos']))
   assert (r.cpu().numpy() == z['kitchen_reward']).all() and (s.cpu().numpy() == z['kitchen_success']).all()
   assert list(glue.KITCHEN_SITES) == [str(x) for x in z['kitchen_site_names']]
+
+
+def test_kitchen_step_and_obs_glue_hip_match_the_reference_goldens(t):
+  """earl_kitchen_action / earl_kitchen_obs (rows a17, a18) against values recorded from the reference's own methods; the default
+  parameter table compiled into the library equals what the reference reads from its franka_config.xml"""
+  from earl_benchmark_amd import glue
+  z = load_golden('kitchen_step')
+  p = glue.kitchen_params()
+  assert (np.ctypeslib.as_array(p.pos_bound) == z['kitchen_pos_bound']).all() and (np.ctypeslib.as_array(p.vel_bound) == z['kitchen_vel_bound']).all()
+  assert (np.ctypeslib.as_array(p.pos_noise_amp) == z['kitchen_pos_noise_amp']).all() and p.step_duration == 40 * 0.002
+  mp = dev(t, z['kstep_mocap'].copy())
+  ctrl = glue.kitchen_action(dev(t, z['kstep_action']), mp, dev(t, z['kstep_last_qpos']))
+  assert (mp.cpu().numpy() == z['kstep_new_mocap']).all() and (ctrl.cpu().numpy() == z['kstep_ctrl']).all()
+  mp = dev(t, z['kstep_mocap'].copy())
+  ctrl = glue.kitchen_action(dev(t, z['kstep_action'].astype(np.float32)), mp, dev(t, z['kstep_last_qpos']))
+  assert (mp.cpu().numpy() == z['kstep_new_mocap_f32act']).all() and (ctrl.cpu().numpy() == z['kstep_ctrl_f32act']).all()
+  obs = glue.kitchen_obs(dev(t, z['kobs_qpos']), dev(t, z['kobs_goal']), dev(t, z['kobs_uniform']))
+  assert (obs.cpu().numpy() == z['kobs_obs']).all()
+  clean = glue.kitchen_obs(dev(t, z['kobs_qpos']), dev(t, z['kobs_goal']))
+  assert (clean.cpu().numpy() == np.concatenate([z['kobs_qpos'], z['kobs_goal']], 1)).all()
