@@ -45,18 +45,20 @@ class SawyerCfg(C.Structure):   # struct earl_sawyer_cfg (include/earl_physics.h
   _fields_ = [('n', C.c_int32), ('env_offset', C.c_int32), ('reward_type', C.c_int32), ('horizon', C.c_int32),
               ('frame_skip', C.c_int32), ('att_hand', C.c_int32), ('att_right', C.c_int32), ('att_left', C.c_int32),
               ('att_obj', C.c_int32), ('obj_dof', C.c_int32), ('obj_kind', C.c_int32), ('n_goal_rows', C.c_int32), ('goal_change_frequency', C.c_int32), ('n_wide', C.c_int32),
+              ('att_grasp', C.c_int32), ('att_lpad', C.c_int32), ('att_rpad', C.c_int32), ('pad2_', C.c_int32),
               ('action_scale', C.c_double),
               ('mocap_low', C.c_double * 3), ('mocap_high', C.c_double * 3), ('mocap_quat', C.c_double * 4),
               ('success_radius', C.c_double), ('hand_init_pos', C.c_double * 3), ('obj_init_pos', C.c_double * 3),
               ('obj_init_angle', C.c_double), ('angle_noise', C.c_double * 2),
               ('obj_low', C.c_double * 3), ('obj_high', C.c_double * 3), ('obj_reject_xy', C.c_double * 2), ('obj_reject_radius', C.c_double),
               ('goal_table', C.c_void_p), ('wide_table', C.c_void_p), ('wide_shift', C.c_double * 3), ('wide_noise', C.c_double),
+              ('init_tcp', C.c_double * 3), ('box_corners', C.c_double * 3 * 4),
               ('seed', C.c_uint64), ('counter', C.c_uint64), ('step_counter', C.c_uint64)]
 
 
 class SawyerState(C.Structure):
   _fields_ = [('qpos', C.c_void_p), ('qvel', C.c_void_p), ('mocap_pos', C.c_void_p), ('goal', C.c_void_p),
-              ('steps_since_reset', C.c_void_p), ('steps_since_goal_change', C.c_void_p)]
+              ('steps_since_reset', C.c_void_p), ('steps_since_goal_change', C.c_void_p), ('obj_init', C.c_void_p)]
 
 
 class SawyerOut(C.Structure):

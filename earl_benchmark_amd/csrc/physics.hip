@@ -192,7 +192,7 @@ struct SharedData {
   SymLds<NV> M;                      // mass matrix
   union {
     struct { double Xq1[NV][4], Xp1[NV][3]; } k2;                    // second buffer of the doubling
-    struct { double att[4][3]; } emit;                               // observation epilogue (after the last timestep of an env step)
+    struct { double att[8][3]; } emit;                               // observation epilogue (after the last timestep of an env step)
     struct {
       double S[NV][6];                 // motion subspace, world coordinates about the origin: [angular; linear] (every lane keeps its own column in registers)
       double I10[NV][10];
@@ -1107,13 +1107,73 @@ __device__ __forceinline__ void door_reward(const earl_sawyer_cfg& cfg, const V3
   }
 }
 
+// ---- metaworld reward_utils / SawyerXYZEnv._gripper_caging_reward [UPSTREAM metaworld, not in the reference tree; UNPINNED]:
+// restated as in oracle/sawyer_oracle.py (tolerance_long_tail, rect_prism_tolerance, hamacher_product, gripper_caging_reward)
+__device__ __forceinline__ double tol_long_tail(double x, double lo, double hi, double margin) {
+#pragma clang fp contract(off)
+  if (lo <= x && x <= hi) return 1.0;
+  if (margin == 0) return 0.0;
+  const double d = (x < lo ? lo - x : x - hi) / margin;
+  const double scale = sqrt(1 / 0.1 - 1);
+  return 1 / ((d * scale) * (d * scale) + 1);
+}
+__device__ __forceinline__ bool in_rng(double a, double b, double c) { return c >= b ? (b <= a && a <= c) : (c <= a && a <= b); }
+__device__ __forceinline__ double rect_prism_tol(const V3 cur, const double* zero, const double* one) {
+#pragma clang fp contract(off)
+  if (in_rng(cur.x, zero[0], one[0]) && in_rng(cur.y, zero[1], one[1]) && in_rng(cur.z, zero[2], one[2]))
+    return (cur.x - zero[0]) / (one[0] - zero[0]) * ((cur.y - zero[1]) / (one[1] - zero[1])) * ((cur.z - zero[2]) / (one[2] - zero[2]));
+  return 1.0;
+}
+__device__ __forceinline__ double hamacher(double a, double b) {
+#pragma clang fp contract(off)
+  const double den = a + b - (a * b);
+  return den > 0 ? (a * b) / den : 0.0;
+}
+// SawyerPegV2.compute_reward, reward_type 'dense' (sawyer_peg.py:231-299); head = obs[4:7] (site pegHead), tcp = obs[:3] (hand)
+__device__ __forceinline__ double peg_dense_reward(const earl_sawyer_cfg& cfg, const V3 tcp, const double tcp_opened, const V3 head, const V3 grasp,
+                                                   const V3 lpad, const V3 rpad, const V3 tcpc, const V3 target, const double* __restrict__ oi,
+                                                   const double effort) {
+#pragma clang fp contract(off)
+  const V3 obj = grasp;                                   // obs[4:7] - pegHead + pegGrasp with obs[4:7] == pegHead
+  const V3 e = vsub(obj, tcp);
+  const double tcp_to_obj = sqrt(e.x * e.x + e.y * e.y + e.z * e.z);
+  const V3 ht{(head.x - target.x) * 1.0, (head.y - target.y) * 2.0, (head.z - target.z) * 2.0};
+  const double obj_to_target = sqrt(ht.x * ht.x + ht.y * ht.y + ht.z * ht.z);
+  const V3 hi{(oi[3] - target.x) * 1.0, (oi[4] - target.y) * 2.0, (oi[5] - target.z) * 2.0};
+  double in_place = tol_long_tail(obj_to_target, 0.0, 0.05, sqrt(hi.x * hi.x + hi.y * hi.y + hi.z * hi.z));
+  const double box1 = rect_prism_tol(head, cfg.box_corners[0], cfg.box_corners[1]), box2 = rect_prism_tol(head, cfg.box_corners[2], cfg.box_corners[3]);
+  in_place = hamacher(in_place, hamacher(box2, box1));
+  const bool lifted = tcp_to_obj < 0.08 && tcp_opened > 0 && obj.z - 0.01 > oi[2];
+  double grasped = 1.0;
+  if (!lifted) {
+    // _gripper_caging_reward(action, obj, obj_radius 0.0075, pad_success_thresh 0.03, object_reach_radius 0.01, xz_thresh 0.005, high_density)
+    const double pl = fabs(lpad.y - obj.y), pr = fabs(rpad.y - obj.y);
+    const double ml = fabs(fabs(lpad.y - oi[1]) - 0.03), mr = fabs(fabs(rpad.y - oi[1]) - 0.03);
+    const double caging_y = hamacher(tol_long_tail(pl, 0.0075, 0.03, ml), tol_long_tail(pr, 0.0075, 0.03, mr));
+    const double ix = oi[0] - cfg.init_tcp[0], iz = oi[2] - cfg.init_tcp[2];
+    const double dx = tcpc.x - obj.x, dz = tcpc.z - obj.z;
+    const double caging_xz = tol_long_tail(sqrt(dx * dx + dz * dz), 0.0, 0.005, sqrt(ix * ix + iz * iz) - 0.005);
+    const double closed = fmin(fmax(0.0, effort), 1.0) / 1.0;
+    const double caging = hamacher(caging_y, caging_xz);
+    const double gripping = caging > 0.97 ? closed : 0.0;
+    grasped = (hamacher(caging, gripping) + caging) / 2;
+  }
+  double r = hamacher(grasped, in_place);
+  if (lifted) r += 1.0 + 5 * in_place;
+  if (obj_to_target <= 0.05) r = 10.0;
+  return r;
+}
+
 // obs[14] + reward + flags of one env from the kinematics in LDS (sawyer_door.py:86-94, :141-177); the whole group calls it
 template <int NV>
 __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model& m, const earl_sawyer_cfg& cfg, const int sub, const bool live,
-                                            const double* __restrict__ goal, double* __restrict__ obs, float* reward, uint8_t* success) {
+                                            const double* __restrict__ goal, double* __restrict__ obs, float* reward, uint8_t* success,
+                                            const double* __restrict__ obj_init = nullptr, const double effort = 0.0) {
 #pragma clang fp contract(off)
-  if (sub < 4) {
-    const int k = sub == 0 ? cfg.att_hand : (sub == 1 ? cfg.att_right : (sub == 2 ? cfg.att_left : cfg.att_obj));
+  const bool peg_dense = cfg.obj_kind >= 1 && cfg.reward_type != 0 && obj_init != nullptr;
+  if (sub < (peg_dense ? 7 : 4)) {
+    const int k = sub == 0 ? cfg.att_hand : (sub == 1 ? cfg.att_right : (sub == 2 ? cfg.att_left : (sub == 3 ? cfg.att_obj :
+                  (sub == 4 ? cfg.att_grasp : (sub == 5 ? cfg.att_lpad : cfg.att_rpad)))));
     const V3 p = attachment<NV>(s, m, k);
     s.emit.att[sub][0] = p.x; s.emit.att[sub][1] = p.y; s.emit.att[sub][2] = p.z;
   }
@@ -1131,6 +1191,12 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model
   if (sub == 0 && live) {
     double r; bool ok;
     door_reward(cfg, ld3(s.emit.att[0]), ld3(s.emit.att[3]), ld3(goal + 4), r, ok);
+    if (peg_dense) {
+      const V3 rr = ld3(s.emit.att[1]), ll = ld3(s.emit.att[2]), dg = vsub(rr, ll);
+      const double opened = fmin(fmax(sqrt(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z) / 0.1, 0.0), 1.0);      // obs[3]
+      r = peg_dense_reward(cfg, ld3(s.emit.att[0]), opened, ld3(s.emit.att[3]), ld3(s.emit.att[4]), ld3(s.emit.att[5]), ld3(s.emit.att[6]),
+                           scl(add(rr, ll), 0.5), ld3(goal + 4), obj_init, effort);
+    }
     if (reward) *reward = (float)r;
     if (success) *success = ok ? 1 : 0;
   }
@@ -1174,7 +1240,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
     const size_t row = (size_t)t * n + env;
     sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.out.obs + row * 14, a.out.reward ? a.out.reward + row : nullptr,
-                    a.out.success ? a.out.success + row : nullptr);
+                    a.out.success ? a.out.success + row : nullptr, a.st.obj_init ? a.st.obj_init + (size_t)env * 6 : nullptr, (double)act.w);
     ++steps;
     if (sub == 0 && live && a.out.done) a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
     if (gcf > 0 && ++sgc >= gcf) {
@@ -1292,6 +1358,11 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
   const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
   substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
   sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.reset_obs + (size_t)env * 14, nullptr, nullptr);
+  // reset_model keeps obj_init_pos and the pegHead site of the freshly placed peg for the dense reward (sawyer_peg.py:213-215)
+  if (resetting && cfg.obj_kind >= 1 && a.st.obj_init && sub < 6) {
+    double* oi = a.st.obj_init + (size_t)env * 6;
+    oi[sub] = sub < 3 ? s.qp[cfg.obj_dof + sub] : s.emit.att[3][sub - 3];
+  }
 }
 
 // compute_reward / is_successful on given observations (sawyer_door.py:141-177), one lane per row
@@ -1362,7 +1433,8 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
   if (cfg->frame_skip < 0 || cfg->att_hand < 0 || cfg->att_right < 0 || cfg->att_left < 0 || cfg->att_obj < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
   SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
-  if (cfg->obj_kind >= 1 && cfg->reward_type != 0) return EARL_ERR_ARG;   // the peg's dense reward (metaworld reward_utils, upstream) is not built
+  if (cfg->obj_kind >= 1 && cfg->reward_type != 0 && (!st->obj_init || cfg->att_grasp < 0 || cfg->att_lpad < 0 || cfg->att_rpad < 0))
+    return EARL_ERR_ARG;                                  // the peg's dense reward needs the reset-time state and the pad / grasp attachments
   if (nv == 10) {
     if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<grid_for<10, 64>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
     else sawyer_rollout_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);

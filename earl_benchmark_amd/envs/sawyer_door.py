@@ -75,12 +75,14 @@ class SawyerDoor:
     self.steps_since_reset = torch.zeros(n, dtype=torch.int32, **kw)
     self.interventions = torch.zeros(n, dtype=torch.int32, **kw)
     self.steps_since_goal_change = torch.zeros(n, dtype=torch.int32, **kw)
+    self.obj_init = torch.zeros(n, 6, dtype=torch.float64, **kw)      # obj_init_pos, peg_head_pos_init kept by reset_model (peg dense reward)
     self.lifelong_return_t = torch.zeros(n, dtype=torch.float64, **kw)
     self.total_step_count = 0
 
     cfg = _abi.SawyerCfg(n=n, env_offset=int(env_offset), reward_type=_abi.REWARD_TYPES[reward_type], horizon=INT32_MAX,
                          frame_skip=FRAME_SKIP, att_hand=names.index('hand'), att_right=names.index('rightEndEffector'),
-                         att_left=names.index('leftEndEffector'), action_scale=1.0 / 100, seed=int(seed) & (2**64 - 1), counter=0)
+                         att_left=names.index('leftEndEffector'), att_grasp=-1, att_lpad=-1, att_rpad=-1, action_scale=1.0 / 100,
+                         seed=int(seed) & (2**64 - 1), counter=0)
     cfg.mocap_low[:] = (-0.5, 0.40, 0.05)      # hand_low / hand_high: sawyer_door.py:25-26, sawyer_peg.py:67-68 (mocap bounds = hand bounds [UPSTREAM])
     cfg.mocap_high[:] = (0.5, 1.0, 0.5)
     cfg.mocap_quat[:] = (1.0, 0.0, 1.0, 0.0)
@@ -91,13 +93,14 @@ class SawyerDoor:
     self._cfg = cfg
     self._st = _abi.SawyerState(qpos=self.qpos.data_ptr(), qvel=self.qvel.data_ptr(), mocap_pos=self.mocap_pos.data_ptr(),
                                 goal=self.goal_t.data_ptr(), steps_since_reset=self.steps_since_reset.data_ptr(),
-                                steps_since_goal_change=self.steps_since_goal_change.data_ptr())
+                                steps_since_goal_change=self.steps_since_goal_change.data_ptr(), obj_init=self.obj_init.data_ptr())
     self._cfg_ref, self._st_ref = C.byref(self._cfg), C.byref(self._st)
 
     self.action_space = Box(-1.0, 1.0, (4,), np.float32)
     self.observation_space = Box(-np.inf, np.inf, (self.OBS_DIM,), np.float64)
     with torch.cuda.device(dev):
       self._reset_state = self._settle_reset_hand()
+      self._after_settle()
       self.reset()
     self.interventions.zero_()
 
@@ -116,6 +119,9 @@ class SawyerDoor:
     cfg.success_radius = 0.02
     cfg.obj_init_angle = float(self.obj_init_angle)
     cfg.angle_noise[:] = (lo, hi)
+
+  def _after_settle(self):
+    pass
 
   # ------------------------------------------------------------------ internals
   @property
@@ -250,12 +256,12 @@ class SawyerDoor:
 
   def state_dict(self):
     return {k: getattr(self, k).clone() for k in ('qpos', 'qvel', 'mocap_pos', 'goal_t', 'steps_since_reset', 'interventions',
-                                                  'steps_since_goal_change', 'lifelong_return_t')} | {
+                                                  'steps_since_goal_change', 'lifelong_return_t', 'obj_init')} | {
                                                       'counter': int(self._cfg.counter), 'total_step_count': self.total_step_count}
 
   def load_state_dict(self, sd):
     for k in ('qpos', 'qvel', 'mocap_pos', 'goal_t', 'steps_since_reset', 'interventions', 'steps_since_goal_change',
-              'lifelong_return_t'):
+              'lifelong_return_t', 'obj_init'):
       getattr(self, k).copy_(sd[k])
     self._cfg.counter = int(sd['counter'])
     self.total_step_count = int(sd['total_step_count'])

@@ -9,8 +9,9 @@ the peg's free joint as three translations + a quaternion).
 STATUS: the dynamics are this build's own stepper and contact model (the peg as a chain of inscribed spheres against the
 gripper plates and the hole block, its corners as points against the table and the block); parity with MuJoCo is UNPINNED
 (DESIGN.md section 9).  Pinned by the reference's data: the sparse success rule (bit-exact on the 1,815 demonstration rows), the
-reset observation (hand pose, gripper opening 1.0, pegHead at z = 0.02), initial / goal tables.  Not built: the dense reward
-(metaworld's reward_utils and _gripper_caging_reward are upstream code absent from the reference tree).
+reset observation (hand pose, gripper opening 1.0, pegHead at z = 0.02), initial / goal tables.  The dense reward is evaluated in the
+kernel from metaworld's reward_utils / _gripper_caging_reward as restated in oracle/sawyer_oracle.py -- upstream code absent from the
+reference tree, hence UNPINNED (the kernel is tested against that restatement only).
 """
 import numpy as np
 import torch
@@ -37,9 +38,6 @@ class SawyerPeg(SawyerDoor):
   TARGET_RADIUS = 0.05                    # sawyer_peg.py:62
 
   def __init__(self, reward_type='sparse', reset_at_goal=False, wide_init=False, **kw):
-    if reward_type != 'sparse':
-      raise NotImplementedError('sawyer_peg: only the sparse reward is built (the dense one needs metaworld reward_utils / '
-                                '_gripper_caging_reward, which are not in the reference tree)')
     self.wide_init = bool(wide_init)
     super().__init__(reward_type=reward_type, reset_at_goal=reset_at_goal, **kw)
 
@@ -50,8 +48,28 @@ class SawyerPeg(SawyerDoor):
     self.initial_states = initial_states.copy()
     self.goal_states = goal_states.copy()
 
+  def _after_settle(self):
+    # SawyerXYZEnv._reset_hand ends with self.init_tcp = self.tcp_center [UPSTREAM]: midpoint of the two finger sites at the settled pose
+    q, v = self._reset_state
+    kw = dict(dtype=torch.float64, device=self.device)
+    _, _, att = self.model.forward(q[None].contiguous(), v[None].contiguous(), torch.tensor([[float(x) for x in self.hand_init_pos]], **kw),
+                                   torch.tensor([[1.0, 0.0, 1.0, 0.0]], **kw), torch.tensor([[-1.0, 1.0]], **kw))
+    names = self.model.att_names
+    tcp = 0.5 * (att[0, names.index('rightEndEffector')] + att[0, names.index('leftEndEffector')])
+    self._cfg.init_tcp[:] = [float(x) for x in tcp.cpu()]
+
+  def compute_reward(self, obs, actions=None):
+    if self._reward_type != 'sparse':
+      raise NotImplementedError('sawyer_peg: the dense reward reads simulator state (sites, pads, reset-time positions) and is evaluated '
+                                'inside step / rollout only; compute_reward(obs) is available for the sparse reward')
+    return super().compute_reward(obs, actions)
+
   def _task_cfg(self, cfg, names):
     cfg.att_obj = names.index('pegHead')                    # _get_pos_objects, sawyer_peg.py:186-187
+    # dense reward (sawyer_peg.py:231-299; metaworld's reward_utils / _gripper_caging_reward restated [UPSTREAM, unpinned])
+    cfg.att_grasp, cfg.att_lpad, cfg.att_rpad = names.index('pegGrasp'), names.index('leftpad'), names.index('rightpad')
+    for k, c in enumerate(self.model.tables['peg_box_corners']):
+      cfg.box_corners[k][:] = [float(x) for x in c]
     cfg.obj_dof, cfg.obj_kind = int(self.model.struct.ball_dof) - 3, 1
     cfg.success_radius = self.TARGET_RADIUS
     pos_box = goal_states[0][4:] - np.array([0.03, 0.0, 0.13])          # :196

@@ -111,7 +111,8 @@ int earl_physics_forward(const earl_link_model* model, const earl_collision_mode
  *   PersistentStateWrapper.step    earl_benchmark/wrappers/persistent_state_wrapper.py:17-31  (done = steps_since_reset >= horizon)
  *   SawyerDoorV2.reset_model       earl_benchmark/envs/sawyer_door.py:111-125 (settled hand pose, object angle init + U(lo, hi))
  *   SawyerPegV2._get_obs           earl_benchmark/envs/sawyer_peg.py:134-142, _get_pos_objects :186-187 (object xyz = site pegHead)
- *   SawyerPegV2.compute_reward     earl_benchmark/envs/sawyer_peg.py:231-299 -- sparse only: is_successful :301-305, radius 0.05
+ *   SawyerPegV2.compute_reward     earl_benchmark/envs/sawyer_peg.py:231-299 -- sparse: is_successful :301-305, radius 0.05; dense:
+ *                                  metaworld's reward_utils / _gripper_caging_reward restated [UPSTREAM, unpinned]
  *   SawyerPegV2.reset_model        earl_benchmark/envs/sawyer_peg.py:192-229, get_next_goal / reset_goal :144-163
  * obs is float64 like the reference's (the demonstrations store it as float32). */
 typedef struct earl_sawyer_cfg {
@@ -132,6 +133,8 @@ typedef struct earl_sawyer_cfg {
                                               switch the goal is redrawn (from goal_table if n_goal_rows > 0, else kept) and the goal block of the
                                               observation returned by that step is the NEW goal; the reward of that step used the old one */
   int32_t n_wide;                          /* rows of wide_table (obj_kind 2) */
+  int32_t att_grasp, att_lpad, att_rpad;   /* peg dense reward: site pegGrasp, bodies leftpad / rightpad (-1: sparse only) */
+  int32_t pad2_;
   double action_scale;
   double mocap_low[3], mocap_high[3], mocap_quat[4];
   double success_radius;
@@ -141,6 +144,8 @@ typedef struct earl_sawyer_cfg {
   const double* goal_table;                /* device, [n_goal_rows, 7] or NULL */
   const double* wide_table;                /* device, [n_wide, 3] or NULL */
   double wide_shift[3], wide_noise;
+  double init_tcp[3];                      /* peg dense reward: midpoint of the finger sites after _reset_hand (SawyerXYZEnv.init_tcp [UPSTREAM]) */
+  double box_corners[4][3];                /* ... and the two keep-out prisms in front of the hole block (sites *_corner_collision_box_{1,2}, sawyer_peg.py:252-256) */
   uint64_t seed, counter;                  /* reset draws: Philox(seed; draw, global env id, counter) */
   uint64_t step_counter;                   /* env steps taken before this launch (goal-switch draws: Philox(seed; 0xFFFE, global env id, step)) */
 } earl_sawyer_cfg;
@@ -152,6 +157,8 @@ typedef struct earl_sawyer_state {
   double* goal;                 /* [n, 7] */
   int32_t* steps_since_reset;   /* [n] */
   int32_t* steps_since_goal_change;   /* [n]; may be NULL when cfg.goal_change_frequency == 0 */
+  double* obj_init;             /* [n, 6] obj_init_pos, peg_head_pos_init as reset_model leaves them (sawyer_peg.py:213-215); may be NULL
+                                   for sparse rewards; written by earl_sawyer_reset, read by the peg's dense reward */
 } earl_sawyer_state;
 
 typedef struct earl_sawyer_out {

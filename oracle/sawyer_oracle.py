@@ -113,6 +113,78 @@ PEG_WIDE_INITIAL = np.array([[-0.3, 0.8, 0.02], [-0.4, 0.8, 0.02], [-0.3, 0.9, 0
 PEG_INITIAL_STATES = np.array([[0.00615235, 0.6001898, 0.19430117, 1.0, x, y, 0.02] for x, y in PEG_INITIAL_XY])
 
 
+# ---- metaworld reward_utils / SawyerXYZEnv._gripper_caging_reward [UPSTREAM metaworld master, NOT in /root/reference: restated from
+# the published source as this builder knows it; UNPINNED].  The reference calls them at sawyer_peg.py:246-249 (tolerance, long_tail),
+# :256-265 (rect_prism_tolerance, hamacher_product), :276-282 (_gripper_caging_reward), :284-286.
+def tolerance_long_tail(x, lo, hi, margin):
+  """reward_utils.tolerance(x, bounds=(lo, hi), margin, sigmoid='long_tail', value_at_margin=0.1)"""
+  if lo <= x <= hi:
+    return 1.0
+  if margin == 0:
+    return 0.0
+  d = (lo - x if x < lo else x - hi) / margin
+  scale = np.sqrt(1 / 0.1 - 1)
+  return float(1 / ((d * scale) ** 2 + 1))
+
+
+def rect_prism_tolerance(curr, zero, one):
+  in_range = lambda a, b, c: (b <= a <= c) if c >= b else (c <= a <= b)
+  if in_range(curr[0], zero[0], one[0]) and in_range(curr[1], zero[1], one[1]) and in_range(curr[2], zero[2], one[2]):
+    diff = one - zero
+    return float((curr[0] - zero[0]) / diff[0] * ((curr[1] - zero[1]) / diff[1]) * ((curr[2] - zero[2]) / diff[2]))
+  return 1.0
+
+
+def hamacher_product(a, b):
+  den = a + b - (a * b)
+  return float((a * b) / den) if den > 0 else 0.0
+
+
+def gripper_caging_reward(action, obj_pos, left_pad, right_pad, tcp, obj_init_pos, init_tcp, obj_radius, pad_success_thresh, xz_thresh):
+  """SawyerXYZEnv._gripper_caging_reward(..., high_density=True) [UPSTREAM]"""
+  pad_y_lr = np.array([left_pad[1], right_pad[1]])
+  pad_to_obj_lr = np.abs(pad_y_lr - obj_pos[1])
+  pad_to_objinit_lr = np.abs(pad_y_lr - obj_init_pos[1])
+  caging_lr_margin = np.abs(pad_to_objinit_lr - pad_success_thresh)
+  caging_lr = [tolerance_long_tail(pad_to_obj_lr[i], obj_radius, pad_success_thresh, caging_lr_margin[i]) for i in range(2)]
+  caging_y = hamacher_product(*caging_lr)
+  xz = [0, 2]
+  caging_xz_margin = np.sqrt(np.sum((obj_init_pos[xz] - init_tcp[xz]) ** 2)) - xz_thresh
+  caging_xz = tolerance_long_tail(np.sqrt(np.sum((tcp[xz] - obj_pos[xz]) ** 2)), 0.0, xz_thresh, caging_xz_margin)
+  gripper_closed = min(max(0.0, float(action[-1])), 1.0) / 1.0
+  caging = hamacher_product(caging_y, caging_xz)
+  gripping = gripper_closed if caging > 0.97 else 0.0
+  caging_and_gripping = hamacher_product(caging, gripping)
+  return (caging_and_gripping + caging) / 2          # high_density
+
+
+def peg_dense_reward(obs, action, grasp_site, head_site, left_pad, right_pad, tcp_center, obj_init_pos, peg_head_pos_init, init_tcp, corners):
+  """SawyerPegV2.compute_reward with reward_type='dense' (sawyer_peg.py:231-299); obs[4:7] is the pegHead site, so
+  obj = obs[4:7] - pegHead + pegGrasp (:233-234)"""
+  tcp, obj_head, tcp_opened, target = obs[:3], obs[4:7], obs[3], obs[11:14]
+  obj = obs[4:7] - head_site + grasp_site
+  tcp_to_obj = np.sqrt(np.sum((obj - tcp) ** 2))
+  scale = np.array([1.0, 2.0, 2.0])
+  obj_to_target = np.sqrt(np.sum(((obj_head - target) * scale) ** 2))
+  in_place_margin = np.sqrt(np.sum(((peg_head_pos_init - target) * scale) ** 2))
+  in_place = tolerance_long_tail(obj_to_target, 0.0, 0.05, in_place_margin)
+  box1 = rect_prism_tolerance(obj_head, corners[0], corners[1])      # curr, zero = bottom-right corner, one = top-left corner (:258-263)
+  box2 = rect_prism_tolerance(obj_head, corners[2], corners[3])
+  in_place = hamacher_product(in_place, hamacher_product(box2, box1))
+  lifted = tcp_to_obj < 0.08 and tcp_opened > 0 and obj[2] - 0.01 > obj_init_pos[2]
+  if lifted:
+    object_grasped = 1.0
+  else:
+    # the caging reward reads self.tcp_center (midpoint of the two finger sites), not the hand position of the observation
+    object_grasped = gripper_caging_reward(action, obj, left_pad, right_pad, tcp_center, obj_init_pos, init_tcp, 0.0075, 0.03, 0.005)
+  reward = hamacher_product(object_grasped, in_place)
+  if lifted:
+    reward += 1.0 + 5 * in_place
+  if obj_to_target <= 0.05:
+    reward = 10.0
+  return float(reward)
+
+
 class SawyerPegOracle(SawyerDoorOracle):
   """SawyerPegV2 (sparse reward) around LinkModel: reference earl_benchmark/envs/sawyer_peg.py
      _get_obs :134-142 (object = site pegHead :186-187), reset_model :192-229, get_next_goal / reset_goal :144-163,
@@ -120,7 +192,6 @@ class SawyerPegOracle(SawyerDoorOracle):
 
   def __init__(self, link_model, reward_type='sparse', reset_at_goal=False, seed=0, env_id=0, horizon=0, frame_skip=5, wide_init=False,
                goal_change_frequency=0):
-    assert reward_type == 'sparse'
     self.wide_init, self.gcf, self.sgc, self.total_steps = wide_init, goal_change_frequency, 0, 0
     self.lm, self.reward_type, self.seed, self.env_id, self.horizon, self.frame_skip = link_model, reward_type, seed, env_id, horizon, frame_skip
     names = [str(x) for x in link_model.att_names]
@@ -174,6 +245,13 @@ class SawyerPegOracle(SawyerDoorOracle):
     v[self.obj_dof:self.obj_dof + 6] = 0.0
     self.qpos, self.qvel, self.mocap, self.steps, self.sgc = q, v, self.hand_init_pos.copy(), 0, 0
     pos_, quat_, _ = self.lm.kinematics(q)
+    # state the dense reward keeps from the reset (sawyer_peg.py:214-215; init_tcp: SawyerXYZEnv._reset_hand [UPSTREAM])
+    names = [str(x) for x in self.lm.att_names]
+    at = lambda n, P=None, Q=None: self.lm.attachment(pos_ if P is None else P, quat_ if Q is None else Q, names.index(n))[0]
+    self.obj_init_pos = pos.copy()
+    self.peg_head_pos_init = at('pegHead')
+    ps, qs, _ = self.lm.kinematics(self.settle()[0])
+    self.init_tcp = 0.5 * (at('rightEndEffector', ps, qs) + at('leftEndEffector', ps, qs))
     return self.obs_from(pos_, quat_)
 
   def step(self, action):
@@ -186,6 +264,13 @@ class SawyerPegOracle(SawyerDoorOracle):
       self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl, self.mocap, MOCAP_QUAT)
     obs = self.obs_from(out['pos'], out['quat'])
     ok = bool(np.sqrt(np.sum((obs[4:7] - obs[11:14]) ** 2)) <= 0.05)             # is_successful :301-305
+    rew = float(ok)
+    if self.reward_type == 'dense':
+      names = [str(x) for x in self.lm.att_names]
+      at = lambda n: self.lm.attachment(out['pos'], out['quat'], names.index(n))[0]
+      rew = peg_dense_reward(obs, a, at('pegGrasp'), at('pegHead'), at('leftpad'), at('rightpad'),
+                             0.5 * (at('rightEndEffector') + at('leftEndEffector')), self.obj_init_pos, self.peg_head_pos_init,
+                             self.init_tcp, self.lm.peg_box_corners)
     self.steps += 1
     if self.gcf > 0:                                    # LifelongWrapper.step (lifelong_wrapper.py:30-44)
       self.sgc += 1
@@ -196,4 +281,4 @@ class SawyerPegOracle(SawyerDoorOracle):
           self.goal = PEG_INITIAL_STATES[min(int(u01(b[0], b[1]) * len(PEG_INITIAL_STATES)), len(PEG_INITIAL_STATES) - 1)].copy()
           obs = np.concatenate([obs[:7], self.goal])
     self.total_steps += 1
-    return obs, np.float32(float(ok)), bool(self.horizon > 0 and self.steps >= self.horizon), ok
+    return obs, np.float32(rew), bool(self.horizon > 0 and self.steps >= self.horizon), ok

@@ -116,7 +116,7 @@ def peg_states(n, seed, lm):
 def test_peg_layout(peg):
   torch, dm, lm = peg
   assert (dm.nv, dm.nq, dm.struct.ball_dof) == (15, 16, 12)
-  assert dm.att_names == ['hand', 'rightEndEffector', 'leftEndEffector', 'endEffector', 'pegHead', 'pegGrasp']
+  assert dm.att_names == ['hand', 'leftpad', 'rightpad', 'rightEndEffector', 'leftEndEffector', 'endEffector', 'pegHead', 'pegGrasp']
 
 
 def test_peg_forward_matches_reference(peg):
@@ -132,7 +132,7 @@ def test_peg_forward_matches_reference(peg):
     ref = lm.forward(qpos[i], qvel[i], ctrl[i], mp[i], mq[i])
     np.testing.assert_allclose(qacc[i], ref['qacc'], rtol=1e-7, atol=1e-8 * np.abs(ref['qacc']).max())
     np.testing.assert_allclose(efc[i], ref['f'][:36], rtol=1e-7, atol=1e-8 * (1 + np.abs(ref['f']).max()))
-    for k in range(6):
+    for k in range(8):
       np.testing.assert_allclose(att[i, k], lm.attachment(ref['pos'], ref['quat'], k)[0], atol=1e-13)
     ncon += len(ref['contacts'])
   assert ncon > 40           # peg corners in the table top were exercised
@@ -150,7 +150,7 @@ def test_peg_steps_match_reference(peg):
   qpos[:6, 9:11] = np.random.default_rng(5).uniform([0.0, 0.5], [0.2, 0.7], size=(6, 2))   # where reset_model puts them (clear of the hole block)
   t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
   dq, dv, dmp, dmq, dc = t(qpos), t(qvel), t(mp), t(mq), t(ctrl)
-  att = torch.empty(n, 6, 3, dtype=torch.float64, device='cuda')
+  att = torch.empty(n, 8, 3, dtype=torch.float64, device='cuda')
   rq, rv = qpos.copy(), qvel.copy()
   seen = 0
   for it in range(iters):

@@ -107,8 +107,8 @@ def test_sparse_rule_on_demo_rows():
     assert (env.is_successful(o).cpu().numpy() == (z['rewards'].ravel() == 1)).all()
     rows += len(z['rewards'])
   assert rows == 1815
-  with pytest.raises(NotImplementedError):
-    SawyerPeg(reward_type='dense')
+  with pytest.raises(NotImplementedError):           # the dense reward reads simulator state: step / rollout only
+    SawyerPeg(reward_type='dense', num_envs=2).compute_reward(o)
 
 
 def place_pegs(env, heads):
@@ -232,8 +232,6 @@ def test_loader_masked_reset_and_lifelong():
   o = life.reset()
   out = life.rollout(torch.zeros(3, 4, 4).cuda())
   assert out['obs'].shape == (3, 4, 14)
-  with pytest.raises(NotImplementedError):
-    eb.EARLEnvs('sawyer_peg', reward_type='dense', num_envs=2)
 
 
 def test_wide_init_reset_matches_oracle(lm):
@@ -308,3 +306,49 @@ def test_demo_prefixes_peg_drop_and_gripper():
   assert np.abs(got[..., 4:7] - want[..., 4:7]).max() < 1.5e-3
   assert np.abs(got[..., :3] - want[..., :3]).max() < 1.5e-2
   assert abs(got[-1, :, 6].mean() - 0.015) < 1e-3 and abs(want[-1, :, 6].mean() - 0.015) < 1e-3       # both rest on the table top
+
+
+def test_dense_reward_matches_the_restatement(lm):
+  """reward_type='dense' (sawyer_peg.py:231-299): metaworld's tolerance(long_tail) / rect_prism_tolerance / hamacher_product /
+  _gripper_caging_reward are UPSTREAM code that is not in the reference tree -- restated in oracle/sawyer_oracle.py, UNPINNED; this
+  checks the kernel against that restatement through reaching, caging, the lifted branch (1 + 5 in_place) and success (10)"""
+  import torch
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  from oracle.sawyer_oracle import SawyerPegOracle
+  eps = episodes('forward')
+  pick = [1, 4, 5, 9]                                   # episodes whose open-loop replay lifts and inserts the peg
+  n = len(pick)
+  env = SawyerPeg(reward_type='dense', num_envs=n, seed=6)
+  env.reset()
+  heads = np.stack([eps[i][0][4:7] for i in pick]).astype(np.float64)
+  place_pegs(env, heads)
+  env.obj_init[:, :3] = env.qpos[:, 9:12]; env.obj_init[:, 3:] = torch.from_numpy(heads).cuda()     # as reset_model would have left them
+  refs = [SawyerPegOracle(lm, 'dense', seed=6, env_id=i) for i in range(n)]
+  for i, r in enumerate(refs):
+    r._settled = refs[0].settle(); r.counter = 1; r.reset()
+    r.qpos[9:12] = heads[i] + [0.1, 0, 0]; r.obj_init_pos = r.qpos[9:12].copy(); r.peg_head_pos_init = heads[i].copy()
+  np.testing.assert_allclose(np.ctypeslib.as_array(env._cfg.init_tcp), refs[0].init_tcp, atol=1e-9)
+  T = max(len(eps[i][1]) for i in pick)
+  acts = np.zeros((T, n, 4), np.float32)
+  for j, i in enumerate(pick):
+    acts[:len(eps[i][1]), j] = eps[i][1]
+  seen = set()
+  for t in range(T):
+    o, r, done, info = env.step(torch.from_numpy(acts[t]).cuda())
+    for j, ref in enumerate(refs):
+      _, rr, _, ok = ref.step(acts[t, j])
+      assert abs(float(r[j]) - float(rr)) <= 1e-6 * max(1.0, abs(float(rr))), (t, j, float(r[j]), float(rr))
+      seen.add('ten' if rr == 10 else ('lifted' if rr > 1 else 'shaping'))
+      # resynchronise (contact dynamics are only piecewise smooth; the reward has thresholds)
+    q = np.stack([ref.qpos for ref in refs]); v = np.stack([ref.qvel for ref in refs]); mp = np.stack([ref.mocap for ref in refs])
+    env.qpos[:] = torch.from_numpy(q).cuda(); env.qvel[:] = torch.from_numpy(v).cuda(); env.mocap_pos[:] = torch.from_numpy(mp).cuda()
+  assert seen == {'ten', 'lifted', 'shaping'}
+
+
+def test_reset_records_the_state_the_dense_reward_needs():
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  env = SawyerPeg(reward_type='dense', num_envs=7, seed=2)
+  o = env.reset()
+  oi = env.obj_init.cpu().numpy()
+  np.testing.assert_allclose(oi[:, :3], env.qpos[:, 9:12].cpu().numpy(), atol=0)       # obj_init_pos = the drawn peg position
+  np.testing.assert_allclose(oi[:, 3:], o[:, 4:7].cpu().numpy(), atol=0)               # peg_head_pos_init = the pegHead site right after it

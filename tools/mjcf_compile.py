@@ -400,12 +400,18 @@ def main():
     colliding = lambda g: bool(m['geom_contype'][g] or m['geom_conaffinity'][g])
     boxes = lambda body: [g for g in range(len(m['geom_body'])) if m['geom_body'][g] == body and m['geom_type'][g] == 4 and colliding(g)]
     peg = pm.geom_id('peg')
-    red = po.reduce_model(pm, None, attach_bodies=['hand'], attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector', 'pegHead', 'pegGrasp'],
+    red = po.reduce_model(pm, None, attach_bodies=['hand', 'leftpad', 'rightpad'],
+                          attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector', 'pegHead', 'pegGrasp'],
                           collision=dict(max_contacts=12, plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], plates_accept=('peg',),
                                          chains=[dict(geom=peg, set='peg', spacing=1.0)],
                                          corner_sets=[dict(names=['peg'], set='pegcorner'), ['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']],
                                          big_boxes=[dict(geom=g, accept=('peg', 'pegcorner', 'corner')) for g in boxes(blockb)] +
                                                    [dict(geom=g, accept=('pegcorner', 'corner')) for g in boxes(table)]))
+    # world-fixed sites the dense reward reads (sawyer_peg.py:252-256): the corners of the two keep-out prisms in front of the hole block
+    kin0 = po.kinematics(pm, po.dof_qpos0(pm))
+    corner = lambda n: kin0['xpos'][pm.site_body[pm.site_id(n)]] + kin0['xmat'][pm.site_body[pm.site_id(n)]] @ pm.site_pos[pm.site_id(n)]
+    red['peg_box_corners'] = np.stack([corner(n) for n in ('bottom_right_corner_collision_box_1', 'top_left_corner_collision_box_1',
+                                                            'bottom_right_corner_collision_box_2', 'top_left_corner_collision_box_2')])
     np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
     print('links:', len(red['parent']), 'spheres', len(red['col_sph_link']), 'boxes', len(red['col_box_link']), 'pairs', len(red['col_pair']),
           'blocks', len(red['col_blk_begin']), 'classes', len(red['col_cls_mu']))
