@@ -151,15 +151,27 @@ __device__ __forceinline__ void kbimp(const double* solref, const double* solimp
   b = 2.0 * rcp_nr(dw * tc);
 }
 
-// Symmetric NV x NV matrix in LDS, lower triangle packed row-major (row i, column j <= i at i (i + 1) / 2 + j): half the
-// LDS of a square array -- the env block is what limits the number of waves on a CU
+// Symmetric NV x NV matrix in LDS.  Big models (nv > 10) keep the lower triangle packed row-major (row i, column j <= i at
+// i (i + 1) / 2 + j): half the LDS of a square array, and the env block is what limits the number of waves on a CU.  Small models
+// keep the plain square (both triangles written): their workgroup fits four times into a CU either way, and the packed form's index
+// arithmetic cost the door kernel 500 VALU instructions per timestep.
 template <int NV>
 struct SymLds {
-  double v[NV * (NV + 1) / 2];
-  __device__ __forceinline__ double& lo(const int i, const int j) { return v[i * (i + 1) / 2 + j]; }               // i >= j
-  __device__ __forceinline__ const double& lo(const int i, const int j) const { return v[i * (i + 1) / 2 + j]; }
+  static constexpr bool PACKED = NV > 10;
+  double v[PACKED ? NV * (NV + 1) / 2 : NV * NV];
+  __device__ __forceinline__ double& lo(const int i, const int j) { return v[PACKED ? i * (i + 1) / 2 + j : i * NV + j]; }               // i >= j
+  __device__ __forceinline__ const double& lo(const int i, const int j) const { return v[PACKED ? i * (i + 1) / 2 + j : i * NV + j]; }
   // entry (i, l) in either order; ltri = l (l + 1) / 2 is kept per lane (i is a compile-time index at every call site)
-  __device__ __forceinline__ double sym(const int i, const int l, const int ltri) const { return v[i >= l ? i * (i + 1) / 2 + l : ltri + i]; }
+  __device__ __forceinline__ double sym(const int i, const int l, const int ltri) const {
+    if constexpr (PACKED) return v[i >= l ? i * (i + 1) / 2 + l : ltri + i];
+    else return v[i * NV + l];
+  }
+  // lane l stores entry (i, l) of its column: the packed form keeps the lower part only, the square form also the mirror image
+  __device__ __forceinline__ void put(const int i, const int l, const double x, const bool mirror) {
+    if constexpr (PACKED) { if (i >= l) v[i * (i + 1) / 2 + l] = x; }
+    else { v[i * NV + l] = x; if (mirror) v[l * NV + i] = x; }
+  }
+  __device__ __forceinline__ double& rowl(const int l, const int ltri, const int j) { return v[PACKED ? ltri + j : l * NV + j]; }        // (l, j), j <= l
 };
 
 // Static bounds by model size: the door model (nv 10) keeps 8 contact slots and 16 collision blocks, which keeps its workgroup
@@ -284,7 +296,7 @@ __device__ __forceinline__ void chol_coop(SymLds<NV>& H, const double (&dl)[NV],
   double r[NV];                                        // row l of H, then of L (entries j <= l; the others are never used)
 #pragma unroll
   for (int j = 0; j < NV; ++j) r[j] = H.sym(j, l, ltri);
-  if (isl) H.v[ltri + l] = r[l] + dl[l];
+  if (isl) H.rowl(l, ltri, l) = r[l] + dl[l];
   fence();
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -297,7 +309,7 @@ __device__ __forceinline__ void chol_coop(SymLds<NV>& H, const double (&dl)[NV],
     }
     const double inv = rsq_nr(sj);
     r[j] = si * inv;
-    if (isl && l >= j) H.v[ltri + j] = l == j ? inv : r[j];
+    if (isl && l >= j) H.rowl(l, ltri, j) = l == j ? inv : r[j];
     fence();
   }
 }
@@ -527,7 +539,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
     v = ((dmask >> i) & 1u) ? v : 0.0;                  // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
     if (i == l) v += m.armature[l];
-    if (isl && l <= i) s.M.lo(i, l) = v;
+    if (isl && l <= i) s.M.put(i, l, v, true);
   }
   fence();
   PSTAMP(4);
@@ -850,8 +862,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       }
       if (isl) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-          if (i >= l) s.con.Hc.lo(i, l) = hcol[i];    // lower part of column l
+        for (int i = 0; i < NV; ++i) s.con.Hc.put(i, l, hcol[i], false);    // column l (packed form: its lower part)
         s.con.rc[l] = rr;
       }
     }
@@ -1170,7 +1181,8 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model
                                             const double* __restrict__ goal, double* __restrict__ obs, float* reward, uint8_t* success,
                                             const double* __restrict__ obj_init = nullptr, const double effort = 0.0) {
 #pragma clang fp contract(off)
-  const bool peg_dense = cfg.obj_kind >= 1 && cfg.reward_type != 0 && obj_init != nullptr;
+  // (compiled into the peg model's kernels only: in the door kernel this code cost 35 more AGPR spills and 10 % of its throughput)
+  const bool peg_dense = NV >= 15 && cfg.obj_kind >= 1 && cfg.reward_type != 0 && obj_init != nullptr;
   if (sub < (peg_dense ? 7 : 4)) {
     const int k = sub == 0 ? cfg.att_hand : (sub == 1 ? cfg.att_right : (sub == 2 ? cfg.att_left : (sub == 3 ? cfg.att_obj :
                   (sub == 4 ? cfg.att_grasp : (sub == 5 ? cfg.att_lpad : cfg.att_rpad)))));
@@ -1191,7 +1203,7 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model
   if (sub == 0 && live) {
     double r; bool ok;
     door_reward(cfg, ld3(s.emit.att[0]), ld3(s.emit.att[3]), ld3(goal + 4), r, ok);
-    if (peg_dense) {
+    if constexpr (NV >= 15) if (peg_dense) {
       const V3 rr = ld3(s.emit.att[1]), ll = ld3(s.emit.att[2]), dg = vsub(rr, ll);
       const double opened = fmin(fmax(sqrt(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z) / 0.1, 0.0), 1.0);      // obs[3]
       r = peg_dense_reward(cfg, ld3(s.emit.att[0]), opened, ld3(s.emit.att[3]), ld3(s.emit.att[4]), ld3(s.emit.att[5]), ld3(s.emit.att[6]),

@@ -10,8 +10,8 @@ import torch
 from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
 from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
 
-print('workgroups: door 4 envs (one wave), four per CU; peg 12 envs (three waves), one per CU; 256 CUs')
-for name, cls, T, per_cu in (('sawyer_door', SawyerDoor, 300, 16), ('sawyer_peg', SawyerPeg, 200, 12)):
+print('workgroups: door 4 envs (one wave), four per CU; peg 16 envs (four waves), one per CU; 256 CUs')
+for name, cls, T, per_cu in (('sawyer_door', SawyerDoor, 300, 16), ('sawyer_peg', SawyerPeg, 200, 16)):
   for n in (256, 1024, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 32768, 65536):
     iters = 3 if n <= 16384 else 1
     env = cls(num_envs=n)
