@@ -182,9 +182,9 @@ template <int NV> struct Lim {
 #ifndef EARL_DOOR_WPB
 #define EARL_DOOR_WPB 1
 #endif
-  static constexpr int WPB = NV <= 10 ? EARL_DOOR_WPB : 4;              // wavefronts per workgroup.  nv 10: 38 KB per single-wave workgroup, four per CU.  nv 15: one
-                                                            // env block is 11.7 KB; a three-wave workgroup (12 envs + the tables once = 151 KB) puts three
-                                                            // waves on a CU where single-wave workgroups (57 KB) would fit two
+  static constexpr int WPB = NV <= 10 ? EARL_DOOR_WPB : 4;  // wavefronts per workgroup.  nv 10: 33 KB per single-wave workgroup, four per CU.  nv 15: an
+                                                            // env block is 9.5 KB; a four-wave workgroup (16 envs + the tables once = 163,672 B of the CU's
+                                                            // 163,840) puts one wave on every SIMD where single-wave workgroups would fit two or three
 #ifndef EARL_DOOR_COOP
 #define EARL_DOOR_COOP 0
 #endif
