@@ -335,7 +335,7 @@ __device__ __forceinline__ void solve_lds(const SymLds<NV>& H, double (&x)[NV]) 
 template <int MB>
 struct BlkTable {
   int n_blk, max_con;
-  int begin[MB], end[MB], box[MB], link[MB], box_link[MB];
+  int begin[MB], end[MB], box[MB], link[MB], box_link[MB], cap[MB];
   double center[MB][3], reach[MB], box_pos[MB][3], box_quat[MB][4], box_half[MB][3];
   double cls_mu[EARL_MAXCLS], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5];   // contact classes
 };
@@ -353,7 +353,7 @@ __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collisi
   }
   if (i < nb) {
     const int b = col->blk_box[i];
-    t.begin[i] = col->blk_begin[i]; t.end[i] = col->blk_end[i]; t.box[i] = b; t.link[i] = col->blk_link[i];
+    t.begin[i] = col->blk_begin[i]; t.end[i] = col->blk_end[i]; t.box[i] = b; t.link[i] = col->blk_link[i]; t.cap[i] = col->blk_cap[i];
     t.box_link[i] = col->box_link[b]; t.reach[i] = col->blk_reach[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { t.center[i][k] = col->blk_center[i][k]; t.box_pos[i][k] = col->box_pos[b][k]; t.box_half[i][k] = col->box_half[b][k]; }
@@ -631,6 +631,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       double Rb[3][3];
       qmat(qb, Rb);
       const V3 h = ld3(bt.box_half[b]);
+      int room = bt.cap[b];                             // contacts this block may still contribute (its first ones in pair order)
       for (int base = bt.begin[b]; base < pend; base += LPE) {
         const int pi = base + sub < pend ? base + sub : pend - 1;
         const bool valid = mine && base + sub < pend;
@@ -675,14 +676,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
         const int before = LPE == 64 ? __popcll(bal & ((1ull << sub) - 1ull)) : __popc(gb & ((1u << sub) - 1u));
         const int total = LPE == 64 ? __popcll(bal) : __popc(gb);
         const int slot = nct + before;
-        if (hit && slot < maxcon) {
+        if (hit && slot < maxcon && before < room) {
           const V3 n = mulv(Rb, nl);
           const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
           double* o = s.con.ct[slot];
           o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
           o[7] = (double)cls; o[8] = (double)lk; o[9] = (double)xl;
         }
-        nct = nct + total < maxcon ? nct + total : maxcon;
+        const int took = total < room ? total : room;
+        room -= took;
+        nct = nct + took < maxcon ? nct + took : maxcon;
       }
     }
     fence();

@@ -76,6 +76,8 @@ typedef struct earl_collision_model {
   int32_t max_con;                           /* contacts kept per env and timestep (<= EARL_MAXCON; <= 8 for models with nv <= 10): the first active pairs */
   int32_t pad_[2];
   int32_t blk_begin[EARL_MAXBLK], blk_end[EARL_MAXBLK], blk_box[EARL_MAXBLK], blk_link[EARL_MAXBLK];
+  int32_t blk_cap[EARL_MAXBLK];              /* contacts a block may contribute (its first ones in pair order); the block order is the
+                                                priority order of the max_con slots */
   double blk_center[EARL_MAXBLK][3], blk_reach[EARL_MAXBLK];
   int32_t sph_link[EARL_MAXSPH];             /* -1 = fixed to the world */
   int32_t box_link[EARL_MAXBOX];

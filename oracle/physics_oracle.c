@@ -286,7 +286,8 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
         const V3 d = v3(x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z));
         if (!(dot(d, d) < col->blk_reach[b] * col->blk_reach[b])) continue;
       }
-      for (int pi = col->blk_begin[b]; pi < col->blk_end[b] && ncon < col->max_con; ++pi) {
+      int btaken = 0;                                /* contacts of this block: at most blk_cap[b] */
+      for (int pi = col->blk_begin[b]; pi < col->blk_end[b] && ncon < col->max_con && btaken < col->blk_cap[b]; ++pi) {
         const int lk = col->pair_rec[pi].sph_link, cls = col->pair_rec[pi].cls;
         const double r = col->pair_rec[pi].r, margin = col->pair_rec[pi].margin;
         V3 c = ld3(col->pair_rec[pi].pos);
@@ -337,7 +338,7 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
           iseq[nr] = 0; rowid[nr] = -1;
           ++nr;
         }
-        ++ncon;
+        ++ncon; ++btaken;
       }
     }
     o->ncon = ncon;

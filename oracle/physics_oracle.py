@@ -515,9 +515,17 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
     ctr = pts.mean(0)
     rad = max(np.sqrt(((pts[k] - ctr) ** 2).sum()) + sph[i]['r'] for k, i in enumerate(members)) + slack
     mmax = max(max(sph[i]['margin'], bx['margin']) for i in members)
-    blocks.append(dict(begin=len(pairs), end=len(pairs) + len(members), box=j, link=bl, center=ctr,
-                       reach=rad + mmax + 1e-6))
-    pairs += [(i, j) for i in members]
+    blocks.append(dict(box=j, link=bl, center=ctr, reach=rad + mmax + 1e-6, set=sname, members=members))
+  # Contacts are kept first come, first served up to max_contacts, so the ORDER of the blocks is a priority: blocks of the sets
+  # listed first in spec['set_priority'] come first (stable otherwise), and a block contributes at most spec['set_cap'][set]
+  # contacts.  Without this a gripper standing in the hole block (16 plate corners in contact) used up every slot and the peg,
+  # untouched on the table, fell through it.
+  prio = list(spec.get('set_priority', ()))
+  blocks.sort(key=lambda b: prio.index(b['set']) if b['set'] in prio else len(prio))
+  for b in blocks:
+    b['begin'], b['end'] = len(pairs), len(pairs) + len(b['members'])
+    b['cap'] = int(spec.get('set_cap', {}).get(b['set'], spec.get('max_contacts', 8)))
+    pairs += [(i, b['box']) for i in b['members']]
   cls, pair_cls = [], []
   for i, j in pairs:                             # contact parameters: MuJoCo mixes the two geoms (max friction / margin, mean solref / solimp)
     a, b = sph[i], box[j]
@@ -537,6 +545,7 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
               col_blk_begin=np.array([b['begin'] for b in blocks], np.int32), col_blk_end=np.array([b['end'] for b in blocks], np.int32),
               col_blk_box=np.array([b['box'] for b in blocks], np.int32), col_blk_link=np.array([b['link'] for b in blocks], np.int32),
               col_blk_center=np.array([b['center'] for b in blocks]), col_blk_reach=np.array([b['reach'] for b in blocks]),
+              col_blk_cap=np.array([b['cap'] for b in blocks], np.int32),
               max_contacts=np.int32(spec.get('max_contacts', 8)))
 
 
@@ -743,8 +752,15 @@ class LinkModel:
         dd = x - np.clip(x, -self.col_box_half[bi], self.col_box_half[bi])
         if (dd ** 2).sum() < self.col_blk_reach[b] ** 2:
           near[self.col_blk_begin[b]:self.col_blk_end[b]] = True
+    blk_of = np.zeros(len(self.col_pair), int)                        # block of every pair, contacts taken per block so far
+    for b in range(len(self.col_blk_begin)):
+      blk_of[self.col_blk_begin[b]:self.col_blk_end[b]] = b
+    caps = getattr(self, 'col_blk_cap', None)
+    taken = np.zeros(len(self.col_blk_begin) + 1, int)
     for pi, (si, bi) in enumerate(self.col_pair):
       if not near[pi]:
+        continue
+      if caps is not None and taken[blk_of[pi]] >= caps[blk_of[pi]]:
         continue
       cls = int(self.col_pair_cls[pi])
       ls, lb = int(self.col_sph_link[si]), int(self.col_box_link[bi])
@@ -771,6 +787,7 @@ class LinkModel:
         n = Rb @ nl
         p = pb + Rb @ q + n * (0.5 * dist)
         out.append(dict(pair=pi, cls=cls, ls=ls, lb=lb, dist=dist, n=n, p=p))
+        taken[blk_of[pi]] += 1
         if len(out) == self.max_contacts:
           break
     return out

@@ -352,3 +352,32 @@ def test_reset_records_the_state_the_dense_reward_needs():
   oi = env.obj_init.cpu().numpy()
   np.testing.assert_allclose(oi[:, :3], env.qpos[:, 9:12].cpu().numpy(), atol=0)       # obj_init_pos = the drawn peg position
   np.testing.assert_allclose(oi[:, 3:], o[:, 4:7].cpu().numpy(), atol=0)               # peg_head_pos_init = the pegHead site right after it
+
+
+@pytest.mark.parametrize('task', ['sawyer_door', 'sawyer_peg'])
+def test_long_random_rollouts_stay_finite(task):
+  """2,000 env steps (10,000 timesteps) of uniform random actions in 512 envs: no NaN / inf anywhere, the hand stays inside the mocap box
+  (+ 10 cm: soft weld), the peg stays above the table and inside the walls' reach, quaternions stay normalised, velocities bounded"""
+  import torch
+  from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  n, T, chunks = 512, 250, 8
+  env = (SawyerPeg if task == 'sawyer_peg' else SawyerDoor)(num_envs=n, seed=13)
+  env.reset()
+  g = torch.Generator(device='cuda').manual_seed(17)
+  for c in range(chunks):
+    acts = (torch.rand(T, n, 4, generator=g, device='cuda') * 2 - 1).float()
+    out = env.rollout(acts)
+    obs = out['obs']
+    assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(env.qpos).all()) and bool(torch.isfinite(env.qvel).all()), c
+    hand = obs[..., :3]
+    lo = torch.tensor([-0.5, 0.40, 0.05], device='cuda') - 0.1
+    hi = torch.tensor([0.5, 1.0, 0.5], device='cuda') + 0.1
+    assert bool((hand >= lo).all()) and bool((hand <= hi).all()), c
+    assert float(env.qvel.abs().max()) < 200.0, c
+    if task == 'sawyer_peg':
+      q = env.qpos
+      assert float((q[:, 12:16].norm(dim=1) - 1).abs().max()) < 1e-9
+      assert bool((q[:, 11] > -0.02).all()) and bool((q[:, 9:12].abs() < 2.0).all()), (c, float(q[:, 11].min()))
+    else:
+      assert bool((env.qpos[:, 9] > -2.2).all()) and bool((env.qpos[:, 9] < 0.3).all()), c        # door hinge range -1.57 .. 0 (+ soft limit)

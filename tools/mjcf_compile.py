@@ -402,7 +402,7 @@ def main():
     peg = pm.geom_id('peg')
     red = po.reduce_model(pm, None, attach_bodies=['hand', 'leftpad', 'rightpad'],
                           attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector', 'pegHead', 'pegGrasp'],
-                          collision=dict(max_contacts=12, plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], plates_accept=('peg',),
+                          collision=dict(max_contacts=12, set_priority=('pegcorner', 'peg', 'corner'), set_cap=dict(pegcorner=4, peg=4, corner=2), plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], plates_accept=('peg',),
                                          chains=[dict(geom=peg, set='peg', spacing=1.0)],
                                          corner_sets=[dict(names=['peg'], set='pegcorner'), ['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']],
                                          big_boxes=[dict(geom=g, accept=('peg', 'pegcorner', 'corner')) for g in boxes(blockb)] +
