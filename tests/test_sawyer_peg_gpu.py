@@ -354,7 +354,7 @@ def test_reset_records_the_state_the_dense_reward_needs():
   np.testing.assert_allclose(oi[:, 3:], o[:, 4:7].cpu().numpy(), atol=0)               # peg_head_pos_init = the pegHead site right after it
 
 
-@pytest.mark.parametrize('task', ['sawyer_door', 'sawyer_peg'])
+@pytest.mark.parametrize('task', ['sawyer_door', 'sawyer_peg', 'sawyer_peg:reset_at_goal', 'sawyer_peg:wide_init'])
 def test_long_random_rollouts_stay_finite(task):
   """2,000 env steps (10,000 timesteps) of uniform random actions in 512 envs: no NaN / inf anywhere, the hand stays inside the mocap box
   (+ 10 cm: soft weld), the peg stays above the table and inside the walls' reach, quaternions stay normalised, velocities bounded"""
@@ -362,7 +362,8 @@ def test_long_random_rollouts_stay_finite(task):
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   n, T, chunks = 512, 250, 8
-  env = (SawyerPeg if task == 'sawyer_peg' else SawyerDoor)(num_envs=n, seed=13)
+  task, _, mode = task.partition(':')
+  env = (SawyerPeg if task == 'sawyer_peg' else SawyerDoor)(num_envs=n, seed=13, **({mode: True} if mode else {}))
   env.reset()
   g = torch.Generator(device='cuda').manual_seed(17)
   for c in range(chunks):
