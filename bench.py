@@ -174,13 +174,13 @@ def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door'):
   rng = np.random.default_rng(0)
   if task == 'sawyer_door':
     hand = np.array([0, 0.4, 0.2], np.float32).astype(np.float64)
-    r = cm.run(np.zeros((1, 10)), np.zeros((1, 10)), hand, [1, 0, 1, 0], [-1, 1], nsub=250)       # sim.reset() + _reset_hand
+    r = cm.run(np.zeros((1, 10)), np.zeros((1, 10)), hand, [1, 0, 1, 0], [-1, 1], nsub=2000)      # sim.reset() + _reset_hand (converged)
     q0, v0 = r['qpos'][0].copy(), r['qvel'][0].copy()
     q0[9], v0[9] = -np.pi / 3, 0.0
     cfg = physics_c.door_cfg(att_names=cm.att_names)
   else:
     hand = np.array([0, 0.6, 0.2])
-    r = cm.run(cm.tables['qpos0'][None], np.zeros((1, 15)), hand, [1, 0, 1, 0], [-1, 1], nsub=250)
+    r = cm.run(cm.tables['qpos0'][None], np.zeros((1, 15)), hand, [1, 0, 1, 0], [-1, 1], nsub=2000)
     q0, v0 = r['qpos'][0].copy(), r['qvel'][0].copy()
     q0[9:12], v0[9:] = [0.1, 0.6, 0.02], 0.0
     cfg = physics_c.peg_cfg(att_names=cm.att_names)

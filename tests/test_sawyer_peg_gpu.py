@@ -55,7 +55,7 @@ def test_reset_and_rollout_match_oracle(lm, reset_at_goal):
     assert len(np.unique(obs0[:, 11])) > 1
   else:
     assert (obs0[:, 4] >= -0.1).all() and (obs0[:, 4] <= 0.1).all() and (obs0[:, 5] >= 0.5).all() and (obs0[:, 5] <= 0.7).all()
-    np.testing.assert_allclose(obs0[:, 6], 0.02, atol=1e-6)      # _set_obj_xyz keeps the settled orientation: 0.1 m x a 2e-7 rad pitch
+    np.testing.assert_allclose(obs0[:, 6], 0.02, atol=1e-5)      # _set_obj_xyz keeps the settled orientation: 0.1 m x a 1.5e-5 rad pitch
     assert len(np.unique(obs0[:, 4])) == n
   rng = np.random.default_rng(3)
   acts = rng.uniform(-1.3, 1.3, size=(T, n, 4)).astype(np.float32)
@@ -80,11 +80,11 @@ def test_reset_observation_against_the_demonstrations():
   env = SawyerPeg(num_envs=16, seed=1)
   o = env.reset().cpu().numpy()
   first = np.stack([e[0] for e in fwd]).astype(np.float64)
-  assert np.abs(o[:, :3] - first[0, :3]).max() < 8e-3            # hand after _reset_hand: a 250-timestep transient, within 8 mm
+  assert np.abs(o[:, :3] - first[0, :3]).max() < 8e-3            # hand after _reset_hand (settled to convergence), within 8 mm
   assert np.abs(o[:, 3] - 1.0).max() < 1e-9 and (first[:, 3] == 1.0).all()
   np.testing.assert_allclose(o[:, 7:], np.repeat(goal_states, 16, 0), atol=0)
   np.testing.assert_allclose(first[:, 7:], np.repeat(goal_states, len(first), 0), atol=1e-7)
-  assert (np.abs(first[:, 6] - 0.02) < 1e-7).all() and (np.abs(o[:, 6] - 0.02) < 1e-6).all()
+  assert (np.abs(first[:, 6] - 0.02) < 1e-7).all() and (np.abs(o[:, 6] - 0.02) < 1e-5).all()
   for x in (o, first):                                           # pegHead = peg - (0.1, 0, 0), peg ~ U([0, 0.2] x [0.5, 0.7])
     assert (x[:, 4] >= -0.1 - 1e-7).all() and (x[:, 4] <= 0.1).all() and (x[:, 5] >= 0.5).all() and (x[:, 5] <= 0.7).all()
   env_r = SawyerPeg(num_envs=16, seed=1, reset_at_goal=True)
@@ -118,13 +118,13 @@ def place_pegs(env, heads):
 
 
 def test_grasp_and_lift_match_the_cpu_statement():
-  """forward demonstration 4 (grasp, lift, carry, insert) from its recorded start: HIP env vs the C restatement of the same
+  """forward demonstration 5 (grasp, lift, carry, insert) from its recorded start: HIP env vs the C restatement of the same
   algorithm, resynchronised every step so that each env step is an independent comparison through plate / peg / table /
   hole-block contacts; and the outcome of the open-loop replay itself."""
   import torch
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   from oracle import physics_c
-  obs0, acts, nobs, rew = episodes('forward')[4]
+  obs0, acts, nobs, rew = episodes('forward')[5]
   T = len(acts)
   env = SawyerPeg(num_envs=3)
   env.reset()
@@ -144,7 +144,7 @@ def test_grasp_and_lift_match_the_cpu_statement():
     lifted = max(lifted, ob[0, 0, 6])
     env.qpos[:] = torch.from_numpy(q).cuda(); env.qvel[:] = torch.from_numpy(v).cuda(); env.mocap_pos[:] = torch.from_numpy(mp).cuda()
   assert ncon_steps >= 15                              # the plates held the peg for a good part of the episode
-  assert lifted > 0.12 and abs(lifted - nobs[:, 6].max()) < 0.02      # lifted as high as MuJoCo's recording (13.6 cm)
+  assert lifted > 0.12 and abs(lifted - nobs[:, 6].max()) < 0.02      # lifted as high as MuJoCo's recording (13.0 cm)
   assert bool(info['success'][0]) and rew[-1] == 1.0   # ... and inserted: the open-loop replay ends in the hole, like the demonstration
   assert bool((env.qpos[0] == env.qpos[1]).all())      # identical envs in one wavefront stay identical
 
@@ -152,8 +152,9 @@ def test_grasp_and_lift_match_the_cpu_statement():
 def test_forward_demos_open_loop_loose():
   """the 10 forward demonstrations (MuJoCo, feedback policy) replayed OPEN LOOP in this build's stepper (sphere-chain
   peg, pyramidal friction, 12-contact cap).  Only loose agreement is asserted; the bounds are what this round measures plus
-  margin (DESIGN.md quotes the measured values): the hand follows the recorded path (RMS < 3 cm), at least half of the episodes
-  lift the peg above 10 cm, at least 3 end inserted."""
+  margin (DESIGN.md quotes the measured values: hand RMS 1.0-2.0 cm, peg RMS 0.8-1.4 cm, 10 / 10 lifted to the recorded height, 4 / 10
+  inserted): the hand follows the recorded path (RMS < 2.5 cm), so does the peg (RMS < 3 cm), at least 9 episodes lift the peg to within
+  2 cm of the recorded height, at least 3 end inserted."""
   import torch
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   eps = episodes('forward')
@@ -172,11 +173,12 @@ def test_forward_demos_open_loop_loose():
   for i, e in enumerate(eps):
     L = len(e[1])
     o, w = obs[:L, i], e[2]
-    assert np.sqrt(((o[:, :3] - w[:, :3]) ** 2).sum(1).mean()) < 0.03, i
+    assert np.sqrt(((o[:, :3] - w[:, :3]) ** 2).sum(1).mean()) < 0.025, i
+    assert np.sqrt(((o[:, 4:7] - w[:, 4:7]) ** 2).sum(1).mean()) < 0.03, i
     assert (o[:, 6] > 0.004).all()                      # the peg is pressed into the soft table top by the plates at most ~1 cm, never through it
-    lifted += o[:, 6].max() > 0.10
+    lifted += abs(o[:, 6].max() - w[:, 6].max()) < 0.02
     inserted += bool(suc[L - 1, i])
-  assert lifted >= 5 and inserted >= 3, (lifted, inserted)
+  assert lifted >= 9 and inserted >= 3, (lifted, inserted)
 
 
 def test_shards_equal_one_batch_and_both_lane_layouts_agree():
@@ -248,7 +250,7 @@ def test_wide_init_reset_matches_oracle(lm):
   ref0 = np.stack([r.reset() for r in refs])
   np.testing.assert_allclose(obs0, ref0, rtol=0, atol=1e-8)
   peg = obs0[:, 4:7] + [0.1, 0, 0]
-  default = (peg[:, 0] >= 0) & (peg[:, 0] <= 0.2) & (peg[:, 1] >= 0.5) & (peg[:, 1] <= 0.7) & (np.abs(peg[:, 2] - 0.02) < 1e-6)
+  default = (peg[:, 0] >= 0) & (peg[:, 0] <= 0.2) & (peg[:, 1] >= 0.5) & (peg[:, 1] <= 0.7) & (np.abs(peg[:, 2] - 0.02) < 1e-5)
   near_table = np.array([np.abs(wide_initial_states + [0.1, 0, 0] - p).max(1).min() <= 0.02 + 1e-9 for p in peg])
   assert (default | near_table).all() and 12 <= default.sum() <= 36 and 12 <= near_table.sum() <= 36
 
@@ -316,7 +318,7 @@ def test_dense_reward_matches_the_restatement(lm):
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   from oracle.sawyer_oracle import SawyerPegOracle
   eps = episodes('forward')
-  pick = [1, 4, 5, 9]                                   # episodes whose open-loop replay lifts and inserts the peg
+  pick = [0, 3, 5, 9]                                   # episodes whose open-loop replay lifts and inserts the peg
   n = len(pick)
   env = SawyerPeg(reward_type='dense', num_envs=n, seed=6)
   env.reset()
