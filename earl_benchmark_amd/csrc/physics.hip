@@ -189,6 +189,8 @@ template <int NV> struct Lim {
 #define EARL_DOOR_COOP 0
 #endif
   static constexpr bool COOP = NV <= 10 && EARL_DOOR_COOP;  // small model: every factorisation shared in LDS instead of per lane in registers (experiment)
+  static constexpr bool CAPS = NV <= 10;                    // edge-vs-capsule blocks compiled in (the door model's handle rods; the peg model has none, and
+                                                            // its kernel has no registers to spare: the host side refuses such tables for it)
   static constexpr int NA = NV <= 10 ? NV : 9;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
                                                             // and free peg are separate trees (checked by the host side); the door model
                                                             // (9 + 1) is factorised densely -- the split did not pay there
@@ -462,8 +464,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   }
   // prefetch this lane's pair record of the first near block: its latency hides behind K3-K7
   int pf_blk = -1, pf_link = -1, pf_cls = 0;
-  double pf_r = 0, pf_margin = 0;
-  V3 pf_pos{0, 0, 0};
+  double pf_r = 0, pf_margin = 0, pf_hl = 0;
+  V3 pf_pos{0, 0, 0}, pf_dir{0, 0, 0};
   if (nearw) {
     pf_blk = __builtin_ctz(nearw);
     const int pend = bt.end[pf_blk], pi0 = bt.begin[pf_blk] + sub;
@@ -471,6 +473,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     pf_link = col->pair_rec[pi].sph_link; pf_cls = col->pair_rec[pi].cls;
     pf_r = col->pair_rec[pi].r; pf_margin = col->pair_rec[pi].margin;
     pf_pos = ld3(col->pair_rec[pi].pos);
+    if constexpr (Lim<NV>::CAPS) { pf_dir = ld3(col->pair_rec[pi].dir); pf_hl = col->pair_rec[pi].hl; }
   }
   PSTAMP(0);
   // ------------------------------------------------------------------ K3: motion subspace + compact spatial inertia
@@ -631,31 +634,52 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       double Rb[3][3];
       qmat(qb, Rb);
       const V3 h = ld3(bt.box_half[b]);
-      int room = bt.cap[b];                             // contacts this block may still contribute (its first ones in pair order)
+      int room = bt.cap[b] & 255;                       // contacts this block may still contribute (its first ones in pair order)
+      const bool capsule = Lim<NV>::CAPS && ((bt.cap[b] >> 8) & 1);   // uniform: edges vs a capsule instead of spheres / points vs a box
       for (int base = bt.begin[b]; base < pend; base += LPE) {
         const int pi = base + sub < pend ? base + sub : pend - 1;
         const bool valid = mine && base + sub < pend;
         int lk, cls;
-        double r, margin;
-        V3 c;
+        double r, margin, hl;
+        V3 c, ed;
         if (b == pf_blk && base == bt.begin[b]) {       // uniform: the record prefetched after C0
-          lk = pf_link; cls = pf_cls; r = pf_r; margin = pf_margin; c = pf_pos;
+          lk = pf_link; cls = pf_cls; r = pf_r; margin = pf_margin; c = pf_pos; ed = pf_dir; hl = pf_hl;
         } else {
           lk = col->pair_rec[pi].sph_link; cls = col->pair_rec[pi].cls;
           r = col->pair_rec[pi].r; margin = col->pair_rec[pi].margin;
           c = ld3(col->pair_rec[pi].pos);
+          if constexpr (Lim<NV>::CAPS) { ed = ld3(col->pair_rec[pi].dir); hl = col->pair_rec[pi].hl; } else { ed = V3{0, 0, 0}; hl = 0; }
         }
         {
           double R[3][3];
           qmat(ldq(s.Xq[lk < 0 ? 0 : lk]), R);
           const V3 w = add(ld3(s.Xp[lk < 0 ? 0 : lk]), mulv(R, c));
           c = selv(lk < 0, c, w);
+          if constexpr (Lim<NV>::CAPS) ed = selv(lk < 0, ed, mulv(R, ed));
         }
-        const V3 x = mulvT(Rb, vsub(c, pb));
-        V3 q{fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z)};
-        const bool outside = fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z;
         double dist;
-        V3 nl;
+        V3 nl, q;                                        // normal and surface point in the box frame
+        bool sane = true;
+        if (Lim<NV>::CAPS && capsule) {
+          // closest points of the edge (c +- hl ed) and the capsule's axis segment (pb +- hc cd); normal from the axis to the edge
+          const V3 cd{Rb[0][2], Rb[1][2], Rb[2][2]}, rr = vsub(c, pb);
+          const double hc = h.z - h.x, rad = h.x;
+          const double b_ = dot(ed, cd), c_ = dot(ed, rr), f_ = dot(cd, rr), den = 1.0 - b_ * b_;
+          double s_ = den > 1e-12 ? fmin(fmax((b_ * f_ - c_) / den, -hl), hl) : 0.0;
+          const double t_ = fmin(fmax(fma(b_, s_, f_), -hc), hc);
+          s_ = fmin(fmax(fma(b_, t_, -c_), -hl), hl);
+          const V3 d = vsub(add(rr, scl(ed, s_)), scl(cd, t_));
+          const double d2 = dot(d, d);
+          sane = d2 > 1e-18;
+          const double inv = rsq_nr(sane ? d2 : 1.0);
+          dist = d2 * inv - rad;
+          const V3 nw = scl(d, inv);
+          nl = mulvT(Rb, nw);
+          q = V3{nl.x * rad, nl.y * rad, t_ + nl.z * rad};   // surface point of the capsule in its own frame (axis = z)
+        } else {
+        const V3 x = mulvT(Rb, vsub(c, pb));
+        q = V3{fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z)};
+        const bool outside = fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z;
         {
           const V3 d = vsub(x, q);
           const double d2 = dot(d, d);
@@ -670,7 +694,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
           nl = selv(outside, scl(d, inv), ni);
           q = selv(outside, q, qi);
         }
-        const bool hit = valid && dist < margin;
+        }
+        const bool hit = valid && sane && dist < margin;
         const unsigned long long bal = __ballot(hit);
         const unsigned int gb = LPE == 64 ? 0u : (unsigned int)((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull));
         const int before = LPE == 64 ? __popcll(bal & ((1ull << sub) - 1ull)) : __popc(gb & ((1u << sub) - 1u));

@@ -35,7 +35,8 @@ class LinkModelStruct(C.Structure):   # struct earl_link_model
 
 
 class PairRec(C.Structure):
-  _fields_ = [('sph_link', C.c_int32), ('cls', C.c_int32), ('pos', C.c_double * 3), ('r', C.c_double), ('margin', C.c_double)]
+  _fields_ = [('sph_link', C.c_int32), ('cls', C.c_int32), ('pos', C.c_double * 3), ('r', C.c_double), ('margin', C.c_double),
+              ('dir', C.c_double * 3), ('hl', C.c_double)]
 
 
 class CollisionModelStruct(C.Structure):   # struct earl_collision_model
@@ -141,6 +142,15 @@ def load_collision_model(d):
     r.sph_link, r.cls, r.r = int(d['col_sph_link'][si]), int(d['col_pair_cls'][i]), float(d['col_sph_r'][si])
     r.pos[:] = [float(x) for x in d['col_sph_pos'][si]]
     r.margin = float(d['col_cls_margin'][r.cls])
+    if 'col_sph_dir' in d:                      # edges (segments) of the edge-vs-capsule blocks; zero for spheres / points
+      r.dir[:] = [float(x) for x in d['col_sph_dir'][si]]
+      r.hl = float(d['col_sph_hl'][si])
+  if 'col_box_kind' in d:                       # kind of each block = kind of its box (1: capsule), carried in bit 8 of blk_cap
+    for b in range(c.n_blk):
+      assert 0 < c.blk_cap[b] < 256
+      kind = int(d['col_box_kind'][int(d['col_blk_box'][b])])
+      assert kind == 0 or small, 'edge-vs-capsule blocks are compiled in for nv <= 10 only (csrc/physics.hip Lim<NV>::CAPS)'
+      c.blk_cap[b] |= kind << 8
   return c
 
 

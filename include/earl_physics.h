@@ -76,8 +76,14 @@ typedef struct earl_collision_model {
   int32_t max_con;                           /* contacts kept per env and timestep (<= EARL_MAXCON; <= 8 for models with nv <= 10): the first active pairs */
   int32_t pad_[2];
   int32_t blk_begin[EARL_MAXBLK], blk_end[EARL_MAXBLK], blk_box[EARL_MAXBLK], blk_link[EARL_MAXBLK];
-  int32_t blk_cap[EARL_MAXBLK];              /* contacts a block may contribute (its first ones in pair order); the block order is the
-                                                priority order of the max_con slots */
+  int32_t blk_cap[EARL_MAXBLK];              /* bits 0-7: contacts a block may contribute (its first ones in pair order); the block order is the
+                                                priority order of the max_con slots.  bit 8: KIND of the block, 0 = spheres / points vs a box,
+                                                1 = EDGES vs a CAPSULE: the block's "box" is a capsule (axis = box z, radius = box_half[0],
+                                                segment half length = box_half[2] - box_half[0]; box_half bounds it for the block's bounding
+                                                test) and its "spheres" are segments (pair_rec.pos = midpoint, .dir = unit direction in the link
+                                                frame, .hl = half length); test = closest points of the two segments, normal from the capsule's
+                                                axis to the edge.  (A chain sphere on the flat of a plate is pushed along the plate normal; MuJoCo's
+                                                box-cylinder contact pushes along the cylinder's radial direction where the plate's edge digs in.) */
   double blk_center[EARL_MAXBLK][3], blk_reach[EARL_MAXBLK];
   int32_t sph_link[EARL_MAXSPH];             /* -1 = fixed to the world */
   int32_t box_link[EARL_MAXBOX];
@@ -86,7 +92,7 @@ typedef struct earl_collision_model {
   uint8_t pair_sph[EARL_MAXPAIR], pair_box[EARL_MAXPAIR], pair_cls[EARL_MAXPAIR];
   uint8_t pad2_[EARL_MAXPAIR];
   /* the same pairs, self-contained (one load per test): sphere link, class, local centre, radius, class margin */
-  struct { int32_t sph_link, cls; double pos[3], r, margin; } pair_rec[EARL_MAXPAIR];
+  struct { int32_t sph_link, cls; double pos[3], r, margin, dir[3], hl; } pair_rec[EARL_MAXPAIR];
   double cls_mu[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS];
 } earl_collision_model;
 

@@ -286,15 +286,33 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
         const V3 d = v3(x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z));
         if (!(dot(d, d) < col->blk_reach[b] * col->blk_reach[b])) continue;
       }
-      int btaken = 0;                                /* contacts of this block: at most blk_cap[b] */
-      for (int pi = col->blk_begin[b]; pi < col->blk_end[b] && ncon < col->max_con && btaken < col->blk_cap[b]; ++pi) {
+      int btaken = 0;                                /* contacts of this block: at most blk_cap[b] (bits 0-7; bit 8: edges vs capsule) */
+      const int bcap = col->blk_cap[b] & 255, capsule = (col->blk_cap[b] >> 8) & 1;
+      for (int pi = col->blk_begin[b]; pi < col->blk_end[b] && ncon < col->max_con && btaken < bcap; ++pi) {
         const int lk = col->pair_rec[pi].sph_link, cls = col->pair_rec[pi].cls;
         const double r = col->pair_rec[pi].r, margin = col->pair_rec[pi].margin;
         V3 c = ld3(col->pair_rec[pi].pos);
         if (lk >= 0) { qmat(ldq(o->Xq[lk]), R); c = add(ld3(o->Xp[lk]), mulv(R, c)); }
+        double dist;
+        V3 n, p;
+        if (capsule) {                               /* edge (segment) vs capsule: closest points of two segments */
+          V3 ed = ld3(col->pair_rec[pi].dir);
+          if (lk >= 0) ed = mulv(R, ed);
+          const V3 cd = v3(Rb[0][2], Rb[1][2], Rb[2][2]), rr = sub(c, pb);
+          const double he = col->pair_rec[pi].hl, hc = h.z - h.x, rad = h.x;
+          const double b_ = dot(ed, cd), c_ = dot(ed, rr), f_ = dot(cd, rr), den = 1.0 - b_ * b_;
+          double s_ = den > 1e-12 ? fmin(fmax((b_ * f_ - c_) / den, -he), he) : 0.0;
+          const double t_ = fmin(fmax(b_ * s_ + f_, -hc), hc);
+          s_ = fmin(fmax(b_ * t_ - c_, -he), he);
+          const V3 pc = add(pb, scl(cd, t_)), d = sub(add(c, scl(ed, s_)), pc);
+          const double nd = sqrt(dot(d, d));
+          dist = nd - rad;
+          if (!(dist < margin && nd > 1e-9)) continue;
+          n = scl(d, 1.0 / nd);
+          p = add(pc, scl(n, rad + 0.5 * dist));
+        } else {
         const V3 x = mulvT(Rb, sub(c, pb));
         V3 q = v3(fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z));
-        double dist;
         V3 nl;
         if (fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z) {
           const V3 d = sub(x, q);
@@ -309,8 +327,9 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
           dist = -(ha - fabs(xa)) - r;
         }
         if (!(dist < margin)) continue;
-        const V3 n = mulv(Rb, nl);
-        const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
+        n = mulv(Rb, nl);
+        p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
+        }
         /* tangents: n x (the coordinate axis least aligned with n) */
         const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
         const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);

@@ -466,7 +466,42 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
     span = max(h - r, 0.0)
     k = 1 if span == 0 else int(np.ceil(2 * span / (spacing * r))) + 1
     for t in (np.linspace(-span, span, k) if k > 1 else [0.0]):
-      sph.append(dict(link=l, pos=p + quat_mat(q) @ (d * t), r=r, set=sname, **params(g)))
+      sph.append(dict(link=l, pos=p + quat_mat(q) @ (d * t), r=r, set=sname, chain=(g, p.copy(), quat_mat(q) @ d, span), **params(g)))
+  if spec.get('drop_contained'):
+    # a chain sphere that lies wholly inside ANOTHER chain's capsule on the same link (the door handle's thin rod runs through a fatter
+    # sleeve) can only touch what the outer capsule already touches: dropped, which keeps the plate blocks at one 16-lane pass
+    def contained(a):
+      for b2 in sph:
+        if 'chain' in b2 and b2['chain'][0] != a['chain'][0] and b2['link'] == a['link'] and b2['r'] >= a['r']:
+          _, c0, ax, sp = b2['chain']
+          t = float(np.clip((a['pos'] - c0) @ ax, -sp, sp))
+          if np.linalg.norm(a['pos'] - (c0 + t * ax)) + a['r'] <= b2['r'] + 1e-12:
+            return True
+      return False
+    sph[:] = [a for a in sph if 'chain' not in a or not contained(a)]
+  # EDGES vs CAPSULES.  A chain sphere touching the flat of a plate is pushed along the plate's normal, whatever the angle between
+  # the plate and the cylinder the chain stands for; MuJoCo's box-cylinder contact sits where the plate's EDGE presses into the
+  # cylinder's side and pushes along the cylinder's radial direction.  So the long edges of the plates (segments; stored as
+  # "spheres" of radius 0 with a direction and a half length) are tested against the cylinders as capsules (stored as "boxes" of
+  # kind 1: axis = local z, half = (r, r, h), hemispherical ends inside the cylinder like the chains').  Closest points of two
+  # segments; normal from the capsule's axis to the edge.  spec['edge_caps'] = dict(plates=[[geom names]], caps=[geom ids], set=name)
+  ec = spec.get('edge_caps')
+  if ec:
+    for g in ec['caps']:
+      l, p, q = gframe(g)
+      assert m.geom_type[g] == 3
+      r, h = float(m.geom_size[g][0]), float(m.geom_size[g][1])
+      box.append(dict(link=l, pos=p, quat=q, half=np.array([r, r, h]), kind=1,
+                      accept=tuple(ec.get('set', 'edge') + str(k) for k in range(len(ec['plates']))) if ec.get('per_plate') else (ec.get('set', 'edge'),), **params(g)))
+    for k, names in enumerate(ec['plates']):
+      l, p, q, half, _, _, Rq = union_box(names)
+      ax = int(np.argmax(half))                     # the long edges run along the plate's longest axis
+      sname = ec.get('set', 'edge') + (str(k) if ec.get('per_plate') else '')   # per_plate: one set (one bounding test) per plate
+      o1, o2 = [a for a in range(3) if a != ax]
+      for s1 in (-1, 1):
+        for s2 in (-1, 1):
+          off = np.zeros(3); off[o1], off[o2] = s1 * half[o1], s2 * half[o2]
+          sph.append(dict(link=l, pos=p + Rq @ off, r=0.0, dir=Rq[:, ax].copy(), hl=float(half[ax]), set=sname, **params(m.geom_id(names[-1]))))
   for e in spec.get('corner_sets', ()):
     names, sname = (e['names'], e.get('set', 'corner')) if isinstance(e, dict) else (e, 'corner')
     l, _, q, _, lo, hi, Rq = union_box(names)
@@ -525,7 +560,7 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
         pts.append(tp + quat_mat(tq) @ (sph[i]['pos'] + m.jnt_axis[l] * mid))
       pts = np.array(pts)
     ctr = pts.mean(0)
-    rad = max(np.sqrt(((pts[k] - ctr) ** 2).sum()) + sph[i]['r'] for k, i in enumerate(members)) + slack
+    rad = max(np.sqrt(((pts[k] - ctr) ** 2).sum()) + sph[i]['r'] + sph[i].get('hl', 0.0) for k, i in enumerate(members)) + slack
     mmax = max(max(sph[i]['margin'], bx['margin']) for i in members)
     blocks.append(dict(box=j, link=bl, center=ctr, reach=rad + mmax + 1e-6, set=sname, members=members))
   # Contacts are kept first come, first served up to max_contacts, so the ORDER of the blocks is a priority: blocks of the sets
@@ -548,6 +583,8 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
     pair_cls.append(cls.index(key))
   return dict(col_sph_link=np.array([x['link'] for x in sph], np.int32), col_sph_pos=np.array([x['pos'] for x in sph]),
               col_sph_r=np.array([x['r'] for x in sph]),
+              col_sph_dir=np.array([x.get('dir', np.zeros(3)) for x in sph]), col_sph_hl=np.array([x.get('hl', 0.0) for x in sph]),
+              col_box_kind=np.array([x.get('kind', 0) for x in box], np.int32),
               col_box_link=np.array([x['link'] for x in box], np.int32), col_box_pos=np.array([x['pos'] for x in box]),
               col_box_quat=np.array([x['quat'] for x in box]), col_box_half=np.array([x['half'] for x in box]),
               col_pair=np.array(pairs, np.int32).reshape(-1, 2), col_pair_cls=np.array(pair_cls, np.int32),
@@ -782,6 +819,27 @@ class LinkModel:
       else:
         pb, Rb = pos[lb] + quat_mat(quat[lb]) @ self.col_box_pos[bi], quat_mat(quat_mul(quat[lb], self.col_box_quat[bi]))
       h, r = self.col_box_half[bi], float(self.col_sph_r[si])
+      margin = float(self.col_cls_margin[cls])
+      if hasattr(self, 'col_box_kind') and self.col_box_kind[bi] == 1:       # edge (segment) vs capsule: closest points of two segments
+        ed = self.col_sph_dir[si] if ls < 0 else quat_mat(quat[ls]) @ self.col_sph_dir[si]
+        he, cd, hc, rad = float(self.col_sph_hl[si]), Rb[:, 2], float(h[2] - h[0]), float(h[0])
+        rr = c - pb
+        b_, c_, f_ = ed @ cd, ed @ rr, cd @ rr
+        den = 1.0 - b_ * b_
+        s_ = min(max((b_ * f_ - c_) / den, -he), he) if den > 1e-12 else 0.0
+        t_ = min(max(b_ * s_ + f_, -hc), hc)
+        s_ = min(max(b_ * t_ - c_, -he), he)
+        pc = pb + t_ * cd
+        d = c + s_ * ed - pc
+        nd = np.sqrt(d @ d)
+        dist = nd - rad
+        if dist < margin and nd > 1e-9:
+          n = d / nd
+          out.append(dict(pair=pi, cls=cls, ls=ls, lb=lb, dist=dist, n=n, p=pc + n * (rad + 0.5 * dist)))
+          taken[blk_of[pi]] += 1
+          if len(out) == self.max_contacts:
+            break
+        continue
       x = Rb.T @ (c - pb)
       q = np.clip(x, -h, h)
       if (np.abs(x) > h).any():
@@ -794,7 +852,6 @@ class LinkModel:
         nl = np.zeros(3); nl[i] = sg
         dist = -(h[i] - abs(x[i])) - r
         q = x.copy(); q[i] = sg * h[i]
-      margin = float(self.col_cls_margin[cls])
       if dist < margin:
         n = Rb @ nl
         p = pb + Rb @ q + n * (0.5 * dist)

@@ -144,6 +144,8 @@ def test_drag_row_is_the_exact_reduction_of_the_door_panel_standing_in_the_table
   e = dict(z)
   e['col_sph_link'] = np.concatenate([z['col_sph_link'], [9] * 4]).astype(np.int32)
   e['col_sph_pos'] = np.vstack([z['col_sph_pos'], pts]); e['col_sph_r'] = np.concatenate([z['col_sph_r'], [0] * 4])
+  e['col_sph_dir'] = np.vstack([z['col_sph_dir'], np.zeros((4, 3))]); e['col_sph_hl'] = np.concatenate([z['col_sph_hl'], [0] * 4])
+  e['col_blk_cap'] = np.full(len(z['col_blk_cap']), 99, np.int32)      # the four pairs are prepended: the block table no longer lines up with the pair list
   # class of the pair (door panel, table): MuJoCo's mixing of the two geoms' parameters, as the compiler computes it for the drag row
   m = po.Model(MODEL)
   gp = [g for g in range(len(m.geom_body)) if m.geom_body[g] == m.body_id('door_link') and m.geom_type[g] == 4 and m.geom_contype[g]][0]

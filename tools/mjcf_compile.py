@@ -385,8 +385,12 @@ def main():
     tbl = [g for g in big if m['geom_body'][g] == table][0]
     red = po.reduce_model(pm, bp, attach_bodies=['hand'], attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector'],
                           attach_geoms=['handle'],
-                          collision=dict(plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], chains=chains,
+                          collision=dict(plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']],
+                                         chains=[dict(geom=g, spacing=0.9 if m['geom_size'][g][0] < 0.015 else 0.75) for g in chains],   # 16 spheres: one pass per plate
+                                        
                                          corner_sets=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], big_boxes=big,
+                                         edge_caps=dict(plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], caps=chains, per_plate=True),
+                                         set_priority=('edge0', 'edge1'), set_cap=dict(edge0=1, edge1=1), drop_contained=True,
                                          drag=[(panel, tbl, -(bp[pm.body_id('door')][2] - m['geom_size'][panel][2]))]))
     np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
   if name == 'sawyer_peg':
