@@ -264,8 +264,8 @@ def main_sawyer(a, torch, dist, world, rank, device):
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': None, 'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
                         'algorithmic_bytes_per_launch': per_launch, 'bytes_per_env_step': bytes_per_env_step,
-                        'note': 'not HBM-bound: instruction issue and LDS latency at one wave per SIMD (door: 46 % of wave cycles issue, '
-                                '49 % wait on LDS / memory counters, profiles/r01_sawyer_rollout_pmc.json); the HBM figure is reported '
+                        'note': 'not HBM-bound: instruction issue and LDS latency at one wave per SIMD (door: 55 % of wave cycles issue, '
+                                '41 % wait on LDS / memory counters, profiles/r01_sawyer_door_rollout_pmc.json); the HBM figure is reported '
                                 'because the schema asks for it'},
            'cpu_baseline': None if a.no_cpu else sawyer_cpu_baseline(T, a.cpu_seconds, a.workload)}
     print(json.dumps(res), flush=True)
