@@ -1,8 +1,9 @@
 /* earl_physics.h -- C ABI of the batched articulated-body stepper (BASELINE config 3:
  * sawyer_door and sawyer_peg).
  *
- * STATUS: smooth dynamics, weld / joint-limit constraints, frictional contacts (spheres / points vs boxes, pyramidal
- * friction).  Parity with MuJoCo is UNPINNED (the
+ * STATUS: smooth dynamics, weld / joint-limit constraints, frictional contacts (spheres / points vs boxes, plate edges vs
+ * capsules, pyramidal friction).  The weld's translational regulariser carries a factor calibrated against the reference's
+ * MuJoCo recordings.  Parity with MuJoCo is UNPINNED (the
  * simulator is not available to this build): the kernel is tested against this build's own CPU reference
  * (oracle/physics_oracle.py: LinkModel) which follows MuJoCo's documented pipeline and is checked by first principles;
  * the model tables and forward kinematics ARE pinned by numbers recorded in the reference (tests/test_physics.py).
@@ -59,7 +60,7 @@ typedef struct earl_link_model {
 } earl_link_model;
 
 /* Collision geometry of a link model: SPHERES (cylinders are chains of spheres; box corners are spheres of radius 0)
- * tested against BOXES over a fixed pair list; per-pair solver parameters by class (MuJoCo's geom mixing rules applied
+ * tested against BOXES, and EDGES (segments) tested against CAPSULES (blk_cap bit 8), over a fixed pair list; per-pair solver parameters by class (MuJoCo's geom mixing rules applied
  * at model-compile time).  At most max_con (<= EARL_MAXCON) contacts per env and timestep: the first active pairs in list order.
  * Models with nv <= 10 are limited to 8 contact slots and 16 blocks (their workgroup then fits four times into a CU's LDS). */
 #define EARL_MAXSPH 64

@@ -170,6 +170,46 @@ def test_drag_row_is_the_exact_reduction_of_the_door_panel_standing_in_the_table
     np.testing.assert_allclose(a['qacc'], b['qacc'], rtol=1e-9, atol=1e-9 * np.abs(b['qacc']).max())
 
 
+def test_edge_vs_capsule_contacts_are_the_closest_points_of_the_two_segments():
+  """the door handle's rods are capsules for the long edges of the finger plates (test kind 2).  States from the
+  grasp of forward demonstration 0: every contact the pair loop reports from a capsule block is checked against a brute-force
+  search over both segments (distance, normal, contact point), and such contacts do occur"""
+  from oracle.sawyer_oracle import SawyerDoorOracle
+  lm = po.LinkModel(LINKS)
+  z = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'demonstrations', 'sawyer_door', 'forward', 'demo_data.npz'))
+  env = SawyerDoorOracle(lm)
+  env.reset()
+  env.qpos[9] = -0.894
+  seen = 0
+  ts, tc = np.linspace(-1, 1, 1201), np.linspace(-1, 1, 1201)
+  for t in range(60):
+    env.step(z['actions'][t])
+    if t < 18 or t % 4:
+      continue
+    pos, quat, _ = lm.kinematics(env.qpos)
+    for c in lm.collide(pos, quat):
+      si, bi = lm.col_pair[c['pair']]
+      if lm.col_box_kind[bi] != 1:
+        continue
+      seen += 1
+      ls, lb = int(lm.col_sph_link[si]), int(lm.col_box_link[bi])
+      e0 = pos[ls] + po.quat_mat(quat[ls]) @ lm.col_sph_pos[si]
+      ed = po.quat_mat(quat[ls]) @ lm.col_sph_dir[si]
+      Rb = po.quat_mat(po.quat_mul(quat[lb], lm.col_box_quat[bi]))
+      c0, cd = pos[lb] + po.quat_mat(quat[lb]) @ lm.col_box_pos[bi], Rb[:, 2]
+      he, rad = float(lm.col_sph_hl[si]), float(lm.col_box_half[bi][0])
+      hc = float(lm.col_box_half[bi][2]) - rad
+      P = e0[None, None] + (ts * he)[:, None, None] * ed[None, None]           # points of the edge   [1201, 1, 3]
+      Q = c0[None, None] + (tc * hc)[None, :, None] * cd[None, None]           # points of the axis   [1, 1201, 3]
+      D = np.linalg.norm(P - Q, axis=2)
+      i, j = np.unravel_index(np.argmin(D), D.shape)
+      assert abs((D[i, j] - rad) - c['dist']) < 2e-6 and c['dist'] < lm.col_cls_margin[c['cls']]
+      n = (P[i, 0] - Q[0, j]) / D[i, j]
+      assert np.abs(n - c['n']).max() < 6e-3 and abs(np.linalg.norm(c['n']) - 1) < 1e-12
+      assert np.abs(Q[0, j] + n * (rad + 0.5 * c['dist']) - c['p']).max() < 5e-4
+  assert seen >= 8
+
+
 def test_block_cull_never_drops_a_contact():
   from oracle.sawyer_oracle import SawyerDoorOracle
   lm = po.LinkModel(LINKS)
