@@ -517,6 +517,7 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
   # reduction against the explicit contacts):  cost 1/2 G (a_j + b v_j)^2,  G = sum_k rho_k^2 / R0.
   nv = len(m.jnt_body)
   drag_G, drag_b = np.zeros(nv), np.zeros(nv)
+  drag_calib = float(spec.get('drag_calibration', 1.0))   # tools/mjcf_compile.py DOOR_DRAG_CALIBRATION
   for g_mov, g_fix, depth in spec.get('drag', ()):
     l, p, q = gframe(g_mov)
     a, b = params(g_mov), params(g_fix)
@@ -530,7 +531,7 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
       for sy in (-1, 1):
         c = p + quat_mat(q) @ np.array([sx * h[0], sy * h[1], -h[2]]) - anchor
         rho2 = c @ c - (c @ axis) ** 2
-        drag_G[l] += rho2 / R0
+        drag_G[l] += drag_calib * rho2 / R0
     drag_b[l] = bb
   # pairs in BOX-MAJOR order, cut into blocks (one box x one set of spheres) that carry a bounding test: the kernel skips
   # a whole block when the set's bounding sphere is clear of the box's.  Chain spheres ride on one link; the corner
@@ -590,7 +591,7 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
               col_pair=np.array(pairs, np.int32).reshape(-1, 2), col_pair_cls=np.array(pair_cls, np.int32),
               col_cls_mu=np.array([c[0] for c in cls]), col_cls_solref=np.array([c[1] for c in cls]),
               col_cls_solimp=np.array([c[2] for c in cls]), col_cls_margin=np.array([c[3] for c in cls]),
-              col_cls_invw=np.array([c[4] for c in cls]), dof_drag_G=drag_G, dof_drag_b=drag_b,
+              col_cls_invw=np.array([c[4] for c in cls]), dof_drag_G=drag_G, dof_drag_b=drag_b, dof_drag_calibration=np.float64(drag_calib),
               col_blk_begin=np.array([b['begin'] for b in blocks], np.int32), col_blk_end=np.array([b['end'] for b in blocks], np.int32),
               col_blk_box=np.array([b['box'] for b in blocks], np.int32), col_blk_link=np.array([b['link'] for b in blocks], np.int32),
               col_blk_center=np.array([b['center'] for b in blocks]), col_blk_reach=np.array([b['reach'] for b in blocks]),

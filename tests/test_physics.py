@@ -135,6 +135,10 @@ def test_drag_row_is_the_exact_reduction_of_the_door_panel_standing_in_the_table
   all pyramid edges active) by one soft velocity row on the door hinge; here the explicit contacts are rebuilt and
   both formulations must give the same accelerations"""
   z = dict(np.load(LINKS))
+  # the shipped table carries that row times a declared calibration against the MuJoCo recordings (tools/mjcf_compile.py
+  # DOOR_DRAG_CALIBRATION); the reduction itself is checked with the factor divided out
+  assert float(z['dof_drag_calibration']) == 0.8
+  z['dof_drag_G'] = z['dof_drag_G'] / float(z['dof_drag_calibration'])
   lm = po.LinkModel(dict(z))
   bi_panel = [i for i in range(len(z['col_box_link'])) if z['col_box_link'][i] == 9][0]
   bi_table = [i for i in range(len(z['col_box_link'])) if z['col_box_link'][i] == -1 and z['col_box_half'][i][0] == 0.7][0]

@@ -157,7 +157,7 @@ def test_contact_dynamics_match_oracle_through_a_grasp(lm):
     # resynchronise so that every step is an independent comparison
     env.qpos[:] = torch.from_numpy(ref.qpos).cuda(); env.qvel[:] = torch.from_numpy(ref.qvel).cuda()
     env.mocap_pos[:] = torch.from_numpy(ref.mocap).cuda()
-    assert np.linalg.norm(o_ref[4:7] - nobs[t][4:7]) < 0.012, (t, o_ref[4:7], nobs[t][4:7])   # ... and its recorded handle position (9 mm behind at step 43)
+    assert np.linalg.norm(o_ref[4:7] - nobs[t][4:7]) < 0.006, (t, o_ref[4:7], nobs[t][4:7])   # ... and its recorded handle position
   assert ncon_steps >= 15
   assert ref.qpos[9] > ang + 0.15                      # the door was dragged towards closed
   assert bool((env.qpos[0] == env.qpos[1]).all())      # identical envs in one wavefront stay identical
@@ -168,12 +168,14 @@ def test_all_demo_episodes_open_loop_loose():
   the first recorded handle position).  The demonstrations come from MuJoCo with a feedback policy; this build's
   stepper is a different simulator (sphere-chain handle, pyramidal friction, 8-contact cap), so only loose agreement is
   asserted -- the bounds are what round 1 measures plus margin, and DESIGN.md section 9 quotes the measured values
-  (tools/door_demo_eval.py prints them).  With the weld regulariser calibrated against the recordings
-  (oracle/physics_oracle.py WELD_TRANSLATION_CALIBRATION):
-  forward (close the door): in at least 4 of 5 episodes the gripper opening follows the recording within 0.01 through the WHOLE
-  episode (grasp, drag, release: the contact sequence is the recorded one), the hand within 6 cm, the handle path RMS < 3 cm; the
-  door ends 3-5 cm short of the goal (it moves ~10 % slower than recorded), so the 2 cm success radius is not reached;
-  reverse (pull the door open): the door is pulled in at least 4 of 5 episodes, handle path RMS < 12 cm, not to the goal."""
+  (tools/door_demo_eval.py prints them).  With the two declared calibrations against the recordings (weld regulariser:
+  oracle/physics_oracle.py WELD_TRANSLATION_CALIBRATION; door drag: tools/mjcf_compile.py DOOR_DRAG_CALIBRATION) and the edge-vs-capsule
+  contacts of the handle rods:
+  forward (close the door): in ALL 5 episodes the replayed handle follows the recorded one within 1 cm RMS over the WHOLE episode
+  (2-4 mm measured), the gripper opening within 0.005 (grasp, drag, release: the contact sequence is the recorded one), the hand
+  within 7 cm; at least 4 reach the goal;
+  reverse (pull the door open): the door is pulled in all 5, at least 3 follow the recorded handle within 2 cm RMS (1.0-1.4 cm measured);
+  two lose the rod on the way (handle path RMS < 10 cm)."""
   import torch
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
   eps = []
@@ -200,9 +202,9 @@ def test_all_demo_episodes_open_loop_loose():
   for i, e in enumerate(eps):
     acts[:len(e[2]), i] = e[2]
   out = env.rollout(torch.from_numpy(acts).cuda())
-  obs = out['obs'].cpu().numpy()
+  obs, suc = out['obs'].cpu().numpy(), out['success'].cpu().numpy()
   assert np.isfinite(obs).all()
-  tracked = pulled = 0
+  reached = pulled = followed = 0
   for i, e in enumerate(eps):
     L = len(e[2])
     o, w = obs[:L, i], e[3]
@@ -212,13 +214,14 @@ def test_all_demo_episodes_open_loop_loose():
     start = np.linalg.norm(w[0, 4:7] - w[0, 11:14])
     closest = np.linalg.norm(o[:, 4:7] - o[:, 11:14], axis=1).min()
     if e[0] == 'forward':
-      tracked += bool(handle_rms < 0.03 and hand_max < 0.06 and grip_max < 0.01 and closest < 0.08)
-      assert handle_rms < 0.09, (i, handle_rms, closest)
+      reached += bool(suc[:L, i].any())
+      assert handle_rms < 0.01 and hand_max < 0.07 and grip_max < 0.005, (i, handle_rms, hand_max, grip_max)
     else:
       pulled += bool(closest < 0.95 * start)
-      assert handle_rms < 0.12, (i, handle_rms, closest, start)
+      followed += bool(handle_rms < 0.02)
+      assert handle_rms < 0.10, (i, handle_rms, closest, start)
     assert (o[:, 9 - 9 + 3] >= 0).all() and (np.abs(o[:, 6] - 0.10003595) < 1e-6).all()     # handle height never changes (hinge about z)
-  assert tracked >= 4 and pulled >= 4, (tracked, pulled)
+  assert reached >= 4 and pulled == 5 and followed >= 3, (reached, pulled, followed)
 
 
 def test_shards_equal_one_batch_and_both_lane_layouts_agree():

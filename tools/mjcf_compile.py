@@ -28,6 +28,16 @@ MODELS = {
 }
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'earl_benchmark_amd', 'models')
 
+# The door panel stands 2.3 cm inside the table top; its four permanent corner contacts reduce to one viscous row on the door hinge
+# (oracle/physics_oracle.py, "Permanent deep box-in-box contacts").  With the coefficient derived from the MJCF parameters and the
+# calibrated weld (physics_oracle.WELD_TRANSLATION_CALIBRATION) the door moves ~10 % slower than in the MuJoCo recordings: the replayed
+# handle ends 3-5 cm behind the recorded one in all five forward demonstrations (path RMS 1.8-2.5 cm).  With 0.8 x the derived value the
+# five forward replays follow the recorded handle path within 2-4 mm RMS over the WHOLE episode (finals 3-7 mm; scan 0.6 / 0.75 / 0.8 /
+# 0.85 / 1.0: RMS 24-30 / 5-9 / 2-4 / 3-8 / 18-25 mm) and the three reverse replays that keep the rod within 10-13 mm (26-35 mm at 1.0).
+# A second CALIBRATION against the recordings (door only), declared as such: which MuJoCo rule accounts for it is not identified
+# (candidates: the table's solref 0.02 taken unmixed gives 0.75; saturation of the elliptic cone at the far corners at speed).
+DOOR_DRAG_CALIBRATION = 0.8
+
 
 # ------------------------------------------------------------------ small math
 def quat_mul(a, b):
@@ -391,7 +401,8 @@ def main():
                                          corner_sets=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], big_boxes=big,
                                          edge_caps=dict(plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']], caps=chains, per_plate=True),
                                          set_priority=('edge0', 'edge1'), set_cap=dict(edge0=1, edge1=1), drop_contained=True,
-                                         drag=[(panel, tbl, -(bp[pm.body_id('door')][2] - m['geom_size'][panel][2]))]))
+                                         drag=[(panel, tbl, -(bp[pm.body_id('door')][2] - m['geom_size'][panel][2]))],
+                                         drag_calibration=DOOR_DRAG_CALIBRATION))
     np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
   if name == 'sawyer_peg':
     # link form of the peg task.  reset_model puts body 'box' at goal - (0.03, 0, 0.13) = its MJCF position (sawyer_peg.py:196-197).
