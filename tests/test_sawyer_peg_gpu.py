@@ -152,9 +152,9 @@ def test_grasp_and_lift_match_the_cpu_statement():
 def test_forward_demos_open_loop_loose():
   """the 10 forward demonstrations (MuJoCo, feedback policy) replayed OPEN LOOP in this build's stepper (sphere-chain
   peg, pyramidal friction, 12-contact cap).  Only loose agreement is asserted; the bounds are what this round measures plus
-  margin (DESIGN.md quotes the measured values: hand RMS 1.0-2.0 cm, peg RMS 0.8-1.4 cm, 10 / 10 lifted to the recorded height, 4 / 10
-  inserted): the hand follows the recorded path (RMS < 2.5 cm), so does the peg (RMS < 3 cm), at least 9 episodes lift the peg to within
-  2 cm of the recorded height, at least 3 end inserted."""
+  margin (DESIGN.md quotes the measured values with the calibrated weld: hand RMS 0.6-0.8 cm, peg RMS 0.6-1.3 cm, 10 / 10 lifted to the
+  recorded height, 3 / 10 inserted): the hand follows the recorded path (RMS < 1.2 cm), so does the peg (RMS < 1.8 cm), at least 9 episodes
+  lift the peg to within 2 cm of the recorded height, at least 3 end inserted."""
   import torch
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   eps = episodes('forward')
@@ -173,8 +173,8 @@ def test_forward_demos_open_loop_loose():
   for i, e in enumerate(eps):
     L = len(e[1])
     o, w = obs[:L, i], e[2]
-    assert np.sqrt(((o[:, :3] - w[:, :3]) ** 2).sum(1).mean()) < 0.025, i
-    assert np.sqrt(((o[:, 4:7] - w[:, 4:7]) ** 2).sum(1).mean()) < 0.03, i
+    assert np.sqrt(((o[:, :3] - w[:, :3]) ** 2).sum(1).mean()) < 0.012, i
+    assert np.sqrt(((o[:, 4:7] - w[:, 4:7]) ** 2).sum(1).mean()) < 0.018, i
     assert (o[:, 6] > 0.004).all()                      # the peg is pressed into the soft table top by the plates at most ~1 cm, never through it
     lifted += abs(o[:, 6].max() - w[:, 6].max()) < 0.02
     inserted += bool(suc[L - 1, i])
@@ -389,9 +389,10 @@ def test_long_random_rollouts_stay_finite(task):
 def test_reverse_demos_open_loop_loose():
   """the 20 reverse demonstrations (reset_at_goal: the peg starts inside the hole, the policy pulls it out and lays it down at one of the
   initial states) replayed OPEN LOOP: the peg settling inside the hole during the first 12 steps follows MuJoCo's recording within 2.5 mm
-  in at least 18 episodes (sphere chain / corner points against the hole walls), the hand path within 2.5 cm RMS in all, the peg path
-  within 2.5 cm RMS over the whole episode in at least 12; the recorded episodes end ON the success radius (4.1 - 5.0 cm), so only a few
-  replays end inside it.  Measured this round: 19 / 20 prefixes within 1.7 mm, 14 / 20 peg paths within 2 cm, 3 / 20 successes."""
+  in at least 18 episodes (sphere chain / corner points against the hole walls), the hand path within 1.6 cm RMS in all, the peg path
+  within 2 cm RMS over the WHOLE episode in all 20; the recorded episodes end ON the success radius (4.1 - 5.0 cm), so only some replays
+  end inside it.  Measured this round with the calibrated weld: 19 / 20 prefixes within 1.7 mm, hand RMS 0.4-1.3 cm, peg RMS
+  0.4-1.7 cm in 20 / 20 (derived weld: 14 / 20 under 2 cm, six lost the peg), 8 / 20 successes."""
   import torch
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   eps = episodes('reverse')
@@ -411,8 +412,8 @@ def test_reverse_demos_open_loop_loose():
   for i, e in enumerate(eps):
     L = len(e[1])
     o, w = obs[:L, i], e[2]
-    assert np.sqrt(((o[:, :3] - w[:, :3]) ** 2).sum(1).mean()) < 0.025, i
+    assert np.sqrt(((o[:, :3] - w[:, :3]) ** 2).sum(1).mean()) < 0.016, i
     prefix += np.abs(o[11, 4:7] - w[11, 4:7]).max() < 2.5e-3
-    path += np.sqrt(((o[:, 4:7] - w[:, 4:7]) ** 2).sum(1).mean()) < 0.025
+    path += np.sqrt(((o[:, 4:7] - w[:, 4:7]) ** 2).sum(1).mean()) < 0.02
     np.testing.assert_allclose(o[:, 7:], np.repeat(e[0][7:][None].astype(np.float64), L, 0), atol=0)
-  assert prefix >= 18 and path >= 12, (prefix, path)
+  assert prefix >= 18 and path == 20, (prefix, path)
