@@ -164,6 +164,15 @@ def cpu_baseline(n, T, reward, seconds):
           'scalar_python_loop_1env': scalar_rate}
 
 
+def sawyer_traffic(workload, n, T):
+  """HBM bytes per launch of the Sawyer rollout kernel from the committed PMC profile (profiles/traffic.json, written by
+  tools/summarize_sawyer.py from separate FETCH_SIZE / WRITE_SIZE passes), or None when the profile is of another shape"""
+  tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+  if not os.path.exists(tpath) or (n, T) != ((8192, 300) if workload == 'sawyer_door' else (8192, 200)):
+    return None
+  return json.load(open(tpath)).get(workload, {}).get('hbm_bytes_per_launch')
+
+
 def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door'):
   """The C restatement of the same stepper and env loop (oracle/physics_oracle.c, OpenMP over envs) on the host cores:
   a short thread sweep, then a bounded sample at the best thread count.  MuJoCo itself is not available on this host;
@@ -262,7 +271,7 @@ def main_sawyer(a, torch, dist, world, rank, device):
                       'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
                       'parallelism': f'env-range shard x{world}, no per-step collective'},
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                        'traffic': None, 'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
+                        'traffic': sawyer_traffic(a.workload, n, T), 'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
                         'algorithmic_bytes_per_launch': per_launch, 'bytes_per_env_step': bytes_per_env_step,
                         'note': 'not HBM-bound: instruction issue and LDS latency at one wave per SIMD (door: 55 % of wave cycles issue, '
                                 '41 % wait on LDS / memory counters, profiles/r01_sawyer_door_rollout_pmc.json); the HBM figure is reported '
