@@ -100,3 +100,15 @@ def test_product_never_imports_the_oracle():
         for line in txt.splitlines():
           if re.search(r'^\s*(from|import)\s+oracle\b|libearl_oracle|#include\s+"[^"]*oracle', line):
             raise AssertionError(f'{f}: {line}')
+
+
+def test_importing_the_product_does_not_load_the_oracle():
+  """the runtime counterpart of the source check above: importing the package and its env / physics / glue / wrapper modules in a
+  fresh interpreter leaves no `oracle` module in sys.modules"""
+  import subprocess
+  import sys
+  code = ('import sys, earl_benchmark_amd, earl_benchmark_amd.glue, earl_benchmark_amd.physics, earl_benchmark_amd.envs.sawyer_door, '
+          'earl_benchmark_amd.envs.sawyer_peg, earl_benchmark_amd.wrappers; '
+          'bad = [m for m in sys.modules if m == "oracle" or m.startswith("oracle.")]; print(bad); sys.exit(1 if bad else 0)')
+  r = subprocess.run([sys.executable, '-c', code], cwd=REPO, capture_output=True, text=True)
+  assert r.returncode == 0, r.stdout + r.stderr
