@@ -143,8 +143,8 @@ def test_reset_pose_and_forward_demonstrations_open_loop():
   passes the 180-degree branch point of the weld's quaternion residual.
   The ten forward demonstrations (MuJoCo + a feedback policy) replayed OPEN LOOP through the C restatement: the hand follows the
   recorded path, EVERY episode grasps the peg and lifts it to the recorded height, the peg path stays within a few cm, several end
-  inserted in the hole.  Measured this round with the calibrated weld: 10 / 10 lifted, 3 / 10 inserted, hand RMS 0.6-0.8 cm,
-  peg RMS 0.6-1.3 cm (derived weld: 1.0-2.0 / 0.5-2.1 cm, 4 / 10; from the 250-timestep transient state, 59 degrees off: 6 / 10 lifted,
+  inserted in the hole.  Measured this round with the calibrated weld: 10 / 10 lifted, 7 / 10 inserted, hand RMS 0.6-0.9 cm,
+  peg RMS 0.4-1.5 cm (derived weld: 1.0-2.0 / 0.5-2.1 cm, 4 / 10; from the 250-timestep transient state, 59 degrees off: 6 / 10 lifted,
   peg RMS 6 cm).  The 20 reverse demonstrations (pull the peg out of the hole, lay it down): peg path within 2 cm RMS in all 20."""
   from oracle import physics_c
   from oracle.sawyer_oracle import SETTLE_TIMESTEPS
@@ -174,7 +174,7 @@ def test_reset_pose_and_forward_demonstrations_open_loop():
     lifted += abs(ob[:, 6].max() - nxt[:, 6].max()) < 0.02
     inserted += bool(suc[-1, 0])
     assert rew[-1] == 1.0
-  assert lifted == 10 and inserted >= 3, (lifted, inserted)
+  assert lifted == 10 and inserted >= 5, (lifted, inserted)
   for obs0, acts, nxt, rew in episodes('reverse'):
     q, v = q0[None].copy(), v0[None].copy()
     q[0, 9:12] = obs0[4:7] + np.array([0.1, 0, 0]); v[0, 9:] = 0
