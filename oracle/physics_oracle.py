@@ -46,6 +46,9 @@ WELD_TRANSLATION_CALIBRATION = 4.0
 #     2 mm (recorded: none), so the peg arrives 2-3 mm low at the hole's mouth; with 0.5 it leans 0.9 degrees;
 #   * door, reverse demonstrations: 4 of 5 keep the rod (3 of 5), one reaches the goal;
 #   * against it: the peg's contact-free prefixes get slightly worse (5.1 -> 6.0 mm).
+# A candidate cause for exactly 0.5: metaworld sets mocap_quat = [1, 0, 1, 0], NOT normalised (norm sqrt 2).  If MuJoCo 2.1 uses it as it
+# is, the orientation residual vec(conj(q_hand) * q_mocap) and its Jacobian are both scaled by sqrt 2, which doubles the rows' weight,
+# i.e. halves their effective regulariser.  (This file normalises the mocap quaternion and carries the factor instead.)
 WELD_ROTATION_CALIBRATION = 0.5
 
 
