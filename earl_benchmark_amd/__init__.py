@@ -41,6 +41,10 @@ _NOT_BUILT = ('{name}: the physics-backed envs (MuJoCo / Bullet dynamics) are no
               'only their initial/goal-state tables and demonstrations are available. See DESIGN.md "out of scope".')
 
 
+class UnpinnedDynamicsWarning(UserWarning):
+  """an env whose dynamics could not be checked against the reference's simulator (absent from this build's environment)"""
+
+
 class EARLEnvs(object):
   """Same constructor and methods as the reference's EARLEnvs (earl_benchmark/__init__.py:83-247)."""
 
@@ -55,19 +59,37 @@ class EARLEnvs(object):
     self._kwargs = kwargs
     self._batch_kwargs = {k: kwargs[k] for k in ('num_envs', 'device', 'seed', 'env_offset', 'scalar_api', 'auto_reset') if k in kwargs}
 
+    if env_name == 'kitchen' and reward_type != 'dense':
+      raise ValueError('Kitchen environment only supports dense rewards.')  # reference: envs/kitchen.py:91-92 (raised while constructing)
     if not self._setup_as_lifelong_learning:
       cfg = deployment_eval_config[env_name]
       self._train_horizon = kwargs.get('train_horizon', cfg['train_horizon'])
       self._eval_horizon = kwargs.get('eval_horizon', cfg['eval_horizon'])
       self._num_initial_state_samples = kwargs.get('num_initial_state_samples', cfg['num_initial_state_samples'])
-      self._train_env = self.get_train_env()
-      self._eval_env = self.get_eval_env()
     else:
       cfg = continuing_eval_config[env_name]
       self._train_horizon = kwargs.get('train_horizon', cfg['train_horizon'])
       self._num_initial_state_samples = kwargs.get('num_initial_state_samples', cfg['num_initial_state_samples'])
       self._goal_change_frequency = kwargs.get('goal_change_frequency', cfg['goal_change_frequency'])
-      self._train_env = self.get_train_env(lifelong=True)
+    # The reference builds its envs here.  This build defers that to the first get_envs(): the tables and demonstrations of EVERY env
+    # name (incl. the ones whose dynamics are not built, and on machines without a GPU) stay reachable through the real constructor.
+    self._envs = None
+
+  def _build_envs(self):
+    if self._envs is None:
+      if not self._setup_as_lifelong_learning:
+        self._envs = (self.get_train_env(), self.get_eval_env())
+      else:
+        self._envs = (self.get_train_env(lifelong=True), None)
+    return self._envs
+
+  @property
+  def _train_env(self):
+    return self._build_envs()[0]
+
+  @property
+  def _eval_env(self):
+    return self._build_envs()[1]
 
   def _make_env(self, reset_at_goal, seed_salt):
     from . import wrappers  # noqa: F401  (imports torch lazily: tables/demos work without a GPU)
@@ -78,6 +100,12 @@ class EARLEnvs(object):
       return tabletop.TabletopManipulation(task_list='rc_r-rc_k-rc_g-rc_b', reward_type=self._reward_type,
                                            reset_at_goal=reset_at_goal,
                                            wide_init_distr=self._kwargs.get('wide_init_distr', False), **kw)
+    if self._env_name in ('sawyer_door', 'sawyer_peg') and not self._kwargs.get('allow_unpinned_dynamics', False):
+      import warnings
+      warnings.warn(f'{self._env_name}: the rigid-body dynamics are this build\'s own stepper and contact model; parity with the reference\'s '
+                    'MuJoCo 2.1 is UNPINNED (DESIGN.md section 9: trajectory-level agreement with the recorded demonstrations only, and three '
+                    'constants calibrated on them).  Pass allow_unpinned_dynamics=True to EARLEnvs to silence this.', UnpinnedDynamicsWarning,
+                    stacklevel=3)
     if self._env_name == 'sawyer_door':
       # reference: earl_benchmark/__init__.py (sawyer_door.SawyerDoorV2(reward_type=..., reset_at_goal=...)); dynamics: this
       # build's own stepper and contact model -- parity with MuJoCo unpinned
@@ -91,8 +119,6 @@ class EARLEnvs(object):
       kw = dict(self._batch_kwargs)
       kw['seed'] = int(kw.get('seed', 0)) + seed_salt
       return sawyer_peg.SawyerPeg(reward_type=self._reward_type, reset_at_goal=reset_at_goal, **kw)
-    if self._env_name == 'kitchen' and self._reward_type != 'dense':
-      raise ValueError('Kitchen environment only supports dense rewards.')  # reference: envs/kitchen.py:91-92
     raise NotImplementedError(_NOT_BUILT.format(name=self._env_name))
 
   def get_train_env(self, lifelong=False):

@@ -26,7 +26,7 @@ class TabletopState(C.Structure):
 
 
 class TabletopOut(C.Structure):
-  _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p)]
+  _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p), ('reward_f64', C.c_void_p)]
 
 
 class MotorParams(C.Structure):   # struct earl_motor_params (include/earl_glue.h)
@@ -58,11 +58,15 @@ class SawyerCfg(C.Structure):   # struct earl_sawyer_cfg (include/earl_physics.h
 
 class SawyerState(C.Structure):
   _fields_ = [('qpos', C.c_void_p), ('qvel', C.c_void_p), ('mocap_pos', C.c_void_p), ('goal', C.c_void_p),
-              ('steps_since_reset', C.c_void_p), ('steps_since_goal_change', C.c_void_p), ('obj_init', C.c_void_p)]
+              ('steps_since_reset', C.c_void_p), ('steps_since_goal_change', C.c_void_p), ('obj_init', C.c_void_p),
+              ('last_obs', C.c_void_p), ('fail_count', C.c_void_p)]
 
 
 class SawyerOut(C.Structure):
-  _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p)]
+  _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p), ('status', C.c_void_p)]
+
+
+STEP_DIVERGED = 1     # EARL_STEP_DIVERGED (include/earl_physics.h)
 
 
 _P = C.POINTER

@@ -1203,11 +1203,19 @@ __device__ __forceinline__ double peg_dense_reward(const earl_sawyer_cfg& cfg, c
   return r;
 }
 
+// any lane of this env's LPE-lane group (the whole wavefront calls it)
+template <int LPE>
+__device__ __forceinline__ bool group_any(const bool pred, const int grp) {
+  const unsigned long long bal = __ballot(pred);
+  if constexpr (LPE == 64) return bal != 0ull;
+  else return ((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull)) != 0ull;
+}
+
 // obs[14] + reward + flags of one env from the kinematics in LDS (sawyer_door.py:86-94, :141-177); the whole group calls it
 template <int NV>
 __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model& m, const earl_sawyer_cfg& cfg, const int sub, const bool live,
                                             const double* __restrict__ goal, double* __restrict__ obs, float* reward, uint8_t* success,
-                                            const double* __restrict__ obj_init = nullptr, const double effort = 0.0) {
+                                            const double* __restrict__ obj_init = nullptr, const double effort = 0.0, double* __restrict__ obs2 = nullptr) {
 #pragma clang fp contract(off)
   // (compiled into the peg model's kernels only: in the door kernel this code cost 35 more AGPR spills and 10 % of its throughput)
   const bool peg_dense = NV >= 15 && cfg.obj_kind >= 1 && cfg.reward_type != 0 && obj_init != nullptr;
@@ -1218,7 +1226,7 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model
     s.emit.att[sub][0] = p.x; s.emit.att[sub][1] = p.y; s.emit.att[sub][2] = p.z;
   }
   fence();
-  if (sub < 14 && live) {
+  if (sub < 14 && live && (obs || obs2)) {
     double v;
     if (sub < 3) v = s.emit.att[0][sub];
     else if (sub == 3) {
@@ -1226,7 +1234,8 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model
       v = fmin(fmax(sqrt(d.x * d.x + d.y * d.y + d.z * d.z) / 0.1, 0.0), 1.0);
     } else if (sub < 7) v = s.emit.att[3][sub - 4];
     else v = goal[sub - 7];
-    obs[sub] = v;
+    if (obs) obs[sub] = v;
+    if (obs2) obs2[sub] = v;
   }
   if (sub == 0 && live) {
     double r; bool ok;
@@ -1279,8 +1288,34 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     const double ctrl[EARL_MAXACT] = {(double)act.w, -(double)act.w, 0, 0};
     for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
     const size_t row = (size_t)t * n + env;
-    sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.out.obs + row * 14, a.out.reward ? a.out.reward + row : nullptr,
+    // failure guard (MuJoCo's mj_checkPos / mj_checkVel; metaworld's `except MujocoException` in SawyerXYZEnv.step [UPSTREAM]): an env whose
+    // state went NaN or beyond EARL_BAD_VALUE is rolled back to its last stable state (the rows in HBM) and re-emits its last stable
+    // observation with reward 0; its neighbours in the wavefront never see it (a group only reads its own LDS block)
+    const bool bad_lane = (sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE)) || (sub < 4 && !(fabs(s.bq[sub]) < 2.0));
+    const bool failed = group_any<LPE>(bad_lane, grp);
+    sawyer_emit<NV>(s, m, cfg, sub, live && !failed, a.st.goal + (size_t)env * 7, a.out.obs + row * 14, a.out.reward ? a.out.reward + row : nullptr,
                     a.out.success ? a.out.success + row : nullptr, a.st.obj_init ? a.st.obj_init + (size_t)env * 6 : nullptr, (double)act.w);
+    if (sub == 0 && live && a.out.status) a.out.status[row] = failed ? EARL_STEP_DIVERGED : 0;
+    if (!failed) {
+      // this state is the env's last stable one from here on
+      if (live) {
+        store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+        if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = sub == 0 ? mpos.x : (sub == 1 ? mpos.y : mpos.z);
+      }
+    } else {
+      load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+      mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
+      if (live) {
+        const double* prev = t > 0 ? a.out.obs + ((size_t)(t - 1) * n + env) * 14 : (a.st.last_obs ? a.st.last_obs + (size_t)env * 14 : nullptr);
+        if (sub < 14) a.out.obs[row * 14 + sub] = prev ? prev[sub] : __builtin_nan("");
+        if (sub == 0) {
+          if (a.out.reward) a.out.reward[row] = 0.f;
+          if (a.out.success) a.out.success[row] = 0;
+          if (a.st.fail_count) a.st.fail_count[env] += 1;
+        }
+      }
+    }
+    fence();
     ++steps;
     if (sub == 0 && live && a.out.done) a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
     if (gcf > 0 && ++sgc >= gcf) {
@@ -1301,8 +1336,8 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     }
   }
   if (!live) return;
-  store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-  if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = sub == 0 ? mpos.x : (sub == 1 ? mpos.y : mpos.z);
+  // (qpos / qvel / mocap_pos were written back after the last stable step)
+  if (a.st.last_obs && a.T > 0 && sub < 14) a.st.last_obs[(size_t)env * 14 + sub] = a.out.obs[((size_t)(a.T - 1) * n + env) * 14 + sub];
   if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
   if (sub == 0 && gcf > 0) a.st.steps_since_goal_change[env] = sgc;
 }
@@ -1392,12 +1427,14 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
     load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   }
   fence();
-  if (!a.reset_obs) return;
+  const bool keep = resetting && ((cfg.obj_kind >= 1 && a.st.obj_init) || a.st.last_obs);     // uniform enough: decided per lane, used per lane below
+  if (!a.reset_obs && !__any(keep)) return;
   // set_state -> sim.forward(): kinematics of the state just written
   const Q4 mq = qnormalize(ldq(cfg.mocap_quat));
   const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
   substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
-  sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.reset_obs + (size_t)env * 14, nullptr, nullptr);
+  sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.reset_obs ? a.reset_obs + (size_t)env * 14 : nullptr, nullptr, nullptr, nullptr, 0.0,
+                  (resetting && a.st.last_obs) ? a.st.last_obs + (size_t)env * 14 : nullptr);
   // reset_model keeps obj_init_pos and the pegHead site of the freshly placed peg for the dense reward (sawyer_peg.py:213-215)
   if (resetting && cfg.obj_kind >= 1 && a.st.obj_init && sub < 6) {
     double* oi = a.st.obj_init + (size_t)env * 6;
@@ -1494,7 +1531,7 @@ int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawye
   if (cfg->obj_kind >= 1 && cfg->obj_dof + 6 > nv) return EARL_ERR_ARG;
   if (cfg->obj_kind == 2 && (cfg->n_wide <= 0 || !cfg->wide_table)) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
-  SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, reset_qpos, reset_qvel, mask, obs, 0};
+  SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr, nullptr}, reset_qpos, reset_qvel, mask, obs, 0};
   if (nv == 10) sawyer_reset_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
   else if (nv == 15) sawyer_reset_kernel<15, 16><<<grid_for<15, 16>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
   else return EARL_ERR_ARG;
@@ -1506,7 +1543,7 @@ int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_saw
   if (!model || !cfg || !st || !obs || cfg->n < 0) return EARL_ERR_ARG;
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
-  SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, obs, 1};
+  SawyerArgs a{model, nullptr, *cfg, *st, nullptr, 0, earl_sawyer_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, obs, 1};
   if (nv == 10) sawyer_reset_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
   else if (nv == 15) sawyer_reset_kernel<15, 16><<<grid_for<15, 16>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
   else return EARL_ERR_ARG;

@@ -101,12 +101,13 @@ __device__ __forceinline__ void store_obs(float* __restrict__ dst, const float (
 template <int NOBJ, bool GENERAL>
 __device__ __forceinline__ void wrapped_step(const KArgs& a, int i, uint64_t counter, Lane<NOBJ>& L,
                                              float (&g)[Dims<NOBJ>::NG], float a0, float a1, float a2,
-                                             float (&o)[Dims<NOBJ>::NOBS], float& reward, bool& done, bool& succ) {
+                                             float (&o)[Dims<NOBJ>::NOBS], float& reward, bool& done, bool& succ, double* r64 = nullptr) {
   move<NOBJ>(L.e, rescale_action(a0), rescale_action(a1), rescale_action(a2), a.th);
   make_obs<NOBJ>(L.e, g, o);
   double r;
   reward_success<NOBJ>(o, a.cfg.reward_type, a.cfg.wide_init, a.th, r, succ);
   reward = (float)r;
+  if (r64) *r64 = r;
   L.steps += 1;                       // persistent_state_wrapper.py:25-26
   done = L.steps >= a.cfg.horizon;    // :28-29
   if constexpr (NOBJ == 1 && GENERAL) {
@@ -147,9 +148,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const KArgs a) {
   float o[Dims<NOBJ>::NOBS];
   float reward;
   bool done, succ;
-  wrapped_step<NOBJ, GENERAL>(a, i, a.cfg.counter, L, g, ap[0], ap[1], ap[2], o, reward, done, succ);
+  double r64;
+  wrapped_step<NOBJ, GENERAL>(a, i, a.cfg.counter, L, g, ap[0], ap[1], ap[2], o, reward, done, succ, &r64);
   if (a.out.obs) store_obs<NOBJ>(a.out.obs + (size_t)i * Dims<NOBJ>::NOBS, o);
   if (a.out.reward) a.out.reward[i] = reward;
+  if (a.out.reward_f64) a.out.reward_f64[i] = r64;
   if (a.out.done) a.out.done[i] = done;
   if (a.out.success) a.out.success[i] = succ;
   store_lane<NOBJ>(a, i, L);
@@ -447,7 +450,7 @@ int do_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const 
              float* obs, earl_stream_t stream) {
   if (int rc = check_common(cfg, st, NOBJ)) return rc;
   if (cfg->n == 0) return EARL_OK;
-  KArgs a{*cfg, *st, earl_tabletop_out{nullptr, nullptr, nullptr, nullptr}, nullptr, ngi, mask, obs, 0, thresholds()};
+  KArgs a{*cfg, *st, earl_tabletop_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, ngi, mask, obs, 0, thresholds()};
   reset_kernel<NOBJ><<<grid_for(cfg->n), kBlock, 0, (hipStream_t)stream>>>(a);
   return launched("reset_kernel");
 }

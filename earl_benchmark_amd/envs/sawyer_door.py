@@ -83,6 +83,8 @@ class SawyerDoor:
     self.steps_since_goal_change = torch.zeros(n, dtype=torch.int32, **kw)
     self.obj_init = torch.zeros(n, 6, dtype=torch.float64, **kw)      # obj_init_pos, peg_head_pos_init kept by reset_model (peg dense reward)
     self.lifelong_return_t = torch.zeros(n, dtype=torch.float64, **kw)
+    self.last_obs = torch.zeros(n, self.OBS_DIM, dtype=torch.float64, **kw)   # SawyerXYZEnv._last_stable_obs [UPSTREAM]
+    self.fail_count = torch.zeros(n, dtype=torch.int32, **kw)                 # env steps rolled back by the failure guard (include/earl_physics.h)
     self.total_step_count = 0
 
     cfg = _abi.SawyerCfg(n=n, env_offset=int(env_offset), reward_type=_abi.REWARD_TYPES[reward_type], horizon=INT32_MAX,
@@ -99,7 +101,8 @@ class SawyerDoor:
     self._cfg = cfg
     self._st = _abi.SawyerState(qpos=self.qpos.data_ptr(), qvel=self.qvel.data_ptr(), mocap_pos=self.mocap_pos.data_ptr(),
                                 goal=self.goal_t.data_ptr(), steps_since_reset=self.steps_since_reset.data_ptr(),
-                                steps_since_goal_change=self.steps_since_goal_change.data_ptr(), obj_init=self.obj_init.data_ptr())
+                                steps_since_goal_change=self.steps_since_goal_change.data_ptr(), obj_init=self.obj_init.data_ptr(),
+                                last_obs=self.last_obs.data_ptr(), fail_count=self.fail_count.data_ptr())
     self._cfg_ref, self._st_ref = C.byref(self._cfg), C.byref(self._st)
 
     self.action_space = Box(-1.0, 1.0, (4,), np.float32)
@@ -125,6 +128,10 @@ class SawyerDoor:
     cfg.success_radius = 0.02
     cfg.obj_init_angle = float(self.obj_init_angle)
     cfg.angle_noise[:] = (lo, hi)
+    # reset_model -> reset_goal() -> get_next_goal() puts the default goal back on every reset (sawyer_door.py:96-109, :123):
+    # a one-row goal table does that in the reset kernel (a custom reset_goal(goal) lasts until the next reset, as in the reference)
+    self._goal_table = torch.tensor(self.goal_states, dtype=torch.float64, device=self.device).contiguous()
+    cfg.n_goal_rows, cfg.goal_table = len(self.goal_states), self._goal_table.data_ptr()
 
   def _after_settle(self):
     pass
@@ -153,11 +160,12 @@ class SawyerDoor:
     return {'obs': torch.empty(*lead, self.num_envs, self.OBS_DIM, dtype=torch.float64, **kw),
             'reward': torch.empty(*lead, self.num_envs, dtype=torch.float32, **kw),
             'done': torch.empty(*lead, self.num_envs, dtype=torch.bool, **kw),
-            'success': torch.empty(*lead, self.num_envs, dtype=torch.bool, **kw)}
+            'success': torch.empty(*lead, self.num_envs, dtype=torch.bool, **kw),
+            'status': torch.empty(*lead, self.num_envs, dtype=torch.uint8, **kw)}
 
   def _launch_rollout(self, actions, T, out):
     o = _abi.SawyerOut(obs=out['obs'].data_ptr(), reward=_ptr(out.get('reward')), done=_ptr(out.get('done')),
-                       success=_ptr(out.get('success')))
+                       success=_ptr(out.get('success')), status=_ptr(out.get('status')))
     self._cfg.step_counter = self.total_step_count
     with torch.cuda.device(self.device):
       _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.model.col_ptr, self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),
@@ -196,7 +204,7 @@ class SawyerDoor:
     self._launch_rollout(self._actions(action, ()), 1, out)
     if self.scalar_api:
       return out['obs'][0].cpu().numpy(), float(out['reward'][0]), bool(out['done'][0]), {}
-    return out['obs'], out['reward'], out['done'], {'success': out['success']}
+    return out['obs'], out['reward'], out['done'], {'success': out['success'], 'status': out['status']}
 
   def rollout(self, actions, out=None):
     """T steps in one launch: actions [T,N,4] -> dict of obs [T,N,14] f64, reward [T,N] f32, done / success [T,N] bool."""
@@ -262,12 +270,13 @@ class SawyerDoor:
 
   def state_dict(self):
     return {k: getattr(self, k).clone() for k in ('qpos', 'qvel', 'mocap_pos', 'goal_t', 'steps_since_reset', 'interventions',
-                                                  'steps_since_goal_change', 'lifelong_return_t', 'obj_init')} | {
+                                                  'steps_since_goal_change', 'lifelong_return_t', 'obj_init', 'last_obs', 'fail_count')} | {
                                                       'counter': int(self._cfg.counter), 'total_step_count': self.total_step_count}
 
   def load_state_dict(self, sd):
     for k in ('qpos', 'qvel', 'mocap_pos', 'goal_t', 'steps_since_reset', 'interventions', 'steps_since_goal_change',
-              'lifelong_return_t', 'obj_init'):
-      getattr(self, k).copy_(sd[k])
+              'lifelong_return_t', 'obj_init', 'last_obs', 'fail_count'):
+      if k in sd:
+        getattr(self, k).copy_(sd[k])
     self._cfg.counter = int(sd['counter'])
     self.total_step_count = int(sd['total_step_count'])

@@ -81,7 +81,9 @@ class SawyerPeg(SawyerDoor):
       cfg.obj_high[:] = (0.2, 0.7, 0.02)
       cfg.obj_reject_xy[:] = [float(pos_box[0]), float(pos_box[1])]
       cfg.obj_reject_radius = 0.1
-      cfg.n_goal_rows, cfg.goal_table = 0, None
+      # get_next_goal without reset_at_goal: a row of goal_states (:144-148); reset_model -> reset_goal() restores it on every reset (:195)
+      self._goal_table = torch.tensor(goal_states, dtype=torch.float64, device=self.device).contiguous()
+      cfg.n_goal_rows, cfg.goal_table = len(goal_states), self._goal_table.data_ptr()
       if self.wide_init:
         # :200-209: with probability 1/2 the draw above, otherwise a row of wide_initial_states - (-0.1, 0, 0) + U(-0.02, 0.02)^3
         self._wide_table = torch.tensor(wide_initial_states, dtype=torch.float64, device=self.device).contiguous()

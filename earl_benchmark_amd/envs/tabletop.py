@@ -214,6 +214,10 @@ class TabletopManipulation:
       outs, ostruct = self._new_out((n,))
     else:
       outs, ostruct = tuple(out), self._out_struct(tuple(out), (n,))
+    r64 = None
+    if self.scalar_api:        # the reference returns the reward as a Python float (float64), not rounded to float32
+      r64 = torch.empty(n, dtype=torch.float64, device=self.device)
+      ostruct.reward_f64 = r64.data_ptr()
     ctx = None
     if torch.cuda.current_device() != self.device.index:   # launches go to the current device's runtime context
       ctx = torch.cuda.device(self.device)
@@ -234,7 +238,7 @@ class TabletopManipulation:
     obs, rew, done, succ = outs
     self._last_success = succ
     if self.scalar_api:
-      return obs[0].cpu().numpy(), float(rew[0]), bool(done[0]), {}
+      return obs[0].cpu().numpy(), float(r64[0]), bool(done[0]), {}
     return obs, rew, done, {'success': succ}
 
   def rollout(self, actions, out=None, reset_first=False):

@@ -154,11 +154,21 @@ def load_collision_model(d):
   return c
 
 
+def check_layouts(lib):
+  """the hand-mirrored ctypes layouts are memcpy'd to the device: refuse a library compiled against other struct layouts"""
+  for fn, mirror in ((lib.earl_physics_model_size, LinkModelStruct), (lib.earl_collision_model_size, CollisionModelStruct),
+                     (lib.earl_sawyer_cfg_size, _abi.SawyerCfg)):
+    if fn() != C.sizeof(mirror):
+      raise _abi.EarlHipError(f'{mirror.__name__}: the library was built with sizeof = {fn()}, this binding expects {C.sizeof(mirror)} '
+                              '(stale csrc/libearl_hip.so or header drift: rebuild with __graft_entry__.build())')
+
+
 class DeviceModel:
   """a link model resident in HBM"""
 
   def __init__(self, name, device='cuda', contacts=True):
     self.lib = _abi.load()
+    check_layouts(self.lib)
     self.struct, self.tables = load_link_model(name)
     self.col_struct = load_collision_model(self.tables) if contacts else None
     if not contacts:

@@ -168,6 +168,10 @@ typedef struct earl_sawyer_state {
   int32_t* steps_since_goal_change;   /* [n]; may be NULL when cfg.goal_change_frequency == 0 */
   double* obj_init;             /* [n, 6] obj_init_pos, peg_head_pos_init as reset_model leaves them (sawyer_peg.py:213-215); may be NULL
                                    for sparse rewards; written by earl_sawyer_reset, read by the peg's dense reward */
+  double* last_obs;             /* [n, 14] may be NULL: the observation last returned for each env (SawyerXYZEnv._last_stable_obs [UPSTREAM]);
+                                   written by earl_sawyer_reset and at the end of earl_sawyer_rollout, read when the FIRST step of a launch
+                                   diverges (later steps copy the previous row of the launch's own output) */
+  int32_t* fail_count;          /* [n] may be NULL: env steps that diverged and were rolled back (see earl_sawyer_out.status) */
 } earl_sawyer_state;
 
 typedef struct earl_sawyer_out {
@@ -175,15 +179,23 @@ typedef struct earl_sawyer_out {
   float* reward;      /* [T, n] */
   uint8_t* done;      /* [T, n] */
   uint8_t* success;   /* [T, n] is_successful(obs) */
+  uint8_t* status;    /* [T, n] may be NULL: 0 = ok, EARL_STEP_DIVERGED = after this env step some qpos / qvel entry was NaN or beyond
+                         EARL_BAD_VALUE in magnitude (MuJoCo's mj_checkPos / mj_checkVel test with mjMAXVAL = 1e10).  Such a step is rolled
+                         back: state, mocap target <- the env's last stable ones, the row carries the last stable observation, reward 0,
+                         success 0 (SawyerXYZEnv.step on MujocoException [UPSTREAM]: `return self._last_stable_obs, 0.0, False, info`);
+                         the step still counts for the horizon.  Other envs of the batch are unaffected. */
 } earl_sawyer_out;
+#define EARL_BAD_VALUE 1e10
+#define EARL_STEP_DIVERGED 1
 
-/* T env steps of every env in ONE launch (state stays in LDS between steps).  action: float32 [T, n, 4]. */
+/* T env steps of every env in ONE launch (state stays in LDS between steps; qpos / qvel / mocap_pos are written back after every
+ * env step that ended finite -- they are the "last stable state" a diverged step rolls back to).  action: float32 [T, n, 4]. */
 int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model* col, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                         const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream);
 
 /* reset the envs with mask[i] != 0 (mask NULL = all): state <- the settled post-_reset_hand state (reset_qpos [nq], reset_qvel
  * [nv], device), object re-initialised as cfg.obj_kind says, mocap <- hand_init_pos, counters cleared; obs [n,14]
- * (may be NULL) is written for the reset envs only. */
+ * (may be NULL: the state, st.obj_init and st.last_obs are still written) is written for the reset envs only. */
 int earl_sawyer_reset(const earl_link_model* model, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                       const double* reset_qpos, const double* reset_qvel, const uint8_t* mask, double* obs,
                       earl_stream_t stream);

@@ -72,6 +72,8 @@ typedef struct earl_tabletop_out {
   float* reward;    /* [..] */
   uint8_t* done;    /* [..] 0/1: horizon reached (the env itself never terminates, :137) */
   uint8_t* success; /* [..] 0/1: is_successful(next_obs) (:197-204) */
+  double* reward_f64; /* [n] may be NULL; written by earl_tabletop_step / earl_tabletop3_step only: the reward before it is rounded to
+                         float32 (the reference's compute_reward returns a Python float under its pinned numpy 1.22, :176-191) */
 } earl_tabletop_out;
 
 /* Lifelong(PersistentStateWrapper(TabletopManipulation)).step(action) for every env of the shard.

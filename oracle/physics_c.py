@@ -34,8 +34,10 @@ class CModel:
                          _p(mq), _p(ct), _p(qacc), _p(efc), _p(att), _p(ncon))
     return dict(qpos=q, qvel=v, qacc=qacc, efc=efc, att=att, ncon=ncon)
 
-  def sawyer_rollout(self, cfg_kwargs, qpos, qvel, mocap_pos, goal, steps_since_reset, actions, steps_since_goal_change=None, goal_table=None):
-    """the env loop of oracle/sawyer_oracle.py for a batch; arrays are updated in place; -> obs, reward, done, success"""
+  def sawyer_rollout(self, cfg_kwargs, qpos, qvel, mocap_pos, goal, steps_since_reset, actions, steps_since_goal_change=None, goal_table=None,
+                     last_obs=None, fail_count=None, status=None):
+    """the env loop of oracle/sawyer_oracle.py for a batch; arrays are updated in place; -> obs, reward, done, success
+    (status [T, n] uint8, last_obs [n, 14], fail_count [n] int32: the failure guard's outputs / state, filled in place when given)"""
     a = self._abi
     T, n = actions.shape[:2]
     cfg = a.SawyerCfg(n=n, **{k: v for k, v in cfg_kwargs.items() if not isinstance(v, (tuple, list, np.ndarray))})
@@ -44,13 +46,15 @@ class CModel:
         getattr(cfg, k)[:] = [float(x) for x in v]
     st = a.SawyerState(qpos=qpos.ctypes.data, qvel=qvel.ctypes.data, mocap_pos=mocap_pos.ctypes.data, goal=goal.ctypes.data,
                        steps_since_reset=steps_since_reset.ctypes.data,
-                       steps_since_goal_change=None if steps_since_goal_change is None else steps_since_goal_change.ctypes.data)
+                       steps_since_goal_change=None if steps_since_goal_change is None else steps_since_goal_change.ctypes.data,
+                       last_obs=None if last_obs is None else last_obs.ctypes.data, fail_count=None if fail_count is None else fail_count.ctypes.data)
     if goal_table is not None:
       self._gt = np.ascontiguousarray(goal_table, np.float64)
       cfg.goal_table, cfg.n_goal_rows = self._gt.ctypes.data, len(self._gt)
     obs, rew = np.zeros((T, n, 14)), np.zeros((T, n), np.float32)
     done, suc = np.zeros((T, n), np.uint8), np.zeros((T, n), np.uint8)
-    out = a.SawyerOut(obs=obs.ctypes.data, reward=rew.ctypes.data, done=done.ctypes.data, success=suc.ctypes.data)
+    out = a.SawyerOut(obs=obs.ctypes.data, reward=rew.ctypes.data, done=done.ctypes.data, success=suc.ctypes.data,
+                      status=None if status is None else status.ctypes.data)
     acts = np.ascontiguousarray(actions, np.float32)
     lib().oracle_sawyer_rollout(C.byref(self.struct), self._col(), C.byref(cfg), C.byref(st), _p(acts), C.c_int32(T), C.byref(out))
     return obs, rew, done.astype(bool), suc.astype(bool)

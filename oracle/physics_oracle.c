@@ -491,16 +491,33 @@ int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* 
     int sgc = gcf > 0 ? st->steps_since_goal_change[e] : 0;
     for (int t = 0; t < T; ++t) {
       const float* a = action + ((size_t)t * n + e) * 4;
+      const double ctrl[EARL_MAXACT] = {(double)a[3], -(double)a[3], 0, 0};
+      /* failure guard (include/earl_physics.h, earl_sawyer_out.status): work on a copy, commit it only when the step ended finite */
+      double q2[EARL_MAXV + 1], v2[EARL_MAXV], mp2[3];
+      memcpy(q2, qp, sizeof(double) * m->nq); memcpy(v2, qv, sizeof(double) * nv);
       for (int k = 0; k < 3; ++k) {
         const float c = fminf(fmaxf(a[k], -1.f), 1.f) * scale;
-        mp[k] = fmin(fmax(mp[k] + (double)c, cfg->mocap_low[k]), cfg->mocap_high[k]);
+        mp2[k] = fmin(fmax(mp[k] + (double)c, cfg->mocap_low[k]), cfg->mocap_high[k]);
       }
-      const double ctrl[EARL_MAXACT] = {(double)a[3], -(double)a[3], 0, 0};
-      for (int ts = 0; ts < cfg->frame_skip; ++ts) substep(m, col, qp, qv, ld3(mp), mq, ctrl, 1, &o);
+      for (int ts = 0; ts < cfg->frame_skip; ++ts) substep(m, col, q2, v2, ld3(mp2), mq, ctrl, 1, &o);
       const size_t row = (size_t)t * n + e;
+      double* ob = out->obs + row * 14;
+      int failed = 0;
+      for (int k = 0; k < m->nq; ++k) failed |= !(fabs(q2[k]) < EARL_BAD_VALUE);
+      for (int k = 0; k < nv; ++k) failed |= !(fabs(v2[k]) < EARL_BAD_VALUE);
+      ++steps;
+      if (out->status) out->status[row] = failed ? EARL_STEP_DIVERGED : 0;
+      if (out->done) out->done[row] = (cfg->horizon > 0 && steps >= cfg->horizon) ? 1 : 0;
+      if (failed) {
+        const double* prev = t > 0 ? out->obs + ((size_t)(t - 1) * n + e) * 14 : (st->last_obs ? st->last_obs + (size_t)e * 14 : NULL);
+        for (int k = 0; k < 14; ++k) ob[k] = prev ? prev[k] : NAN;
+        if (out->reward) out->reward[row] = 0.f;
+        if (out->success) out->success[row] = 0;
+        if (st->fail_count) st->fail_count[e] += 1;
+      } else {
+      memcpy(qp, q2, sizeof(double) * m->nq); memcpy(qv, v2, sizeof(double) * nv); memcpy(mp, mp2, sizeof(mp2));
       const V3 hand = attachment(m, &o, cfg->att_hand), rr = attachment(m, &o, cfg->att_right), ll = attachment(m, &o, cfg->att_left),
                obj = attachment(m, &o, cfg->att_obj);
-      double* ob = out->obs + row * 14;
       const V3 dg = sub(rr, ll);
       ob[0] = hand.x; ob[1] = hand.y; ob[2] = hand.z;
       ob[3] = fmin(fmax(sqrt(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z) / 0.1, 0.0), 1.0);
@@ -517,10 +534,9 @@ int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* 
         r = 3 * hand_in_place + 6 * in_place;
         if (obj_to_target < 0.05) r = 10;
       }
-      ++steps;
       if (out->reward) out->reward[row] = (float)r;
       if (out->success) out->success[row] = (uint8_t)ok;
-      if (out->done) out->done[row] = (cfg->horizon > 0 && steps >= cfg->horizon) ? 1 : 0;
+      }
       if (gcf > 0 && ++sgc >= gcf) {   /* LifelongWrapper.step, lifelong_wrapper.py:36-42: new goal, observation re-read with it */
         sgc = 0;
         if (cfg->n_goal_rows > 0 && cfg->goal_table) {
@@ -537,6 +553,7 @@ int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* 
     }
     if (st->steps_since_reset) st->steps_since_reset[e] = steps;
     if (gcf > 0) st->steps_since_goal_change[e] = sgc;
+    if (st->last_obs && T > 0) memcpy(st->last_obs + (size_t)e * 14, out->obs + ((size_t)(T - 1) * n + e) * 14, sizeof(double) * 14);
   }
   return 0;
 }

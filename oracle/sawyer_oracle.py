@@ -19,6 +19,7 @@ MOCAP_QUAT = np.array([1.0, 0.0, 1.0, 0.0])
 # the demonstrations show MuJoCo ending that transient with a vertical gripper; this stepper's transient takes 1,000 timesteps to get there)
 SETTLE_TIMESTEPS = 2000
 OBJ_INIT_POS = np.array([0.1, 0.95, 0.1], dtype=np.float32).astype(np.float64)                     # :36
+BAD_VALUE = 1e10            # EARL_BAD_VALUE (MuJoCo's mjMAXVAL): beyond it, or NaN, an env step is rolled back
 
 
 def u01(lo, hi):
@@ -87,20 +88,34 @@ class SawyerDoorOracle:
     v[self.obj_dof] = 0.0
     self.qpos, self.qvel, self.mocap, self.steps = q, v, self.hand_init_pos.copy(), 0
     pos, quat, _ = self.lm.kinematics(q)
-    return self.obs_from(pos, quat)
+    self.last_obs = self.obs_from(pos, quat)
+    return self.last_obs.copy()
 
   def step(self, action):
     a = np.asarray(action, dtype=np.float32)
     delta = (np.clip(a[:3], np.float32(-1), np.float32(1)) * np.float32(1.0 / 100)).astype(np.float64)   # f32 product, as numpy computes it
+    mocap0 = self.mocap
     self.mocap = np.clip(self.mocap + delta, MOCAP_LOW, MOCAP_HIGH)
     ctrl = np.array([float(a[3]), -float(a[3])])
     out = None
+    stable = (self.qpos.copy(), self.qvel.copy(), mocap0)
     for _ in range(self.frame_skip):
       self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl, self.mocap, MOCAP_QUAT)
+    self.steps += 1
+    done = bool(self.horizon > 0 and self.steps >= self.horizon)
+    if self._diverged():                                    # failure guard: include/earl_physics.h, earl_sawyer_out.status
+      self.qpos, self.qvel, self.mocap = stable
+      self.fail_count += 1
+      return self.last_obs.copy(), np.float32(0.0), done, False
     obs = self.obs_from(out['pos'], out['quat'])            # mj_step leaves the kinematics of the last timestep's START
     r, ok = compute_reward(obs, self.reward_type, self.hand_init_pos)
-    self.steps += 1
-    return obs, np.float32(r), bool(self.horizon > 0 and self.steps >= self.horizon), bool(ok)
+    self.last_obs = obs.copy()
+    return obs, np.float32(r), done, bool(ok)
+
+  fail_count = 0
+
+  def _diverged(self):
+    return not (np.all(np.abs(self.qpos) < BAD_VALUE) and np.all(np.abs(self.qvel) < BAD_VALUE))
 
 
 # ---------------------------------------------------------------------------------------------------- sawyer_peg
@@ -255,20 +270,29 @@ class SawyerPegOracle(SawyerDoorOracle):
     self.peg_head_pos_init = at('pegHead')
     ps, qs, _ = self.lm.kinematics(self.settle()[0])
     self.init_tcp = 0.5 * (at('rightEndEffector', ps, qs) + at('leftEndEffector', ps, qs))
-    return self.obs_from(pos_, quat_)
+    self.last_obs = self.obs_from(pos_, quat_)
+    return self.last_obs.copy()
 
   def step(self, action):
     a = np.asarray(action, dtype=np.float32)
     delta = (np.clip(a[:3], np.float32(-1), np.float32(1)) * np.float32(1.0 / 100)).astype(np.float64)
+    stable = (self.qpos.copy(), self.qvel.copy(), self.mocap)
     self.mocap = np.clip(self.mocap + delta, MOCAP_LOW, MOCAP_HIGH)
     ctrl = np.array([float(a[3]), -float(a[3])])
     out = None
     for _ in range(self.frame_skip):
       self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl, self.mocap, MOCAP_QUAT)
-    obs = self.obs_from(out['pos'], out['quat'])
-    ok = bool(np.sqrt(np.sum((obs[4:7] - obs[11:14]) ** 2)) <= 0.05)             # is_successful :301-305
+    failed = self._diverged()                            # failure guard: include/earl_physics.h, earl_sawyer_out.status
+    if failed:
+      self.qpos, self.qvel, self.mocap = stable
+      self.fail_count += 1
+      obs = self.last_obs.copy()
+    else:
+      obs = self.obs_from(out['pos'], out['quat'])
+      self.last_obs = obs.copy()
+    ok = (not failed) and bool(np.sqrt(np.sum((obs[4:7] - obs[11:14]) ** 2)) <= 0.05)             # is_successful :301-305
     rew = float(ok)
-    if self.reward_type == 'dense':
+    if self.reward_type == 'dense' and not failed:
       names = [str(x) for x in self.lm.att_names]
       at = lambda n: self.lm.attachment(out['pos'], out['quat'], names.index(n))[0]
       rew = peg_dense_reward(obs, a, at('pegGrasp'), at('pegHead'), at('leftpad'), at('rightpad'),

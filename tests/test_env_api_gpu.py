@@ -74,6 +74,12 @@ def test_scalar_api_is_the_reference_surface(torch, orc):
   assert isinstance(out[0], np.ndarray) and isinstance(out[1], float) and isinstance(out[2], bool) and out[3] == {}
   r = o.step(np.array([[1.0, 0.0, 1.0]], np.float32))
   np.testing.assert_array_equal(out[0], r[0][0]); assert abs(out[1] - r[1][0]) < 1e-6
+  # the scalar API returns the float64 reward (the reference's compute_reward returns a Python float under numpy 1.22), not its float32
+  # rounding: it equals the reference expression (tabletop_manipulation.py:179-189) evaluated in float64 on the float32 norms
+  ob32 = out[0]
+  n1 = np.float32(np.linalg.norm(ob32[2:4] - ob32[8:10])); gg = 0.5 * float(np.float32(np.linalg.norm(ob32[:2] - ob32[2:4])))
+  want = -float(n1) + 2. * np.exp(-float(np.float32(n1 * n1)) / 0.01) - gg + 0.5 * np.exp(-(gg * gg) / 0.01)
+  assert abs(out[1] - want) < 1e-9 * max(1.0, abs(want)) and out[1] != float(np.float32(out[1]))
   assert evl.attached_object == (-1, -1) and isinstance(evl.is_successful(), bool)
   # reference-style injection hooks: set_state / attached / reset_goal(goal) / compute_reward(obs)
   evl.set_state(np.array([0.1, 0.0, 0.2, 0.0, -10.0]))

@@ -7,9 +7,19 @@ from conftest import load_golden
 
 
 def bare(name, **kw):
-  L = eb.EARLEnvs.__new__(eb.EARLEnvs)   # table/demo accessors do not need an env (and hence no GPU)
-  L._env_name, L._kwargs = name, kw
-  return L
+  # the real constructor: envs are built on the first get_envs(), so tables / demos need no GPU (and exist for every env name)
+  return eb.EARLEnvs(name, reward_type='dense' if name == 'kitchen' else 'sparse', **kw)
+
+
+def test_constructor_needs_no_gpu_and_keeps_the_reference_errors():
+  for name in eb.deployment_eval_config:
+    L = bare(name)
+    assert L._env_name == name and L._envs is None
+    bare(name, setup_as_lifelong_learning=True)
+  with pytest.raises(ValueError, match='only supports dense'):
+    eb.EARLEnvs('kitchen', reward_type='sparse')          # reference: envs/kitchen.py:91-92
+  with pytest.raises(KeyError):
+    eb.EARLEnvs('no_such_env')
 
 
 def test_configs_match_reference_values():
