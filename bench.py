@@ -40,6 +40,8 @@ def parse():
   p.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
   p.add_argument('--cpu-seconds', type=float, default=10.0)
   p.add_argument('--no-step-api', action='store_true')
+  p.add_argument('--no-sawyer', action='store_true', help='skip the sawyer_door / sawyer_peg (BASELINE configs[2]) legs of the default line')
+  p.add_argument('--sawyer-cpu-seconds', type=float, default=2.0, help='seconds per repetition and thread count of the Sawyer CPU baselines')
   p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door', 'sawyer_peg'],
                  help='tabletop = BASELINE configs[1] (the default, the quoted metric); sawyer_door / sawyer_peg = configs[2] shape, N=8192 each (next rows)')
   return p.parse_args()
@@ -64,50 +66,95 @@ def alloc_out(torch, T, n, device):
           torch.empty(T, n, dtype=torch.bool, device=device), torch.empty(T, n, dtype=torch.bool, device=device))
 
 
-def time_rollouts(torch, dist, env, acts, out, steps, warmup, world):
-  """K x (reset + T steps, one launch each), barrier + synchronize on both sides; HIP events around every launch."""
+class _Clock:
+  """HIP events on the launch stream (torch's current stream) when the job runs on a GPU; on CPU tensors (the gloo test of this very
+  sequence, tests/test_bench_sequence.py) there is nothing to synchronise and the wall clock stands in for the events"""
+
+  def __init__(self, torch, device):
+    self.torch, self.cuda = torch, str(device).startswith('cuda')
+    if self.cuda:
+      self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+  def sync(self):
+    if self.cuda:
+      self.torch.cuda.synchronize()
+
+  def start(self):
+    self.t0 = time.perf_counter()
+    if self.cuda:
+      self.e0.record()
+
+  def stop(self):
+    if self.cuda:
+      self.e1.record()
+    self.t1 = time.perf_counter()
+
+  def elapsed_ms(self):
+    return self.e0.elapsed_time(self.e1) if self.cuda else (self.t1 - self.t0) * 1e3
+
+
+def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cuda', gather_rollout=False):
+  """The timed region of the job: W warm-up launches; barrier + synchronize; K x (reset + T steps, one launch each); the ONE collective
+  of the job (evaluation result of the last rollout -> every rank); synchronize + barrier; wall time, MAX over ranks.
+  -> (seconds, [ms per launch from one event pair around the region], gathered [N_global, 2], gathered rollout or None)"""
+  from earl_benchmark_amd import sharding
   for _ in range(warmup):
     env.rollout(acts, out=out, reset_first=True)
   # one HIP event pair around the whole timed region, recorded on torch's current stream == the launch stream.
   # (An event pair per launch costs ~3 us of queue time per event on this stack -- 20 % of a 34 us kernel.)
-  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  torch.cuda.synchronize()
+  clk = _Clock(torch, device)
+  clk.sync()
   if world > 1:
     dist.barrier()
-  torch.cuda.synchronize()
+  clk.sync()
   t0 = time.perf_counter()
-  e0.record()
+  clk.start()
   for k in range(steps):
     env.rollout(acts, out=out, reset_first=True)     # reset() of every env + T steps: ONE kernel launch
-  e1.record()
-  gathered = None
+  clk.stop()
+  gathered, rollout = None, None
   if world > 1:                 # the one collective of the job: evaluation result of the last rollout -> every rank
-    from earl_benchmark_amd import sharding
-    gathered = sharding.gather_summary(sharding.rollout_summary(out[1], out[3]), sizes=[acts.shape[1]] * world)   # [N_global, 2]
-  torch.cuda.synchronize()
+    sizes = [acts.shape[1]] * world
+    gathered = sharding.gather_summary(sharding.rollout_summary(out[1], out[3]), sizes=sizes)   # [N_global, 2]
+    if gather_rollout:          # SURVEY 8(e): the whole [T, N/W, D+2] trajectory buffer of every rank -> [T, N, D+2]
+      rollout = sharding.gather_rollout(sharding.pack_rollout(*out), sizes=sizes)
+  clk.sync()
   if world > 1:
     dist.barrier()
-  torch.cuda.synchronize()
+  clk.sync()
   dt = time.perf_counter() - t0
-  kern_ms = [e0.elapsed_time(e1) / steps]   # average launch duration over the timed region (incl. the inter-launch gap)
-  return dt, kern_ms, gathered
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  kern_ms = [clk.elapsed_ms() / steps]   # average launch duration over the timed region (incl. the inter-launch gap)
+  return dt, kern_ms, gathered, rollout
 
 
-def time_step_api(torch, env, acts, steps, warmup):
-  """the same workload through the gym-style API: one step() launch per env step (eager, no graph)."""
+def time_step_api(torch, env, acts, steps, warmup, graph=False):
+  """the same workload through the gym-style API, one step() launch per env step: eager (a ctypes call per step), or the T launches
+  captured once by env.make_step_graph(T) and replayed with one host call per episode (the action ring holds the episode's actions)."""
   T = acts.shape[0]
+  if graph:
+    g = env.unwrapped.make_step_graph(T)
+    g.actions.copy_(acts)
+
+    def episode():
+      env.reset()
+      g.replay()
+  else:
+    def episode():
+      env.reset()
+      for t in range(T):
+        env.step(acts[t])
   for _ in range(max(1, warmup // 4)):
-    env.reset()
-    for t in range(T):
-      env.step(acts[t])
+    episode()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record()
   for _ in range(steps):
-    env.reset()
-    for t in range(T):
-      env.step(acts[t])
+    episode()
   e1.record()
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
@@ -164,21 +211,23 @@ def cpu_baseline(n, T, reward, seconds):
           'scalar_python_loop_1env': scalar_rate}
 
 
-def sawyer_traffic(workload, n, T):
-  """HBM bytes per launch of the Sawyer rollout kernel from the committed PMC profile (profiles/traffic.json, written by
-  tools/summarize_sawyer.py from separate FETCH_SIZE / WRITE_SIZE passes), or None when the profile is of another shape"""
+def sawyer_profile(workload, n, T):
+  """static content of profiles/traffic.json for the Sawyer rollout kernel (written by tools/summarize_sawyer.py from separate rocprofv3
+  --pmc passes over this same command): HBM bytes per launch and the SQ issue-slot shares; None when the profile is of another shape"""
   tpath = os.path.join(REPO, 'profiles', 'traffic.json')
   if not os.path.exists(tpath) or (n, T) != ((8192, 300) if workload == 'sawyer_door' else (8192, 200)):
-    return None
-  return json.load(open(tpath)).get(workload, {}).get('hbm_bytes_per_launch')
+    return {}
+  return json.load(open(tpath)).get(workload, {})
 
 
-def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door'):
-  """The C restatement of the same stepper and env loop (oracle/physics_oracle.c, OpenMP over envs) on the host cores:
-  a short thread sweep, then a bounded sample at the best thread count.  MuJoCo itself is not available on this host;
-  this port runs the same algorithm the kernel runs (3.8 us per timestep per core where it was written)."""
+def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door', n=8192, reps=3):
+  """The C restatement of the same stepper and env loop (oracle/physics_oracle.c, OpenMP over envs) on the host cores.  MuJoCo itself
+  is not available on this host; this port runs the same algorithm the kernel runs.  Method: FIXED batch (n envs, the bench's own
+  size) at every thread count; per count a short probe sizes a run of >= `seconds` (T env steps of random actions from the reset
+  state), which is repeated `reps` times and the fastest repetition kept; the best count is reported."""
   import numpy as np
   from oracle import physics_c
+  del T_sample
   cm = physics_c.CModel(task)
   rng = np.random.default_rng(0)
   if task == 'sawyer_door':
@@ -193,39 +242,44 @@ def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door'):
     q0, v0 = r['qpos'][0].copy(), r['qvel'][0].copy()
     q0[9:12], v0[9:] = [0.1, 0.6, 0.02], 0.0
     cfg = physics_c.peg_cfg(att_names=cm.att_names)
+  acts_all = rng.uniform(-1, 1, (64, n, 4)).astype(np.float32)
 
-  def run(threads, n, T):
+  def run(threads, T):
     physics_c.set_threads(threads)
     q, v, mp = np.tile(q0, (n, 1)), np.tile(v0, (n, 1)), np.tile(hand, (n, 1))
     goal, steps = np.zeros((n, 7)), np.zeros(n, np.int32)
-    acts = rng.uniform(-1, 1, (T, n, 4)).astype(np.float32)
+    acts = acts_all[:T] if T <= len(acts_all) else np.concatenate([acts_all] * (T // len(acts_all) + 1))[:T]
     t0 = time.perf_counter()
     cm.sawyer_rollout(cfg, q, v, mp, goal, steps, acts)
-    return n * T / (time.perf_counter() - t0)
+    return time.perf_counter() - t0
   ncpu = len(os.sched_getaffinity(0))
-  cands = sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu), ncpu})
-  sweep = {c: run(c, 64 * c, 10) for c in cands}
+  cands = sorted({1, min(16, ncpu), min(64, ncpu), min(128, ncpu), ncpu})
+  sweep, detail = {}, {}
+  for c in cands:
+    run(c, 1)                                                     # thread pool, page faults
+    probe = run(c, 2) / 2                                         # seconds per env step of the batch
+    T = max(2, int(np.ceil(seconds / probe)))
+    best = min(run(c, T) for _ in range(reps))
+    sweep[c] = n * T / best
+    detail[c] = {'T': T, 'best_s': round(best, 3)}
   best = max(sweep, key=sweep.get)
-  n = 64 * best
-  T = max(10, min(T_sample, int(seconds * sweep[best] / n)))
-  val = run(best, n, T)
-  return {'value': val, 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
-          'sample': f'{n} envs x {T} env steps (5 timesteps each, random actions from the reset state) through the C restatement of the '
-                    f'same stepper (oracle/physics_oracle.c, OpenMP); thread sweep {({k: round(v) for k, v in sweep.items()})}; '
-                    'MuJoCo itself is not available on this host',
-          'single_core': sweep[1]}
+  return {'value': sweep[best], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
+          'sample': f'{n} envs x {detail[best]["T"]} env steps (5 timesteps each, random actions from the reset state), fastest of {reps} repetitions of '
+                    f'>= {seconds:g} s each, through the C restatement of the same stepper (oracle/physics_oracle.c, OpenMP static over envs); the same '
+                    f'{n}-env batch at every thread count: {({k: round(v) for k, v in sweep.items()})}; MuJoCo itself is not available on this host',
+          'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}}
 
 
-def main_sawyer(a, torch, dist, world, rank, device):
-  """BASELINE configs[2] shape (Sawyer door half): N envs per GPU, reset + one fused T-step rollout per bench step.
-  The dynamics are this build's own stepper (own contact model, parity with MuJoCo unpinned) -- see DESIGN.md."""
+def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8192, T=None, cpu_seconds=None):
+  """BASELINE configs[2] shape: n envs per GPU, reset + one fused T-step rollout per bench step, barrier + synchronize on both sides, max
+  over ranks.  The dynamics are this build's own stepper (own contact model, parity with MuJoCo unpinned) -- see DESIGN.md.
+  -> result dict on rank 0 (None elsewhere)"""
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   from earl_benchmark_amd.wrappers import PersistentStateWrapper
   from earl_benchmark_amd import sharding
-  peg = a.workload == 'sawyer_peg'
-  n = a.envs if a.envs != 4096 else 8192
-  T = a.horizon if a.horizon != 200 else (200 if peg else 300)          # the reference's eval horizons (earl_benchmark/__init__.py:24-35)
+  peg = workload == 'sawyer_peg'
+  T = T or (200 if peg else 300)                         # the reference's eval horizons (earl_benchmark/__init__.py:24-35)
   kw = sharding.shard_kwargs(n * world, rank, world) if world > 1 else {}
   env = PersistentStateWrapper((SawyerPeg if peg else SawyerDoor)(reward_type=a.reward, num_envs=n, seed=1234,
                                                                   env_offset=kw.get('env_offset', rank * n)), T)
@@ -238,45 +292,71 @@ def main_sawyer(a, torch, dist, world, rank, device):
   def step():
     env.reset()
     env.rollout(acts, out=out)
-  for _ in range(a.warmup):
+  for _ in range(warmup):
     step()
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
+  torch.cuda.synchronize()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
   e0.record(stream)
-  for _ in range(a.steps):
+  for _ in range(steps):
     step()
   e1.record(stream)
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
+  torch.cuda.synchronize()
   dt = time.perf_counter() - t0
-  gpu_ms = e0.elapsed_time(e1) / a.steps
+  gpu_ms = e0.elapsed_time(e1) / steps
   if world > 1:
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
   assert bool(out['done'][-1].all()) and not bool(out['done'][:-1].any()) and bool(torch.isfinite(out['obs']).all())
+  diverged = int(out['status'].sum())
+  if rank != 0:
+    return None
+  # algorithmic HBM bytes per env step: action 16 in; obs 14 x 8 + reward 4 + done 1 + success 1 + status 1 out; the last-stable state row
+  # (qpos, qvel, mocap) written after every env step; per launch the state read once and the last observation written once
+  state_row = (nq + nv + 3) * 8
+  bytes_per_env_step = 16 + 14 * 8 + 4 + 1 + 1 + 1 + state_row
+  per_launch = n * (T * bytes_per_env_step + state_row + 7 * 8 + 4 + 14 * 8)
+  achieved = per_launch / (gpu_ms * 1e-3) / 1e9
+  prof = sawyer_profile(workload, n, T)
+  issue = prof.get('issue') or {}
+  res = {'value': steps * n * T * world / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
+         'kernel_ms': gpu_ms, 'timesteps_per_s': steps * n * T * world * 5 / dt, 'diverged_env_steps_last_rollout': diverged,
+         'config': {'workload': f'{workload} {a.reward} reward, {n} batched envs per MI355X, reset + fused {T}-step rollout '
+                                f'(5 timesteps per env step) per bench step; own stepper incl. contacts, parity with MuJoCo unpinned',
+                    'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
+                    'parallelism': f'env-range shard x{world}, no per-step collective'},
+         # the bound of this kernel is instruction issue at low occupancy, not HBM: the roofline is the share of wave cycles that issue
+         'issue_frac': issue.get('issue_any'),
+         'roofline': {'bound': 'issue', 'achieved': issue.get('issue_any'), 'peak': 1.0, 'unit': 'share of wave cycles issuing an instruction '
+                      '(SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)', 'frac': issue.get('issue_any'), 'valu': issue.get('valu'), 'lds': issue.get('lds'),
+                      'scalar': issue.get('scalar'), 'wait': issue.get('wait_any'), 'waves_per_simd': prof.get('waves_per_simd'),
+                      'source': (prof.get('source', '') + ' (static: SQ counters collected by rocprofv3 --pmc in separate runs of this command)') if issue else None,
+                      'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
+                      'hbm': {'achieved_GBs': achieved, 'frac_of_8TBs': achieved / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': per_launch,
+                              'bytes_per_env_step': bytes_per_env_step, 'traffic': prof.get('hbm_bytes_per_launch'),
+                              'traffic_source': (prof.get('source', '') + ' (static)') if prof else None}},
+         'cpu_baseline': None if cpu_seconds is None else sawyer_cpu_baseline(T, cpu_seconds, workload, n=n)}
+  del env, acts, out
+  torch.cuda.empty_cache()
+  return res
+
+
+def main_sawyer(a, torch, dist, world, rank, device):
+  n = a.envs if a.envs != 4096 else 8192
+  T = a.horizon if a.horizon != 200 else None
+  r = run_sawyer(a, torch, dist, world, rank, device, a.workload, a.steps, a.warmup, n=n, T=T, cpu_seconds=None if a.no_cpu else max(2.0, a.cpu_seconds / 5))
   if rank == 0:
-    bytes_per_env_step = 16 + 14 * 8 + 4 + 1 + 1          # action + obs (f64) + reward + done + success
-    per_launch = n * (T * bytes_per_env_step + 2 * ((nq + nv) * 8 + 3 * 8) + 7 * 8 + 4 * 2)
-    achieved = per_launch / (gpu_ms * 1e-3) / 1e9
-    res = {'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': a.steps * n * T * world / dt, 'unit': 'env-steps/s',
-           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-           'config': {'workload': f'{a.workload} {a.reward} reward, {n} batched envs per MI355X, reset + fused {T}-step rollout '
-                                  f'(5 timesteps per env step) per bench step; own stepper incl. contacts, parity with MuJoCo unpinned',
-                      'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
-                      'parallelism': f'env-range shard x{world}, no per-step collective'},
-           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                        'traffic': sawyer_traffic(a.workload, n, T), 'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
-                        'algorithmic_bytes_per_launch': per_launch, 'bytes_per_env_step': bytes_per_env_step,
-                        'note': 'not HBM-bound: instruction issue and LDS latency at one wave per SIMD (door: 55 % of wave cycles issue, '
-                                '41 % wait on LDS / memory counters, profiles/r01_sawyer_door_rollout_pmc.json); the HBM figure is reported '
-                                'because the schema asks for it'},
-           'cpu_baseline': None if a.no_cpu else sawyer_cpu_baseline(T, a.cpu_seconds, a.workload)}
+    res = {'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': a.steps,
+           'warmup': a.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+           'data': 'synthetic', 'config': r['config'], 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline'],
+           'kernel_ms': r['kernel_ms'], 'issue_frac': r['issue_frac'], 'diverged_env_steps_last_rollout': r['diverged_env_steps_last_rollout']}
     print(json.dumps(res), flush=True)
   if world > 1:
     dist.barrier()
@@ -285,6 +365,7 @@ def main_sawyer(a, torch, dist, world, rank, device):
 
 def main():
   a = parse()
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC for RCCL: must be in the environment before the HIP runtime starts
   import torch
   import torch.distributed as dist
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -299,7 +380,6 @@ def main():
   torch.cuda.set_device(local_rank)
   device = f'cuda:{local_rank}'
   if world > 1:
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group('nccl', device_id=torch.device(device))
   if a.workload in ('sawyer_door', 'sawyer_peg'):
     return main_sawyer(a, torch, dist, world, rank, device)
@@ -308,27 +388,33 @@ def main():
   env = make_env(torch, n, T, a.reward, rank, device)
   acts = synth_actions(torch, T, n, rank, device)
   out = alloc_out(torch, T, n, device)
-  dt, kern_ms, gathered = time_rollouts(torch, dist, env, acts, out, a.steps, a.warmup, world)
+  dt, kern_ms, gathered, _ = time_rollouts(torch, dist, env, acts, out, a.steps, a.warmup, world, device)
   if world > 1:
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    assert gathered.shape == (n * world, 2)
   total_env_steps = a.steps * n * T * world
   value = total_env_steps / dt
   assert bool(out[2][-1].all()) and not bool(out[2][:-1].any())     # done fires exactly at the horizon
 
+  # BASELINE configs[2] in the same run (every rank takes part: same barrier / max-over-ranks timing; the CPU legs at N = 1 only)
+  sawyer = {}
+  if not a.no_sawyer:
+    for w in ('sawyer_door', 'sawyer_peg'):
+      sawyer[w] = run_sawyer(a, torch, dist, world, rank, device, w, steps=max(3, a.steps // 20), warmup=2,
+                             cpu_seconds=None if (a.no_cpu or world > 1) else a.sawyer_cpu_seconds)
   res = None
   if rank == 0:
     kmean = sum(kern_ms) / len(kern_ms)
     kmed = kern_ms[len(kern_ms) // 2]
     bytes_per_launch = n * (T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH)
     achieved = bytes_per_launch / (kmean * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(REPO, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
       tj = json.load(open(tpath))
       key = f'rollout_n{n}_T{T}'
       traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
+      if traffic is not None:
+        traffic_source = f"profiles/traffic.json <- {tj[key].get('source')} (static: FETCH_SIZE / WRITE_SIZE passes of rocprofv3 --pmc over this command, not measured in this run)"
     res = {
         'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': value, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
@@ -338,18 +424,23 @@ def main():
                    'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': n * T * world,
                    'parallelism': f'env-range shard x{world}, no per-step collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'rollout_ws_kernel',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source, 'kernel': 'rollout_ws_kernel',
                      'kernel_ms_mean': kmean, 'kernel_ms_median': kmed, 'algorithmic_bytes_per_launch': bytes_per_launch,
                      'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT},
     }
     if not a.no_step_api:
       env2 = make_env(torch, n, T, a.reward, rank, device)
       ks = max(1, a.steps // 20)
-      sdt, sgpu = time_step_api(torch, env2, acts, ks, a.warmup)
-      res['step_api'] = {'value': ks * n * T / sdt, 'unit': 'env-steps/s', 'launches': ks * T,
-                         'us_per_step_call_wall': sdt / (ks * T) * 1e6, 'us_per_step_call_gpu': sgpu / (ks * T) * 1e6,
-                         'note': 'same workload, one eager step() launch per env step (host-launch bound at N=4096)',
-                         'achieved_GBs': n * BYTES_PER_ENV_STEP_STEP / (sgpu / (ks * T)) / 1e9}
+
+      def leg(graph):
+        sdt, sgpu = time_step_api(torch, env2, acts, ks, a.warmup, graph=graph)
+        return {'value': ks * n * T / sdt, 'unit': 'env-steps/s', 'launches': ks * T, 'us_per_step_call_wall': sdt / (ks * T) * 1e6,
+                'us_per_step_call_gpu': sgpu / (ks * T) * 1e6, 'achieved_GBs': n * BYTES_PER_ENV_STEP_STEP / (sgpu / (ks * T)) / 1e9}
+      res['step_api'] = leg(True)
+      res['step_api']['note'] = ('same workload, one step() kernel launch per env step, the T launches of an episode captured by '
+                                 'env.make_step_graph(T) and replayed with one host call (closed-loop users capture their policy in between)')
+      res['step_api']['eager'] = leg(False)
+      res['step_api']['eager']['note'] = 'one eager step() call per env step from Python (host-launch bound at N=4096)'
     if a.sweep:
       sw = []
       for ns in (64, 1024, 4096, 16384, 65536, 262144, 1048576):
@@ -358,7 +449,7 @@ def main():
         ac = synth_actions(torch, Ts, ns, 0, device)
         o = alloc_out(torch, Ts, ns, device)
         k = max(3, min(a.steps, int(2e9 // (ns * Ts * 66)) + 3))
-        d, km, _ = time_rollouts(torch, dist, e, ac, o, k, 3, 1)
+        d, km, _, _ = time_rollouts(torch, dist, e, ac, o, k, 3, 1, device)
         kmn = sum(km) / len(km)
         sw.append({'envs': ns, 'T': Ts, 'env_steps_per_s': k * ns * Ts / d, 'kernel_ms': kmn,
                    'GBs': ns * (Ts * 66 + STATE_BYTES_PER_ENV_LAUNCH) / (kmn * 1e-3) / 1e9})
@@ -369,6 +460,7 @@ def main():
       res['cpu_baseline'] = cpu_baseline(n, T, a.reward, a.cpu_seconds)
     else:
       res['cpu_baseline'] = None
+    res.update(sawyer)            # "sawyer_door": {...}, "sawyer_peg": {...}: value, kernel_ms, issue_frac, roofline, cpu_baseline
     print(json.dumps(res), flush=True)
   if world > 1:
     dist.barrier()

@@ -215,3 +215,53 @@ def test_launches_are_graph_capturable(torch, orc):
       assert torch.equal(x, y)
     assert torch.equal(env.qpos, qpos_ref)
   assert int(env.interventions[0]) == 1 + 3        # one eager episode + three replays (capture itself executes nothing)
+
+
+def test_step_graph_ring_and_closed_loop_policy(torch, orc):
+  """make_step_graph(T): T captured step() launches replayed by one host call.  Ring mode == the oracle step by step over several
+  replays (bit for bit); policy mode == the eager closed loop with the same policy, and chains across replays through obs_in."""
+  from earl_benchmark_amd.envs import tabletop
+  n, T = 300, 25
+  env = tabletop.TabletopManipulation(reward_type='sparse', num_envs=n, seed=5, scalar_api=False)
+  env._cfg.horizon = 60
+  env.reset()
+  o = mirror(orc, env)
+  g = env.make_step_graph(T)
+  rng = np.random.default_rng(2)
+  for rep in range(3):
+    a = rng.uniform(-1, 1, size=(T, n, 3)).astype(np.float32)
+    g.actions.copy_(torch.from_numpy(a))
+    obs, rew, done, info = g.replay()
+    torch.cuda.synchronize()
+    for t in range(T):
+      r = o.step(a[t])
+      np.testing.assert_array_equal(obs[t].cpu().numpy(), r[0]); np.testing.assert_array_equal(rew[t].cpu().numpy(), r[1])
+      np.testing.assert_array_equal(done[t].cpu().numpy(), r[2].astype(bool))
+      np.testing.assert_array_equal(info['success'][t].cpu().numpy(), r[3].astype(bool))
+  assert env.total_step_count == 3 * T and bool(done[-1].all())             # 75 steps >= horizon 60
+  np.testing.assert_array_equal(env.qpos.cpu().numpy(), o.qpos)
+
+  # closed loop: the policy's kernels are captured between the steps
+  def policy(ob):
+    to_obj = ob[:, 2:4] - ob[:, 0:2]
+    to_goal = ob[:, 8:10] - ob[:, 2:4]
+    holding = (ob[:, 4:5] == 0).to(ob.dtype)
+    move = torch.clamp((holding * to_goal + (1 - holding) * to_obj) * 5.0, -1.0, 1.0)
+    return torch.cat([move, torch.ones_like(ob[:, :1])], 1)
+  e1 = tabletop.TabletopManipulation(reward_type='sparse', num_envs=n, seed=6, scalar_api=False)
+  e2 = tabletop.TabletopManipulation(reward_type='sparse', num_envs=n, seed=6, scalar_api=False)
+  ob = e1.reset(); e2.reset()
+  g2 = e2.make_step_graph(T, policy=policy)
+  assert torch.equal(g2.obs_in, ob)
+  for rep in range(2):
+    obs, rew, done, info = g2.replay()
+    torch.cuda.synchronize()
+    for t in range(T):
+      ob, r, d, i = e1.step(policy(ob))
+      assert torch.equal(obs[t], ob) and torch.equal(rew[t], r) and torch.equal(info['success'][t], i['success'])
+    assert torch.equal(g2.obs_in, ob)
+  assert float(((obs[-1][:, 2:4] - obs[-1][:, 8:10]).norm(dim=1) < 0.3).float().mean()) > 0.9   # the scripted policy carried the mugs to their goals
+  lifelong = tabletop.TabletopManipulation(num_envs=4, scalar_api=False)
+  lifelong._cfg.goal_change_frequency = 10
+  with pytest.raises(NotImplementedError):
+    lifelong.make_step_graph(4)
