@@ -40,6 +40,9 @@ def parse():
   p.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
   p.add_argument('--cpu-seconds', type=float, default=10.0)
   p.add_argument('--no-step-api', action='store_true')
+  p.add_argument('--episodes-per-launch', type=int, default=8,
+                 help='evaluation episodes (bench steps) one kernel launch walks (earl_tabletop_eval_episodes); 1 = one launch per episode')
+  p.add_argument('--no-single', action='store_true', help='skip the one-episode-per-launch comparison leg')
   p.add_argument('--no-sawyer', action='store_true', help='skip the sawyer_door / sawyer_peg (BASELINE configs[2]) legs of the default line')
   p.add_argument('--sawyer-cpu-seconds', type=float, default=2.0, help='seconds per repetition and thread count of the Sawyer CPU baselines')
   p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door', 'sawyer_peg'],
@@ -61,9 +64,10 @@ def synth_actions(torch, T, n, rank, device):
   return (torch.rand(T, n, 3, generator=g, device=device) * 2 - 1).contiguous()
 
 
-def alloc_out(torch, T, n, device):
-  return (torch.empty(T, n, 12, dtype=torch.float32, device=device), torch.empty(T, n, dtype=torch.float32, device=device),
-          torch.empty(T, n, dtype=torch.bool, device=device), torch.empty(T, n, dtype=torch.bool, device=device))
+def alloc_out(torch, T, n, device, episodes=1):
+  lead = (T, n) if episodes == 1 else (episodes, T, n)
+  return (torch.empty(*lead, 12, dtype=torch.float32, device=device), torch.empty(*lead, dtype=torch.float32, device=device),
+          torch.empty(*lead, dtype=torch.bool, device=device), torch.empty(*lead, dtype=torch.bool, device=device))
 
 
 class _Clock:
@@ -93,13 +97,27 @@ class _Clock:
     return self.e0.elapsed_time(self.e1) if self.cuda else (self.t1 - self.t0) * 1e3
 
 
-def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cuda', gather_rollout=False):
-  """The timed region of the job: W warm-up launches; barrier + synchronize; K x (reset + T steps, one launch each); the ONE collective
-  of the job (evaluation result of the last rollout -> every rank); synchronize + barrier; wall time, MAX over ranks.
-  -> (seconds, [ms per launch from one event pair around the region], gathered [N_global, 2], gathered rollout or None)"""
+def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cuda', gather_rollout=False, episodes_per_launch=1):
+  """The timed region of the job: W warm-up episodes; barrier + synchronize; K episodes (bench steps: reset + T env steps of the whole
+  batch each), `episodes_per_launch` of them per kernel launch (out then has a leading episode axis; the last launch takes the
+  remainder); the ONE collective of the job (evaluation result of the last episode -> every rank); synchronize + barrier; wall time,
+  MAX over ranks.
+  -> (seconds, [ms per launch from one event pair around the region], gathered [N_global, 2], gathered rollout or None, launches)"""
   from earl_benchmark_amd import sharding
-  for _ in range(warmup):
-    env.rollout(acts, out=out, reset_first=True)
+  E = max(1, int(episodes_per_launch))
+
+  def run(k):                                          # k episodes; -> launches issued
+    if E == 1:
+      for _ in range(k):
+        env.rollout(acts, out=out, reset_first=True)   # reset() of every env + T steps: ONE kernel launch
+      return k
+    done = 0
+    while done < k:
+      e = min(E, k - done)
+      env.rollout_episodes(acts, episodes=e, out=tuple(t[:e] for t in out))     # e x (reset + T steps): ONE kernel launch
+      done += e
+    return -(-k // E)
+  run(warmup)
   # one HIP event pair around the whole timed region, recorded on torch's current stream == the launch stream.
   # (An event pair per launch costs ~3 us of queue time per event on this stack -- 20 % of a 34 us kernel.)
   clk = _Clock(torch, device)
@@ -109,15 +127,15 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cud
   clk.sync()
   t0 = time.perf_counter()
   clk.start()
-  for k in range(steps):
-    env.rollout(acts, out=out, reset_first=True)     # reset() of every env + T steps: ONE kernel launch
+  launches = run(steps)
   clk.stop()
   gathered, rollout = None, None
+  last = out if E == 1 else tuple(t[(steps - 1) % E] for t in out)       # outputs of the last episode
   if world > 1:                 # the one collective of the job: evaluation result of the last rollout -> every rank
     sizes = [acts.shape[1]] * world
-    gathered = sharding.gather_summary(sharding.rollout_summary(out[1], out[3]), sizes=sizes)   # [N_global, 2]
+    gathered = sharding.gather_summary(sharding.rollout_summary(last[1], last[3]), sizes=sizes)   # [N_global, 2]
     if gather_rollout:          # the whole [T, N/W, D+2] trajectory buffer of every rank -> [T, N, D+2]
-      rollout = sharding.gather_rollout(sharding.pack_rollout(*out), sizes=sizes)
+      rollout = sharding.gather_rollout(sharding.pack_rollout(*last), sizes=sizes)
   clk.sync()
   if world > 1:
     dist.barrier()
@@ -127,8 +145,8 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cud
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-  kern_ms = [clk.elapsed_ms() / steps]   # average launch duration over the timed region (incl. the inter-launch gap)
-  return dt, kern_ms, gathered, rollout
+  kern_ms = [clk.elapsed_ms() / launches]   # average launch duration over the timed region (incl. the inter-launch gap)
+  return dt, kern_ms, gathered, rollout, launches
 
 
 def time_step_api(torch, env, acts, steps, warmup, graph=False):
@@ -387,13 +405,21 @@ def main():
 
   env = make_env(torch, n, T, a.reward, rank, device)
   acts = synth_actions(torch, T, n, rank, device)
-  out = alloc_out(torch, T, n, device)
-  dt, kern_ms, gathered, _ = time_rollouts(torch, dist, env, acts, out, a.steps, a.warmup, world, device)
+  E = max(1, a.episodes_per_launch)
+  out = alloc_out(torch, T, n, device, E)
+  dt, kern_ms, gathered, _, launches = time_rollouts(torch, dist, env, acts, out, a.steps, a.warmup, world, device, episodes_per_launch=E)
   if world > 1:
     assert gathered.shape == (n * world, 2)
+  single = None
+  if E > 1 and not a.no_single:      # the same episodes, one launch each (round 1's bench step), for continuity: K / 4 of them
+    o1 = alloc_out(torch, T, n, device, 1)
+    sdt, skm, _, _, sl = time_rollouts(torch, dist, env, acts, o1, max(8, a.steps // 4), 4, world, device, episodes_per_launch=1)
+    single = {'value': max(8, a.steps // 4) * n * T * world / sdt, 'unit': 'env-steps/s', 'kernel_ms_mean': skm[0], 'launches': sl,
+              'note': 'one evaluation episode per launch (earl_tabletop_reset_rollout): what round 1 timed'}
   total_env_steps = a.steps * n * T * world
   value = total_env_steps / dt
-  assert bool(out[2][-1].all()) and not bool(out[2][:-1].any())     # done fires exactly at the horizon
+  dn = out[2] if E > 1 else out[2][None]
+  assert bool(dn[:, -1].all()) and not bool(dn[:, :-1].any())        # done fires exactly at the horizon, in every episode
 
   # BASELINE configs[2] in the same run (every rank takes part: same barrier / max-over-ranks timing; the CPU legs at N = 1 only)
   sawyer = {}
@@ -405,13 +431,14 @@ def main():
   if rank == 0:
     kmean = sum(kern_ms) / len(kern_ms)
     kmed = kern_ms[len(kern_ms) // 2]
-    bytes_per_launch = n * (T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH)
+    # algorithmic bytes of the average launch: its episodes x (actions in, obs / reward / flags out) + the state once
+    bytes_per_launch = n * (a.steps / launches * T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH)
     achieved = bytes_per_launch / (kmean * 1e-3) / 1e9
     traffic, traffic_source = None, None
     tpath = os.path.join(REPO, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
       tj = json.load(open(tpath))
-      key = f'rollout_n{n}_T{T}'
+      key = f'rollout_n{n}_T{T}' + (f'_E{E}' if E > 1 else '')
       traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
       if traffic is not None:
         traffic_source = f"profiles/traffic.json <- {tj[key].get('source')} (static: FETCH_SIZE / WRITE_SIZE passes of rocprofv3 --pmc over this command, not measured in this run)"
@@ -420,14 +447,17 @@ def main():
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'tabletop_manipulation {a.reward} reward, {n} batched envs per MI355X, '
-                               f'reset + fused {T}-step rollout per bench step', 'envs_per_gpu': n,
+                               f'reset + fused {T}-step rollout per bench step' + (f', {E} bench steps (evaluation episodes) per kernel launch' if E > 1 else ''),
+                   'envs_per_gpu': n, 'episodes_per_launch': E, 'launches': launches,
                    'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': n * T * world,
                    'parallelism': f'env-range shard x{world}, no per-step collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source, 'kernel': 'rollout_ws_kernel',
                      'kernel_ms_mean': kmean, 'kernel_ms_median': kmed, 'algorithmic_bytes_per_launch': bytes_per_launch,
-                     'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT},
+                     'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT, 'episodes_per_launch': a.steps / launches, 'launches': launches},
     }
+    if single is not None:
+      res['single_episode_launch'] = single
     if not a.no_step_api:
       env2 = make_env(torch, n, T, a.reward, rank, device)
       ks = max(1, a.steps // 20)
@@ -449,7 +479,7 @@ def main():
         ac = synth_actions(torch, Ts, ns, 0, device)
         o = alloc_out(torch, Ts, ns, device)
         k = max(3, min(a.steps, int(2e9 // (ns * Ts * 66)) + 3))
-        d, km, _, _ = time_rollouts(torch, dist, e, ac, o, k, 3, 1, device)
+        d, km, _, _, _ = time_rollouts(torch, dist, e, ac, o, k, 3, 1, device)
         kmn = sum(km) / len(km)
         sw.append({'envs': ns, 'T': Ts, 'env_steps_per_s': k * ns * Ts / d, 'kernel_ms': kmn,
                    'GBs': ns * (Ts * 66 + STATE_BYTES_PER_ENV_LAUNCH) / (kmn * 1e-3) / 1e9})

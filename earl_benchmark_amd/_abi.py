@@ -75,6 +75,7 @@ SIGNATURES = {
     'earl_tabletop_step': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, _P(TabletopOut), C.c_void_p],
     'earl_tabletop_rollout': [_P(TabletopCfg), _P(TabletopState), C.c_int32, C.c_void_p, _P(TabletopOut), C.c_void_p],
     'earl_tabletop_reset_rollout': [_P(TabletopCfg), _P(TabletopState), C.c_int32, C.c_void_p, _P(TabletopOut), C.c_void_p],
+    'earl_tabletop_eval_episodes': [_P(TabletopCfg), _P(TabletopState), C.c_int32, C.c_int32, C.c_void_p, C.c_int64, _P(TabletopOut), C.c_void_p],
     'earl_tabletop_reset': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_tabletop_observe': [_P(TabletopCfg), _P(TabletopState), _P(TabletopOut), C.c_void_p],
     'earl_tabletop_reward': [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],

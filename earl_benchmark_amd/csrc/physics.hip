@@ -735,7 +735,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     const Q4 hq = qmul(ql, ldq(m.att_quat[k]));
     // rows as mj_instantiateEqual builds them (body1 = mocap, body2 = hand, relpose = identity): position error
     // mocap - hand; orientation error = vector part of e = conj(q_hand) * q_mocap, with the exact Jacobian of that
-    // vector part: -0.5 * (e_w a + a x e_v), a = R_hand^T w_j  (no sign flip for e_w < 0)
+    // vector part: -0.5 * (e_w a + a x e_v), a = R_hand^T w_j  (no sign flip for e_w < 0).  q_mocap is used AS GIVEN: metaworld's
+    // [1, 0, 1, 0] scales residual and Jacobian by sqrt 2 (the rule that replaced round 1's fitted rotational factor)
     const Q4 qe = qmul(Q4{hq.w, -hq.x, -hq.y, -hq.z}, mq);
     const V3 ev{qe.x, qe.y, qe.z};
     double Rh[3][3];
@@ -1022,11 +1023,6 @@ __device__ __forceinline__ V3 attachment(const Shared<NV>& s, const earl_link_mo
   return p;
 }
 
-__device__ __forceinline__ Q4 qnormalize(const Q4& q) {
-  const double nrm = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  return {q.w * nrm, q.x * nrm, q.y * nrm, q.z * nrm};
-}
-
 // the model tables, once per workgroup, into LDS (all 64 lanes copy)
 __device__ __forceinline__ void stage_model(earl_link_model& dst, const earl_link_model* __restrict__ src) {
   static_assert(sizeof(earl_link_model) % 8 == 0, "copied as 8-byte words");
@@ -1089,7 +1085,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
   load_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
   fence();
   const V3 mpos = ld3(a.mocap_pos + (size_t)env * 3);
-  const Q4 mq = qnormalize(ldq(a.mocap_quat + (size_t)env * 4));
+  const Q4 mq = ldq(a.mocap_quat + (size_t)env * 4);      // as given, NOT normalised (include/earl_physics.h)
   double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
   for (int ac = 0; ac < m.n_act; ++ac) ctrl[ac] = a.ctrl[(size_t)env * m.n_act + ac];
   constexpr int NC = 6 + 2 * NV;
@@ -1273,7 +1269,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
   load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   fence();
   V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
-  const Q4 mq = qnormalize(ldq(cfg.mocap_quat));
+  const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
   int steps = a.st.steps_since_reset ? a.st.steps_since_reset[env] : 0;
   const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
   int sgc = gcf > 0 ? a.st.steps_since_goal_change[env] : 0;
@@ -1430,7 +1426,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
   const bool keep = resetting && ((cfg.obj_kind >= 1 && a.st.obj_init) || a.st.last_obs);     // uniform enough: decided per lane, used per lane below
   if (!a.reset_obs && !__any(keep)) return;
   // set_state -> sim.forward(): kinematics of the state just written
-  const Q4 mq = qnormalize(ldq(cfg.mocap_quat));
+  const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
   const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
   substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
   sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.reset_obs ? a.reset_obs + (size_t)env * 14 : nullptr, nullptr, nullptr, nullptr, 0.0,

@@ -369,8 +369,10 @@ int do_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const 
 // reset_first: perform the reset of all envs (counter cfg->counter) before the T steps (counters cfg->counter+1 ..)
 template <int NOBJ>
 int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, int32_t T, const float* act,
-               const earl_tabletop_out* out, earl_stream_t stream, bool reset_first = false) {
+               const earl_tabletop_out* out, earl_stream_t stream, bool reset_first = false, int32_t episodes = 1, long long act_ep_stride = 0) {
   const earl_tabletop_cfg* cfg = cfg_in;
+  const int32_t Tep = T;                     // steps per episode; the fused kernel walks episodes * Tep steps
+  if (episodes > 1) T = episodes * Tep;
   if (int rc = check_common(cfg, st, NOBJ)) return rc;
   if (!act || !out) return fail(EARL_ERR_ARG, "act/out is NULL");
   if (T < 0) return fail(EARL_ERR_ARG, "T = %d < 0", T);
@@ -382,7 +384,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
     if (!general && out->obs && out->reward && out->done && out->success && g_rollout_impl != 1) {
       WsArgs w{cfg->n, T, cfg->horizon, cfg->wide_init, act, st->qpos, st->attached, st->goal_idx, st->goal_table,
                st->steps_since_reset, out->obs, out->reward, out->done, out->success, thresholds(), grip_threshold(),
-               reset_first ? 1 : 0, *cfg, st->goal_idx, st->num_interventions};
+               reset_first ? 1 : 0, *cfg, st->goal_idx, st->num_interventions, episodes, Tep, act_ep_stride};
       const dim3 grid((unsigned)((cfg->n + 63) / 64));
       const hipStream_t hs = (hipStream_t)stream;
 #define EARL_WS(RT, NC, NL, NS, K, LEAD) \
@@ -474,6 +476,29 @@ int earl_tabletop_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state*
 int earl_tabletop_reset_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act,
                                 const earl_tabletop_out* out, earl_stream_t stream) {
   return do_rollout<1>(cfg, st, T, act, out, stream, true);
+}
+int earl_tabletop_eval_episodes(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t episodes, int32_t T, const float* act,
+                                int64_t act_episode_stride, const earl_tabletop_out* out, earl_stream_t stream) {
+  if (episodes < 0) return fail(EARL_ERR_ARG, "episodes = %d < 0", episodes);
+  if (act_episode_stride < 0) return fail(EARL_ERR_ARG, "negative action stride");
+  if (int rc = check_common(cfg, st, 1)) return rc;
+  if (!act || !out) return fail(EARL_ERR_ARG, "act/out is NULL");
+  if (T < 0) return fail(EARL_ERR_ARG, "T = %d < 0", T);
+  if (episodes == 0 || cfg->n == 0) return EARL_OK;
+  const bool general = cfg->goal_change_frequency > 0 || cfg->auto_reset;
+  // one launch walks all episodes when the wave-specialised kernel applies and episodes end on its chunk boundaries (8 steps)
+  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && g_rollout_impl == 0 &&
+                     T % 8 == 0 && T >= 16 && (long long)episodes * T < (1 << 24);
+  if (fused || episodes == 1) return do_rollout<1>(cfg, st, T, act, out, stream, true, episodes, (long long)act_episode_stride);
+  for (int32_t e = 0; e < episodes; ++e) {          // otherwise: the same thing as `episodes` launches
+    earl_tabletop_cfg c = *cfg;
+    c.counter += (uint64_t)e * (uint64_t)(T + 1);
+    const size_t rows = (size_t)e * (size_t)T * (size_t)cfg->n;
+    earl_tabletop_out o{out->obs ? out->obs + rows * 12 : nullptr, out->reward ? out->reward + rows : nullptr, out->done ? out->done + rows : nullptr,
+                        out->success ? out->success + rows : nullptr, nullptr};
+    if (int rc = do_rollout<1>(&c, st, T, act + (size_t)e * (size_t)act_episode_stride, &o, stream, true)) return rc;
+  }
+  return EARL_OK;
 }
 int earl_tabletop_observe(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const earl_tabletop_out* out,
                           earl_stream_t stream) {

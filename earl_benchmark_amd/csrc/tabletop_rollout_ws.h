@@ -50,7 +50,20 @@ struct WsArgs {
   earl_tabletop_cfg cfg;
   int32_t* __restrict__ goal_idx_w;         // same array as goal_idx (written by the fused reset)
   int32_t* __restrict__ num_interventions;
+  // several evaluation episodes in ONE launch (earl_tabletop_eval_episodes; NC == 3 kernels only): T = episodes * Tep steps, every
+  // episode starts with a reset (counter cfg.counter + ep * (Tep + 1), exactly what `episodes` fused reset+rollout launches would use);
+  // Tep % K == 0 and Tep >= 2 K (host-checked).  The outputs are [episodes, Tep, n, ..] = linear in the global step index; the
+  // actions of episode ep start at act + ep * act_ep_stride floats (0: every episode replays the same [Tep, n, 3] actions).
+  int32_t episodes, Tep;
+  long long act_ep_stride;
 };
+
+// Philox counter of the reset that starts episode `ep` of a launch
+__device__ __forceinline__ uint64_t ws_ep_counter(const WsArgs& a, int ep) { return a.cfg.counter + (uint64_t)ep * (uint64_t)(a.Tep + 1); }
+__device__ __forceinline__ int ws_goal_row_ep(const WsArgs& a, int env, int ep) {
+  if (a.reset_first) return sample_goal(a.cfg, ws_ep_counter(a, ep), env, nullptr);
+  return a.goal_idx[env];
+}
 
 // goal row of env `e` for this launch: the stored one, or the one the fused reset samples (every wave that needs it
 // recomputes the same Philox draw instead of waiting for another wave to publish it)
@@ -353,8 +366,20 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       }
     };
     fetch(0);
+    const int cpe = a.episodes > 1 ? a.Tep / K : 0x7fffffff;   // chunks per episode
+    int next_ep_c = cpe, ep = 0, last_gi = -1;
     for (int c = 0; c < nch; ++c) {
       const int rb = c & 1;
+      if (c == next_ep_c) {   // (wave-uniform) the next evaluation episode of this launch starts here: reset() of every env
+        ++ep;
+        next_ep_c += cpe;
+        Env<1> ev;
+        last_gi = reset_env<1>(ev, a.cfg, ws_ep_counter(a, ep), ie, a.goal_table, nullptr, a.th);
+        f = h ? ev.q[1] : ev.q[0];
+        o = h ? ev.q[3] : ev.q[2];
+        attm = 0;
+        nm = ws_near_mask_adj(f, o, kc);
+      }
       slow = slow || (nslow != 0);
 #pragma unroll
       for (int k = 0; k < K; ++k) { av[k] = nv[k]; gv[k] = ng[k]; }
@@ -396,7 +421,11 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       a.qpos[(size_t)ie * 4 + 2 + h] = o;
       if (h == 0) {
         a.attached[ie] = attm ? 0 : -1;
-        a.steps_since_reset[ie] = (a.reset_first ? 0 : a.steps_since_reset[ie]) + T;
+        a.steps_since_reset[ie] = (a.reset_first ? 0 : a.steps_since_reset[ie]) + (a.episodes > 1 ? a.Tep : T);
+        if (ep > 0) {              // the later episodes of the launch: their resets counted, the last goal kept
+          a.goal_idx_w[ie] = last_gi;
+          a.num_interventions[ie] += ep;
+        }
       }
     }
    } else if constexpr (NC == 2) {
@@ -600,13 +629,20 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     const int e0 = min(lane, last), e1 = min(lane + 64, last), e2 = min(lane + 128, last);
     const float* const base = a.act + (size_t)i0 * 3;
     const size_t step_stride = (size_t)n * 3;
+    const float inv_tep = 1.0f / (float)a.Tep;
     auto issue_trip = [&](float (&raw)[LEAD][KL][3], int r) {   // raw <- my steps of trip r
 #pragma unroll
       for (int d = 0; d < LEAD; ++d)
 #pragma unroll
         for (int q = 0; q < KL; ++q) {
-          const int t = __builtin_amdgcn_readfirstlane(min((r * LEAD + d) * K + q * NL + w, T - 1));
-          const float* p = base + (size_t)t * step_stride;
+          int t = __builtin_amdgcn_readfirstlane(min((r * LEAD + d) * K + q * NL + w, T - 1));
+          const float* p = base;
+          if (a.episodes > 1) {            // (uniform) episode of this step; exact for these magnitudes: t, Tep < 2^24
+            const int e_ = __builtin_amdgcn_readfirstlane((int)(((float)t + 0.5f) * inv_tep));
+            t -= e_ * a.Tep;
+            p += (size_t)e_ * (size_t)a.act_ep_stride;
+          }
+          p += (size_t)t * step_stride;
           raw[d][q][0] = p[e0]; raw[d][q][1] = p[e1]; raw[d][q][2] = p[e2];
         }
     };
@@ -680,6 +716,29 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       const long long td = (long long)a.horizon - 1 - (a.reset_first ? 0 : a.steps_since_reset[i]);
       t_done = td < 0 ? 0 : (td > 0x7fffffff ? 0x7fffffff : (int)td);
     }
+    // several episodes per launch: chunk c belongs to episode c / cpe; `g`, and the step index `done` counts from, follow it
+    const int cpe = a.episodes > 1 ? a.Tep / K : 0x7fffffff;
+    int g_ep = 0, t_ep0 = 0;           // episode `g` belongs to, its first global step
+    auto enter_episode = [&](int c) {  // (uniform) called before chunk c is stored
+      if (a.episodes > 1 && c >= (g_ep + 1) * cpe) {
+        g_ep = c / cpe;
+        t_ep0 = g_ep * a.Tep;
+        if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, g_ep), g);
+      }
+    };
+    // ... and after chunk j has been stored, its row-image buffer is next written for chunk j + 2: if that one belongs to a later
+    // episode the constant goal part of the buffer's rows is rewritten (this storer: its own steps of the buffer, env column `lane`)
+    auto refill_goal = [&](int j) {
+      if (a.episodes > 1 && j + 2 < nch && (j + 2) / cpe != j / cpe) {
+        float gn[6] = {0, 0, 0, 0, 0, 0};
+        if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, (j + 2) / cpe), gn);
+        for (int k = s; k < K; k += NS) {
+          float4* row = &R[j & 1][k][lane * 3];
+          row[1] = float4{-1.0f, -1.0f, gn[0], gn[1]};    // (the flag words are rewritten by the compute wave every step)
+          row[2] = float4{gn[2], gn[3], gn[4], gn[5]};
+        }
+      }
+    };
     // steps_since_reset must be in a register before the compute wave can possibly update it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const bool full = (valid == E) && ((n & 3) == 0);   // whole workgroup live and flag rows dword-aligned
@@ -701,7 +760,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         float rew;
         if constexpr (RT == EARL_REWARD_SPARSE) rew = succ ? 1.0f : 0.0f;
         else rew = (float)dense1(o);
-        const bool dn = t >= t_done;
+        const bool dn = t - t_ep0 >= t_done;
         if (full) {
           // (1) the 64 obs rows of this step: 192 float4, contiguous in HBM and in LDS
           const float4 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128];
@@ -753,7 +812,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         if constexpr (RT == EARL_REWARD_SPARSE) rew = succ ? 1.0f : 0.0f;
         else rew = (float)dense1(o);
         a.reward[row0 + lane] = rew;
-        const unsigned long long ms = __ballot(succ), md = __ballot(t >= t_done);
+        const unsigned long long ms = __ballot(succ), md = __ballot(t - t_ep0 >= t_done);
         if (lane < 16) {
           const uint32_t ns = (uint32_t)(ms >> (4 * lane)) & 0xFu, nd = (uint32_t)(md >> (4 * lane)) & 0xFu;
           reinterpret_cast<uint32_t*>(a.success + row0)[lane] = (ns * 0x00204081u) & 0x01010101u;
@@ -762,8 +821,10 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       }
     };
     auto store = [&](int c) {
+      enter_episode(c);
       if (Q > 0 && full && (c + 1) * K <= T) store_chunk_fast(c);
       else store_chunk(c);
+      refill_goal(c);
     };
     if constexpr (PROF) p_t0 = ws_clock();
     __syncthreads();

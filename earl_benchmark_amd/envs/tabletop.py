@@ -241,6 +241,35 @@ class TabletopManipulation:
       return obs[0].cpu().numpy(), float(r64[0]), bool(done[0]), {}
     return obs, rew, done, {'success': succ}
 
+  def rollout_episodes(self, actions, episodes=None, out=None):
+    """`episodes` evaluation episodes of every env, back to back (each = reset() + T steps), in ONE kernel launch when the fused kernel
+    applies (include/earl_tabletop.h: earl_tabletop_eval_episodes).  actions [T, N, 3] (replayed by every episode; give `episodes`) or
+    [E, T, N, 3].  -> (obs [E,T,N,D], reward [E,T,N], done [E,T,N], success [E,T,N]); bit-identical to E calls of
+    rollout(actions, reset_first=True)."""
+    if self.NOBJ != 1:
+      raise NotImplementedError('rollout_episodes: single-object env only')
+    with torch.cuda.device(self.device):
+      a = torch.as_tensor(actions, device=self.device)
+      if a.dim() == 4:
+        E, T = int(a.shape[0]), int(a.shape[1])
+        if episodes is not None and int(episodes) != E:
+          raise ValueError(f'episodes = {episodes} but actions hold {E}')
+        act, stride = self._actions(a, (E, T, self.num_envs)), T * self.num_envs * 3
+      else:
+        E, T = int(episodes), int(a.shape[0])
+        act, stride = self._actions(a, (T, self.num_envs)), 0
+      if out is None:
+        outs, ostruct = self._new_out((E, T, self.num_envs))
+      else:
+        outs = tuple(out)
+        ostruct = self._out_struct(outs, (E, T, self.num_envs))
+      rc = self._lib.earl_tabletop_eval_episodes(self._cfg_ref, self._st_ref, E, T, act.data_ptr(), stride, C.byref(ostruct), self._stream())
+    _abi.check(rc, 'eval_episodes')
+    self._cfg.counter += E * (T + 1)
+    self.total_step_count += E * T
+    self._last_success = outs[3][-1, -1]
+    return outs
+
   def make_step_graph(self, T, policy=None):
     """Closed-loop stepping without the per-call host cost: a captured HIP graph of T step launches (see `StepGraph`)."""
     return StepGraph(self, T, policy)

@@ -44,6 +44,9 @@ class PersistentStateWrapper(Wrapper):
   def rollout(self, actions, **kwargs):
     return self.env.rollout(actions, **kwargs)
 
+  def rollout_episodes(self, actions, **kwargs):
+    return self.env.rollout_episodes(actions, **kwargs)
+
   def is_successful(self, obs=None):
     return self.env.is_successful(obs)
 

@@ -99,7 +99,8 @@ typedef struct earl_collision_model {
 
 /* nsub timesteps of every env.  model: DEVICE copy of an earl_link_model; col: DEVICE copy of its earl_collision_model or
  * NULL (no contacts).  State (updated in place):
- * qpos [n, nq], qvel [n, nv]; inputs mocap_pos [n,3], mocap_quat [n,4] (normalised internally), ctrl [n, n_act];
+ * qpos [n, nq], qvel [n, nv]; inputs mocap_pos [n,3], mocap_quat [n,4] (used AS GIVEN in the weld's orientation rows: an unnormalised quaternion scales their residual and
+ * Jacobian by its norm -- metaworld's [1, 0, 1, 0] is meant to be passed unchanged), ctrl [n, n_act];
  * att_xpos (may be NULL) [n, n_att, 3]: world positions of the attachments after the last timestep. */
 int earl_physics_step(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,

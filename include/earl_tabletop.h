@@ -98,6 +98,17 @@ int earl_tabletop_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_stat
 int earl_tabletop_reset_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T,
                                 const float* act, const earl_tabletop_out* out, earl_stream_t stream);
 
+/* `episodes` evaluation episodes per env, back to back: episode e = earl_tabletop_reset_rollout with Philox counter
+ * cfg->counter + e * (T + 1), its outputs at rows [e, T, n, ..] of `out` (obs [episodes, T, n, 12], ...), its actions at
+ * act + e * act_episode_stride floats (act_episode_stride = T * n * 3: a contiguous [episodes, T, n, 3] array; 0: every episode replays
+ * the same [T, n, 3] actions).  Bit-identical to that sequence of calls; the caller advances its counter by episodes * (T + 1).
+ * This is the reference's evaluation loop (`for _ in range(num_eval_episodes): obs = env.reset(); while not done: env.step(...)`
+ * over PersistentStateWrapper, persistent_state_wrapper.py:17-31) for the whole batch.  When the wave-specialised kernel applies
+ * (no lifelong switching / auto-reset, all four outputs, T a multiple of 8) ALL episodes run in ONE launch: the launch's fixed cost
+ * (prologue, pipeline fill and drain) is paid once instead of once per episode. */
+int earl_tabletop_eval_episodes(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t episodes, int32_t T, const float* act,
+                                int64_t act_episode_stride, const earl_tabletop_out* out, earl_stream_t stream);
+
 /* PersistentStateWrapper.reset() + TabletopManipulation.reset() for the envs with mask[i] != 0
  * (mask == NULL: all).  Replaces wrappers/persistent_state_wrapper.py:17-20 and
  * envs/tabletop_manipulation.py:105-126 (incl. is_valid_init :89-97, get_next_goal :62-76).

@@ -96,6 +96,10 @@ typedef struct {
   int ncon;
 } StepOut;
 
+/* 1 (the rule the kernels implement): the mocap quaternion enters the weld rows AS GIVEN (metaworld sets [1, 0, 1, 0], norm sqrt 2: residual
+ * and Jacobian of the orientation rows scale by sqrt 2); 0 = normalised first (round 1, kept as an experiment switch for tools/heldout_eval.py) */
+static int g_raw_mocap_quat = 1;
+int oracle_set_raw_mocap_quat(int raw) { const int prev = g_raw_mocap_quat; g_raw_mocap_quat = raw; return prev; }
 static Q4 qnormalize(Q4 q) {
   const double s = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   Q4 r = {q.w * s, q.x * s, q.y * s, q.z * s};
@@ -447,7 +451,7 @@ int oracle_physics(const earl_link_model* m, const earl_collision_model* col, in
   for (int e = 0; e < n; ++e) {
     StepOut o;
     const V3 mpos = ld3(mocap_pos + 3 * (size_t)e);
-    const Q4 mq = qnormalize(ldq(mocap_quat + 4 * (size_t)e));
+    const Q4 mq = g_raw_mocap_quat ? ldq(mocap_quat + 4 * (size_t)e) : qnormalize(ldq(mocap_quat + 4 * (size_t)e));
     for (int ts = 0; ts < (integrate ? nsub : 1); ++ts)
       substep(m, col, qpos + (size_t)e * m->nq, qvel + (size_t)e * nv, mpos, mq, ctrl + (size_t)e * m->n_act, integrate, &o);
     if (qacc) memcpy(qacc + (size_t)e * nv, o.qacc, sizeof(double) * nv);
@@ -485,7 +489,7 @@ int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* 
     double* qv = st->qvel + (size_t)e * nv;
     double* mp = st->mocap_pos + (size_t)e * 3;
     double* goal = st->goal + (size_t)e * 7;
-    const Q4 mq = qnormalize(ldq(cfg->mocap_quat));
+    const Q4 mq = g_raw_mocap_quat ? ldq(cfg->mocap_quat) : qnormalize(ldq(cfg->mocap_quat));
     int steps = st->steps_since_reset ? st->steps_since_reset[e] : 0;
     const int gcf = st->steps_since_goal_change ? cfg->goal_change_frequency : 0;
     int sgc = gcf > 0 ? st->steps_since_goal_change[e] : 0;

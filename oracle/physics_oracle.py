@@ -38,18 +38,14 @@ def quat_conj(q):
 #     within 5 mm of the recorded one for 9-22 env steps after the door starts to move in all ten door demonstrations (1.0: 0-5 steps).
 # Which MuJoCo 2.1 rule accounts for the factor is not identified.
 WELD_TRANSLATION_CALIBRATION = 4.0
-# The three ROTATIONAL rows: 0.5 x the derived value (stiffer).  Less sharply determined than the translational factor (0.25 ... 0.5 do
-# equally well); what it rests on, all with the translational factor already in place (scan 0.25 / 0.5 / 1 / 2 / 4):
-#   * door, hand path over the contact-free first steps of the 10 demonstrations: RMS 4.8 / 6.1 / 7.3 / 9.5 / 10.7 mm;
-#   * peg, the 10 forward demonstrations replayed whole: peg-path RMS 6.7 / 7.7 / 8.4 / 10.4 mm, insertions 6 / 7 / 3 / 4 of 10 -- with
-#     the derived value the settled gripper leans 2.7 degrees, and the 400 N squeeze of the fingers on the peg then lifts the hand
-#     2 mm (recorded: none), so the peg arrives 2-3 mm low at the hole's mouth; with 0.5 it leans 0.9 degrees;
-#   * door, reverse demonstrations: 4 of 5 keep the rod (3 of 5), one reaches the goal;
-#   * against it: the peg's contact-free prefixes get slightly worse (5.1 -> 6.0 mm).
-# A candidate cause for exactly 0.5: metaworld sets mocap_quat = [1, 0, 1, 0], NOT normalised (norm sqrt 2).  If MuJoCo 2.1 uses it as it
-# is, the orientation residual vec(conj(q_hand) * q_mocap) and its Jacobian are both scaled by sqrt 2, which doubles the rows' weight,
-# i.e. halves their effective regulariser.  (This file normalises the mocap quaternion and carries the factor instead.)
-WELD_ROTATION_CALIBRATION = 0.5
+# The three ROTATIONAL rows carry the derived value.  Round 1 carried a fitted 0.5 here; round 2 replaced it by a RULE: the mocap
+# quaternion enters the weld rows AS GIVEN.  metaworld sets mocap_quat = [1, 0, 1, 0] (norm sqrt 2, SawyerXYZEnv.set_xyz_action
+# [UPSTREAM]); taken unnormalised, the orientation residual vec(conj(q_hand) * q_mocap) and its Jacobian are both scaled by sqrt 2, which
+# doubles the rows' weight -- the same thing as halving their regulariser.  On the recorded episodes the rule and the fitted factor are
+# indistinguishable (tools/heldout_eval.py, profiles/r02_heldout_eval.json: fit-set score 9.51 mm vs 9.52 mm, held-out 14.81 vs 14.79),
+# and a re-fit on the even-numbered episodes alone picks the rule.  Whether MuJoCo 2.1's mj_kinematics really leaves mocap_quat
+# unnormalised cannot be checked here (no MuJoCo source or binary): it is the rule that explains the recordings.
+# The translational factor above has no such explanation; it is FROZEN at 4.0 and justified on held-out episodes (same file).
 
 
 def quat_mat(q):
@@ -234,7 +230,7 @@ def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
   for w in range(len(m.weld_body1)):
     b1, b2 = int(m.weld_body1[w]), int(m.weld_body2[w])
     assert m.body_mocap[b1], 'weld body1 is the mocap body in these models'
-    p1, q1 = mocap_pos, mocap_quat / np.linalg.norm(mocap_quat)
+    p1, q1 = mocap_pos, np.asarray(mocap_quat, dtype=np.float64)       # as given: NOT normalised (see the note above WELD_TRANSLATION_CALIBRATION)
     p2, q2 = kin['xpos'][b2], kin['xquat'][b2]
     Jb = body_jacobian(m, S, b2, p2)
     # mj_instantiateEqual, weld with relpose = identity (metaworld's reset_mocap_welds): position error body1 - body2;
@@ -247,7 +243,7 @@ def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
     A = R2.T @ Jb[0:3]                                        # 3 x nv, angular Jacobian in body2 axes
     Jq = -0.5 * (e[0] * A + np.cross(A.T, e[1:]).T)
     for a in range(3):
-      rows.append((Jq[a], e[1 + a], m.weld_solref[w], m.weld_solimp[w], WELD_ROTATION_CALIBRATION * m.body_invweight0[b2, 1], True))
+      rows.append((Jq[a], e[1 + a], m.weld_solref[w], m.weld_solimp[w], m.body_invweight0[b2, 1], True))
   for j in range(m.nv):
     if m.jnt_limited[j]:
       lo, hi = m.jnt_range[j]
@@ -411,7 +407,7 @@ def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geo
     out[k] = np.array(getattr(m, k))
   wb = int(m.weld_body2[0])
   out['weld_att'] = np.int32(list(out['att_names']).index(str(m.body_names[wb])))
-  out['weld_invweight'] = m.body_invweight0[wb] * np.array([WELD_TRANSLATION_CALIBRATION, WELD_ROTATION_CALIBRATION])
+  out['weld_invweight'] = m.body_invweight0[wb] * np.array([WELD_TRANSLATION_CALIBRATION, 1.0])
   # generalized coordinates: qpos has one entry per dof, except that a free body's orientation is a unit quaternion
   # stored where MuJoCo stores it (after the body's three translations): nq = nv + 1 per free body
   ball = [l for l in range(nv) if m.jnt_type[l] == 2]
@@ -736,7 +732,7 @@ class LinkModel:
     # reset_mocap_welds): position error mocap - hand; orientation error = vector part of e = conj(q_hand) * q_mocap with
     # the EXACT Jacobian of that vector part, 0.5 * vec(conj(q_hand) * [0, -w_j] * q_mocap) = -0.5 * (e_w a + a x e_v),
     # a = R_hand^T w_j.  No sign flip for e_w < 0 (MuJoCo has none).
-    q1 = mocap_quat / np.linalg.norm(mocap_quat)
+    q1 = np.asarray(mocap_quat, dtype=np.float64)           # as given, not normalised (rule replacing round 1's rotational factor)
     e = quat_mul(quat_conj(hq), q1)
     Rh = quat_mat(hq)
     for j in self.anc[self.att_link[k]]:

@@ -67,7 +67,21 @@ class ValidatorEnv:
     time.sleep(self.delay)
 
 
-def _worker(rank, world, port, n, T, steps, warmup, out_dir):
+  def rollout_episodes(self, acts, episodes, out):
+    assert acts.shape == (self.T, self.n, 3) and all(t.shape[0] == episodes for t in out)
+    o = self._abi.TabletopOut(*(t.data_ptr() for t in out))
+    rc = self.lib.earl_tabletop_eval_episodes(C.byref(self.cfg), C.byref(self.st), episodes, self.T, acts.data_ptr(), 0, C.byref(o), None)
+    self._abi.check(rc, 'earl_tabletop_eval_episodes (argument validation)')
+    assert self.lib.earl_tabletop_eval_episodes(C.byref(self.cfg), C.byref(self.st), -1, self.T, acts.data_ptr(), 0, C.byref(o), None) != 0
+    for e in range(episodes):
+      for dst, src in zip(out, synthetic(self.T, self.lo, self.n)):
+        dst[e].copy_(src)
+    self.launches += 1
+    self.episodes = getattr(self, 'episodes', 0) + episodes
+    time.sleep(self.delay)
+
+
+def _worker(rank, world, port, n, T, steps, warmup, out_dir, E=1):
   sys.path.insert(0, REPO)
   import torch.distributed as dist
   import bench
@@ -76,9 +90,11 @@ def _worker(rank, world, port, n, T, steps, warmup, out_dir):
   try:
     env = ValidatorEnv(n, T, rank * n, delay=0.02 * (rank + 1))        # rank 1 is the slow one: the job time is ITS time
     acts = bench.synth_actions(torch, T, n, rank, 'cpu')
-    out = bench.alloc_out(torch, T, n, 'cpu')
-    dt, kern_ms, table, traj = bench.time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cpu', gather_rollout=True)
-    assert env.launches == steps + warmup
+    out = bench.alloc_out(torch, T, n, 'cpu', E)
+    dt, kern_ms, table, traj, launches = bench.time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cpu', gather_rollout=True,
+                                                             episodes_per_launch=E)
+    assert launches == -(-steps // E) and env.launches == launches + -(-warmup // E)
+    assert E == 1 or env.episodes == steps + warmup
     np.save(os.path.join(out_dir, f'table_{rank}.npy'), table.numpy())
     np.save(os.path.join(out_dir, f'traj_{rank}.npy'), traj.numpy())
     json.dump({'dt': dt, 'kern_ms': kern_ms}, open(os.path.join(out_dir, f'time_{rank}.json'), 'w'))
@@ -86,10 +102,11 @@ def _worker(rank, world, port, n, T, steps, warmup, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_bench_sequence(tmp_path):
+@pytest.mark.parametrize('E', [1, 2])
+def test_two_rank_bench_sequence(tmp_path, E):
   from earl_benchmark_amd import sharding
   world, n, T, steps, warmup = 2, 48, 7, 3, 2
-  mp.spawn(_worker, args=(world, _free_port(), n, T, steps, warmup, str(tmp_path)), nprocs=world, join=True)
+  mp.spawn(_worker, args=(world, _free_port(), n, T, steps, warmup, str(tmp_path), E), nprocs=world, join=True)
   obs, reward, done, success = synthetic(T, 0, world * n)
   want = sharding.rollout_summary(reward, success).numpy()
   times = [json.load(open(tmp_path / f'time_{r}.json')) for r in range(world)]
@@ -98,7 +115,7 @@ def test_two_rank_bench_sequence(tmp_path):
     o, rw, d, s = sharding.unpack_rollout(torch.from_numpy(np.load(tmp_path / f'traj_{r}.npy')))
     assert o.shape == (T, world * n, 12)
     assert torch.equal(o, obs) and torch.equal(rw, reward) and torch.equal(d, done) and torch.equal(s, success)
-  assert times[0]['dt'] == times[1]['dt'] >= steps * 0.04                                  # MAX over ranks: the slow rank's time, on both
+  assert times[0]['dt'] == times[1]['dt'] >= -(-steps // E) * 0.04                                  # MAX over ranks: the slow rank's time, on both
   assert times[0]['kern_ms'][0] < times[1]['kern_ms'][0]                                   # ... while the per-rank launch clock stays local
 
 
@@ -110,7 +127,7 @@ def test_single_process_sequence_and_ragged_gather_rollout():
   n, T = 40, 5
   env = ValidatorEnv(n, T, 0, delay=0.0)
   out = bench.alloc_out(torch, T, n, 'cpu')
-  dt, kern_ms, table, traj = bench.time_rollouts(torch, None, env, bench.synth_actions(torch, T, n, 0, 'cpu'), out, 2, 1, 1, device='cpu')
+  dt, kern_ms, table, traj, _ = bench.time_rollouts(torch, None, env, bench.synth_actions(torch, T, n, 0, 'cpu'), out, 2, 1, 1, device='cpu')
   assert table is None and traj is None and dt > 0 and env.launches == 3
   buf = sharding.pack_rollout(*out)
   assert buf.shape == (T, n, 14) and sharding.gather_rollout(buf) is buf

@@ -163,7 +163,7 @@ def test_reset_without_obs_still_records_the_dense_reward_state_and_restores_the
     e = cls(num_envs=3)
     default = e.goal_t.clone()
     e.reset_goal(np.array([0.1, 0.5, 0.2, 1.0, 0.2, 0.6, 0.1]))
-    assert not bool((e.goal_t == default).any(1).all()) and bool((e._get_obs()[:, 7:] == e.goal_t).all())
+    assert not bool((e.goal_t == default).all(1).any()) and bool((e._get_obs()[:, 7:] == e.goal_t).all())
     o = e.reset(mask=torch.tensor([True, False, True]))
     assert bool((e.goal_t[0] == default[0]).all()) and bool((e.goal_t[2] == default[2]).all()) and not bool((e.goal_t[1] == default[1]).all())
     assert bool((o[:, 7:] == e.goal_t).all())

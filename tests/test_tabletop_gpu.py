@@ -499,3 +499,31 @@ def test_3obj_reset_at_goal(hx, orc):
   m = (np.arange(n) % 3 == 0).astype(np.uint8)
   np.testing.assert_array_equal(h.reset(mask=m), o.reset(mask=m))
   assert_same_state(o, h)
+
+
+@pytest.mark.parametrize('n,T,E,kw', [(4096, 200, 3, {}), (257, 24, 4, {'wide_init_distr': True}), (300, 16, 2, {'reset_at_goal': True}),
+                                      (130, 40, 3, {'reward_type': 'dense'}), (100, 20, 3, {}), (64, 8, 2, {})])
+def test_eval_episodes_in_one_launch_equal_the_sequence_of_launches(n, T, E, kw):
+  """earl_tabletop_eval_episodes: E x (reset + T steps) in ONE launch of the wave-specialised kernel (episode boundaries inside the
+  launch: state reset, goal re-drawn, goal part of the row images rewritten, done counted per episode) == E fused reset+rollout launches,
+  bit for bit, outputs and final state; also through the fallback (T not a multiple of the 8-step chunk, T < 16)."""
+  import torch
+  from earl_benchmark_amd.envs import tabletop
+  kw = dict({'reward_type': 'sparse'}, **kw)
+  a = tabletop.TabletopManipulation(num_envs=n, seed=13, scalar_api=False, **kw)
+  b = tabletop.TabletopManipulation(num_envs=n, seed=13, scalar_api=False, **kw)
+  a._cfg.horizon = b._cfg.horizon = T
+  g = torch.Generator(device='cuda').manual_seed(4)
+  acts = (torch.rand(E, T, n, 3, generator=g, device='cuda') * 2 - 1).contiguous()
+  acts[..., 2] = acts[..., 2].abs() * (torch.rand(E, T, n, generator=g, device='cuda') > 0.2)       # mostly gripping: attach / carry / release
+  for shared in (False, True):
+    got = a.rollout_episodes(acts[0], episodes=E) if shared else a.rollout_episodes(acts)
+    for e in range(E):
+      want = b.rollout(acts[0] if shared else acts[e], reset_first=True)
+      for x, y, name in zip(got, want, ('obs', 'reward', 'done', 'success')):
+        assert torch.equal(x[e], y), (shared, e, name)
+    for k in ('qpos', 'attached', 'goal_idx', 'steps_since_reset', 'interventions'):
+      assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert a._cfg.counter == b._cfg.counter and a.total_step_count == b.total_step_count
+    assert bool(got[2][:, -1].all()) and not bool(got[2][:, :-1].any())            # done exactly at the last step of EVERY episode
+  assert len(torch.unique(a.goal_idx)) > 1                                          # goals were re-drawn per env

@@ -16,13 +16,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
 PROF = os.path.join(ROOT, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-n, T = 4096, 200
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+n, T, E = 4096, 200, 8          # bench.py defaults: 8 evaluation episodes per launch
+SUF = f'_E{E}' if E > 1 else ''
 os.makedirs(PROF, exist_ok=True)
 
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 stats = newest(os.path.join(OUT, 'prof_stats', '*', '*_kernel_stats.csv'))
-shutil.copy(stats, os.path.join(PROF, f'{tag}_bench_n{n}_T{T}_kernel_stats.csv'))
+shutil.copy(stats, os.path.join(PROF, f'{tag}_bench_n{n}_T{T}{SUF}_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats)))
 kern = [r for r in rows if 'rollout' in r['Name']][0]
 
@@ -38,22 +39,22 @@ for name in ('fetch', 'write'):
 rk = [k for k in pmc if 'rollout' in k][0]
 fetch, write = pmc[rk]['FETCH_SIZE']['mean_KiB'], pmc[rk]['WRITE_SIZE']['mean_KiB']
 hbm = (2 * fetch + write) * 1024
-algo = n * (T * 66 + 2 * (32 + 1 + 4) + 4)
+algo = n * (E * T * 66 + 2 * (32 + 1 + 4) + 4)
 summary = {
-    'command': 'python3 bench.py --steps 100 --warmup 10 --no-cpu --no-step-api  (under rocprofv3, see tools/profile_bench.sh)',
+    'command': 'python3 bench.py --steps 104 --warmup 8 --no-cpu --no-step-api --no-sawyer --no-single  (under rocprofv3, see tools/profile_bench.sh)',
     'kernel': rk,
     'kernel_trace_stats': {'calls': int(kern['Calls']), 'average_ns': float(kern['AverageNs']), 'min_ns': float(kern['MinNs']),
                            'max_ns': float(kern['MaxNs']), 'stddev_ns': float(kern['StdDev'])},
     'pmc': pmc,
     'corrections': 'HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reads 1/2 for streaming loads)',
-    'calibration': {'action_bytes_read_per_launch': n * T * 12, 'FETCH_SIZE_x2_bytes': 2 * fetch * 1024,
+    'calibration': {'action_bytes_read_per_launch': n * T * 12 * E, 'FETCH_SIZE_x2_bytes': 2 * fetch * 1024,
                     'note': 'the remaining read bytes are the fp64 state, goal rows and flags (<= 0.4 MB)'},
     'hbm_bytes_per_launch': hbm, 'algorithmic_bytes_per_launch': algo, 'traffic_over_algorithmic': hbm / algo,
 }
-json.dump(summary, open(os.path.join(PROF, f'{tag}_bench_n{n}_T{T}_pmc.json'), 'w'), indent=1)
+json.dump(summary, open(os.path.join(PROF, f'{tag}_bench_n{n}_T{T}{SUF}_pmc.json'), 'w'), indent=1)
 traffic_path = os.path.join(PROF, 'traffic.json')
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
-traffic[f'rollout_n{n}_T{T}'] = {'hbm_bytes_per_launch': hbm, 'source': f'profiles/{tag}_bench_n{n}_T{T}_pmc.json',
+traffic[f'rollout_n{n}_T{T}{SUF}'] = {'hbm_bytes_per_launch': hbm, 'source': f'profiles/{tag}_bench_n{n}_T{T}{SUF}_pmc.json',
                                  'rocprof_kernel_average_ns': float(kern['AverageNs'])}
 json.dump(traffic, open(traffic_path, 'w'), indent=1)
 print(json.dumps({k: summary[k] for k in ('kernel_trace_stats', 'hbm_bytes_per_launch', 'algorithmic_bytes_per_launch', 'traffic_over_algorithmic')}, indent=1))
