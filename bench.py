@@ -40,7 +40,7 @@ def parse():
   p.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
   p.add_argument('--cpu-seconds', type=float, default=10.0)
   p.add_argument('--no-step-api', action='store_true')
-  p.add_argument('--episodes-per-launch', type=int, default=8,
+  p.add_argument('--episodes-per-launch', type=int, default=25,
                  help='evaluation episodes (bench steps) one kernel launch walks (earl_tabletop_eval_episodes); 1 = one launch per episode')
   p.add_argument('--no-single', action='store_true', help='skip the one-episode-per-launch comparison leg')
   p.add_argument('--no-sawyer', action='store_true', help='skip the sawyer_door / sawyer_peg (BASELINE configs[2]) legs of the default line')

@@ -389,6 +389,8 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
       const hipStream_t hs = (hipStream_t)stream;
 #define EARL_WS(RT, NC, NL, NS, K, LEAD) \
   rollout_ws_kernel<RT, NC, NL, NS, K, LEAD><<<grid, 64 * (((NC) == 3 ? 2 : (NC)) + NL + NS), g_rollout_lds_pad, hs>>>(w)
+#define EARL_WSM(RT, NC, NL, NS, K, LEAD) \
+  rollout_ws_kernel<RT, NC, NL, NS, K, LEAD, false, true><<<grid, 64 * (((NC) == 3 ? 2 : (NC)) + NL + NS), g_rollout_lds_pad, hs>>>(w)
       if (cfg->reward_type == EARL_REWARD_SPARSE) {
         switch (g_rollout_impl) {   // tuning variants (tools/tune_rollout.py); 0 = the shipped configuration
           case 2: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 4, 6); break;
@@ -422,15 +424,22 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
             // Two loaders, not four: fewer waves compete with the compute waves for issue slots (4 loaders: 30.4 us, 2: 29.0 us
             // at N = 4096, T = 200).  Large grids (more than one workgroup per CU) prefer shorter loader trips (LEAD 2):
             // 69.5 vs 65.0 G env-steps/s at N = 2^20.
-            if (grid.x <= 256) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
+            if (episodes > 1) {          // several evaluation episodes per launch: the MULTI instantiation of the shipped configuration
+              if (grid.x <= 256) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
+              else EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
+            } else if (grid.x <= 256) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
             else EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
             break;
         }
       } else {
-        if (grid.x <= 256) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
+        if (episodes > 1) {
+          if (grid.x <= 256) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
+          else EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
+        } else if (grid.x <= 256) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
         else EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
       }
 #undef EARL_WS
+#undef EARL_WSM
       return launched("rollout_ws_kernel");
     }
   }

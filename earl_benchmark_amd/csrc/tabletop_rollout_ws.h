@@ -271,12 +271,15 @@ __device__ __forceinline__ unsigned long long ws_clock() {
 // RT reward type; NC compute waves: 1 = one lane per env (64 envs), 2 = two 32-env waves with x / y in the two lane
 // halves; NL loader waves (steps of a chunk are dealt round-robin to them), NS storer waves (likewise), K steps per
 // chunk, LEAD chunks per loader trip.  K % NL == 0.
-template <int RT, int NC, int NL, int NS, int K, int LEAD, bool PROF = false>
+// MULTI: several evaluation episodes per launch (WsArgs.episodes > 1; NC == 3 only) -- a separate instantiation, so the one-episode kernel
+// carries none of the episode bookkeeping.
+template <int RT, int NC, int NL, int NS, int K, int LEAD, bool PROF = false, bool MULTI = false>
 __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_ws_kernel(const WsArgs a) {
   constexpr int E = 64;
   constexpr int NCW = NC == 3 ? 2 : NC;     // compute WAVES (NC == 3: two, x / y in adjacent lanes)
   constexpr int KL = K / NL;          // steps of a chunk handled by one loader
   static_assert(K % NL == 0, "K must be a multiple of NL");
+  static_assert(!MULTI || NC == 3, "several episodes per launch: adjacent-lane compute waves only");
   static_assert(NC == 1 || NC == 2 || NC == 3, "NC is 1, 2 or 3");
   // rescaled (a0, a1).  NC == 1: [2e], [2e+1] of env e.  NC == 2: wave cw reads [64cw + lane]: a0 of its 32 envs, then a1
   __shared__ double A[3][K][2 * E];
@@ -366,11 +369,11 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       }
     };
     fetch(0);
-    const int cpe = a.episodes > 1 ? a.Tep / K : 0x7fffffff;   // chunks per episode
+    const int cpe = MULTI ? a.Tep / K : 0x7fffffff;   // chunks per episode
     int next_ep_c = cpe, ep = 0, last_gi = -1;
     for (int c = 0; c < nch; ++c) {
       const int rb = c & 1;
-      if (c == next_ep_c) {   // (wave-uniform) the next evaluation episode of this launch starts here: reset() of every env
+      if (MULTI && c == next_ep_c) {   // (wave-uniform) the next evaluation episode of this launch starts here: reset() of every env
         ++ep;
         next_ep_c += cpe;
         Env<1> ev;
@@ -421,8 +424,8 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       a.qpos[(size_t)ie * 4 + 2 + h] = o;
       if (h == 0) {
         a.attached[ie] = attm ? 0 : -1;
-        a.steps_since_reset[ie] = (a.reset_first ? 0 : a.steps_since_reset[ie]) + (a.episodes > 1 ? a.Tep : T);
-        if (ep > 0) {              // the later episodes of the launch: their resets counted, the last goal kept
+        a.steps_since_reset[ie] = (a.reset_first ? 0 : a.steps_since_reset[ie]) + (MULTI ? a.Tep : T);
+        if (MULTI && ep > 0) {     // the later episodes of the launch: their resets counted, the last goal kept
           a.goal_idx_w[ie] = last_gi;
           a.num_interventions[ie] += ep;
         }
@@ -629,18 +632,23 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     const int e0 = min(lane, last), e1 = min(lane + 64, last), e2 = min(lane + 128, last);
     const float* const base = a.act + (size_t)i0 * 3;
     const size_t step_stride = (size_t)n * 3;
-    const float inv_tep = 1.0f / (float)a.Tep;
+    const int cpe = MULTI ? a.Tep / K : 0x7fffffff;
+    int l_ep_end = cpe, l_ep_first = 0;       // loader's episode cursor: chunks [l_ep_first, l_ep_end) belong to the current episode
+    size_t l_ep_base = 0;                     // ... whose actions start at base + l_ep_base
     auto issue_trip = [&](float (&raw)[LEAD][KL][3], int r) {   // raw <- my steps of trip r
 #pragma unroll
       for (int d = 0; d < LEAD; ++d)
 #pragma unroll
         for (int q = 0; q < KL; ++q) {
-          int t = __builtin_amdgcn_readfirstlane(min((r * LEAD + d) * K + q * NL + w, T - 1));
+          int t;
           const float* p = base;
-          if (a.episodes > 1) {            // (uniform) episode of this step; exact for these magnitudes: t, Tep < 2^24
-            const int e_ = __builtin_amdgcn_readfirstlane((int)(((float)t + 0.5f) * inv_tep));
-            t -= e_ * a.Tep;
-            p += (size_t)e_ * (size_t)a.act_ep_stride;
+          if constexpr (MULTI) {           // chunk j of the launch = chunk j - ep_first of episode l_ep (all wave-uniform scalars)
+            const int j = min(r * LEAD + d, nch - 1);
+            while (j >= l_ep_end) { l_ep_end += cpe; l_ep_base += (size_t)a.act_ep_stride; l_ep_first += cpe; }
+            t = __builtin_amdgcn_readfirstlane((j - l_ep_first) * K + q * NL + w);
+            p += l_ep_base;
+          } else {
+            t = __builtin_amdgcn_readfirstlane(min((r * LEAD + d) * K + q * NL + w, T - 1));
           }
           p += (size_t)t * step_stride;
           raw[d][q][0] = p[e0]; raw[d][q][1] = p[e1]; raw[d][q][2] = p[e2];
@@ -716,22 +724,23 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       const long long td = (long long)a.horizon - 1 - (a.reset_first ? 0 : a.steps_since_reset[i]);
       t_done = td < 0 ? 0 : (td > 0x7fffffff ? 0x7fffffff : (int)td);
     }
-    // several episodes per launch: chunk c belongs to episode c / cpe; `g`, and the step index `done` counts from, follow it
-    const int cpe = a.episodes > 1 ? a.Tep / K : 0x7fffffff;
-    int g_ep = 0, t_ep0 = 0;           // episode `g` belongs to, its first global step
-    auto enter_episode = [&](int c) {  // (uniform) called before chunk c is stored
-      if (a.episodes > 1 && c >= (g_ep + 1) * cpe) {
-        g_ep = c / cpe;
-        t_ep0 = g_ep * a.Tep;
+    // several episodes per launch: chunk c belongs to episode c / cpe; `g`, and the step index `done` counts from, follow it (cursors,
+    // no divisions: eight storer waves share the SIMDs with the compute waves)
+    const int cpe = MULTI ? a.Tep / K : 0x7fffffff;
+    int g_ep = 0, t_ep0 = 0, g_end = cpe;      // episode `g` belongs to, its first global step, its end (chunk index)
+    auto enter_episode = [&](int c) {           // (uniform) called before chunk c is stored; c advances by one
+      if (MULTI && c >= g_end) {
+        g_ep += 1; g_end += cpe; t_ep0 += a.Tep;
         if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, g_ep), g);
       }
     };
     // ... and after chunk j has been stored, its row-image buffer is next written for chunk j + 2: if that one belongs to a later
-    // episode the constant goal part of the buffer's rows is rewritten (this storer: its own steps of the buffer, env column `lane`)
+    // episode (an episode boundary b with j < b <= j + 2; g_end is the first boundary > j after enter_episode(j)) the constant goal part
+    // of the buffer's rows is rewritten (this storer: its own steps of the buffer, env column `lane`)
     auto refill_goal = [&](int j) {
-      if (a.episodes > 1 && j + 2 < nch && (j + 2) / cpe != j / cpe) {
+      if (MULTI && g_end <= j + 2 && j + 2 < nch) {
         float gn[6] = {0, 0, 0, 0, 0, 0};
-        if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, (j + 2) / cpe), gn);
+        if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, g_ep + 1), gn);
         for (int k = s; k < K; k += NS) {
           float4* row = &R[j & 1][k][lane * 3];
           row[1] = float4{-1.0f, -1.0f, gn[0], gn[1]};    // (the flag words are rewritten by the compute wave every step)

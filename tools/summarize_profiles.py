@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
 PROF = os.path.join(ROOT, 'profiles')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
-n, T, E = 4096, 200, 8          # bench.py defaults: 8 evaluation episodes per launch
+n, T, E = 4096, 200, 25         # bench.py defaults: 25 evaluation episodes per launch
 SUF = f'_E{E}' if E > 1 else ''
 os.makedirs(PROF, exist_ok=True)
 
@@ -41,7 +41,7 @@ fetch, write = pmc[rk]['FETCH_SIZE']['mean_KiB'], pmc[rk]['WRITE_SIZE']['mean_Ki
 hbm = (2 * fetch + write) * 1024
 algo = n * (E * T * 66 + 2 * (32 + 1 + 4) + 4)
 summary = {
-    'command': 'python3 bench.py --steps 104 --warmup 8 --no-cpu --no-step-api --no-sawyer --no-single  (under rocprofv3, see tools/profile_bench.sh)',
+    'command': 'python3 bench.py --steps 200 --warmup 25 --no-cpu --no-step-api --no-sawyer --no-single  (under rocprofv3, see tools/profile_bench.sh)',
     'kernel': rk,
     'kernel_trace_stats': {'calls': int(kern['Calls']), 'average_ns': float(kern['AverageNs']), 'min_ns': float(kern['MinNs']),
                            'max_ns': float(kern['MaxNs']), 'stddev_ns': float(kern['StdDev'])},
