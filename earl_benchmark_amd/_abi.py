@@ -96,10 +96,12 @@ SIGNATURES = {
     'earl_kitchen_default_params': [_P(KitchenParams)],
     'earl_kitchen_action': [C.c_int32, _P(KitchenParams)] + [C.c_void_p] * 5,
     'earl_kitchen_obs': [C.c_int32, _P(KitchenParams)] + [C.c_void_p] * 5,
+    'earl_philox_uniform': [C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_uint32, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     # include/earl_physics.h
     'earl_physics_step': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7,
     'earl_physics_forward': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9,
     'earl_physics_model_size': [],
+    'earl_physics_model24_size': [],
     'earl_collision_model_size': [],
     'earl_sawyer_cfg_size': [],
     'earl_debug_set_physics_lanes': [C.c_int],

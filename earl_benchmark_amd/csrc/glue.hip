@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "../../include/earl_glue.h"
+#include "philox.h"
 
 namespace {
 constexpr int kB = 256;
@@ -172,6 +173,19 @@ int done(const char* what) {
   return EARL_OK;
 }
 inline unsigned blocks(long long n) { return (unsigned)((n + kB - 1) / kB); }
+// U(lo, hi) draws keyed by (seed; stream, global env id, counter): k draws per env, numpy's low + (high - low) * u
+__global__ void uniform_kernel(int n, int k, uint64_t seed, uint64_t counter, int env_offset, uint32_t stream, double lo, double hi, double* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one Philox block = two draws
+  const int pairs = (k + 1) / 2;
+  if (idx >= (long long)n * pairs) return;
+  const int env = (int)(idx / pairs), j = (int)(idx % pairs);
+  const earl::U4 b = earl::philox4x32_10(earl::U4{stream + (uint32_t)j, (uint32_t)(env_offset + env), (uint32_t)counter, (uint32_t)(counter >> 32)},
+                                         (uint32_t)seed, (uint32_t)(seed >> 32));
+  double* o = out + (size_t)env * k + 2 * j;
+  o[0] = lo + (hi - lo) * earl::u01(b.x, b.y);
+  if (2 * j + 1 < k) o[1] = lo + (hi - lo) * earl::u01(b.z, b.w);
+}
+
 }  // namespace
 
 extern "C" {
@@ -241,6 +255,13 @@ int earl_kitchen_obs(int32_t n, const earl_kitchen_params* p, const double* qpos
   if (n == 0) return EARL_OK;
   kitchen_obs_kernel<<<blocks((long long)n * 46), kB, 0, (hipStream_t)s>>>(n, *p, qpos, goal, noise, obs);
   return done("kitchen_obs");
+}
+int earl_philox_uniform(int32_t n, int32_t k, uint64_t seed, uint64_t counter, int32_t env_offset, uint32_t stream_id, double lo, double hi,
+                        double* out, earl_stream_t s) {
+  if (n < 0 || k < 0 || !out) return EARL_ERR_ARG;
+  if (n == 0 || k == 0) return EARL_OK;
+  uniform_kernel<<<blocks((long long)n * ((k + 1) / 2)), kB, 0, (hipStream_t)s>>>(n, k, seed, counter, env_offset, stream_id, lo, hi, out);
+  return done("philox_uniform");
 }
 int earl_kitchen_reward(int32_t n, const double* obs, const double* mocap_pos, const double* site_xpos, double* reward,
                         uint8_t* success, earl_stream_t s) {

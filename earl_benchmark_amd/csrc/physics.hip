@@ -174,26 +174,34 @@ struct SymLds {
   __device__ __forceinline__ double& rowl(const int l, const int ltri, const int j) { return v[PACKED ? ltri + j : l * NV + j]; }        // (l, j), j <= l
 };
 
+// model table type by size: nv <= 16 the compact form, nv = 23 (kitchen) the 24-dof form with the extra joint tables
+template <int NV> struct ModelOf { using T = earl_link_model; };
+template <> struct ModelOf<23> { using T = earl_link_model24; };
+
 // Static bounds by model size: the door model (nv 10) keeps 8 contact slots and 16 collision blocks, which keeps its workgroup
 // under 40 KB of LDS (four workgroups per CU, one wave per SIMD); the peg model (nv 15) needs 12 / 32.
 template <int NV> struct Lim {
   static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
-  static constexpr int MB = NV <= 10 ? 16 : 28;             // collision blocks (<= EARL_MAXBLK; the peg model has 25)
+  static constexpr int MB = NV <= 10 ? 16 : 28;             // collision blocks (<= EARL_MAXBLK; the peg model has 25, the kitchen 26)
 #ifndef EARL_DOOR_WPB
 #define EARL_DOOR_WPB 1
 #endif
   static constexpr int WPB = NV <= 10 ? EARL_DOOR_WPB : 4;  // wavefronts per workgroup.  nv 10: 33 KB per single-wave workgroup, four per CU.  nv 15: an
                                                             // env block is 9.5 KB; a four-wave workgroup (16 envs + the tables once = 163,672 B of the CU's
-                                                            // 163,840) puts one wave on every SIMD where single-wave workgroups would fit two or three
+                                                            // 163,840) puts one wave on every SIMD where single-wave workgroups would fit two or three.
+                                                            // nv 23: 32 lanes per env, two envs per wave, four waves = 8 envs per workgroup (one per CU)
 #ifndef EARL_DOOR_COOP
 #define EARL_DOOR_COOP 0
 #endif
-  static constexpr bool COOP = NV <= 10 && EARL_DOOR_COOP;  // small model: every factorisation shared in LDS instead of per lane in registers (experiment)
+  static constexpr bool COOP = (NV <= 10 && EARL_DOOR_COOP) || NV > 16;  // every factorisation shared in LDS instead of per lane in registers: an experiment for
+                                                            // the small model, the only possibility for nv = 23 (a register-resident factor would need 552 VGPRs)
   static constexpr bool CAPS = NV <= 10;                    // edge-vs-capsule blocks compiled in (the door model's handle rods; the peg model has none, and
                                                             // its kernel has no registers to spare: the host side refuses such tables for it)
-  static constexpr int NA = NV <= 10 ? NV : 9;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
+  static constexpr int NA = NV == 15 ? 9 : NV;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
                                                             // and free peg are separate trees (checked by the host side); the door model
                                                             // (9 + 1) is factorised densely -- the split did not pay there
+  static constexpr bool EXTRAS = NV > 16;                   // dry joint friction, joint springs, force-limited actuators, joint couplings (earl_link_model24)
+  static constexpr int LPE = NV > 16 ? 32 : 16;             // lanes per env instance (64 = one wavefront per env: measurement switch for nv <= 16)
 };
 
 // Per-env LDS block.  The three phase groups of the union are live at disjoint times.
@@ -367,7 +375,7 @@ __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collisi
 // One timestep of one env by its LPE-lane group (`sub` = lane within the group; every lane of the wave runs this, the
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
 template <int NV, int LPE, bool INTEGRATE>
-__device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m, const BlkTable<Lim<NV>::MB>& bt, const earl_collision_model* __restrict__ col, const int sub,
+__device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV>::T& m, const BlkTable<Lim<NV>::MB>& bt, const earl_collision_model* __restrict__ col, const int sub,
                                         const int grp, const V3 mpos, const Q4 mq, const double (&ctrl)[EARL_MAXACT], double* qacc_out,
                                         double* efc_out) {
   static_assert(NV <= LPE, "one lane per link");
@@ -459,7 +467,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       nearg |= (unsigned int)bal; nearw |= (unsigned int)bal;
     } else {
       nearg |= (unsigned int)((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull)) << cb;
-      nearw |= (unsigned int)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull) << cb;
+      if constexpr (LPE == 32) nearw |= (unsigned int)((bal | (bal >> 32)) & 0xFFFFFFFFull) << cb;
+      else nearw |= (unsigned int)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull) << cb;
     }
   }
   // prefetch this lane's pair record of the first near block: its latency hides behind K3-K7
@@ -605,10 +614,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     }
     // ---------------------------------------------------------------- K7: applied + passive - bias
     double t = -m.damping[l] * qdl - (dot(Sw, ns) + dot(Sv, fs));
+    if constexpr (Lim<NV>::EXTRAS) t -= m.stiffness[l] * (s.qp[l] - m.springref[l]);     // joint spring (mj_passive)
     for (int ac = 0; ac < m.n_act; ++ac)
       if (m.act_joint[ac] == l) {
         const double c = fmin(fmax(ctrl[ac], m.act_ctrlrange[ac][0]), m.act_ctrlrange[ac][1]);
-        t += m.act_kp[ac] * (c - s.qp[l]);
+        double frc = m.act_kp[ac] * (c - s.qp[l]);
+        if constexpr (Lim<NV>::EXTRAS) frc = fmin(fmax(frc, m.act_forcerange[ac][0]), m.act_forcerange[ac][1]);   // forcelimited actuator
+        t += frc;
       }
     tau_l = t;
   }
@@ -781,6 +793,17 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     lim_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
     lim_aref = -bb * (lim_side * s.qv[l]) - kk * dd * res;
   }
+  // dry friction of this lane's dof (mjCNSTR_FRICTION_DOF): residual 0, cost 1/2 D x^2 for |x| <= loss / D, linear beyond (x = a_l - aref);
+  // state 0 = quadratic zone (adds D to the diagonal), +-1 = saturated (constant force -+loss)
+  double fr_D = 0, fr_aref = 0, fr_loss = 0;
+  int fr_state = 0;
+  if constexpr (Lim<NV>::EXTRAS) {
+    fr_loss = isl ? m.frictionloss[l] : 0.0;
+    double kk, bb, dd;
+    kbimp(m.jsolref[l], m.jsolimp[l], 0.0, dt, kk, bb, dd);
+    fr_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
+    fr_aref = -bb * s.qv[l];
+  }
   PSTAMP(7);
   // ------------------------------------------------------------------ C3: contact rows (reference: LinkModel.contact_rows)
   double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};       // lane c (< nct) owns contact c: edge weights and reference accelerations
@@ -852,6 +875,21 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
       hw[i] = h;
     }
     g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
+    if constexpr (Lim<NV>::EXTRAS) {
+      // joint couplings q[j1] - c0 - c1 q[j2] = 0: soft equality rows with two non-zeros (1 at j1, -c1 at j2)
+      for (int e = 0; e < m.n_jeq; ++e) {
+        const int j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
+        const double c0 = m.jeq_coef[e][0], c1 = m.jeq_coef[e][1];
+        const double res = s.qp[j1] - c0 - c1 * s.qp[j2], Jv = s.qv[j1] - c1 * s.qv[j2];
+        double kk, bb, dd;
+        kbimp(m.jeq_solref[e], m.jeq_solimp[e], res, dt, kk, bb, dd);
+        const double D = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
+        const double Jl = l == j1 ? 1.0 : (l == j2 ? -c1 : 0.0), DJl = D * Jl;
+        g = fma(DJl, -bb * Jv - kk * dd * res, g);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) hw[i] += (i == j1 ? DJl : 0.0) + (i == j2 ? -c1 * DJl : 0.0);
+      }
+    }
     rw = g;
   }
   PSTAMP(9);
@@ -863,8 +901,15 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
   for (int it = 0; it < 8; ++it) {
     PCOUNT(25, 1);
     if (isl) {
-      s.con.dl[l] = act ? lim_D : 0.0;
-      s.con.rl[l] = act ? lim_D * lim_aref * lim_side : 0.0;
+      double dlv = act ? lim_D : 0.0, rlv = act ? lim_D * lim_aref * lim_side : 0.0;
+      if constexpr (Lim<NV>::EXTRAS) {
+        if (fr_loss > 0) {
+          dlv += fr_state == 0 ? fr_D : 0.0;
+          rlv += fr_state == 0 ? fr_D * fr_aref : -(double)fr_state * fr_loss;
+        }
+      }
+      s.con.dl[l] = dlv;
+      s.con.rl[l] = rlv;
     }
     if (ncmax > 0 && sub < MC) {
       // edges (n + mu t1, n - mu t1, n + mu t2, n - mu t2): sum_e D a_e u_e u_e' on (Jn, Jt1, Jt2) and sum_e D a_e aref_e u_e
@@ -919,6 +964,14 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
     const bool want = lim_inst && (lim_side * al - lim_aref < 0);
     bool changed = want != act;
     act = want;
+    if constexpr (Lim<NV>::EXTRAS) {
+      if (fr_loss > 0) {
+        const double x = al - fr_aref;
+        const int ns = fabs(x) * fr_D <= fr_loss ? 0 : (x > 0 ? 1 : -1);
+        changed = changed || ns != fr_state;
+        fr_state = ns;
+      }
+    }
     if (ncmax > 0) {
       const int c = sub < MC ? sub : MC - 1;
       double an = 0, at1 = 0, at2 = 0;
@@ -1012,7 +1065,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const earl_link_model& m,
 
 // world position of attachment k from the kinematics currently in LDS
 template <int NV>
-__device__ __forceinline__ V3 attachment(const Shared<NV>& s, const earl_link_model& m, const int k) {
+__device__ __forceinline__ V3 attachment(const Shared<NV>& s, const typename ModelOf<NV>::T& m, const int k) {
   const int la = m.att_link[k];
   V3 p = ld3(m.att_pos[k]);
   if (la >= 0) {
@@ -1024,18 +1077,19 @@ __device__ __forceinline__ V3 attachment(const Shared<NV>& s, const earl_link_mo
 }
 
 // the model tables, once per workgroup, into LDS (all 64 lanes copy)
-__device__ __forceinline__ void stage_model(earl_link_model& dst, const earl_link_model* __restrict__ src) {
-  static_assert(sizeof(earl_link_model) % 8 == 0, "copied as 8-byte words");
+template <typename MT>
+__device__ __forceinline__ void stage_model(MT& dst, const void* __restrict__ src) {
+  static_assert(sizeof(MT) % 8 == 0, "copied as 8-byte words");
   const unsigned long long* g = reinterpret_cast<const unsigned long long*>(src);
   unsigned long long* d = reinterpret_cast<unsigned long long*>(&dst);
-  for (int i = threadIdx.x; i < (int)(sizeof(earl_link_model) / 8); i += blockDim.x) d[i] = g[i];
+  for (int i = threadIdx.x; i < (int)(sizeof(MT) / 8); i += blockDim.x) d[i] = g[i];
   __syncthreads();                                     // the only workgroup barrier: afterwards every wave works on its own LDS blocks
 }
 
 // state rows <-> LDS.  qpos rows are [nq]: one entry per dof, except that the free body's orientation quaternion sits at
 // [ball_dof, ball_dof + 4) (normalised on load, as mj_kinematics does)
 template <int NV>
-__device__ __forceinline__ void load_state(Shared<NV>& s, const earl_link_model& m, const double* __restrict__ qrow, const double* __restrict__ vrow, const int sub) {
+__device__ __forceinline__ void load_state(Shared<NV>& s, const typename ModelOf<NV>::T& m, const double* __restrict__ qrow, const double* __restrict__ vrow, const int sub) {
   const int bd = m.ball_dof;
   if (sub < NV) {
     s.qp[sub] = (bd < 0 || sub < bd) ? qrow[sub] : 0.0;
@@ -1051,7 +1105,7 @@ __device__ __forceinline__ void load_state(Shared<NV>& s, const earl_link_model&
   }
 }
 template <int NV>
-__device__ __forceinline__ void store_state(const Shared<NV>& s, const earl_link_model& m, double* __restrict__ qrow, double* __restrict__ vrow, const int sub) {
+__device__ __forceinline__ void store_state(const Shared<NV>& s, const typename ModelOf<NV>::T& m, double* __restrict__ qrow, double* __restrict__ vrow, const int sub) {
   const int bd = m.ball_dof;
   if (sub < NV) {
     if (bd < 0 || sub < bd) qrow[sub] = s.qp[sub];
@@ -1061,7 +1115,7 @@ __device__ __forceinline__ void store_state(const Shared<NV>& s, const earl_link
 }
 
 struct PArgs {
-  const earl_link_model* m;
+  const void* m;                 // earl_link_model (nv <= 16) or earl_link_model24
   const earl_collision_model* col;
   int n, nsub;
   double* qpos; double* qvel;
@@ -1072,7 +1126,7 @@ struct PArgs {
 template <int NV, int LPE, bool INTEGRATE>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs a) {
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ earl_link_model m;
+  __shared__ typename ModelOf<NV>::T m;
   __shared__ BlkTable<Lim<NV>::MB> bt;
   __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
@@ -1105,7 +1159,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
 
 // ------------------------------------------------------------------------------------------------ Sawyer env kernels
 struct SawyerArgs {
-  const earl_link_model* m;
+  const void* m;
   const earl_collision_model* col;
   earl_sawyer_cfg cfg;
   earl_sawyer_state st;
@@ -1209,7 +1263,7 @@ __device__ __forceinline__ bool group_any(const bool pred, const int grp) {
 
 // obs[14] + reward + flags of one env from the kinematics in LDS (sawyer_door.py:86-94, :141-177); the whole group calls it
 template <int NV>
-__device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const earl_link_model& m, const earl_sawyer_cfg& cfg, const int sub, const bool live,
+__device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const typename ModelOf<NV>::T& m, const earl_sawyer_cfg& cfg, const int sub, const bool live,
                                             const double* __restrict__ goal, double* __restrict__ obs, float* reward, uint8_t* success,
                                             const double* __restrict__ obj_init = nullptr, const double effort = 0.0, double* __restrict__ obs2 = nullptr) {
 #pragma clang fp contract(off)
@@ -1255,7 +1309,7 @@ template <int NV, int LPE>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_rollout_kernel(const SawyerArgs a) {
   static_assert(LPE >= 14, "the observation is written by 14 lanes");
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ earl_link_model m;
+  __shared__ typename ModelOf<NV>::T m;
   __shared__ BlkTable<Lim<NV>::MB> bt;
   __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
@@ -1342,7 +1396,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
 template <int NV, int LPE>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const SawyerArgs a) {
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ earl_link_model m;
+  __shared__ typename ModelOf<NV>::T m;
   __shared__ BlkTable<Lim<NV>::MB> bt;
   __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
@@ -1467,7 +1521,8 @@ template <int NV> constexpr int block_for() { return 64 * Lim<NV>::WPB; }
 
 template <int NV, bool INTEGRATE>
 void launch_physics(const PArgs& a, hipStream_t st) {
-  if (g_lpe == 64) physics_kernel<NV, 64, INTEGRATE><<<grid_for<NV, 64>(a.n), block_for<NV>(), 0, st>>>(a);
+  if constexpr (NV > 16) physics_kernel<NV, 32, INTEGRATE><<<grid_for<NV, 32>(a.n), block_for<NV>(), 0, st>>>(a);   // 32 lanes per env: two envs per wave
+  else if (g_lpe == 64) physics_kernel<NV, 64, INTEGRATE><<<grid_for<NV, 64>(a.n), block_for<NV>(), 0, st>>>(a);
   else physics_kernel<NV, 16, INTEGRATE><<<grid_for<NV, 16>(a.n), block_for<NV>(), 0, st>>>(a);
 }
 
@@ -1475,7 +1530,7 @@ void launch_physics(const PArgs& a, hipStream_t st) {
 
 extern "C" {
 
-int earl_physics_step(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
+int earl_physics_step(const void* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
                       earl_stream_t stream) {
   if (!model || n < 0 || nsub < 0 || !qpos || !qvel || !mocap_pos || !mocap_quat || !ctrl) return EARL_ERR_ARG;
@@ -1483,11 +1538,12 @@ int earl_physics_step(const earl_link_model* model, const earl_collision_model* 
   PArgs a{model, col, n, nsub, qpos, qvel, mocap_pos, mocap_quat, ctrl, att_xpos, nullptr, nullptr};
   if (nv == 10) launch_physics<10, true>(a, (hipStream_t)stream);
   else if (nv == 15) launch_physics<15, true>(a, (hipStream_t)stream);
+  else if (nv == 23) launch_physics<23, true>(a, (hipStream_t)stream);
   else return EARL_ERR_ARG;
   return launched("physics_step");
 }
 
-int earl_physics_forward(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, const double* qpos, const double* qvel,
+int earl_physics_forward(const void* model, const earl_collision_model* col, int32_t nv, int32_t n, const double* qpos, const double* qvel,
                          const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc,
                          double* efc_force, double* att_xpos, earl_stream_t stream) {
   if (!model || n < 0 || !qpos || !qvel || !mocap_pos || !mocap_quat || !ctrl || !qacc) return EARL_ERR_ARG;
@@ -1495,6 +1551,7 @@ int earl_physics_forward(const earl_link_model* model, const earl_collision_mode
   PArgs a{model, col, n, 1, const_cast<double*>(qpos), const_cast<double*>(qvel), mocap_pos, mocap_quat, ctrl, att_xpos, qacc, efc_force};
   if (nv == 10) launch_physics<10, false>(a, (hipStream_t)stream);
   else if (nv == 15) launch_physics<15, false>(a, (hipStream_t)stream);
+  else if (nv == 23) launch_physics<23, false>(a, (hipStream_t)stream);
   else return EARL_ERR_ARG;
   return launched("physics_forward");
 }
@@ -1572,6 +1629,7 @@ int earl_debug_read_phys_profile(unsigned long long* out, int reset) {
 #endif
 
 int earl_physics_model_size(void) { return (int)sizeof(earl_link_model); }
+int earl_physics_model24_size(void) { return (int)sizeof(earl_link_model24); }
 int earl_collision_model_size(void) { return (int)sizeof(earl_collision_model); }
 int earl_sawyer_cfg_size(void) { return (int)sizeof(earl_sawyer_cfg); }
 

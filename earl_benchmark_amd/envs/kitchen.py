@@ -1,0 +1,273 @@
+"""Batched, GPU-resident counterpart of the reference's kitchen env (BASELINE configs[3]).
+
+Mirrors `Kitchen(KitchenTaskRelaxV1)` (reference: earl_benchmark/envs/kitchen.py:86-187 on top of
+envs/kitchen_assets/adept_envs/adept_envs/franka/kitchen_multitask_v0.py:91-139 and .../franka/robot/franka_robot.py:137-264): `reset`, `step`,
+`reset_goal`, `get_next_goal`, `compute_reward`, `is_successful`, `_get_obs`, observation layout (robot qpos 9, fixture qpos 14, goal 23; with
+the reference's uniform sensor noise), dense reward only -- for `num_envs` independent instances.
+
+One env step = four launches on the caller's stream:
+  earl_kitchen_action  (csrc/glue.hip)    action clip / scale, mocap target, the nine position targets (row a17; bit-exact vs the reference's numpy)
+  earl_physics_step    (csrc/physics.hip) 40 timesteps of the nv = 23 model: 32 lanes per env, in-LDS factorisations                  (row a16)
+  earl_kitchen_obs     (csrc/glue.hip)    observation with sensor noise from Philox draws                                              (row a18)
+  earl_kitchen_reward  (csrc/glue.hip)    Kitchen._get_reward_n_score / is_successful                                                  (row a19)
+
+STATUS of the dynamics: this build's own articulated-body stepper on tables compiled from the reference's MJCF (tools/mjcf_compile.py kitchen):
+Franka arm (link inertias from the collision hulls and the given masses), 14 single-dof fixtures, the mocap weld on panda0_link7, joint limits,
+the five knob / burner and switch / light couplings, dry friction and springs on the fixture joints, force-limited finger actuators, and a
+DECLARED, reduced collision set (each finger one box; handles as sphere chains; door panels against the finger corners -- counters, walls, floor
+and the arm links' hulls are not collided).  **PARITY WITH MUJOCO IS UNPINNED**: the reference ships no recording of this env and MuJoCo cannot
+run here.  What is pinned: the numpy glue around the simulator (bit-exact on goldens recorded from the reference's own methods),
+the model tables' provenance, and the kernel against this build's CPU statement (oracle/physics_oracle.LinkModel).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _abi, glue, physics, tables
+from ..spaces import Box
+
+INT32_MAX = 2**31 - 1
+FRAME_SKIP = 40                                           # kitchen_multitask_v0.py:40
+MIDPOINT_POS = (-0.440, 0.1, 2.226)                       # :46
+# kitchen_multitask_v0.py:68-73 (overrides the keyframe)
+INIT_QPOS = np.array([1.48388023e-01, -1.76848573e+00, 1.84390296e+00, -2.47685760e+00, 2.60252026e-01, 7.12533105e-01, 1.59515394e+00,
+                      4.79267505e-02, 3.71350919e-02, -2.66279850e-04, -5.18043486e-05, 3.12877220e-05, -4.51199853e-05, -3.90842156e-06,
+                      -4.22629655e-05, 6.28065475e-05, 4.04984708e-05, 4.62730939e-04, -2.26906415e-04, -4.65501369e-04, -6.44129196e-03,
+                      -1.77048263e-03, 1.08009684e-03])
+STREAM_NOISE, STREAM_RESET = 0x4B00, 0x4B80               # Philox stream ids (csrc/glue.hip earl_philox_uniform)
+
+
+class _Cfg:
+  """the two wrapper-controlled numbers (wrappers.py sets them the way it does for the other envs)"""
+  horizon = INT32_MAX
+  goal_change_frequency = 0
+
+
+class Kitchen:
+  OBS_DIM, NV, N_ROBOT, N_OBJ = 46, 23, 9, 14
+
+  def __init__(self, task='all_pairs', reward_type='dense', num_envs=1, device='cuda', seed=0, env_offset=0, scalar_api=None,
+               sensor_noise=True, contacts=True, reset_at_goal=False, auto_reset=False):
+    if reward_type != 'dense':
+      raise ValueError('Kitchen environment only supports dense rewards.')      # kitchen.py:91-92
+    if auto_reset or reset_at_goal:
+      raise NotImplementedError('kitchen: auto_reset / reset_at_goal do not exist in the reference env')
+    self._lib = _abi.load()
+    dev = torch.device(device)
+    if dev.type != 'cuda' or not torch.cuda.is_available():
+      raise _abi.EarlHipError(f'device={device!r}: the kitchen env runs on MI355X only (no CPU fallback)')
+    if dev.index is None:
+      dev = torch.device('cuda', torch.cuda.current_device())
+    self.device, self.num_envs, self._task = dev, int(num_envs), task
+    n = self.num_envs
+    self.scalar_api = (n == 1) if scalar_api is None else bool(scalar_api)
+    if self.scalar_api and n != 1:
+      raise ValueError('scalar_api needs num_envs == 1')
+    self._seed, self._env_offset, self._counter = int(seed) & (2**64 - 1), int(env_offset), 0
+    self.sensor_noise = bool(sensor_noise)
+    self._cfg = _Cfg()
+    self._params = glue.kitchen_params()
+    self._initial_states = tables.initial_states('kitchen')                     # kitchen.py:57-85, the 6 'all_pairs' rows
+    self._goal_states = tables.goal_states('kitchen')
+    with torch.cuda.device(dev):
+      self.model = physics.DeviceModel('kitchen', device=dev, contacts=contacts)
+    assert self.model.nv == self.NV
+    names = self.model.att_names
+    self._site_idx = torch.tensor([names.index(s) for s in glue.KITCHEN_SITES], device=dev)
+    kw = dict(dtype=torch.float64, device=dev)
+    self.qpos, self.qvel = torch.zeros(n, self.NV, **kw), torch.zeros(n, self.NV, **kw)
+    self.mocap_pos = torch.tensor(MIDPOINT_POS, **kw).repeat(n, 1).contiguous()
+    self.mocap_quat = torch.tensor(self.model.tables['weld_mocap_quat'], **kw).repeat(n, 1).contiguous()   # the mocap body's orientation never changes
+    self.goal_t = torch.tensor(self._goal_states[0], **kw).repeat(n, 1).contiguous()
+    self.last_qp_robot = torch.zeros(n, self.N_ROBOT, **kw)                     # qpos_robot of the newest cached (noisy) observation
+    self.att = torch.zeros(n, self.model.n_att, 3, **kw)
+    self.steps_since_reset = torch.zeros(n, dtype=torch.int32, device=dev)
+    self.interventions = torch.zeros(n, dtype=torch.int32, device=dev)
+    self.fail_count = torch.zeros(n, dtype=torch.int32, device=dev)
+    self.lifelong_return_t = torch.zeros(n, **kw)
+    self.steps_since_goal_change = torch.zeros(n, dtype=torch.int32, device=dev)
+    self.total_step_count = 0
+    self.last_obs = torch.zeros(n, self.OBS_DIM, **kw)
+    self.action_space = Box(-1.0, 1.0, (self.N_ROBOT,), np.float32)              # kitchen_multitask_v0.py:78-80
+    self.observation_space = Box(-8.0, 8.0, (self.OBS_DIM,), np.float64)         # :82-84
+    with torch.cuda.device(dev):
+      self._reset_states = self._settle_reset_states()
+      self.reset()
+    self.interventions.zero_()
+
+  # ------------------------------------------------------------------ internals
+  @property
+  def unwrapped(self):
+    return self
+
+  def _stream(self):
+    return torch.cuda.current_stream(self.device).cuda_stream
+
+  def _uniform(self, k, stream_id, lo, hi, n=None):
+    n = self.num_envs if n is None else n
+    out = torch.empty(n, k, dtype=torch.float64, device=self.device)
+    with torch.cuda.device(self.device):
+      _abi.check(self._lib.earl_philox_uniform(n, k, self._seed, self._counter, self._env_offset, stream_id, lo, hi, out.data_ptr(), self._stream()),
+                 'earl_philox_uniform')
+    return out
+
+  def _settle_reset_states(self):
+    """Kitchen.reset_model (kitchen.py:118-139) for each of the initial-state rows: robot.reset (qpos <- init_qpos with the row's fixture
+    positions, clipped to the position bounds; qvel <- 0), mocap <- midpoint, then ten robot steps of zero action = 400 timesteps.  Those
+    steps are deterministic: their position targets are the cached robot joints 0 and 1 clamped to the finger actuators' ctrlrange [0, 0.04]
+    (the nu = 2 quirk), i.e. 0.04 and 0 whatever the sensor noise -- so the result is computed once per row and cached."""
+    rows = self._initial_states if self._task == 'all_pairs' else self._initial_states[:1]
+    kw = dict(dtype=torch.float64, device=self.device)
+    pb = np.ctypeslib.as_array(self._params.pos_bound)
+    q = np.tile(INIT_QPOS, (len(rows), 1))
+    q[:, 9:] = rows[:, 9:]
+    q = np.clip(q, pb[:, 0], pb[:, 1])                                           # Robot.reset -> clip_positions (franka_robot.py:212, :170-174)
+    q, v = torch.tensor(q, **kw).contiguous(), torch.zeros(len(rows), self.NV, **kw)
+    mp = torch.tensor(MIDPOINT_POS, **kw).repeat(len(rows), 1).contiguous()
+    mq = self.mocap_quat[:1].repeat(len(rows), 1).contiguous()
+    ctrl = torch.tensor([[0.04, 0.0]], **kw).repeat(len(rows), 1).contiguous()
+    self.model.step(q, v, mp, mq, ctrl, nsub=10 * FRAME_SKIP)
+    return q, v
+
+  def _observe(self, noise):
+    u = self._uniform(46, STREAM_NOISE, -1.0, 1.0) if (noise and self.sensor_noise) else None
+    obs = glue.kitchen_obs(self.qpos, self.goal_t, u, self._params)
+    self.last_qp_robot.copy_(obs[:, :self.N_ROBOT])
+    return obs
+
+  def _reward(self, obs):
+    sites = self.att.index_select(1, self._site_idx).contiguous()
+    return glue.kitchen_reward(obs, self.mocap_pos, sites)
+
+  # ------------------------------------------------------------------ gym-style API
+  def reset(self, mask=None):
+    """reset (masked) envs -> obs [N, 46] (numpy [46] with scalar_api)"""
+    n = self.num_envs
+    with torch.cuda.device(self.device):
+      rows = self._reset_states[0].shape[0]
+      pick = (self._uniform(1, STREAM_RESET, 0.0, 1.0)[:, 0] * rows).long().clamp_(max=rows - 1)      # np.random.randint(rows), kitchen.py:123
+      m = torch.ones(n, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
+      self.qpos[m] = self._reset_states[0][pick][m]
+      self.qvel[m] = self._reset_states[1][pick][m]
+      self.mocap_pos[m] = torch.tensor(MIDPOINT_POS, dtype=torch.float64, device=self.device)
+      self.goal_t[m] = torch.tensor(self.get_next_goal(), dtype=torch.float64, device=self.device)   # reset_goal(), kitchen.py:138
+      self.steps_since_reset[m] = 0
+      self.steps_since_goal_change[m] = 0
+      self.interventions += m.to(torch.int32)
+      # set_state -> sim.forward(): site positions of the reset state (nothing integrated)
+      self.att.copy_(self.model.forward(self.qpos, self.qvel, self.mocap_pos, self.mocap_quat, torch.zeros(n, 2, dtype=torch.float64, device=self.device))[2])
+      prev = self.last_obs.clone()
+      obs = self._observe(noise=True)
+      obs = torch.where(m[:, None], obs, prev)
+      self.last_obs.copy_(obs)
+    self._counter += 1
+    return obs[0].cpu().numpy() if self.scalar_api else obs
+
+  def step(self, action, b=None):
+    del b
+    n = self.num_envs
+    with torch.cuda.device(self.device):
+      a = torch.as_tensor(np.asarray(action, dtype=np.float32) if not torch.is_tensor(action) else action, device=self.device)
+      a = a.to(torch.float32).reshape(n, self.N_ROBOT).to(torch.float64)         # np.clip keeps float32, the scaling promotes (glue.hip)
+      ctrl9 = glue.kitchen_action(a, self.mocap_pos, self.last_qp_robot, self._params)
+      ctrl = ctrl9[:, :2].contiguous()                                           # MujocoEnv.do_simulation: ctrl[i] for i < nu = 2 (mujoco_env.py:148-157)
+      q0, v0 = self.qpos.clone(), self.qvel.clone()
+      self.model.step(self.qpos, self.qvel, self.mocap_pos, self.mocap_quat, ctrl, nsub=FRAME_SKIP, att_xpos=self.att)
+      # failure guard (adept's _mj_warning_fn only prints; here a diverged env is rolled back and flagged, like the Sawyer kernels do)
+      bad = ~(torch.isfinite(self.qpos).all(1) & torch.isfinite(self.qvel).all(1) & (self.qvel.abs() < 1e10).all(1) & (self.qpos.abs() < 1e10).all(1))
+      self.qpos[bad], self.qvel[bad] = q0[bad], v0[bad]
+      self.fail_count += bad.to(torch.int32)
+      obs = self._observe(noise=True)
+      rew, suc = self._reward(obs)
+      obs = torch.where(bad[:, None], self.last_obs, obs)
+      rew = torch.where(bad, torch.zeros_like(rew), rew)
+      suc = suc & ~bad
+      self.last_obs.copy_(obs)
+      self.steps_since_reset += 1
+      done = self.steps_since_reset >= self._cfg.horizon
+      gcf = int(self._cfg.goal_change_frequency)
+      if gcf > 0:                                                                # LifelongWrapper.step (lifelong_wrapper.py:30-44)
+        self.lifelong_return_t += rew
+        self.steps_since_goal_change += 1
+        sw = self.steps_since_goal_change >= gcf
+        self.steps_since_goal_change[sw] = 0
+        self.goal_t[sw] = torch.tensor(self.get_next_goal(), dtype=torch.float64, device=self.device)
+        obs = torch.cat([obs[:, :23], torch.where(sw[:, None], self.goal_t, obs[:, 23:])], 1)
+    self._counter += 1
+    self.total_step_count += 1
+    self._last_success = suc
+    if self.scalar_api:
+      return obs[0].cpu().numpy(), float(rew[0]), bool(done[0]), {}
+    return obs, rew, done, {'success': suc, 'status': bad.to(torch.uint8)}
+
+  def rollout(self, actions, out=None):
+    """T steps: actions [T, N, 9] -> dict(obs [T,N,46], reward [T,N], done, success, status)"""
+    a = torch.as_tensor(actions, device=self.device)
+    T = a.shape[0]
+    res = out if out is not None else {}
+    rows = [self.step(a[t]) for t in range(T)]
+    res['obs'] = torch.stack([r[0] for r in rows]); res['reward'] = torch.stack([r[1] for r in rows]); res['done'] = torch.stack([r[2] for r in rows])
+    res['success'] = torch.stack([r[3]['success'] for r in rows]); res['status'] = torch.stack([r[3]['status'] for r in rows])
+    return res
+
+  def _get_obs(self):
+    with torch.cuda.device(self.device):
+      obs = self._observe(noise=True)
+    self._counter += 1
+    return obs[0].cpu().numpy() if self.scalar_api else obs
+
+  get_obs = _get_obs
+
+  def compute_reward(self, obs):
+    """Kitchen.compute_reward (kitchen.py:177-178): like the reference's, it reads the simulator's CURRENT mocap and site positions"""
+    o = torch.as_tensor(obs, dtype=torch.float64, device=self.device).reshape(-1, self.OBS_DIM)
+    if o.shape[0] != self.num_envs:
+      raise ValueError('compute_reward(obs): one observation per env (the reward also reads each env\'s mocap / site positions)')
+    r, _ = self._reward(o.contiguous())
+    return float(r[0]) if self.scalar_api else r
+
+  def is_successful(self, obs=None):
+    o = self.last_obs if obs is None else torch.as_tensor(obs, dtype=torch.float64, device=self.device).reshape(-1, self.OBS_DIM)
+    s = (o[:, 9:23] - o[:, 32:46]).norm(dim=1) <= 0.3                             # kitchen.py:180-183
+    return bool(s[0]) if self.scalar_api else s
+
+  # ------------------------------------------------------------------ goals (kitchen.py:106-112)
+  def get_next_goal(self):
+    return self._goal_states[0]
+
+  def reset_goal(self, goal=None, mask=None):
+    g = torch.as_tensor(self.get_next_goal() if goal is None else goal, dtype=torch.float64, device=self.device).expand(self.num_envs, 23)
+    if mask is None:
+      self.goal_t.copy_(g)
+    else:
+      m = torch.as_tensor(mask, device=self.device).bool()
+      self.goal_t[m] = g[m]
+
+  def get_task(self):
+    return self._task
+
+  def get_init_states(self):
+    return self._initial_states
+
+  @property
+  def goal(self):
+    return self.goal_t[0].cpu().numpy() if self.scalar_api else self.goal_t
+
+  def set_state(self, qpos, qvel):
+    self.qpos.copy_(torch.as_tensor(qpos, dtype=torch.float64, device=self.device).reshape(self.num_envs, self.NV))
+    self.qvel.copy_(torch.as_tensor(qvel, dtype=torch.float64, device=self.device).reshape(self.num_envs, self.NV))
+
+  def state_dict(self):
+    keys = ('qpos', 'qvel', 'mocap_pos', 'goal_t', 'last_qp_robot', 'att', 'steps_since_reset', 'interventions', 'fail_count', 'lifelong_return_t',
+            'steps_since_goal_change', 'last_obs')
+    return {k: getattr(self, k).clone() for k in keys} | {'counter': self._counter, 'total_step_count': self.total_step_count}
+
+  def load_state_dict(self, sd):
+    for k, v in sd.items():
+      if k == 'counter':
+        self._counter = int(v)
+      elif k == 'total_step_count':
+        self.total_step_count = int(v)
+      else:
+        getattr(self, k).copy_(v)

@@ -13,7 +13,8 @@ import torch
 from .. import _abi
 
 MAXV, MAXATT, MAXACT = 16, 8, 4
-MAXSPH, MAXBOX, MAXPAIR, MAXCLS, MAXCON, MAXBLK = 64, 16, 512, 16, 12, 32
+MAXSPH, MAXBOX, MAXPAIR, MAXCLS, MAXCON, MAXBLK = 96, 16, 512, 16, 12, 32
+MAXV24, MAXATT24, MAXJEQ = 24, 16, 8
 MODEL_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'models')
 
 
@@ -32,6 +33,25 @@ class LinkModelStruct(C.Structure):   # struct earl_link_model
               ('weld_solref', C.c_double * 2), ('weld_solimp', C.c_double * 5), ('weld_invweight', C.c_double * 2),
               ('gravity', C.c_double * 3), ('dt', C.c_double), ('drag_G', C.c_double * MAXV), ('drag_b', C.c_double * MAXV),
               ('cd_mask', C.c_uint32 * MAXV)]
+
+
+class LinkModelStruct24(C.Structure):   # struct earl_link_model24: up to 24 dofs + dry friction / springs / force limits / joint couplings
+  _fields_ = [('nv', C.c_int32), ('n_att', C.c_int32), ('n_act', C.c_int32), ('weld_att', C.c_int32),
+              ('n_jump', C.c_int32), ('ball_dof', C.c_int32), ('nq', C.c_int32), ('n_jeq', C.c_int32), ('jump', C.c_int32 * MAXV24 * 5),
+              ('parent', C.c_int32 * MAXV24), ('jtype', C.c_int32 * MAXV24), ('limited', C.c_int32 * MAXV24),
+              ('anc_mask', C.c_uint32 * MAXV24), ('desc_mask', C.c_uint32 * MAXV24), ('att_link', C.c_int32 * MAXATT24),
+              ('act_joint', C.c_int32 * MAXACT), ('jeq_joint1', C.c_int32 * MAXJEQ), ('jeq_joint2', C.c_int32 * MAXJEQ),
+              ('tpos', C.c_double * 3 * MAXV24), ('tquat', C.c_double * 4 * MAXV24), ('jaxis', C.c_double * 3 * MAXV24),
+              ('jpos', C.c_double * 3 * MAXV24), ('mass', C.c_double * MAXV24), ('com', C.c_double * 3 * MAXV24),
+              ('inertia', C.c_double * 6 * MAXV24), ('range', C.c_double * 2 * MAXV24), ('damping', C.c_double * MAXV24),
+              ('armature', C.c_double * MAXV24), ('jsolref', C.c_double * 2 * MAXV24), ('jsolimp', C.c_double * 5 * MAXV24),
+              ('dof_invweight', C.c_double * MAXV24), ('att_pos', C.c_double * 3 * MAXATT24), ('att_quat', C.c_double * 4 * MAXATT24),
+              ('act_kp', C.c_double * MAXACT), ('act_ctrlrange', C.c_double * 2 * MAXACT),
+              ('weld_solref', C.c_double * 2), ('weld_solimp', C.c_double * 5), ('weld_invweight', C.c_double * 2),
+              ('gravity', C.c_double * 3), ('dt', C.c_double), ('drag_G', C.c_double * MAXV24), ('drag_b', C.c_double * MAXV24),
+              ('cd_mask', C.c_uint32 * MAXV24), ('frictionloss', C.c_double * MAXV24), ('stiffness', C.c_double * MAXV24),
+              ('springref', C.c_double * MAXV24), ('act_forcerange', C.c_double * 2 * MAXACT), ('jeq_coef', C.c_double * 2 * MAXJEQ),
+              ('jeq_solref', C.c_double * 2 * MAXJEQ), ('jeq_solimp', C.c_double * 5 * MAXJEQ), ('jeq_invweight', C.c_double * MAXJEQ)]
 
 
 class PairRec(C.Structure):
@@ -64,8 +84,9 @@ def load_link_model(name):
   with np.load(os.path.join(MODEL_DIR, name + '_links.npz')) as z:
     d = {k: z[k] for k in z.files}
   nv, natt, nact = len(d['parent']), len(d['att_link']), len(d['act_joint'])
-  assert nv <= MAXV and natt <= MAXATT and nact <= MAXACT
-  s = LinkModelStruct()
+  big = nv > MAXV                               # the kitchen: struct earl_link_model24
+  assert (nv <= MAXV24 and natt <= MAXATT24 if big else nv <= MAXV and natt <= MAXATT) and nact <= MAXACT
+  s = LinkModelStruct24() if big else LinkModelStruct()
   s.nv, s.n_att, s.n_act, s.weld_att = nv, natt, nact, int(d['weld_att'])
   s.ball_dof = int(d['ball_dof']) if 'ball_dof' in d else -1
   s.nq = nv + (1 if s.ball_dof >= 0 else 0)
@@ -89,7 +110,7 @@ def load_link_model(name):
   depth = [bin(int(a)).count('1') for a in anc]
   s.n_jump = max(1, int(np.ceil(np.log2(max(depth)))))
   assert s.n_jump <= 4
-  jump = np.full((4, MAXV), -1, np.int32)
+  jump = np.full((4, MAXV24 if big else MAXV), -1, np.int32)
   for l in range(nv):
     chain = []
     p = par[l]
@@ -113,6 +134,18 @@ def load_link_model(name):
   if 'dof_drag_G' in d:
     _fill(s.drag_G, d['dof_drag_G'])
     _fill(s.drag_b, d['dof_drag_b'])
+  if big:
+    s.n_jeq = len(d['jeq_joint1'])
+    assert s.n_jeq <= MAXJEQ
+    fr = np.array(d['act_forcerange'], float)
+    fr = np.where(np.isfinite(fr), fr, np.sign(fr) * 1e300)          # +-inf = not force limited
+    for dst, src in ((s.frictionloss, d['jnt_frictionloss']), (s.stiffness, d['jnt_stiffness']), (s.springref, d['jnt_springref']),
+                     (s.act_forcerange, fr), (s.jeq_joint1, d['jeq_joint1']), (s.jeq_joint2, d['jeq_joint2']), (s.jeq_coef, d['jeq_coef']),
+                     (s.jeq_solref, d['jeq_solref']), (s.jeq_solimp, d['jeq_solimp']), (s.jeq_invweight, d['jeq_invweight'])):
+      _fill(dst, src)
+  else:
+    assert not np.any(d.get('jnt_frictionloss', 0)) and not np.any(d.get('jnt_stiffness', 0)) and len(d.get('jeq_joint1', ())) == 0, \
+        'dry friction / springs / joint couplings need the 24-dof model form'
   return s, d
 
 
@@ -156,7 +189,8 @@ def load_collision_model(d):
 
 def check_layouts(lib):
   """the hand-mirrored ctypes layouts are memcpy'd to the device: refuse a library compiled against other struct layouts"""
-  for fn, mirror in ((lib.earl_physics_model_size, LinkModelStruct), (lib.earl_collision_model_size, CollisionModelStruct),
+  for fn, mirror in ((lib.earl_physics_model_size, LinkModelStruct), (lib.earl_physics_model24_size, LinkModelStruct24),
+                     (lib.earl_collision_model_size, CollisionModelStruct),
                      (lib.earl_sawyer_cfg_size, _abi.SawyerCfg)):
     if fn() != C.sizeof(mirror):
       raise _abi.EarlHipError(f'{mirror.__name__}: the library was built with sizeof = {fn()}, this binding expects {C.sizeof(mirror)} '

@@ -84,6 +84,13 @@ int earl_kitchen_action(int32_t n, const earl_kitchen_params* p, const double* a
 int earl_kitchen_obs(int32_t n, const earl_kitchen_params* p, const double* qpos, const double* goal, const double* noise, double* obs,
                      earl_stream_t stream);
 
+/* k draws of U(lo, hi) per env, out [n, k] float64 (numpy's low + (high - low) * u): Philox4x32-10 keyed by `seed`, counter block
+ * (stream_id + j / 2, env_offset + env, counter).  Stands in for the reference's global / env.np_random streams (sensor noise of
+ * Robot.get_obs, franka_robot.py:137-168; np.random.randint of Kitchen.reset_model, kitchen.py:122-124): parity is defined given the draws,
+ * and the draws of an env do not depend on how the batch is sharded. */
+int earl_philox_uniform(int32_t n, int32_t k, uint64_t seed, uint64_t counter, int32_t env_offset, uint32_t stream_id, double lo, double hi,
+                        double* out, earl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,11 +59,43 @@ typedef struct earl_link_model {
                                               axes of a free body all use the velocity before any of them (mj_comVel) */
 } earl_link_model;
 
+/* The same tables for models of up to 24 dofs (the kitchen: nv = 23), plus what only that model uses: dry joint
+ * friction, joint springs, force-limited actuators and linear joint couplings.  A separate struct so that the 16-dof form above -- staged in LDS
+ * by the Sawyer kernels, whose workgroups fill a CU's LDS to the last 200 bytes -- keeps its size.  Kernels take it when nv > EARL_MAXV. */
+#define EARL_MAXV24 24
+#define EARL_MAXATT24 16
+#define EARL_MAXJEQ 8
+typedef struct earl_link_model24 {
+  int32_t nv, n_att, n_act, weld_att;
+  int32_t n_jump, ball_dof, nq, n_jeq;
+  int32_t jump[5][EARL_MAXV24];
+  int32_t parent[EARL_MAXV24], jtype[EARL_MAXV24], limited[EARL_MAXV24];
+  uint32_t anc_mask[EARL_MAXV24], desc_mask[EARL_MAXV24];
+  int32_t att_link[EARL_MAXATT24];
+  int32_t act_joint[EARL_MAXACT];
+  int32_t jeq_joint1[EARL_MAXJEQ], jeq_joint2[EARL_MAXJEQ];   /* coupling e: q[joint1] - c0 - c1 q[joint2] = 0 (MuJoCo <equality><joint polycoef>, linear term, qpos0 = 0) */
+  double tpos[EARL_MAXV24][3], tquat[EARL_MAXV24][4];
+  double jaxis[EARL_MAXV24][3], jpos[EARL_MAXV24][3];
+  double mass[EARL_MAXV24], com[EARL_MAXV24][3], inertia[EARL_MAXV24][6];
+  double range[EARL_MAXV24][2], damping[EARL_MAXV24], armature[EARL_MAXV24];
+  double jsolref[EARL_MAXV24][2], jsolimp[EARL_MAXV24][5], dof_invweight[EARL_MAXV24];
+  double att_pos[EARL_MAXATT24][3], att_quat[EARL_MAXATT24][4];
+  double act_kp[EARL_MAXACT], act_ctrlrange[EARL_MAXACT][2];
+  double weld_solref[2], weld_solimp[5], weld_invweight[2];
+  double gravity[3], dt;
+  double drag_G[EARL_MAXV24], drag_b[EARL_MAXV24];
+  uint32_t cd_mask[EARL_MAXV24];
+  double frictionloss[EARL_MAXV24];            /* dry friction: a constraint row per dof whose force is bounded by +- frictionloss (mjCNSTR_FRICTION_DOF) */
+  double stiffness[EARL_MAXV24], springref[EARL_MAXV24];   /* joint spring: passive force -stiffness (q - springref) */
+  double act_forcerange[EARL_MAXACT][2];       /* force-limited actuators: kp (ctrl - q) clamped to this range (+-inf: not limited) */
+  double jeq_coef[EARL_MAXJEQ][2], jeq_solref[EARL_MAXJEQ][2], jeq_solimp[EARL_MAXJEQ][5], jeq_invweight[EARL_MAXJEQ];
+} earl_link_model24;
+
 /* Collision geometry of a link model: SPHERES (cylinders are chains of spheres; box corners are spheres of radius 0)
  * tested against BOXES, and EDGES (segments) tested against CAPSULES (blk_cap bit 8), over a fixed pair list; per-pair solver parameters by class (MuJoCo's geom mixing rules applied
  * at model-compile time).  At most max_con (<= EARL_MAXCON) contacts per env and timestep: the first active pairs in list order.
  * Models with nv <= 10 are limited to 8 contact slots and 16 blocks (their workgroup then fits four times into a CU's LDS). */
-#define EARL_MAXSPH 64
+#define EARL_MAXSPH 96
 #define EARL_MAXBOX 16
 #define EARL_MAXPAIR 512
 #define EARL_MAXCLS 16
@@ -97,17 +129,17 @@ typedef struct earl_collision_model {
   double cls_mu[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS];
 } earl_collision_model;
 
-/* nsub timesteps of every env.  model: DEVICE copy of an earl_link_model; col: DEVICE copy of its earl_collision_model or
+/* nsub timesteps of every env.  model: DEVICE copy of an earl_link_model (nv <= 16) or of an earl_link_model24 (nv = 23); col: DEVICE copy of its earl_collision_model or
  * NULL (no contacts).  State (updated in place):
  * qpos [n, nq], qvel [n, nv]; inputs mocap_pos [n,3], mocap_quat [n,4] (used AS GIVEN in the weld's orientation rows: an unnormalised quaternion scales their residual and
  * Jacobian by its norm -- metaworld's [1, 0, 1, 0] is meant to be passed unchanged), ctrl [n, n_act];
  * att_xpos (may be NULL) [n, n_att, 3]: world positions of the attachments after the last timestep. */
-int earl_physics_step(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
+int earl_physics_step(const void* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
                       earl_stream_t stream);
 
 /* Forward quantities of the CURRENT state without integrating (tests): qacc [n,nv], efc_force [n, 6+2nv] (may be NULL) */
-int earl_physics_forward(const earl_link_model* model, const earl_collision_model* col, int32_t nv, int32_t n, const double* qpos, const double* qvel,
+int earl_physics_forward(const void* model, const earl_collision_model* col, int32_t nv, int32_t n, const double* qpos, const double* qvel,
                          const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc,
                          double* efc_force, double* att_xpos, earl_stream_t stream);
 
@@ -216,6 +248,7 @@ int earl_debug_set_physics_lanes(int lanes_per_env);
 
 /* sizeof(earl_link_model) as compiled into the library (bindings check their struct layout against it) */
 int earl_physics_model_size(void);
+int earl_physics_model24_size(void);
 int earl_collision_model_size(void);
 int earl_sawyer_cfg_size(void);
 

@@ -349,7 +349,7 @@ def inverse_weights(m):
 # Reduced ("link") model: one link per dof = the jointed body merged with its fixed descendants.  This is the form
 # the HIP stepper consumes (earl_benchmark_amd/csrc/physics.hip); `LinkModel.step` is its line-by-line reference.
 # ======================================================================================================================
-def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geoms=(), collision=None):
+def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geoms=(), collision=None, weld_translation_calibration=None):
   """-> dict of arrays: links in an order where parents precede children (the dof order of these models)"""
   bp = m.body_pos if body_pos is None else body_pos
   link_of_body = np.full(m.nb, -1)          # nearest moving ancestor-or-self link of each body (-1: world-fixed)
@@ -405,9 +405,25 @@ def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geo
   for k in ('jnt_limited', 'jnt_range', 'jnt_damping', 'jnt_armature', 'jnt_solref', 'jnt_solimp', 'dof_invweight0',
             'act_joint', 'act_kp', 'act_ctrlrange', 'weld_solref', 'weld_solimp', 'gravity', 'timestep'):
     out[k] = np.array(getattr(m, k))
+  # optional joint tables (models compiled before round 2 do not carry them): dry friction, springs, actuator force limits, joint couplings
+  out['jnt_frictionloss'] = np.array(getattr(m, 'jnt_frictionloss', np.zeros(nv)))
+  out['jnt_stiffness'] = np.array(getattr(m, 'jnt_stiffness', np.zeros(nv)))
+  out['jnt_springref'] = np.array(getattr(m, 'jnt_springref', np.zeros(nv)))
+  out['act_forcerange'] = np.array(getattr(m, 'act_forcerange', np.tile([-np.inf, np.inf], (len(m.act_joint), 1)))).reshape(-1, 2)
+  neq = len(getattr(m, 'jeq_joint1', ()))
+  out['jeq_joint1'] = np.array(getattr(m, 'jeq_joint1', np.zeros(0)), np.int32)
+  out['jeq_joint2'] = np.array(getattr(m, 'jeq_joint2', np.zeros(0)), np.int32)
+  out['jeq_coef'] = np.array(getattr(m, 'jeq_coef', np.zeros((0, 2))), float).reshape(neq, 2)
+  out['jeq_solref'] = np.array(getattr(m, 'jeq_solref', np.zeros((0, 2))), float).reshape(neq, 2)
+  out['jeq_solimp'] = np.array(getattr(m, 'jeq_solimp', np.zeros((0, 5))), float).reshape(neq, 5)
+  # mj_diagApprox, joint equality: dof_invweight0 of the two joints
+  out['jeq_invweight'] = np.array([m.dof_invweight0[out['jeq_joint1'][e]] + m.dof_invweight0[out['jeq_joint2'][e]] for e in range(neq)])
   wb = int(m.weld_body2[0])
   out['weld_att'] = np.int32(list(out['att_names']).index(str(m.body_names[wb])))
-  out['weld_invweight'] = m.body_invweight0[wb] * np.array([WELD_TRANSLATION_CALIBRATION, 1.0])
+  ftr = WELD_TRANSLATION_CALIBRATION if weld_translation_calibration is None else float(weld_translation_calibration)
+  out['weld_invweight'] = m.body_invweight0[wb] * np.array([ftr, 1.0])
+  out['weld_mocap_quat'] = np.array(m.body_quat[int(m.weld_body1[0])])          # the mocap body's orientation in the model (its mocap_quat after sim.reset())
+  out['weld_mocap_pos'] = np.array(m.body_pos[int(m.weld_body1[0])])
   # generalized coordinates: qpos has one entry per dof, except that a free body's orientation is a unit quaternion
   # stored where MuJoCo stores it (after the body's three translations): nq = nv + 1 per free body
   ball = [l for l in range(nv) if m.jnt_type[l] == 2]
@@ -457,6 +473,17 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
   for names in spec.get('plates', ()):
     l, p, q, half, _, _, _ = union_box(names)
     box.append(dict(link=l, pos=p, quat=q, half=half, accept=tuple(spec.get('plates_accept', ('chain',))), **params(m.geom_id(names[-1]))))
+  # boxes given explicitly (a finger built from a dozen capsules and a box is stood in for by ONE box): dict(body, pos, quat, half, like = geom
+  # whose contact parameters it carries, accept); with 'corners': its eight corner points also become a sphere set of that name
+  for e in spec.get('explicit_boxes', ()):
+    b = m.body_id(e['body'])
+    l, p, q = int(link_of_body[b]), rel_pos[b] + quat_mat(rel_quat[b]) @ np.asarray(e['pos'], float), quat_mul(rel_quat[b], np.asarray(e.get('quat', [1.0, 0, 0, 0]), float))
+    box.append(dict(link=l, pos=p, quat=q, half=np.asarray(e['half'], float), accept=tuple(e['accept']), **params(e['like'])))
+    if e.get('corners'):
+      for sx in (-1, 1):
+        for sy in (-1, 1):
+          for sz in (-1, 1):
+            sph.append(dict(link=l, pos=p + quat_mat(q) @ (np.asarray(e['half'], float) * [sx, sy, sz]), r=0.0, set=e['corners'], **params(e['like'])))
   for e in spec.get('big_boxes', ()):
     g, accept = (e['geom'], tuple(e['accept'])) if isinstance(e, dict) else (e, ('corner',))
     l, p, q = gframe(g)
@@ -469,8 +496,10 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
       ax = int(np.argmax(sz))
       r, h = float(np.min(np.delete(sz, ax))), float(sz[ax])
       d = np.eye(3)[ax]
-    else:                                          # cylinder: axis z, size = (radius, half length)
+    else:                                          # cylinder / capsule: axis z, size = (radius, half length)
       r, h, d = float(m.geom_size[g][0]), float(m.geom_size[g][1]), np.array([0.0, 0, 1])
+      if m.geom_type[g] == 2:
+        h += r                                     # a capsule's hemispherical caps lie beyond its half length
     span = max(h - r, 0.0)
     k = 1 if span == 0 else int(np.ceil(2 * span / (spacing * r))) + 1
     for t in (np.linspace(-span, span, k) if k > 1 else [0.0]):
@@ -717,9 +746,14 @@ class LinkModel:
         F[self.parent[l]] += F[l]
     bias = np.array([S[l] @ F[l] for l in range(nv)])
     tau = -self.jnt_damping * qvel - bias
+    if hasattr(self, 'jnt_stiffness'):             # joint springs (mj_passive): -k (q - springref)
+      tau = tau - self.jnt_stiffness * (np.asarray(qpos[:nv], float) - self.jnt_springref)
     for a in range(len(self.act_joint)):
       j = self.act_joint[a]
-      tau[j] += self.act_kp[a] * (np.clip(ctrl[a], *self.act_ctrlrange[a]) - qpos[j])
+      frc = self.act_kp[a] * (np.clip(ctrl[a], *self.act_ctrlrange[a]) - qpos[j])
+      if hasattr(self, 'act_forcerange'):          # forcelimited actuators (mj_fwdActuation clamps the actuator force)
+        frc = float(np.clip(frc, *self.act_forcerange[a]))
+      tau[j] += frc
     a0 = np.linalg.solve(M, tau)
     # constraint rows: 6 weld rows (equalities), then lower / upper limit of every dof, then 4 pyramid edges per contact
     k = int(self.weld_att)
@@ -759,14 +793,28 @@ class LinkModel:
         row = np.zeros(nv); row[j] = 1.0
         J = np.vstack([J, row]); aref = np.append(aref, -self.dof_drag_b[j] * qvel[j]); Rg = np.append(Rg, 1.0 / self.dof_drag_G[j])
         inst = np.append(inst, True); res = np.append(res, 0.0)
+    # joint couplings (mjEQ_JOINT, linear: q1 - c0 - c1 q2 = 0 with qpos0 = 0): soft equality rows, regulariser from both dofs' invweight
+    for e in range(len(getattr(self, 'jeq_joint1', ()))):
+      j1, j2 = int(self.jeq_joint1[e]), int(self.jeq_joint2[e])
+      c0, c1 = self.jeq_coef[e]
+      row = np.zeros(nv); row[j1], row[j2] = 1.0, -c1
+      r_ = qpos[j1] - c0 - c1 * qpos[j2]
+      kk, bb, dd = kbimp(self.jeq_solref[e], self.jeq_solimp[e], r_, self.dt)
+      J = np.vstack([J, row]); aref = np.append(aref, -bb * (row @ qvel) - kk * dd * r_)
+      Rg = np.append(Rg, max((1 - dd) / dd * self.jeq_invweight[e], 1e-15)); inst = np.append(inst, True); res = np.append(res, r_)
     n_eq_extra = len(aref) - nlim
+    # dry joint friction (mjCNSTR_FRICTION_DOF): one row per dof with frictionloss, residual 0, force bounded by +- frictionloss
+    fric = []
+    for j in np.nonzero(getattr(self, 'jnt_frictionloss', np.zeros(nv)))[0]:
+      kk, bb, dd = kbimp(self.jnt_solref[j], self.jnt_solimp[j], 0.0, self.dt)
+      fric.append((int(j), -bb * qvel[j], max((1 - dd) / dd * self.dof_invweight0[j], 1e-15), float(self.jnt_frictionloss[j])))
     contacts = self.collide(pos, quat) if (self.contacts and hasattr(self, 'col_pair')) else []
     if contacts:
       Jc, arc, Rc = self.contact_rows(contacts, S, qvel)
       J, aref, Rg = np.vstack([J, Jc]), np.concatenate([aref, arc]), np.concatenate([Rg, Rc])
       inst = np.concatenate([inst, np.ones(len(arc), bool)])
     is_eq = np.zeros(len(aref), bool); is_eq[:6] = True; is_eq[nlim:nlim + n_eq_extra] = True
-    qacc, act = self.solve_primal(M, tau, J[inst], aref[inst], 1.0 / Rg[inst], is_eq[inst])
+    qacc, act = self.solve_primal(M, tau, J[inst], aref[inst], 1.0 / Rg[inst], is_eq[inst], fric=fric)
     f = np.zeros(len(aref)); active = np.zeros(len(aref), bool)
     idx = np.nonzero(inst)[0]
     f[idx] = np.where(act, -(J[idx] @ qacc - aref[idx]) / Rg[idx], 0.0)
@@ -777,19 +825,30 @@ class LinkModel:
   contacts = True          # class-level switch: LinkModel.contacts = False gives the contact-free stepper
   max_contacts = 8         # the kernel's cap (tables: 'max_contacts' = earl_collision_model.max_con): the first max_contacts active pairs in pair order
 
-  def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8):
+  def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8, fric=()):
     """MuJoCo's primal problem  min_a 1/2 (a-a0)' M (a-a0) + sum_r 1/2 D_r [J_r a - aref_r]_-^2  (equalities: both signs)
-    by the active-set Newton iteration the kernel runs: rows start active, then active <=> J_r a < aref_r."""
+    by the active-set Newton iteration the kernel runs: rows start active, then active <=> J_r a < aref_r.
+    fric: dry-friction rows (dof j, aref, R, loss): cost 1/2 x^2 / R for |x| <= R loss, loss (|x| - R loss / 2) beyond (x = a_j - aref): a
+    row is QUADRATIC (state 0: it adds 1 / R to the diagonal) or saturated (state +-1: it pushes with -+loss); rows start quadratic."""
     act = np.ones(len(aref), bool)
+    fs = np.zeros(len(fric), int)
     a = None
     for _ in range(iters):
       Ja = J[act]
       H = M + Ja.T @ (D[act, None] * Ja)
-      a = np.linalg.solve(H, tau + Ja.T @ (D[act] * aref[act]))
+      g = tau + Ja.T @ (D[act] * aref[act])
+      for k, (j, ar, R, loss) in enumerate(fric):
+        if fs[k] == 0:
+          H[j, j] += 1.0 / R
+          g[j] += ar / R
+        else:
+          g[j] -= fs[k] * loss
+      a = np.linalg.solve(H, g)
       want = is_eq | (J @ a - aref < 0)
-      if (want == act).all():
+      nfs = np.array([0 if abs(a[j] - ar) <= R * loss else (1 if a[j] - ar > 0 else -1) for (j, ar, R, loss) in fric], int)
+      if (want == act).all() and (nfs == fs).all():
         break
-      act = want
+      act, fs = want, nfs
     return a, act
 
   def collide(self, pos, quat):

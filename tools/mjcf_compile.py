@@ -25,6 +25,7 @@ REF_ENVS = '/root/reference/earl_benchmark/envs'
 MODELS = {
     'sawyer_door': 'metaworld_assets/sawyer_xyz/sawyer_door_pull.xml',
     'sawyer_peg': 'metaworld_assets/sawyer_xyz/sawyer_peg_insertion_side.xml',
+    'kitchen': 'kitchen_assets/adept_envs/adept_envs/franka/assets/franka_kitchen_jntpos_act_ab.xml',
 }
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'earl_benchmark_amd', 'models')
 
@@ -77,6 +78,15 @@ def mat_quat(R):
     q[0] = (R[k, j] - R[j, k]) / s; q[1 + i] = 0.25 * s
     q[1 + j] = (R[j, i] + R[i, j]) / s; q[1 + k] = (R[k, i] + R[i, k]) / s
   return quat_norm(q)
+
+
+def solimp5(s):
+  """solimp attribute: missing trailing entries keep MuJoCo's defaults (0.9 0.95 0.001 0.5 2)"""
+  d = np.array([0.9, 0.95, 0.001, 0.5, 2.0])
+  if s is not None:
+    v = np.array([float(x) for x in s.split()], float)
+    d[:len(v)] = v
+  return d
 
 
 def vec(s, n=None, default=None):
@@ -146,7 +156,13 @@ def geom_frame(a):
   else:
     q = np.array([1.0, 0, 0, 0])
   if a.get('fromto') is not None:
-    raise NotImplementedError('fromto geoms')
+    # capsule / cylinder given by its two end points: centre = midpoint, z axis along the segment, size[1] = half length (set by the caller)
+    ft = vec(a['fromto'])
+    d = ft[3:] - ft[:3]
+    z = d / np.linalg.norm(d)
+    x = np.cross([0, 1.0, 0], z) if abs(z[1]) < 0.9 else np.cross([1.0, 0, 0], z)
+    x /= np.linalg.norm(x)
+    return 0.5 * (ft[:3] + ft[3:]), mat_quat(np.stack([x, np.cross(z, x), z], 1))
   return pos, q
 
 
@@ -213,6 +229,31 @@ def mesh_center(path):
   return (cen * vol[:, None]).sum(0) / vol.sum(), c0, tri
 
 
+def mesh_inertia(path, scale, mass):
+  """mass properties of a mesh geom with a given mass: the mesh is the union of the pyramids spanned by its faces and the centre c0
+  (MuJoCo 2.1 processes meshes this way, with |volume| weights: exact for shapes that are star-convex about c0, which these collision
+  hulls are) -> com (mesh frame), inertia tensor about the com (mesh frame)"""
+  _, c0, tri = mesh_center(path)
+  tri = tri * np.asarray(scale, float)
+  c0 = c0 * np.asarray(scale, float)
+  a, b, c = tri[:, 0] - c0, tri[:, 1] - c0, tri[:, 2] - c0
+  vol = np.abs(np.einsum('ij,ij->i', a, np.cross(b, c))) / 6
+  cen = (a + b + c) / 4                              # tetrahedron centroid relative to c0 (fourth vertex at the origin)
+  V = vol.sum()
+  com_rel = (cen * vol[:, None]).sum(0) / V
+  # second moments of a tetrahedron with one vertex at the origin: integral x x' dV = V / 20 * (sum_i v_i v_i' + (sum v)(sum v)')
+  S = np.zeros((3, 3))
+  for k in range(len(tri)):
+    vs = np.stack([a[k], b[k], c[k]])
+    sm = vs.sum(0)
+    S += vol[k] / 20.0 * (vs.T @ vs + np.outer(sm, sm))
+  dens = mass / V
+  C = dens * S                                       # about c0
+  I0 = np.trace(C) * np.eye(3) - C
+  I = I0 - mass * (com_rel @ com_rel * np.eye(3) - np.outer(com_rel, com_rel))
+  return c0 + com_rel, I
+
+
 # ------------------------------------------------------------------ the compiler
 def compile_model(name):
   path = os.path.join(REF_ENVS, MODELS[name])
@@ -226,10 +267,12 @@ def compile_model(name):
   opt = {}
   for o in root.findall('option'):
     opt.update(o.attrib)
-  meshes = {}
+  meshes, mesh_scale = {}, {}
+  meshdir = os.path.normpath(os.path.join(os.path.dirname(path), comp.get('meshdir', '.')))
   for a in root.findall('asset'):
     for m in a.findall('mesh'):
-      meshes[m.get('name')] = os.path.normpath(os.path.join(os.path.dirname(path), m.get('file')))
+      meshes[m.get('name')] = os.path.normpath(os.path.join(meshdir, m.get('file')))
+      mesh_scale[m.get('name')] = vec(m.get('scale'), 3, [1, 1, 1])
 
   bodies, joints, geoms, sites = [], [], [], []
   names = {'body': ['world'], 'joint': [], 'geom': [], 'site': []}
@@ -240,15 +283,24 @@ def compile_model(name):
     gtype = a.get('type', 'sphere')
     pos, q = geom_frame(a)
     size = vec(a.get('size'), 3, [0, 0, 0])
+    if a.get('fromto') is not None:
+      ft = vec(a['fromto'])
+      size = np.array([size[0], 0.5 * np.linalg.norm(ft[3:] - ft[:3]), 0.0])
     g = dict(body=bid, type=gtype, pos=pos, quat=q, size=size, group=int(a.get('group', 0)),
              contype=int(a.get('contype', 1)), conaffinity=int(a.get('conaffinity', 1)), condim=int(a.get('condim', 3)),
              density=float(a.get('density', 1000)), mass=(float(a['mass']) if 'mass' in a else None),
              friction=vec(a.get('friction'), 3, [1, 0.005, 0.0001]), solref=vec(a.get('solref'), 2, [0.02, 1]),
              solimp=vec(a.get('solimp'), 5, [0.9, 0.95, 0.001, 0.5, 2]), margin=float(a.get('margin', 0)),
              mesh=a.get('mesh'))
-    if gtype == 'mesh':   # MuJoCo moves the geom frame to the mesh centre (orientation: principal axes, not needed here)
+    inertial_mesh = gtype == 'mesh' and grp_lo <= g['group'] <= grp_hi and g['mass'] is not None and g['mass'] > 0
+    if gtype == 'mesh' and (inertial_mesh or name != 'kitchen'):
+      # MuJoCo moves the geom frame to the mesh centre (orientation: principal axes, not needed here).  (The kitchen's purely visual
+      # meshes -- group 0 / 1, no mass, no collision -- are never read by anything and are left where they are.)
       cen, _, _ = mesh_center(meshes[a['mesh']])
-      g['pos'] = pos + quat_mat(q) @ cen
+      g['pos'] = pos + quat_mat(q) @ (cen * mesh_scale[a['mesh']])
+    if inertial_mesh:
+      com, I = mesh_inertia(meshes[a['mesh']], mesh_scale[a['mesh']], g['mass'])
+      g['mesh_com'], g['mesh_I'] = pos + quat_mat(q) @ com, quat_mat(q) @ I @ quat_mat(q).T      # body frame
     names['geom'].append(a.get('name', ''))
     geoms.append(g)
     bodies[bid]['geoms'].append(len(geoms) - 1)
@@ -270,7 +322,8 @@ def compile_model(name):
             a = dfl.attrs(sub, cls)
             base = dict(body=bid, pos=vec(a.get('pos'), 3, [0, 0, 0]), limited=int(a.get('limited', 'false') == 'true'),
                         range=vec(a.get('range'), 2, [0, 0]), damping=float(a.get('damping', 0)),
-                        armature=float(a.get('armature', 0)), solref=vec(a.get('solreflimit'), 2, [0.02, 1]),
+                        armature=float(a.get('armature', 0)), frictionloss=float(a.get('frictionloss', 0)), stiffness=float(a.get('stiffness', 0)),
+                        springref=float(a.get('springref', 0)), solref=vec(a.get('solreflimit'), 2, [0.02, 1]),
                         solimp=vec(a.get('solimplimit'), 5, [0.9, 0.95, 0.001, 0.5, 2]), margin=float(a.get('margin', 0)))
             if a.get('type', 'hinge') == 'free':
               # A free joint becomes six 1-dof entries on the same body, in MuJoCo's dof order: three translations along the
@@ -320,6 +373,9 @@ def compile_model(name):
         if grp_lo <= g['group'] <= grp_hi and g['type'] not in ('plane', 'mesh'):
           m, d = primitive_inertia(g['type'], g['size'], g['density'], g['mass'])
           parts.append((m, g['pos'], quat_mat(g['quat']), d))
+        elif 'mesh_I' in g:                       # mesh geom with a given mass (the Franka links' collision hulls)
+          w, V = np.linalg.eigh(g['mesh_I'])
+          parts.append((g['mass'], g['mesh_com'], V, w))
       if parts:
         mass[b], ipos[b], iquat[b], inertia[b] = combine_inertia(parts)
 
@@ -330,14 +386,22 @@ def compile_model(name):
     for el in ac:
       a = dfl.attrs(el, None)
       assert el.tag == 'position'
+      a = dfl.attrs(el, el.get('class'))
       acts.append(dict(joint=names['joint'].index(a['joint']), kp=float(a.get('kp', 1)), ctrlrange=vec(a.get('ctrlrange'), 2, [0, 0]),
-                       ctrllimited=int(a.get('ctrllimited', 'false') == 'true')))
-  welds = []
+                       ctrllimited=int(a.get('ctrllimited', 'false') == 'true'),
+                       forcerange=vec(a.get('forcerange'), 2, [0, 0]) if a.get('forcelimited', 'false') == 'true' else np.array([-np.inf, np.inf])))
+  welds, jeqs = [], []
   for eq in root.findall('equality'):
     for el in eq:
+      if el.tag == 'joint':                          # joint1 - ref1 = polynomial(joint2 - ref2): these models use the linear term only
+        pc = vec(el.get('polycoef'), 5, [0, 1, 0, 0, 0])
+        assert pc[2] == pc[3] == pc[4] == 0
+        jeqs.append(dict(joint1=names['joint'].index(el.get('joint1')), joint2=names['joint'].index(el.get('joint2')), c0=pc[0], c1=pc[1],
+                         solref=vec(el.get('solref'), 2, [0.02, 1]), solimp=solimp5(el.get('solimp'))))
+        continue
       assert el.tag == 'weld'
       welds.append(dict(body1=names['body'].index(el.get('body1')), body2=names['body'].index(el.get('body2')),
-                        solref=vec(el.get('solref'), 2, [0.02, 1]), solimp=vec(el.get('solimp'), 5, [0.9, 0.95, 0.001, 0.5, 2])))
+                        solref=vec(el.get('solref'), 2, [0.02, 1]), solimp=solimp5(el.get('solimp'))))
 
   out = dict(
       name=np.array(name), timestep=np.float64(opt.get('timestep', 0.002)), gravity=vec(opt.get('gravity'), 3, [0, 0, -9.81]),
@@ -362,6 +426,12 @@ def compile_model(name):
       act_ctrlrange=np.stack([a['ctrlrange'] for a in acts]),
       weld_body1=np.array([w['body1'] for w in welds], np.int32), weld_body2=np.array([w['body2'] for w in welds], np.int32),
       weld_solref=np.stack([w['solref'] for w in welds]), weld_solimp=np.stack([w['solimp'] for w in welds]),
+      jnt_frictionloss=np.array([j['frictionloss'] for j in joints]), jnt_stiffness=np.array([j['stiffness'] for j in joints]),
+      jnt_springref=np.array([j['springref'] for j in joints]), act_forcerange=np.stack([a['forcerange'] for a in acts]),
+      jeq_joint1=np.array([e['joint1'] for e in jeqs], np.int32), jeq_joint2=np.array([e['joint2'] for e in jeqs], np.int32),
+      jeq_coef=np.array([[e['c0'], e['c1']] for e in jeqs], float).reshape(-1, 2),
+      jeq_solref=np.array([e['solref'] for e in jeqs], float).reshape(-1, 2), jeq_solimp=np.array([e['solimp'] for e in jeqs], float).reshape(-1, 5),
+      key_qpos=np.array([float(x) for k in root.findall('keyframe') for kk in k.findall('key') for x in kk.get('qpos', '').split()]),
       body_names=np.array(names['body']), joint_names=np.array(names['joint']), geom_names=np.array(names['geom']),
       site_names=np.array(names['site']),
   )
@@ -430,6 +500,37 @@ def main():
     np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
     print('links:', len(red['parent']), 'spheres', len(red['col_sph_link']), 'boxes', len(red['col_box_link']), 'pairs', len(red['col_pair']),
           'blocks', len(red['col_blk_begin']), 'classes', len(red['col_cls_mu']))
+  if name == 'kitchen':
+    # Link form of the kitchen (BASELINE configs[3]): nv = 23 = 7 arm hinges + 2 finger slides + 14 single-dof fixtures
+    # (each its own tree), 5 joint couplings, dry friction on six joints, the mocap weld on panda0_link7.
+    # Collision set (this build's own, DECLARED: MuJoCo's 117 colliding geoms incl. nine convex link hulls are not reproduced): each finger
+    # (twelve capsules + a box) is ONE box; the graspable fixtures are sphere chains -- microwave handle, the two hinge-door handles, the
+    # slide-door handle, the four knob bars, the light switch -- tested against the two finger boxes; the finger boxes' corners are points
+    # tested against the four door panels.  Left out: counters, oven body, walls, floor, the arm links' hulls, the handle stubs, the knob discs.
+    pm = po.Model(m)
+    gb, gt, gs = m['geom_body'], m['geom_type'], m['geom_size']
+    colliding = lambda g: bool(m['geom_contype'][g] or m['geom_conaffinity'][g])
+    on = lambda body: [g for g in range(len(gb)) if gb[g] == pm.body_id(body) and colliding(g)]
+    longest = lambda gl, types: max((g for g in gl if gt[g] in types), key=lambda g: gs[g][1] if gt[g] in (2, 3) else max(gs[g]))
+    chains = [dict(geom=longest(on('microdoorroot'), (2, 3)), set='micro', spacing=1.5), dict(geom=longest(on('hingeleftdoor'), (2, 3)), set='hingel', spacing=1.5),
+              dict(geom=longest(on('hingerightdoor'), (2, 3)), set='hinger', spacing=1.5), dict(geom=longest(on('slidelink'), (2, 3)), set='slide', spacing=1.5),
+              dict(geom=longest(on('lightswitchroot'), (2, 3)), set='light', spacing=1.5)]
+    for k in range(1, 5):
+      chains.append(dict(geom=[g for g in on(f'knob {k}') if gt[g] == 4][0], set=f'knob{k}', spacing=1.5))
+    panels = [[g for g in on(b) if gt[g] == 4][0] for b in ('microdoorroot', 'hingeleftdoor', 'hingerightdoor', 'slidelink')]
+    finger_geom = {b: [g for g in on(b) if gt[g] == 4][0] for b in ('panda0_leftfinger', 'panda0_rightfinger')}      # contact parameters of the finger class
+    sets = tuple(c['set'] for c in chains)
+    fingers = [dict(body='panda0_leftfinger', pos=[0.0, 0.0125, 0.0475], half=[0.0185, 0.0125, 0.0475], like=finger_geom['panda0_leftfinger'], accept=sets, corners='tipl'),
+               dict(body='panda0_rightfinger', pos=[0.0, -0.0125, 0.0475], half=[0.0185, 0.0125, 0.0475], like=finger_geom['panda0_rightfinger'], accept=sets, corners='tipr')]
+    red = po.reduce_model(pm, None, attach_bodies=['panda0_link7'],
+                          attach_sites=['end_effector', 'knob1_site', 'knob2_site', 'knob3_site', 'knob4_site', 'light_site', 'slide_site', 'hinge_site2', 'microhandle_site'],
+                          weld_translation_calibration=1.0,        # no recordings of this env exist: the derived value, not the Sawyer calibration
+                          collision=dict(max_contacts=12, explicit_boxes=fingers, chains=chains, big_boxes=[dict(geom=g, accept=('tipl', 'tipr')) for g in panels],
+                                         set_priority=sets, set_cap=dict({c['set']: 4 for c in chains}, tipl=2, tipr=2)))
+    red['key_qpos'] = m['key_qpos']
+    np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
+    print('links:', len(red['parent']), 'spheres', len(red['col_sph_link']), 'boxes', len(red['col_box_link']), 'pairs', len(red['col_pair']),
+          'blocks', len(red['col_blk_begin']), 'classes', len(red['col_cls_mu']), 'attachments', list(red['att_names']))
   nb, nj, ng = len(m['body_parent']), len(m['jnt_body']), len(m['geom_body'])
   col = int(((m['geom_contype'] != 0) | (m['geom_conaffinity'] != 0)).sum())
   print(f'{name}: {nb} bodies, {nj} joints (nv={nj}), {ng} geoms ({col} colliding), {len(m["act_joint"])} actuators, '
