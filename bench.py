@@ -45,7 +45,8 @@ def parse():
   p.add_argument('--no-single', action='store_true', help='skip the one-episode-per-launch comparison leg')
   p.add_argument('--no-sawyer', action='store_true', help='skip the sawyer_door / sawyer_peg (BASELINE configs[2]) legs of the default line')
   p.add_argument('--sawyer-cpu-seconds', type=float, default=2.0, help='seconds per repetition and thread count of the Sawyer CPU baselines')
-  p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door', 'sawyer_peg'],
+  p.add_argument('--no-kitchen', action='store_true', help='skip the kitchen (BASELINE configs[3]) leg of the default line')
+  p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door', 'sawyer_peg', 'kitchen'],
                  help='tabletop = BASELINE configs[1] (the default, the quoted metric); sawyer_door / sawyer_peg = configs[2] shape, N=8192 each (next rows)')
   return p.parse_args()
 
@@ -366,6 +367,79 @@ def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8
   return res
 
 
+def kitchen_cpu_baseline(seconds):
+  """this build's CPU statement of the kitchen stepper (oracle/physics_oracle.LinkModel: numpy, one core) -- the only CPU form of the nv = 23
+  model so far; MuJoCo itself is not available on this host.  One env, whole env steps (40 timesteps each) for about `seconds`."""
+  import numpy as np
+  from earl_benchmark_amd.envs.kitchen import INIT_QPOS, MIDPOINT_POS
+  from oracle import physics_oracle as po
+  lm = po.LinkModel(os.path.join(REPO, 'earl_benchmark_amd', 'models', 'kitchen_links.npz'))
+  q, v, mp, mq = INIT_QPOS.copy(), np.zeros(23), np.array(MIDPOINT_POS), np.array(lm.weld_mocap_quat)
+  rng = np.random.default_rng(0)
+  k, t0 = 0, time.perf_counter()
+  while time.perf_counter() - t0 < seconds:
+    mp = np.clip(mp + rng.uniform(-0.02, 0.02, 3), [-0.7, -0.1, 1.8], [0.4, 0.5, 2.6])
+    for _ in range(40):
+      q, v, _ = lm.step(q, v, rng.uniform(0, 0.04, 2), mp, mq)
+    k += 1
+  dt = time.perf_counter() - t0
+  return {'value': k / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+          'sample': f'{k} env steps (40 timesteps each) of ONE env through the numpy statement of the same stepper (oracle/physics_oracle.py LinkModel), {dt:.1f} s; '
+                    'no C port of the nv = 23 model exists yet, and MuJoCo itself is not available on this host'}
+
+
+def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=2048, T=400, cpu_seconds=None):
+  """BASELINE configs[3]: kitchen, 2048 envs in total range-sharded over the GPUs (n_global / world per GPU: STRONG scaling), one bench step =
+  reset + T = 400 env steps (the reference's eval horizon) of 40 timesteps each; four launches per env step (glue, stepper, glue, glue).
+  Own stepper, reduced collision set, parity with MuJoCo unpinned (envs/kitchen.py).  -> result dict on rank 0"""
+  from earl_benchmark_amd.envs.kitchen import Kitchen
+  from earl_benchmark_amd.wrappers import PersistentStateWrapper
+  from earl_benchmark_amd import sharding
+  kw = sharding.shard_kwargs(n_global, rank, world)
+  n = kw['num_envs']
+  env = PersistentStateWrapper(Kitchen(num_envs=n, seed=1234, env_offset=kw['env_offset']), T)
+  g = torch.Generator(device=device).manual_seed(77 + rank)
+  acts = (torch.rand(T, n, 9, generator=g, device=device) * 2 - 1).to(torch.float32)
+
+  def episode():
+    env.reset()
+    for t in range(T):
+      out = env.step(acts[t])
+    return out
+  for _ in range(warmup):
+    episode()
+  clk = _Clock(torch, device)
+  clk.sync()
+  if world > 1:
+    dist.barrier()
+  clk.sync()
+  t0 = time.perf_counter()
+  clk.start()
+  for _ in range(steps):
+    o, r, done, info = episode()
+  clk.stop()
+  clk.sync()
+  if world > 1:
+    dist.barrier()
+  clk.sync()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  assert bool(done.all()) and bool(torch.isfinite(o).all())
+  fails = int(env.unwrapped.fail_count.sum())
+  if rank != 0:
+    return None
+  return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
+          'timesteps_per_s': steps * n_global * T * 40 / dt, 'gpu_ms_per_env_step': clk.elapsed_ms() / (steps * T), 'scaling': 'strong',
+          'diverged_env_steps': fails,
+          'config': {'workload': f'kitchen dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + {T} env steps of 40 timesteps '
+                                 'per bench step; own stepper (nv = 23, 32 lanes per env), reduced collision set, parity with MuJoCo unpinned',
+                     'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 40, 'launches_per_env_step': 4},
+          'cpu_baseline': None if cpu_seconds is None else kitchen_cpu_baseline(cpu_seconds)}
+
+
 def main_sawyer(a, torch, dist, world, rank, device):
   n = a.envs if a.envs != 4096 else 8192
   T = a.horizon if a.horizon != 200 else None
@@ -401,6 +475,17 @@ def main():
     dist.init_process_group('nccl', device_id=torch.device(device))
   if a.workload in ('sawyer_door', 'sawyer_peg'):
     return main_sawyer(a, torch, dist, world, rank, device)
+  if a.workload == 'kitchen':
+    r = run_kitchen(a, torch, dist, world, rank, device, a.steps if a.steps != 200 else 3, min(a.warmup, 1), cpu_seconds=None if a.no_cpu else 5.0)
+    if rank == 0:
+      print(json.dumps({'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world,
+                        'steps': r['steps'], 'warmup': r['warmup'], 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
+                        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'config': r['config'], 'cpu_baseline': r['cpu_baseline'],
+                        'timesteps_per_s': r['timesteps_per_s'], 'gpu_ms_per_env_step': r['gpu_ms_per_env_step']}), flush=True)
+    if world > 1:
+      dist.barrier()
+      dist.destroy_process_group()
+    return
   n, T = a.envs, a.horizon
 
   env = make_env(torch, n, T, a.reward, rank, device)
@@ -427,6 +512,8 @@ def main():
     for w in ('sawyer_door', 'sawyer_peg'):
       sawyer[w] = run_sawyer(a, torch, dist, world, rank, device, w, steps=max(3, a.steps // 20), warmup=2,
                              cpu_seconds=None if (a.no_cpu or world > 1) else a.sawyer_cpu_seconds)
+  if not a.no_kitchen:      # BASELINE configs[3] in the same run (2048 envs in total, sharded over the ranks)
+    sawyer['kitchen'] = run_kitchen(a, torch, dist, world, rank, device, steps=2, warmup=1, cpu_seconds=None if (a.no_cpu or world > 1) else 3.0)
   res = None
   if rank == 0:
     kmean = sum(kern_ms) / len(kern_ms)

@@ -174,6 +174,28 @@ class EARLEnvs(object):
       print('please download the demonstrations corresponding to ', self._env_name)
 
 
+  def get_demonstrations_on_device(self, device='cuda', buffer=None):
+    """The demonstrations as device-resident tensors, for seeding a replay buffer without a host round trip per batch:
+    -> (forward, reverse), each a dict of `observations` / `next_observations` [N, D] float32, `actions` [N, A] float32, `rewards` [N, 1]
+    float32, `terminals` [N, 1] bool -- the reference's layout (:238-247) minus the empty `infos`.  With `buffer` (a dict of preallocated
+    tensors with the same keys and at least N_forward + N_reverse rows) the rows are also written into it, forward first, and the number of
+    rows written is returned as a third value."""
+    import torch
+    demos = self.get_demonstrations()
+    if demos is None:
+      return None
+    out = tuple({k: torch.as_tensor(d[k], device=device) for k in DEMO_KEYS if k != 'infos'} for d in demos)
+    if buffer is None:
+      return out
+    n = 0
+    for d in out:
+      m = d['observations'].shape[0]
+      for k, v in d.items():
+        buffer[k][n:n + m].copy_(v.to(buffer[k].dtype))
+      n += m
+    return out + (n,)
+
+
 DEMO_KEYS = ('observations', 'actions', 'rewards', 'terminals', 'next_observations', 'infos')
 
 

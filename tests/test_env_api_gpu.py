@@ -265,3 +265,18 @@ def test_step_graph_ring_and_closed_loop_policy(torch, orc):
   lifelong._cfg.goal_change_frequency = 10
   with pytest.raises(NotImplementedError):
     lifelong.make_step_graph(4)
+
+
+def test_demonstrations_seed_a_device_replay_buffer(torch):
+  """the reference's demonstration layout, resident on the device, written into a caller's replay buffer"""
+  import earl_benchmark_amd as eb
+  L = eb.EARLEnvs('tabletop_manipulation', reward_type='sparse')
+  fwd, rev = L.get_demonstrations()
+  buf = {'observations': torch.zeros(5000, 12, device='cuda'), 'next_observations': torch.zeros(5000, 12, device='cuda'),
+         'actions': torch.zeros(5000, 3, device='cuda'), 'rewards': torch.zeros(5000, 1, device='cuda'), 'terminals': torch.zeros(5000, 1, dtype=torch.bool, device='cuda')}
+  dfwd, drev, n = L.get_demonstrations_on_device('cuda', buffer=buf)
+  assert n == 1278 + 1256 and dfwd['observations'].is_cuda and dfwd['terminals'].dtype == torch.bool
+  for k in buf:
+    np.testing.assert_array_equal(buf[k][:1278].cpu().numpy(), fwd[k]); np.testing.assert_array_equal(buf[k][1278:n].cpu().numpy(), rev[k])
+    assert not bool(buf[k][n:].any())
+  assert eb.EARLEnvs('kitchen', reward_type='dense').get_demonstrations_on_device() is None     # no demonstrations ship for the kitchen

@@ -242,7 +242,8 @@ def test_active_set_newton_converges_to_the_kkt_point_through_a_grasp():
   seen = []
   orig = po.LinkModel.solve_primal
 
-  def checked(self, M, tau, J, aref, D, is_eq, iters=8):
+  def checked(self, M, tau, J, aref, D, is_eq, iters=8, fric=()):
+    assert len(fric) == 0                                          # (dry joint friction: the kitchen model only)
     a, act = orig(self, M, tau, J, aref, D, is_eq, iters)
     x = J @ a - aref
     want = is_eq | (x < 0)
