@@ -151,5 +151,6 @@ def test_full_size_soak_2048_envs_400_steps():
   hi = torch.tensor(u.model.tables['jnt_range'][:, 1], device='cuda') + 0.8
   assert bool(((u.qpos >= lo) & (u.qpos <= hi)).all())
   assert float(moved[:, [0, 2, 4, 6]].max()) > 0.5 and float(moved[:, 12].max()) > 0.3     # some knob was turned, some hinge door opened
-  assert float((u.mocap_pos - torch.tensor([[-0.7, -0.1, 1.8]], device='cuda')).min()) >= 0 and float((u.mocap_pos - torch.tensor([[0.4, 0.5, 2.6]], device='cuda')).max()) <= 0
+  f64 = dict(dtype=torch.float64, device='cuda')
+  assert float((u.mocap_pos - torch.tensor([[-0.7, -0.1, 1.8]], **f64)).min()) >= 0 and float((u.mocap_pos - torch.tensor([[0.4, 0.5, 2.6]], **f64)).max()) <= 0
   assert float(u.qvel.abs().max()) < 50

@@ -176,6 +176,7 @@ def test_stale_library_layout_is_refused(monkeypatch):
 
   class Fake:
     earl_physics_model_size = staticmethod(lambda: 8)
+    earl_physics_model24_size = lib.earl_physics_model24_size
     earl_collision_model_size = lib.earl_collision_model_size
     earl_sawyer_cfg_size = lib.earl_sawyer_cfg_size
   with pytest.raises(_abi.EarlHipError, match='sizeof'):
