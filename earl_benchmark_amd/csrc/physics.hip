@@ -155,9 +155,12 @@ __device__ __forceinline__ void kbimp(const double* solref, const double* solimp
 // i (i + 1) / 2 + j): half the LDS of a square array, and the env block is what limits the number of waves on a CU.  Small models
 // keep the plain square (both triangles written): their workgroup fits four times into a CU either way, and the packed form's index
 // arithmetic cost the door kernel 500 VALU instructions per timestep.
+#ifndef EARL_DOOR_PACKED
+#define EARL_DOOR_PACKED 0
+#endif
 template <int NV>
 struct SymLds {
-  static constexpr bool PACKED = NV > 10;
+  static constexpr bool PACKED = NV > 10 || EARL_DOOR_PACKED;   // (small model: packed only in the eight-waves-per-CU build, where the block size decides)
   double v[PACKED ? NV * (NV + 1) / 2 : NV * NV];
   __device__ __forceinline__ double& lo(const int i, const int j) { return v[PACKED ? i * (i + 1) / 2 + j : i * NV + j]; }               // i >= j
   __device__ __forceinline__ const double& lo(const int i, const int j) const { return v[PACKED ? i * (i + 1) / 2 + j : i * NV + j]; }
@@ -224,13 +227,16 @@ struct SharedData {
       };
     } dyn;
     struct {
-      double J6[6][NV], wD[6], war[6], dl[NV], rl[NV];
+      double wD[6], war[6], dl[NV], rl[NV];
       double CJ[MC][3][NV];            // contact Jacobians: normal, tangent 1, tangent 2
       union {
-        double ct[MC][10];             // contact records (C2 -> C3): dist, normal (3), point (3), class, sphere link, box link
+        double ct[MC][8];              // contact records (C2 -> C3): dist, normal (3), point (3), (class, sphere link + 1, box link + 1) packed as class + 64 (ls + 1) + 4096 (lb + 1)
         double cw[MC][8];              // per-iteration weights of the active pyramid edges (K9)
       };
-      SymLds<NV> Hc;                   // Hessian of the iteration; the shared factorisation overwrites it with L
+      union {
+        double J6[6][NV];              // weld Jacobian (K8 -> the equality part of K9; dead once every lane holds its Hessian column hw)
+        SymLds<NV> Hc;                 // Hessian of the iteration (written after that); the shared factorisation overwrites it with L
+      };
       double rc[NV];                   // its right-hand side; then the right-hand side of K10
     } con;
   };
@@ -248,6 +254,8 @@ struct Shared : SharedData<NV> {
 // NA < NV: the matrix is block diagonal, rows / columns [0, NA) and [NA, NV) -- the arm and the free object are separate
 // trees, so the mass matrix always is, and the Hessian is unless a contact joins the two.  The entries of the off-diagonal block
 // are then never read or written (their registers are dead on that path).
+// (every multiply-subtract is an explicit fma in the same order as chol_coop / solve_lds below: the register-resident and the in-LDS
+// factorisation then produce the same bits, which is what lets earl_sawyer_rollout switch between its two door builds by batch size)
 template <int NV, int NA>
 __device__ __forceinline__ void chol_regs(double (&L)[NV * (NV + 1) / 2]) {
 #pragma unroll
@@ -255,14 +263,14 @@ __device__ __forceinline__ void chol_regs(double (&L)[NV * (NV + 1) / 2]) {
     const int p0 = j >= NA ? NA : 0;                  // first column of row j's block
     double d = L[j * (j + 1) / 2 + j];
 #pragma unroll
-    for (int p = p0; p < j; ++p) d -= L[j * (j + 1) / 2 + p] * L[j * (j + 1) / 2 + p];
+    for (int p = p0; p < j; ++p) d = fma(-L[j * (j + 1) / 2 + p], L[j * (j + 1) / 2 + p], d);
     const double inv = rsq_nr(d);
     L[j * (j + 1) / 2 + j] = inv;
 #pragma unroll
     for (int i = j + 1; i < (j < NA ? NA : NV); ++i) {
       double s = L[i * (i + 1) / 2 + j];
 #pragma unroll
-      for (int p = p0; p < j; ++p) s -= L[i * (i + 1) / 2 + p] * L[j * (j + 1) / 2 + p];
+      for (int p = p0; p < j; ++p) s = fma(-L[i * (i + 1) / 2 + p], L[j * (j + 1) / 2 + p], s);
       L[i * (i + 1) / 2 + j] = s * inv;
     }
   }
@@ -273,14 +281,14 @@ __device__ __forceinline__ void solve_regs(const double (&L)[NV * (NV + 1) / 2],
   for (int i = 0; i < NV; ++i) {
     double s = x[i];
 #pragma unroll
-    for (int p = (i >= NA ? NA : 0); p < i; ++p) s -= L[i * (i + 1) / 2 + p] * x[p];
+    for (int p = (i >= NA ? NA : 0); p < i; ++p) s = fma(-L[i * (i + 1) / 2 + p], x[p], s);
     x[i] = s * L[i * (i + 1) / 2 + i];
   }
 #pragma unroll
   for (int i = NV - 1; i >= 0; --i) {
     double s = x[i];
 #pragma unroll
-    for (int p = i + 1; p < (i < NA ? NA : NV); ++p) s -= L[p * (p + 1) / 2 + i] * x[p];
+    for (int p = i + 1; p < (i < NA ? NA : NV); ++p) s = fma(-L[p * (p + 1) / 2 + i], x[p], s);
     x[i] = s * L[i * (i + 1) / 2 + i];
   }
 }
@@ -475,7 +483,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   int pf_blk = -1, pf_link = -1, pf_cls = 0;
   double pf_r = 0, pf_margin = 0, pf_hl = 0;
   V3 pf_pos{0, 0, 0}, pf_dir{0, 0, 0};
-  if (nearw) {
+#ifndef EARL_NO_PREFETCH
+#define EARL_NO_PREFETCH 0
+#endif
+  if (nearw && !(EARL_NO_PREFETCH && NV <= 10)) {      // (two waves per SIMD hide that latency themselves; the registers are worth more there)
     pf_blk = __builtin_ctz(nearw);
     const int pend = bt.end[pf_blk], pi0 = bt.begin[pf_blk] + sub;
     const int pi = pi0 < pend ? pi0 : pend - 1;
@@ -718,7 +729,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
           double* o = s.con.ct[slot];
           o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
-          o[7] = (double)cls; o[8] = (double)lk; o[9] = (double)xl;
+          o[7] = (double)(cls + 64 * (lk + 1) + 4096 * (xl + 1));
         }
         const int took = total < room ? total : room;
         room -= took;
@@ -814,7 +825,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const double* rec = s.con.ct[c];
       const bool cv = c < nct;
       const V3 n = selv(cv, ld3(rec + 1), V3{0, 0, 1}), p = selv(cv, ld3(rec + 4), V3{0, 0, 0});
-      const int ls = cv ? (int)rec[8] : -1, lb = cv ? (int)rec[9] : -1;
+      const int pk = cv ? (int)rec[7] : 0;
+      const int ls = ((pk >> 6) & 63) - 1, lb = (pk >> 12) - 1;
       coupled = coupled || (ls >= 0 && lb >= 0 && ((ls < NA) != (lb < NA)));
       // tangents: n x (the coordinate axis least aligned with n), normalised, then n x t1
       const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
@@ -842,7 +854,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         vn = fma(s.con.CJ[c][0][j], qd, vn); vt1 = fma(s.con.CJ[c][1][j], qd, vt1); vt2 = fma(s.con.CJ[c][2][j], qd, vt2);
       }
       const double* rec = s.con.ct[c];
-      const int cls = cv ? (int)rec[7] : 0;
+      const int cls = cv ? ((int)rec[7] & 63) : 0;
       const double margin = bt.cls_margin[cls];
       cmu = bt.cls_mu[cls];
       double kk, bb, dd;
@@ -998,6 +1010,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
     if (qacc_out && isl) qacc_out[l] = al;
     if (efc_out) {
+      // the weld Jacobian shares its storage with the Hessian: put this lane's column back before the rows are read
+      fence();
+      if (isl) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s.con.J6[r][l] = Jc[r];
+      }
+      fence();
       if (sub < 6) {
         double Ja = 0;
 #pragma unroll
@@ -1021,13 +1040,15 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fence();
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i];
+    // the implicit-damping diagonal dt * B goes through LDS in both forms: as an operand of the add in load_tri the product would be contracted
+    // into an fma, in chol_coop it is a rounded product -- the two door builds must agree to the bit
+    if (isl) s.con.dl[l] = dt * m.damping[l];
+    fence();
     if constexpr (Lim<NV>::COOP) {                     // M is rebuilt next timestep: factorise it in place
-      if (isl) s.con.dl[l] = dt * m.damping[l];
-      fence();
       chol_coop<NV>(s.M, s.con.dl, l, isl);
       solve_lds<NV>(s.M, a);
     } else {
-      load_tri<NV, NA>(L, s.M, [&](int i) { return dt * m.damping[i]; });     // the mass matrix is block diagonal: two trees
+      load_tri<NV, NA>(L, s.M, [&](int i) { return s.con.dl[i]; });           // the mass matrix is block diagonal: two trees
       chol_regs<NV, NA>(L);
       solve_regs<NV, NA>(L, a);
     }
@@ -1492,6 +1513,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
   }
 }
 
+#ifndef EARL_PHYS_VARIANT_W8
 // compute_reward / is_successful on given observations (sawyer_door.py:141-177), one lane per row
 __global__ void sawyer_door_reward_kernel(const int n, const double* __restrict__ obs, const earl_sawyer_cfg cfg, float* __restrict__ reward,
                                           uint8_t* __restrict__ success) {
@@ -1503,6 +1525,7 @@ __global__ void sawyer_door_reward_kernel(const int n, const double* __restrict_
   if (reward) reward[i] = (float)r;
   if (success) success[i] = ok ? 1 : 0;
 }
+#endif
 
 int launched(const char* what) {
   const hipError_t e = hipGetLastError();
@@ -1513,6 +1536,7 @@ int launched(const char* what) {
   return EARL_OK;
 }
 
+int g_door_variant = 0;   // earl_debug_set_door_variant: 0 = by batch size, 1 = four single-wave workgroups per CU, 2 = one eight-wave workgroup per CU
 int g_lpe = 16;   // lanes per env (earl_debug_set_physics_lanes): 16 = four envs per wavefront, 64 = one wavefront per env
 
 // launch geometry: Lim<NV>::WPB wavefronts per workgroup, 64 / LPE envs per wavefront
@@ -1530,6 +1554,7 @@ void launch_physics(const PArgs& a, hipStream_t st) {
 
 extern "C" {
 
+#ifndef EARL_PHYS_VARIANT_W8
 int earl_physics_step(const void* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
                       earl_stream_t stream) {
@@ -1556,6 +1581,20 @@ int earl_physics_forward(const void* model, const earl_collision_model* col, int
   return launched("physics_forward");
 }
 
+#endif
+#ifdef EARL_PHYS_VARIANT_W8
+// This translation unit is physics_w8.hip: the door model's rollout kernel built with eight-wave workgroups (EARL_DOOR_WPB 8: 32 envs share one
+// copy of the tables, packed matrices, in-LDS factorisations, 256 registers per wave) = eight waves per CU.  Same arithmetic, bit-identical
+// outputs; chosen by earl_sawyer_rollout for batches of more than 4096 envs (one round of 8192 envs instead of two of 4096).
+int earl_sawyer_rollout_door_w8(const earl_link_model* model, const earl_collision_model* col, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+                                const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream) {
+  SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
+  sawyer_rollout_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
+  return launched("sawyer_rollout (door, 8 waves per CU)");
+}
+#else
+int earl_sawyer_rollout_door_w8(const earl_link_model* model, const earl_collision_model* col, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+                                const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream);      // physics_w8.hip
 int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model* col, int32_t nv, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                         const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream) {
   if (!model || !cfg || !st || !out || !action || T < 0 || cfg->n < 0) return EARL_ERR_ARG;
@@ -1565,6 +1604,8 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
   SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
   if (cfg->obj_kind >= 1 && cfg->reward_type != 0 && (!st->obj_init || cfg->att_grasp < 0 || cfg->att_lpad < 0 || cfg->att_rpad < 0))
     return EARL_ERR_ARG;                                  // the peg's dense reward needs the reset-time state and the pad / grasp attachments
+  if (nv == 10 && g_lpe != 64 && (g_door_variant == 2 || (g_door_variant == 0 && cfg->n > 4096)))
+    return earl_sawyer_rollout_door_w8(model, col, cfg, st, action, T, out, stream);      // eight waves per CU: wins from two rounds of 4096 envs on
   if (nv == 10) {
     if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<grid_for<10, 64>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
     else sawyer_rollout_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
@@ -1632,5 +1673,12 @@ int earl_physics_model_size(void) { return (int)sizeof(earl_link_model); }
 int earl_physics_model24_size(void) { return (int)sizeof(earl_link_model24); }
 int earl_collision_model_size(void) { return (int)sizeof(earl_collision_model); }
 int earl_sawyer_cfg_size(void) { return (int)sizeof(earl_sawyer_cfg); }
+
+int earl_debug_set_door_variant(int v) {
+  if (v < 0 || v > 2) return EARL_ERR_ARG;
+  g_door_variant = v;
+  return EARL_OK;
+}
+#endif   // EARL_PHYS_VARIANT_W8
 
 }  // extern "C"

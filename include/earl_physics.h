@@ -246,6 +246,10 @@ int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double*
  * wavefront per env).  Results are identical; DESIGN.md quotes both timings. */
 int earl_debug_set_physics_lanes(int lanes_per_env);
 
+/* measurement / test switch for the door model's rollout: 0 (default) = by batch size (n > 4096: one eight-wave workgroup per CU, see
+ * csrc/physics_w8.hip; otherwise four single-wave workgroups per CU), 1 / 2 force the one or the other.  Results are bit-identical. */
+int earl_debug_set_door_variant(int variant);
+
 /* sizeof(earl_link_model) as compiled into the library (bindings check their struct layout against it) */
 int earl_physics_model_size(void);
 int earl_physics_model24_size(void);

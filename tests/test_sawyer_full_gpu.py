@@ -181,3 +181,28 @@ def test_stale_library_layout_is_refused(monkeypatch):
     earl_sawyer_cfg_size = lib.earl_sawyer_cfg_size
   with pytest.raises(_abi.EarlHipError, match='sizeof'):
     physics.check_layouts(Fake)
+
+
+def test_door_rollout_variants_are_bit_identical():
+  """the door rollout kernel exists in two builds (csrc/physics.hip: four single-wave workgroups per CU; csrc/physics_w8.hip: one eight-wave
+  workgroup per CU, packed matrices, in-LDS factorisations): same outputs and state, bit for bit, incl. a ragged last workgroup and contacts"""
+  import torch
+  from earl_benchmark_amd import _abi
+  lib = _abi.load()
+  n, T = 203, 60
+  acts = actions(T, n, seed=8)
+  acts[:, :, 1] = acts[:, :, 1].abs()           # drive the hands towards the door: contacts
+  res = []
+  try:
+    for variant in (1, 2):
+      assert lib.earl_debug_set_door_variant(variant) == 0
+      env = make('sawyer_door', n, seed=2)
+      env.reset()
+      out = env.rollout(acts)
+      res.append((out, env.unwrapped.qpos.clone(), env.unwrapped.qvel.clone()))
+  finally:
+    lib.earl_debug_set_door_variant(0)
+  for key in ('obs', 'reward', 'done', 'success', 'status'):
+    assert bool((res[0][0][key] == res[1][0][key]).all()), key
+  assert bool((res[0][1] == res[1][1]).all()) and bool((res[0][2] == res[1][2]).all())
+  assert lib.earl_debug_set_door_variant(3) != 0
