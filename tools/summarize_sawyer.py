@@ -18,7 +18,8 @@ stats = newest(os.path.join(OUT, f'prof_{w}_stats', '*', '*_kernel_stats.csv'))
 shutil.copy(stats, os.path.join(PROF, f'{tag}_bench_{w}_kernel_stats.csv'))
 kern = [r for r in csv.DictReader(open(stats)) if 'rollout' in r['Name']][0]
 res = {'workload': w, 'kernel': kern['Name'], 'launches': int(kern['Calls']), 'mean_ms': float(kern['AverageNs']) / 1e6, 'counters': {}}
-for f in sorted(glob.glob(os.path.join(OUT, f'prof_{w}_pmc*', '*', '*_counter_collection.csv'))):
+# one counter file per pass: the NEWEST in each pass directory (gpurun_out/ keeps the files of earlier rounds next to the new ones)
+for f in [newest(os.path.join(d, '*', '*_counter_collection.csv')) for d in sorted(glob.glob(os.path.join(OUT, f'prof_{w}_pmc*'))) if os.path.isdir(d)]:
   agg = collections.defaultdict(list)
   for r in csv.DictReader(open(f)):
     if 'rollout' in r['Kernel_Name']:
