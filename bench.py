@@ -345,17 +345,20 @@ def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8
   achieved = per_launch / (gpu_ms * 1e-3) / 1e9
   prof = sawyer_profile(workload, n, T)
   issue = prof.get('issue') or {}
+  simd_issue = None if not issue else min(1.0, (prof.get('waves_per_simd') or 1) * issue['issue_any'])
   res = {'value': steps * n * T * world / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
          'kernel_ms': gpu_ms, 'timesteps_per_s': steps * n * T * world * 5 / dt, 'diverged_env_steps_last_rollout': diverged,
          'config': {'workload': f'{workload} {a.reward} reward, {n} batched envs per MI355X, reset + fused {T}-step rollout '
                                 f'(5 timesteps per env step) per bench step; own stepper incl. contacts, parity with MuJoCo unpinned',
                     'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
                     'parallelism': f'env-range shard x{world}, no per-step collective'},
-         # the bound of this kernel is instruction issue at low occupancy, not HBM: the roofline is the share of wave cycles that issue
-         'issue_frac': issue.get('issue_any'),
-         'roofline': {'bound': 'issue', 'achieved': issue.get('issue_any'), 'peak': 1.0, 'unit': 'share of wave cycles issuing an instruction '
-                      '(SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)', 'frac': issue.get('issue_any'), 'valu': issue.get('valu'), 'lds': issue.get('lds'),
-                      'scalar': issue.get('scalar'), 'wait': issue.get('wait_any'), 'waves_per_simd': prof.get('waves_per_simd'),
+         # the bound of this kernel is instruction issue, not HBM: the roofline is the share of a SIMD's cycles in which it issues an instruction =
+         # resident waves per SIMD x the share of a wave's cycles that issue (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES), peak 1.0
+         'issue_frac': simd_issue,
+         'roofline': {'bound': 'issue', 'achieved': simd_issue, 'peak': 1.0, 'unit': 'share of SIMD cycles issuing an instruction (waves per SIMD x '
+                      'SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)', 'frac': simd_issue, 'per_wave_issue': issue.get('issue_any'), 'valu': issue.get('valu'),
+                      'lds': issue.get('lds'), 'scalar': issue.get('scalar'), 'wait': issue.get('wait_any'), 'issue_stall': issue.get('wait_inst'),
+                      'waves_per_simd': prof.get('waves_per_simd'),
                       'source': (prof.get('source', '') + ' (static: SQ counters collected by rocprofv3 --pmc in separate runs of this command)') if issue else None,
                       'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
                       'hbm': {'achieved_GBs': achieved, 'frac_of_8TBs': achieved / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': per_launch,
