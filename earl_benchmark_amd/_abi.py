@@ -69,6 +69,20 @@ class SawyerOut(C.Structure):
 STEP_DIVERGED = 1     # EARL_STEP_DIVERGED (include/earl_physics.h)
 
 
+class KitchenCfg(C.Structure):     # struct earl_kitchen_cfg (include/earl_physics.h)
+  _fields_ = [('n', C.c_int32), ('env_offset', C.c_int32), ('horizon', C.c_int32), ('frame_skip', C.c_int32), ('sensor_noise', C.c_int32),
+              ('n_att', C.c_int32), ('site_att', C.c_int32 * 8), ('seed', C.c_uint64), ('counter', C.c_uint64), ('mocap_quat_dev', C.c_void_p)]
+
+
+class KitchenState(C.Structure):   # struct earl_kitchen_state
+  _fields_ = [(k, C.c_void_p) for k in ('qpos', 'qvel', 'mocap_pos', 'goal', 'last_qp_robot', 'att_xpos', 'steps_since_reset', 'fail_count', 'last_obs',
+                                        'action64', 'ctrl9', 'noise', 'qpos_bak', 'qvel_bak', 'sites', 'bad')]
+
+
+class KitchenOut(C.Structure):     # struct earl_kitchen_out
+  _fields_ = [(k, C.c_void_p) for k in ('obs', 'reward', 'done', 'success', 'status')]
+
+
 _P = C.POINTER
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/earl_tabletop.h one to one
 SIGNATURES = {
@@ -106,6 +120,7 @@ SIGNATURES = {
     'earl_sawyer_cfg_size': [],
     'earl_debug_set_physics_lanes': [C.c_int],
     'earl_debug_set_door_variant': [C.c_int],
+    'earl_kitchen_step': [C.c_void_p, C.c_void_p, _P(KitchenParams), _P(KitchenCfg), _P(KitchenState), C.c_void_p, _P(KitchenOut), C.c_void_p],
     'earl_sawyer_rollout': [C.c_void_p, C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_int32, _P(SawyerOut), C.c_void_p],
     'earl_sawyer_reset': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState)] + [C.c_void_p] * 5,
     'earl_sawyer_observe': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_void_p],

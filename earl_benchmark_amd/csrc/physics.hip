@@ -29,6 +29,7 @@
 #include <cstdio>
 
 #include "../../include/earl_physics.h"
+#include "../../include/earl_glue.h"
 #include "philox.h"
 
 #pragma clang fp contract(fast)
@@ -200,9 +201,10 @@ template <int NV> struct Lim {
                                                             // the small model, the only possibility for nv = 23 (a register-resident factor would need 552 VGPRs)
   static constexpr bool CAPS = NV <= 10;                    // edge-vs-capsule blocks compiled in (the door model's handle rods; the peg model has none, and
                                                             // its kernel has no registers to spare: the host side refuses such tables for it)
-  static constexpr int NA = NV == 15 ? 9 : NV;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
+  static constexpr int NA = (NV == 15 || NV == 23) ? 9 : NV;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
                                                             // and free peg are separate trees (checked by the host side); the door model
-                                                            // (9 + 1) is factorised densely -- the split did not pay there
+                                                            // (9 + 1) is factorised densely -- the split did not pay there; the kitchen's arm (7 + 2)
+                                                            // is one tree and each of its 14 fixtures its own (coupled at most in pairs)
   static constexpr bool EXTRAS = NV > 16;                   // dry joint friction, joint springs, force-limited actuators, joint couplings (earl_link_model24)
   static constexpr int LPE = NV > 16 ? 32 : 16;             // lanes per env instance (64 = one wavefront per env: measurement switch for nv <= 16)
 };
@@ -329,6 +331,48 @@ __device__ __forceinline__ void chol_coop(SymLds<NV>& H, const double (&dl)[NV],
     r[j] = si * inv;
     if (isl && l >= j) H.rowl(l, ltri, j) = l == j ? inv : r[j];
     fence();
+  }
+}
+// the same on the leading N x N block only (a model whose first N dofs are one tree and whose other dofs are decoupled from it: the kitchen's arm)
+template <int NV, int N>
+__device__ __forceinline__ void chol_coop_lead(SymLds<NV>& H, const double (&dl)[NV], const int l, const bool isl) {
+  const int ltri = l * (l + 1) / 2;
+  const bool mine = isl && l < N;
+  double r[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) r[j] = H.sym(j, l < N ? l : 0, l < N ? ltri : 0);
+  if (mine) H.rowl(l, ltri, l) = r[l] + dl[l];
+  fence();
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double sj = H.lo(j, j), si = r[j] + (l == j ? dl[l] : 0.0);
+#pragma unroll
+    for (int p = 0; p < j; ++p) {
+      const double pj = H.lo(j, p);
+      sj = fma(-pj, pj, sj);
+      si = fma(-r[p], pj, si);
+    }
+    const double inv = rsq_nr(sj);
+    r[j] = si * inv;
+    if (mine && l >= j) H.rowl(l, ltri, j) = l == j ? inv : r[j];
+    fence();
+  }
+}
+template <int NV, int N>
+__device__ __forceinline__ void solve_lds_lead(const SymLds<NV>& H, double (&x)[NV]) {   // leading block of (L L') x' = x
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = x[i];
+#pragma unroll
+    for (int p = 0; p < i; ++p) s = fma(-H.lo(i, p), x[p], s);
+    x[i] = s * H.lo(i, i);
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = x[i];
+#pragma unroll
+    for (int p = i + 1; p < N; ++p) s = fma(-H.lo(p, i), x[p], s);
+    x[i] = s * H.lo(i, i);
   }
 }
 template <int NV>
@@ -955,7 +999,39 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fence();
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
-    if constexpr (Lim<NV>::COOP) {
+    if constexpr (Lim<NV>::EXTRAS) {
+      if (coupled) {                                   // a finger touches a fixture (uniform over the wave): dense shared factorisation
+        chol_coop<NV>(s.con.Hc, s.con.dl, l, isl);
+        solve_lds<NV>(s.con.Hc, a);
+      } else {
+        // no contact joins the arm and the fixtures: the Hessian is the arm's NA x NA block plus, per fixture, a scalar or -- for the
+        // knob / burner and switch / light couplings -- a 2 x 2 block with its partner (earl_link_model24.pair)
+        chol_coop_lead<NV, NA>(s.con.Hc, s.con.dl, l, isl);
+        if (isl && l >= NA) {
+          const int p = m.pair[l];
+          const double d = s.con.Hc.lo(l, l) + s.con.dl[l];
+          double x;
+          if (p >= 0) {
+            const int hi = l > p ? l : p, lo_ = l > p ? p : l;
+            const double o = s.con.Hc.lo(hi, lo_), dp = s.con.Hc.lo(p, p) + s.con.dl[p];
+            double gl = 0, gp = 0;
+#pragma unroll
+            for (int i = NA; i < NV; ++i) { gl = i == l ? a[i] : gl; gp = i == p ? a[i] : gp; }
+            x = (dp * gl - o * gp) * rcp_nr(d * dp - o * o);
+          } else {
+            double gl = 0;
+#pragma unroll
+            for (int i = NA; i < NV; ++i) gl = i == l ? a[i] : gl;
+            x = gl * rcp_nr(d);
+          }
+          s.con.rc[l] = x;                              // (every lane already holds the right-hand side in a[])
+        }
+        solve_lds_lead<NV, NA>(s.con.Hc, a);
+        fence();
+#pragma unroll
+        for (int i = NA; i < NV; ++i) a[i] = s.con.rc[i];
+      }
+    } else if constexpr (Lim<NV>::COOP) {
       chol_coop<NV>(s.con.Hc, s.con.dl, l, isl);
       solve_lds<NV>(s.con.Hc, a);
     } else if constexpr (NA == NV) {                   // small model: dense, in registers
@@ -1044,7 +1120,19 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     // into an fma, in chol_coop it is a rounded product -- the two door builds must agree to the bit
     if (isl) s.con.dl[l] = dt * m.damping[l];
     fence();
-    if constexpr (Lim<NV>::COOP) {                     // M is rebuilt next timestep: factorise it in place
+    if constexpr (Lim<NV>::EXTRAS) {                   // the mass matrix is ALWAYS the arm's block + one scalar per fixture
+      chol_coop_lead<NV, NA>(s.M, s.con.dl, l, isl);
+      if (isl && l >= NA) {
+        double gl = 0;
+#pragma unroll
+        for (int i = NA; i < NV; ++i) gl = i == l ? a[i] : gl;
+        s.con.rc[l] = gl * rcp_nr(s.M.lo(l, l) + s.con.dl[l]);
+      }
+      solve_lds_lead<NV, NA>(s.M, a);
+      fence();
+#pragma unroll
+      for (int i = NA; i < NV; ++i) a[i] = s.con.rc[i];
+    } else if constexpr (Lim<NV>::COOP) {              // M is rebuilt next timestep: factorise it in place
       chol_coop<NV>(s.M, s.con.dl, l, isl);
       solve_lds<NV>(s.M, a);
     } else {
@@ -1142,6 +1230,8 @@ struct PArgs {
   double* qpos; double* qvel;
   const double* mocap_pos; const double* mocap_quat; const double* ctrl;
   double* att_xpos; double* qacc_out; double* efc_out;
+  int ctrl_stride;               // doubles per env in `ctrl` (0: n_act; the kitchen hands over its nine position targets, of which the first n_act = 2 count)
+  int mq_stride;                 // doubles per env in `mocap_quat` (0: ONE quaternion for the whole batch; else 4)
 };
 
 template <int NV, int LPE, bool INTEGRATE>
@@ -1160,9 +1250,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
   load_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
   fence();
   const V3 mpos = ld3(a.mocap_pos + (size_t)env * 3);
-  const Q4 mq = ldq(a.mocap_quat + (size_t)env * 4);      // as given, NOT normalised (include/earl_physics.h)
+  const Q4 mq = ldq(a.mocap_quat + (size_t)env * a.mq_stride);      // as given, NOT normalised (include/earl_physics.h)
   double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
-  for (int ac = 0; ac < m.n_act; ++ac) ctrl[ac] = a.ctrl[(size_t)env * m.n_act + ac];
+  for (int ac = 0; ac < m.n_act; ++ac) ctrl[ac] = a.ctrl[(size_t)env * (a.ctrl_stride ? a.ctrl_stride : m.n_act) + ac];
   constexpr int NC = 6 + 2 * NV;
   for (int ts = 0; ts < a.nsub; ++ts)
     substep<NV, LPE, INTEGRATE>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, (a.qacc_out && live) ? a.qacc_out + (size_t)env * NV : nullptr,
@@ -1527,6 +1617,58 @@ __global__ void sawyer_door_reward_kernel(const int n, const double* __restrict_
 }
 #endif
 
+#ifndef EARL_PHYS_VARIANT_W8
+// ------------------------------------------------------------------------------------------------ kitchen env step (include/earl_physics.h)
+// small per-env kernels around the stepper; the numpy glue of the reference (action scaling, observation noise, reward) stays in csrc/glue.hip
+struct KitchenArgs {
+  earl_kitchen_cfg cfg;
+  earl_kitchen_state st;
+  earl_kitchen_out out;
+  const float* action;
+  int n_att;
+};
+// before the stepper: the float32 action promoted to float64 (np.clip keeps float32; the reference's scaling then promotes), the state saved
+__global__ void kitchen_pre_kernel(const KitchenArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.cfg.n * 23) return;
+  const int e = i / 23, j = i % 23;
+  a.st.qpos_bak[i] = a.st.qpos[i];
+  a.st.qvel_bak[i] = a.st.qvel[i];
+  if (j < 9) a.st.action64[e * 9 + j] = (double)a.action[e * 9 + j];
+}
+// after the stepper: failure guard (roll a diverged env back), the eight task sites gathered for the reward
+__global__ void kitchen_guard_kernel(const KitchenArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.cfg.n) return;
+  bool bad = false;
+  for (int j = 0; j < 23; ++j) bad = bad || !(fabs(a.st.qpos[e * 23 + j]) < EARL_BAD_VALUE) || !(fabs(a.st.qvel[e * 23 + j]) < EARL_BAD_VALUE);
+  if (bad) {
+    for (int j = 0; j < 23; ++j) { a.st.qpos[e * 23 + j] = a.st.qpos_bak[e * 23 + j]; a.st.qvel[e * 23 + j] = a.st.qvel_bak[e * 23 + j]; }
+    if (a.st.fail_count) a.st.fail_count[e] += 1;
+  }
+  if (a.out.status) a.out.status[e] = bad ? EARL_STEP_DIVERGED : 0;
+  a.st.bad[e] = bad ? 1 : 0;
+  for (int k = 0; k < 8; ++k)
+    for (int c = 0; c < 3; ++c) a.st.sites[(e * 8 + k) * 3 + c] = a.st.att_xpos[(e * a.n_att + a.cfg.site_att[k]) * 3 + c];
+}
+// last: the observation / reward / flags of the step (a rolled-back env returns its last stable observation, reward 0), wrapper bookkeeping
+__global__ void kitchen_finish_kernel(const KitchenArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.cfg.n) return;
+  const bool bad = a.st.bad[e] != 0;
+  for (int k = 0; k < 46; ++k) {
+    const double v = bad ? a.st.last_obs[e * 46 + k] : a.out.obs[e * 46 + k];
+    a.out.obs[e * 46 + k] = v;
+    a.st.last_obs[e * 46 + k] = v;
+    if (k < 9 && !bad) a.st.last_qp_robot[e * 9 + k] = v;          // the newest cached (noisy) robot joint readings
+  }
+  if (bad) { a.out.reward[e] = 0.0; a.out.success[e] = 0; }
+  const int steps = a.st.steps_since_reset[e] + 1;
+  a.st.steps_since_reset[e] = steps;
+  a.out.done[e] = (a.cfg.horizon > 0 && steps >= a.cfg.horizon) ? 1 : 0;
+}
+#endif
+
 int launched(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -1560,7 +1702,7 @@ int earl_physics_step(const void* model, const earl_collision_model* col, int32_
                       earl_stream_t stream) {
   if (!model || n < 0 || nsub < 0 || !qpos || !qvel || !mocap_pos || !mocap_quat || !ctrl) return EARL_ERR_ARG;
   if (n == 0 || nsub == 0) return EARL_OK;
-  PArgs a{model, col, n, nsub, qpos, qvel, mocap_pos, mocap_quat, ctrl, att_xpos, nullptr, nullptr};
+  PArgs a{model, col, n, nsub, qpos, qvel, mocap_pos, mocap_quat, ctrl, att_xpos, nullptr, nullptr, 0, 4};
   if (nv == 10) launch_physics<10, true>(a, (hipStream_t)stream);
   else if (nv == 15) launch_physics<15, true>(a, (hipStream_t)stream);
   else if (nv == 23) launch_physics<23, true>(a, (hipStream_t)stream);
@@ -1573,7 +1715,7 @@ int earl_physics_forward(const void* model, const earl_collision_model* col, int
                          double* efc_force, double* att_xpos, earl_stream_t stream) {
   if (!model || n < 0 || !qpos || !qvel || !mocap_pos || !mocap_quat || !ctrl || !qacc) return EARL_ERR_ARG;
   if (n == 0) return EARL_OK;
-  PArgs a{model, col, n, 1, const_cast<double*>(qpos), const_cast<double*>(qvel), mocap_pos, mocap_quat, ctrl, att_xpos, qacc, efc_force};
+  PArgs a{model, col, n, 1, const_cast<double*>(qpos), const_cast<double*>(qvel), mocap_pos, mocap_quat, ctrl, att_xpos, qacc, efc_force, 0, 4};
   if (nv == 10) launch_physics<10, false>(a, (hipStream_t)stream);
   else if (nv == 15) launch_physics<15, false>(a, (hipStream_t)stream);
   else if (nv == 23) launch_physics<23, false>(a, (hipStream_t)stream);
@@ -1650,6 +1792,33 @@ int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double*
   if (n == 0) return EARL_OK;
   sawyer_door_reward_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, obs, *cfg, reward, success);
   return launched("sawyer_door_reward");
+}
+
+int earl_kitchen_step(const void* model, const earl_collision_model* col, const earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
+                      const earl_kitchen_state* st, const float* action, const earl_kitchen_out* out, earl_stream_t stream) {
+  if (!model || !params || !cfg || !st || !action || !out || cfg->n < 0 || cfg->n_att < 10 || cfg->frame_skip < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !st->last_qp_robot || !st->att_xpos || !st->steps_since_reset || !st->last_obs) return EARL_ERR_ARG;
+  if (!st->action64 || !st->ctrl9 || !st->qpos_bak || !st->qvel_bak || !st->sites || !st->bad || (cfg->sensor_noise && !st->noise)) return EARL_ERR_ARG;
+  if (!out->obs || !out->reward || !out->done || !out->success) return EARL_ERR_ARG;
+  for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
+  const int n = cfg->n;
+  if (n == 0) return EARL_OK;
+  const hipStream_t hs = (hipStream_t)stream;
+  KitchenArgs k{*cfg, *st, *out, action, cfg->n_att};
+  kitchen_pre_kernel<<<(n * 23 + 255) / 256, 256, 0, hs>>>(k);
+  // KitchenV0.step up to do_simulation: mocap target, the nine position targets (csrc/glue.hip)
+  if (int rc = earl_kitchen_action(n, params, st->action64, st->mocap_pos, st->last_qp_robot, st->ctrl9, stream)) return rc;
+  // do_simulation: ctrl[i] = targets[i] for i < nu = 2, frame_skip timesteps (adept_envs/mujoco_env.py:148-157)
+  PArgs a{model, col, n, cfg->frame_skip, st->qpos, st->qvel, st->mocap_pos, cfg->mocap_quat_dev, st->ctrl9, st->att_xpos, nullptr, nullptr, 9, 0};
+  launch_physics<23, true>(a, hs);
+  kitchen_guard_kernel<<<(n + 255) / 256, 256, 0, hs>>>(k);
+  // Robot.get_obs + KitchenV0._get_obs: sensor noise from Philox draws keyed by the global env id
+  if (cfg->sensor_noise)
+    if (int rc = earl_philox_uniform(n, 46, cfg->seed, cfg->counter, cfg->env_offset, 0x4B00u, -1.0, 1.0, st->noise, stream)) return rc;
+  if (int rc = earl_kitchen_obs(n, params, st->qpos, st->goal, cfg->sensor_noise ? st->noise : nullptr, out->obs, stream)) return rc;
+  if (int rc = earl_kitchen_reward(n, out->obs, st->mocap_pos, st->sites, out->reward, out->success, stream)) return rc;
+  kitchen_finish_kernel<<<(n + 255) / 256, 256, 0, hs>>>(k);
+  return launched("kitchen_step");
 }
 
 int earl_debug_set_physics_lanes(int lanes_per_env) {

@@ -38,9 +38,8 @@ INIT_QPOS = np.array([1.48388023e-01, -1.76848573e+00, 1.84390296e+00, -2.476857
 STREAM_NOISE, STREAM_RESET = 0x4B00, 0x4B80               # Philox stream ids (csrc/glue.hip earl_philox_uniform)
 
 
-class _Cfg:
-  """the two wrapper-controlled numbers (wrappers.py sets them the way it does for the other envs)"""
-  horizon = INT32_MAX
+class _Cfg(_abi.KitchenCfg):
+  """struct earl_kitchen_cfg + the lifelong wrapper's number (wrappers.py sets `horizon` and `goal_change_frequency` the way it does for the other envs)"""
   goal_change_frequency = 0
 
 
@@ -66,7 +65,6 @@ class Kitchen:
       raise ValueError('scalar_api needs num_envs == 1')
     self._seed, self._env_offset, self._counter = int(seed) & (2**64 - 1), int(env_offset), 0
     self.sensor_noise = bool(sensor_noise)
-    self._cfg = _Cfg()
     self._params = glue.kitchen_params()
     self._initial_states = tables.initial_states('kitchen')                     # kitchen.py:57-85, the 6 'all_pairs' rows
     self._goal_states = tables.goal_states('kitchen')
@@ -89,6 +87,16 @@ class Kitchen:
     self.steps_since_goal_change = torch.zeros(n, dtype=torch.int32, device=dev)
     self.total_step_count = 0
     self.last_obs = torch.zeros(n, self.OBS_DIM, **kw)
+    # scratch of earl_kitchen_step (caller-owned like the state) and its argument structs
+    self._scr = dict(action64=torch.zeros(n, 9, **kw), ctrl9=torch.zeros(n, 9, **kw), noise=torch.zeros(n, 46, **kw), qpos_bak=torch.zeros(n, self.NV, **kw),
+                     qvel_bak=torch.zeros(n, self.NV, **kw), sites=torch.zeros(n, 8, 3, **kw), bad=torch.zeros(n, dtype=torch.uint8, device=dev))
+    self._mq1 = self.mocap_quat[0].clone().contiguous()
+    self._cfg = _Cfg(n=n, env_offset=self._env_offset, horizon=INT32_MAX, frame_skip=FRAME_SKIP, sensor_noise=int(self.sensor_noise), n_att=self.model.n_att,
+                     seed=self._seed, counter=0, mocap_quat_dev=self._mq1.data_ptr())
+    self._cfg.site_att[:] = [names.index(s) for s in glue.KITCHEN_SITES]
+    self._st = _abi.KitchenState(qpos=self.qpos.data_ptr(), qvel=self.qvel.data_ptr(), mocap_pos=self.mocap_pos.data_ptr(), goal=self.goal_t.data_ptr(),
+                                 last_qp_robot=self.last_qp_robot.data_ptr(), att_xpos=self.att.data_ptr(), steps_since_reset=self.steps_since_reset.data_ptr(),
+                                 fail_count=self.fail_count.data_ptr(), last_obs=self.last_obs.data_ptr(), **{k: v.data_ptr() for k, v in self._scr.items()})
     self.action_space = Box(-1.0, 1.0, (self.N_ROBOT,), np.float32)              # kitchen_multitask_v0.py:78-80
     self.observation_space = Box(-8.0, 8.0, (self.OBS_DIM,), np.float64)         # :82-84
     with torch.cuda.device(dev):
@@ -164,28 +172,23 @@ class Kitchen:
     self._counter += 1
     return obs[0].cpu().numpy() if self.scalar_api else obs
 
-  def step(self, action, b=None):
+  def step(self, action, b=None, out=None):
+    """one env step of every env: ONE call of earl_kitchen_step (eight launches on the caller's stream, include/earl_physics.h)"""
     del b
     n = self.num_envs
     with torch.cuda.device(self.device):
       a = torch.as_tensor(np.asarray(action, dtype=np.float32) if not torch.is_tensor(action) else action, device=self.device)
-      a = a.to(torch.float32).reshape(n, self.N_ROBOT).to(torch.float64)         # np.clip keeps float32, the scaling promotes (glue.hip)
-      ctrl9 = glue.kitchen_action(a, self.mocap_pos, self.last_qp_robot, self._params)
-      ctrl = ctrl9[:, :2].contiguous()                                           # MujocoEnv.do_simulation: ctrl[i] for i < nu = 2 (mujoco_env.py:148-157)
-      q0, v0 = self.qpos.clone(), self.qvel.clone()
-      self.model.step(self.qpos, self.qvel, self.mocap_pos, self.mocap_quat, ctrl, nsub=FRAME_SKIP, att_xpos=self.att)
-      # failure guard (adept's _mj_warning_fn only prints; here a diverged env is rolled back and flagged, like the Sawyer kernels do)
-      bad = ~(torch.isfinite(self.qpos).all(1) & torch.isfinite(self.qvel).all(1) & (self.qvel.abs() < 1e10).all(1) & (self.qpos.abs() < 1e10).all(1))
-      self.qpos[bad], self.qvel[bad] = q0[bad], v0[bad]
-      self.fail_count += bad.to(torch.int32)
-      obs = self._observe(noise=True)
-      rew, suc = self._reward(obs)
-      obs = torch.where(bad[:, None], self.last_obs, obs)
-      rew = torch.where(bad, torch.zeros_like(rew), rew)
-      suc = suc & ~bad
-      self.last_obs.copy_(obs)
-      self.steps_since_reset += 1
-      done = self.steps_since_reset >= self._cfg.horizon
+      a = a.to(torch.float32).reshape(n, self.N_ROBOT).contiguous()
+      if out is None:
+        out = dict(obs=torch.empty(n, self.OBS_DIM, dtype=torch.float64, device=self.device), reward=torch.empty(n, dtype=torch.float64, device=self.device),
+                   done=torch.empty(n, dtype=torch.bool, device=self.device), success=torch.empty(n, dtype=torch.bool, device=self.device),
+                   status=torch.empty(n, dtype=torch.uint8, device=self.device))
+      o = _abi.KitchenOut(obs=out['obs'].data_ptr(), reward=out['reward'].data_ptr(), done=out['done'].data_ptr(), success=out['success'].data_ptr(),
+                          status=out['status'].data_ptr())
+      self._cfg.counter = self._counter
+      _abi.check(self._lib.earl_kitchen_step(self.model.buf.data_ptr(), self.model.col_ptr, C.byref(self._params), C.byref(self._cfg), C.byref(self._st),
+                                             a.data_ptr(), C.byref(o), self._stream()), 'earl_kitchen_step')
+      obs, rew, done, suc = out['obs'], out['reward'], out['done'], out['success']
       gcf = int(self._cfg.goal_change_frequency)
       if gcf > 0:                                                                # LifelongWrapper.step (lifelong_wrapper.py:30-44)
         self.lifelong_return_t += rew
@@ -199,7 +202,7 @@ class Kitchen:
     self._last_success = suc
     if self.scalar_api:
       return obs[0].cpu().numpy(), float(rew[0]), bool(done[0]), {}
-    return obs, rew, done, {'success': suc, 'status': bad.to(torch.uint8)}
+    return obs, rew, done, {'success': suc, 'status': out['status']}
 
   def rollout(self, actions, out=None):
     """T steps: actions [T, N, 9] -> dict(obs [T,N,46], reward [T,N], done, success, status)"""

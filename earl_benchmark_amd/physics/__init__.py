@@ -51,7 +51,8 @@ class LinkModelStruct24(C.Structure):   # struct earl_link_model24: up to 24 dof
               ('gravity', C.c_double * 3), ('dt', C.c_double), ('drag_G', C.c_double * MAXV24), ('drag_b', C.c_double * MAXV24),
               ('cd_mask', C.c_uint32 * MAXV24), ('frictionloss', C.c_double * MAXV24), ('stiffness', C.c_double * MAXV24),
               ('springref', C.c_double * MAXV24), ('act_forcerange', C.c_double * 2 * MAXACT), ('jeq_coef', C.c_double * 2 * MAXJEQ),
-              ('jeq_solref', C.c_double * 2 * MAXJEQ), ('jeq_solimp', C.c_double * 5 * MAXJEQ), ('jeq_invweight', C.c_double * MAXJEQ)]
+              ('jeq_solref', C.c_double * 2 * MAXJEQ), ('jeq_solimp', C.c_double * 5 * MAXJEQ), ('jeq_invweight', C.c_double * MAXJEQ),
+              ('pair', C.c_int32 * MAXV24)]
 
 
 class PairRec(C.Structure):
@@ -143,6 +144,14 @@ def load_link_model(name):
                      (s.act_forcerange, fr), (s.jeq_joint1, d['jeq_joint1']), (s.jeq_joint2, d['jeq_joint2']), (s.jeq_coef, d['jeq_coef']),
                      (s.jeq_solref, d['jeq_solref']), (s.jeq_solimp, d['jeq_solimp']), (s.jeq_invweight, d['jeq_invweight'])):
       _fill(dst, src)
+    # structure the kernel's solver relies on: the first 9 dofs are one tree (the arm), every other dof is its own tree, couplings tie
+    # fixtures in disjoint pairs
+    pair = np.full(MAXV24, -1, np.int32)
+    for j1, j2 in zip(d['jeq_joint1'], d['jeq_joint2']):
+      assert pair[j1] < 0 and pair[j2] < 0 and j1 >= 9 and j2 >= 9
+      pair[j1], pair[j2] = j2, j1
+    assert nv == 23 and all(int(d['parent'][l]) == (l - 1 if 0 < l < 7 else (6 if l in (7, 8) else -1)) for l in range(nv)), 'kitchen tree shape'
+    _fill(s.pair, pair)
   else:
     assert not np.any(d.get('jnt_frictionloss', 0)) and not np.any(d.get('jnt_stiffness', 0)) and len(d.get('jeq_joint1', ())) == 0, \
         'dry friction / springs / joint couplings need the 24-dof model form'

@@ -89,6 +89,8 @@ typedef struct earl_link_model24 {
   double stiffness[EARL_MAXV24], springref[EARL_MAXV24];   /* joint spring: passive force -stiffness (q - springref) */
   double act_forcerange[EARL_MAXACT][2];       /* force-limited actuators: kp (ctrl - q) clamped to this range (+-inf: not limited) */
   double jeq_coef[EARL_MAXJEQ][2], jeq_solref[EARL_MAXJEQ][2], jeq_solimp[EARL_MAXJEQ][5], jeq_invweight[EARL_MAXJEQ];
+  int32_t pair[EARL_MAXV24];                   /* the dof a coupling ties this dof to, -1 = none: dofs beyond the first tree (the arm: the first 9) are
+                                                  their own trees, so without contacts the constraint Hessian is the arm's block plus 2 x 2 / 1 x 1 blocks */
 } earl_link_model24;
 
 /* Collision geometry of a link model: SPHERES (cylinders are chains of spheres; box corners are spheres of radius 0)
@@ -245,6 +247,51 @@ int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double*
 /* measurement switch: lanes of a wavefront that work on one env instance -- 16 (default: four envs per wavefront) or 64 (one
  * wavefront per env).  Results are identical; DESIGN.md quotes both timings. */
 int earl_debug_set_physics_lanes(int lanes_per_env);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Kitchen env step (BASELINE configs[3]).  Replaces, per env instance, PersistentStateWrapper.step
+ * (wrappers/persistent_state_wrapper.py:17-31) o Kitchen.step (envs/kitchen.py:185-187) o KitchenV0.step
+ * (envs/kitchen_assets/adept_envs/adept_envs/franka/kitchen_multitask_v0.py:91-125): action clip / scale and mocap update (:92-102), Robot.step
+ * (franka/robot/franka_robot.py:178-207: velocity-limited position targets, do_simulation = frame_skip x mj_step with ctrl = the first nu = 2
+ * targets), _get_obs with sensor noise (:127-139, franka_robot.py:137-168), Kitchen._get_reward_n_score / is_successful (kitchen.py:141-183).
+ * The launches go to `stream` in order: promote + save, earl_kitchen_action, the nv = 23 stepper, failure guard, noise, earl_kitchen_obs,
+ * earl_kitchen_reward, bookkeeping.  Everything is caller-owned device memory, scratch included. */
+struct earl_kitchen_params;      /* include/earl_glue.h */
+typedef struct earl_kitchen_cfg {
+  int32_t n, env_offset;
+  int32_t horizon;               /* <= 0: never done */
+  int32_t frame_skip;            /* 40 (kitchen_multitask_v0.py:40) */
+  int32_t sensor_noise;          /* 0: observations without noise (the reference's `initializing` mode) */
+  int32_t n_att;                 /* attachments of the model (rows of st.att_xpos per env) */
+  int32_t site_att[8];           /* attachment indices of knob1..4_site, light_site, slide_site, hinge_site2, microhandle_site (kitchen.py:148-155) */
+  uint64_t seed, counter;        /* noise draws: Philox(seed; 0x4B00 + j / 2, global env id, counter) */
+  const double* mocap_quat_dev;  /* device, [4]: the mocap body's (constant) orientation, used as given */
+} earl_kitchen_cfg;
+typedef struct earl_kitchen_state {
+  double* qpos; double* qvel;    /* [n, 23] */
+  double* mocap_pos;             /* [n, 3] */
+  const double* goal;            /* [n, 23] */
+  double* last_qp_robot;         /* [n, 9] robot joints of the newest (noisy) observation: Robot_VelAct.ctrl_velocity_limits starts from them */
+  double* att_xpos;              /* [n, n_att, 3] attachment positions the stepper leaves (kinematics of the last timestep's start) */
+  int32_t* steps_since_reset;    /* [n] */
+  int32_t* fail_count;           /* [n] may be NULL */
+  double* last_obs;              /* [n, 46] */
+  /* scratch, caller-owned like everything else: */
+  double* action64;              /* [n, 9] */
+  double* ctrl9;                 /* [n, 9] */
+  double* noise;                 /* [n, 46] (may be NULL when sensor_noise == 0) */
+  double* qpos_bak; double* qvel_bak;   /* [n, 23] the state a diverged step is rolled back to */
+  double* sites;                 /* [n, 8, 3] */
+  uint8_t* bad;                  /* [n] */
+} earl_kitchen_state;
+typedef struct earl_kitchen_out {
+  double* obs;                   /* [n, 46] */
+  double* reward;                /* [n] float64, like the reference's */
+  uint8_t* done; uint8_t* success;
+  uint8_t* status;               /* [n] may be NULL: EARL_STEP_DIVERGED as in earl_sawyer_out */
+} earl_kitchen_out;
+int earl_kitchen_step(const void* model24, const earl_collision_model* col, const struct earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
+                      const earl_kitchen_state* st, const float* action /* [n, 9] */, const earl_kitchen_out* out, earl_stream_t stream);
 
 /* measurement / test switch for the door model's rollout: 0 (default) = by batch size (n > 4096: one eight-wave workgroup per CU, see
  * csrc/physics_w8.hip; otherwise four single-wave workgroups per CU), 1 / 2 force the one or the other.  Results are bit-identical. */

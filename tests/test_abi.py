@@ -52,7 +52,8 @@ def test_every_struct_layout_matches_what_gcc_sees(tmp_path):
   from earl_benchmark_amd.physics import CollisionModelStruct, LinkModelStruct, LinkModelStruct24
   mirrors = {'earl_tabletop_cfg': _abi.TabletopCfg, 'earl_tabletop_state': _abi.TabletopState, 'earl_tabletop_out': _abi.TabletopOut,
              'earl_motor_params': _abi.MotorParams, 'earl_kitchen_params': _abi.KitchenParams, 'earl_link_model': LinkModelStruct, 'earl_link_model24': LinkModelStruct24, 'earl_collision_model': CollisionModelStruct, 'earl_sawyer_cfg': _abi.SawyerCfg,
-             'earl_sawyer_state': _abi.SawyerState, 'earl_sawyer_out': _abi.SawyerOut}
+             'earl_sawyer_state': _abi.SawyerState, 'earl_sawyer_out': _abi.SawyerOut, 'earl_kitchen_cfg': _abi.KitchenCfg,
+             'earl_kitchen_state': _abi.KitchenState, 'earl_kitchen_out': _abi.KitchenOut}
   lines = []
   for cname, cls in mirrors.items():
     lines.append(f'printf("{cname} %zu", sizeof({cname}));')
