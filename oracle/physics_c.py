@@ -30,8 +30,9 @@ class CModel:
     mp, mq, ct = (np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.float64), (n, k))) for x, k in ((mocap_pos, 3), (mocap_quat, 4), (ctrl, self.n_act)))
     qacc, efc = np.zeros((n, self.nv)), np.zeros((n, 6 + 2 * self.nv))
     att, ncon = np.zeros((n, self.n_att, 3)), np.zeros(n, np.int32)
-    lib().oracle_physics(C.byref(self.struct), self._col(), C.c_int32(n), C.c_int32(nsub), C.c_int32(int(integrate)), _p(q), _p(v), _p(mp),
-                         _p(mq), _p(ct), _p(qacc), _p(efc), _p(att), _p(ncon))
+    fn = lib().oracle_physics24 if self.nv > 16 else lib().oracle_physics      # the kitchen's 24-dof table form / the Sawyer envs' 16-dof one
+    fn(C.byref(self.struct), self._col(), C.c_int32(n), C.c_int32(nsub), C.c_int32(int(integrate)), _p(q), _p(v), _p(mp),
+       _p(mq), _p(ct), _p(qacc), _p(efc), _p(att), _p(ncon))
     return dict(qpos=q, qvel=v, qacc=qacc, efc=efc, att=att, ncon=ncon)
 
   def sawyer_rollout(self, cfg_kwargs, qpos, qvel, mocap_pos, goal, steps_since_reset, actions, steps_since_goal_change=None, goal_table=None,

@@ -16,8 +16,31 @@
 
 #include "../include/earl_physics.h"
 
-#define NVMAX EARL_MAXV
-#define NROWMAX (6 + 2 * EARL_MAXV + 4 * EARL_MAXCON)
+#define NVMAX EARL_MAXV24
+#define NROWMAX (6 + 2 * EARL_MAXV24 + EARL_MAXV24 + EARL_MAXJEQ + 4 * EARL_MAXCON)
+
+/* The stepper below works on the 24-dof table form (earl_link_model24: the kitchen's, with dry friction / springs / force limits / joint
+ * couplings); a 16-dof model (the Sawyer envs') is widened into it first -- the extras empty. */
+typedef earl_link_model24 LM;
+static void widen(const earl_link_model* s, LM* d) {
+  memset(d, 0, sizeof(*d));
+  d->nv = s->nv; d->n_att = s->n_att; d->n_act = s->n_act; d->weld_att = s->weld_att; d->n_jump = s->n_jump; d->ball_dof = s->ball_dof; d->nq = s->nq; d->n_jeq = 0;
+  for (int l = 0; l < EARL_MAXV; ++l) {
+    d->parent[l] = s->parent[l]; d->jtype[l] = s->jtype[l]; d->limited[l] = s->limited[l]; d->anc_mask[l] = s->anc_mask[l]; d->desc_mask[l] = s->desc_mask[l];
+    d->cd_mask[l] = s->cd_mask[l]; d->mass[l] = s->mass[l]; d->damping[l] = s->damping[l]; d->armature[l] = s->armature[l]; d->dof_invweight[l] = s->dof_invweight[l];
+    d->drag_G[l] = s->drag_G[l]; d->drag_b[l] = s->drag_b[l]; d->pair[l] = -1;
+    memcpy(d->tpos[l], s->tpos[l], sizeof(s->tpos[l])); memcpy(d->tquat[l], s->tquat[l], sizeof(s->tquat[l])); memcpy(d->jaxis[l], s->jaxis[l], sizeof(s->jaxis[l]));
+    memcpy(d->jpos[l], s->jpos[l], sizeof(s->jpos[l])); memcpy(d->com[l], s->com[l], sizeof(s->com[l])); memcpy(d->inertia[l], s->inertia[l], sizeof(s->inertia[l]));
+    memcpy(d->range[l], s->range[l], sizeof(s->range[l])); memcpy(d->jsolref[l], s->jsolref[l], sizeof(s->jsolref[l])); memcpy(d->jsolimp[l], s->jsolimp[l], sizeof(s->jsolimp[l]));
+  }
+  for (int k = 0; k < EARL_MAXATT; ++k) { d->att_link[k] = s->att_link[k]; memcpy(d->att_pos[k], s->att_pos[k], sizeof(s->att_pos[k])); memcpy(d->att_quat[k], s->att_quat[k], sizeof(s->att_quat[k])); }
+  for (int a = 0; a < EARL_MAXACT; ++a) {
+    d->act_joint[a] = s->act_joint[a]; d->act_kp[a] = s->act_kp[a]; d->act_ctrlrange[a][0] = s->act_ctrlrange[a][0]; d->act_ctrlrange[a][1] = s->act_ctrlrange[a][1];
+    d->act_forcerange[a][0] = -1e300; d->act_forcerange[a][1] = 1e300;
+  }
+  memcpy(d->weld_solref, s->weld_solref, sizeof(s->weld_solref)); memcpy(d->weld_solimp, s->weld_solimp, sizeof(s->weld_solimp));
+  memcpy(d->weld_invweight, s->weld_invweight, sizeof(s->weld_invweight)); memcpy(d->gravity, s->gravity, sizeof(s->gravity)); d->dt = s->dt;
+}
 
 typedef struct { double w, x, y, z; } Q4;
 typedef struct { double x, y, z; } V3;
@@ -108,7 +131,7 @@ static Q4 qnormalize(Q4 q) {
 
 /* one timestep (integrate != 0) or the forward quantities only; reference: LinkModel.forward / step.
  * qp is a qpos row [nq] (the free body's quaternion at [ball_dof, ball_dof + 4)), qv a qvel row [nv]. */
-static void substep(const earl_link_model* m, const earl_collision_model* col, double* qp, double* qv, V3 mpos, Q4 mq, const double* ctrl,
+static void substep(const LM* m, const earl_collision_model* col, double* qp, double* qv, V3 mpos, Q4 mq, const double* ctrl,
                     int integrate, StepOut* o) {
   const int nv = m->nv;
   const double dt = m->dt;
@@ -210,12 +233,12 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
     for (int l = 0; l < nv; ++l) {
       double bias = 0;
       for (int e = 0; e < 6; ++e) bias += S[l][e] * F[l][e];
-      tau[l] = -m->damping[l] * qv[l] - bias;
+      tau[l] = -m->damping[l] * qv[l] - bias - m->stiffness[l] * (qp[l] - m->springref[l]);     /* (+ joint spring, mj_passive) */
     }
     for (int ac = 0; ac < m->n_act; ++ac) {
       const int j = m->act_joint[ac];
       const double c = fmin(fmax(ctrl[ac], m->act_ctrlrange[ac][0]), m->act_ctrlrange[ac][1]);
-      tau[j] += m->act_kp[ac] * (c - qp[j]);
+      tau[j] += fmin(fmax(m->act_kp[ac] * (c - qp[j]), m->act_forcerange[ac][0]), m->act_forcerange[ac][1]);   /* forcelimited actuator */
     }
   }
   /* constraint rows */
@@ -272,6 +295,27 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
     if (m->drag_G[j] != 0) {                        /* soft velocity row of a permanent dragging contact */
       J[nr][j] = 1.0; aref[nr] = -m->drag_b[j] * qv[j]; D[nr] = m->drag_G[j]; iseq[nr] = 1; rowid[nr] = -1;
       ++nr;
+    }
+  for (int e = 0; e < m->n_jeq; ++e) {              /* joint couplings q1 - c0 - c1 q2 = 0 (LinkModel.forward) */
+    const int j1 = m->jeq_joint1[e], j2 = m->jeq_joint2[e];
+    const double c0 = m->jeq_coef[e][0], c1 = m->jeq_coef[e][1], res = qp[j1] - c0 - c1 * qp[j2];
+    double kk, bb, dd;
+    kbimp(m->jeq_solref[e], m->jeq_solimp[e], res, dt, &kk, &bb, &dd);
+    J[nr][j1] = 1.0; J[nr][j2] = -c1;
+    aref[nr] = -bb * (qv[j1] - c1 * qv[j2]) - kk * dd * res;
+    D[nr] = 1.0 / fmax((1 - dd) / dd * m->jeq_invweight[e], 1e-15);
+    iseq[nr] = 1; rowid[nr] = -1;
+    ++nr;
+  }
+  /* dry joint friction: rows with a bounded force (state 0 quadratic, +-1 saturated), kept apart from the unilateral rows */
+  int fj[NVMAX], fs[NVMAX], nf = 0;
+  double far_[NVMAX], fD[NVMAX], floss[NVMAX];
+  for (int j = 0; j < nv; ++j)
+    if (m->frictionloss[j] > 0) {
+      double kk, bb, dd;
+      kbimp(m->jsolref[j], m->jsolimp[j], 0.0, dt, &kk, &bb, &dd);
+      fj[nf] = j; fs[nf] = 0; far_[nf] = -bb * qv[j]; fD[nf] = 1.0 / fmax((1 - dd) / dd * m->dof_invweight[j], 1e-15); floss[nf] = m->frictionloss[j];
+      ++nf;
     }
   o->ncon = 0;
   if (col) {
@@ -382,8 +426,18 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
         for (int j = 0; j < nv; ++j) H[i][j] += w * J[r][j];
       }
     }
+    for (int k = 0; k < nf; ++k) {
+      if (fs[k] == 0) { H[fj[k]][fj[k]] += fD[k]; a[fj[k]] += fD[k] * far_[k]; }
+      else a[fj[k]] -= fs[k] * floss[k];
+    }
     chol_solve(nv, H, a);
     int changed = 0;
+    for (int k = 0; k < nf; ++k) {
+      const double x = a[fj[k]] - far_[k];
+      const int ns = fabs(x) * fD[k] <= floss[k] ? 0 : (x > 0 ? 1 : -1);
+      changed |= ns != fs[k];
+      fs[k] = ns;
+    }
     for (int r = 0; r < nr; ++r) {
       double x = -aref[r];
       for (int j = 0; j < nv; ++j) x += J[r][j] * a[j];
@@ -425,7 +479,7 @@ static void substep(const earl_link_model* m, const earl_collision_model* col, d
   }
 }
 
-static V3 attachment(const earl_link_model* m, const StepOut* o, int k) {
+static V3 attachment(const LM* m, const StepOut* o, int k) {
   const int la = m->att_link[k];
   V3 p = ld3(m->att_pos[k]);
   if (la >= 0) { double R[3][3]; qmat(ldq(o->Xq[la]), R); p = add(ld3(o->Xp[la]), mulv(R, p)); }
@@ -442,10 +496,10 @@ int oracle_set_physics_threads(int n) {
 #endif
 }
 
-/* earl_physics_step / earl_physics_forward on host arrays (integrate: 1 = step nsub times, 0 = forward quantities) */
-int oracle_physics(const earl_link_model* m, const earl_collision_model* col, int32_t n, int32_t nsub, int32_t integrate, double* qpos,
-                   double* qvel, const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc, double* efc,
-                   double* att_xpos, int32_t* ncon) {
+/* earl_physics_step / earl_physics_forward on host arrays (integrate: 1 = step nsub times, 0 = forward quantities); ctrl_stride: doubles per env
+ * in ctrl (0: n_act); mq_stride: 4 = a quaternion per env, 0 = one for all */
+static int physics24(const LM* m, const earl_collision_model* col, int32_t n, int32_t nsub, int32_t integrate, double* qpos, double* qvel,
+                     const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc, double* efc, double* att_xpos, int32_t* ncon) {
   const int nv = m->nv;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < n; ++e) {
@@ -466,6 +520,18 @@ int oracle_physics(const earl_link_model* m, const earl_collision_model* col, in
   }
   return 0;
 }
+int oracle_physics(const earl_link_model* m16, const earl_collision_model* col, int32_t n, int32_t nsub, int32_t integrate, double* qpos,
+                   double* qvel, const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc, double* efc,
+                   double* att_xpos, int32_t* ncon) {
+  LM m;
+  widen(m16, &m);
+  return physics24(&m, col, n, nsub, integrate, qpos, qvel, mocap_pos, mocap_quat, ctrl, qacc, efc, att_xpos, ncon);
+}
+int oracle_physics24(const earl_link_model24* m, const earl_collision_model* col, int32_t n, int32_t nsub, int32_t integrate, double* qpos,
+                     double* qvel, const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* qacc, double* efc,
+                     double* att_xpos, int32_t* ncon) {
+  return physics24(m, col, n, nsub, integrate, qpos, qvel, mocap_pos, mocap_quat, ctrl, qacc, efc, att_xpos, ncon);
+}
 
 static double tolerance_gaussian(double x, double hi, double margin) {
   if (0.0 <= x && x <= hi) return 1.0;
@@ -478,8 +544,11 @@ void oracle_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* ou
 static double u01_(uint32_t lo, uint32_t hi) { return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0); }
 
 /* earl_sawyer_rollout on host arrays (same cfg / state / out structs with host pointers); reference: oracle/sawyer_oracle.py */
-int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* col, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
+int oracle_sawyer_rollout(const earl_link_model* m16, const earl_collision_model* col, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                           const float* action, int32_t T, const earl_sawyer_out* out) {
+  LM mw;
+  widen(m16, &mw);
+  const LM* m = &mw;
   const int nv = m->nv, n = cfg->n;
   const float scale = (float)cfg->action_scale;
 #pragma omp parallel for schedule(static)
@@ -497,7 +566,7 @@ int oracle_sawyer_rollout(const earl_link_model* m, const earl_collision_model* 
       const float* a = action + ((size_t)t * n + e) * 4;
       const double ctrl[EARL_MAXACT] = {(double)a[3], -(double)a[3], 0, 0};
       /* failure guard (include/earl_physics.h, earl_sawyer_out.status): work on a copy, commit it only when the step ended finite */
-      double q2[EARL_MAXV + 1], v2[EARL_MAXV], mp2[3];
+      double q2[NVMAX + 1], v2[NVMAX], mp2[3];
       memcpy(q2, qp, sizeof(double) * m->nq); memcpy(v2, qv, sizeof(double) * nv);
       for (int k = 0; k < 3; ++k) {
         const float c = fminf(fmaxf(a[k], -1.f), 1.f) * scale;

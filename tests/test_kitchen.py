@@ -162,3 +162,26 @@ def test_kitchen_oracle_env_step_runs(lm):
   env.set(INIT_QPOS, np.zeros(23), MIDPOINT_POS, far, INIT_QPOS[:9])
   obs, r, s, _ = env.step(np.zeros(9, np.float32))
   assert not s and r < 0                               # -10 * 1.5 + 7 solved components - 0.5 |mocap - microwave handle|
+
+
+def test_c_restatement_matches_the_numpy_statement(lm):
+  """oracle/physics_oracle.c on the 24-dof table form (joint couplings, dry friction, springs, force limits incl.) vs LinkModel: forward
+  accelerations of states with open doors / active couplings / sliding friction, and a 40-timestep env step"""
+  from earl_benchmark_amd.envs.kitchen import INIT_QPOS, MIDPOINT_POS
+  from oracle import physics_c
+  cm = physics_c.CModel('kitchen')
+  rng = np.random.default_rng(0)
+  n = 6
+  q = np.tile(INIT_QPOS, (n, 1)) + rng.normal(0, 0.05, (n, 23)); v = rng.normal(0, 0.3, (n, 23)); q[:, 7:9] = rng.uniform(0, 0.04, (n, 2))
+  q[1, 22] = -0.5; q[2, 19] = 0.3; q[3, 9] = -0.7; q[3, 10] = -0.004; v[4, 19:] = [3, -2, 2, -4]
+  mp = np.tile(MIDPOINT_POS, (n, 1)) + rng.normal(0, 0.05, (n, 3)); mq = np.tile(lm.weld_mocap_quat, (n, 1)); ctrl = rng.uniform(-0.01, 0.05, (n, 2))
+  r = cm.run(q, v, mp, mq, ctrl, integrate=False)
+  for i in range(n):
+    ref = lm.forward(q[i], v[i], ctrl[i], mp[i], mq[i])
+    np.testing.assert_allclose(r['qacc'][i], ref['qacc'], rtol=1e-10, atol=1e-10 * np.abs(ref['qacc']).max())
+  r2 = cm.run(q[:2], v[:2], mp[:2], mq[:2], ctrl[:2], nsub=40)
+  for i in range(2):
+    qq, vv = q[i].copy(), v[i].copy()
+    for _ in range(40):
+      qq, vv, _ = lm.step(qq, vv, ctrl[i], mp[i], mq[i])
+    np.testing.assert_allclose(r2['qpos'][i], qq, atol=1e-12); np.testing.assert_allclose(r2['qvel'][i], vv, atol=1e-11)
