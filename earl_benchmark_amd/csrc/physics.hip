@@ -205,9 +205,17 @@ template <int NV> struct Lim {
                                                             // and free peg are separate trees (checked by the host side); the door model
                                                             // (9 + 1) is factorised densely -- the split did not pay there; the kitchen's arm (7 + 2)
                                                             // is one tree and each of its 14 fixtures its own (coupled at most in pairs)
+  static constexpr int NT = NV > 16 ? 9 : NV;               // links that can have ancestors / descendants other than themselves: all, except in the kitchen
+                                                            // model, where only the arm's nine do (every fixture is a tree of one link; checked by the host
+                                                            // side).  The masked ancestor / subtree sums run over [0, NT) plus the lane's own link.
   static constexpr bool EXTRAS = NV > 16;                   // dry joint friction, joint springs, force-limited actuators, joint couplings (earl_link_model24)
   static constexpr int LPE = NV > 16 ? 32 : 16;             // lanes per env instance (64 = one wavefront per env: measurement switch for nv <= 16)
 };
+
+// the equality part of the Hessian (M + weld / coupling / drag rows), kept in LDS for the big model: its 23-entry columns would otherwise sit in
+// registers across the whole active-set iteration (the nv = 23 kernel spilled 1.6 KB per lane into scratch)
+template <int NV, bool ON> struct HwStore {};
+template <int NV> struct HwStore<NV, true> { SymLds<NV> Hw; };
 
 // Per-env LDS block.  The three phase groups of the union are live at disjoint times.
 template <int NV>
@@ -217,6 +225,7 @@ struct SharedData {
   double bq[4];                      // orientation of the free body (unit quaternion), identity if the model has none
   double Xq[NV][4], Xp[NV][3];       // world frame of every link (final buffer of the ancestor doubling)
   SymLds<NV> M;                      // mass matrix
+  HwStore<NV, (NV > 16)> hwst;
   union {
     struct { double Xq1[NV][4], Xp1[NV][3]; } k2;                    // second buffer of the doubling
     struct { double att[8][3]; } emit;                               // observation epilogue (after the last timestep of an env step)
@@ -333,6 +342,51 @@ __device__ __forceinline__ void chol_coop(SymLds<NV>& H, const double (&dl)[NV],
     fence();
   }
 }
+#ifndef EARL_KITCHEN_DENSE
+#define EARL_KITCHEN_DENSE 0
+#endif
+// Looping form of the two for the big model (nv = 23): fully unrolled, chol_coop + solve_lds keep two 23-entry vectors in registers and made the
+// kernel spill 1.4 KB per lane into scratch.  Here the lane's row of L stays where it is (in H), the right-hand side / solution stays in LDS
+// (every lane of the env runs the same substitution on the same numbers, so the redundant stores agree), and nothing is indexed dynamically in
+// registers.  Only taken when a contact joins the arm to a fixture.
+template <int NV>
+__device__ __forceinline__ void chol_coop_loop(SymLds<NV>& H, const double (&dl)[NV], const int l, const bool isl) {
+  static_assert(SymLds<NV>::PACKED, "packed storage");
+  const int ltri = l * (l + 1) / 2;
+  if (isl) H.v[ltri + l] += dl[l];
+  fence();
+  for (int j = 0; j < NV; ++j) {
+    const int jtri = j * (j + 1) / 2;
+    double sj = H.v[jtri + j], si = H.v[(l >= j ? ltri : jtri) + j];
+#pragma unroll 4
+    for (int p = 0; p < j; ++p) {
+      const double pj = H.v[jtri + p], rp = H.v[(l >= j ? ltri : jtri) + p];
+      sj = fma(-pj, pj, sj);
+      si = fma(-rp, pj, si);
+    }
+    const double inv = rsq_nr(sj);
+    fence();                                            // every lane has read column j's inputs before the pivot row is overwritten
+    if (isl && l >= j) H.v[ltri + j] = l == j ? inv : si * inv;
+    fence();
+  }
+}
+template <int NV>
+__device__ __forceinline__ void solve_lds_loop(const SymLds<NV>& H, double (&x)[NV]) {   // x in LDS, in place; L as chol_coop_loop leaves it
+  for (int i = 0; i < NV; ++i) {
+    const int itri = i * (i + 1) / 2;
+    double s = x[i];
+#pragma unroll 4
+    for (int p = 0; p < i; ++p) s = fma(-H.v[itri + p], x[p], s);
+    x[i] = s * H.v[itri + i];
+  }
+  for (int i = NV - 1; i >= 0; --i) {
+    double s = x[i];
+#pragma unroll 4
+    for (int p = i + 1; p < NV; ++p) s = fma(-H.v[p * (p + 1) / 2 + i], x[p], s);
+    x[i] = s * H.v[i * (i + 1) / 2 + i];
+  }
+}
+
 // the same on the leading N x N block only (a model whose first N dofs are one tree and whose other dofs are decoupled from it: the kitchen's arm)
 template <int NV, int N>
 __device__ __forceinline__ void chol_coop_lead(SymLds<NV>& H, const double (&dl)[NV], const int l, const bool isl) {
@@ -431,7 +485,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
                                         const int grp, const V3 mpos, const Q4 mq, const double (&ctrl)[EARL_MAXACT], double* qacc_out,
                                         double* efc_out) {
   static_assert(NV <= LPE, "one lane per link");
-  constexpr int MC = Lim<NV>::MC, NA = Lim<NV>::NA;
+  constexpr int MC = Lim<NV>::MC, NA = Lim<NV>::NA, NT = Lim<NV>::NT;
   static_assert(MC <= LPE, "one lane per contact");
   const int maxcon = bt.max_con < MC ? bt.max_con : MC;
   const double dt = m.dt;
@@ -585,10 +639,15 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   {
     double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int d = 0; d < NV; ++d) {
+    for (int d = 0; d < NT; ++d) {
       const double w = ((dmask >> d) & 1u) ? 1.0 : 0.0;
 #pragma unroll
       for (int e = 0; e < 10; ++e) acc[e] = fma(w, s.dyn.I10[d][e], acc[e]);
+    }
+    if constexpr (NT < NV) {                             // a single-link tree: its composite inertia is its own
+      const double w = l >= NT ? 1.0 : 0.0;
+#pragma unroll
+      for (int e = 0; e < 10; ++e) acc[e] = fma(w, s.dyn.I10[l][e], acc[e]);
     }
     V3 n, f;
     iapply(acc, Sw, Sv, n, f);
@@ -601,12 +660,18 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   PSTAMP(3);
   // ------------------------------------------------------------------ K5: mass matrix, lane = column j
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
+  for (int i = 0; i < NT; ++i) {
     const double* fs = s.dyn.crb.FS[i];
     double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
     v = ((dmask >> i) & 1u) ? v : 0.0;                  // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
     if (i == l) v += m.armature[l];
     if (isl && l <= i) s.M.put(i, l, v, true);
+  }
+  if constexpr (NT < NV) {                               // single-link trees: a diagonal entry each; the entries that join them to anything else were
+    if (isl && l >= NT) {                                // zeroed when the kernel started and are never written
+      const double* fs = s.dyn.crb.FS[l];
+      s.M.put(l, l, Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5] + m.armature[l], true);
+    }
   }
   fence();
   PSTAMP(4);
@@ -615,11 +680,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   {
     V3 w{0, 0, 0}, v{0, 0, 0};
 #pragma unroll
-    for (int a = 0; a < NV; ++a) {
+    for (int a = 0; a < NT; ++a) {
       const double qd = ((amask >> a) & 1u) ? s.qv[a] : 0.0;
       const double* sa = s.dyn.S[a];
       w = add(w, scl(ld3(sa), qd));
       v = add(v, scl(ld3(sa + 3), qd));
+    }
+    if constexpr (NT < NV) {                             // single-link tree: only its own joint moves it
+      const double qd = l >= NT ? s.qv[l] : 0.0;
+      w = add(w, scl(Sw, qd));
+      v = add(v, scl(Sv, qd));
     }
     // crossm(V_l) S_l qd_l = [w x sw ; v x sw + w x sv] qd   (V of the parent and V_l differ by S_l qd_l, whose cross with S_l is 0)
     const double qdl = s.qv[l];
@@ -643,11 +713,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fence();
     V3 aw{0, 0, 0}, av{-m.gravity[0], -m.gravity[1], -m.gravity[2]};
 #pragma unroll
-    for (int a = 0; a < NV; ++a) {
+    for (int a = 0; a < NT; ++a) {
       const double wgt = ((amask >> a) & 1u) ? 1.0 : 0.0;
       const double* ca = s.dyn.rne.Cc[a];
       aw = add(aw, scl(ld3(ca), wgt));
       av = add(av, scl(ld3(ca + 3), wgt));
+    }
+    if constexpr (NT < NV) {
+      const double wgt = l >= NT ? 1.0 : 0.0;
+      aw = add(aw, scl(cw, wgt));
+      av = add(av, scl(cv, wgt));
     }
     V3 n1, f1, n2, f2;
     iapply(s.dyn.I10[l], aw, av, n1, f1);
@@ -661,11 +736,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fence();
     V3 ns{0, 0, 0}, fs{0, 0, 0};
 #pragma unroll
-    for (int d = 0; d < NV; ++d) {
+    for (int d = 0; d < NT; ++d) {
       const double wgt = ((dmask >> d) & 1u) ? 1.0 : 0.0;
       const double* fd = s.dyn.rne.F[d];
       ns = add(ns, scl(ld3(fd), wgt));
       fs = add(fs, scl(ld3(fd + 3), wgt));
+    }
+    if constexpr (NT < NV) {
+      const double wgt = l >= NT ? 1.0 : 0.0;
+      ns = add(ns, scl(n, wgt));
+      fs = add(fs, scl(f, wgt));
     }
     // ---------------------------------------------------------------- K7: applied + passive - bias
     double t = -m.damping[l] * qdl - (dot(Sw, ns) + dot(Sv, fs));
@@ -827,7 +907,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     const int r = sub < 6 ? sub : 5;
     double Jv = 0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) Jv = fma(s.con.J6[r][j], s.qv[j], Jv);
+    for (int j = 0; j < NT; ++j) Jv = fma(s.con.J6[r][j], s.qv[j], Jv);          // (the weld's chain lies within the first NT links)
     const double res = r < 3 ? pick3(rpos, r) : pick3(rrot, r - 3);
     double kk, bb, dd;
     kbimp(m.weld_solref, m.weld_solimp, res, dt, kk, bb, dd);
@@ -925,8 +1005,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       double h = s.M.sym(i, l, ltri);
+      if (i < NT) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
+        for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
+      }
       if (i == l) h += m.drag_G[l];                     // soft velocity row of a permanent dragging contact
       hw[i] = h;
     }
@@ -944,6 +1026,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         g = fma(DJl, -bb * Jv - kk * dd * res, g);
 #pragma unroll
         for (int i = 0; i < NV; ++i) hw[i] += (i == j1 ? DJl : 0.0) + (i == j2 ? -c1 * DJl : 0.0);
+      }
+      if (isl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s.hwst.Hw.put(i, l, hw[i], false);     // (the lower part of column l; hw dies here)
       }
     }
     rw = g;
@@ -977,7 +1063,26 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       w[7] = cmu * (a3 * car[2] - a4 * car[3]);
     }
     fence();
-    {
+    if constexpr (Lim<NV>::EXTRAS) {
+      // column l of the iteration's Hessian, built in place in LDS: the stored equality part, then the active contact edges
+      double rr = rw;
+      if (isl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) if (i >= l) s.con.Hc.lo(i, l) = s.hwst.Hw.lo(i, l);
+      }
+      for (int c = 0; c < ncmax; ++c) {
+        const double* w = s.con.cw[c];
+        const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
+        const bool cv = c < nct;
+        const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+        rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
+        if (isl) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) if (i >= l) s.con.Hc.lo(i, l) += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+        }
+      }
+      if (isl) s.con.rc[l] = rr;
+    } else {
       double hcol[NV], rr = rw;
 #pragma unroll
       for (int i = 0; i < NV; ++i) hcol[i] = hw[i];
@@ -1000,9 +1105,79 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
     if constexpr (Lim<NV>::EXTRAS) {
-      if (coupled) {                                   // a finger touches a fixture (uniform over the wave): dense shared factorisation
-        chol_coop<NV>(s.con.Hc, s.con.dl, l, isl);
-        solve_lds<NV>(s.con.Hc, a);
+      if (coupled && EARL_KITCHEN_DENSE) {             // (measurement switch: the generic dense factorisation in its looping form)
+        if (isl) s.con.rc[l] += s.con.rl[l];
+        chol_coop_loop<NV>(s.con.Hc, s.con.dl, l, isl);
+        solve_lds_loop<NV>(s.con.Hc, s.con.rc);
+        fence();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i];
+      } else if (coupled) {
+        // A finger touches a fixture (uniform over the wave).  H = [A B'; B F]: A the arm's NA x NA block, F the fixtures' block (1 x 1 / 2 x 2
+        // blocks, no fill), B the rows that contacts put between them.  Eliminate the fixtures: S = A - B' F^-1 B, solve the arm, back-substitute.
+        double* const fi0 = &s.con.cw[0][0];             // F^-1 (f, f), F^-1 (f, pair f), F^-1 g_f, B_f . x_arm: the edge weights are dead until the next iteration
+        double* const fi1 = fi0 + NV;
+        double* const fy = fi1 + NV;
+        double* const ft = fy + NV;
+        static_assert(4 * NV <= MC * 8, "scratch vectors fit the edge-weight block");
+        if (isl && l >= NA) {
+          const int p = m.pair[l];
+          const double d = s.con.Hc.lo(l, l) + s.con.dl[l], gl = s.con.rc[l] + s.con.rl[l];
+          double i0, i1 = 0.0, y;
+          if (p >= 0) {
+            const int hi = l > p ? l : p, lo_ = l > p ? p : l;
+            const double o = s.con.Hc.lo(hi, lo_), dp = s.con.Hc.lo(p, p) + s.con.dl[p], idet = rcp_nr(d * dp - o * o);
+            i0 = dp * idet; i1 = -o * idet;
+            y = i0 * gl + i1 * (s.con.rc[p] + s.con.rl[p]);
+          } else {
+            i0 = rcp_nr(d);
+            y = i0 * gl;
+          }
+          fi0[l] = i0; fi1[l] = i1; fy[l] = y;
+        }
+        fence();
+        if (isl && l < NA) {                              // row l of the Schur complement and of its right-hand side, in place
+          double row[NA], g = s.con.rc[l] + s.con.rl[l];
+#pragma unroll
+          for (int c = 0; c < NA; ++c) row[c] = c <= l ? s.con.Hc.lo(l, c) : 0.0;
+#pragma unroll
+          for (int f = NA; f < NV; ++f) {
+            const double bl = s.con.Hc.lo(f, l);
+            if (bl != 0.0) {                              // only the fixtures this env's fingers touch have a row in B
+              const int p = m.pair[f];
+              const double w0 = bl * fi0[f], w1 = bl * fi1[f];
+              g = fma(-bl, fy[f], g);
+#pragma unroll
+              for (int c = 0; c < NA; ++c) {
+                double t = w0 * s.con.Hc.lo(f, c);
+                if (p >= 0) t = fma(w1, s.con.Hc.lo(p, c), t);
+                row[c] -= c <= l ? t : 0.0;
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < NA; ++c) if (c <= l) s.con.Hc.lo(l, c) = row[c];
+          s.con.rc[l] = g - s.con.rl[l];                  // (a[] below is formed as rc + rl again)
+        }
+        fence();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
+        chol_coop_lead<NV, NA>(s.con.Hc, s.con.dl, l, isl);
+        solve_lds_lead<NV, NA>(s.con.Hc, a);
+        if (isl && l >= NA) {                             // t_f = B_f . x_arm
+          double t = 0;
+#pragma unroll
+          for (int c = 0; c < NA; ++c) t = fma(s.con.Hc.lo(l, c), a[c], t);
+          ft[l] = t;
+        }
+        fence();
+        if (isl && l >= NA) {
+          const int p = m.pair[l];
+          s.con.rc[l] = fy[l] - fi0[l] * ft[l] - (p >= 0 ? fi1[l] * ft[p] : 0.0);
+        }
+        fence();
+#pragma unroll
+        for (int i = NA; i < NV; ++i) a[i] = s.con.rc[i];
       } else {
         // no contact joins the arm and the fixtures: the Hessian is the arm's NA x NA block plus, per fixture, a scalar or -- for the
         // knob / burner and switch / light couplings -- a 2 x 2 block with its partner (earl_link_model24.pair)
@@ -1248,6 +1423,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
   const int env = live ? env_raw : a.n - 1;            // idle groups shadow the last env and store nothing
   Shared<NV>& s = sh[wave * EPW + grp];
   load_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
+  if constexpr (Lim<NV>::NT < NV) {                     // the mass-matrix entries between different trees are never written (K5): zero, once
+    for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
+  }
   fence();
   const V3 mpos = ld3(a.mocap_pos + (size_t)env * 3);
   const Q4 mq = ldq(a.mocap_quat + (size_t)env * a.mq_stride);      // as given, NOT normalised (include/earl_physics.h)
