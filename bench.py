@@ -461,7 +461,18 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
   fails = int(env.unwrapped.fail_count.sum())
   if rank != 0:
     return None
+  prof = {}
+  tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+  if os.path.exists(tpath) and (n_global, T, world) == (2048, 400, 1):
+    prof = json.load(open(tpath)).get('kitchen', {})
+  issue = prof.get('issue') or {}
+  simd_issue = None if not issue else min(1.0, (prof.get('waves_per_simd') or 1) * issue['issue_any'])
   return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
+          'issue_frac': simd_issue,
+          'roofline': {'bound': 'issue', 'achieved': simd_issue, 'peak': 1.0, 'unit': 'share of SIMD cycles issuing an instruction (waves per SIMD x '
+                       'SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES) of physics_kernel<23, 32>', 'frac': simd_issue, 'valu': issue.get('valu'), 'lds': issue.get('lds'),
+                       'scalar': issue.get('scalar'), 'wait': issue.get('wait_any'), 'waves_per_simd': prof.get('waves_per_simd'),
+                       'source': (prof.get('source', '') + ' (static: SQ counters collected by rocprofv3 --pmc in separate runs of this workload)') if issue else None},
           'timesteps_per_s': steps * n_global * T * 40 / dt, 'gpu_ms_per_env_step': clk.elapsed_ms() / (steps * T), 'scaling': 'strong',
           'diverged_env_steps': fails,
           'config': {'workload': f'kitchen dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + {T} env steps of 40 timesteps '
