@@ -1082,6 +1082,29 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         }
       }
       if (isl) s.con.rc[l] = rr;
+    } else if constexpr (Lim<NV>::COOP) {
+      // (in-LDS factorisation, i.e. the eight-waves-per-CU door build: the same column built in place, from the register copy of the equality part --
+      // one 10-entry register vector less under the 256-register cap)
+      double rr = rw;
+      if (isl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s.con.Hc.put(i, l, hw[i], false);
+      }
+      for (int c = 0; c < ncmax; ++c) {
+        const double* w = s.con.cw[c];
+        const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
+        const bool cv = c < nct;
+        const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+        rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
+        if (isl) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const double t = cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+            if (!SymLds<NV>::PACKED || i >= l) s.con.Hc.lo(i, l) += t;      // (lo(i, l) addresses entry (i, l): any i in the square form, i >= l in the packed one)
+          }
+        }
+      }
+      if (isl) s.con.rc[l] = rr;
     } else {
       double hcol[NV], rr = rw;
 #pragma unroll

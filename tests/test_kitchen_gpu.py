@@ -154,3 +154,38 @@ def test_full_size_soak_2048_envs_400_steps():
   f64 = dict(dtype=torch.float64, device='cuda')
   assert float((u.mocap_pos - torch.tensor([[-0.7, -0.1, 1.8]], **f64)).min()) >= 0 and float((u.mocap_pos - torch.tensor([[0.4, 0.5, 2.6]], **f64)).max()) <= 0
   assert float(u.qvel.abs().max()) < 50
+
+
+def test_scalar_api_lifelong_wrapper_and_state_dict():
+  """the reference's call surface for ONE env (numpy obs, python float reward, bool done, {}), the LifelongWrapper goal switch, checkpointing"""
+  import torch
+  import earl_benchmark_amd as eb
+  L = eb.EARLEnvs('kitchen', reward_type='dense', eval_horizon=2, allow_unpinned_dynamics=True)
+  train, ev = L.get_envs()
+  o = ev.reset()
+  assert isinstance(o, np.ndarray) and o.shape == (46,) and o.dtype == np.float64
+  o, r, d, info = ev.step(np.zeros(9))
+  assert isinstance(r, float) and d is False and info == {} and isinstance(ev.is_successful(), bool)
+  o, r, d, info = ev.step(np.zeros(9))
+  assert d is True and ev.total_steps == 2 and ev.num_interventions == 1
+  assert abs(ev.compute_reward(o) - r) < 1e-9                                   # the reward of the CURRENT simulator state, like the reference's
+  LL = eb.EARLEnvs('kitchen', reward_type='dense', setup_as_lifelong_learning=True, num_envs=4, goal_change_frequency=3, allow_unpinned_dynamics=True)
+  env = LL.get_envs()
+  env.reset()
+  u = env.unwrapped
+  custom = torch.tensor(L.get_goal_states()[0], device='cuda').clone(); custom[22] = -1.0
+  u.reset_goal(custom.cpu().numpy())
+  rets = torch.zeros(4, dtype=torch.float64, device='cuda')
+  for t in range(3):
+    o, r, d, info = env.step(torch.zeros(4, 9))
+    rets += r
+    if t < 2:
+      assert bool((o[:, 23:] == custom).all())
+  assert bool((o[:, 23:] == torch.tensor(L.get_goal_states()[0], device='cuda')).all())      # switched back by reset_goal() on the third step: NEW goal in the obs
+  assert float(r[0]) < 0                                                                       # ... while the reward of that step used the OLD one (microwave far open)
+  np.testing.assert_allclose(env.lifelong_return.cpu().numpy(), rets.cpu().numpy())
+  sd = u.state_dict()
+  a = torch.rand(4, 9, device='cuda') * 2 - 1
+  o1 = env.step(a)[0].clone()
+  u.load_state_dict(sd)
+  assert bool((env.step(a)[0] == o1).all())                                                    # same state + same Philox counter -> same step, noise included
