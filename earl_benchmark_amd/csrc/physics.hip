@@ -186,7 +186,7 @@ template <> struct ModelOf<23> { using T = earl_link_model24; };
 // under 40 KB of LDS (four workgroups per CU, one wave per SIMD); the peg model (nv 15) needs 12 / 32.
 template <int NV> struct Lim {
   static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
-  static constexpr int MB = NV <= 10 ? 16 : 28;             // collision blocks (<= EARL_MAXBLK; the peg model has 25, the kitchen 26)
+  static constexpr int MB = NV <= 10 ? 16 : 32;             // collision blocks (<= EARL_MAXBLK; the peg model has 29, the kitchen 26)
 #ifndef EARL_DOOR_WPB
 #define EARL_DOOR_WPB 1
 #endif

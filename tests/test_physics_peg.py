@@ -54,7 +54,8 @@ def test_model_facts():
   from oracle.sawyer_oracle import PEG_INITIAL_STATES
   peg_xy = PEG_INITIAL_STATES[:, 4:6] + [0.1, 0.0]
   assert (peg_xy >= [0.0, 0.5]).all() and (peg_xy <= [0.2, 0.7]).all() and (PEG_INITIAL_STATES[:, 6] == 0.02).all()
-  assert len(d['col_pair']) == 327 and len(d['col_blk_begin']) == 25 and len(d['col_sph_link']) == 39 and len(d['col_box_link']) == 10
+  # 39 spheres (15 chain + 8 peg corners + 16 plate corners) x 14 boxes (2 plates, 7 hole-block boxes, table top, 4 retaining walls: round 2)
+  assert len(d['col_pair']) == 359 and len(d['col_blk_begin']) == 29 and len(d['col_sph_link']) == 39 and len(d['col_box_link']) == 14
 
 
 def test_free_body_obeys_eulers_equations_and_conserves_momentum():
@@ -181,3 +182,25 @@ def test_reset_pose_and_forward_demonstrations_open_loop():
     ob = cm.sawyer_rollout(cfg, q, v, MP[None].copy(), obs0[7:][None].astype(np.float64), np.zeros(1, np.int32), acts[:, None, :])[0][:, 0]
     assert np.sqrt(((ob[:, :3] - nxt[:, :3]) ** 2).sum(1).mean()) < 0.016
     assert np.sqrt(((ob[:, 4:7] - nxt[:, 4:7]) ** 2).sum(1).mean()) < 0.02
+
+
+def test_retaining_walls_keep_a_pushed_peg_on_the_table():
+  """the four table-edge walls (metaworld_assets/scene/basic_scene.xml:49-58) are colliders of the peg's corner points since round 2: a peg
+  sliding at 2 m/s towards either long edge stops at the wall (inner face at y = 0.6 +- 0.38, peg half width 0.015) instead of leaving the
+  table and falling forever"""
+  from oracle import physics_c
+  cm = physics_c.CModel('sawyer_peg')
+  hand = np.array([0, 0.6, 0.2])
+  r = cm.run(cm.tables['qpos0'][None], np.zeros((1, 15)), hand, [1, 0, 1, 0], [-1, 1], nsub=1500)
+  q0, v0 = r['qpos'][0].copy(), r['qvel'][0].copy()
+  for vy, y0, wall in ((2.0, 0.85, 0.98), (-2.0, 0.35, 0.22)):
+    q, v = q0[None].copy(), v0[None].copy()
+    q[0, 9:12] = [0.3, y0, 0.02]; v[0, 9:] = 0; v[0, 10] = vy
+    ys, zs = [], []
+    for _ in range(40):
+      rr = cm.run(q, v, hand, [1, 0, 1, 0], [-1, 1], nsub=10)
+      q, v = rr['qpos'], rr['qvel']
+      ys.append(q[0, 10]); zs.append(q[0, 11])
+    assert min(zs) > 0.012 and abs(v[0, 10]) < 0.05                       # still lying on the table top, at rest
+    assert (max(ys) < wall - 0.005) if vy > 0 else (min(ys) > wall + 0.005)
+    assert abs(ys[-1] - wall) < 0.03                                        # ... right at the wall

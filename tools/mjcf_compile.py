@@ -478,7 +478,7 @@ def main():
     # link form of the peg task.  reset_model puts body 'box' at goal - (0.03, 0, 0.13) = its MJCF position (sawyer_peg.py:196-197).
     # Collision set: the peg (a 3 x 3 x 24 cm box) is a chain of inscribed spheres against the gripper plates and the
     # seven boxes of the hole block, and its 8 corners are points against the table top and the block; the plate corners
-    # are points against the table top and the block.  Left out: wrist mesh hulls, retaining walls, floor.
+    # are points against the table top, the block and the four retaining walls.  Left out: wrist mesh hulls, floor.
     pm = po.Model(m)
     table = pm.body_id('tablelink')
     blockb = [b for b in range(len(m['body_parent'])) if m['body_parent'][b] == pm.body_id('box')][0]
@@ -491,7 +491,10 @@ def main():
                                          chains=[dict(geom=peg, set='peg', spacing=1.0)],
                                          corner_sets=[dict(names=['peg'], set='pegcorner'), ['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']],
                                          big_boxes=[dict(geom=g, accept=('peg', 'pegcorner', 'corner')) for g in boxes(blockb)] +
-                                                   [dict(geom=g, accept=('pegcorner', 'corner')) for g in boxes(table)]))
+                                                   [dict(geom=g, accept=('pegcorner', 'corner')) for g in boxes(table)] +
+                                                   # the four retaining walls at the table's edges (scene/basic_scene.xml:49-58) keep a pushed peg on the
+                                                   # table (round 2; round 1 left them out: "a peg pushed off the table would fall forever")
+                                                   [dict(geom=g, accept=('pegcorner',)) for g in boxes(pm.body_id('RetainingWall'))]))
     # world-fixed sites the dense reward reads (sawyer_peg.py:252-256): the corners of the two keep-out prisms in front of the hole block
     kin0 = po.kinematics(pm, po.dof_qpos0(pm))
     corner = lambda n: kin0['xpos'][pm.site_body[pm.site_id(n)]] + kin0['xmat'][pm.site_body[pm.site_id(n)]] @ pm.site_pos[pm.site_id(n)]
