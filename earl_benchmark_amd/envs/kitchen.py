@@ -5,11 +5,12 @@ envs/kitchen_assets/adept_envs/adept_envs/franka/kitchen_multitask_v0.py:91-139 
 `reset_goal`, `get_next_goal`, `compute_reward`, `is_successful`, `_get_obs`, observation layout (robot qpos 9, fixture qpos 14, goal 23; with
 the reference's uniform sensor noise), dense reward only -- for `num_envs` independent instances.
 
-One env step = four launches on the caller's stream:
+One env step = ONE C-ABI call, earl_kitchen_step (include/earl_physics.h), which puts eight launches on the caller's stream, among them:
   earl_kitchen_action  (csrc/glue.hip)    action clip / scale, mocap target, the nine position targets (row a17; bit-exact vs the reference's numpy)
-  earl_physics_step    (csrc/physics.hip) 40 timesteps of the nv = 23 model: 32 lanes per env, in-LDS factorisations                  (row a16)
+  the nv = 23 stepper  (csrc/physics.hip) 40 timesteps: 32 lanes per env, tree-structured in-LDS factorisations                        (row a16)
   earl_kitchen_obs     (csrc/glue.hip)    observation with sensor noise from Philox draws                                              (row a18)
   earl_kitchen_reward  (csrc/glue.hip)    Kitchen._get_reward_n_score / is_successful                                                  (row a19)
+plus the per-env failure guard and the wrapper bookkeeping as small kernels.
 
 STATUS of the dynamics: this build's own articulated-body stepper on tables compiled from the reference's MJCF (tools/mjcf_compile.py kitchen):
 Franka arm (link inertias from the collision hulls and the given masses), 14 single-dof fixtures, the mocap weld on panda0_link7, joint limits,
