@@ -47,6 +47,11 @@ __device__ unsigned long long g_phys_prof[32];
   } while (0)
 #define PSTART() unsigned long long p_last = __builtin_readcyclecounter()
 #define PCOUNT(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phys_prof[i] += (v); } while (0)
+#elif defined(EARL_PHYS_MARK)
+// ISA markers (compile with -DEARL_PHYS_MARK -S and count the instructions between them); not in the product build
+#define PCOUNT(i, v) do {} while (0)
+#define PSTAMP(i) asm volatile("; EARL_PHASE_END " #i ::: "memory")
+#define PSTART() asm volatile("; EARL_PHASE_START" ::: "memory")
 #else
 #define PCOUNT(i, v) do {} while (0)
 #define PSTAMP(i) do {} while (0)
@@ -1935,6 +1940,16 @@ int earl_sawyer_rollout_door_w8(const earl_link_model* model, const earl_collisi
   sawyer_rollout_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
   return launched("sawyer_rollout (door, 8 waves per CU)");
 }
+#ifdef EARL_PHYS_PROF
+int earl_debug_read_phys_profile_w8(unsigned long long* out, int reset) {          // this unit's own copy of the phase counters
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_prof), sizeof(unsigned long long) * 32) != hipSuccess) return EARL_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phys_prof), z, sizeof(z)) != hipSuccess) return EARL_ERR_LAUNCH;
+  }
+  return EARL_OK;
+}
+#endif
 #else
 int earl_sawyer_rollout_door_w8(const earl_link_model* model, const earl_collision_model* col, const earl_sawyer_cfg* cfg, const earl_sawyer_state* st,
                                 const float* action, int32_t T, const earl_sawyer_out* out, earl_stream_t stream);      // physics_w8.hip

@@ -13,7 +13,7 @@ NAMES = ['K1-2 joint + world transforms + C0 bounding tests', 'K3 subspace + ine
 
 
 def build():
-  srcs = [os.path.join(ROOT, 'earl_benchmark_amd', 'csrc', f) for f in ('physics.hip', 'tabletop.hip', 'glue.hip')]
+  srcs = [os.path.join(ROOT, 'earl_benchmark_amd', 'csrc', f) for f in ('physics.hip', 'physics_w8.hip', 'tabletop.hip', 'glue.hip')]
   subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-o', LIB] + srcs, check=True)
 
 
@@ -23,19 +23,24 @@ def rollout_counters(n, T):
   sys.path.insert(0, ROOT)
   from earl_benchmark_amd import _abi
   _abi.LIB_PATH = LIB
-  _abi.SIGNATURES['earl_debug_read_phys_profile'] = [C.c_void_p, C.c_int]
+  w8 = '--w8' in sys.argv                         # the door's eight-waves-per-CU build (its own translation unit and counters)
+  reader = 'earl_debug_read_phys_profile_w8' if w8 else 'earl_debug_read_phys_profile'
+  _abi.SIGNATURES[reader] = [C.c_void_p, C.c_int]
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   env = (SawyerPeg if '--peg' in sys.argv else SawyerDoor)(num_envs=n)
   lib = _abi.load()
+  if w8:
+    lib.earl_debug_set_door_variant(2)
+  read = getattr(lib, reader)
   out = (C.c_ulonglong * 32)()
   acts = torch.rand(T, n, 4, device='cuda') * 2 - 1
   env.reset()
   torch.cuda.synchronize()
-  lib.earl_debug_read_phys_profile(out, 1)
+  read(out, 1)
   env.rollout(acts)
   torch.cuda.synchronize()
-  lib.earl_debug_read_phys_profile(out, 1)
+  read(out, 1)
   ts = max(1, out[20])
   print(f'rollout N={n} T={T}: timesteps of wave 0: {out[20]}; with a near block {out[21] / ts:.3f} (blocks per timestep {out[22] / ts:.2f}); '
         f'with contacts {out[23] / ts:.3f} (max contacts per env, mean {out[24] / ts:.2f}); Newton iterations per timestep {out[25] / ts:.2f}')
@@ -47,7 +52,7 @@ def main():
   if '--build' in sys.argv:
     return build()
   if '--rollout' in sys.argv:
-    return rollout_counters(1024, 200 if '--peg' in sys.argv else 300)
+    return rollout_counters(8192 if '--w8' in sys.argv else 1024, 200 if '--peg' in sys.argv else 300)
   import numpy as np
   import torch
   sys.path.insert(0, ROOT)
