@@ -46,6 +46,7 @@ __device__ unsigned long long g_phys_prof[32];
     p_last = t_;                                                                           \
   } while (0)
 #define PSTART() unsigned long long p_last = __builtin_readcyclecounter()
+__device__ unsigned long long g_wave_cycles[4096];      // duration of every wave of the last rollout launch (load balance)
 #define PCOUNT(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phys_prof[i] += (v); } while (0)
 #elif defined(EARL_PHYS_MARK)
 // ISA markers (compile with -DEARL_PHYS_MARK -S and count the instructions between them); not in the product build
@@ -256,13 +257,25 @@ struct SharedData {
       double rc[NV];                   // its right-hand side; then the right-hand side of K10
     } con;
   };
+  double aprev[(NV + 1) & ~1];       // solution of the previous timestep of this env step: warm start of the active-set iteration (last, even
+                                     // length: the 16-byte alignment of the arrays above decides between ds_read_b128 and two b64)
 };
 // The four env blocks of a wave must not start on the same LDS banks (every broadcast access would conflict 4 ways): the block
 // size is padded to 64 or 192 mod 256 bytes, whichever is nearer
+#ifndef EARL_STRIDE_MOD_10
+#define EARL_STRIDE_MOD_10 -1
+#endif
+#ifndef EARL_STRIDE_MOD_15
+#define EARL_STRIDE_MOD_15 -1
+#endif
+#ifndef EARL_STRIDE_MOD_23
+#define EARL_STRIDE_MOD_23 -1
+#endif
 template <int NV>
 struct Shared : SharedData<NV> {
   static constexpr int R = (int)(sizeof(SharedData<NV>) % 256);
-  static constexpr int PAD = R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R);
+  static constexpr int TARGET = NV <= 10 ? (EARL_STRIDE_MOD_10) : (NV <= 15 ? (EARL_STRIDE_MOD_15) : (EARL_STRIDE_MOD_23));   // block size mod 256 (-1: the rule above)
+  static constexpr int PAD = TARGET >= 0 ? (TARGET - R + 256) % 256 : (R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R));
   char bank_pad[PAD == 0 ? 8 : PAD];
 };
 
@@ -458,6 +471,11 @@ struct BlkTable {
   int n_blk, max_con;
   int begin[MB], end[MB], box[MB], link[MB], box_link[MB], cap[MB];
   double center[MB][3], reach[MB], box_pos[MB][3], box_quat[MB][4], box_half[MB][3];
+  // second bounding test (include/earl_physics.h blk_obb_*).  Compiled in for the small model only: the door's random-action workload has 2.4 near
+  // blocks per env by the sphere test and 0.5 by both (35.1 -> 36.1 M env-steps/s); the peg lies on the table (that block is always near) and the
+  // kitchen's hands are far from the fixtures, so there the extra test only costs (peg -3.5 %, kitchen 0).  Results do not depend on it.
+  static constexpr bool SAT = MB <= 16;
+  double obb_center[SAT ? MB : 1][3], obb_half[SAT ? MB : 1][3];
   double cls_mu[EARL_MAXCLS], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5];   // contact classes
 };
 template <int MB>
@@ -477,7 +495,10 @@ __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collisi
     t.begin[i] = col->blk_begin[i]; t.end[i] = col->blk_end[i]; t.box[i] = b; t.link[i] = col->blk_link[i]; t.cap[i] = col->blk_cap[i];
     t.box_link[i] = col->box_link[b]; t.reach[i] = col->blk_reach[i];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { t.center[i][k] = col->blk_center[i][k]; t.box_pos[i][k] = col->box_pos[b][k]; t.box_half[i][k] = col->box_half[b][k]; }
+    for (int k = 0; k < 3; ++k) {
+      t.center[i][k] = col->blk_center[i][k]; t.box_pos[i][k] = col->box_pos[b][k]; t.box_half[i][k] = col->box_half[b][k];
+      if constexpr (BlkTable<MB>::SAT) { t.obb_center[i][k] = col->blk_obb_center[i][k]; t.obb_half[i][k] = col->blk_obb_half[i][k]; }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) t.box_quat[i][k] = col->box_quat[b][k];
   }
@@ -487,8 +508,12 @@ __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collisi
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
 template <int NV, int LPE, bool INTEGRATE>
 __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV>::T& m, const BlkTable<Lim<NV>::MB>& bt, const earl_collision_model* __restrict__ col, const int sub,
-                                        const int grp, const V3 mpos, const Q4 mq, const double (&ctrl)[EARL_MAXACT], double* qacc_out,
+                                        const int grp, const V3 mpos, const Q4 mq, const double (&ctrl)[EARL_MAXACT], const bool warm, double* qacc_out,
                                         double* efc_out) {
+  // warm (uniform): s.aprev holds the solution of the previous timestep of the same env step / call, and the active-set iteration of K9 starts
+  // from the set the new rows take AT it (MuJoCo warm-starts its solver from the previous qacc likewise) instead of from "every row active".
+  // The fixed point is the same and so are the bits of the result (the last iteration builds the same Hessian from the same set); what changes is
+  // the number of iterations: 1.81 -> 1.38 per timestep in contact for the door under random actions (oracle/physics_oracle.c g_newton_stats).
   static_assert(NV <= LPE, "one lane per link");
   constexpr int MC = Lim<NV>::MC, NA = Lim<NV>::NA, NT = Lim<NV>::NT;
   static_assert(MC <= LPE, "one lane per contact");
@@ -553,13 +578,21 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     // C0: bounding test per block, lane = block (LPE blocks per pass)
     const int b = cb + sub < bt.n_blk ? cb + sub : 0;
     const int bl = bt.link[b], xl = bt.box_link[b];
-    V3 cs = ld3(bt.center[b]), cb_ = ld3(bt.box_pos[b]);
+    constexpr bool SAT = BlkTable<Lim<NV>::MB>::SAT;
+    V3 cs = ld3(bt.center[b]), cb_ = ld3(bt.box_pos[b]), ca = ld3(bt.obb_center[SAT ? b : 0]);
     Q4 qb = ldq(bt.box_quat[b]);
+    double RA[3][3];                                   // frame of the set's link (identity: world)
     {
       double R[3][3];
       qmat(ldq(s.Xq[bl < 0 ? 0 : bl]), R);
-      const V3 w = add(ld3(s.Xp[bl < 0 ? 0 : bl]), mulv(R, cs));
+      const V3 xa = ld3(s.Xp[bl < 0 ? 0 : bl]);
+      const V3 w = add(xa, mulv(R, cs));
       cs = selv(bl < 0, cs, w);
+      ca = selv(bl < 0, ca, add(xa, mulv(R, ca)));
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) RA[i][j] = bl < 0 ? (i == j ? 1.0 : 0.0) : R[i][j];
       const Q4 ql = ldq(s.Xq[xl < 0 ? 0 : xl]);
       qmat(ql, R);
       const V3 w2 = add(ld3(s.Xp[xl < 0 ? 0 : xl]), mulv(R, cb_));
@@ -572,7 +605,26 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     qmat(qb, Rb);
     const V3 x = mulvT(Rb, vsub(cs, cb_)), h = ld3(bt.box_half[b]);
     const V3 d{x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z)};
-    const bool nearb = cb + sub < bt.n_blk && dot(d, d) < bt.reach[b] * bt.reach[b];
+    // second test: a face axis of the set's box (frame RA, centre ca, half extents incl. radii and margin) or of the block's box separates them
+    bool separated = false;
+    if constexpr (SAT) {
+      const V3 t = mulvT(RA, vsub(cb_, ca)), ha = ld3(bt.obb_half[b]);
+      const double tt[3] = {t.x, t.y, t.z}, hA[3] = {ha.x, ha.y, ha.z}, hB[3] = {h.x, h.y, h.z};
+      double Rm[3][3], aR[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          Rm[i][j] = RA[0][i] * Rb[0][j] + RA[1][i] * Rb[1][j] + RA[2][i] * Rb[2][j];
+          aR[i][j] = fabs(Rm[i][j]);
+        }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) separated |= fabs(tt[i]) > hA[i] + (aR[i][0] * hB[0] + aR[i][1] * hB[1] + aR[i][2] * hB[2]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        separated |= fabs(tt[0] * Rm[0][j] + tt[1] * Rm[1][j] + tt[2] * Rm[2][j]) > hB[j] + (hA[0] * aR[0][j] + hA[1] * aR[1][j] + hA[2] * aR[2][j]);
+    }
+    const bool nearb = cb + sub < bt.n_blk && dot(d, d) < bt.reach[b] * bt.reach[b] && !separated;
     const unsigned long long bal = __ballot(nearb);
     if constexpr (LPE == 64) {
       nearg |= (unsigned int)bal; nearw |= (unsigned int)bal;
@@ -976,11 +1028,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     {
       const int c = sub < MC ? sub : MC - 1;
       const bool cv = sub < nct;
-      double vn = 0, vt1 = 0, vt2 = 0;
+      double vn = 0, vt1 = 0, vt2 = 0, pn = 0, pt1 = 0, pt2 = 0;      // J qvel; J a_prev (warm start)
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        const double qd = s.qv[j];
-        vn = fma(s.con.CJ[c][0][j], qd, vn); vt1 = fma(s.con.CJ[c][1][j], qd, vt1); vt2 = fma(s.con.CJ[c][2][j], qd, vt2);
+        const double qd = s.qv[j], ap = s.aprev[j];
+        const double jn = s.con.CJ[c][0][j], j1 = s.con.CJ[c][1][j], j2 = s.con.CJ[c][2][j];
+        vn = fma(jn, qd, vn); vt1 = fma(j1, qd, vt1); vt2 = fma(j2, qd, vt2);
+        pn = fma(jn, ap, pn); pt1 = fma(j1, ap, pt1); pt2 = fma(j2, ap, pt2);
       }
       const double* rec = s.con.ct[c];
       const int cls = cv ? ((int)rec[7] & 63) : 0;
@@ -993,7 +1047,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const double basea = -kk * dd * (rec[0] - margin);
       car[0] = -bb * (vn + cmu * vt1) + basea; car[1] = -bb * (vn - cmu * vt1) + basea;
       car[2] = -bb * (vn + cmu * vt2) + basea; car[3] = -bb * (vn - cmu * vt2) + basea;
-      cact = cv ? 0xFu : 0u;
+      unsigned int wb = 0;                              // the edges that pull at a_prev
+      wb |= (pn + cmu * pt1 - car[0] < 0) ? 1u : 0u;
+      wb |= (pn - cmu * pt1 - car[1] < 0) ? 2u : 0u;
+      wb |= (pn + cmu * pt2 - car[2] < 0) ? 4u : 0u;
+      wb |= (pn - cmu * pt2 - car[3] < 0) ? 8u : 0u;
+      cact = cv ? (warm ? wb : 0xFu) : 0u;
     }
   }
   fence();
@@ -1042,6 +1101,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   PSTAMP(9);
   coupled = __any(coupled);
   bool act = lim_inst;
+  if (warm) act = lim_inst && (lim_side * s.aprev[l] - lim_aref < 0);     // (dry-friction rows keep their cold start, the quadratic zone: from a_prev's
+                                                                          // zones the three-state iteration cycled 18 times as often in the kitchen model)
   double a[NV];
   double L[NV * (NV + 1) / 2];
   PCOUNT(23, ncmax > 0 ? 1 : 0); PCOUNT(24, ncmax);
@@ -1282,6 +1343,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fence();
     if (!__any(changed)) break;
   }
+  if constexpr (INTEGRATE) {
+    double al = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
+    if (isl) s.aprev[l] = al;                           // (read after the fences of the next timestep)
+  }
   PSTAMP(8);
   if constexpr (!INTEGRATE) {
     double al = 0;
@@ -1406,6 +1473,7 @@ __device__ __forceinline__ void load_state(Shared<NV>& s, const typename ModelOf
   if (sub < NV) {
     s.qp[sub] = (bd < 0 || sub < bd) ? qrow[sub] : 0.0;
     s.qv[sub] = vrow[sub];
+    s.aprev[sub] = 0.0;              // (read, and discarded, by the cold first timestep)
   }
   if (sub < 4) {
     double v = sub == 0 ? 1.0 : 0.0;
@@ -1461,7 +1529,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
   for (int ac = 0; ac < m.n_act; ++ac) ctrl[ac] = a.ctrl[(size_t)env * (a.ctrl_stride ? a.ctrl_stride : m.n_act) + ac];
   constexpr int NC = 6 + 2 * NV;
   for (int ts = 0; ts < a.nsub; ++ts)
-    substep<NV, LPE, INTEGRATE>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, (a.qacc_out && live) ? a.qacc_out + (size_t)env * NV : nullptr,
+    substep<NV, LPE, INTEGRATE>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, INTEGRATE && ts > 0, (a.qacc_out && live) ? a.qacc_out + (size_t)env * NV : nullptr,
                                 (a.efc_out && live) ? a.efc_out + (size_t)env * NC : nullptr);
   if constexpr (INTEGRATE) {
     if (live) store_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
@@ -1633,6 +1701,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
   stage_model(m, a.m);
   const earl_sawyer_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
+#ifdef EARL_PHYS_PROF
+  const unsigned long long wave_t0 = __builtin_readcyclecounter();
+#endif
   const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
   const bool live = env_raw < n;
   const int env = live ? env_raw : n - 1;
@@ -1653,7 +1724,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     mpos.y = fmin(fmax(mpos.y + (double)cy, cfg.mocap_low[1]), cfg.mocap_high[1]);
     mpos.z = fmin(fmax(mpos.z + (double)cz, cfg.mocap_low[2]), cfg.mocap_high[2]);
     const double ctrl[EARL_MAXACT] = {(double)act.w, -(double)act.w, 0, 0};
-    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
+    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, ts > 0, nullptr, nullptr);   // (every env step starts cold: step() x T == rollout(T))
     const size_t row = (size_t)t * n + env;
     // failure guard (MuJoCo's mj_checkPos / mj_checkVel; metaworld's `except MujocoException` in SawyerXYZEnv.step [UPSTREAM]): an env whose
     // state went NaN or beyond EARL_BAD_VALUE is rolled back to its last stable state (the rows in HBM) and re-emits its last stable
@@ -1702,6 +1773,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next step's observation reads the goal row back through global memory
     }
   }
+#ifdef EARL_PHYS_PROF
+  if (lane == 0 && blockIdx.x * WPB + wave < 4096) g_wave_cycles[blockIdx.x * WPB + wave] = __builtin_readcyclecounter() - wave_t0;
+#endif
   if (!live) return;
   // (qpos / qvel / mocap_pos were written back after the last stable step)
   if (a.st.last_obs && a.T > 0 && sub < 14) a.st.last_obs[(size_t)env * 14 + sub] = a.out.obs[((size_t)(a.T - 1) * n + env) * 14 + sub];
@@ -1799,7 +1873,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
   // set_state -> sim.forward(): kinematics of the state just written
   const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
   const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
-  substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mpos, mq, ctrl, nullptr, nullptr);
+  substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mpos, mq, ctrl, false, nullptr, nullptr);
   sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.reset_obs ? a.reset_obs + (size_t)env * 14 : nullptr, nullptr, nullptr, nullptr, 0.0,
                   (resetting && a.st.last_obs) ? a.st.last_obs + (size_t)env * 14 : nullptr);
   // reset_model keeps obj_init_pos and the pegHead site of the freshly placed peg for the dense reward (sawyer_peg.py:213-215)
@@ -1941,6 +2015,9 @@ int earl_sawyer_rollout_door_w8(const earl_link_model* model, const earl_collisi
   return launched("sawyer_rollout (door, 8 waves per CU)");
 }
 #ifdef EARL_PHYS_PROF
+int earl_debug_read_wave_cycles_w8(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_cycles), sizeof(unsigned long long) * 4096) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
 int earl_debug_read_phys_profile_w8(unsigned long long* out, int reset) {          // this unit's own copy of the phase counters
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_prof), sizeof(unsigned long long) * 32) != hipSuccess) return EARL_ERR_LAUNCH;
   if (reset) {
@@ -2044,6 +2121,9 @@ int earl_debug_set_physics_lanes(int lanes_per_env) {
 }
 
 #ifdef EARL_PHYS_PROF
+int earl_debug_read_wave_cycles(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_cycles), sizeof(unsigned long long) * 4096) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
 int earl_debug_read_phys_profile(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_prof), sizeof(unsigned long long) * 32) != hipSuccess) return EARL_ERR_LAUNCH;
   if (reset) {

@@ -64,7 +64,7 @@ class CollisionModelStruct(C.Structure):   # struct earl_collision_model
   _fields_ = [('n_sph', C.c_int32), ('n_box', C.c_int32), ('n_pair', C.c_int32), ('n_cls', C.c_int32),
               ('n_blk', C.c_int32), ('max_con', C.c_int32), ('pad_', C.c_int32 * 2), ('blk_begin', C.c_int32 * MAXBLK), ('blk_end', C.c_int32 * MAXBLK),
               ('blk_box', C.c_int32 * MAXBLK), ('blk_link', C.c_int32 * MAXBLK), ('blk_cap', C.c_int32 * MAXBLK), ('blk_center', C.c_double * 3 * MAXBLK),
-              ('blk_reach', C.c_double * MAXBLK),
+              ('blk_reach', C.c_double * MAXBLK), ('blk_obb_center', C.c_double * 3 * MAXBLK), ('blk_obb_half', C.c_double * 3 * MAXBLK),
               ('sph_link', C.c_int32 * MAXSPH), ('box_link', C.c_int32 * MAXBOX),
               ('sph_pos', C.c_double * 3 * MAXSPH), ('sph_r', C.c_double * MAXSPH),
               ('box_pos', C.c_double * 3 * MAXBOX), ('box_quat', C.c_double * 4 * MAXBOX), ('box_half', C.c_double * 3 * MAXBOX),
@@ -171,7 +171,9 @@ def load_collision_model(d):
   assert c.n_blk <= (16 if small else 32) and 0 < c.max_con <= (8 if small else MAXCON)      # Lim<NV>::MB, ::MC
   for dst, src in ((c.blk_begin, d['col_blk_begin']), (c.blk_end, d['col_blk_end']), (c.blk_box, d['col_blk_box']),
                    (c.blk_link, d['col_blk_link']), (c.blk_center, d['col_blk_center']), (c.blk_reach, d['col_blk_reach']),
-                   (c.blk_cap, d['col_blk_cap'] if 'col_blk_cap' in d else np.full(c.n_blk, c.max_con, np.int32))):
+                   (c.blk_cap, d['col_blk_cap'] if 'col_blk_cap' in d else np.full(c.n_blk, c.max_con, np.int32)),
+                   (c.blk_obb_center, d['col_blk_obb_center'] if 'col_blk_obb_half' in d else np.zeros((c.n_blk, 3))),
+                   (c.blk_obb_half, d['col_blk_obb_half'] if 'col_blk_obb_half' in d else np.full((c.n_blk, 3), 1e30))):   # (absent: never separated)
     _fill(dst, src)
   for dst, src in ((c.sph_link, d['col_sph_link']), (c.box_link, d['col_box_link']), (c.sph_pos, d['col_sph_pos']), (c.sph_r, d['col_sph_r']),
                    (c.box_pos, d['col_box_pos']), (c.box_quat, d['col_box_quat']), (c.box_half, d['col_box_half']),

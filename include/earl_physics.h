@@ -120,6 +120,10 @@ typedef struct earl_collision_model {
                                                 axis to the edge.  (A chain sphere on the flat of a plate is pushed along the plate normal; MuJoCo's
                                                 box-cylinder contact pushes along the cylinder's radial direction where the plate's edge digs in.) */
   double blk_center[EARL_MAXBLK][3], blk_reach[EARL_MAXBLK];
+  /* second bounding test of a block: the box of its set in the frame of blk_link (axis-aligned there; radii, edge lengths, the slack of sliding
+   * members and the contact margin included) against the block's box, by the six face axes of the two boxes: a separating axis means no pair
+   * of the block is within its margin, so the block is skipped.  Both tests only ever skip blocks without contacts: results do not depend on them */
+  double blk_obb_center[EARL_MAXBLK][3], blk_obb_half[EARL_MAXBLK][3];
   int32_t sph_link[EARL_MAXSPH];             /* -1 = fixed to the world */
   int32_t box_link[EARL_MAXBOX];
   double sph_pos[EARL_MAXSPH][3], sph_r[EARL_MAXSPH];
@@ -135,7 +139,12 @@ typedef struct earl_collision_model {
  * NULL (no contacts).  State (updated in place):
  * qpos [n, nq], qvel [n, nv]; inputs mocap_pos [n,3], mocap_quat [n,4] (used AS GIVEN in the weld's orientation rows: an unnormalised quaternion scales their residual and
  * Jacobian by its norm -- metaworld's [1, 0, 1, 0] is meant to be passed unchanged), ctrl [n, n_act];
- * att_xpos (may be NULL) [n, n_att, 3]: world positions of the attachments after the last timestep. */
+ * att_xpos (may be NULL) [n, n_att, 3]: world positions of the attachments after the last timestep.
+ * Solver start: the active-set iteration of the call's FIRST timestep starts from "every instantiated row active"; every later timestep of the same
+ * call starts from the set its rows take at the previous timestep's solution (dry-friction rows always from their quadratic zone) -- MuJoCo warm-starts
+ * from the previous qacc likewise.  The fixed point does not depend on the start, so one call of nsub timesteps and nsub calls of one agree whenever
+ * the iteration converges within its 8 passes (always, in the door and peg soaks; 33 of 1 M kitchen timesteps did not).  The env entry points
+ * (earl_sawyer_rollout, earl_kitchen_step) start every ENV step cold, so T calls of one step and one fused rollout of T run the same iteration. */
 int earl_physics_step(const void* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
                       earl_stream_t stream);

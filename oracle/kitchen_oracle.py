@@ -37,7 +37,7 @@ class KitchenOracle:
     self.mocap = mp[0]
     out = None
     for _ in range(FRAME_SKIP):
-      self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl9[0, :2], self.mocap, self.mq)
+      self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl9[0, :2], self.mocap, self.mq, None if out is None else out['qacc'])
     obs = go.kitchen_obs(self.p, self.qpos[None], self.goal[None], None if noise is None else np.asarray(noise)[None])[0]
     self.last = obs[:9].copy()
     sites = np.stack([self.lm.attachment(out['pos'], out['quat'], k)[0] for k in self.site_idx])     # kinematics of the last timestep's start

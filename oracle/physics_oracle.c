@@ -117,7 +117,19 @@ typedef struct {
   double qacc[NVMAX];
   double efc[6 + 2 * NVMAX];
   int ncon;
+  int warm;                               /* qacc holds the previous timestep's solution of the SAME call (env step): the active-set iteration starts from it */
 } StepOut;
+
+/* Warm start of the active-set iteration (the rule the kernels implement): the first timestep of a call / of an env step starts from "every
+ * instantiated row active" (friction rows in their quadratic zone); every later timestep starts from the set its NEW rows take at the previous
+ * timestep's solution a_prev (row active iff J a_prev - aref < 0; dry-friction rows always start in their quadratic zone).  The fixed point -- and so the result, up to
+ * the order of the sums -- is the same; the iteration count is what changes.  0 = always the cold start (round 1 / early round 2). */
+static int g_warm_start = 1;
+int oracle_set_warm_start(int w) { const int prev = g_warm_start; g_warm_start = w; return prev; }
+static long long g_newton_stats[5];       /* timesteps, Newton iterations, timesteps with contacts, iterations in those, timesteps that used all 8 iterations without reaching a fixed point */
+void oracle_newton_stats(long long* out, int reset) {
+  for (int i = 0; i < 5; ++i) { out[i] = g_newton_stats[i]; if (reset) g_newton_stats[i] = 0; }
+}
 
 /* 1 (the rule the kernels implement): the mocap quaternion enters the weld rows AS GIVEN (metaworld sets [1, 0, 1, 0], norm sqrt 2: residual
  * and Jacobian of the orientation rows scale by sqrt 2); 0 = normalised first (round 1, kept as an experiment switch for tools/heldout_eval.py) */
@@ -334,6 +346,26 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
         const V3 d = v3(x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z));
         if (!(dot(d, d) < col->blk_reach[b] * col->blk_reach[b])) continue;
       }
+      {
+        /* second bounding test (include/earl_physics.h blk_obb_*): a face axis of the set's box or of the block's box separates them */
+        double RA[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        V3 ca = ld3(col->blk_obb_center[b]);
+        const V3 ha = ld3(col->blk_obb_half[b]);
+        if (bl >= 0) { qmat(ldq(o->Xq[bl]), RA); ca = add(ld3(o->Xp[bl]), mulv(RA, ca)); }
+        const V3 t = mulvT(RA, sub(pb, ca));
+        const double tt[3] = {t.x, t.y, t.z}, hA[3] = {ha.x, ha.y, ha.z}, hB[3] = {h.x, h.y, h.z};
+        double Rm[3][3], aR[3][3];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) {
+            Rm[i][j] = RA[0][i] * Rb[0][j] + RA[1][i] * Rb[1][j] + RA[2][i] * Rb[2][j];
+            aR[i][j] = fabs(Rm[i][j]);
+          }
+        int separated = 0;
+        for (int i = 0; i < 3; ++i) separated |= fabs(tt[i]) > hA[i] + (aR[i][0] * hB[0] + aR[i][1] * hB[1] + aR[i][2] * hB[2]);
+        for (int j = 0; j < 3; ++j)
+          separated |= fabs(tt[0] * Rm[0][j] + tt[1] * Rm[1][j] + tt[2] * Rm[2][j]) > hB[j] + (hA[0] * aR[0][j] + hA[1] * aR[1][j] + hA[2] * aR[2][j]);
+        if (separated) continue;
+      }
       int btaken = 0;                                /* contacts of this block: at most blk_cap[b] (bits 0-7; bit 8: edges vs capsule) */
       const int bcap = col->blk_cap[b] & 255, capsule = (col->blk_cap[b] >> 8) & 1;
       for (int pi = col->blk_begin[b]; pi < col->blk_end[b] && ncon < col->max_con && btaken < bcap; ++pi) {
@@ -414,7 +446,18 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
   int act[NROWMAX];
   double a[NVMAX];
   for (int r = 0; r < nr; ++r) act[r] = 1;
+  if (g_warm_start && o->warm) {
+    /* (the dry-friction rows keep their cold start, the quadratic zone: started from a_prev's zones the three-state iteration cycled 18 times
+     * as often in the kitchen model -- 3,295 against 181 of 1 M timesteps used all 8 iterations; with this rule 33) */
+    for (int r = 0; r < nr; ++r) {
+      double x = -aref[r];
+      for (int j = 0; j < nv; ++j) x += J[r][j] * o->qacc[j];
+      act[r] = iseq[r] || x < 0;
+    }
+  }
+  int iters = 0, converged = 0;
   for (int it = 0; it < 8; ++it) {
+    ++iters;
     double H[NVMAX][NVMAX];
     for (int i = 0; i < nv; ++i) { a[i] = tau[i]; for (int j = 0; j < nv; ++j) H[i][j] = M[i][j]; }
     for (int r = 0; r < nr; ++r) {
@@ -445,8 +488,22 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       changed |= want != act[r];
       act[r] = want;
     }
-    if (!changed) break;
+    if (!changed) { converged = 1; break; }
   }
+  {
+    const int hasc = col && o->ncon > 0;
+#pragma omp atomic
+    g_newton_stats[4] += !converged;
+#pragma omp atomic
+    g_newton_stats[0] += 1;
+#pragma omp atomic
+    g_newton_stats[1] += iters;
+#pragma omp atomic
+    g_newton_stats[2] += hasc;
+#pragma omp atomic
+    g_newton_stats[3] += hasc ? iters : 0;
+  }
+  o->warm = integrate ? 1 : 0;
   for (int i = 0; i < nv; ++i) o->qacc[i] = a[i];
   memset(o->efc, 0, sizeof(o->efc));
   for (int r = 0; r < nr; ++r) {
@@ -504,6 +561,7 @@ static int physics24(const LM* m, const earl_collision_model* col, int32_t n, in
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < n; ++e) {
     StepOut o;
+    o.warm = 0;
     const V3 mpos = ld3(mocap_pos + 3 * (size_t)e);
     const Q4 mq = g_raw_mocap_quat ? ldq(mocap_quat + 4 * (size_t)e) : qnormalize(ldq(mocap_quat + 4 * (size_t)e));
     for (int ts = 0; ts < (integrate ? nsub : 1); ++ts)
@@ -572,6 +630,7 @@ int oracle_sawyer_rollout(const earl_link_model* m16, const earl_collision_model
         const float c = fminf(fmaxf(a[k], -1.f), 1.f) * scale;
         mp2[k] = fmin(fmax(mp[k] + (double)c, cfg->mocap_low[k]), cfg->mocap_high[k]);
       }
+      o.warm = 0;                                     /* every env step starts cold: step-by-step and fused rollouts agree */
       for (int ts = 0; ts < cfg->frame_skip; ++ts) substep(m, col, q2, v2, ld3(mp2), mq, ctrl, 1, &o);
       const size_t row = (size_t)t * n + e;
       double* ob = out->obs + row * 14;

@@ -584,11 +584,12 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
     if len(links) == 1:
       bl, slack = links[0], 0.0
       pts = np.array([sph[i]['pos'] for i in members])
+      dirs = np.array([sph[i].get('dir', np.zeros(3)) for i in members])
     else:                                         # sets on sibling slide links: bound them in the parent's frame at mid range
       bl = parent[links[0]]
       assert all(parent[l] == bl and m.jnt_type[l] == 1 for l in links)
       slack = max(0.5 * (m.jnt_range[l][1] - m.jnt_range[l][0]) for l in links)
-      pts = []
+      pts, dirs = [], []
       for i in members:
         l = sph[i]['link']
         jb = int(m.jnt_body[l]); pb = int(m.body_parent[jb])
@@ -596,11 +597,17 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
         tq = quat_mul(rel_quat[pb], m.body_quat[jb])
         mid = 0.5 * (m.jnt_range[l][0] + m.jnt_range[l][1])
         pts.append(tp + quat_mat(tq) @ (sph[i]['pos'] + m.jnt_axis[l] * mid))
-      pts = np.array(pts)
+        dirs.append(quat_mat(tq) @ sph[i].get('dir', np.zeros(3)))
+      pts, dirs = np.array(pts), np.array(dirs)
     ctr = pts.mean(0)
     rad = max(np.sqrt(((pts[k] - ctr) ** 2).sum()) + sph[i]['r'] + sph[i].get('hl', 0.0) for k, i in enumerate(members)) + slack
     mmax = max(max(sph[i]['margin'], bx['margin']) for i in members)
-    blocks.append(dict(box=j, link=bl, center=ctr, reach=rad + mmax + 1e-6, set=sname, members=members))
+    # second bound: the set's box in the frame of `bl` (axis-aligned there; radii, edge half-lengths and the slide slack included, the
+    # margin too), tested against the block's box by the six face axes of the two boxes (a separating axis = no pair within the margin)
+    ext = np.array([sph[i]['r'] + np.abs(dirs[k]) * sph[i].get('hl', 0.0) for k, i in enumerate(members)])
+    lo, hi = (pts - ext).min(0) - slack, (pts + ext).max(0) + slack
+    blocks.append(dict(box=j, link=bl, center=ctr, reach=rad + mmax + 1e-6, set=sname, members=members,
+                       obb_center=0.5 * (lo + hi), obb_half=0.5 * (hi - lo) + mmax + 1e-6))
   # Contacts are kept first come, first served up to max_contacts, so the ORDER of the blocks is a priority: blocks of the sets
   # listed first in spec['set_priority'] come first (stable otherwise), and a block contributes at most spec['set_cap'][set]
   # contacts.  Without this a gripper standing in the hole block (16 plate corners in contact) used up every slot and the peg,
@@ -633,6 +640,7 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
               col_blk_box=np.array([b['box'] for b in blocks], np.int32), col_blk_link=np.array([b['link'] for b in blocks], np.int32),
               col_blk_center=np.array([b['center'] for b in blocks]), col_blk_reach=np.array([b['reach'] for b in blocks]),
               col_blk_cap=np.array([b['cap'] for b in blocks], np.int32),
+              col_blk_obb_center=np.array([b['obb_center'] for b in blocks]), col_blk_obb_half=np.array([b['obb_half'] for b in blocks]),
               max_contacts=np.int32(spec.get('max_contacts', 8)))
 
 
@@ -712,7 +720,7 @@ class LinkModel:
       return self.att_pos[k].copy(), self.att_quat[k].copy()
     return pos[l] + quat_mat(quat[l]) @ self.att_pos[k], quat_mul(quat[l], self.att_quat[k])
 
-  def forward(self, qpos, qvel, ctrl, mocap_pos, mocap_quat):
+  def forward(self, qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev=None):
     nv = self.nv
     pos, quat, S = self.kinematics(qpos)
     I6 = []
@@ -814,7 +822,7 @@ class LinkModel:
       J, aref, Rg = np.vstack([J, Jc]), np.concatenate([aref, arc]), np.concatenate([Rg, Rc])
       inst = np.concatenate([inst, np.ones(len(arc), bool)])
     is_eq = np.zeros(len(aref), bool); is_eq[:6] = True; is_eq[nlim:nlim + n_eq_extra] = True
-    qacc, act = self.solve_primal(M, tau, J[inst], aref[inst], 1.0 / Rg[inst], is_eq[inst], fric=fric)
+    qacc, act = self.solve_primal(M, tau, J[inst], aref[inst], 1.0 / Rg[inst], is_eq[inst], fric=fric, **({} if a_prev is None else dict(a_prev=a_prev)))
     f = np.zeros(len(aref)); active = np.zeros(len(aref), bool)
     idx = np.nonzero(inst)[0]
     f[idx] = np.where(act, -(J[idx] @ qacc - aref[idx]) / Rg[idx], 0.0)
@@ -825,13 +833,17 @@ class LinkModel:
   contacts = True          # class-level switch: LinkModel.contacts = False gives the contact-free stepper
   max_contacts = 8         # the kernel's cap (tables: 'max_contacts' = earl_collision_model.max_con): the first max_contacts active pairs in pair order
 
-  def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8, fric=()):
+  def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8, fric=(), a_prev=None):
     """MuJoCo's primal problem  min_a 1/2 (a-a0)' M (a-a0) + sum_r 1/2 D_r [J_r a - aref_r]_-^2  (equalities: both signs)
     by the active-set Newton iteration the kernel runs: rows start active, then active <=> J_r a < aref_r.
     fric: dry-friction rows (dof j, aref, R, loss): cost 1/2 x^2 / R for |x| <= R loss, loss (|x| - R loss / 2) beyond (x = a_j - aref): a
-    row is QUADRATIC (state 0: it adds 1 / R to the diagonal) or saturated (state +-1: it pushes with -+loss); rows start quadratic."""
+    row is QUADRATIC (state 0: it adds 1 / R to the diagonal) or saturated (state +-1: it pushes with -+loss); rows start quadratic.
+    a_prev (warm start; the kernels pass the previous timestep's solution within one env step): the iteration starts from the set the rows
+    take AT a_prev instead.  The fixed point is the same, so is the result; only the number of iterations changes."""
     act = np.ones(len(aref), bool)
     fs = np.zeros(len(fric), int)
+    if a_prev is not None:
+      act = is_eq | (J @ a_prev - aref < 0)       # (the dry-friction rows keep their cold start: from a_prev's zones the iteration cycles far more often)
     a = None
     for _ in range(iters):
       Ja = J[act]
@@ -851,6 +863,24 @@ class LinkModel:
       act, fs = want, nfs
     return a, act
 
+  def obb_separated(self, b, bl, pos, quat, cb, Rb, hb):
+    """the block's second bounding test: one of the six face axes of (set box, block box) separates them (the margin is part of the set box)"""
+    if not hasattr(self, 'col_blk_obb_half'):
+      return False
+    RA = np.eye(3) if bl < 0 else quat_mat(quat[bl])
+    ca = self.col_blk_obb_center[b] if bl < 0 else pos[bl] + RA @ self.col_blk_obb_center[b]
+    ha = self.col_blk_obb_half[b]
+    R = RA.T @ Rb
+    t = RA.T @ (cb - ca)
+    aR = np.abs(R)
+    for i in range(3):
+      if abs(t[i]) > ha[i] + (aR[i, 0] * hb[0] + aR[i, 1] * hb[1] + aR[i, 2] * hb[2]):
+        return True
+    for j in range(3):
+      if abs(t[0] * R[0, j] + t[1] * R[1, j] + t[2] * R[2, j]) > hb[j] + (ha[0] * aR[0, j] + ha[1] * aR[1, j] + ha[2] * aR[2, j]):
+        return True
+    return False
+
   def collide(self, pos, quat):
     """sphere / point vs box tests over the model's pair list -> contacts (dist < margin), at most max_contacts"""
     out = []
@@ -867,7 +897,7 @@ class LinkModel:
           cb, Rb = pos[lb] + quat_mat(quat[lb]) @ self.col_box_pos[bi], quat_mat(quat_mul(quat[lb], self.col_box_quat[bi]))
         x = Rb.T @ (cs - cb)
         dd = x - np.clip(x, -self.col_box_half[bi], self.col_box_half[bi])
-        if (dd ** 2).sum() < self.col_blk_reach[b] ** 2:
+        if (dd ** 2).sum() < self.col_blk_reach[b] ** 2 and not self.obb_separated(b, bl, pos, quat, cb, Rb, self.col_box_half[bi]):
           near[self.col_blk_begin[b]:self.col_blk_end[b]] = True
     blk_of = np.zeros(len(self.col_pair), int)                        # block of every pair, contacts taken per block so far
     for b in range(len(self.col_blk_begin)):
@@ -959,8 +989,9 @@ class LinkModel:
         R.append(2 * mu * mu * R0)
     return np.array(J), np.array(aref), np.array(R)
 
-  def step(self, qpos, qvel, ctrl, mocap_pos, mocap_quat):
-    out = self.forward(qpos, qvel, ctrl, mocap_pos, mocap_quat)
+  def step(self, qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev=None):
+    """a_prev: out['qacc'] of the previous timestep of the same env step (warm start of the active-set iteration), None = cold"""
+    out = self.forward(qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev)
     M = out['M']
     qacc = np.linalg.solve(M + self.dt * np.diag(self.jnt_damping), M @ out['qacc'])
     qvel = qvel + self.dt * qacc

@@ -99,8 +99,8 @@ class SawyerDoorOracle:
     ctrl = np.array([float(a[3]), -float(a[3])])
     out = None
     stable = (self.qpos.copy(), self.qvel.copy(), mocap0)
-    for _ in range(self.frame_skip):
-      self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl, self.mocap, MOCAP_QUAT)
+    for _ in range(self.frame_skip):                       # (every env step starts cold, later timesteps from the previous solution)
+      self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl, self.mocap, MOCAP_QUAT, None if out is None else out['qacc'])
     self.steps += 1
     done = bool(self.horizon > 0 and self.steps >= self.horizon)
     if self._diverged():                                    # failure guard: include/earl_physics.h, earl_sawyer_out.status
@@ -280,8 +280,8 @@ class SawyerPegOracle(SawyerDoorOracle):
     self.mocap = np.clip(self.mocap + delta, MOCAP_LOW, MOCAP_HIGH)
     ctrl = np.array([float(a[3]), -float(a[3])])
     out = None
-    for _ in range(self.frame_skip):
-      self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl, self.mocap, MOCAP_QUAT)
+    for _ in range(self.frame_skip):                       # (every env step starts cold, later timesteps from the previous solution)
+      self.qpos, self.qvel, out = self.lm.step(self.qpos, self.qvel, ctrl, self.mocap, MOCAP_QUAT, None if out is None else out['qacc'])
     failed = self._diverged()                            # failure guard: include/earl_physics.h, earl_sawyer_out.status
     if failed:
       self.qpos, self.qvel, self.mocap = stable

@@ -181,7 +181,7 @@ def test_c_restatement_matches_the_numpy_statement(lm):
     np.testing.assert_allclose(r['qacc'][i], ref['qacc'], rtol=1e-10, atol=1e-10 * np.abs(ref['qacc']).max())
   r2 = cm.run(q[:2], v[:2], mp[:2], mq[:2], ctrl[:2], nsub=40)
   for i in range(2):
-    qq, vv = q[i].copy(), v[i].copy()
-    for _ in range(40):
-      qq, vv, _ = lm.step(qq, vv, ctrl[i], mp[i], mq[i])
+    qq, vv, out = q[i].copy(), v[i].copy(), None
+    for _ in range(40):                                      # one call = one env step: its first timestep starts the active-set iteration cold
+      qq, vv, out = lm.step(qq, vv, ctrl[i], mp[i], mq[i], None if out is None else out['qacc'])
     np.testing.assert_allclose(r2['qpos'][i], qq, atol=1e-12); np.testing.assert_allclose(r2['qvel'][i], vv, atol=1e-11)

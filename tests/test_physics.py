@@ -239,12 +239,15 @@ def test_active_set_newton_converges_to_the_kkt_point_through_a_grasp():
   (J a < aref, force > 0), inactive ones are satisfied (J a >= aref)"""
   from oracle.sawyer_oracle import SawyerDoorOracle
   lm = po.LinkModel(LINKS)
-  seen = []
+  seen, warm_calls = [], []
   orig = po.LinkModel.solve_primal
 
-  def checked(self, M, tau, J, aref, D, is_eq, iters=8, fric=()):
+  def checked(self, M, tau, J, aref, D, is_eq, iters=8, fric=(), a_prev=None):
     assert len(fric) == 0                                          # (dry joint friction: the kitchen model only)
-    a, act = orig(self, M, tau, J, aref, D, is_eq, iters)
+    a, act = orig(self, M, tau, J, aref, D, is_eq, iters, a_prev=a_prev)
+    cold, cold_act = orig(self, M, tau, J, aref, D, is_eq, iters)   # the warm start changes the path, not the fixed point
+    assert (cold_act == act).all() and np.array_equal(cold, a)
+    warm_calls.append(a_prev is not None)
     x = J @ a - aref
     want = is_eq | (x < 0)
     seen.append(((want == act).all(), len(aref), int((~is_eq & act).sum())))
@@ -263,6 +266,7 @@ def test_active_set_newton_converges_to_the_kkt_point_through_a_grasp():
     po.LinkModel.solve_primal = orig
   seen = np.array(seen)
   assert seen[:, 0].all(), 'converged every time'
+  assert sum(warm_calls) == 4 * 60 and warm_calls[-5:] == [False, True, True, True, True]     # the first timestep of every env step starts cold (and so does every settling timestep)
   assert seen[:, 1].max() > 20 and seen[:, 2].max() >= 6, (seen[:, 1].max(), seen[:, 2].max())      # contact rows were in play
 
 

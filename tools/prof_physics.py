@@ -26,6 +26,7 @@ def rollout_counters(n, T):
   w8 = '--w8' in sys.argv                         # the door's eight-waves-per-CU build (its own translation unit and counters)
   reader = 'earl_debug_read_phys_profile_w8' if w8 else 'earl_debug_read_phys_profile'
   _abi.SIGNATURES[reader] = [C.c_void_p, C.c_int]
+  _abi.SIGNATURES['earl_debug_read_wave_cycles_w8' if w8 else 'earl_debug_read_wave_cycles'] = [C.c_void_p]
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
   env = (SawyerPeg if '--peg' in sys.argv else SawyerDoor)(num_envs=n)
@@ -34,6 +35,7 @@ def rollout_counters(n, T):
     lib.earl_debug_set_door_variant(2)
   read = getattr(lib, reader)
   out = (C.c_ulonglong * 32)()
+  torch.manual_seed(0)
   acts = torch.rand(T, n, 4, device='cuda') * 2 - 1
   env.reset()
   torch.cuda.synchronize()
@@ -41,6 +43,12 @@ def rollout_counters(n, T):
   env.rollout(acts)
   torch.cuda.synchronize()
   read(out, 1)
+  wc = (C.c_ulonglong * 4096)()
+  getattr(lib, 'earl_debug_read_wave_cycles_w8' if w8 else 'earl_debug_read_wave_cycles')(wc)
+  import numpy as np
+  w = np.array(wc[:min(4096, n // 4)], dtype=np.float64) / (T * 5)
+  print(f'  wave durations, cycles per timestep: min {w.min():.0f}  p10 {np.percentile(w, 10):.0f}  median {np.median(w):.0f}  mean {w.mean():.0f}  p90 {np.percentile(w, 90):.0f}  '
+        f'p99 {np.percentile(w, 99):.0f}  max {w.max():.0f}   (the launch lasts as long as its slowest wave)')
   ts = max(1, out[20])
   print(f'rollout N={n} T={T}: timesteps of wave 0: {out[20]}; with a near block {out[21] / ts:.3f} (blocks per timestep {out[22] / ts:.2f}); '
         f'with contacts {out[23] / ts:.3f} (max contacts per env, mean {out[24] / ts:.2f}); Newton iterations per timestep {out[25] / ts:.2f}')
