@@ -48,15 +48,21 @@ __device__ unsigned long long g_phys_prof[32];
 #define PSTART() unsigned long long p_last = __builtin_readcyclecounter()
 __device__ unsigned long long g_wave_cycles[4096];      // duration of every wave of the last rollout launch (load balance)
 #define PCOUNT(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phys_prof[i] += (v); } while (0)
+#define RSTAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); PCOUNT(i, t_ - r_last); r_last = t_; } while (0)
+#define RSTART() unsigned long long r_last = __builtin_readcyclecounter()
 #elif defined(EARL_PHYS_MARK)
 // ISA markers (compile with -DEARL_PHYS_MARK -S and count the instructions between them); not in the product build
 #define PCOUNT(i, v) do {} while (0)
 #define PSTAMP(i) asm volatile("; EARL_PHASE_END " #i ::: "memory")
 #define PSTART() asm volatile("; EARL_PHASE_START" ::: "memory")
+#define RSTAMP(i) do {} while (0)
+#define RSTART() do {} while (0)
 #else
 #define PCOUNT(i, v) do {} while (0)
 #define PSTAMP(i) do {} while (0)
 #define PSTART() do {} while (0)
+#define RSTAMP(i) do {} while (0)
+#define RSTART() do {} while (0)
 #endif
 
 __device__ __forceinline__ void fence() {
@@ -257,6 +263,7 @@ struct SharedData {
       double rc[NV];                   // its right-hand side; then the right-hand side of K10
     } con;
   };
+  double mocap[4];                   // mocap position of this env (input of the weld rows; in LDS rather than in six registers that live across the whole rollout)
   double aprev[(NV + 1) & ~1];       // solution of the previous timestep of this env step: warm start of the active-set iteration (last, even
                                      // length: the 16-byte alignment of the arrays above decides between ds_read_b128 and two b64)
 };
@@ -508,7 +515,7 @@ __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collisi
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
 template <int NV, int LPE, bool INTEGRATE>
 __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV>::T& m, const BlkTable<Lim<NV>::MB>& bt, const earl_collision_model* __restrict__ col, const int sub,
-                                        const int grp, const V3 mpos, const Q4 mq, const double (&ctrl)[EARL_MAXACT], const bool warm, double* qacc_out,
+                                        const int grp, const Q4 mq, const double (&ctrl)[EARL_MAXACT], const bool warm, double* qacc_out,
                                         double* efc_out) {
   // warm (uniform): s.aprev holds the solution of the previous timestep of the same env step / call, and the active-set iteration of K9 starts
   // from the set the new rows take AT it (MuJoCo warm-starts its solver from the previous qacc likewise) instead of from "every row active".
@@ -946,7 +953,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     double Rh[3][3];
     qmat(hq, Rh);
     rrot = ev;
-    rpos = vsub(mpos, hp);
+    rpos = vsub(ld3(s.mocap), hp);
     const bool inchain = isl && ((m.anc_mask[la] >> l) & 1u);
     const V3 pv = add(Sv, cross(Sw, hp));
     const V3 aa = mulvT(Rh, Sw);
@@ -973,7 +980,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   }
   // limit row of this lane's dof: at most one side can be violated
   double lim_side, lim_D, lim_aref;
-  bool lim_inst;
+  bool lim_inst, lim_start;
   {
     const double q = s.qp[l], lo = m.range[l][0], hi = m.range[l][1];
     const bool islo = q - lo < 0;
@@ -984,6 +991,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     kbimp(m.jsolref[l], m.jsolimp[l], res, dt, kk, bb, dd);
     lim_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
     lim_aref = -bb * (lim_side * s.qv[l]) - kk * dd * res;
+    // start of the active-set iteration: the row if it is violated; warm: if it also pulls at a_prev.  (Where this line stands matters to the register
+    // allocator: here the eight-wave door build spills 100 B less than with the test at the head of K9, there the peg build is 3 % faster.)
+    if constexpr (NV <= 10) lim_start = lim_inst && (!warm || lim_side * s.aprev[l] - lim_aref < 0);
+    else lim_start = lim_inst;
   }
   // dry friction of this lane's dof (mjCNSTR_FRICTION_DOF): residual 0, cost 1/2 D x^2 for |x| <= loss / D, linear beyond (x = a_l - aref);
   // state 0 = quadratic zone (adds D to the diagonal), +-1 = saturated (constant force -+loss)
@@ -1100,9 +1111,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   }
   PSTAMP(9);
   coupled = __any(coupled);
-  bool act = lim_inst;
-  if (warm) act = lim_inst && (lim_side * s.aprev[l] - lim_aref < 0);     // (dry-friction rows keep their cold start, the quadratic zone: from a_prev's
-                                                                          // zones the three-state iteration cycled 18 times as often in the kitchen model)
+  if constexpr (NV > 10) { if (warm) lim_start = lim_inst && (lim_side * s.aprev[l] - lim_aref < 0); }
+  bool act = lim_start;                                // (dry-friction rows keep their cold start, the quadratic zone: from a_prev's zones the
+                                                       // three-state iteration cycled 18 times as often in the kitchen model)
   double a[NV];
   double L[NV * (NV + 1) / 2];
   PCOUNT(23, ncmax > 0 ? 1 : 0); PCOUNT(24, ncmax);
@@ -1522,14 +1533,14 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
   if constexpr (Lim<NV>::NT < NV) {                     // the mass-matrix entries between different trees are never written (K5): zero, once
     for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
   }
+  if (sub < 3) s.mocap[sub] = a.mocap_pos[(size_t)env * 3 + sub];
   fence();
-  const V3 mpos = ld3(a.mocap_pos + (size_t)env * 3);
   const Q4 mq = ldq(a.mocap_quat + (size_t)env * a.mq_stride);      // as given, NOT normalised (include/earl_physics.h)
   double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
   for (int ac = 0; ac < m.n_act; ++ac) ctrl[ac] = a.ctrl[(size_t)env * (a.ctrl_stride ? a.ctrl_stride : m.n_act) + ac];
   constexpr int NC = 6 + 2 * NV;
   for (int ts = 0; ts < a.nsub; ++ts)
-    substep<NV, LPE, INTEGRATE>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, INTEGRATE && ts > 0, (a.qacc_out && live) ? a.qacc_out + (size_t)env * NV : nullptr,
+    substep<NV, LPE, INTEGRATE>(s, m, bt, a.col, sub, grp, mq, ctrl, INTEGRATE && ts > 0, (a.qacc_out && live) ? a.qacc_out + (size_t)env * NV : nullptr,
                                 (a.efc_out && live) ? a.efc_out + (size_t)env * NC : nullptr);
   if constexpr (INTEGRATE) {
     if (live) store_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
@@ -1709,22 +1720,27 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
   const int env = live ? env_raw : n - 1;
   Shared<NV>& s = sh[wave * EPW + grp];
   load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+  if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
   fence();
-  V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
   const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
   int steps = a.st.steps_since_reset ? a.st.steps_since_reset[env] : 0;
   const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
   int sgc = gcf > 0 ? a.st.steps_since_goal_change[env] : 0;
   const float scale = (float)cfg.action_scale;
+  RSTART();
   for (int t = 0; t < a.T; ++t) {
     const float4 act = *reinterpret_cast<const float4*>(a.action + ((size_t)t * n + env) * 4);
     // set_xyz_action [UPSTREAM]: clip, float32 product with the scale, float64 add, box clip
     const float cx = fminf(fmaxf(act.x, -1.f), 1.f) * scale, cy = fminf(fmaxf(act.y, -1.f), 1.f) * scale, cz = fminf(fmaxf(act.z, -1.f), 1.f) * scale;
-    mpos.x = fmin(fmax(mpos.x + (double)cx, cfg.mocap_low[0]), cfg.mocap_high[0]);
-    mpos.y = fmin(fmax(mpos.y + (double)cy, cfg.mocap_low[1]), cfg.mocap_high[1]);
-    mpos.z = fmin(fmax(mpos.z + (double)cz, cfg.mocap_low[2]), cfg.mocap_high[2]);
+    if (sub < 3) {                                      // lane k moves coordinate k
+      const float ck = sub == 0 ? cx : (sub == 1 ? cy : cz);
+      s.mocap[sub] = fmin(fmax(s.mocap[sub] + (double)ck, cfg.mocap_low[sub]), cfg.mocap_high[sub]);
+    }
+    fence();
     const double ctrl[EARL_MAXACT] = {(double)act.w, -(double)act.w, 0, 0};
-    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mpos, mq, ctrl, ts > 0, nullptr, nullptr);   // (every env step starts cold: step() x T == rollout(T))
+    RSTAMP(12);
+    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);   // (every env step starts cold: step() x T == rollout(T))
+    RSTAMP(13);
     const size_t row = (size_t)t * n + env;
     // failure guard (MuJoCo's mj_checkPos / mj_checkVel; metaworld's `except MujocoException` in SawyerXYZEnv.step [UPSTREAM]): an env whose
     // state went NaN or beyond EARL_BAD_VALUE is rolled back to its last stable state (the rows in HBM) and re-emits its last stable
@@ -1733,16 +1749,17 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     const bool failed = group_any<LPE>(bad_lane, grp);
     sawyer_emit<NV>(s, m, cfg, sub, live && !failed, a.st.goal + (size_t)env * 7, a.out.obs + row * 14, a.out.reward ? a.out.reward + row : nullptr,
                     a.out.success ? a.out.success + row : nullptr, a.st.obj_init ? a.st.obj_init + (size_t)env * 6 : nullptr, (double)act.w);
+    RSTAMP(14);
     if (sub == 0 && live && a.out.status) a.out.status[row] = failed ? EARL_STEP_DIVERGED : 0;
     if (!failed) {
       // this state is the env's last stable one from here on
       if (live) {
         store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-        if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = sub == 0 ? mpos.x : (sub == 1 ? mpos.y : mpos.z);
+        if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = s.mocap[sub];
       }
     } else {
       load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-      mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
+      if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
       if (live) {
         const double* prev = t > 0 ? a.out.obs + ((size_t)(t - 1) * n + env) * 14 : (a.st.last_obs ? a.st.last_obs + (size_t)env * 14 : nullptr);
         if (sub < 14) a.out.obs[row * 14 + sub] = prev ? prev[sub] : __builtin_nan("");
@@ -1755,6 +1772,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     }
     fence();
     ++steps;
+    RSTAMP(15);
     if (sub == 0 && live && a.out.done) a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
     if (gcf > 0 && ++sgc >= gcf) {
       // LifelongWrapper.step (lifelong_wrapper.py:36-42): reset_goal() -> get_next_goal(), then the observation is re-read with the new
@@ -1799,7 +1817,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
   Shared<NV>& s = sh[wave * EPW + grp];
   const bool resetting = !a.observe_only && env_raw < cfg.n && (!a.mask || a.mask[env]);
   const bool live = env_raw < cfg.n && (a.observe_only || resetting);
-  V3 mpos = ld3(a.st.mocap_pos + (size_t)env * 3);
+  if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
   if (resetting) {
     const uint32_t gid = (uint32_t)(cfg.env_offset + env), c0 = (uint32_t)cfg.counter, c1 = (uint32_t)(cfg.counter >> 32);
     const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
@@ -1860,8 +1878,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");    // the observation below reads the goal row back through global memory
     fence();
     store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-    mpos = ld3(cfg.hand_init_pos);
-    if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = cfg.hand_init_pos[sub];
+    if (sub < 3) { s.mocap[sub] = cfg.hand_init_pos[sub]; a.st.mocap_pos[(size_t)env * 3 + sub] = cfg.hand_init_pos[sub]; }
     if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
     if (sub == 0 && a.st.steps_since_goal_change) a.st.steps_since_goal_change[env] = 0;     // LifelongWrapper.reset (lifelong_wrapper.py:25-28)
   } else {
@@ -1873,7 +1890,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
   // set_state -> sim.forward(): kinematics of the state just written
   const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
   const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
-  substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mpos, mq, ctrl, false, nullptr, nullptr);
+  substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mq, ctrl, false, nullptr, nullptr);
   sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.reset_obs ? a.reset_obs + (size_t)env * 14 : nullptr, nullptr, nullptr, nullptr, 0.0,
                   (resetting && a.st.last_obs) ? a.st.last_obs + (size_t)env * 14 : nullptr);
   // reset_model keeps obj_init_pos and the pegHead site of the freshly placed peg for the dense reward (sawyer_peg.py:213-215)

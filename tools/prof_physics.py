@@ -52,6 +52,9 @@ def rollout_counters(n, T):
   ts = max(1, out[20])
   print(f'rollout N={n} T={T}: timesteps of wave 0: {out[20]}; with a near block {out[21] / ts:.3f} (blocks per timestep {out[22] / ts:.2f}); '
         f'with contacts {out[23] / ts:.3f} (max contacts per env, mean {out[24] / ts:.2f}); Newton iterations per timestep {out[25] / ts:.2f}')
+  es = max(1, ts // 5)
+  print(f'  env-step level, cycles per ENV step: action load + mocap {out[12] / es:.0f}, the 5 timesteps {out[13] / es:.0f}, guard + observation / reward {out[14] / es:.0f}, '
+        f'state store + bookkeeping {out[15] / es:.0f}')
   tot = sum(out[:12])
   print(f'  cycles per timestep {tot / ts:.0f}: ' + ', '.join(f'{NAMES[i].split()[0]} {out[i] / ts:.0f}' for i in range(12) if NAMES[i] != '-'))
 
