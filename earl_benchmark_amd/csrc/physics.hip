@@ -1739,7 +1739,17 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     fence();
     const double ctrl[EARL_MAXACT] = {(double)act.w, -(double)act.w, 0, 0};
     RSTAMP(12);
-    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);   // (every env step starts cold: step() x T == rollout(T))
+    for (int ts = 0; ts < cfg.frame_skip; ++ts) {
+      // The lane's index is passed through an empty asm at the head of every timestep: the per-lane LDS addresses derived from it are then recomputed
+      // inside the timestep (a few integer adds) instead of being hoisted out of the rollout loop, where dozens of them lived across the whole kernel
+      // and went to scratch memory under the register cap -- every reload is a global-memory round trip on the timestep's critical path (scratch per
+      // lane: eight-wave door build 296 -> 212 B, peg 36 -> 0 B).  (Doing the same to the block pointer hides that it is an LDS address: 640 B.)
+      // (Small model only: the peg build, with 512 registers, loses 2 % to the recomputation although its last 36 B of scratch go too.)
+      int sub_ = sub;
+      if constexpr (NV <= 10) asm volatile("" : "+v"(sub_));
+      __builtin_assume(sub_ >= 0 && sub_ < LPE);
+      substep<NV, LPE, true>(s, m, bt, a.col, sub_, grp, mq, ctrl, ts > 0, nullptr, nullptr);   // (every env step starts cold: step() x T == rollout(T))
+    }
     RSTAMP(13);
     const size_t row = (size_t)t * n + env;
     // failure guard (MuJoCo's mj_checkPos / mj_checkVel; metaworld's `except MujocoException` in SawyerXYZEnv.step [UPSTREAM]): an env whose
