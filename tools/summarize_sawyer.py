@@ -38,7 +38,8 @@ if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
   res['hbm_bytes_per_launch'] = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
   tp = os.path.join(PROF, 'traffic.json')
   tj = json.load(open(tp)) if os.path.exists(tp) else {}
-  tj[w] = {"hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": f"profiles/{tag}_{w}_rollout_pmc.json", "rocprof_kernel_average_ns": float(kern["AverageNs"]), "issue": res.get("derived"), "waves_per_simd": None}
+  tj[w] = {"hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": f"profiles/{tag}_{w}_rollout_pmc.json", "rocprof_kernel_average_ns": float(kern["AverageNs"]), "issue": res.get("derived"),
+           "waves_per_simd": 2 if w == "sawyer_door" else 1}      # the bench batch (8192 envs) runs the door's eight-waves-per-CU build: two waves per SIMD; the peg has one
   json.dump(tj, open(tp, 'w'), indent=1)
 json.dump(res, open(os.path.join(PROF, f'{tag}_{w}_rollout_pmc.json'), 'w'), indent=1)
 print(json.dumps(res, indent=1))
