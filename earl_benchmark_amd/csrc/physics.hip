@@ -979,21 +979,24 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     if (sub < 6) { s.con.wD[r] = rcp_nr(Rg); s.con.war[r] = -bb * Jv - kk * dd * res; }
   }
   // limit row of this lane's dof: at most one side can be violated
-  double lim_side, lim_D, lim_aref;
+  double lim_D, lim_aref;
+  bool lim_lo;                                         // which side: the row's sign +1 (lower limit) / -1 is applied as a select (x or -x: the same bits as
+                                                       // the product with +-1.0, and one fp64 value less to keep -- the peg build reloaded it from scratch
+                                                       // memory in every pass of the active-set iteration)
   bool lim_inst, lim_start;
   {
     const double q = s.qp[l], lo = m.range[l][0], hi = m.range[l][1];
     const bool islo = q - lo < 0;
     const double res = islo ? q - lo : hi - q;
-    lim_side = islo ? 1.0 : -1.0;
+    lim_lo = islo;
     lim_inst = isl && m.limited[l] && res < 0;
     double kk, bb, dd;
     kbimp(m.jsolref[l], m.jsolimp[l], res, dt, kk, bb, dd);
     lim_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
-    lim_aref = -bb * (lim_side * s.qv[l]) - kk * dd * res;
+    lim_aref = -bb * (lim_lo ? s.qv[l] : -s.qv[l]) - kk * dd * res;
     // start of the active-set iteration: the row if it is violated; warm: if it also pulls at a_prev.  (Where this line stands matters to the register
     // allocator: here the eight-wave door build spills 100 B less than with the test at the head of K9, there the peg build is 3 % faster.)
-    if constexpr (NV <= 10) lim_start = lim_inst && (!warm || lim_side * s.aprev[l] - lim_aref < 0);
+    if constexpr (NV <= 10) lim_start = lim_inst && (!warm || (lim_lo ? s.aprev[l] : -s.aprev[l]) - lim_aref < 0);
     else lim_start = lim_inst;
   }
   // dry friction of this lane's dof (mjCNSTR_FRICTION_DOF): residual 0, cost 1/2 D x^2 for |x| <= loss / D, linear beyond (x = a_l - aref);
@@ -1111,7 +1114,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   }
   PSTAMP(9);
   coupled = __any(coupled);
-  if constexpr (NV > 10) { if (warm) lim_start = lim_inst && (lim_side * s.aprev[l] - lim_aref < 0); }
+  if constexpr (NV > 10) { if (warm) lim_start = lim_inst && ((lim_lo ? s.aprev[l] : -s.aprev[l]) - lim_aref < 0); }
   bool act = lim_start;                                // (dry-friction rows keep their cold start, the quadratic zone: from a_prev's zones the
                                                        // three-state iteration cycled 18 times as often in the kitchen model)
   double a[NV];
@@ -1120,7 +1123,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   for (int it = 0; it < 8; ++it) {
     PCOUNT(25, 1);
     if (isl) {
-      double dlv = act ? lim_D : 0.0, rlv = act ? lim_D * lim_aref * lim_side : 0.0;
+      const double lda = lim_D * lim_aref;
+      double dlv = act ? lim_D : 0.0, rlv = act ? (lim_lo ? lda : -lda) : 0.0;
       if constexpr (Lim<NV>::EXTRAS) {
         if (fr_loss > 0) {
           dlv += fr_state == 0 ? fr_D : 0.0;
@@ -1324,7 +1328,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     double al = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
-    const bool want = lim_inst && (lim_side * al - lim_aref < 0);
+    const bool want = lim_inst && ((lim_lo ? al : -al) - lim_aref < 0);
     bool changed = want != act;
     act = want;
     if constexpr (Lim<NV>::EXTRAS) {
@@ -1381,9 +1385,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         efc_out[sub] = -s.con.wD[sub] * (Ja - s.con.war[sub]);
       }
       if (isl) {
-        const double f = act ? -lim_D * (lim_side * al - lim_aref) : 0.0;
-        efc_out[6 + 2 * l] = lim_side > 0 ? f : 0.0;
-        efc_out[7 + 2 * l] = lim_side > 0 ? 0.0 : f;
+        const double f = act ? -lim_D * ((lim_lo ? al : -al) - lim_aref) : 0.0;
+        efc_out[6 + 2 * l] = lim_lo ? f : 0.0;
+        efc_out[7 + 2 * l] = lim_lo ? 0.0 : f;
       }
     }
   } else {
