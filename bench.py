@@ -420,7 +420,8 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
 
 def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=2048, T=400, cpu_seconds=None):
   """BASELINE configs[3]: kitchen, 2048 envs in total range-sharded over the GPUs (n_global / world per GPU: STRONG scaling), one bench step =
-  reset + T = 400 env steps (the reference's eval horizon) of 40 timesteps each; four launches per env step (glue, stepper, glue, glue).
+  reset + T = 400 env steps (the reference's eval horizon) of 40 timesteps each in ONE fused launch (earl_kitchen_rollout); the per-step surface
+  (earl_kitchen_step, eight launches per env step) is timed beside it as `step_api`.
   Own stepper, reduced collision set, parity with MuJoCo unpinned (envs/kitchen.py).  -> result dict on rank 0"""
   from earl_benchmark_amd.envs.kitchen import Kitchen
   from earl_benchmark_amd.wrappers import PersistentStateWrapper
@@ -431,11 +432,17 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
   g = torch.Generator(device=device).manual_seed(77 + rank)
   acts = (torch.rand(T, n, 9, generator=g, device=device) * 2 - 1).to(torch.float32)
 
-  def episode():
+  outbuf = {}
+
+  def episode():                                       # reset + ONE fused launch of T env steps (earl_kitchen_rollout), like the Sawyer lines
     env.reset()
-    for t in range(T):
-      out = env.step(acts[t])
-    return out
+    res = env.unwrapped.rollout(acts, out=outbuf)
+    return res['obs'][-1], res['reward'][-1], res['done'][-1], {'status': res['status'][-1]}
+
+  def stepped(k):                                      # the closed-loop surface: one earl_kitchen_step call (eight launches) per env step
+    env.reset()
+    for t in range(k):
+      env.step(acts[t])
   for _ in range(warmup):
     episode()
   clk = _Clock(torch, device)
@@ -459,6 +466,11 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
     dt = float(tmax.item())
   assert bool(done.all()) and bool(torch.isfinite(o).all())
   fails = int(env.unwrapped.fail_count.sum())
+  clk.sync()
+  t1 = time.perf_counter()
+  stepped(T)
+  clk.sync()
+  dt_step = time.perf_counter() - t1
   if rank != 0:
     return None
   prof = {}
@@ -470,14 +482,17 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
   return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
           'issue_frac': simd_issue,
           'roofline': {'bound': 'issue', 'achieved': simd_issue, 'peak': 1.0, 'unit': 'share of SIMD cycles issuing an instruction (waves per SIMD x '
-                       'SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES) of physics_kernel<23, 32>', 'frac': simd_issue, 'valu': issue.get('valu'), 'lds': issue.get('lds'),
+                       'SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES) of kitchen_rollout_kernel', 'frac': simd_issue, 'valu': issue.get('valu'), 'lds': issue.get('lds'),
                        'scalar': issue.get('scalar'), 'wait': issue.get('wait_any'), 'waves_per_simd': prof.get('waves_per_simd'),
                        'source': (prof.get('source', '') + ' (static: SQ counters collected by rocprofv3 --pmc in separate runs of this workload)') if issue else None},
           'timesteps_per_s': steps * n_global * T * 40 / dt, 'gpu_ms_per_env_step': clk.elapsed_ms() / (steps * T), 'scaling': 'strong',
           'diverged_env_steps': fails,
-          'config': {'workload': f'kitchen dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + {T} env steps of 40 timesteps '
-                                 'per bench step; own stepper (nv = 23, 32 lanes per env), reduced collision set, parity with MuJoCo unpinned',
-                     'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 40, 'launches_per_env_step': 4},
+          'step_api': {'value': n * T / dt_step, 'unit': 'env-steps/s (this rank)', 'ms_per_env_step': dt_step / T * 1e3,
+                       'note': 'the same episode through env.step(): one earl_kitchen_step call = eight launches per env step; every launch of the stepper '
+                               'lasts as long as its slowest wave, which the fused rollout only pays once per episode'},
+          'config': {'workload': f'kitchen dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 40 '
+                                 'timesteps per bench step; own stepper (nv = 23, 32 lanes per env), reduced collision set, parity with MuJoCo unpinned',
+                     'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 40, 'launches_per_episode': 1},
           'cpu_baseline': None if cpu_seconds is None else kitchen_cpu_baseline(cpu_seconds)}
 
 

@@ -121,6 +121,7 @@ SIGNATURES = {
     'earl_debug_set_physics_lanes': [C.c_int],
     'earl_debug_set_door_variant': [C.c_int],
     'earl_kitchen_step': [C.c_void_p, C.c_void_p, _P(KitchenParams), _P(KitchenCfg), _P(KitchenState), C.c_void_p, _P(KitchenOut), C.c_void_p],
+    'earl_kitchen_rollout': [C.c_void_p, C.c_void_p, _P(KitchenParams), _P(KitchenCfg), _P(KitchenState), C.c_void_p, C.c_int32, _P(KitchenOut), C.c_void_p],
     'earl_sawyer_rollout': [C.c_void_p, C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_int32, _P(SawyerOut), C.c_void_p],
     'earl_sawyer_reset': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState)] + [C.c_void_p] * 5,
     'earl_sawyer_observe': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_void_p],

@@ -241,6 +241,7 @@ struct SharedData {
   union {
     struct { double Xq1[NV][4], Xp1[NV][3]; } k2;                    // second buffer of the doubling
     struct { double att[8][3]; } emit;                               // observation epilogue (after the last timestep of an env step)
+    struct { double obs[46], noise[46], sites[8][3], targets[9]; } kit;   // kitchen env step inside the fused rollout (before / after the timesteps)
     struct {
       double S[NV][6];                 // motion subspace, world coordinates about the origin: [angular; linear] (every lane keeps its own column in registers)
       double I10[NV][10];
@@ -1978,6 +1979,151 @@ __global__ void kitchen_finish_kernel(const KitchenArgs a) {
   a.st.steps_since_reset[e] = steps;
   a.out.done[e] = (a.cfg.horizon > 0 && steps >= a.cfg.horizon) ? 1 : 0;
 }
+// The whole env step of earl_kitchen_step, T times, in ONE launch: a wave walks its two envs through action glue -> 40 timesteps -> failure guard ->
+// observation (Philox noise) -> reward -> bookkeeping without ever meeting the other waves.  A launch of the stepper lasts as long as its slowest
+// wave -- the one env with a finger on a fixture -- and between the launches of consecutive env steps every other wave waited for it; here the
+// waves drift apart and only the sum over the rollout counts.  Same arithmetic as the per-step kernels above and csrc/glue.hip (expression by
+// expression: kitchen_action_kernel, kitchen_obs_kernel, uniform_kernel, kitchen_reward_kernel, kitchen_guard / finish): bit-identical outputs.
+struct KitchenRolloutArgs {
+  const void* m;
+  const earl_collision_model* col;
+  earl_kitchen_params p;
+  earl_kitchen_cfg cfg;
+  earl_kitchen_state st;
+  earl_kitchen_out out;          // rows [T, n, ...]
+  const float* action;           // [T, n, 9]
+  int T;
+};
+__device__ __forceinline__ double kit_norm_diff(const double* a, const double* b, const int n) {     // glue.hip norm_diff
+  double d = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double x = a[i] - b[i];
+    d = fma(x, x, d);
+  }
+  return sqrt(d);
+}
+__global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(const KitchenRolloutArgs a) {
+#pragma clang fp contract(off)
+  constexpr int NV = 23, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
+  __shared__ typename ModelOf<NV>::T m;
+  __shared__ BlkTable<Lim<NV>::MB> bt;
+  __shared__ Shared<NV> sh[EPW * WPB];
+  __shared__ earl_kitchen_params kp;
+  stage_blocks(bt, a.col);
+  if (threadIdx.x == 0) kp = a.p;
+  stage_model(m, a.m);                                  // (ends with the workgroup barrier)
+  const earl_kitchen_cfg& cfg = a.cfg;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
+  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
+  const bool live = env_raw < n;
+  const int env = live ? env_raw : n - 1;
+  Shared<NV>& s = sh[wave * EPW + grp];
+  load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
+  for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;      // (entries between different trees are never written, K5)
+  if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
+  fence();
+  const Q4 mq = ldq(cfg.mocap_quat_dev);
+  int steps = a.st.steps_since_reset[env];
+  const int kk = sub < 9 ? sub : 8;                     // this lane's action component
+  for (int t = 0; t < a.T; ++t) {
+    const size_t row = (size_t)t * n + env;
+    // ---- KitchenV0.step up to do_simulation (kitchen_action_kernel): mocap target, the nine position targets
+    {
+      const double x = (double)a.action[row * 9 + kk];
+      const double c = x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x);
+      const double ak = kp.act_mid[kk] + c * kp.act_amp[kk];
+      if (sub < 3) {
+        const double y = s.mocap[sub] + ak * kp.mocap_range[sub];
+        s.mocap[sub] = y < kp.mocap_clip_lower[sub] ? kp.mocap_clip_lower[sub] : (y > kp.mocap_clip_upper[sub] ? kp.mocap_clip_upper[sub] : y);
+      }
+      if (sub < 9) {
+        const double v = ak < kp.vel_bound[sub][0] ? kp.vel_bound[sub][0] : (ak > kp.vel_bound[sub][1] ? kp.vel_bound[sub][1] : ak);
+        const double y = a.st.last_qp_robot[(size_t)env * 9 + sub] + v * kp.step_duration;
+        s.kit.targets[sub] = y < kp.pos_bound[sub][0] ? kp.pos_bound[sub][0] : (y > kp.pos_bound[sub][1] ? kp.pos_bound[sub][1] : y);
+      }
+    }
+    fence();
+    const double ctrl[EARL_MAXACT] = {s.kit.targets[0], s.kit.targets[1], 0, 0};      // do_simulation: ctrl[i] = targets[i] for i < nu = 2
+    if (sub < 3 && live) a.st.mocap_pos[(size_t)env * 3 + sub] = s.mocap[sub];
+    fence();
+    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);
+    // ---- attachments at the kinematics of the last timestep's start; the eight task sites for the reward
+    if (sub < m.n_att && live) {
+      const V3 p = attachment<NV>(s, m, sub);
+      double* o = a.st.att_xpos + ((size_t)env * m.n_att + sub) * 3;
+      o[0] = p.x; o[1] = p.y; o[2] = p.z;
+    }
+    const bool bad_lane = sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE);
+    const bool failed = group_any<LPE>(bad_lane, grp);
+    if (failed) {
+      // rolled back to the last stable state (the rows in HBM); returns its last stable observation, reward 0 (kitchen_guard / finish kernels)
+      load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
+      if (live) {
+        for (int k = sub; k < 46; k += LPE) a.out.obs[row * 46 + k] = a.st.last_obs[(size_t)env * 46 + k];
+        if (sub == 0) {
+          a.out.reward[row] = 0.0; a.out.success[row] = 0;
+          if (a.st.fail_count) a.st.fail_count[env] += 1;
+        }
+      }
+    } else {
+      if (live) store_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
+      if (sub < 8) {
+        const V3 p = attachment<NV>(s, m, cfg.site_att[sub]);
+        s.kit.sites[sub][0] = p.x; s.kit.sites[sub][1] = p.y; s.kit.sites[sub][2] = p.z;
+      }
+      // Robot.get_obs + KitchenV0._get_obs: 46 draws of U(-1, 1) per env (uniform_kernel: one Philox block = two draws), then kitchen_obs_kernel
+      if (cfg.sensor_noise && sub < 23) {
+        const uint64_t ctr = cfg.counter + (uint64_t)t;
+        const earl::U4 b = earl::philox4x32_10(earl::U4{0x4B00u + (uint32_t)sub, (uint32_t)(cfg.env_offset + env), (uint32_t)ctr, (uint32_t)(ctr >> 32)},
+                                               (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
+        const double lo = -1.0, hi = 1.0;
+        s.kit.noise[2 * sub] = lo + (hi - lo) * earl::u01(b.x, b.y);
+        s.kit.noise[2 * sub + 1] = lo + (hi - lo) * earl::u01(b.z, b.w);
+      }
+      fence();
+      for (int k = sub; k < 46; k += LPE) {
+        double v;
+        if (k < 23) {
+          v = s.qp[k];
+          if (cfg.sensor_noise) v = v + (kp.robot_noise_ratio * kp.pos_noise_amp[k]) * s.kit.noise[k < 9 ? k : k + 9];
+        } else {
+          v = a.st.goal[(size_t)env * 23 + (k - 23)];
+        }
+        s.kit.obs[k] = v;
+        if (live) {
+          a.out.obs[row * 46 + k] = v;
+          a.st.last_obs[(size_t)env * 46 + k] = v;
+          if (k < 9) a.st.last_qp_robot[(size_t)env * 9 + k] = v;
+        }
+      }
+      fence();
+      if (sub == 0 && live) {                           // kitchen.py:141-183 (kitchen_reward_kernel)
+        const double* o = s.kit.obs;
+        const double dist = kit_norm_diff(o + 9, o + 32, 14);
+        double r = -10 * dist;
+        const int start[8] = {9, 11, 13, 15, 17, 19, 20, 22}, len[8] = {2, 2, 2, 2, 2, 1, 2, 1};
+        bool reaching = false;
+        for (int c = 0; c < 8; ++c) {
+          if (kit_norm_diff(o + start[c], o + start[c] + 23, len[c]) < len[c] * 0.01) r += 1;
+          else if (!reaching) {
+            reaching = true;
+            r += -0.5 * kit_norm_diff(s.mocap, s.kit.sites[c], 3);
+          }
+        }
+        a.out.reward[row] = r;
+        a.out.success[row] = dist <= 0.3;
+      }
+    }
+    ++steps;
+    if (sub == 0 && live) {
+      if (a.out.status) a.out.status[row] = failed ? EARL_STEP_DIVERGED : 0;
+      a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");    // the next step reads last_qp_robot (and, after a failure, the state rows) back through global memory
+    fence();
+  }
+  if (sub == 0 && live) a.st.steps_since_reset[env] = steps;
+}
 #endif
 
 int launched(const char* what) {
@@ -2143,6 +2289,18 @@ int earl_kitchen_step(const void* model, const earl_collision_model* col, const 
   if (int rc = earl_kitchen_reward(n, out->obs, st->mocap_pos, st->sites, out->reward, out->success, stream)) return rc;
   kitchen_finish_kernel<<<(n + 255) / 256, 256, 0, hs>>>(k);
   return launched("kitchen_step");
+}
+
+int earl_kitchen_rollout(const void* model, const earl_collision_model* col, const earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
+                         const earl_kitchen_state* st, const float* action, int32_t T, const earl_kitchen_out* out, earl_stream_t stream) {
+  if (!model || !params || !cfg || !st || !action || !out || cfg->n < 0 || T < 0 || cfg->n_att < 10 || cfg->n_att > 32 || cfg->frame_skip < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !st->last_qp_robot || !st->att_xpos || !st->steps_since_reset || !st->last_obs) return EARL_ERR_ARG;
+  if (!out->obs || !out->reward || !out->done || !out->success || !cfg->mocap_quat_dev) return EARL_ERR_ARG;
+  for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
+  if (cfg->n == 0 || T == 0) return EARL_OK;
+  KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T};
+  kitchen_rollout_kernel<<<grid_for<23, 32>(cfg->n), block_for<23>(), 0, (hipStream_t)stream>>>(k);
+  return launched("kitchen_rollout");
 }
 
 int earl_debug_set_physics_lanes(int lanes_per_env) {

@@ -206,9 +206,29 @@ class Kitchen:
     return obs, rew, done, {'success': suc, 'status': out['status']}
 
   def rollout(self, actions, out=None):
-    """T steps: actions [T, N, 9] -> dict(obs [T,N,46], reward [T,N], done, success, status)"""
+    """T steps: actions [T, N, 9] -> dict(obs [T,N,46], reward [T,N], done, success, status).  ONE launch (earl_kitchen_rollout: every wave walks its
+    envs through all T steps) unless the lifelong wrapper's goal switch is on, which steps; the results are those of T step() calls, bit for bit."""
     a = torch.as_tensor(actions, device=self.device)
     T = a.shape[0]
+    if int(self._cfg.goal_change_frequency) == 0 and not self.scalar_api and T > 0:
+      n = self.num_envs
+      with torch.cuda.device(self.device):
+        a = a.to(torch.float32).reshape(T, n, self.N_ROBOT).contiguous()
+        res = out if out is not None else {}
+        kw = dict(device=self.device)
+        for k, shape, dt in (('obs', (T, n, self.OBS_DIM), torch.float64), ('reward', (T, n), torch.float64), ('done', (T, n), torch.bool),
+                             ('success', (T, n), torch.bool), ('status', (T, n), torch.uint8)):
+          if k not in res or res[k].shape != shape or res[k].dtype != dt:
+            res[k] = torch.empty(shape, dtype=dt, **kw)
+        o = _abi.KitchenOut(obs=res['obs'].data_ptr(), reward=res['reward'].data_ptr(), done=res['done'].data_ptr(), success=res['success'].data_ptr(),
+                            status=res['status'].data_ptr())
+        self._cfg.counter = self._counter
+        _abi.check(self._lib.earl_kitchen_rollout(self.model.buf.data_ptr(), self.model.col_ptr, C.byref(self._params), C.byref(self._cfg), C.byref(self._st),
+                                                  a.data_ptr(), T, C.byref(o), self._stream()), 'earl_kitchen_rollout')
+      self._counter += T
+      self.total_step_count += T
+      self._last_success = res['success'][-1]
+      return res
     res = out if out is not None else {}
     rows = [self.step(a[t]) for t in range(T)]
     res['obs'] = torch.stack([r[0] for r in rows]); res['reward'] = torch.stack([r[1] for r in rows]); res['done'] = torch.stack([r[2] for r in rows])

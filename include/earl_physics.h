@@ -302,6 +302,13 @@ typedef struct earl_kitchen_out {
 int earl_kitchen_step(const void* model24, const earl_collision_model* col, const struct earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
                       const earl_kitchen_state* st, const float* action /* [n, 9] */, const earl_kitchen_out* out, earl_stream_t stream);
 
+/* T env steps of every env in ONE launch: action [T, n, 9] float32, the rows of `out` are [T, n, ...].  Equal, bit for bit, to T calls of
+ * earl_kitchen_step with cfg.counter, cfg.counter + 1, ... (state, scratch-free: action64 / ctrl9 / noise / qpos_bak / qvel_bak / sites / bad of
+ * `st` are not used and may be NULL); every wave walks its envs through the whole rollout on its own, so the launch costs the slowest wave's SUM
+ * over the T steps instead of T times the slowest wave of a step.  The lifelong wrapper's goal switch is not part of it (callers step those). */
+int earl_kitchen_rollout(const void* model24, const earl_collision_model* col, const struct earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
+                         const earl_kitchen_state* st, const float* action /* [T, n, 9] */, int32_t T, const earl_kitchen_out* out, earl_stream_t stream);
+
 /* measurement / test switch for the door model's rollout: 0 (default) = by batch size (n > 4096: one eight-wave workgroup per CU, see
  * csrc/physics_w8.hip; otherwise four single-wave workgroups per CU), 1 / 2 force the one or the other.  Results are bit-identical. */
 int earl_debug_set_door_variant(int variant);

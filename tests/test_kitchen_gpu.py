@@ -156,6 +156,59 @@ def test_full_size_soak_2048_envs_400_steps():
   assert float(u.qvel.abs().max()) < 50
 
 
+def test_fused_rollout_equals_stepping_bit_for_bit():
+  """earl_kitchen_rollout (ONE launch, T env steps) == T calls of earl_kitchen_step: outputs and every piece of state, incl. the sensor noise
+  (same Philox counters), through fixture contacts (200 steps of random actions reach them), for a batch that does not fill its last workgroup"""
+  import torch
+  from earl_benchmark_amd.envs.kitchen import Kitchen
+  n, T = 203, 200
+  a_env, b_env = Kitchen(num_envs=n, seed=11), Kitchen(num_envs=n, seed=11)
+  g = torch.Generator(device='cuda').manual_seed(5)
+  acts = torch.rand(T, n, 9, generator=g, device='cuda') * 2 - 1
+  acts[:, :40, 2] -= 0.6                                   # some hands go down to the counter's knobs and stay in contact
+  acts[3, 7] = float('nan')                                # a NaN action: the guard trips in env 7 at step 3 in both paths
+  a_env.reset(); b_env.reset()
+  fused = a_env.rollout(acts)
+  rows = [b_env.step(acts[t]) for t in range(T)]
+  assert torch.equal(fused['obs'].view(torch.int64), torch.stack([r[0] for r in rows]).view(torch.int64))
+  assert torch.equal(fused['reward'].view(torch.int64), torch.stack([r[1] for r in rows]).view(torch.int64))
+  assert torch.equal(fused['done'], torch.stack([r[2] for r in rows])) and torch.equal(fused['success'], torch.stack([r[3]['success'] for r in rows]))
+  assert torch.equal(fused['status'], torch.stack([r[3]['status'] for r in rows]))
+  assert int(fused['status'][3, 7]) == 1 and int(fused['status'].sum()) >= 1 and int(a_env.fail_count[7]) >= 1
+  for k in ('qpos', 'qvel', 'mocap_pos', 'last_qp_robot', 'last_obs', 'steps_since_reset', 'fail_count'):
+    x, y = getattr(a_env, k), getattr(b_env, k)
+    assert torch.equal(x.view(torch.int64) if x.dtype == torch.float64 else x, y.view(torch.int64) if y.dtype == torch.float64 else y), k
+  ok = (fused['status'][-1] == 0)
+  assert torch.equal(a_env.att[ok].view(torch.int64), b_env.att[ok].view(torch.int64))
+  assert a_env._counter == b_env._counter and a_env.total_step_count == b_env.total_step_count
+  # and the next rollout continues from there (counters, cached readings)
+  more = torch.rand(3, n, 9, generator=g, device='cuda') * 2 - 1
+  f2 = a_env.rollout(more)
+  r2 = [b_env.step(more[t]) for t in range(3)]
+  assert torch.equal(f2['obs'].view(torch.int64), torch.stack([r[0] for r in r2]).view(torch.int64))
+
+
+def test_fused_rollout_full_size():
+  """2048 envs x 400 steps in one launch: finite, done exactly at the horizon, nobody diverges; the first 64 envs equal a 64-env batch stepped one step at a time"""
+  import torch
+  from earl_benchmark_amd.envs.kitchen import Kitchen
+  from earl_benchmark_amd.wrappers import PersistentStateWrapper
+  n, T = 2048, 400
+  env = PersistentStateWrapper(Kitchen(num_envs=n, seed=3), T)
+  env.reset()
+  g = torch.Generator(device='cuda').manual_seed(0)
+  acts = torch.rand(T, n, 9, generator=g, device='cuda') * 2 - 1
+  out = env.unwrapped.rollout(acts)
+  assert bool(torch.isfinite(out['obs']).all()) and bool(torch.isfinite(out['reward']).all())
+  assert bool(out['done'][-1].all()) and not bool(out['done'][:-1].any()) and int(out['status'].sum()) == 0
+  small = PersistentStateWrapper(Kitchen(num_envs=64, seed=3), T)
+  small.reset()
+  for t in range(60):
+    o, r, d, info = small.step(acts[t, :64])
+    assert torch.equal(o.view(torch.int64), out['obs'][t, :64].view(torch.int64)), t
+    assert torch.equal(r.view(torch.int64), out['reward'][t, :64].view(torch.int64)), t
+
+
 def test_scalar_api_lifelong_wrapper_and_state_dict():
   """the reference's call surface for ONE env (numpy obs, python float reward, bool done, {}), the LifelongWrapper goal switch, checkpointing"""
   import torch

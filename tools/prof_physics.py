@@ -40,13 +40,18 @@ def rollout_counters(n, T):
   env.reset()
   torch.cuda.synchronize()
   read(out, 1)
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
   env.rollout(acts)
+  e1.record()
   torch.cuda.synchronize()
+  launch_ms = e0.elapsed_time(e1)
   read(out, 1)
   wc = (C.c_ulonglong * 4096)()
   getattr(lib, 'earl_debug_read_wave_cycles_w8' if w8 else 'earl_debug_read_wave_cycles')(wc)
   import numpy as np
   w = np.array(wc[:min(4096, n // 4)], dtype=np.float64) / (T * 5)
+  print(f'  launch {launch_ms:.2f} ms; sum of all wave durations / (wave slots = min(waves, 1024 single-wave or 2048 eight-wave-build slots)) would be the balanced time')
   print(f'  wave durations, cycles per timestep: min {w.min():.0f}  p10 {np.percentile(w, 10):.0f}  median {np.median(w):.0f}  mean {w.mean():.0f}  p90 {np.percentile(w, 90):.0f}  '
         f'p99 {np.percentile(w, 99):.0f}  max {w.max():.0f}   (the launch lasts as long as its slowest wave)')
   ts = max(1, out[20])
@@ -63,7 +68,7 @@ def main():
   if '--build' in sys.argv:
     return build()
   if '--rollout' in sys.argv:
-    return rollout_counters(8192 if '--w8' in sys.argv else 1024, 200 if '--peg' in sys.argv else 300)
+    return rollout_counters(8192 if ('--w8' in sys.argv or '--full' in sys.argv) else 1024, 200 if '--peg' in sys.argv else 300)
   import numpy as np
   import torch
   sys.path.insert(0, ROOT)
