@@ -48,6 +48,7 @@ __device__ unsigned long long g_phys_prof[32];
 #define PSTART() unsigned long long p_last = __builtin_readcyclecounter()
 __device__ unsigned long long g_wave_cycles[4096];      // duration of every wave of the last rollout launch (load balance)
 #define PCOUNT(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phys_prof[i] += (v); } while (0)
+#define PCOUNT_ALL(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_phys_prof[i], (unsigned long long)(v)); } while (0)   // every wave
 #define RSTAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); PCOUNT(i, t_ - r_last); r_last = t_; } while (0)
 #define RSTART() unsigned long long r_last = __builtin_readcyclecounter()
 #elif defined(EARL_PHYS_MARK)
@@ -55,12 +56,14 @@ __device__ unsigned long long g_wave_cycles[4096];      // duration of every wav
 #define PCOUNT(i, v) do {} while (0)
 #define PSTAMP(i) asm volatile("; EARL_PHASE_END " #i ::: "memory")
 #define PSTART() asm volatile("; EARL_PHASE_START" ::: "memory")
+#define PCOUNT_ALL(i, v) do {} while (0)
 #define RSTAMP(i) do {} while (0)
 #define RSTART() do {} while (0)
 #else
 #define PCOUNT(i, v) do {} while (0)
 #define PSTAMP(i) do {} while (0)
 #define PSTART() do {} while (0)
+#define PCOUNT_ALL(i, v) do {} while (0)
 #define RSTAMP(i) do {} while (0)
 #define RSTART() do {} while (0)
 #endif
@@ -1120,7 +1123,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
                                                        // three-state iteration cycled 18 times as often in the kitchen model)
   double a[NV];
   double L[NV * (NV + 1) / 2];
-  PCOUNT(23, ncmax > 0 ? 1 : 0); PCOUNT(24, ncmax);
+  PCOUNT(23, ncmax > 0 ? 1 : 0); PCOUNT(24, ncmax); PCOUNT(26, coupled ? 1 : 0);
+#ifdef EARL_PHYS_PROF
+  const unsigned long long k9_t0 = __builtin_readcyclecounter();
+#endif
   for (int it = 0; it < 8; ++it) {
     PCOUNT(25, 1);
     if (isl) {
@@ -1365,6 +1371,15 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
     if (isl) s.aprev[l] = al;                           // (read after the fences of the next timestep)
   }
+#ifdef EARL_PHYS_PROF
+  {
+    const unsigned long long dk = __builtin_readcyclecounter() - k9_t0;
+    PCOUNT(coupled ? 27 : 28, dk);
+#ifdef EARL_PHYS_PROF_ALL                                // (atomics of every wave: perturbs the clocks; for the counts only)
+    PCOUNT_ALL(29, 1); PCOUNT_ALL(30, coupled ? 1 : 0); PCOUNT_ALL(31, coupled ? dk : 0);
+#endif
+  }
+#endif
   PSTAMP(8);
   if constexpr (!INTEGRATE) {
     double al = 0;

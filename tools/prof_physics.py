@@ -57,6 +57,11 @@ def rollout_counters(n, T):
   ts = max(1, out[20])
   print(f'rollout N={n} T={T}: timesteps of wave 0: {out[20]}; with a near block {out[21] / ts:.3f} (blocks per timestep {out[22] / ts:.2f}); '
         f'with contacts {out[23] / ts:.3f} (max contacts per env, mean {out[24] / ts:.2f}); Newton iterations per timestep {out[25] / ts:.2f}')
+  nc = out[26]
+  print(f'  timesteps in which a contact joins the arm and the object (shared dense factorisation): {nc / ts:.3f}; active-set phase: {out[27] / max(1, nc):.0f} cycles in those, '
+        f'{out[28] / max(1, ts - nc):.0f} in the others')
+  if out[29]:                                      # (library built with -DEARL_PHYS_PROF_ALL)
+    print(f'  all waves: {out[29]} wave-timesteps, coupled {out[30] / max(1, out[29]):.3f}')
   es = max(1, ts // 5)
   print(f'  env-step level, cycles per ENV step: action load + mocap {out[12] / es:.0f}, the 5 timesteps {out[13] / es:.0f}, guard + observation / reward {out[14] / es:.0f}, '
         f'state store + bookkeeping {out[15] / es:.0f}')
