@@ -223,6 +223,8 @@ template <int NV> struct Lim {
   static constexpr int NT = NV > 16 ? 9 : NV;               // links that can have ancestors / descendants other than themselves: all, except in the kitchen
                                                             // model, where only the arm's nine do (every fixture is a tree of one link; checked by the host
                                                             // side).  The masked ancestor / subtree sums run over [0, NT) plus the lane's own link.
+  static constexpr int TS = NV == 15 ? 9 : NT;              // peg model: two trees, links [0, 9) = arm and [9, 15) = the free peg (checked by the host side, like NA): a
+                                                            // lane's ancestor / subtree sums then run over its OWN tree only, 9 terms instead of 15 (the others had weight 0)
   static constexpr bool EXTRAS = NV > 16;                   // dry joint friction, joint springs, force-limited actuators, joint couplings (earl_link_model24)
   static constexpr int LPE = NV > 16 ? 32 : 16;             // lanes per env instance (64 = one wavefront per env: measurement switch for nv <= 16)
 };
@@ -703,12 +705,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   fence();
   PSTAMP(1);
   const uint32_t amask = m.anc_mask[l], dmask = m.desc_mask[l];
+  // the links this lane's masked sums visit: [tbase, tend), KT of them at most (all of [0, NT) unless the model has two multi-link trees)
+  constexpr int TS = Lim<NV>::TS, KT = TS < NT ? (TS > NT - TS ? TS : NT - TS) : NT;
+  const int tbase = (TS < NT && l >= TS) ? TS : 0, tend = (TS < NT && l < TS) ? TS : NT;
   // ------------------------------------------------------------------ K4: composite inertia = masked subtree sum; FS = Ic S
   {
     double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int d = 0; d < NT; ++d) {
-      const double w = ((dmask >> d) & 1u) ? 1.0 : 0.0;
+    for (int k = 0; k < KT; ++k) {
+      const int d = TS < NT ? (tbase + k < tend ? tbase + k : tend - 1) : k;
+      const double w = ((TS == NT || tbase + k < tend) && ((dmask >> d) & 1u)) ? 1.0 : 0.0;
 #pragma unroll
       for (int e = 0; e < 10; ++e) acc[e] = fma(w, s.dyn.I10[d][e], acc[e]);
     }
@@ -728,12 +734,14 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   PSTAMP(3);
   // ------------------------------------------------------------------ K5: mass matrix, lane = column j
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
+  for (int k = 0; k < KT; ++k) {
+    const bool in = TS == NT || tbase + k < tend;
+    const int i = TS < NT ? (in ? tbase + k : tend - 1) : k;
     const double* fs = s.dyn.crb.FS[i];
     double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
     v = ((dmask >> i) & 1u) ? v : 0.0;                  // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
     if (i == l) v += m.armature[l];
-    if (isl && l <= i) s.M.put(i, l, v, true);
+    if (isl && l <= i && in) s.M.put(i, l, v, true);    // (the entries between the two trees were zeroed when the kernel started and are never written)
   }
   if constexpr (NT < NV) {                               // single-link trees: a diagonal entry each; the entries that join them to anything else were
     if (isl && l >= NT) {                                // zeroed when the kernel started and are never written
@@ -748,8 +756,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   {
     V3 w{0, 0, 0}, v{0, 0, 0};
 #pragma unroll
-    for (int a = 0; a < NT; ++a) {
-      const double qd = ((amask >> a) & 1u) ? s.qv[a] : 0.0;
+    for (int k = 0; k < KT; ++k) {
+      const bool in = TS == NT || tbase + k < tend;
+      const int a = TS < NT ? (in ? tbase + k : tend - 1) : k;
+      const double qd = (in && ((amask >> a) & 1u)) ? s.qv[a] : 0.0;
       const double* sa = s.dyn.S[a];
       w = add(w, scl(ld3(sa), qd));
       v = add(v, scl(ld3(sa + 3), qd));
@@ -781,8 +791,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fence();
     V3 aw{0, 0, 0}, av{-m.gravity[0], -m.gravity[1], -m.gravity[2]};
 #pragma unroll
-    for (int a = 0; a < NT; ++a) {
-      const double wgt = ((amask >> a) & 1u) ? 1.0 : 0.0;
+    for (int k = 0; k < KT; ++k) {
+      const bool in = TS == NT || tbase + k < tend;
+      const int a = TS < NT ? (in ? tbase + k : tend - 1) : k;
+      const double wgt = (in && ((amask >> a) & 1u)) ? 1.0 : 0.0;
       const double* ca = s.dyn.rne.Cc[a];
       aw = add(aw, scl(ld3(ca), wgt));
       av = add(av, scl(ld3(ca + 3), wgt));
@@ -804,8 +816,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fence();
     V3 ns{0, 0, 0}, fs{0, 0, 0};
 #pragma unroll
-    for (int d = 0; d < NT; ++d) {
-      const double wgt = ((dmask >> d) & 1u) ? 1.0 : 0.0;
+    for (int k = 0; k < KT; ++k) {
+      const bool in = TS == NT || tbase + k < tend;
+      const int d = TS < NT ? (in ? tbase + k : tend - 1) : k;
+      const double wgt = (in && ((dmask >> d) & 1u)) ? 1.0 : 0.0;
       const double* fd = s.dyn.rne.F[d];
       ns = add(ns, scl(ld3(fd), wgt));
       fs = add(fs, scl(ld3(fd + 3), wgt));
@@ -1550,7 +1564,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
   const int env = live ? env_raw : a.n - 1;            // idle groups shadow the last env and store nothing
   Shared<NV>& s = sh[wave * EPW + grp];
   load_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
-  if constexpr (Lim<NV>::NT < NV) {                     // the mass-matrix entries between different trees are never written (K5): zero, once
+  if constexpr (Lim<NV>::NT < NV || Lim<NV>::TS < Lim<NV>::NT) {   // the mass-matrix entries between different trees are never written (K5): zero, once
     for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
   }
   if (sub < 3) s.mocap[sub] = a.mocap_pos[(size_t)env * 3 + sub];
@@ -1740,6 +1754,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
   const int env = live ? env_raw : n - 1;
   Shared<NV>& s = sh[wave * EPW + grp];
   load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+  if constexpr (Lim<NV>::TS < Lim<NV>::NT) {            // the mass-matrix entries between the two trees are never written (K5): zero, once
+    for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
+  }
   if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
   fence();
   const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
@@ -1765,10 +1782,12 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
       // and went to scratch memory under the register cap -- every reload is a global-memory round trip on the timestep's critical path (scratch per
       // lane: eight-wave door build 296 -> 212 B, peg 36 -> 0 B).  (Doing the same to the block pointer hides that it is an LDS address: 640 B.)
       // (Small model only: the peg build, with 512 registers, loses 2 % to the recomputation although its last 36 B of scratch go too.)
-      int sub_ = sub;
+      int sub_ = sub, grp_ = grp;
       if constexpr (NV <= 10) asm volatile("" : "+v"(sub_));
+      else asm volatile("" : "+v"(grp_));               // (peg: the block's base address was what got spilled, and reloaded six times per timestep)
       __builtin_assume(sub_ >= 0 && sub_ < LPE);
-      substep<NV, LPE, true>(s, m, bt, a.col, sub_, grp, mq, ctrl, ts > 0, nullptr, nullptr);   // (every env step starts cold: step() x T == rollout(T))
+      __builtin_assume(grp_ >= 0 && grp_ < EPW);
+      substep<NV, LPE, true>(sh[wave * EPW + grp_], m, bt, a.col, sub_, grp_, mq, ctrl, ts > 0, nullptr, nullptr);   // (every env step starts cold: step() x T == rollout(T))
     }
     RSTAMP(13);
     const size_t row = (size_t)t * n + env;
@@ -1847,6 +1866,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
   Shared<NV>& s = sh[wave * EPW + grp];
   const bool resetting = !a.observe_only && env_raw < cfg.n && (!a.mask || a.mask[env]);
   const bool live = env_raw < cfg.n && (a.observe_only || resetting);
+  if constexpr (Lim<NV>::TS < Lim<NV>::NT) {            // (the forward pass below reads the whole mass matrix; K5 leaves the entries between the trees alone)
+    for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
+  }
   if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
   if (resetting) {
     const uint32_t gid = (uint32_t)(cfg.env_offset + env), c0 = (uint32_t)cfg.counter, c1 = (uint32_t)(cfg.counter >> 32);
