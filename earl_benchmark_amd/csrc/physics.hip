@@ -51,6 +51,8 @@ __device__ unsigned long long g_wave_cycles[4096];      // duration of every wav
 #define PCOUNT_ALL(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_phys_prof[i], (unsigned long long)(v)); } while (0)   // every wave
 #define RSTAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); PCOUNT(i, t_ - r_last); r_last = t_; } while (0)
 #define RSTART() unsigned long long r_last = __builtin_readcyclecounter()
+#define KSTART() unsigned long long k_last = __builtin_readcyclecounter()
+#define KSTAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); PCOUNT(i, t_ - k_last); k_last = t_; } while (0)
 #elif defined(EARL_PHYS_MARK)
 // ISA markers (compile with -DEARL_PHYS_MARK -S and count the instructions between them); not in the product build
 #define PCOUNT(i, v) do {} while (0)
@@ -59,6 +61,8 @@ __device__ unsigned long long g_wave_cycles[4096];      // duration of every wav
 #define PCOUNT_ALL(i, v) do {} while (0)
 #define RSTAMP(i) do {} while (0)
 #define RSTART() do {} while (0)
+#define KSTART() do {} while (0)
+#define KSTAMP(i) do {} while (0)
 #else
 #define PCOUNT(i, v) do {} while (0)
 #define PSTAMP(i) do {} while (0)
@@ -66,6 +70,8 @@ __device__ unsigned long long g_wave_cycles[4096];      // duration of every wav
 #define PCOUNT_ALL(i, v) do {} while (0)
 #define RSTAMP(i) do {} while (0)
 #define RSTART() do {} while (0)
+#define KSTART() do {} while (0)
+#define KSTAMP(i) do {} while (0)
 #endif
 
 __device__ __forceinline__ void fence() {
@@ -989,7 +995,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     const int r = sub < 6 ? sub : 5;
     double Jv = 0;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) Jv = fma(s.con.J6[r][j], s.qv[j], Jv);          // (the weld's chain lies within the first NT links)
+    for (int j = 0; j < (TS < NT ? TS : NT); ++j) Jv = fma(s.con.J6[r][j], s.qv[j], Jv);          // (the weld's chain lies within the first tree)
     const double res = r < 3 ? pick3(rpos, r) : pick3(rrot, r - 3);
     double kk, bb, dd;
     kbimp(m.weld_solref, m.weld_solimp, res, dt, kk, bb, dd);
@@ -1033,6 +1039,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};       // lane c (< nct) owns contact c: edge weights and reference accelerations
   unsigned int cact = 0;                               // active pyramid edges of that contact (bits 0..3)
   bool coupled = false;                                // some contact of some env of the wave joins the two trees (arm / object)
+  bool ctA = true, ctP = true;                         // ... and of the contact this lane owns
+  unsigned int armmask = 0, pegmask = 0;               // two-tree model: contact slots whose Jacobian has entries in the first / second tree in SOME env of the wave
   if (ncmax > 0) {
     for (int c = 0; c < ncmax; ++c) {
       const double* rec = s.con.ct[c];
@@ -1041,6 +1049,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const int pk = cv ? (int)rec[7] : 0;
       const int ls = ((pk >> 6) & 63) - 1, lb = (pk >> 12) - 1;
       coupled = coupled || (ls >= 0 && lb >= 0 && ((ls < NA) != (lb < NA)));
+      if constexpr (TS < NT) {
+        armmask |= __any(cv && ((ls >= 0 && ls < TS) || (lb >= 0 && lb < TS))) ? (1u << c) : 0u;
+        pegmask |= __any(cv && (ls >= TS || lb >= TS)) ? (1u << c) : 0u;
+      }
       // tangents: n x (the coordinate axis least aligned with n), normalised, then n x t1
       const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
       const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
@@ -1060,15 +1072,33 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     {
       const int c = sub < MC ? sub : MC - 1;
       const bool cv = sub < nct;
+      const double* rec = s.con.ct[c];
+      if constexpr (TS < NT) {                          // two-tree model: the trees in which this lane's contact has Jacobian entries (the other rows are exact zeros)
+        const int pk = cv ? (int)rec[7] : 0;
+        const int ls = ((pk >> 6) & 63) - 1, lb = (pk >> 12) - 1;
+        ctA = cv && ((ls >= 0 && ls < TS) || (lb >= 0 && lb < TS));
+        ctP = cv && (ls >= TS || lb >= TS);
+      }
       double vn = 0, vt1 = 0, vt2 = 0, pn = 0, pt1 = 0, pt2 = 0;      // J qvel; J a_prev (warm start)
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
+      auto rows = [&](const int j) {
         const double qd = s.qv[j], ap = s.aprev[j];
         const double jn = s.con.CJ[c][0][j], j1 = s.con.CJ[c][1][j], j2 = s.con.CJ[c][2][j];
         vn = fma(jn, qd, vn); vt1 = fma(j1, qd, vt1); vt2 = fma(j2, qd, vt2);
         pn = fma(jn, ap, pn); pt1 = fma(j1, ap, pt1); pt2 = fma(j2, ap, pt2);
+      };
+      if constexpr (TS < NT) {
+        if (ctA) {
+#pragma unroll
+          for (int j = 0; j < TS; ++j) rows(j);
+        }
+        if (ctP) {
+#pragma unroll
+          for (int j = TS; j < NV; ++j) rows(j);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) rows(j);
       }
-      const double* rec = s.con.ct[c];
       const int cls = cv ? ((int)rec[7] & 63) : 0;
       const double margin = bt.cls_margin[cls];
       cmu = bt.cls_mu[cls];
@@ -1101,7 +1131,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       double h = s.M.sym(i, l, ltri);
-      if (i < NT) {
+      if (i < (TS < NT ? TS : NT)) {                     // (the weld's chain lies within the first tree: its Jacobian is zero in the other rows)
 #pragma unroll
         for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
       }
@@ -1143,6 +1173,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #endif
   for (int it = 0; it < 8; ++it) {
     PCOUNT(25, 1);
+    KSTART();
     if (isl) {
       const double lda = lim_D * lim_aref;
       double dlv = act ? lim_D : 0.0, rlv = act ? (lim_lo ? lda : -lda) : 0.0;
@@ -1165,6 +1196,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       w[7] = cmu * (a3 * car[2] - a4 * car[3]);
     }
     fence();
+    KSTAMP(16);
     if constexpr (Lim<NV>::EXTRAS) {
       // column l of the iteration's Hessian, built in place in LDS: the stored equality part, then the active contact edges
       double rr = rw;
@@ -1217,8 +1249,21 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const bool cv = c < nct;
         const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
         rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
+        if constexpr (TS < NT) {
+          // the rows of a tree that slot c touches in no env of the wave hold exact zeros (C3 wrote them): skipped.  A peg lying on the table gives
+          // four contacts with entries in the peg's six rows only -- 18 of the 45 reads and multiply-adds per contact
+          if ((armmask >> c) & 1u) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+            for (int i = 0; i < TS; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+          }
+          if ((pegmask >> c) & 1u) {
+#pragma unroll
+            for (int i = TS; i < NV; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+        }
       }
       if (isl) {
 #pragma unroll
@@ -1227,6 +1272,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       }
     }
     fence();
+    KSTAMP(17);
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
     if constexpr (Lim<NV>::EXTRAS) {
@@ -1346,6 +1392,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       chol_regs<NV, NA>(L);
       solve_regs<NV, NA>(L, a);
     }
+    KSTAMP(18);
     double al = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
@@ -1363,9 +1410,20 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     if (ncmax > 0) {
       const int c = sub < MC ? sub : MC - 1;
       double an = 0, at1 = 0, at2 = 0;
+      if constexpr (TS < NT) {
+        if (ctA) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        an = fma(s.con.CJ[c][0][j], a[j], an); at1 = fma(s.con.CJ[c][1][j], a[j], at1); at2 = fma(s.con.CJ[c][2][j], a[j], at2);
+          for (int j = 0; j < TS; ++j) { an = fma(s.con.CJ[c][0][j], a[j], an); at1 = fma(s.con.CJ[c][1][j], a[j], at1); at2 = fma(s.con.CJ[c][2][j], a[j], at2); }
+        }
+        if (ctP) {
+#pragma unroll
+          for (int j = TS; j < NV; ++j) { an = fma(s.con.CJ[c][0][j], a[j], an); at1 = fma(s.con.CJ[c][1][j], a[j], at1); at2 = fma(s.con.CJ[c][2][j], a[j], at2); }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          an = fma(s.con.CJ[c][0][j], a[j], an); at1 = fma(s.con.CJ[c][1][j], a[j], at1); at2 = fma(s.con.CJ[c][2][j], a[j], at2);
+        }
       }
       unsigned int nb = 0;
       nb |= (an + cmu * at1 - car[0] < 0) ? 1u : 0u;
@@ -1377,6 +1435,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       cact = nb;
     }
     fence();
+    KSTAMP(19);
     if (!__any(changed)) break;
   }
   if constexpr (INTEGRATE) {

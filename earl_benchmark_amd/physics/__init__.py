@@ -155,6 +155,13 @@ def load_link_model(name):
   else:
     assert not np.any(d.get('jnt_frictionloss', 0)) and not np.any(d.get('jnt_stiffness', 0)) and len(d.get('jeq_joint1', ())) == 0, \
         'dry friction / springs / joint couplings need the 24-dof model form'
+    if nv == 15:
+      # csrc/physics.hip Lim<15>::TS = 9: two trees, links [0, 9) and [9, 15), with the weld on the first -- the lanes' ancestor / subtree sums and the
+      # contact rows are restricted to one tree each on the strength of this
+      par = [int(x) for x in d['parent']]
+      root = lambda l: l if par[l] < 0 else root(par[l])
+      assert all(root(l) == 0 for l in range(9)) and all(root(l) == 9 for l in range(9, 15)), 'peg model: trees [0, 9) and [9, 15)'
+      assert int(d['att_link'][int(d['weld_att'])]) < 9, 'peg model: the weld sits on the first tree'
   return s, d
 
 

@@ -62,6 +62,7 @@ def rollout_counters(n, T):
         f'{out[28] / max(1, ts - nc):.0f} in the others')
   if out[29]:                                      # (library built with -DEARL_PHYS_PROF_ALL)
     print(f'  all waves: {out[29]} wave-timesteps, coupled {out[30] / max(1, out[29]):.3f}')
+  print(f'  active-set pass, cycles per timestep: edge weights {out[16] / ts:.0f}, Hessian columns {out[17] / ts:.0f}, factor + solve {out[18] / ts:.0f}, row test {out[19] / ts:.0f}')
   es = max(1, ts // 5)
   print(f'  env-step level, cycles per ENV step: action load + mocap {out[12] / es:.0f}, the 5 timesteps {out[13] / es:.0f}, guard + observation / reward {out[14] / es:.0f}, '
         f'state store + bookkeeping {out[15] / es:.0f}')
