@@ -158,8 +158,15 @@ __device__ __forceinline__ void iapply(const double* I, const V3& w, const V3& v
   f = vsub(scl(v, I[0]), cross(h, w));
 }
 
-// MuJoCo impedance d(r) and (k, b) of a soft constraint row (reference: physics_oracle.kbimp)
-__device__ __forceinline__ void kbimp(const double* solref, const double* solimp, double r, double dt, double& k, double& b, double& d) {
+// MuJoCo impedance d(r) and (k, b) of a soft constraint row (reference: physics_oracle.kbimp).  (k, b) depend on the row's solref / solimp and the
+// timestep only: the kernels compute them ONCE per launch into the block table (stage_kb) instead of in every timestep -- two reciprocals with their
+// Newton steps, a chain of ~25 dependent operations per row kind
+__device__ __forceinline__ void kb_of(const double* solref, const double* solimp, double dt, double& k, double& b) {
+  const double tc = fmax(solref[0], 2 * dt), dr = solref[1], dw = solimp[1];
+  k = rcp_nr(dw * dw * tc * tc * dr * dr);
+  b = 2.0 * rcp_nr(dw * tc);
+}
+__device__ __forceinline__ void kbimp(const double* solref, const double* solimp, double r, double dt, double& k, double& b, double& d) {   // (all three, per call: the peg build)
   const double tc = fmax(solref[0], 2 * dt), dr = solref[1];
   const double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
   const double x = width > 0 ? fmin(fabs(r) * rcp_nr(width), 1.0) : 1.0;
@@ -171,6 +178,16 @@ __device__ __forceinline__ void kbimp(const double* solref, const double* solimp
   d = d0 + y * (dw - d0);
   k = rcp_nr(dw * dw * tc * tc * dr * dr);
   b = 2.0 * rcp_nr(dw * tc);
+}
+__device__ __forceinline__ double imp_of(const double* solimp, double r) {
+  const double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  const double x = width > 0 ? fmin(fabs(r) * rcp_nr(width), 1.0) : 1.0;
+  double y;
+  if (power == 1 || d0 == dw) y = x;
+  else if (power == 2) y = x <= mid ? x * x * rcp_nr(mid) : 1 - (1 - x) * (1 - x) * rcp_nr(1 - mid);
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  return d0 + y * (dw - d0);
 }
 
 // Symmetric NV x NV matrix in LDS.  Big models (nv > 10) keep the lower triangle packed row-major (row i, column j <= i at
@@ -231,6 +248,8 @@ template <int NV> struct Lim {
                                                             // side).  The masked ancestor / subtree sums run over [0, NT) plus the lane's own link.
   static constexpr int TS = NV == 15 ? 9 : NT;              // peg model: two trees, links [0, 9) = arm and [9, 15) = the free peg (checked by the host side, like NA): a
                                                             // lane's ancestor / subtree sums then run over its OWN tree only, 9 terms instead of 15 (the others had weight 0)
+  static constexpr bool KBT = NV != 15;                     // take the rows' (k, b) from the per-launch table (stage_kb) instead of recomputing them in every timestep: door +0.9 %,
+                                                            // kitchen +1.5 %; the peg build (512 registers, one wave per SIMD: the recomputation hides behind LDS latency) -4 %
   static constexpr bool EXTRAS = NV > 16;                   // dry joint friction, joint springs, force-limited actuators, joint couplings (earl_link_model24)
   static constexpr int LPE = NV > 16 ? 32 : 16;             // lanes per env instance (64 = one wavefront per env: measurement switch for nv <= 16)
 };
@@ -485,7 +504,7 @@ __device__ __forceinline__ void solve_lds(const SymLds<NV>& H, double (&x)[NV]) 
 }
 
 // block table of the collision model (bounding tests), staged once per workgroup
-template <int MB>
+template <int MB, bool KB>
 struct BlkTable {
   int n_blk, max_con;
   int begin[MB], end[MB], box[MB], link[MB], box_link[MB], cap[MB];
@@ -496,9 +515,13 @@ struct BlkTable {
   static constexpr bool SAT = MB <= 16;
   double obb_center[SAT ? MB : 1][3], obb_half[SAT ? MB : 1][3];
   double cls_mu[EARL_MAXCLS], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5];   // contact classes
+  // (k, b) of every row kind, once per launch (stage_kb): weld, joint limit / dry friction of dof l, contact class, joint coupling; the dry-friction
+  // rows' regulariser (their residual is always 0, so the whole of it is a constant)
+  // (not in the peg build, Lim<15>::KBT: even unused, the 976 B in front of the env blocks cost it 4 %)
+  double kb_weld[2], kb_lim[KB ? 24 : 1][2], kb_cls[KB ? EARL_MAXCLS : 1][2], kb_jeq[KB ? 8 : 1][2], fr_D[KB ? 24 : 1];
 };
-template <int MB>
-__device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collision_model* __restrict__ col) {
+template <int MB, bool KB>
+__device__ __forceinline__ void stage_blocks(BlkTable<MB, KB>& t, const earl_collision_model* __restrict__ col) {
   const int i = threadIdx.x;                           // n_blk <= 32 < one wavefront
   // (bounds are clamped here; the Python / C front ends refuse models that exceed them)
   const int nb = col ? (col->n_blk < MB ? col->n_blk : MB) : 0;
@@ -516,17 +539,37 @@ __device__ __forceinline__ void stage_blocks(BlkTable<MB>& t, const earl_collisi
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       t.center[i][k] = col->blk_center[i][k]; t.box_pos[i][k] = col->box_pos[b][k]; t.box_half[i][k] = col->box_half[b][k];
-      if constexpr (BlkTable<MB>::SAT) { t.obb_center[i][k] = col->blk_obb_center[i][k]; t.obb_half[i][k] = col->blk_obb_half[i][k]; }
+      if constexpr (BlkTable<MB, KB>::SAT) { t.obb_center[i][k] = col->blk_obb_center[i][k]; t.obb_half[i][k] = col->blk_obb_half[i][k]; }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) t.box_quat[i][k] = col->box_quat[b][k];
   }
 }
 
+template <int NV, int MB, bool KB>
+__device__ __forceinline__ void stage_kb(BlkTable<MB, KB>& t, const void* __restrict__ model, const earl_collision_model* __restrict__ col) {
+  if constexpr (!Lim<NV>::KBT) return;
+  const typename ModelOf<NV>::T* mg = reinterpret_cast<const typename ModelOf<NV>::T*>(model);     // (global memory: the LDS copy is not complete yet)
+  const int i = threadIdx.x;
+  const double dt = mg->dt;
+  if (i < NV) {
+    kb_of(mg->jsolref[i], mg->jsolimp[i], dt, t.kb_lim[i][0], t.kb_lim[i][1]);
+    if constexpr (Lim<NV>::EXTRAS) {
+      const double dd = imp_of(mg->jsolimp[i], 0.0);
+      t.fr_D[i] = rcp_nr(fmax((1 - dd) * mg->dof_invweight[i] * rcp_nr(dd), 1e-15));
+    }
+  }
+  if (i == 32) kb_of(mg->weld_solref, mg->weld_solimp, dt, t.kb_weld[0], t.kb_weld[1]);
+  if (col && i >= 33 && i < 33 + EARL_MAXCLS) kb_of(col->cls_solref[i - 33], col->cls_solimp[i - 33], dt, t.kb_cls[i - 33][0], t.kb_cls[i - 33][1]);
+  if constexpr (Lim<NV>::EXTRAS) {
+    if (i >= 56 && i < 64 && i - 56 < mg->n_jeq) kb_of(mg->jeq_solref[i - 56], mg->jeq_solimp[i - 56], dt, t.kb_jeq[i - 56][0], t.kb_jeq[i - 56][1]);
+  }
+}
+
 // One timestep of one env by its LPE-lane group (`sub` = lane within the group; every lane of the wave runs this, the
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
 template <int NV, int LPE, bool INTEGRATE>
-__device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV>::T& m, const BlkTable<Lim<NV>::MB>& bt, const earl_collision_model* __restrict__ col, const int sub,
+__device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV>::T& m, const BlkTable<Lim<NV>::MB, Lim<NV>::KBT>& bt, const earl_collision_model* __restrict__ col, const int sub,
                                         const int grp, const Q4 mq, const double (&ctrl)[EARL_MAXACT], const bool warm, double* qacc_out,
                                         double* efc_out) {
   // warm (uniform): s.aprev holds the solution of the previous timestep of the same env step / call, and the active-set iteration of K9 starts
@@ -597,7 +640,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     // C0: bounding test per block, lane = block (LPE blocks per pass)
     const int b = cb + sub < bt.n_blk ? cb + sub : 0;
     const int bl = bt.link[b], xl = bt.box_link[b];
-    constexpr bool SAT = BlkTable<Lim<NV>::MB>::SAT;
+    constexpr bool SAT = BlkTable<Lim<NV>::MB, Lim<NV>::KBT>::SAT;
     V3 cs = ld3(bt.center[b]), cb_ = ld3(bt.box_pos[b]), ca = ld3(bt.obb_center[SAT ? b : 0]);
     Q4 qb = ldq(bt.box_quat[b]);
     double RA[3][3];                                   // frame of the set's link (identity: world)
@@ -997,8 +1040,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
     for (int j = 0; j < (TS < NT ? TS : NT); ++j) Jv = fma(s.con.J6[r][j], s.qv[j], Jv);          // (the weld's chain lies within the first tree)
     const double res = r < 3 ? pick3(rpos, r) : pick3(rrot, r - 3);
-    double kk, bb, dd;
-    kbimp(m.weld_solref, m.weld_solimp, res, dt, kk, bb, dd);
+    double kk = bt.kb_weld[0], bb = bt.kb_weld[1], dd;
+    if constexpr (Lim<NV>::KBT) dd = imp_of(m.weld_solimp, res);
+    else kbimp(m.weld_solref, m.weld_solimp, res, dt, kk, bb, dd);
     const double Rg = fmax((1 - dd) * m.weld_invweight[r < 3 ? 0 : 1] * rcp_nr(dd), 1e-15);
     if (sub < 6) { s.con.wD[r] = rcp_nr(Rg); s.con.war[r] = -bb * Jv - kk * dd * res; }
   }
@@ -1014,8 +1058,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     const double res = islo ? q - lo : hi - q;
     lim_lo = islo;
     lim_inst = isl && m.limited[l] && res < 0;
-    double kk, bb, dd;
-    kbimp(m.jsolref[l], m.jsolimp[l], res, dt, kk, bb, dd);
+    double kk = bt.kb_lim[Lim<NV>::KBT ? l : 0][0], bb = bt.kb_lim[Lim<NV>::KBT ? l : 0][1];
+    double dd;
+    if constexpr (Lim<NV>::KBT) dd = imp_of(m.jsolimp[l], res);
+    else kbimp(m.jsolref[l], m.jsolimp[l], res, dt, kk, bb, dd);
     lim_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
     lim_aref = -bb * (lim_lo ? s.qv[l] : -s.qv[l]) - kk * dd * res;
     // start of the active-set iteration: the row if it is violated; warm: if it also pulls at a_prev.  (Where this line stands matters to the register
@@ -1029,10 +1075,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   int fr_state = 0;
   if constexpr (Lim<NV>::EXTRAS) {
     fr_loss = isl ? m.frictionloss[l] : 0.0;
-    double kk, bb, dd;
-    kbimp(m.jsolref[l], m.jsolimp[l], 0.0, dt, kk, bb, dd);
-    fr_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
-    fr_aref = -bb * s.qv[l];
+    fr_D = bt.fr_D[l];
+    fr_aref = -bt.kb_lim[l][1] * s.qv[l];
   }
   PSTAMP(7);
   // ------------------------------------------------------------------ C3: contact rows (reference: LinkModel.contact_rows)
@@ -1102,8 +1146,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const int cls = cv ? ((int)rec[7] & 63) : 0;
       const double margin = bt.cls_margin[cls];
       cmu = bt.cls_mu[cls];
-      double kk, bb, dd;
-      kbimp(bt.cls_solref[cls], bt.cls_solimp[cls], rec[0] - margin, dt, kk, bb, dd);
+      double kk = bt.kb_cls[Lim<NV>::KBT ? cls : 0][0], bb = bt.kb_cls[Lim<NV>::KBT ? cls : 0][1];
+      double dd;
+      if constexpr (Lim<NV>::KBT) dd = imp_of(bt.cls_solimp[cls], rec[0] - margin);
+      else kbimp(bt.cls_solref[cls], bt.cls_solimp[cls], rec[0] - margin, dt, kk, bb, dd);
       const double R0 = fmax((1 - dd) * bt.cls_invw[cls] * rcp_nr(dd), 1e-15);
       cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
       const double basea = -kk * dd * (rec[0] - margin);
@@ -1145,8 +1191,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const int j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
         const double c0 = m.jeq_coef[e][0], c1 = m.jeq_coef[e][1];
         const double res = s.qp[j1] - c0 - c1 * s.qp[j2], Jv = s.qv[j1] - c1 * s.qv[j2];
-        double kk, bb, dd;
-        kbimp(m.jeq_solref[e], m.jeq_solimp[e], res, dt, kk, bb, dd);
+        const double kk = bt.kb_jeq[e][0], bb = bt.kb_jeq[e][1], dd = imp_of(m.jeq_solimp[e], res);
         const double D = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
         const double Jl = l == j1 ? 1.0 : (l == j2 ? -c1 : 0.0), DJl = D * Jl;
         g = fma(DJl, -bb * Jv - kk * dd * res, g);
@@ -1613,9 +1658,10 @@ template <int NV, int LPE, bool INTEGRATE>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs a) {
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
   __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB> bt;
+  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
   __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
+  stage_kb<NV>(bt, a.m, a.col);
   stage_model(m, a.m);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE;
   const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
@@ -1799,9 +1845,10 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
   static_assert(LPE >= 14, "the observation is written by 14 lanes");
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
   __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB> bt;
+  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
   __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
+  stage_kb<NV>(bt, a.m, a.col);
   stage_model(m, a.m);
   const earl_sawyer_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
@@ -1914,9 +1961,10 @@ template <int NV, int LPE>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const SawyerArgs a) {
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
   __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB> bt;
+  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
   __shared__ Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
+  stage_kb<NV>(bt, a.m, a.col);
   stage_model(m, a.m);
   const earl_sawyer_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE;
@@ -2102,10 +2150,11 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
 #pragma clang fp contract(off)
   constexpr int NV = 23, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
   __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB> bt;
+  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
   __shared__ Shared<NV> sh[EPW * WPB];
   __shared__ earl_kitchen_params kp;
   stage_blocks(bt, a.col);
+  stage_kb<NV>(bt, a.m, a.col);
   if (threadIdx.x == 0) kp = a.p;
   stage_model(m, a.m);                                  // (ends with the workgroup barrier)
   const earl_kitchen_cfg& cfg = a.cfg;
