@@ -1288,6 +1288,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       double hcol[NV], rr = rw;
 #pragma unroll
       for (int i = 0; i < NV; ++i) hcol[i] = hw[i];
+#pragma unroll 2
       for (int c = 0; c < ncmax; ++c) {
         const double* w = s.con.cw[c];
         const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
