@@ -414,7 +414,10 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 32: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 4, 4, 6); break;
           case 33: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2); break;    // = shipped for larger grids
           case 34: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 4); break;
-          case 29: rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, 8, 3, true><<<grid, 64 * 12, 0, hs>>>(w); break;  // stamps
+          case 29:                                                                                                     // stamps
+            if (episodes > 1) rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, 8, 3, true, true><<<grid, 64 * 12, 0, hs>>>(w);
+            else rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, 8, 3, true><<<grid, 64 * 12, 0, hs>>>(w);
+            break;
           case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 4, 8, 3, true><<<grid, 64 * 10, 0, hs>>>(w); break;  // stamps
           case 19: rollout_ws_kernel<EARL_REWARD_SPARSE, 1, 4, 4, 8, 3, true><<<grid, 64 * 9, 0, hs>>>(w); break;  // stamps
           default:
@@ -496,7 +499,7 @@ int earl_tabletop_eval_episodes(const earl_tabletop_cfg* cfg, const earl_tableto
   if (episodes == 0 || cfg->n == 0) return EARL_OK;
   const bool general = cfg->goal_change_frequency > 0 || cfg->auto_reset;
   // one launch walks all episodes when the wave-specialised kernel applies and episodes end on its chunk boundaries (8 steps)
-  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && g_rollout_impl == 0 &&
+  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && (g_rollout_impl == 0 || g_rollout_impl == 29) &&
                      T % 8 == 0 && T >= 16 && (long long)episodes * T < (1 << 24);
   if (fused || episodes == 1) return do_rollout<1>(cfg, st, T, act, out, stream, true, episodes, (long long)act_episode_stride);
   for (int32_t e = 0; e < episodes; ++e) {          // otherwise: the same thing as `episodes` launches

@@ -28,6 +28,10 @@
 
 #include "tabletop_device.h"
 
+#ifndef EARL_WSM_OFF
+#define EARL_WSM_OFF 0      // measurement only: bit 0 loaders, 1 storers, 2 compute waves ignore the episode structure of a multi-episode launch (WRONG results)
+#endif
+
 namespace earl {
 
 struct WsArgs {
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     int next_ep_c = cpe, ep = 0, last_gi = -1;
     for (int c = 0; c < nch; ++c) {
       const int rb = c & 1;
-      if (MULTI && c == next_ep_c) {   // (wave-uniform) the next evaluation episode of this launch starts here: reset() of every env
+      if (MULTI && !(EARL_WSM_OFF & 4) && c == next_ep_c) {   // (wave-uniform) the next evaluation episode of this launch starts here: reset() of every env
         ++ep;
         next_ep_c += cpe;
         Env<1> ev;
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         unsigned long long* op = g_ws_prof + blockIdx.x * 16;
         op[0] = p_first; op[1] = p_read; op[2] = p_comp; op[3] = p_bar; op[4] = p_x - p_t0;
       }
+      if (lane == 0 && blockIdx.x < 64 && wave == 1) g_ws_prof[blockIdx.x * 16 + 13] = p_bar;      // the second compute wave's barrier wait
     }
     if (alive) {
       a.qpos[(size_t)ie * 4 + h] = f;
@@ -636,23 +641,38 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     int l_ep_end = cpe, l_ep_first = 0;       // loader's episode cursor: chunks [l_ep_first, l_ep_end) belong to the current episode
     size_t l_ep_base = 0;                     // ... whose actions start at base + l_ep_base
     auto issue_trip = [&](float (&raw)[LEAD][KL][3], int r) {   // raw <- my steps of trip r
+      // MULTI: chunk j of the launch = chunk j - l_ep_first of the episode the cursor stands in (wave-uniform scalars).  The row offsets of the whole
+      // trip are worked out FIRST, branch-free (chunks come one after the other: at most one episode boundary per chunk); then the loads follow
+      // back to back.  A loop or a branch between the loads of a trip makes the compiler drain them there, which put the loaders on the
+      // critical path of the multi-episode kernel (118 ns per step against the single-episode kernel's 101).
+      // (one 64-bit row pointer per chunk, then this loader's steps of the chunk by a constant stride: the loaders are scalar-ALU bound here)
+      const float* rowp[LEAD];
+      size_t off[LEAD][KL];
 #pragma unroll
-      for (int d = 0; d < LEAD; ++d)
+      for (int d = 0; d < LEAD; ++d) {
+        if constexpr (MULTI && !(EARL_WSM_OFF & 1)) {
+          const int j = min(r * LEAD + d, nch - 1);
+          const int xm = -(int)(j >= l_ep_end);
+          l_ep_end += cpe & xm; l_ep_first += cpe & xm;
+          l_ep_base += (size_t)a.act_ep_stride & (size_t)(long long)xm;
+          rowp[d] = base + l_ep_base + (size_t)__builtin_amdgcn_readfirstlane((j - l_ep_first) * K + w) * step_stride;
+        } else {
+#pragma unroll
+          for (int q = 0; q < KL; ++q)
+            off[d][q] = (size_t)__builtin_amdgcn_readfirstlane(min((r * LEAD + d) * K + q * NL + w, (MULTI ? a.Tep : T) - 1)) * step_stride;
+        }
+      }
+      const size_t qstride = (size_t)NL * step_stride;
+#pragma unroll
+      for (int d = 0; d < LEAD; ++d) {
+        const float* pq = (MULTI && !(EARL_WSM_OFF & 1)) ? rowp[d] : base;
 #pragma unroll
         for (int q = 0; q < KL; ++q) {
-          int t;
-          const float* p = base;
-          if constexpr (MULTI) {           // chunk j of the launch = chunk j - ep_first of episode l_ep (all wave-uniform scalars)
-            const int j = min(r * LEAD + d, nch - 1);
-            while (j >= l_ep_end) { l_ep_end += cpe; l_ep_base += (size_t)a.act_ep_stride; l_ep_first += cpe; }
-            t = __builtin_amdgcn_readfirstlane((j - l_ep_first) * K + q * NL + w);
-            p += l_ep_base;
-          } else {
-            t = __builtin_amdgcn_readfirstlane(min((r * LEAD + d) * K + q * NL + w, T - 1));
-          }
-          p += (size_t)t * step_stride;
+          const float* p = (MULTI && !(EARL_WSM_OFF & 1)) ? pq : base + off[d][q];
           raw[d][q][0] = p[e0]; raw[d][q][1] = p[e1]; raw[d][q][2] = p[e2];
+          pq += qstride;
         }
+      }
     };
     unsigned long long p_proc = 0, p_bar = 0;
     auto process = [&](const float (&raw)[KL][3], int j) {  // transpose through LDS, rescale, publish chunk j
@@ -713,6 +733,10 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         unsigned long long* o = g_ws_prof + blockIdx.x * 16;
         o[5] = p_proc; o[6] = p_bar; o[7] = p_x - p_t0;
       }
+      if (lane == 0 && blockIdx.x < 64 && w == NL - 1 && NL > 1) {      // the last loader wave too
+        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+        o[14] = p_proc; o[15] = p_bar;
+      }
     }
   } else {
     // ================================================================= STORERS
@@ -729,7 +753,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     const int cpe = MULTI ? a.Tep / K : 0x7fffffff;
     int g_ep = 0, t_ep0 = 0, g_end = cpe;      // episode `g` belongs to, its first global step, its end (chunk index)
     auto enter_episode = [&](int c) {           // (uniform) called before chunk c is stored; c advances by one
-      if (MULTI && c >= g_end) {
+      if (MULTI && !(EARL_WSM_OFF & 2) && c >= g_end) {
         g_ep += 1; g_end += cpe; t_ep0 += a.Tep;
         if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, g_ep), g);
       }
@@ -738,7 +762,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     // episode (an episode boundary b with j < b <= j + 2; g_end is the first boundary > j after enter_episode(j)) the constant goal part
     // of the buffer's rows is rewritten (this storer: its own steps of the buffer, env column `lane`)
     auto refill_goal = [&](int j) {
-      if (MULTI && g_end <= j + 2 && j + 2 < nch) {
+      if (MULTI && !(EARL_WSM_OFF & 2) && g_end <= j + 2 && j + 2 < nch) {
         float gn[6] = {0, 0, 0, 0, 0, 0};
         if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, g_ep + 1), gn);
         for (int k = s; k < K; k += NS) {
@@ -849,6 +873,14 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       if (lane == 0 && blockIdx.x < 64 && s == 0) {
         unsigned long long* o = g_ws_prof + blockIdx.x * 16;
         o[8] = p_st; o[9] = p_bar; o[10] = ws_clock() - p_t0;
+      }
+      if (lane == 0 && blockIdx.x == 0 && gridDim.x <= 32) {             // (small grids: every storer wave of workgroup 0, rows 32 .. 32 + NS)
+        unsigned long long* o = g_ws_prof + (32 + s) * 16;
+        o[8] = p_st; o[9] = p_bar;
+      }
+      if (lane == 0 && blockIdx.x < 64 && s == NS - 1 && NS > 1) {      // the last storer wave too
+        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+        o[11] = p_st; o[12] = p_bar;
       }
     }
   }
