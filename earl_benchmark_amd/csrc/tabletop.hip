@@ -420,6 +420,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
             break;
           case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 4, 8, 3, true><<<grid, 64 * 10, 0, hs>>>(w); break;  // stamps
           case 19: rollout_ws_kernel<EARL_REWARD_SPARSE, 1, 4, 4, 8, 3, true><<<grid, 64 * 9, 0, hs>>>(w); break;  // stamps
+          case 36:
           default:
             // 2 compute waves with x / y in adjacent lanes (DPP, VGPR-only masks) + 2 loaders + 8 storers, 8-step chunks:
             // fastest of the variants above at N = 4096 and not slower at any larger N measured (tools/tune_rollout.py;
@@ -428,7 +429,11 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
             // at N = 4096, T = 200).  Large grids (more than one workgroup per CU) prefer shorter loader trips (LEAD 2):
             // 69.5 vs 65.0 G env-steps/s at N = 2^20.
             if (episodes > 1) {          // several evaluation episodes per launch: the MULTI instantiation of the shipped configuration
-              if (grid.x <= 256) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
+              // 16-step chunks (two 8-step granules; an episode may end between them) when every workgroup has a CU to itself: the per-chunk costs
+              // -- barrier, action fetch, loop -- are paid half as often (105 -> 99 ns per step at N = 4096); 152 KB of LDS, so larger grids keep
+              // the 8-step chunks (77 KB, two workgroups per CU).  impl 36 forces the 8-step form for comparison.
+              if (grid.x <= 256 && Tep >= 32 && g_rollout_impl != 36) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 16, 2);
+              else if (grid.x <= 256) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
               else EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
             } else if (grid.x <= 256) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
             else EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
@@ -436,7 +441,8 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
         }
       } else {
         if (episodes > 1) {
-          if (grid.x <= 256) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
+          if (grid.x <= 256 && Tep >= 32) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 16, 2);
+          else if (grid.x <= 256) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
           else EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
         } else if (grid.x <= 256) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
         else EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
@@ -499,7 +505,7 @@ int earl_tabletop_eval_episodes(const earl_tabletop_cfg* cfg, const earl_tableto
   if (episodes == 0 || cfg->n == 0) return EARL_OK;
   const bool general = cfg->goal_change_frequency > 0 || cfg->auto_reset;
   // one launch walks all episodes when the wave-specialised kernel applies and episodes end on its chunk boundaries (8 steps)
-  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && (g_rollout_impl == 0 || g_rollout_impl == 29) &&
+  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && (g_rollout_impl == 0 || g_rollout_impl == 29 || g_rollout_impl == 36) &&
                      T % 8 == 0 && T >= 16 && (long long)episodes * T < (1 << 24);
   if (fused || episodes == 1) return do_rollout<1>(cfg, st, T, act, out, stream, true, episodes, (long long)act_episode_stride);
   for (int32_t e = 0; e < episodes; ++e) {          // otherwise: the same thing as `episodes` launches

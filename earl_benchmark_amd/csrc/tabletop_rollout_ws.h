@@ -373,20 +373,37 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       }
     };
     fetch(0);
-    const int cpe = MULTI ? a.Tep / K : 0x7fffffff;   // chunks per episode
-    int next_ep_c = cpe, ep = 0, last_gi = -1;
-    for (int c = 0; c < nch; ++c) {
-      const int rb = c & 1;
-      if (MULTI && !(EARL_WSM_OFF & 4) && c == next_ep_c) {   // (wave-uniform) the next evaluation episode of this launch starts here: reset() of every env
+    // several episodes per launch: episodes are whole numbers of GRANULES of GR = 8 steps (Tep % 8 == 0), a chunk is K / GR granules -- one for
+    // the 8-step chunks, two for the 16-step ones, where an episode of e.g. 200 steps ends in the middle of every other chunk
+    constexpr int GR = 8, GPC = K / GR;
+    static_assert(!MULTI || (K % GR == 0 && GPC <= 2), "multi-episode launches: chunks of one or two 8-step granules");
+    const int gpe = MULTI ? a.Tep / GR : 0x7fffffff;   // granules per episode
+    int next_ep_g = gpe, ep = 0, last_gi = -1;
+    // (wave-uniform) granule gidx starts the next evaluation episode of this launch: reset() of every env.  The draw is made at the head of the
+    // chunk, where few registers are live (`pend`); a boundary at the chunk's second granule is then only a handful of moves inside the step loop.
+    double f_pend = 0, o_pend = 0;
+    bool pend = false;
+    auto prepare_episode = [&](const int gidx) -> bool {
+      if (MULTI && !(EARL_WSM_OFF & 4) && gidx == next_ep_g && gidx * GR < T) {    // (the last chunk of a launch may be half a chunk)
         ++ep;
-        next_ep_c += cpe;
+        next_ep_g += gpe;
         Env<1> ev;
         last_gi = reset_env<1>(ev, a.cfg, ws_ep_counter(a, ep), ie, a.goal_table, nullptr, a.th);
-        f = h ? ev.q[1] : ev.q[0];
-        o = h ? ev.q[3] : ev.q[2];
-        attm = 0;
-        nm = ws_near_mask_adj(f, o, kc);
+        f_pend = h ? ev.q[1] : ev.q[0];
+        o_pend = h ? ev.q[3] : ev.q[2];
+        return true;
       }
+      return false;
+    };
+    auto apply_episode = [&]() {
+      f = f_pend; o = o_pend;
+      attm = 0;
+      nm = ws_near_mask_adj(f, o, kc);
+    };
+    for (int c = 0; c < nch; ++c) {
+      const int rb = c & 1;
+      if (prepare_episode(c * (MULTI ? GPC : 1))) apply_episode();
+      if constexpr (MULTI && GPC == 2) pend = prepare_episode(c * GPC + 1);
       slow = slow || (nslow != 0);
 #pragma unroll
       for (int k = 0; k < K; ++k) { av[k] = nv[k]; gv[k] = ng[k]; }
@@ -398,6 +415,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         for (int k = 0; k < K; ++k) {
           if constexpr (!decltype(full)::value)
             if (c * K + k >= T) break;      // tail chunk only (wave-uniform)
+          if constexpr (MULTI && GPC == 2) { if (k == GR && pend) apply_episode(); }      // an episode may start at the chunk's second granule
           if constexpr (decltype(exact)::value) ws_step_adj_exact(f, o, attm, av[k], gv[k], h, a.th);
           else ws_step_adj(f, o, nm, attm, av[k], gv[k], kc);
           float* rowf = reinterpret_cast<float*>(&R[rb][k][e * 3]);   // (fx, fy, ox, oy), (flag, flag, ..)
@@ -637,8 +655,9 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     const int e0 = min(lane, last), e1 = min(lane + 64, last), e2 = min(lane + 128, last);
     const float* const base = a.act + (size_t)i0 * 3;
     const size_t step_stride = (size_t)n * 3;
-    const int cpe = MULTI ? a.Tep / K : 0x7fffffff;
-    int l_ep_end = cpe, l_ep_first = 0;       // loader's episode cursor: chunks [l_ep_first, l_ep_end) belong to the current episode
+    constexpr int GR = 8, GPC = MULTI ? K / GR : 1;      // (granules: see the compute waves)
+    const int gpe = MULTI ? a.Tep / GR : 0x7fffffff;
+    int l_ep_end = gpe, l_ep_first = 0;       // loader's episode cursor: GRANULES [l_ep_first, l_ep_end) belong to the current episode
     size_t l_ep_base = 0;                     // ... whose actions start at base + l_ep_base
     auto issue_trip = [&](float (&raw)[LEAD][KL][3], int r) {   // raw <- my steps of trip r
       // MULTI: chunk j of the launch = chunk j - l_ep_first of the episode the cursor stands in (wave-uniform scalars).  The row offsets of the whole
@@ -646,16 +665,20 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       // back to back.  A loop or a branch between the loads of a trip makes the compiler drain them there, which put the loaders on the
       // critical path of the multi-episode kernel (118 ns per step against the single-episode kernel's 101).
       // (one 64-bit row pointer per chunk, then this loader's steps of the chunk by a constant stride: the loaders are scalar-ALU bound here)
-      const float* rowp[LEAD];
+      const float* rowp[LEAD][GPC];
       size_t off[LEAD][KL];
 #pragma unroll
       for (int d = 0; d < LEAD; ++d) {
         if constexpr (MULTI && !(EARL_WSM_OFF & 1)) {
           const int j = min(r * LEAD + d, nch - 1);
-          const int xm = -(int)(j >= l_ep_end);
-          l_ep_end += cpe & xm; l_ep_first += cpe & xm;
-          l_ep_base += (size_t)a.act_ep_stride & (size_t)(long long)xm;
-          rowp[d] = base + l_ep_base + (size_t)__builtin_amdgcn_readfirstlane((j - l_ep_first) * K + w) * step_stride;
+#pragma unroll
+          for (int hg = 0; hg < GPC; ++hg) {            // the granules of chunk j, one after the other: at most one episode boundary each
+            const int gidx = min(j * GPC + hg, T / GR - 1);      // (the last chunk of a launch may be half a chunk: its second granule repeats the first)
+            const int xm = -(int)(gidx >= l_ep_end);
+            l_ep_end += gpe & xm; l_ep_first += gpe & xm;
+            l_ep_base += (size_t)a.act_ep_stride & (size_t)(long long)xm;
+            rowp[d][hg] = base + l_ep_base + (size_t)__builtin_amdgcn_readfirstlane((gidx - l_ep_first) * GR + w) * step_stride;
+          }
         } else {
 #pragma unroll
           for (int q = 0; q < KL; ++q)
@@ -663,14 +686,16 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         }
       }
       const size_t qstride = (size_t)NL * step_stride;
+      static_assert(!MULTI || GR % NL == 0, "a loader's steps of a granule: a whole number");
+      constexpr int QG = MULTI ? GR / NL : KL;           // this loader's steps per granule (step q NL + w of the chunk lies in granule q / QG)
 #pragma unroll
       for (int d = 0; d < LEAD; ++d) {
-        const float* pq = (MULTI && !(EARL_WSM_OFF & 1)) ? rowp[d] : base;
 #pragma unroll
         for (int q = 0; q < KL; ++q) {
-          const float* p = (MULTI && !(EARL_WSM_OFF & 1)) ? pq : base + off[d][q];
+          const float* p;
+          if constexpr (MULTI && !(EARL_WSM_OFF & 1)) p = rowp[d][q / QG] + (size_t)(q % QG) * qstride;
+          else p = base + off[d][q];
           raw[d][q][0] = p[e0]; raw[d][q][1] = p[e1]; raw[d][q][2] = p[e2];
-          pq += qstride;
         }
       }
     };
@@ -750,23 +775,40 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     }
     // several episodes per launch: chunk c belongs to episode c / cpe; `g`, and the step index `done` counts from, follow it (cursors,
     // no divisions: eight storer waves share the SIMDs with the compute waves)
-    const int cpe = MULTI ? a.Tep / K : 0x7fffffff;
-    int g_ep = 0, t_ep0 = 0, g_end = cpe;      // episode `g` belongs to, its first global step, its end (chunk index)
-    auto enter_episode = [&](int c) {           // (uniform) called before chunk c is stored; c advances by one
-      if (MULTI && !(EARL_WSM_OFF & 2) && c >= g_end) {
-        g_ep += 1; g_end += cpe; t_ep0 += a.Tep;
-        if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, g_ep), g);
+    // (in GRANULES of 8 steps, see the compute waves: a 16-step chunk is two of them, and an episode may end between the two)
+    constexpr int GR = 8, GPC = MULTI ? K / GR : 1;
+    const int gpe = MULTI ? a.Tep / GR : 0x7fffffff;
+    int g_ep = 0, t_ep0 = 0, g_end = gpe;      // episode `g` belongs to, its first global step, its end (granule index)
+    float gn[6] = {0, 0, 0, 0, 0, 0};          // goal of the episode AFTER that one: loaded once per episode, an episode ahead of its use, at the head
+    bool gn_stale = false;                     // of a chunk's stores (reload_next_goal)
+    if (MULTI && live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, 1), gn);
+    auto reload_next_goal = [&]() {             // (uniform, once per episode) before any store of the chunk is issued
+      if (MULTI && gn_stale) {
+        gn_stale = false;
+        if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, g_ep + 1), gn);
       }
     };
-    // ... and after chunk j has been stored, its row-image buffer is next written for chunk j + 2: if that one belongs to a later
-    // episode (an episode boundary b with j < b <= j + 2; g_end is the first boundary > j after enter_episode(j)) the constant goal part
-    // of the buffer's rows is rewritten (this storer: its own steps of the buffer, env column `lane`)
-    auto refill_goal = [&](int j) {
-      if (MULTI && !(EARL_WSM_OFF & 2) && g_end <= j + 2 && j + 2 < nch) {
-        float gn[6] = {0, 0, 0, 0, 0, 0};
-        if (live) load_goal<1>(a.goal_table, ws_goal_row_ep(a, i, g_ep + 1), gn);
-        for (int k = s; k < K; k += NS) {
-          float4* row = &R[j & 1][k][lane * 3];
+    auto enter_episode = [&](int gidx) {        // (uniform) called before the steps of granule gidx are stored; gidx advances by one
+      if (MULTI && !(EARL_WSM_OFF & 2) && gidx >= g_end) {
+        // the next episode's goal is ALREADY in registers (gn): no global load between this chunk's stores -- vmcnt counts loads and stores alike, and a
+        // load under this rare branch made the compiler drain the wave's stores in every chunk
+        g_ep += 1; g_end += gpe; t_ep0 += a.Tep;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[k] = gn[k];
+        gn_stale = true;
+      }
+    };
+    // ... and after the rows of granule gidx have been stored, their row images are next written for granule gidx + 2 GPC (same buffer, two
+    // chunks on): if that one belongs to a later episode (an episode boundary b with gidx < b <= gidx + 2 GPC; g_end is the first boundary > gidx
+    // after enter_episode(gidx); episodes are longer than that window) the constant goal part of those rows is rewritten (this storer: its own
+    // steps of the granule, env column `lane`)
+    auto refill_goal = [&](int gidx) {
+      if (MULTI && !(EARL_WSM_OFF & 2) && g_end <= gidx + 2 * GPC && (gidx / GPC) + 2 < nch) {
+        reload_next_goal();                      // (episodes of a few granules only: the boundary ahead can be the one after an episode that has just begun)
+        const int k0 = (gidx % GPC) * GR;       // first step of this granule within its chunk
+        for (int k = k0 + (s % GR); k < k0 + GR; k += NS) {
+          if ((k % NS) != s) continue;
+          float4* row = &R[(gidx / GPC) & 1][k][lane * 3];
           row[1] = float4{-1.0f, -1.0f, gn[0], gn[1]};    // (the flag words are rewritten by the compute wave every step)
           row[2] = float4{gn[2], gn[3], gn[4], gn[5]};
         }
@@ -780,6 +822,12 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       const int rb = c & 1;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
+        if constexpr (MULTI) {             // granule boundaries of the chunk: the previous granule's rows are done with, the next one's goal comes in
+          if (k % GR == 0) {
+            if (k > 0) refill_goal(c * GPC + k / GR - 1);
+            enter_episode(c * GPC + k / GR);
+          }
+        }
         if ((k % NS) != s) continue;     // storers interleave over the steps of a chunk
         const int t = c * K + k;
         if (t >= T) continue;
@@ -819,6 +867,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
           }
         }
       }
+      if constexpr (MULTI) refill_goal(c * GPC + GPC - 1);
     };
     // Fast form for whole chunks of a full workgroup (K % NS == 0): this storer owns steps s, s+NS, .. of the chunk.
     // All LDS reads of those steps are issued first (one round trip instead of two per step), then the HBM stores and
@@ -826,20 +875,21 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     constexpr int Q = (K % NS == 0) ? K / NS : 0;
     auto store_chunk_fast = [&](int c) {
       const int rb = c & 1;
-      float4 p[Q > 0 ? Q : 1], v0[Q > 0 ? Q : 1], v1[Q > 0 ? Q : 1], v2[Q > 0 ? Q : 1];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
+      struct Rows { float4 v0, v1, v2, p; };              // the row image of one step: by value, never an array (arrays of them ended up in scratch
+                                                          // memory once the episode hooks stood between their definition and their use)
+      auto load_rows = [&](const int q) -> Rows {
         const float4* src = &R[rb][s + NS * q][0];
-        v0[q] = src[lane]; v1[q] = src[lane + 64]; v2[q] = src[lane + 128];
-        p[q] = src[lane * 3];
-      }
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
+        return Rows{src[lane], src[lane + 64], src[lane + 128], src[lane * 3]};
+      };
+      const Rows r0 = load_rows(0), r1 = load_rows(Q > 1 ? 1 : 0), r2 = load_rows(Q > 2 ? 2 : 0), r3 = load_rows(Q > 3 ? 3 : 0);
+      auto step_q = [&](auto qc, const Rows rw) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (MULTI) enter_episode(c * GPC + q);      // (NS == GR: this storer's q-th step lies in the chunk's q-th granule)
         const int t = c * K + s + NS * q;
         const size_t row0 = (size_t)t * n + i0;
         float4* dst = reinterpret_cast<float4*>(a.obs + row0 * 12);
-        dst[lane] = v0[q]; dst[lane + 64] = v1[q]; dst[lane + 128] = v2[q];
-        const float o[12] = {p[q].x, p[q].y, p[q].z, p[q].w, 0.f, 0.f, g[0], g[1], g[2], g[3], g[4], g[5]};
+        dst[lane] = rw.v0; dst[lane + 64] = rw.v1; dst[lane + 128] = rw.v2;
+        const float o[12] = {rw.p.x, rw.p.y, rw.p.z, rw.p.w, 0.f, 0.f, g[0], g[1], g[2], g[3], g[4], g[5]};
         const bool succ = success1(o, a.wide, a.th);
         float rew;
         if constexpr (RT == EARL_REWARD_SPARSE) rew = succ ? 1.0f : 0.0f;
@@ -851,13 +901,18 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
           reinterpret_cast<uint32_t*>(a.success + row0)[lane] = (ns * 0x00204081u) & 0x01010101u;
           reinterpret_cast<uint32_t*>(a.done + row0)[lane] = (nd * 0x00204081u) & 0x01010101u;
         }
-      }
+        if constexpr (MULTI) refill_goal(c * GPC + q);         // (every row image of the chunk is in registers by now)
+      };
+      static_assert(Q <= 4, "steps of a chunk per storer");
+      if constexpr (Q > 0) step_q(std::integral_constant<int, 0>{}, r0);
+      if constexpr (Q > 1) step_q(std::integral_constant<int, 1>{}, r1);
+      if constexpr (Q > 2) step_q(std::integral_constant<int, 2>{}, r2);
+      if constexpr (Q > 3) step_q(std::integral_constant<int, 3>{}, r3);
     };
     auto store = [&](int c) {
-      enter_episode(c);
-      if (Q > 0 && full && (c + 1) * K <= T) store_chunk_fast(c);
+      reload_next_goal();
+      if (Q > 0 && (!MULTI || NS == GR) && full && (c + 1) * K <= T) store_chunk_fast(c);
       else store_chunk(c);
-      refill_goal(c);
     };
     if constexpr (PROF) p_t0 = ws_clock();
     __syncthreads();

@@ -502,7 +502,11 @@ def test_3obj_reset_at_goal(hx, orc):
 
 
 @pytest.mark.parametrize('n,T,E,kw', [(4096, 200, 3, {}), (257, 24, 4, {'wide_init_distr': True}), (300, 16, 2, {'reset_at_goal': True}),
-                                      (130, 40, 3, {'reward_type': 'dense'}), (100, 20, 3, {}), (64, 8, 2, {})])
+                                      (130, 40, 3, {'reward_type': 'dense'}), (100, 20, 3, {}), (64, 8, 2, {}),
+                                      # 16-step chunks (T >= 32, up to 256 workgroups): episodes that end in the middle of a chunk (T % 16 == 8), a launch
+                                      # that ends in half a chunk (odd E x such a T), episodes of exactly two chunks, the shortest ones the path takes
+                                      (4096, 200, 4, {}), (1000, 40, 5, {}), (200, 32, 3, {'wide_init_distr': True}), (333, 56, 7, {'reward_type': 'dense'}),
+                                      (129, 48, 2, {'reset_at_goal': True}), (16384, 72, 3, {})])
 def test_eval_episodes_in_one_launch_equal_the_sequence_of_launches(n, T, E, kw):
   """earl_tabletop_eval_episodes: E x (reset + T steps) in ONE launch of the wave-specialised kernel (episode boundaries inside the
   launch: state reset, goal re-drawn, goal part of the row images rewritten, done counted per episode) == E fused reset+rollout launches,
