@@ -415,7 +415,8 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 33: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2); break;    // = shipped for larger grids
           case 34: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 4); break;
           case 29:                                                                                                     // stamps
-            if (episodes > 1) rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, 8, 3, true, true><<<grid, 64 * 12, 0, hs>>>(w);
+            if (episodes > 1 && Tep >= 32) rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, 16, 2, true, true><<<grid, 64 * 12, 0, hs>>>(w);
+            else if (episodes > 1) rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, 8, 3, true, true><<<grid, 64 * 12, 0, hs>>>(w);
             else rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, 8, 3, true><<<grid, 64 * 12, 0, hs>>>(w);
             break;
           case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 4, 8, 3, true><<<grid, 64 * 10, 0, hs>>>(w); break;  // stamps
