@@ -9,7 +9,7 @@ n,E,T=4096,16,208
 acts = (torch.rand(T, n, 3, device='cuda') * 2 - 1).contiguous()
 L = eb.EARLEnvs('tabletop_manipulation', reward_type='sparse', num_envs=n, eval_horizon=T, scalar_api=False)
 _, env = L.get_envs()
-for impl in (0,35):
+for impl in (0,):
   lib.earl_debug_set_rollout_impl(impl)
   f = lambda: env.rollout_episodes(acts, episodes=E)
   for _ in range(3): f()
