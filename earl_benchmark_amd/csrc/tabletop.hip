@@ -436,8 +436,8 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
               if (grid.x <= 256 && Tep >= 32 && g_rollout_impl != 36) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 16, 2);
               else if (grid.x <= 256) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
               else EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
-            } else if (grid.x <= 256 && T >= 32 && g_rollout_impl != 36) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 16, 2);   // (16-step chunks, as above)
-            else if (grid.x <= 256) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
+            } else if (grid.x <= 256) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);     // (one episode per launch: 16-step chunks lengthen the pipeline's fill by
+                                                                                      // as much as they save over 200 steps: 27.9 against 27.3 us)
             else EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
             break;
         }
@@ -446,8 +446,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           if (grid.x <= 256 && Tep >= 32) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 16, 2);
           else if (grid.x <= 256) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
           else EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
-        } else if (grid.x <= 256 && T >= 32) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 16, 2);
-        else if (grid.x <= 256) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
+        } else if (grid.x <= 256) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
         else EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
       }
 #undef EARL_WS
