@@ -1,4 +1,4 @@
-"""Per-step vs per-episode cost of the multi-episode tabletop launch: time E episodes of T steps for several T (N = 4096)."""
+"""(round 2 tuning aid) Per-step vs per-episode cost of the multi-episode tabletop launch: time E episodes of T steps for several T (N = 4096)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

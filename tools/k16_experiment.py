@@ -1,3 +1,5 @@
+"""(round 2 tuning aid) Multi-episode tabletop launch: per-episode launches of the plain kernel (impl 1, the reference), 8-step chunks (impl 36) and the shipped
+16-step chunks (impl 0) on the same seeds: time per step and bit-identity of all outputs.  python tools/k16_experiment.py [T]"""
 import sys, time, torch
 sys.path.insert(0,'/root/repo')
 import earl_benchmark_amd as eb
