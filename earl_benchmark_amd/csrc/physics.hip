@@ -1166,7 +1166,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   fence();
   PSTAMP(6);
   // ------------------------------------------------------------------ K9: Hessian of the equality part, then the active-set Newton
-  double hw[NV], rw;                                   // this lane's column of M + J6' D J6 (+ drag) and its right-hand side: registers, all iterations
+  double hw[Lim<NV>::EXTRAS ? 1 : NV], rw;             // this lane's column of M + J6' D J6 (+ drag) and its right-hand side: registers, all iterations
+                                                       // (big model: the column goes straight to LDS, s.hwst.Hw)
   {
     double DJ[6], g = tau_l;
 #pragma unroll
@@ -1174,18 +1175,34 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       DJ[r] = s.con.wD[r] * Jc[r];
       g = fma(DJ[r], s.con.war[r], g);
     }
+    if constexpr (!Lim<NV>::EXTRAS) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      double h = s.M.sym(i, l, ltri);
-      if (i < (TS < NT ? TS : NT)) {                     // (the weld's chain lies within the first tree: its Jacobian is zero in the other rows)
+      for (int i = 0; i < NV; ++i) {
+        double h = s.M.sym(i, l, ltri);
+        if (i < (TS < NT ? TS : NT)) {                     // (the weld's chain lies within the first tree: its Jacobian is zero in the other rows)
 #pragma unroll
-        for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
+          for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
+        }
+        if (i == l) h += m.drag_G[l];                     // soft velocity row of a permanent dragging contact
+        hw[i] = h;
       }
-      if (i == l) h += m.drag_G[l];                     // soft velocity row of a permanent dragging contact
-      hw[i] = h;
     }
     g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
     if constexpr (Lim<NV>::EXTRAS) {
+      // The equality part has the model's structure (checked by the host side): the arm's NT x NT block (mass matrix + weld rows), one diagonal entry per
+      // fixture, one off-diagonal entry per coupled pair of fixtures.  Only those entries of s.hwst.Hw are ever written; the others were zeroed when the
+      // kernel started.  (The earlier form built all 23 rows of every column in registers and ran every coupling over all of them with selects: 14 k of
+      // the timestep's 62 k cycles.)  Same values, same order of additions per entry.
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        double h = s.M.sym(i, l, ltri);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
+        if (i == l) h += m.drag_G[l];
+        if (isl && l < NT && i >= l) s.hwst.Hw.lo(i, l) = h;
+      }
+      double hd = s.M.sym(l, l, ltri) + m.drag_G[l], ho = 0.0;        // fixture lanes: the diagonal entry, the entry shared with the coupled partner
+      const int pl = m.pair[l];
       // joint couplings q[j1] - c0 - c1 q[j2] = 0: soft equality rows with two non-zeros (1 at j1, -c1 at j2)
       for (int e = 0; e < m.n_jeq; ++e) {
         const int j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
@@ -1195,12 +1212,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const double D = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
         const double Jl = l == j1 ? 1.0 : (l == j2 ? -c1 : 0.0), DJl = D * Jl;
         g = fma(DJl, -bb * Jv - kk * dd * res, g);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) hw[i] += (i == j1 ? DJl : 0.0) + (i == j2 ? -c1 * DJl : 0.0);
+        // rows j1 and j2 of column l get DJl and -c1 DJl: for lane j1 that is its diagonal and its partner's row, for lane j2 the other way round
+        hd += l == j1 ? DJl : (l == j2 ? -c1 * DJl : 0.0);
+        ho += l == j1 ? -c1 * DJl : (l == j2 ? DJl : 0.0);
       }
-      if (isl) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) s.hwst.Hw.put(i, l, hw[i], false);     // (the lower part of column l; hw dies here)
+      if (isl && l >= NT) {
+        s.hwst.Hw.lo(l, l) = hd;
+        if (pl > l) s.hwst.Hw.lo(pl, l) = ho;              // (the lower triangle: the lane with the smaller index of a pair stores the shared entry)
       }
     }
     rw = g;
@@ -1672,6 +1690,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
   load_state<NV>(s, m, a.qpos + (size_t)env * m.nq, a.qvel + (size_t)env * NV, sub);
   if constexpr (Lim<NV>::NT < NV || Lim<NV>::TS < Lim<NV>::NT) {   // the mass-matrix entries between different trees are never written (K5): zero, once
     for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
+  }
+  if constexpr (Lim<NV>::EXTRAS) {                       // ... and so are the structural zeros of the equality Hessian (K9)
+    for (int k = sub; k < (int)(sizeof(s.hwst.Hw.v) / sizeof(double)); k += LPE) s.hwst.Hw.v[k] = 0.0;
   }
   if (sub < 3) s.mocap[sub] = a.mocap_pos[(size_t)env * 3 + sub];
   fence();
@@ -2166,6 +2187,7 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
   Shared<NV>& s = sh[wave * EPW + grp];
   load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
   for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;      // (entries between different trees are never written, K5)
+  for (int k = sub; k < (int)(sizeof(s.hwst.Hw.v) / sizeof(double)); k += LPE) s.hwst.Hw.v[k] = 0.0;   // (nor the structural zeros of the equality Hessian, K9)
   if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
   fence();
   const Q4 mq = ldq(cfg.mocap_quat_dev);
