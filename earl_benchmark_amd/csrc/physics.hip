@@ -485,6 +485,23 @@ __device__ __forceinline__ void solve_lds_lead(const SymLds<NV>& H, double (&x)[
     x[i] = s * H.lo(i, i);
   }
 }
+// the leading N x N block factorised and solved in REGISTERS, redundantly per lane (chol_regs / solve_regs on a copy: same operations in the same order
+// as chol_coop_lead / solve_lds_lead, which cost nine plus eighteen LDS round trips in a row)
+template <int NV, int N, typename D>
+__device__ __forceinline__ void solve_lead_regs(const SymLds<NV>& H, D diag, double (&x)[NV]) {
+  double L[N * (N + 1) / 2], y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < i; ++j) L[i * (i + 1) / 2 + j] = H.lo(i, j);
+    L[i * (i + 1) / 2 + i] = H.lo(i, i) + diag(i);
+    y[i] = x[i];
+  }
+  chol_regs<N, N>(L);
+  solve_regs<N, N>(L, y);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = y[i];
+}
 template <int NV>
 __device__ __forceinline__ void solve_lds(const SymLds<NV>& H, double (&x)[NV]) {   // (L L') x' = x, L in LDS as chol_coop leaves it
 #pragma unroll
@@ -1416,7 +1433,6 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       } else {
         // no contact joins the arm and the fixtures: the Hessian is the arm's NA x NA block plus, per fixture, a scalar or -- for the
         // knob / burner and switch / light couplings -- a 2 x 2 block with its partner (earl_link_model24.pair)
-        chol_coop_lead<NV, NA>(s.con.Hc, s.con.dl, l, isl);
         if (isl && l >= NA) {
           const int p = m.pair[l];
           const double d = s.con.Hc.lo(l, l) + s.con.dl[l];
@@ -1436,7 +1452,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           }
           s.con.rc[l] = x;                              // (every lane already holds the right-hand side in a[])
         }
-        solve_lds_lead<NV, NA>(s.con.Hc, a);
+        solve_lead_regs<NV, NA>(s.con.Hc, [&](int i) { return s.con.dl[i]; }, a);
         fence();
 #pragma unroll
         for (int i = NA; i < NV; ++i) a[i] = s.con.rc[i];
@@ -1559,14 +1575,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     if (isl) s.con.dl[l] = dt * m.damping[l];
     fence();
     if constexpr (Lim<NV>::EXTRAS) {                   // the mass matrix is ALWAYS the arm's block + one scalar per fixture
-      chol_coop_lead<NV, NA>(s.M, s.con.dl, l, isl);
       if (isl && l >= NA) {
         double gl = 0;
 #pragma unroll
         for (int i = NA; i < NV; ++i) gl = i == l ? a[i] : gl;
         s.con.rc[l] = gl * rcp_nr(s.M.lo(l, l) + s.con.dl[l]);
       }
-      solve_lds_lead<NV, NA>(s.M, a);
+      solve_lead_regs<NV, NA>(s.M, [&](int i) { return s.con.dl[i]; }, a);
       fence();
 #pragma unroll
       for (int i = NA; i < NV; ++i) a[i] = s.con.rc[i];
