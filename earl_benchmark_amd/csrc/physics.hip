@@ -1220,15 +1220,26 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       }
       double hd = s.M.sym(l, l, ltri) + m.drag_G[l], ho = 0.0;        // fixture lanes: the diagonal entry, the entry shared with the coupled partner
       const int pl = m.pair[l];
-      // joint couplings q[j1] - c0 - c1 q[j2] = 0: soft equality rows with two non-zeros (1 at j1, -c1 at j2)
-      for (int e = 0; e < m.n_jeq; ++e) {
-        const int j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
+      // joint couplings q[j1] - c0 - c1 q[j2] = 0: soft equality rows with two non-zeros (1 at j1, -c1 at j2).  Lane e works out coupling e's
+      // regulariser and reference acceleration (a chain of dependent operations incl. three reciprocals: five of them in a row, in every lane, were
+      // 5 k cycles of the timestep); the lanes of the pair pick them up from LDS (the edge-weight block is free until the first pass of K9)
+      double* const jq = &s.con.cw[0][0];
+      static_assert(2 * EARL_MAXJEQ <= MC * 8, "coupling terms fit the edge-weight block");
+      if (sub < m.n_jeq) {
+        const int e = sub, j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
         const double c0 = m.jeq_coef[e][0], c1 = m.jeq_coef[e][1];
         const double res = s.qp[j1] - c0 - c1 * s.qp[j2], Jv = s.qv[j1] - c1 * s.qv[j2];
         const double kk = bt.kb_jeq[e][0], bb = bt.kb_jeq[e][1], dd = imp_of(m.jeq_solimp[e], res);
-        const double D = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
+        jq[2 * e] = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
+        jq[2 * e + 1] = -bb * Jv - kk * dd * res;
+      }
+      fence();
+      for (int e = 0; e < m.n_jeq; ++e) {
+        const int j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
+        const double c1 = m.jeq_coef[e][1];
+        const double D = jq[2 * e];
         const double Jl = l == j1 ? 1.0 : (l == j2 ? -c1 : 0.0), DJl = D * Jl;
-        g = fma(DJl, -bb * Jv - kk * dd * res, g);
+        g = fma(DJl, jq[2 * e + 1], g);
         // rows j1 and j2 of column l get DJl and -c1 DJl: for lane j1 that is its diagonal and its partner's row, for lane j2 the other way round
         hd += l == j1 ? DJl : (l == j2 ? -c1 * DJl : 0.0);
         ho += l == j1 ? -c1 * DJl : (l == j2 ? DJl : 0.0);
