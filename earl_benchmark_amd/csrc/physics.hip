@@ -1018,6 +1018,11 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
     for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
   }
+#ifdef EARL_PHYS_VARIANT_W8
+  // Two waves share a SIMD in this build, and the launch lasts as long as its slowest wave -- the one whose envs are in contact.  A wave with
+  // contacts in this timestep takes the issue slot first (s_setprio) for the rest of it; the wave it delays has slack.
+  if (ncmax > 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
   // ------------------------------------------------------------------ K8: constraint rows
   double Jc[6];                                        // this lane's column of the weld Jacobian
   V3 rpos, rrot;
