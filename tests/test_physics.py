@@ -344,3 +344,38 @@ def test_c_restatement_equals_the_numpy_statement():
     assert float(rew[t, 0]) == float(r) and bool(suc[t, 0]) == ok
   np.testing.assert_allclose(q[0], env.qpos, atol=1e-7)
   assert steps[0] == T
+
+
+@pytest.mark.parametrize('task', ['sawyer_door', 'sawyer_peg'])
+def test_warm_start_changes_the_passes_not_the_results(task):
+  """The active-set iteration started from the previous timestep's solution (the rule of the kernels, include/earl_physics.h earl_physics_step) and
+  started cold reach the same fixed point: random-action rollouts through contacts are bit-identical, with fewer passes"""
+  import ctypes as C
+  from oracle import physics_c
+  from oracle.tabletop_oracle import lib
+  cm = physics_c.CModel(task)
+  n, T = 24, 60
+  hand = np.array([0, 0.4, 0.2] if task == 'sawyer_door' else [0, 0.6, 0.2], np.float32).astype(np.float64)
+  q0 = cm.tables['qpos0'][None] if task == 'sawyer_peg' else np.zeros((1, cm.nv))
+  r = cm.run(q0, np.zeros((1, cm.nv)), hand, [1, 0, 1, 0], [-1, 1], nsub=1500)
+  cfg = (physics_c.door_cfg if task == 'sawyer_door' else physics_c.peg_cfg)(att_names=cm.att_names)
+  acts = np.random.default_rng(1).uniform(-1, 1, (T, n, 4)).astype(np.float32)
+  acts[:, :, 2] -= 0.5                                         # towards the handle / the peg: contacts
+  res, passes = {}, {}
+  try:
+    for warm in (0, 1):
+      lib().oracle_set_warm_start(C.c_int(warm))
+      q, v, mp = np.tile(r['qpos'][0], (n, 1)), np.tile(r['qvel'][0], (n, 1)), np.tile(hand, (n, 1))
+      if task == 'sawyer_door':
+        q[:, 9] = -np.pi / 3 + np.random.default_rng(0).uniform(0, np.pi / 20, n)
+      st = (C.c_longlong * 5)()
+      lib().oracle_newton_stats(st, C.c_int(1))
+      obs, rew, done, suc = cm.sawyer_rollout(cfg, q, v, mp, np.zeros((n, 7)), np.zeros(n, np.int32), acts)
+      lib().oracle_newton_stats(st, C.c_int(1))
+      res[warm], passes[warm] = (obs[:, :, :7].copy(), q.copy(), v.copy()), (st[1], st[2], st[3], st[4])
+  finally:
+    lib().oracle_set_warm_start(C.c_int(1))
+  for a, b in zip(res[0], res[1]):
+    assert np.array_equal(a, b)
+  assert passes[0][3] == 0 and passes[1][3] == 0               # every timestep reached its fixed point within the 8 passes
+  assert passes[1][0] <= passes[0][0] and passes[0][1] > 0     # never more passes warm; contacts were in play
