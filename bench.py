@@ -421,7 +421,7 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
 def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=2048, T=400, cpu_seconds=None):
   """BASELINE configs[3]: kitchen, 2048 envs in total range-sharded over the GPUs (n_global / world per GPU: STRONG scaling), one bench step =
   reset + T = 400 env steps (the reference's eval horizon) of 40 timesteps each in ONE fused launch (earl_kitchen_rollout); the per-step surface
-  (earl_kitchen_step, eight launches per env step) is timed beside it as `step_api`.
+  (env.step(): one launch per env step) is timed beside it as `step_api`.
   Own stepper, reduced collision set, parity with MuJoCo unpinned (envs/kitchen.py).  -> result dict on rank 0"""
   from earl_benchmark_amd.envs.kitchen import Kitchen
   from earl_benchmark_amd.wrappers import PersistentStateWrapper
@@ -439,7 +439,7 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
     res = env.unwrapped.rollout(acts, out=outbuf)
     return res['obs'][-1], res['reward'][-1], res['done'][-1], {'status': res['status'][-1]}
 
-  def stepped(k):                                      # the closed-loop surface: one earl_kitchen_step call (eight launches) per env step
+  def stepped(k):                                      # the closed-loop surface: one launch per env step
     env.reset()
     for t in range(k):
       env.step(acts[t])
@@ -488,8 +488,8 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
           'timesteps_per_s': steps * n_global * T * 40 / dt, 'gpu_ms_per_env_step': clk.elapsed_ms() / (steps * T), 'scaling': 'strong',
           'diverged_env_steps': fails,
           'step_api': {'value': n * T / dt_step, 'unit': 'env-steps/s (this rank)', 'ms_per_env_step': dt_step / T * 1e3,
-                       'note': 'the same episode through env.step(): one earl_kitchen_step call = eight launches per env step; every launch of the stepper '
-                               'lasts as long as its slowest wave, which the fused rollout only pays once per episode'},
+                       'note': 'the same episode through env.step(): one launch per env step (the rollout kernel with T = 1); every launch lasts as long as '
+                               'its slowest wave, which the fused rollout only pays once per episode'},
           'config': {'workload': f'kitchen dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 40 '
                                  'timesteps per bench step; own stepper (nv = 23, 32 lanes per env), reduced collision set, parity with MuJoCo unpinned',
                      'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 40, 'launches_per_episode': 1},

@@ -65,6 +65,7 @@ class Kitchen:
     if self.scalar_api and n != 1:
       raise ValueError('scalar_api needs num_envs == 1')
     self._seed, self._env_offset, self._counter = int(seed) & (2**64 - 1), int(env_offset), 0
+    self._fused_step = True            # step() through earl_kitchen_rollout(T = 1); False: through earl_kitchen_step (the per-step C entry point, kept and tested)
     self.sensor_noise = bool(sensor_noise)
     self._params = glue.kitchen_params()
     self._initial_states = tables.initial_states('kitchen')                     # kitchen.py:57-85, the 6 'all_pairs' rows
@@ -174,7 +175,7 @@ class Kitchen:
     return obs[0].cpu().numpy() if self.scalar_api else obs
 
   def step(self, action, b=None, out=None):
-    """one env step of every env: ONE call of earl_kitchen_step (eight launches on the caller's stream, include/earl_physics.h)"""
+    """one env step of every env: ONE launch (the fused rollout kernel with T = 1; `_fused_step = False` takes earl_kitchen_step's eight launches instead)"""
     del b
     n = self.num_envs
     with torch.cuda.device(self.device):
@@ -187,8 +188,12 @@ class Kitchen:
       o = _abi.KitchenOut(obs=out['obs'].data_ptr(), reward=out['reward'].data_ptr(), done=out['done'].data_ptr(), success=out['success'].data_ptr(),
                           status=out['status'].data_ptr())
       self._cfg.counter = self._counter
-      _abi.check(self._lib.earl_kitchen_step(self.model.buf.data_ptr(), self.model.col_ptr, C.byref(self._params), C.byref(self._cfg), C.byref(self._st),
-                                             a.data_ptr(), C.byref(o), self._stream()), 'earl_kitchen_step')
+      if self._fused_step:             # ONE launch: the fused rollout kernel with T = 1 (bit-identical to earl_kitchen_step's eight launches, tests/test_kitchen_gpu.py)
+        _abi.check(self._lib.earl_kitchen_rollout(self.model.buf.data_ptr(), self.model.col_ptr, C.byref(self._params), C.byref(self._cfg), C.byref(self._st),
+                                                  a.data_ptr(), 1, C.byref(o), self._stream()), 'earl_kitchen_rollout')
+      else:
+        _abi.check(self._lib.earl_kitchen_step(self.model.buf.data_ptr(), self.model.col_ptr, C.byref(self._params), C.byref(self._cfg), C.byref(self._st),
+                                               a.data_ptr(), C.byref(o), self._stream()), 'earl_kitchen_step')
       obs, rew, done, suc = out['obs'], out['reward'], out['done'], out['success']
       gcf = int(self._cfg.goal_change_frequency)
       if gcf > 0:                                                                # LifelongWrapper.step (lifelong_wrapper.py:30-44)

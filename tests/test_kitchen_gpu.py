@@ -168,6 +168,7 @@ def test_fused_rollout_equals_stepping_bit_for_bit():
   acts[:, :40, 2] -= 0.6                                   # some hands go down to the counter's knobs and stay in contact
   acts[3, 7] = float('nan')                                # a NaN action: the guard trips in env 7 at step 3 in both paths
   a_env.reset(); b_env.reset()
+  b_env._fused_step = False                                  # the per-step C entry point (earl_kitchen_step, eight launches) is the other side
   fused = a_env.rollout(acts)
   rows = [b_env.step(acts[t]) for t in range(T)]
   assert torch.equal(fused['obs'].view(torch.int64), torch.stack([r[0] for r in rows]).view(torch.int64))
@@ -186,6 +187,13 @@ def test_fused_rollout_equals_stepping_bit_for_bit():
   f2 = a_env.rollout(more)
   r2 = [b_env.step(more[t]) for t in range(3)]
   assert torch.equal(f2['obs'].view(torch.int64), torch.stack([r[0] for r in r2]).view(torch.int64))
+  # step() itself goes through the fused kernel with T = 1 by default: the same again
+  c_env = Kitchen(num_envs=n, seed=11)
+  c_env.reset()
+  for t in range(12):
+    o, r, d, info = c_env.step(acts[t])
+    assert torch.equal(o.view(torch.int64), fused['obs'][t].view(torch.int64)) and torch.equal(r.view(torch.int64), fused['reward'][t].view(torch.int64)), t
+    assert torch.equal(info['status'], fused['status'][t])
 
 
 def test_fused_rollout_full_size():
