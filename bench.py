@@ -560,6 +560,7 @@ def main():
   total_env_steps = a.steps * n * T * world
   value = total_env_steps / dt
   dn = out[2] if E > 1 else out[2][None]
+  dn = dn[:(E if a.steps >= E else a.steps)]                         # (fewer steps than episodes per launch: the one launch wrote the first `steps` episodes only)
   assert bool(dn[:, -1].all()) and not bool(dn[:, :-1].any())        # done fires exactly at the horizon, in every episode
 
   # BASELINE configs[2] in the same run (every rank takes part: same barrier / max-over-ranks timing; the CPU legs at N = 1 only)
