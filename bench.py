@@ -66,9 +66,12 @@ def synth_actions(torch, T, n, rank, device):
 
 
 def alloc_out(torch, T, n, device, episodes=1):
+  # zeros, not empty: the buffers are written once here, at allocation.  A launch that is the FIRST to write a region of device memory runs
+  # measurably slower (467 against 416 us for 20 episodes = 1.08 GB of outputs, tools/repro20.py), and with few bench steps the timed launch
+  # would be exactly that launch -- the warm-up launch of `--warmup 5` only reaches the first five episodes' rows.
   lead = (T, n) if episodes == 1 else (episodes, T, n)
-  return (torch.empty(*lead, 12, dtype=torch.float32, device=device), torch.empty(*lead, dtype=torch.float32, device=device),
-          torch.empty(*lead, dtype=torch.bool, device=device), torch.empty(*lead, dtype=torch.bool, device=device))
+  return (torch.zeros(*lead, 12, dtype=torch.float32, device=device), torch.zeros(*lead, dtype=torch.float32, device=device),
+          torch.zeros(*lead, dtype=torch.bool, device=device), torch.zeros(*lead, dtype=torch.bool, device=device))
 
 
 class _Clock:
