@@ -40,7 +40,7 @@ def parse():
   p.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
   p.add_argument('--cpu-seconds', type=float, default=10.0)
   p.add_argument('--no-step-api', action='store_true')
-  p.add_argument('--episodes-per-launch', type=int, default=25,
+  p.add_argument('--episodes-per-launch', type=int, default=28,
                  help='evaluation episodes (bench steps) one kernel launch walks (earl_tabletop_eval_episodes); 1 = one launch per episode')
   p.add_argument('--no-single', action='store_true', help='skip the one-episode-per-launch comparison leg')
   p.add_argument('--no-sawyer', action='store_true', help='skip the sawyer_door / sawyer_peg (BASELINE configs[2]) legs of the default line')
@@ -560,6 +560,18 @@ def main():
     sdt, skm, _, _, sl = time_rollouts(torch, dist, env, acts, o1, max(8, a.steps // 4), 4, world, device, episodes_per_launch=1)
     single = {'value': max(8, a.steps // 4) * n * T * world / sdt, 'unit': 'env-steps/s', 'kernel_ms_mean': skm[0], 'launches': sl,
               'note': 'one evaluation episode per launch (earl_tabletop_reset_rollout): what round 1 timed'}
+  sequential = None
+  if E > 1 and not a.no_single and (n + 63) // 64 * 2 <= 256:      # the same multi-episode launches with the episodes ONE AFTER THE OTHER (debug switch 38)
+    from earl_benchmark_amd import _abi as _abi_
+    lib_ = _abi_.load()
+    lib_.earl_debug_set_rollout_impl(38)
+    try:
+      ks = max(E, (a.steps // 2 // E) * E)
+      qdt, qkm, _, _, ql = time_rollouts(torch, dist, env, acts, out, ks, E, world, device, episodes_per_launch=E)
+    finally:
+      lib_.earl_debug_set_rollout_impl(0)
+    sequential = {'value': ks * n * T * world / qdt, 'unit': 'env-steps/s', 'kernel_ms_mean': qkm[0], 'launches': ql,
+                  'note': f'{E} evaluation episodes per launch, one after the other on the batch\'s 64 workgroups (what the line reported before episodes ran side by side)'}
   total_env_steps = a.steps * n * T * world
   value = total_env_steps / dt
   dn = out[2] if E > 1 else out[2][None]
@@ -588,14 +600,18 @@ def main():
       key = f'rollout_n{n}_T{T}' + (f'_E{E}' if E > 1 else '')
       traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
       if traffic is not None:
+        traffic = traffic * (a.steps / launches) / E       # (the profiled launches hold E episodes each; this run's average launch may hold fewer)
         traffic_source = f"profiles/traffic.json <- {tj[key].get('source')} (static: FETCH_SIZE / WRITE_SIZE passes of rocprofv3 --pmc over this command, not measured in this run)"
     res = {
         'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': value, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'tabletop_manipulation {a.reward} reward, {n} batched envs per MI355X, '
-                               f'reset + fused {T}-step rollout per bench step' + (f', {E} bench steps (evaluation episodes) per kernel launch' if E > 1 else ''),
-                   'envs_per_gpu': n, 'episodes_per_launch': E, 'launches': launches,
+                               f'reset + fused {T}-step rollout per bench step' + (f', up to {E} bench steps (evaluation episodes) per kernel launch, '
+                               f'{min(min(E, a.steps), max(1, 256 // ((n + 63) // 64)))} of them in flight at a time (episodes are independent: each starts with reset(); '
+                               'a 4096-env batch is 64 workgroups on 256 CUs)' if E > 1 else ''),
+                   'envs_per_gpu': n, 'episodes_per_launch': E, 'episodes_in_flight': (min(min(E, a.steps), max(1, 256 // ((n + 63) // 64))) if E > 1 and (n + 63) // 64 * 2 <= 256 else 1),
+                   'launches': launches,
                    'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': n * T * world,
                    'parallelism': f'env-range shard x{world}, no per-step collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -605,6 +621,8 @@ def main():
     }
     if single is not None:
       res['single_episode_launch'] = single
+    if sequential is not None:
+      res['sequential_episodes'] = sequential
     if not a.no_step_api:
       env2 = make_env(torch, n, T, a.reward, rank, device)
       ks = max(1, a.steps // 20)

@@ -384,8 +384,18 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
     if (!general && out->obs && out->reward && out->done && out->success && g_rollout_impl != 1) {
       WsArgs w{cfg->n, T, cfg->horizon, cfg->wide_init, act, st->qpos, st->attached, st->goal_idx, st->goal_table,
                st->steps_since_reset, out->obs, out->reward, out->done, out->success, thresholds(), grip_threshold(),
-               reset_first ? 1 : 0, *cfg, st->goal_idx, st->num_interventions, episodes, Tep, act_ep_stride};
-      const dim3 grid((unsigned)((cfg->n + 63) / 64));
+               reset_first ? 1 : 0, *cfg, st->goal_idx, st->num_interventions, episodes, Tep, act_ep_stride, 0, 1, episodes};
+      dim3 grid((unsigned)((cfg->n + 63) / 64));
+      w.wgs = (int)grid.x;
+      // Evaluation episodes are independent of one another (each starts with reset()): when the env batch does not fill the chip -- 4096 envs are
+      // 64 workgroups on 256 CUs -- several of them run side by side, each group of episodes on its own workgroups (WsArgs::ep_groups).  Same
+      // outputs, same final state as the sequence.  impl 38 forces the sequence (one group) for comparison.
+      if (episodes > 1 && reset_first && g_rollout_impl != 38 && grid.x * 2 <= 256) {
+        const int P = (int)(256 / grid.x) < episodes ? (int)(256 / grid.x) : episodes;
+        w.ep_per_group = (episodes + P - 1) / P;
+        w.ep_groups = (episodes + w.ep_per_group - 1) / w.ep_per_group;
+        grid.x *= (unsigned)w.ep_groups;
+      }
       const hipStream_t hs = (hipStream_t)stream;
 #define EARL_WS(RT, NC, NL, NS, K, LEAD) \
   rollout_ws_kernel<RT, NC, NL, NS, K, LEAD><<<grid, 64 * (((NC) == 3 ? 2 : (NC)) + NL + NS), g_rollout_lds_pad, hs>>>(w)
@@ -422,6 +432,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 4, 8, 3, true><<<grid, 64 * 10, 0, hs>>>(w); break;  // stamps
           case 19: rollout_ws_kernel<EARL_REWARD_SPARSE, 1, 4, 4, 8, 3, true><<<grid, 64 * 9, 0, hs>>>(w); break;  // stamps
           case 36:
+          case 38:
           default:
             // 2 compute waves with x / y in adjacent lanes (DPP, VGPR-only masks) + 2 loaders + 8 storers, 8-step chunks:
             // fastest of the variants above at N = 4096 and not slower at any larger N measured (tools/tune_rollout.py;
@@ -507,7 +518,7 @@ int earl_tabletop_eval_episodes(const earl_tabletop_cfg* cfg, const earl_tableto
   if (episodes == 0 || cfg->n == 0) return EARL_OK;
   const bool general = cfg->goal_change_frequency > 0 || cfg->auto_reset;
   // one launch walks all episodes when the wave-specialised kernel applies and episodes end on its chunk boundaries (8 steps)
-  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && (g_rollout_impl == 0 || g_rollout_impl == 29 || g_rollout_impl == 36) &&
+  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && (g_rollout_impl == 0 || g_rollout_impl == 29 || g_rollout_impl == 36 || g_rollout_impl == 38) &&
                      T % 8 == 0 && T >= 16 && (long long)episodes * T < (1 << 24);
   if (fused || episodes == 1) return do_rollout<1>(cfg, st, T, act, out, stream, true, episodes, (long long)act_episode_stride);
   for (int32_t e = 0; e < episodes; ++e) {          // otherwise: the same thing as `episodes` launches

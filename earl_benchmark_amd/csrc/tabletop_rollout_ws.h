@@ -60,6 +60,11 @@ struct WsArgs {
   // actions of episode ep start at act + ep * act_ep_stride floats (0: every episode replays the same [Tep, n, 3] actions).
   int32_t episodes, Tep;
   long long act_ep_stride;
+  // ... and, the evaluation episodes of a launch being independent of one another (each starts with reset()), SEVERAL OF THEM IN FLIGHT: the grid is
+  // ep_groups x wgs workgroups, group g walks episodes [g ep_per_group, (g + 1) ep_per_group) of the launch on its own wgs workgroups (its own
+  // rows of the outputs and of the actions, the Philox counters those episodes have in the sequence); the group of the LAST episode leaves the
+  // env state behind, as the sequence would.  ep_groups = 1: the plain sequence.
+  int32_t wgs, ep_groups, ep_per_group;
 };
 
 // Philox counter of the reset that starts episode `ep` of a launch
@@ -278,8 +283,28 @@ __device__ __forceinline__ unsigned long long ws_clock() {
 // MULTI: several evaluation episodes per launch (WsArgs.episodes > 1; NC == 3 only) -- a separate instantiation, so the one-episode kernel
 // carries none of the episode bookkeeping.
 template <int RT, int NC, int NL, int NS, int K, int LEAD, bool PROF = false, bool MULTI = false>
-__global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_ws_kernel(const WsArgs a) {
+__global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_ws_kernel(const WsArgs a_in) {
   constexpr int E = 64;
+  // several episodes in flight (WsArgs::ep_groups): this workgroup's group sees a launch of its OWN episodes -- shifted counter, rows, actions
+  WsArgs a = a_in;
+  int wg = blockIdx.x;
+  bool leaves_state = true;                  // (the group that walks the launch's last episode)
+  int eps_before = 0;                        // episodes of the launch before this group's first
+  if constexpr (MULTI) {
+    if (a_in.ep_groups > 1) {
+      const int grp = (int)blockIdx.x / a_in.wgs;
+      wg = (int)blockIdx.x - grp * a_in.wgs;
+      eps_before = grp * a_in.ep_per_group;
+      const int ne = min(a_in.ep_per_group, a_in.episodes - eps_before);
+      leaves_state = eps_before + ne == a_in.episodes;
+      a.episodes = ne;
+      a.T = ne * a_in.Tep;
+      a.cfg.counter = a_in.cfg.counter + (uint64_t)eps_before * (uint64_t)(a_in.Tep + 1);
+      const size_t row0 = (size_t)eps_before * (size_t)a_in.Tep * (size_t)a_in.n;
+      a.act = a_in.act + (size_t)eps_before * (size_t)a_in.act_ep_stride;
+      a.obs = a_in.obs + row0 * 12; a.reward = a_in.reward + row0; a.done = a_in.done + row0; a.success = a_in.success + row0;
+    }
+  }
   constexpr int NCW = NC == 3 ? 2 : NC;     // compute WAVES (NC == 3: two, x / y in adjacent lanes)
   constexpr int KL = K / NL;          // steps of a chunk handled by one loader
   static_assert(K % NL == 0, "K must be a multiple of NL");
@@ -298,7 +323,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
   // readfirstlane: tell hipcc the role index is wave-uniform (otherwise every role test becomes exec-mask code)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = a.n, T = a.T;
-  const int i0 = blockIdx.x * E;
+  const int i0 = wg * E;
   const int i = i0 + lane;
   const int valid = min(E, n - i0);   // live envs of this workgroup
   const bool live = lane < valid;
@@ -338,9 +363,9 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         const int gi = reset_env<1>(ev, a.cfg, a.cfg.counter, ie, a.goal_table, nullptr, a.th);
         f = h ? ev.q[1] : ev.q[0];         // (selects, not ev.q[h]: a dynamic index would put the array into scratch memory)
         o = h ? ev.q[3] : ev.q[2];
-        if (h == 0) {
+        if (h == 0 && leaves_state) {      // (episodes in flight: only the group of the launch's last episode touches the env state)
           a.goal_idx_w[ie] = gi;
-          a.num_interventions[ie] += 1;
+          a.num_interventions[ie] += 1 + eps_before;
         }
       } else {
         f = a.qpos[(size_t)ie * 4 + h];
@@ -442,7 +467,7 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       }
       if (lane == 0 && blockIdx.x < 64 && wave == 1) g_ws_prof[blockIdx.x * 16 + 13] = p_bar;      // the second compute wave's barrier wait
     }
-    if (alive) {
+    if (alive && leaves_state) {
       a.qpos[(size_t)ie * 4 + h] = f;
       a.qpos[(size_t)ie * 4 + 2 + h] = o;
       if (h == 0) {

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
 PROF = os.path.join(ROOT, 'profiles')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
-n, T, E = 4096, 200, 25         # bench.py defaults: 25 evaluation episodes per launch
+n, T, E = 4096, 200, 28         # bench.py defaults: 28 evaluation episodes per launch (four groups of seven in flight)
 SUF = f'_E{E}' if E > 1 else ''
 os.makedirs(PROF, exist_ok=True)
 
