@@ -105,7 +105,9 @@ int earl_tabletop_reset_rollout(const earl_tabletop_cfg* cfg, const earl_tableto
  * This is the reference's evaluation loop (`for _ in range(num_eval_episodes): obs = env.reset(); while not done: env.step(...)`
  * over PersistentStateWrapper, persistent_state_wrapper.py:17-31) for the whole batch.  When the wave-specialised kernel applies
  * (no lifelong switching / auto-reset, all four outputs, T a multiple of 8) ALL episodes run in ONE launch: the launch's fixed cost
- * (prologue, pipeline fill and drain) is paid once instead of once per episode. */
+ * (prologue, pipeline fill and drain) is paid once instead of once per episode.  The episodes being independent of one another (each starts
+ * with the reset), a batch that leaves CUs idle (up to 8192 envs) has several of them IN FLIGHT at a time, each group of episodes on its own
+ * workgroups; outputs and the state left behind are those of the sequence, bit for bit. */
 int earl_tabletop_eval_episodes(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t episodes, int32_t T, const float* act,
                                 int64_t act_episode_stride, const earl_tabletop_out* out, earl_stream_t stream);
 
