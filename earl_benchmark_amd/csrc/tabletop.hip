@@ -391,7 +391,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
       // 64 workgroups on 256 CUs -- several of them run side by side, each group of episodes on its own workgroups (WsArgs::ep_groups).  Same
       // outputs, same final state as the sequence.  impl 38 forces the sequence (one group) for comparison.
       if (episodes > 1 && reset_first && g_rollout_impl != 38 && grid.x * 2 <= 256) {
-        const int P = (int)(256 / grid.x) < episodes ? (int)(256 / grid.x) : episodes;
+        const int P = (int)(256 / grid.x) < episodes ? (int)(256 / grid.x) : episodes;     // (eight groups, two workgroups per CU: no faster -- HBM-bound)
         w.ep_per_group = (episodes + P - 1) / P;
         w.ep_groups = (episodes + w.ep_per_group - 1) / w.ep_per_group;
         grid.x *= (unsigned)w.ep_groups;

@@ -5,11 +5,11 @@ sys.path.insert(0,'/root/repo')
 import earl_benchmark_amd as eb
 from earl_benchmark_amd import _abi
 lib=_abi.load()
-n,E,T=4096,16,208 if len(sys.argv)>1 else 200
+n,E,T=4096,32,200
 T=int(sys.argv[1]) if len(sys.argv)>1 else 208
 acts = (torch.rand(T, n, 3, device='cuda') * 2 - 1).contiguous()
 res={}
-for impl in (1, 36, 0):        # 1 = the plain kernel, one launch per episode: the reference
+for impl in (1, 36, 0, 38):        # 38: the episodes of a launch one after the other        # 1 = the plain kernel, one launch per episode: the reference
   L = eb.EARLEnvs('tabletop_manipulation', reward_type='sparse', num_envs=n, eval_horizon=T, scalar_api=False)     # fresh env: same Philox counters in both runs
   _, env = L.get_envs()
   lib.earl_debug_set_rollout_impl(impl)
