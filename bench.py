@@ -118,9 +118,11 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cud
     done = 0
     while done < k:
       e = min(E, k - done)
-      env.rollout_episodes(acts, episodes=e, out=tuple(t[:e] for t in out))     # e x (reset + T steps): ONE kernel launch
+      env.rollout_episodes(acts, episodes=e, out=views[e])     # e x (reset + T steps): ONE kernel launch
       done += e
     return -(-k // E)
+  # the output views of every launch size this job issues, made once (host-side bookkeeping of static buffers, not part of a bench step)
+  views = {e: tuple(t[:e] for t in out) for e in {E, steps % E or E, warmup % E or E}} if E > 1 else {}
   run(warmup)
   # one HIP event pair around the whole timed region, recorded on torch's current stream == the launch stream.
   # (An event pair per launch costs ~3 us of queue time per event on this stack -- 20 % of a 34 us kernel.)
@@ -134,8 +136,8 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cud
   launches = run(steps)
   clk.stop()
   gathered, rollout = None, None
-  last = out if E == 1 else tuple(t[(steps - 1) % E] for t in out)       # outputs of the last episode
   if world > 1:                 # the one collective of the job: evaluation result of the last rollout -> every rank
+    last = out if E == 1 else tuple(t[(steps - 1) % E] for t in out)       # outputs of the last episode
     sizes = [acts.shape[1]] * world
     gathered = sharding.gather_summary(sharding.rollout_summary(last[1], last[3]), sizes=sizes)   # [N_global, 2]
     if gather_rollout:          # the whole [T, N/W, D+2] trajectory buffer of every rank -> [T, N, D+2]
