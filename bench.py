@@ -31,8 +31,8 @@ STATE_BYTES_PER_ENV_LAUNCH = 2 * (32 + 1 + 4) + 4   # rollout: state read+writte
 def parse():
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
-  p.add_argument('--steps', type=int, default=200)
-  p.add_argument('--warmup', type=int, default=20)
+  p.add_argument('--steps', type=int, default=196)      # 7 launches of 28 evaluation episodes (the command tools/profile_bench.sh profiles)
+  p.add_argument('--warmup', type=int, default=28)
   p.add_argument('--envs', type=int, default=4096, help='envs per GPU')
   p.add_argument('--horizon', type=int, default=200)
   p.add_argument('--reward', default='sparse')
@@ -537,7 +537,7 @@ def main():
   if a.workload in ('sawyer_door', 'sawyer_peg'):
     return main_sawyer(a, torch, dist, world, rank, device)
   if a.workload == 'kitchen':
-    r = run_kitchen(a, torch, dist, world, rank, device, a.steps if a.steps != 200 else 3, min(a.warmup, 1), cpu_seconds=None if a.no_cpu else 5.0)
+    r = run_kitchen(a, torch, dist, world, rank, device, a.steps if a.steps != 196 else 3, min(a.warmup, 1), cpu_seconds=None if a.no_cpu else 5.0)
     if rank == 0:
       print(json.dumps({'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world,
                         'steps': r['steps'], 'warmup': r['warmup'], 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
