@@ -913,7 +913,19 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         const int t = c * K + s + NS * q;
         const size_t row0 = (size_t)t * n + i0;
         float4* dst = reinterpret_cast<float4*>(a.obs + row0 * 12);
+        // NON-TEMPORAL stores: the observation rows (48 of the 54 bytes written per env step) are written once and never read back by the kernel;
+        // as ordinary stores they went through the L2 write-back path and, with four episodes in flight, held the kernel at 5.1-5.7 TB/s;
+        // streamed past it the launch runs at 7.3 TB/s algorithmic = 6.3 TB/s at the HBM interface (the actions hit the cache), which is what
+        // MI355X_MICROARCH.md gives as the achievable HBM bandwidth.  (EARL_WS_TEMPORAL_STORES: the ordinary stores, for comparison.)
+#ifndef EARL_WS_TEMPORAL_STORES
+        typedef float nt4 __attribute__((ext_vector_type(4)));
+        nt4* d4 = reinterpret_cast<nt4*>(dst);
+        __builtin_nontemporal_store(nt4{rw.v0.x, rw.v0.y, rw.v0.z, rw.v0.w}, d4 + lane);
+        __builtin_nontemporal_store(nt4{rw.v1.x, rw.v1.y, rw.v1.z, rw.v1.w}, d4 + lane + 64);
+        __builtin_nontemporal_store(nt4{rw.v2.x, rw.v2.y, rw.v2.z, rw.v2.w}, d4 + lane + 128);
+#else
         dst[lane] = rw.v0; dst[lane + 64] = rw.v1; dst[lane + 128] = rw.v2;
+#endif
         const float o[12] = {rw.p.x, rw.p.y, rw.p.z, rw.p.w, 0.f, 0.f, g[0], g[1], g[2], g[3], g[4], g[5]};
         const bool succ = success1(o, a.wide, a.th);
         float rew;

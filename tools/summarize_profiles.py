@@ -41,7 +41,7 @@ fetch, write = pmc[rk]['FETCH_SIZE']['mean_KiB'], pmc[rk]['WRITE_SIZE']['mean_Ki
 hbm = (2 * fetch + write) * 1024
 algo = n * (E * T * 66 + 2 * (32 + 1 + 4) + 4)
 summary = {
-    'command': 'python3 bench.py --steps 200 --warmup 25 --no-cpu --no-step-api --no-sawyer --no-single  (under rocprofv3, see tools/profile_bench.sh)',
+    'command': 'python3 bench.py --no-cpu --no-step-api --no-sawyer --no-kitchen --no-single  [defaults: --steps 196 --warmup 28 = 7 + 1 launches of 28 episodes]  (under rocprofv3, see tools/profile_bench.sh)',
     'kernel': rk,
     'kernel_trace_stats': {'calls': int(kern['Calls']), 'average_ns': float(kern['AverageNs']), 'min_ns': float(kern['MinNs']),
                            'max_ns': float(kern['MaxNs']), 'stddev_ns': float(kern['StdDev'])},
