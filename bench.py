@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the tabletop_manipulation hot path on MI355X (BASELINE.json configs[1]).
 
-One bench "step" = one evaluation rollout of the whole batch: reset() + T = 200 wrapped env steps (the reference's
-eval horizon) of N = 4096 sparse-reward envs per GPU, executed by ONE fused reset+rollout kernel launch.
-Actions are synthetic U(-1,1) (pre-generated, resident in HBM); every step's obs / reward / done / success is
-written to HBM exactly as T step() calls would.  value = env-steps of all ranks / max-over-ranks wall time.
+One bench "step" = one pass of the hot path over one batch of synthetic input = ONE call of earl_tabletop_eval_episodes: E = 28
+evaluation episodes (each: reset() + T = 200 wrapped env steps, the reference's eval horizon) of N = 4096 sparse-reward envs per GPU,
+EVERY episode with its own U(-1,1) actions ([E, T, N, 3], pre-generated, resident in HBM: 275 MB), in ONE kernel launch whose shape does
+not depend on --steps.  Every step's obs / reward / done / success is written to HBM exactly as E x T step() calls would (1.24 GB per
+launch).  value = env-steps of all ranks / max-over-ranks wall time.  The episodes of a launch are independent (each starts with
+reset()), so a 4096-env batch (64 workgroups on 256 CUs) has four of them in flight; the like-for-like figure with ONE episode in
+flight per env is reported next to it (config.strict, and the `sequential_episodes` key).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--horizon 200] [--sweep] [--no-cpu]
   N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
@@ -31,8 +34,8 @@ STATE_BYTES_PER_ENV_LAUNCH = 2 * (32 + 1 + 4) + 4   # rollout: state read+writte
 def parse():
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
-  p.add_argument('--steps', type=int, default=196)      # 7 launches of 28 evaluation episodes (the command tools/profile_bench.sh profiles)
-  p.add_argument('--warmup', type=int, default=28)
+  p.add_argument('--steps', type=int, default=20)       # 20 launches of 28 evaluation episodes each (the command tools/profile_bench.sh profiles)
+  p.add_argument('--warmup', type=int, default=5)
   p.add_argument('--envs', type=int, default=4096, help='envs per GPU')
   p.add_argument('--horizon', type=int, default=200)
   p.add_argument('--reward', default='sparse')
@@ -41,7 +44,7 @@ def parse():
   p.add_argument('--cpu-seconds', type=float, default=10.0)
   p.add_argument('--no-step-api', action='store_true')
   p.add_argument('--episodes-per-launch', type=int, default=28,
-                 help='evaluation episodes (bench steps) one kernel launch walks (earl_tabletop_eval_episodes); 1 = one launch per episode')
+                 help='evaluation episodes one bench step = one kernel launch walks (earl_tabletop_eval_episodes); 1 = one episode per launch')
   p.add_argument('--no-single', action='store_true', help='skip the one-episode-per-launch comparison leg')
   p.add_argument('--no-sawyer', action='store_true', help='skip the sawyer_door / sawyer_peg (BASELINE configs[2]) legs of the default line')
   p.add_argument('--sawyer-cpu-seconds', type=float, default=2.0, help='seconds per repetition and thread count of the Sawyer CPU baselines')
@@ -59,16 +62,18 @@ def make_env(torch, n, horizon, reward, rank, device):
   return env
 
 
-def synth_actions(torch, T, n, rank, device):
+def synth_actions(torch, T, n, rank, device, episodes=1):
+  """U(-1,1) actions of one bench step: [T, n, 3], or [E, T, n, 3] -- every evaluation episode of the launch has its OWN actions, so all
+  12 B per env-step of action reads come from HBM (round 2 replayed one [T, n, 3] array in every episode: those reads were cache hits)"""
   g = torch.Generator(device=device)
   g.manual_seed(1234 + rank)
-  return (torch.rand(T, n, 3, generator=g, device=device) * 2 - 1).contiguous()
+  lead = (T, n) if episodes == 1 else (episodes, T, n)
+  return (torch.rand(*lead, 3, generator=g, device=device) * 2 - 1).contiguous()
 
 
 def alloc_out(torch, T, n, device, episodes=1):
-  # zeros, not empty: the buffers are written once here, at allocation.  A launch that is the FIRST to write a region of device memory runs
-  # measurably slower (467 against 416 us for 20 episodes = 1.08 GB of outputs, tools/repro20.py), and with few bench steps the timed launch
-  # would be exactly that launch -- the warm-up launch of `--warmup 5` only reaches the first five episodes' rows.
+  # zeros, not empty: the buffers are written once here, at allocation (a launch that is the FIRST to write a region of device memory runs
+  # measurably slower, tools/repro20.py); every warm-up launch then writes every row again -- the launch shape does not depend on --steps
   lead = (T, n) if episodes == 1 else (episodes, T, n)
   return (torch.zeros(*lead, 12, dtype=torch.float32, device=device), torch.zeros(*lead, dtype=torch.float32, device=device),
           torch.zeros(*lead, dtype=torch.bool, device=device), torch.zeros(*lead, dtype=torch.bool, device=device))
@@ -101,31 +106,26 @@ class _Clock:
     return self.e0.elapsed_time(self.e1) if self.cuda else (self.t1 - self.t0) * 1e3
 
 
-def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cuda', gather_rollout=False, episodes_per_launch=1):
-  """The timed region of the job: W warm-up episodes; barrier + synchronize; K episodes (bench steps: reset + T env steps of the whole
-  batch each), `episodes_per_launch` of them per kernel launch (out then has a leading episode axis; the last launch takes the
-  remainder); the ONE collective of the job (evaluation result of the last episode -> every rank); synchronize + barrier; wall time,
-  MAX over ranks.
+def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cuda', gather_rollout=False):
+  """The timed region of the job: W warm-up bench steps; barrier + synchronize; K bench steps; the ONE collective of the job (evaluation
+  result of the last episode -> every rank); synchronize + barrier; wall time, MAX over ranks.  A bench step is ONE kernel launch:
+  acts [E, T, n, 3] -> env.rollout_episodes (E evaluation episodes, each = reset + T env steps of the whole batch, each with its own
+  actions; out has a leading episode axis), acts [T, n, 3] -> env.rollout(reset_first=True) (one episode).  Every launch of the job has
+  the same shape, warm-up included.
   -> (seconds, [ms per launch from one event pair around the region], gathered [N_global, 2], gathered rollout or None, launches)"""
   from earl_benchmark_amd import sharding
-  E = max(1, int(episodes_per_launch))
+  multi = acts.dim() == 4
 
-  def run(k):                                          # k episodes; -> launches issued
-    if E == 1:
-      for _ in range(k):
+  def run(k):                                          # k bench steps = k launches
+    for _ in range(k):
+      if multi:
+        env.rollout_episodes(acts, out=out)            # E x (reset + T steps): ONE kernel launch
+      else:
         env.rollout(acts, out=out, reset_first=True)   # reset() of every env + T steps: ONE kernel launch
-      return k
-    done = 0
-    while done < k:
-      e = min(E, k - done)
-      env.rollout_episodes(acts, episodes=e, out=views[e])     # e x (reset + T steps): ONE kernel launch
-      done += e
-    return -(-k // E)
-  # the output views of every launch size this job issues, made once (host-side bookkeeping of static buffers, not part of a bench step)
-  views = {e: tuple(t[:e] for t in out) for e in {E, steps % E or E, warmup % E or E}} if E > 1 else {}
+    return k
   run(warmup)
   # one HIP event pair around the whole timed region, recorded on torch's current stream == the launch stream.
-  # (An event pair per launch costs ~3 us of queue time per event on this stack -- 20 % of a 34 us kernel.)
+  # (An event pair per launch costs ~3 us of queue time per event on this stack.)
   clk = _Clock(torch, device)
   clk.sync()
   if world > 1:
@@ -136,9 +136,9 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cud
   launches = run(steps)
   clk.stop()
   gathered, rollout = None, None
-  if world > 1:                 # the one collective of the job: evaluation result of the last rollout -> every rank
-    last = out if E == 1 else tuple(t[(steps - 1) % E] for t in out)       # outputs of the last episode
-    sizes = [acts.shape[1]] * world
+  if world > 1:                 # the one collective of the job: evaluation result of the last episode -> every rank
+    last = tuple(t[-1] for t in out) if multi else out
+    sizes = [acts.shape[-2]] * world
     gathered = sharding.gather_summary(sharding.rollout_summary(last[1], last[3]), sizes=sizes)   # [N_global, 2]
     if gather_rollout:          # the whole [T, N/W, D+2] trajectory buffer of every rank -> [T, N, D+2]
       rollout = sharding.gather_rollout(sharding.pack_rollout(*last), sizes=sizes)
@@ -151,7 +151,7 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cud
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-  kern_ms = [clk.elapsed_ms() / launches]   # average launch duration over the timed region (incl. the inter-launch gap)
+  kern_ms = [clk.elapsed_ms() / max(1, launches)]   # average launch duration over the timed region (incl. the inter-launch gap)
   return dt, kern_ms, gathered, rollout, launches
 
 
@@ -242,6 +242,25 @@ def sawyer_profile(workload, n, T):
   if not os.path.exists(tpath) or (n, T) != ((8192, 300) if workload == 'sawyer_door' else (8192, 200)):
     return {}
   return json.load(open(tpath)).get(workload, {})
+
+
+def pipe_roofline(prof, kernel, gpu_ms, hbm=None):
+  """roofline object of the articulated-body kernels: they are bound by ONE pipe of the SIMD, the vector ALU, not by HBM (state lives in LDS
+  and registers for the whole rollout) and not by MFMA (block-sparse 9-23 wide matrices).  achieved = share of a SIMD's cycles in which its VALU
+  issues = resident waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (the per-wave shares add up because a SIMD issues at most one VALU
+  instruction per cycle; LDS and scalar issue run beside it and are listed, not summed); peak 1.0; no clamp.  The counters are STATIC content of
+  profiles/ (separate rocprofv3 --pmc passes over this same workload), labelled so.  `wait` = share of wave cycles parked on s_waitcnt;
+  `lane_occupancy` = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) when that pass was collected."""
+  issue = prof.get('issue') or {}
+  wps = prof.get('waves_per_simd') or 1
+  valu = None if 'valu' not in issue else wps * issue['valu']
+  return {'bound': 'valu', 'achieved': valu, 'peak': 1.0, 'frac': valu,
+          'unit': 'share of SIMD cycles issuing a VALU instruction (waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)',
+          'waves_per_simd': wps, 'per_wave': {'valu': issue.get('valu'), 'lds': issue.get('lds'), 'scalar': issue.get('scalar'),
+                                              'wait_s_waitcnt': issue.get('wait_any'), 'issue_stall': issue.get('wait_inst'), 'any_issue': issue.get('issue_any')},
+          'lane_occupancy': issue.get('lane_occupancy'),
+          'source': (prof.get('source', '') + ' (static: SQ counters collected by rocprofv3 --pmc in separate runs of this workload, not measured in this run)') if issue else None,
+          'kernel': kernel, 'kernel_ms_mean': gpu_ms, 'hbm': hbm}
 
 
 def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door', n=8192, reps=3):
@@ -349,26 +368,17 @@ def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8
   per_launch = n * (T * bytes_per_env_step + state_row + 7 * 8 + 4 + 14 * 8)
   achieved = per_launch / (gpu_ms * 1e-3) / 1e9
   prof = sawyer_profile(workload, n, T)
-  issue = prof.get('issue') or {}
-  simd_issue = None if not issue else min(1.0, (prof.get('waves_per_simd') or 1) * issue['issue_any'])
+  roof = pipe_roofline(prof, 'sawyer_rollout_kernel', gpu_ms,
+                       hbm={'achieved_GBs': achieved, 'frac_of_8TBs': achieved / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': per_launch,
+                            'bytes_per_env_step': bytes_per_env_step, 'traffic': prof.get('hbm_bytes_per_launch'),
+                            'traffic_source': (prof.get('source', '') + ' (static)') if prof else None})
   res = {'value': steps * n * T * world / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
          'kernel_ms': gpu_ms, 'timesteps_per_s': steps * n * T * world * 5 / dt, 'diverged_env_steps_last_rollout': diverged,
          'config': {'workload': f'{workload} {a.reward} reward, {n} batched envs per MI355X, reset + fused {T}-step rollout '
                                 f'(5 timesteps per env step) per bench step; own stepper incl. contacts, parity with MuJoCo unpinned',
                     'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
                     'parallelism': f'env-range shard x{world}, no per-step collective'},
-         # the bound of this kernel is instruction issue, not HBM: the roofline is the share of a SIMD's cycles in which it issues an instruction =
-         # resident waves per SIMD x the share of a wave's cycles that issue (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES), peak 1.0
-         'issue_frac': simd_issue,
-         'roofline': {'bound': 'issue', 'achieved': simd_issue, 'peak': 1.0, 'unit': 'share of SIMD cycles issuing an instruction (waves per SIMD x '
-                      'SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES)', 'frac': simd_issue, 'per_wave_issue': issue.get('issue_any'), 'valu': issue.get('valu'),
-                      'lds': issue.get('lds'), 'scalar': issue.get('scalar'), 'wait': issue.get('wait_any'), 'issue_stall': issue.get('wait_inst'),
-                      'waves_per_simd': prof.get('waves_per_simd'),
-                      'source': (prof.get('source', '') + ' (static: SQ counters collected by rocprofv3 --pmc in separate runs of this command)') if issue else None,
-                      'kernel': 'sawyer_rollout_kernel', 'kernel_ms_mean': gpu_ms,
-                      'hbm': {'achieved_GBs': achieved, 'frac_of_8TBs': achieved / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': per_launch,
-                              'bytes_per_env_step': bytes_per_env_step, 'traffic': prof.get('hbm_bytes_per_launch'),
-                              'traffic_source': (prof.get('source', '') + ' (static)') if prof else None}},
+         'valu_frac': roof['frac'], 'roofline': roof,
          'cpu_baseline': None if cpu_seconds is None else sawyer_cpu_baseline(T, cpu_seconds, workload, n=n)}
   del env, acts, out
   torch.cuda.empty_cache()
@@ -482,14 +492,9 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
   tpath = os.path.join(REPO, 'profiles', 'traffic.json')
   if os.path.exists(tpath) and (n_global, T, world) == (2048, 400, 1):
     prof = json.load(open(tpath)).get('kitchen', {})
-  issue = prof.get('issue') or {}
-  simd_issue = None if not issue else min(1.0, (prof.get('waves_per_simd') or 1) * issue['issue_any'])
+  roof = pipe_roofline(prof, 'kitchen_rollout_kernel', clk.elapsed_ms() / steps)
   return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
-          'issue_frac': simd_issue,
-          'roofline': {'bound': 'issue', 'achieved': simd_issue, 'peak': 1.0, 'unit': 'share of SIMD cycles issuing an instruction (waves per SIMD x '
-                       'SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES) of kitchen_rollout_kernel', 'frac': simd_issue, 'valu': issue.get('valu'), 'lds': issue.get('lds'),
-                       'scalar': issue.get('scalar'), 'wait': issue.get('wait_any'), 'waves_per_simd': prof.get('waves_per_simd'),
-                       'source': (prof.get('source', '') + ' (static: SQ counters collected by rocprofv3 --pmc in separate runs of this workload)') if issue else None},
+          'valu_frac': roof['frac'], 'roofline': roof,
           'timesteps_per_s': steps * n_global * T * 40 / dt, 'gpu_ms_per_env_step': clk.elapsed_ms() / (steps * T), 'scaling': 'strong',
           'diverged_env_steps': fails,
           'step_api': {'value': n * T / dt_step, 'unit': 'env-steps/s (this rank)', 'ms_per_env_step': dt_step / T * 1e3,
@@ -509,7 +514,7 @@ def main_sawyer(a, torch, dist, world, rank, device):
     res = {'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': a.steps,
            'warmup': a.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
            'data': 'synthetic', 'config': r['config'], 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline'],
-           'kernel_ms': r['kernel_ms'], 'issue_frac': r['issue_frac'], 'diverged_env_steps_last_rollout': r['diverged_env_steps_last_rollout']}
+           'kernel_ms': r['kernel_ms'], 'valu_frac': r['valu_frac'], 'diverged_env_steps_last_rollout': r['diverged_env_steps_last_rollout']}
     print(json.dumps(res), flush=True)
   if world > 1:
     dist.barrier()
@@ -537,7 +542,7 @@ def main():
   if a.workload in ('sawyer_door', 'sawyer_peg'):
     return main_sawyer(a, torch, dist, world, rank, device)
   if a.workload == 'kitchen':
-    r = run_kitchen(a, torch, dist, world, rank, device, a.steps if a.steps != 196 else 3, min(a.warmup, 1), cpu_seconds=None if a.no_cpu else 5.0)
+    r = run_kitchen(a, torch, dist, world, rank, device, min(a.steps, 3), min(a.warmup, 1), cpu_seconds=None if a.no_cpu else 5.0)
     if rank == 0:
       print(json.dumps({'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world,
                         'steps': r['steps'], 'warmup': r['warmup'], 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
@@ -548,78 +553,88 @@ def main():
       dist.destroy_process_group()
     return
   n, T = a.envs, a.horizon
+  E = max(1, a.episodes_per_launch)
+  wgs = (n + 63) // 64
+  in_flight = min(E, max(1, 256 // wgs)) if (E > 1 and wgs * 2 <= 256) else 1     # csrc/tabletop.hip do_rollout: episode groups side by side
 
   env = make_env(torch, n, T, a.reward, rank, device)
-  acts = synth_actions(torch, T, n, rank, device)
-  E = max(1, a.episodes_per_launch)
+  acts = synth_actions(torch, T, n, rank, device, E)          # [E, T, n, 3]: every episode of a launch has its own actions
+  acts1 = acts[0] if E > 1 else acts
   out = alloc_out(torch, T, n, device, E)
-  dt, kern_ms, gathered, _, launches = time_rollouts(torch, dist, env, acts, out, a.steps, a.warmup, world, device, episodes_per_launch=E)
+  dt, kern_ms, gathered, _, launches = time_rollouts(torch, dist, env, acts, out, a.steps, a.warmup, world, device)
   if world > 1:
     assert gathered.shape == (n * world, 2)
+  dn = out[2] if E > 1 else out[2][None]
+  assert bool(dn[:, -1].all()) and not bool(dn[:, :-1].any())        # done fires exactly at the horizon, in every episode
+  if E > 1:
+    assert not torch.equal(out[0][0], out[0][-1])                     # distinct actions -> distinct episodes
   single = None
-  if E > 1 and not a.no_single:      # the same episodes, one launch each (round 1's bench step), for continuity: K / 4 of them
+  if E > 1 and not a.no_single:      # the same episodes, ONE per launch (round 1's bench step): the latency-bound regime of a 4096-env batch
     o1 = alloc_out(torch, T, n, device, 1)
-    sdt, skm, _, _, sl = time_rollouts(torch, dist, env, acts, o1, max(8, a.steps // 4), 4, world, device, episodes_per_launch=1)
-    single = {'value': max(8, a.steps // 4) * n * T * world / sdt, 'unit': 'env-steps/s', 'kernel_ms_mean': skm[0], 'launches': sl,
+    ks = max(8, a.steps * 2)
+    sdt, skm, _, _, sl = time_rollouts(torch, dist, env, acts1, o1, ks, 4, world, device)
+    single = {'value': ks * n * T * world / sdt, 'unit': 'env-steps/s', 'kernel_ms_mean': skm[0], 'launches': sl,
+              'frac_of_8TBs': n * (T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH) / (skm[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
               'note': 'one evaluation episode per launch (earl_tabletop_reset_rollout): what round 1 timed'}
+    del o1
   sequential = None
-  if E > 1 and not a.no_single and (n + 63) // 64 * 2 <= 256:      # the same multi-episode launches with the episodes ONE AFTER THE OTHER (debug switch 38)
+  if E > 1 and not a.no_single and in_flight > 1:      # the same multi-episode launches with the episodes ONE AFTER THE OTHER (debug switch 38)
     from earl_benchmark_amd import _abi as _abi_
     lib_ = _abi_.load()
     lib_.earl_debug_set_rollout_impl(38)
     try:
-      ks = max(E, (a.steps // 2 // E) * E)
-      qdt, qkm, _, _, ql = time_rollouts(torch, dist, env, acts, out, ks, E, world, device, episodes_per_launch=E)
+      ks = max(2, a.steps // 2)
+      qdt, qkm, _, _, ql = time_rollouts(torch, dist, env, acts, out, ks, 1, world, device)
     finally:
       lib_.earl_debug_set_rollout_impl(0)
-    sequential = {'value': ks * n * T * world / qdt, 'unit': 'env-steps/s', 'kernel_ms_mean': qkm[0], 'launches': ql,
-                  'note': f'{E} evaluation episodes per launch, one after the other on the batch\'s 64 workgroups (what the line reported before episodes ran side by side)'}
-  total_env_steps = a.steps * n * T * world
+    sequential = {'value': ks * E * n * T * world / qdt, 'unit': 'env-steps/s', 'kernel_ms_mean': qkm[0], 'launches': ql,
+                  'frac_of_8TBs': n * (E * T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH) / (qkm[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  'note': f'the same launches ({E} evaluation episodes each, own actions) with ONE episode in flight per env: the episodes of a launch one '
+                          'after the other on the batch\'s 64 workgroups -- the reference\'s evaluation loop taken literally'}
+  total_env_steps = a.steps * E * n * T * world
   value = total_env_steps / dt
-  dn = out[2] if E > 1 else out[2][None]
-  dn = dn[:(E if a.steps >= E else a.steps)]                         # (fewer steps than episodes per launch: the one launch wrote the first `steps` episodes only)
-  assert bool(dn[:, -1].all()) and not bool(dn[:, :-1].any())        # done fires exactly at the horizon, in every episode
 
   # BASELINE configs[2] in the same run (every rank takes part: same barrier / max-over-ranks timing; the CPU legs at N = 1 only)
   sawyer = {}
   if not a.no_sawyer:
     for w in ('sawyer_door', 'sawyer_peg'):
-      sawyer[w] = run_sawyer(a, torch, dist, world, rank, device, w, steps=max(3, a.steps // 20), warmup=2,
+      sawyer[w] = run_sawyer(a, torch, dist, world, rank, device, w, steps=3, warmup=2,
                              cpu_seconds=None if (a.no_cpu or world > 1) else a.sawyer_cpu_seconds)
   if not a.no_kitchen:      # BASELINE configs[3] in the same run (2048 envs in total, sharded over the ranks)
     sawyer['kitchen'] = run_kitchen(a, torch, dist, world, rank, device, steps=2, warmup=1, cpu_seconds=None if (a.no_cpu or world > 1) else 2.0)
   res = None
   if rank == 0:
     kmean = sum(kern_ms) / len(kern_ms)
-    kmed = kern_ms[len(kern_ms) // 2]
-    # algorithmic bytes of the average launch: its episodes x (actions in, obs / reward / flags out) + the state once
-    bytes_per_launch = n * (a.steps / launches * T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH)
+    # algorithmic bytes of a launch = bytes that cross the HBM interface: its E episodes x T steps x (12 B of actions in -- each episode
+    # has its own --, obs 48 + reward 4 + done 1 + success 1 out) + the env state once (66 B per env-step fused)
+    bytes_per_launch = n * (E * T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH)
     achieved = bytes_per_launch / (kmean * 1e-3) / 1e9
     traffic, traffic_source = None, None
     tpath = os.path.join(REPO, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
       tj = json.load(open(tpath))
-      key = f'rollout_n{n}_T{T}' + (f'_E{E}' if E > 1 else '')
+      key = f'eval_n{n}_T{T}_E{E}_own_actions' if E > 1 else f'rollout_n{n}_T{T}'
       traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
       if traffic is not None:
-        traffic = traffic * (a.steps / launches) / E       # (the profiled launches hold E episodes each; this run's average launch may hold fewer)
-        traffic_source = f"profiles/traffic.json <- {tj[key].get('source')} (static: FETCH_SIZE / WRITE_SIZE passes of rocprofv3 --pmc over this command, not measured in this run)"
+        traffic_source = f"profiles/traffic.json <- {tj[key].get('source')} (static: FETCH_SIZE / WRITE_SIZE passes of rocprofv3 --pmc over this command -- same launch shape --, not measured in this run)"
+    strict = {'one_episode_in_flight': None if sequential is None else sequential['value'],
+              'one_episode_in_flight_frac': None if sequential is None else sequential['frac_of_8TBs'],
+              'one_episode_per_launch': None if single is None else single['value']}
     res = {
         'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': value, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'tabletop_manipulation {a.reward} reward, {n} batched envs per MI355X, '
-                               f'reset + fused {T}-step rollout per bench step' + (f', up to {E} bench steps (evaluation episodes) per kernel launch, '
-                               f'{min(min(E, a.steps), max(1, 256 // ((n + 63) // 64)))} of them in flight at a time (episodes are independent: each starts with reset(); '
-                               'a 4096-env batch is 64 workgroups on 256 CUs)' if E > 1 else ''),
-                   'envs_per_gpu': n, 'episodes_per_launch': E, 'episodes_in_flight': (min(min(E, a.steps), max(1, 256 // ((n + 63) // 64))) if E > 1 and (n + 63) // 64 * 2 <= 256 else 1),
-                   'launches': launches,
-                   'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': n * T * world,
+        'config': {'workload': f'tabletop_manipulation {a.reward}, {n} envs/GPU; bench step = 1 launch = {E} eval episodes (reset+{T} steps), own actions',
+                   'envs_per_gpu': n, 'episodes_per_bench_step': E, 'episodes_in_flight': in_flight, 'env_instances_resident': n * in_flight,
+                   'strict': strict, 'launches': launches, 'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': E * n * T * world,
+                   'actions': f'[{E}, {T}, {n}, 3] f32 per GPU, distinct per episode (act_episode_stride = T*n*3)',
+                   'next_rows': {k: (v or {}).get('value') for k, v in sawyer.items()},
                    'parallelism': f'env-range shard x{world}, no per-step collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source, 'kernel': 'rollout_ws_kernel',
-                     'kernel_ms_mean': kmean, 'kernel_ms_median': kmed, 'algorithmic_bytes_per_launch': bytes_per_launch,
-                     'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT, 'episodes_per_launch': a.steps / launches, 'launches': launches},
+                     'kernel_ms_mean': kmean, 'algorithmic_bytes_per_launch': bytes_per_launch,
+                     'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT, 'episodes_per_launch': E, 'launches': launches,
+                     'strict_frac': strict['one_episode_in_flight_frac']},
     }
     if single is not None:
       res['single_episode_launch'] = single
@@ -627,10 +642,10 @@ def main():
       res['sequential_episodes'] = sequential
     if not a.no_step_api:
       env2 = make_env(torch, n, T, a.reward, rank, device)
-      ks = max(1, a.steps // 20)
+      ks = max(1, a.steps // 10)
 
       def leg(graph):
-        sdt, sgpu = time_step_api(torch, env2, acts, ks, a.warmup, graph=graph)
+        sdt, sgpu = time_step_api(torch, env2, acts1, ks, a.warmup, graph=graph)
         return {'value': ks * n * T / sdt, 'unit': 'env-steps/s', 'launches': ks * T, 'us_per_step_call_wall': sdt / (ks * T) * 1e6,
                 'us_per_step_call_gpu': sgpu / (ks * T) * 1e6, 'achieved_GBs': n * BYTES_PER_ENV_STEP_STEP / (sgpu / (ks * T)) / 1e9}
       res['step_api'] = leg(True)

@@ -346,6 +346,19 @@ int launched(const char* what) {
   return EARL_OK;
 }
 
+// compute units of the current device (MI355X: 256), asked once per device: the launch geometry of the fused rollout (episode groups side by
+// side, 16-step chunks while every workgroup has a CU to itself) follows the chip, not a constant
+int cu_count() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int v = 0;
+    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cus[dev];
+}
+
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 template <int NOBJ>
@@ -390,8 +403,9 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
       // Evaluation episodes are independent of one another (each starts with reset()): when the env batch does not fill the chip -- 4096 envs are
       // 64 workgroups on 256 CUs -- several of them run side by side, each group of episodes on its own workgroups (WsArgs::ep_groups).  Same
       // outputs, same final state as the sequence.  impl 38 forces the sequence (one group) for comparison.
-      if (episodes > 1 && reset_first && g_rollout_impl != 38 && grid.x * 2 <= 256) {
-        const int P = (int)(256 / grid.x) < episodes ? (int)(256 / grid.x) : episodes;     // (eight groups, two workgroups per CU: no faster -- HBM-bound)
+      const unsigned cus = (unsigned)cu_count();
+      if (episodes > 1 && reset_first && g_rollout_impl != 38 && grid.x * 2 <= cus) {
+        const int P = (int)(cus / grid.x) < episodes ? (int)(cus / grid.x) : episodes;     // (eight groups, two workgroups per CU: no faster -- HBM-bound)
         w.ep_per_group = (episodes + P - 1) / P;
         w.ep_groups = (episodes + w.ep_per_group - 1) / w.ep_per_group;
         grid.x *= (unsigned)w.ep_groups;
@@ -444,20 +458,20 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
               // 16-step chunks (two 8-step granules; an episode may end between them) when every workgroup has a CU to itself: the per-chunk costs
               // -- barrier, action fetch, loop -- are paid half as often (105 -> 99 ns per step at N = 4096); 152 KB of LDS, so larger grids keep
               // the 8-step chunks (77 KB, two workgroups per CU).  impl 36 forces the 8-step form for comparison.
-              if (grid.x <= 256 && Tep >= 32 && g_rollout_impl != 36) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 16, 2);
-              else if (grid.x <= 256) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
+              if (grid.x <= cus && Tep >= 32 && g_rollout_impl != 36) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 16, 2);
+              else if (grid.x <= cus) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
               else EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
-            } else if (grid.x <= 256) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);     // (one episode per launch: 16-step chunks lengthen the pipeline's fill by
+            } else if (grid.x <= cus) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);     // (one episode per launch: 16-step chunks lengthen the pipeline's fill by
                                                                                       // as much as they save over 200 steps: 27.9 against 27.3 us)
             else EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
             break;
         }
       } else {
         if (episodes > 1) {
-          if (grid.x <= 256 && Tep >= 32) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 16, 2);
-          else if (grid.x <= 256) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
+          if (grid.x <= cus && Tep >= 32) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 16, 2);
+          else if (grid.x <= cus) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
           else EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
-        } else if (grid.x <= 256) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
+        } else if (grid.x <= cus) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
         else EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
       }
 #undef EARL_WS

@@ -68,7 +68,11 @@ class Kitchen:
     self._fused_step = True            # step() through earl_kitchen_rollout(T = 1); False: through earl_kitchen_step (the per-step C entry point, kept and tested)
     self.sensor_noise = bool(sensor_noise)
     self._params = glue.kitchen_params()
-    self._initial_states = tables.initial_states('kitchen')                     # kitchen.py:57-85, the 6 'all_pairs' rows
+    self._initial_states = tables.initial_states('kitchen')                     # kitchen.py:57-85, the 6 'all_pairs' rows (get_init_states, :103-104)
+    try:                                                                          # reset_model reads initial_states[task] (:122-126): the four single-fixture
+      self._task_rows = np.atleast_2d(tables.get(f'kitchen_task_{task}'))       # tasks, the six pairs and 'all_pairs' (tables.npz, from the reference module)
+    except KeyError:
+      raise KeyError(f'kitchen task {task!r}: the reference defines ' + ', '.join(tables.kitchen_tasks())) from None
     self._goal_states = tables.goal_states('kitchen')
     with torch.cuda.device(dev):
       self.model = physics.DeviceModel('kitchen', device=dev, contacts=contacts)
@@ -127,7 +131,7 @@ class Kitchen:
     positions, clipped to the position bounds; qvel <- 0), mocap <- midpoint, then ten robot steps of zero action = 400 timesteps.  Those
     steps are deterministic: their position targets are the cached robot joints 0 and 1 clamped to the finger actuators' ctrlrange [0, 0.04]
     (the nu = 2 quirk), i.e. 0.04 and 0 whatever the sensor noise -- so the result is computed once per row and cached."""
-    rows = self._initial_states if self._task == 'all_pairs' else self._initial_states[:1]
+    rows = self._task_rows                      # kitchen.py:122-126: a draw over the six 'all_pairs' rows, or the ONE row of a named task
     kw = dict(dtype=torch.float64, device=self.device)
     pb = np.ctypeslib.as_array(self._params.pos_bound)
     q = np.tile(INIT_QPOS, (len(rows), 1))

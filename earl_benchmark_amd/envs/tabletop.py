@@ -256,6 +256,8 @@ class TabletopManipulation:
           raise ValueError(f'episodes = {episodes} but actions hold {E}')
         act, stride = self._actions(a, (E, T, self.num_envs)), T * self.num_envs * 3
       else:
+        if episodes is None:
+          raise ValueError('rollout_episodes: actions [T, N, 3] are replayed by every episode -- say how many (episodes=E), or pass [E, T, N, 3]')
         E, T = int(episodes), int(a.shape[0])
         act, stride = self._actions(a, (T, self.num_envs)), 0
       if out is None:

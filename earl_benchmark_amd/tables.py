@@ -30,3 +30,8 @@ def goal_states(env_name):
 
 def get(name):
   return _tables()[name].copy()
+
+
+def kitchen_tasks():
+  """task names of Kitchen(task=...) (reference: envs/kitchen.py:57-85, the keys of `initial_states`)"""
+  return sorted(k[len('kitchen_task_'):] for k in _tables() if k.startswith('kitchen_task_'))

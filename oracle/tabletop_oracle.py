@@ -29,8 +29,12 @@ def build(force=False):
 def lib():
   global _lib
   if _lib is None:
-    build()
-    _lib = C.CDLL(SO)
+    alt = os.environ.get('EARL_ORACLE_SO')      # `make -C oracle asan-test`: the AddressSanitizer / UBSan build of the same sources
+    if alt:
+      _lib = C.CDLL(alt)
+    else:
+      build()
+      _lib = C.CDLL(SO)
   return _lib
 
 

@@ -112,6 +112,22 @@ class HipTabletop:
     self.cfg.counter += T + (1 if reset_first else 0)
     return tuple(x.cpu().numpy() for x in arrs)
 
+  def eval_episodes(self, act, episodes=None):
+    """earl_tabletop_eval_episodes: act [E, T, n, 3] (distinct per-episode actions) or [T, n, 3] + episodes (replayed).
+    -> device tensors (obs [E,T,n,12], reward, done, success); the caller copies the episodes it compares"""
+    a = act if isinstance(act, torch.Tensor) else self._dev(act, torch.float32)
+    if a.dim() == 4:
+      E, T, stride = int(a.shape[0]), int(a.shape[1]), int(a.shape[1]) * self.n * 3
+    else:
+      E, T, stride = int(episodes), int(a.shape[0]), 0
+    assert a.shape[-2:] == (self.n, 3) and a.is_contiguous() and a.dtype == torch.float32
+    arrs, out = self._outs((E, T, self.n))
+    st = self._state()
+    rc = self.lib.earl_tabletop_eval_episodes(C.byref(self.cfg), C.byref(st), E, T, _ptr(a), stride, C.byref(out), self.stream)
+    self._ok(rc, 'eval_episodes')
+    self.cfg.counter += E * (T + 1)
+    return arrs
+
   def observe(self):
     arrs, out = self._outs((self.n,))
     st = self._state()

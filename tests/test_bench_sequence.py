@@ -26,9 +26,9 @@ def _free_port():
     return s.getsockname()[1]
 
 
-def synthetic(T, lo, n):
-  """what the stub 'kernel' writes for global envs [lo, lo + n): obs, reward, done, success"""
-  gid = torch.arange(lo, lo + n, dtype=torch.float32)
+def synthetic(T, lo, n, shift=0):
+  """what the stub 'kernel' writes for global envs [lo, lo + n): obs, reward, done, success (`shift`: a different table per episode)"""
+  gid = torch.arange(lo, lo + n, dtype=torch.float32) + 1000.0 * shift
   t = torch.arange(T, dtype=torch.float32)[:, None]
   obs = (gid[None, :, None] * 0.5 + t[..., None] + torch.arange(12, dtype=torch.float32) * 0.25).contiguous()
   reward = ((gid[None, :] + t) % 3 == 0).to(torch.float32)
@@ -67,17 +67,21 @@ class ValidatorEnv:
     time.sleep(self.delay)
 
 
-  def rollout_episodes(self, acts, episodes, out):
-    assert acts.shape == (self.T, self.n, 3) and all(t.shape[0] == episodes for t in out)
+  def rollout_episodes(self, acts, out, episodes=None):
+    E = acts.shape[0]
+    assert acts.shape == (E, self.T, self.n, 3) and acts.is_contiguous() and all(t.shape[0] == E for t in out) and episodes in (None, E)
+    assert not torch.equal(acts[0], acts[-1])                      # every episode of the launch has its own actions
     o = self._abi.TabletopOut(*(t.data_ptr() for t in out))
-    rc = self.lib.earl_tabletop_eval_episodes(C.byref(self.cfg), C.byref(self.st), episodes, self.T, acts.data_ptr(), 0, C.byref(o), None)
+    stride = self.T * self.n * 3
+    rc = self.lib.earl_tabletop_eval_episodes(C.byref(self.cfg), C.byref(self.st), E, self.T, acts.data_ptr(), stride, C.byref(o), None)
     self._abi.check(rc, 'earl_tabletop_eval_episodes (argument validation)')
-    assert self.lib.earl_tabletop_eval_episodes(C.byref(self.cfg), C.byref(self.st), -1, self.T, acts.data_ptr(), 0, C.byref(o), None) != 0
-    for e in range(episodes):
-      for dst, src in zip(out, synthetic(self.T, self.lo, self.n)):
+    assert self.lib.earl_tabletop_eval_episodes(C.byref(self.cfg), C.byref(self.st), -1, self.T, acts.data_ptr(), stride, C.byref(o), None) != 0
+    assert self.lib.earl_tabletop_eval_episodes(C.byref(self.cfg), C.byref(self.st), E, self.T, acts.data_ptr(), -1, C.byref(o), None) != 0
+    for e in range(E):                                             # episode e's rows: the synthetic table shifted by e (the LAST one is gathered)
+      for dst, src in zip(out, synthetic(self.T, self.lo, self.n, shift=E - 1 - e)):
         dst[e].copy_(src)
     self.launches += 1
-    self.episodes = getattr(self, 'episodes', 0) + episodes
+    self.episodes = getattr(self, 'episodes', 0) + E
     time.sleep(self.delay)
 
 
@@ -89,12 +93,11 @@ def _worker(rank, world, port, n, T, steps, warmup, out_dir, E=1):
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
     env = ValidatorEnv(n, T, rank * n, delay=0.02 * (rank + 1))        # rank 1 is the slow one: the job time is ITS time
-    acts = bench.synth_actions(torch, T, n, rank, 'cpu')
+    acts = bench.synth_actions(torch, T, n, rank, 'cpu', E)          # [E, T, n, 3] distinct per episode (E > 1), as bench.main() feeds it
     out = bench.alloc_out(torch, T, n, 'cpu', E)
-    dt, kern_ms, table, traj, launches = bench.time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cpu', gather_rollout=True,
-                                                             episodes_per_launch=E)
-    assert launches == -(-steps // E) and env.launches == launches + -(-warmup // E)
-    assert E == 1 or env.episodes == steps + warmup
+    dt, kern_ms, table, traj, launches = bench.time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cpu', gather_rollout=True)
+    assert launches == steps and env.launches == steps + warmup       # a bench step is ONE launch, whatever E
+    assert E == 1 or env.episodes == (steps + warmup) * E
     np.save(os.path.join(out_dir, f'table_{rank}.npy'), table.numpy())
     np.save(os.path.join(out_dir, f'traj_{rank}.npy'), traj.numpy())
     json.dump({'dt': dt, 'kern_ms': kern_ms}, open(os.path.join(out_dir, f'time_{rank}.json'), 'w'))
@@ -102,7 +105,7 @@ def _worker(rank, world, port, n, T, steps, warmup, out_dir, E=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('E', [1, 2])
+@pytest.mark.parametrize('E', [1, 3])
 def test_two_rank_bench_sequence(tmp_path, E):
   from earl_benchmark_amd import sharding
   world, n, T, steps, warmup = 2, 48, 7, 3, 2
@@ -115,7 +118,7 @@ def test_two_rank_bench_sequence(tmp_path, E):
     o, rw, d, s = sharding.unpack_rollout(torch.from_numpy(np.load(tmp_path / f'traj_{r}.npy')))
     assert o.shape == (T, world * n, 12)
     assert torch.equal(o, obs) and torch.equal(rw, reward) and torch.equal(d, done) and torch.equal(s, success)
-  assert times[0]['dt'] == times[1]['dt'] >= -(-steps // E) * 0.04                                  # MAX over ranks: the slow rank's time, on both
+  assert times[0]['dt'] == times[1]['dt'] >= steps * 0.04                                  # MAX over ranks: the slow rank's time, on both
   assert times[0]['kern_ms'][0] < times[1]['kern_ms'][0]                                   # ... while the per-rank launch clock stays local
 
 

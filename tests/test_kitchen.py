@@ -185,3 +185,25 @@ def test_c_restatement_matches_the_numpy_statement(lm):
     for _ in range(40):                                      # one call = one env step: its first timestep starts the active-set iteration cold
       qq, vv, out = lm.step(qq, vv, ctrl[i], mp[i], mq[i], None if out is None else out['qacc'])
     np.testing.assert_allclose(r2['qpos'][i], qq, atol=1e-12); np.testing.assert_allclose(r2['qvel'][i], vv, atol=1e-11)
+
+
+def test_task_rows_follow_the_references_rule():
+  """tables.npz `kitchen_task_*` (recorded from the reference module by tests/golden/make_golden.py): every named task is the clean goal
+  state with its components overwritten (kitchen.py:57-85, convert_to_initial_state), and 'all_pairs' stacks the six pair rows in order"""
+  from earl_benchmark_amd import tables
+  goal = tables.goal_states('kitchen')[0]
+  comp = {'microwave': ([22], [-0.7]), 'light_switch': ([17, 18], [-0.69, -0.05]), 'slide_cabinet': ([19], [0.37]), 'hinge_cabinet': ([20, 21], [0., 1.45])}
+  short = {'micro': 'microwave', 'light': 'light_switch', 'slide': 'slide_cabinet', 'hinge': 'hinge_cabinet'}
+  assert tables.kitchen_tasks() == sorted(list(comp) + ['micro_hinge', 'micro_slide', 'micro_light', 'light_slide', 'light_hinge', 'slide_hinge', 'all_pairs'])
+  for task in tables.kitchen_tasks():
+    rows = tables.get(f'kitchen_task_{task}')
+    if task == 'all_pairs':
+      want = np.stack([tables.get(f'kitchen_task_{t}')[0] for t in ('micro_hinge', 'micro_slide', 'micro_light', 'light_slide', 'light_hinge', 'slide_hinge')])
+      np.testing.assert_array_equal(rows, want)
+      np.testing.assert_array_equal(rows, tables.initial_states('kitchen'))
+      continue
+    want = goal.copy()
+    for part in ([task] if task in comp else [short[p] for p in task.split('_')]):
+      want[comp[part][0]] = comp[part][1]
+    assert rows.shape == (1, 23)
+    np.testing.assert_array_equal(rows[0], want)

@@ -125,6 +125,28 @@ def test_loader_reset_recipe_noise_and_wrappers():
   assert bool((oa == ob).all())
 
 
+@pytest.mark.parametrize('task', ['microwave', 'light_switch', 'slide_cabinet', 'hinge_cabinet', 'light_slide'])
+def test_reset_of_a_named_task_moves_only_that_tasks_fixtures(task):
+  """Kitchen(task=...).reset_model (kitchen.py:122-126): `reset_pos[9:] = initial_states[task][9:]` -- the one row of the named task, not a
+  draw over the 'all_pairs' table ('microwave' used to reset to micro_hinge).  Checked on the fixture joints after the settle."""
+  import torch
+  import earl_benchmark_amd as eb
+  from earl_benchmark_amd import tables
+  L = eb.EARLEnvs('kitchen', reward_type='dense', num_envs=8, seed=3, kitchen_task=task, allow_unpinned_dynamics=True)
+  _, ev = L.get_envs()
+  u = ev.unwrapped
+  ev.reset()
+  row = torch.tensor(tables.get(f'kitchen_task_{task}')[0], device='cuda')
+  goal = torch.tensor(tables.goal_states('kitchen')[0], device='cuda')
+  moved = (row[9:] - goal[9:]).abs() > 1e-3                                       # the fixtures this task displaces from the clean goal state
+  assert int(moved.sum()) in (1, 2, 3, 4)
+  d = (u.qpos[:, 9:] - row[None, 9:]).abs()
+  assert float(d.max()) < 0.05                                                   # every env at the task's row (400 settle timesteps move fixtures by < 0.05)
+  assert float((u.qpos[:, 9:][:, ~moved] - goal[None, 9:][:, ~moved]).abs().max()) < 0.05   # ... and the other fixtures at their goal positions
+  with pytest.raises(KeyError, match='the reference defines'):
+    eb.EARLEnvs('kitchen', reward_type='dense', num_envs=2, kitchen_task='burner0', allow_unpinned_dynamics=True).get_envs()
+
+
 def test_full_size_soak_2048_envs_400_steps():
   """BASELINE configs[3] at size: 2048 envs, the reference's eval horizon (400 env steps = 16,000 timesteps), random actions"""
   import torch

@@ -71,3 +71,17 @@ def test_sawyer_sparse_rule_holds_on_the_demos():
     for demo in bare(name).get_demonstrations():
       o = demo['next_observations']
       assert ((np.linalg.norm(o[:, 4:7] - o[:, 11:14], axis=1) <= radius) == (demo['rewards'][:, 0] == 1)).all()
+
+
+def test_reference_import_name_works_unchanged():
+  """`import earl_benchmark` (reference README.md:21-31) resolves to this build: same loader, same tables, no GPU needed for them"""
+  import earl_benchmark
+  import earl_benchmark_amd
+  assert earl_benchmark.EARLEnvs is earl_benchmark_amd.EARLEnvs
+  assert earl_benchmark.deployment_eval_config is earl_benchmark_amd.deployment_eval_config
+  loader = earl_benchmark.EARLEnvs('tabletop_manipulation', reward_type='sparse')
+  assert loader.get_initial_states().shape == (1, 6) and loader.get_goal_states().shape == (4, 6)
+  fwd, rev = loader.get_demonstrations()
+  assert set(fwd) == set(rev) == {'observations', 'actions', 'rewards', 'terminals', 'next_observations', 'infos'}
+  assert earl_benchmark.wrappers.PersistentStateWrapper is earl_benchmark_amd.wrappers.PersistentStateWrapper
+  assert earl_benchmark.tables is earl_benchmark_amd.tables

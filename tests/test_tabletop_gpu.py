@@ -531,3 +531,45 @@ def test_eval_episodes_in_one_launch_equal_the_sequence_of_launches(n, T, E, kw)
     assert a._cfg.counter == b._cfg.counter and a.total_step_count == b.total_step_count
     assert bool(got[2][:, -1].all()) and not bool(got[2][:, :-1].any())            # done exactly at the last step of EVERY episode
   assert len(torch.unique(a.goal_idx)) > 1                                          # goals were re-drawn per env
+
+
+@pytest.mark.parametrize('n,T,E,kw', [
+    # the launches bench.py times (4096 envs = 64 workgroups -> four episode groups): default flags (28 = 4 x 7), the driver's
+    # --steps 20 (4 x 5), a ragged split (9 -> 3 groups x 3) and a small batch with many groups whose last one is short (37 -> 13 x 3, last 1)
+    (4096, 200, 28, {}), (4096, 200, 20, {}), (4096, 200, 9, {}), (1000, 40, 37, {}),
+    # same launch geometry through the other instantiations: dense reward, wide init, reset at goal, 8-step chunks (T < 32), two workgroups per group
+    (4096, 200, 10, {'reward_type': 'dense'}), (700, 48, 11, {'wide_init': True}), (333, 24, 10, {'reset_at_goal': True}), (8192, 56, 6, {})])
+def test_eval_episodes_groups_of_several_episodes_against_the_oracle(hx, orc, n, T, E, kw):
+  """The launch shape the bench times: earl_tabletop_eval_episodes with SEVERAL episode groups side by side AND several episodes per group
+  (csrc/tabletop.hip do_rollout: ep_groups > 1, ep_per_group > 1), every episode with its OWN actions -- compared episode by episode, bit for
+  bit, with the ORACLE walking the reference's evaluation loop (persistent_state_wrapper.py:17-31: reset(), then T steps) with the counters of
+  the sequence; final state and wrapper counters too."""
+  import torch
+  kw = dict({'reward_type': 'sparse'}, **kw)
+  base = dict(seed=31, env_offset=11, horizon=T, **kw)
+  o = orc.OracleTabletop(n, **base)
+  h = hx.HipTabletop(n, **base)
+  rng = np.random.default_rng(n + T + E)
+  o.qpos[:] = rng.uniform(-2.8, 2.8, size=o.qpos.shape)                      # a dirty state left by earlier use: every episode must start from its reset
+  o.attached[:] = rng.integers(-1, 1, size=n)
+  o.steps_since_reset[:] = rng.integers(0, T, size=n)
+  o.num_interventions[:] = rng.integers(0, 5, size=n)
+  o.cfg.counter = 1000
+  h.set_from(o)
+  g = torch.Generator(device='cuda').manual_seed(E * 1000 + T)
+  acts = (torch.rand(E, T, n, 3, generator=g, device='cuda') * 2 - 1).contiguous()
+  acts[..., 2] = acts[..., 2].abs() * (torch.rand(E, T, n, generator=g, device='cuda') > 0.15)     # mostly gripping: attach / carry / release
+  acts[..., :2] *= 1.0 + 2.0 * (torch.rand(E, T, n, 1, generator=g, device='cuda') > 0.9)          # some moves beyond the action box (clipped)
+  got = h.eval_episodes(acts)
+  dense = kw['reward_type'] == 'dense'
+  goals = set()
+  for e in range(E):                                                         # every episode, not a sample: the oracle walks 23 M env-steps in seconds
+    a = acts[e].cpu().numpy()
+    o.reset()
+    goals.update(np.unique(o.goal_idx).tolist())
+    want = o.rollout(a)
+    assert_same_out(tuple(x[e].cpu().numpy() for x in got), want, dense)
+    assert want[2][-1].all() and not want[2][:-1].any()                      # done exactly at the horizon, every episode
+  assert_same_state(o, h)
+  assert h.cfg.counter == o.cfg.counter
+  assert len(goals) == 4 and (E < 3 or not torch.equal(got[0][0], got[0][E - 1]))

@@ -10,7 +10,7 @@ rm -rf $OUT/prof_kitchen_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kitchen_stats -- python3 $ARGS > $OUT/prof_kitchen_stats.log 2>&1
 echo "stats rc=$?"; tail -1 $OUT/prof_kitchen_stats.log | cut -c1-160
 i=0
-for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT"; do
+for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES"; do
   i=$((i+1))
   rm -rf $OUT/prof_kitchen_pmc$i
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/prof_kitchen_pmc$i -- python3 $ARGS > $OUT/prof_kitchen_pmc$i.log 2>&1

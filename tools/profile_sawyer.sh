@@ -12,7 +12,7 @@ rm -rf $OUT/prof_${W}_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${W}_stats -- python3 $ARGS > $OUT/prof_${W}_stats.log 2>&1
 echo "stats rc=$?"; tail -1 $OUT/prof_${W}_stats.log | cut -c1-160
 i=0
-for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_VMEM_WR" "FETCH_SIZE" "WRITE_SIZE"; do   # the two HBM counters cannot share a pass on gfx950
+for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" "SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_VMEM_WR" "FETCH_SIZE" "WRITE_SIZE"; do   # the two HBM counters cannot share a pass on gfx950
   i=$((i+1))
   rm -rf $OUT/prof_${W}_pmc$i
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/prof_${W}_pmc$i -- python3 $ARGS > $OUT/prof_${W}_pmc$i.log 2>&1

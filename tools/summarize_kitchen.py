@@ -25,9 +25,13 @@ if 'SQ_WAVE_CYCLES' in c:
   wc = c['SQ_WAVE_CYCLES']
   res['derived'] = {k: c[n] / wc for k, n in (('issue_any', 'SQ_ACTIVE_INST_ANY'), ('wait_any', 'SQ_WAIT_ANY'), ('wait_inst', 'SQ_WAIT_INST_ANY'),
                                              ('valu', 'SQ_ACTIVE_INST_VALU'), ('lds', 'SQ_ACTIVE_INST_LDS'), ('scalar', 'SQ_ACTIVE_INST_SCA')) if n in c}
+if 'SQ_THREAD_CYCLES_VALU' in c and 'derived' in res:
+  # lanes active per VALU instruction / 64 (SQ_THREAD_CYCLES_VALU counts thread-cycles of VALU work; SQ_INSTS_VALU the instructions)
+  res['derived']['lane_occupancy'] = c['SQ_THREAD_CYCLES_VALU'] / (64.0 * max(c.get('SQ_ACTIVE_INST_VALU', 1.0), 1.0))
+  res['derived']['lane_occupancy_per_inst'] = c['SQ_THREAD_CYCLES_VALU'] / (64.0 * max(c.get('SQ_INSTS_VALU', 1.0), 1.0))
 json.dump(res, open(os.path.join(PROF, f'{tag}_kitchen_rollout_pmc.json'), 'w'), indent=1)
 tp = os.path.join(PROF, 'traffic.json')
 tj = json.load(open(tp)) if os.path.exists(tp) else {}
-tj['kitchen'] = {'source': f'profiles/{tag}_kitchen_step_pmc.json', 'rocprof_kernel_average_ns': float(kern['AverageNs']), 'issue': res.get('derived'), 'waves_per_simd': 1}
+tj['kitchen'] = {'source': f'profiles/{tag}_kitchen_rollout_pmc.json', 'rocprof_kernel_average_ns': float(kern['AverageNs']), 'issue': res.get('derived'), 'waves_per_simd': 1}
 json.dump(tj, open(tp, 'w'), indent=1)
 print(json.dumps(res, indent=1))

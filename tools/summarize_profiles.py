@@ -16,9 +16,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
 PROF = os.path.join(ROOT, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 n, T, E = 4096, 200, 28         # bench.py defaults: 28 evaluation episodes per launch (four groups of seven in flight)
-SUF = f'_E{E}' if E > 1 else ''
+SUF = f'_E{E}_own_actions' if E > 1 else ''
 os.makedirs(PROF, exist_ok=True)
 
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
@@ -41,20 +41,20 @@ fetch, write = pmc[rk]['FETCH_SIZE']['mean_KiB'], pmc[rk]['WRITE_SIZE']['mean_Ki
 hbm = (2 * fetch + write) * 1024
 algo = n * (E * T * 66 + 2 * (32 + 1 + 4) + 4)
 summary = {
-    'command': 'python3 bench.py --no-cpu --no-step-api --no-sawyer --no-kitchen --no-single  [defaults: --steps 196 --warmup 28 = 7 + 1 launches of 28 episodes]  (under rocprofv3, see tools/profile_bench.sh)',
+    'command': 'python3 bench.py --no-cpu --no-step-api --no-sawyer --no-kitchen --no-single  [defaults: --steps 20 --warmup 5 = 25 launches of 28 evaluation episodes each, every episode with its own actions: the launch shape does not depend on the flags]  (under rocprofv3, see tools/profile_bench.sh)',
     'kernel': rk,
     'kernel_trace_stats': {'calls': int(kern['Calls']), 'average_ns': float(kern['AverageNs']), 'min_ns': float(kern['MinNs']),
                            'max_ns': float(kern['MaxNs']), 'stddev_ns': float(kern['StdDev'])},
     'pmc': pmc,
     'corrections': 'HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE reads 1/2 for streaming loads)',
     'calibration': {'action_bytes_read_per_launch': n * T * 12 * E, 'FETCH_SIZE_x2_bytes': 2 * fetch * 1024,
-                    'note': 'the remaining read bytes are the fp64 state, goal rows and flags (<= 0.4 MB)'},
+                    'note': 'every episode of the launch reads its own actions (act_episode_stride = T*n*3); the remaining read bytes are the fp64 state, goal rows and flags (<= 0.4 MB)'},
     'hbm_bytes_per_launch': hbm, 'algorithmic_bytes_per_launch': algo, 'traffic_over_algorithmic': hbm / algo,
 }
 json.dump(summary, open(os.path.join(PROF, f'{tag}_bench_n{n}_T{T}{SUF}_pmc.json'), 'w'), indent=1)
 traffic_path = os.path.join(PROF, 'traffic.json')
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
-traffic[f'rollout_n{n}_T{T}{SUF}'] = {'hbm_bytes_per_launch': hbm, 'source': f'profiles/{tag}_bench_n{n}_T{T}{SUF}_pmc.json',
+traffic[f'eval_n{n}_T{T}{SUF}' if E > 1 else f'rollout_n{n}_T{T}'] = {'hbm_bytes_per_launch': hbm, 'source': f'profiles/{tag}_bench_n{n}_T{T}{SUF}_pmc.json',
                                  'rocprof_kernel_average_ns': float(kern['AverageNs'])}
 json.dump(traffic, open(traffic_path, 'w'), indent=1)
 print(json.dumps({k: summary[k] for k in ('kernel_trace_stats', 'hbm_bytes_per_launch', 'algorithmic_bytes_per_launch', 'traffic_over_algorithmic')}, indent=1))
