@@ -99,6 +99,7 @@ SIGNATURES = {
     'earl_tabletop3_reset': [_P(TabletopCfg), _P(TabletopState), C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_tabletop3_reward': [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_debug_set_rollout_impl': [C.c_int],
+    'earl_debug_set_rollout_wgs_per_cu': [C.c_int],
     'earl_debug_read_ws_profile': [C.c_void_p, C.c_int32],
     # include/earl_glue.h
     'earl_sawyer_sparse_f64': [C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p],

@@ -271,6 +271,7 @@ __global__ __launch_bounds__(kBlock) void valid_init_kernel(int n, const double*
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[512] = "";
 int g_rollout_lds_pad = 0;  // extra dynamic LDS per workgroup of the wave-specialised kernel (limits co-residency; tuning)
+int g_rollout_wgs_per_cu = 1;  // (tuning) workgroups per CU the episode groups of a multi-episode launch may fill
 int g_rollout_impl = 0;  // 0 = auto (wave-specialised when applicable), 1 = force the plain one-lane-per-env kernel
 
 int fail(int code, const char* fmt, ...) {
@@ -404,8 +405,9 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
       // 64 workgroups on 256 CUs -- several of them run side by side, each group of episodes on its own workgroups (WsArgs::ep_groups).  Same
       // outputs, same final state as the sequence.  impl 38 forces the sequence (one group) for comparison.
       const unsigned cus = (unsigned)cu_count();
-      if (episodes > 1 && reset_first && g_rollout_impl != 38 && grid.x * 2 <= cus) {
-        const int P = (int)(cus / grid.x) < episodes ? (int)(cus / grid.x) : episodes;     // (eight groups, two workgroups per CU: no faster -- HBM-bound)
+      if (episodes > 1 && reset_first && g_rollout_impl != 38 && grid.x * 2 <= cus * (unsigned)g_rollout_wgs_per_cu) {
+        const int slots = (int)(cus * (unsigned)g_rollout_wgs_per_cu / grid.x);
+        const int P = slots < episodes ? slots : episodes;     // (eight groups, two workgroups per CU: no faster -- HBM-bound)
         w.ep_per_group = (episodes + P - 1) / P;
         w.ep_groups = (episodes + w.ep_per_group - 1) / w.ep_per_group;
         grid.x *= (unsigned)w.ep_groups;
@@ -445,6 +447,16 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
             break;
           case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 4, 8, 3, true><<<grid, 64 * 10, 0, hs>>>(w); break;  // stamps
           case 19: rollout_ws_kernel<EARL_REWARD_SPARSE, 1, 4, 4, 8, 3, true><<<grid, 64 * 9, 0, hs>>>(w); break;  // stamps
+#define EARL_WSX(K, LEAD, NT) rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, K, LEAD, false, true, NT><<<grid, 64 * 12, g_rollout_lds_pad, hs>>>(w)
+          // experiments on the multi-episode launch with per-episode actions (tools/own_actions_experiment.py): prefetch depth, chunk length, nt loads
+          case 40: if (episodes > 1) { EARL_WSX(16, 3, false); break; } [[fallthrough]];
+          case 41: if (episodes > 1) { EARL_WSX(8, 3, false); break; } [[fallthrough]];
+          case 42: if (episodes > 1) { EARL_WSX(8, 4, false); break; } [[fallthrough]];
+          case 43: if (episodes > 1) { EARL_WSX(8, 6, false); break; } [[fallthrough]];
+          case 44: if (episodes > 1) { EARL_WSX(16, 2, true); break; } [[fallthrough]];
+          case 45: if (episodes > 1) { EARL_WSX(8, 3, true); break; } [[fallthrough]];
+          case 46: if (episodes > 1) { EARL_WSX(8, 2, false); break; } [[fallthrough]];
+#undef EARL_WSX
           case 36:
           case 38:
           default:
@@ -458,7 +470,9 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
               // 16-step chunks (two 8-step granules; an episode may end between them) when every workgroup has a CU to itself: the per-chunk costs
               // -- barrier, action fetch, loop -- are paid half as often (105 -> 99 ns per step at N = 4096); 152 KB of LDS, so larger grids keep
               // the 8-step chunks (77 KB, two workgroups per CU).  impl 36 forces the 8-step form for comparison.
-              if (grid.x <= cus && Tep >= 32 && g_rollout_impl != 36) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 16, 2);
+              // ... but only while ONE episode is in flight per env (latency-bound).  With several episode groups side by side the launch is
+              // HBM-bound and the 8-step chunks win (own actions per episode: 280-290 against 245-260 us per 28-episode launch).
+              if (grid.x <= cus && Tep >= 32 && g_rollout_impl != 36 && w.ep_groups == 1) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 16, 2);
               else if (grid.x <= cus) EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);
               else EARL_WSM(EARL_REWARD_SPARSE, 3, 2, 8, 8, 2);
             } else if (grid.x <= cus) EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3);     // (one episode per launch: 16-step chunks lengthen the pipeline's fill by
@@ -468,7 +482,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
         }
       } else {
         if (episodes > 1) {
-          if (grid.x <= cus && Tep >= 32) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 16, 2);
+          if (grid.x <= cus && Tep >= 32 && w.ep_groups == 1) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 16, 2);
           else if (grid.x <= cus) EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
           else EARL_WSM(EARL_REWARD_DENSE, 3, 2, 8, 8, 2);
         } else if (grid.x <= cus) EARL_WS(EARL_REWARD_DENSE, 3, 2, 8, 8, 3);
@@ -532,7 +546,7 @@ int earl_tabletop_eval_episodes(const earl_tabletop_cfg* cfg, const earl_tableto
   if (episodes == 0 || cfg->n == 0) return EARL_OK;
   const bool general = cfg->goal_change_frequency > 0 || cfg->auto_reset;
   // one launch walks all episodes when the wave-specialised kernel applies and episodes end on its chunk boundaries (8 steps)
-  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && (g_rollout_impl == 0 || g_rollout_impl == 29 || g_rollout_impl == 36 || g_rollout_impl == 38) &&
+  const bool fused = episodes > 1 && !general && out->obs && out->reward && out->done && out->success && (g_rollout_impl == 0 || g_rollout_impl == 29 || g_rollout_impl == 36 || g_rollout_impl == 38 || (g_rollout_impl >= 40 && g_rollout_impl <= 46)) &&
                      T % 8 == 0 && T >= 16 && (long long)episodes * T < (1 << 24);
   if (fused || episodes == 1) return do_rollout<1>(cfg, st, T, act, out, stream, true, episodes, (long long)act_episode_stride);
   for (int32_t e = 0; e < episodes; ++e) {          // otherwise: the same thing as `episodes` launches
@@ -595,6 +609,13 @@ int earl_debug_set_rollout_impl(int impl) {
   const int prev = g_rollout_impl + 1000 * (g_rollout_lds_pad / 1024);
   g_rollout_lds_pad = (impl / 1000) * 1024;        // thousands digit and up: KiB of LDS padding per workgroup
   g_rollout_impl = impl % 1000;
+  return prev;
+}
+
+/* tuning hook: workgroups per CU that the episode groups of earl_tabletop_eval_episodes may occupy (1 = shipped); returns the previous value */
+int earl_debug_set_rollout_wgs_per_cu(int k) {
+  const int prev = g_rollout_wgs_per_cu;
+  if (k >= 1 && k <= 4) g_rollout_wgs_per_cu = k;
   return prev;
 }
 

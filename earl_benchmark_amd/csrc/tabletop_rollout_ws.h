@@ -32,7 +32,32 @@
 #define EARL_WSM_OFF 0      // measurement only: bit 0 loaders, 1 storers, 2 compute waves ignore the episode structure of a multi-episode launch (WRONG results)
 #endif
 
+// Memory-policy switches of the HBM-bound regime (round 3; measured with every evaluation episode reading its OWN actions, i.e. all 66 B per
+// env-step crossing the HBM interface: 4096 envs x 200 steps x 28 episodes, four in flight, one MI355X, three repetitions on one box,
+// gpurun_out/own_actions_experiment3.txt; tools/build_ws_variant.sh builds tools/ubench/libearl_ws_<tag>.so with other settings):
+//   EARL_WS_SMALL_NT   (on)  reward / done / success rows are stored non-temporally like the observation rows: 312-326 -> 285-290 us per launch
+//                            with 16-step chunks, 288-298 -> 254-260 us with 8-step chunks.  As ordinary stores those 6 of the 54 written
+//                            bytes per env-step sat in the L2s as partial dirty lines beside the action reads.
+//   EARL_WS_XCD_REMAP  (on)  hardware workgroup b works on env block (b % 8) * (grid / 8) + b / 8: dispatch is round-robin over the 8 XCDs, so
+//                            the workgroups of one XCD now cover CONSECUTIVE env blocks and the two 64-byte halves of a done / success line
+//                            (64 envs each) meet in one L2: 254-260 -> 245-249 us (6.1-6.2 TB/s).
+//   EARL_WS_LD_AUX=<bits>    (off) actions through raw buffer loads with cache-policy bits (1 sc0, 2 nt, 16 sc1): sc1 no gain; nt loads help
+//                            only while the small stores are ordinary (249-267 us) and cost 25 % once they are non-temporal (316-323 us)
+//   EARL_WS_ST_AUX=<bits>    (off) observation rows through raw buffer stores with these bits instead of the nt builtin: nt | sc1 = nt; sc1 alone slower
+#if !defined(EARL_WS_NO_SMALL_NT) && !defined(EARL_WS_SMALL_NT)
+#define EARL_WS_SMALL_NT 1
+#endif
+#if !defined(EARL_WS_NO_XCD_REMAP) && !defined(EARL_WS_XCD_REMAP)
+#define EARL_WS_XCD_REMAP 1
+#endif
 namespace earl {
+
+typedef int ws_v4i __attribute__((ext_vector_type(4)));
+typedef float ws_v4f __attribute__((ext_vector_type(4)));
+// buffer resource over [p, p + 4 GiB) for the raw buffer loads / stores of the experiments (wave-uniform base: the descriptor lives in SGPRs)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
 
 struct WsArgs {
   int32_t n, T, horizon, wide;
@@ -282,18 +307,24 @@ __device__ __forceinline__ unsigned long long ws_clock() {
 // chunk, LEAD chunks per loader trip.  K % NL == 0.
 // MULTI: several evaluation episodes per launch (WsArgs.episodes > 1; NC == 3 only) -- a separate instantiation, so the one-episode kernel
 // carries none of the episode bookkeeping.
-template <int RT, int NC, int NL, int NS, int K, int LEAD, bool PROF = false, bool MULTI = false>
+template <int RT, int NC, int NL, int NS, int K, int LEAD, bool PROF = false, bool MULTI = false, bool LDNT = false>
 __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_ws_kernel(const WsArgs a_in) {
   constexpr int E = 64;
   // several episodes in flight (WsArgs::ep_groups): this workgroup's group sees a launch of its OWN episodes -- shifted counter, rows, actions
   WsArgs a = a_in;
-  int wg = blockIdx.x;
+#ifdef EARL_WS_XCD_REMAP
+  // XCD-aware block -> env-block map (MI355X: 8 XCDs, workgroups dealt round-robin; each XCD has its own 4 MiB L2)
+  const int bid = (gridDim.x % 8 == 0) ? (int)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) : (int)blockIdx.x;
+#else
+  const int bid = (int)blockIdx.x;
+#endif
+  int wg = bid;
   bool leaves_state = true;                  // (the group that walks the launch's last episode)
   int eps_before = 0;                        // episodes of the launch before this group's first
   if constexpr (MULTI) {
     if (a_in.ep_groups > 1) {
-      const int grp = (int)blockIdx.x / a_in.wgs;
-      wg = (int)blockIdx.x - grp * a_in.wgs;
+      const int grp = bid / a_in.wgs;
+      wg = bid - grp * a_in.wgs;
       eps_before = grp * a_in.ep_per_group;
       const int ne = min(a_in.ep_per_group, a_in.episodes - eps_before);
       leaves_state = eps_before + ne == a_in.episodes;
@@ -720,7 +751,19 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
           const float* p;
           if constexpr (MULTI && !(EARL_WSM_OFF & 1)) p = rowp[d][q / QG] + (size_t)(q % QG) * qstride;
           else p = base + off[d][q];
-          raw[d][q][0] = p[e0]; raw[d][q][1] = p[e1]; raw[d][q][2] = p[e2];
+#ifdef EARL_WS_LD_AUX
+          if constexpr (true) {
+            const __amdgpu_buffer_rsrc_t rs = ws_rsrc(p);
+            raw[d][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, e0 * 4, 0, EARL_WS_LD_AUX));
+            raw[d][q][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, e1 * 4, 0, EARL_WS_LD_AUX));
+            raw[d][q][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, e2 * 4, 0, EARL_WS_LD_AUX));
+          } else
+#endif
+          if constexpr (LDNT) {        // (experiment) non-temporal loads: the actions are read once
+            raw[d][q][0] = __builtin_nontemporal_load(p + e0); raw[d][q][1] = __builtin_nontemporal_load(p + e1); raw[d][q][2] = __builtin_nontemporal_load(p + e2);
+          } else {
+            raw[d][q][0] = p[e0]; raw[d][q][1] = p[e1]; raw[d][q][2] = p[e2];
+          }
         }
       }
     };
@@ -917,7 +960,14 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         // as ordinary stores they went through the L2 write-back path and, with four episodes in flight, held the kernel at 5.1-5.7 TB/s;
         // streamed past it the launch runs at 7.3 TB/s algorithmic = 6.3 TB/s at the HBM interface (the actions hit the cache), which is what
         // MI355X_MICROARCH.md gives as the achievable HBM bandwidth.  (EARL_WS_TEMPORAL_STORES: the ordinary stores, for comparison.)
-#ifndef EARL_WS_TEMPORAL_STORES
+#ifdef EARL_WS_ST_AUX
+        {
+          const __amdgpu_buffer_rsrc_t rs = ws_rsrc(dst);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_v4i, ws_v4f{rw.v0.x, rw.v0.y, rw.v0.z, rw.v0.w}), rs, lane * 16, 0, EARL_WS_ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_v4i, ws_v4f{rw.v1.x, rw.v1.y, rw.v1.z, rw.v1.w}), rs, (lane + 64) * 16, 0, EARL_WS_ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_v4i, ws_v4f{rw.v2.x, rw.v2.y, rw.v2.z, rw.v2.w}), rs, (lane + 128) * 16, 0, EARL_WS_ST_AUX);
+        }
+#elif !defined(EARL_WS_TEMPORAL_STORES)
         typedef float nt4 __attribute__((ext_vector_type(4)));
         nt4* d4 = reinterpret_cast<nt4*>(dst);
         __builtin_nontemporal_store(nt4{rw.v0.x, rw.v0.y, rw.v0.z, rw.v0.w}, d4 + lane);
@@ -931,12 +981,21 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         float rew;
         if constexpr (RT == EARL_REWARD_SPARSE) rew = succ ? 1.0f : 0.0f;
         else rew = (float)dense1(o);
+#ifdef EARL_WS_SMALL_NT
+        __builtin_nontemporal_store(rew, a.reward + row0 + lane);
+#else
         a.reward[row0 + lane] = rew;
+#endif
         const unsigned long long ms = __ballot(succ), md = __ballot(t - t_ep0 >= t_done);
         if (lane < 16) {
           const uint32_t ns = (uint32_t)(ms >> (4 * lane)) & 0xFu, nd = (uint32_t)(md >> (4 * lane)) & 0xFu;
+#ifdef EARL_WS_SMALL_NT
+          __builtin_nontemporal_store((ns * 0x00204081u) & 0x01010101u, reinterpret_cast<uint32_t*>(a.success + row0) + lane);
+          __builtin_nontemporal_store((nd * 0x00204081u) & 0x01010101u, reinterpret_cast<uint32_t*>(a.done + row0) + lane);
+#else
           reinterpret_cast<uint32_t*>(a.success + row0)[lane] = (ns * 0x00204081u) & 0x01010101u;
           reinterpret_cast<uint32_t*>(a.done + row0)[lane] = (nd * 0x00204081u) & 0x01010101u;
+#endif
         }
         if constexpr (MULTI) refill_goal(c * GPC + q);         // (every row image of the chunk is in registers by now)
       };

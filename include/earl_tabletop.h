@@ -148,6 +148,7 @@ int earl_tabletop3_reward(int32_t n, const float* obs, int32_t reward_type, floa
  * lifelong switching and auto-reset are off and all four outputs are requested), 1 = always the plain
  * one-lane-per-env kernel.  Both produce bit-identical outputs.  Returns the previous setting. */
 int earl_debug_set_rollout_impl(int impl);
+int earl_debug_set_rollout_wgs_per_cu(int k);
 /* Diagnostic: per-workgroup cycle sums of the instrumented rollout variant (impl 9); blocks until the copy is done. */
 int earl_debug_read_ws_profile(uint64_t* out, int32_t n_words);
 const char* earl_version(void);
