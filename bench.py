@@ -45,6 +45,8 @@ def parse():
   p.add_argument('--no-step-api', action='store_true')
   p.add_argument('--episodes-per-launch', type=int, default=28,
                  help='evaluation episodes one bench step = one kernel launch walks (earl_tabletop_eval_episodes); 1 = one episode per launch')
+  p.add_argument('--action-sets', type=int, default=4,
+                 help='distinct action tensors [E, T, N, 3] the launches read round-robin (4 x 275 MB: nothing of an earlier launch survives in the 256 MiB Infinity Cache)')
   p.add_argument('--no-single', action='store_true', help='skip the one-episode-per-launch comparison leg')
   p.add_argument('--no-sawyer', action='store_true', help='skip the sawyer_door / sawyer_peg (BASELINE configs[2]) legs of the default line')
   p.add_argument('--sawyer-cpu-seconds', type=float, default=2.0, help='seconds per repetition and thread count of the Sawyer CPU baselines')
@@ -114,14 +116,22 @@ def time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cud
   the same shape, warm-up included.
   -> (seconds, [ms per launch from one event pair around the region], gathered [N_global, 2], gathered rollout or None, launches)"""
   from earl_benchmark_amd import sharding
+  # `acts` may be a LIST of action tensors of one shape: launch j reads acts[j % len(acts)].  bench.main() passes several whose total
+  # size is several times the 256 MiB Infinity Cache, so no launch finds the actions of an earlier one in a cache: every action byte of
+  # every launch crosses the HBM interface (one tensor re-read by every launch read at 6.3-6.5 TB/s "algorithmic", 5.2-6.2 for real)
+  sets = list(acts) if isinstance(acts, (list, tuple)) else [acts]
+  acts = sets[0]
   multi = acts.dim() == 4
+  issued = [0]
 
   def run(k):                                          # k bench steps = k launches
     for _ in range(k):
+      a = sets[issued[0] % len(sets)]
+      issued[0] += 1
       if multi:
-        env.rollout_episodes(acts, out=out)            # E x (reset + T steps): ONE kernel launch
+        env.rollout_episodes(a, out=out)               # E x (reset + T steps): ONE kernel launch
       else:
-        env.rollout(acts, out=out, reset_first=True)   # reset() of every env + T steps: ONE kernel launch
+        env.rollout(a, out=out, reset_first=True)      # reset() of every env + T steps: ONE kernel launch
     return k
   run(warmup)
   # one HIP event pair around the whole timed region, recorded on torch's current stream == the launch stream.
@@ -558,10 +568,13 @@ def main():
   in_flight = min(E, max(1, 256 // wgs)) if (E > 1 and wgs * 2 <= 256) else 1     # csrc/tabletop.hip do_rollout: episode groups side by side
 
   env = make_env(torch, n, T, a.reward, rank, device)
-  acts = synth_actions(torch, T, n, rank, device, E)          # [E, T, n, 3]: every episode of a launch has its own actions
+  R = max(1, a.action_sets)
+  # [E, T, n, 3] x R: every episode of a launch has its own actions, and consecutive launches read different tensors
+  act_sets = [synth_actions(torch, T, n, rank + 1000 * r, device, E) for r in range(R)]
+  acts = act_sets[0]
   acts1 = acts[0] if E > 1 else acts
   out = alloc_out(torch, T, n, device, E)
-  dt, kern_ms, gathered, _, launches = time_rollouts(torch, dist, env, acts, out, a.steps, a.warmup, world, device)
+  dt, kern_ms, gathered, _, launches = time_rollouts(torch, dist, env, act_sets, out, a.steps, a.warmup, world, device)
   if world > 1:
     assert gathered.shape == (n * world, 2)
   dn = out[2] if E > 1 else out[2][None]
@@ -572,7 +585,7 @@ def main():
   if E > 1 and not a.no_single:      # the same episodes, ONE per launch (round 1's bench step): the latency-bound regime of a 4096-env batch
     o1 = alloc_out(torch, T, n, device, 1)
     ks = max(8, a.steps * 2)
-    sdt, skm, _, _, sl = time_rollouts(torch, dist, env, acts1, o1, ks, 4, world, device)
+    sdt, skm, _, _, sl = time_rollouts(torch, dist, env, [x[e] for x in act_sets for e in range(E)] if E > 1 else act_sets, o1, ks, 4, world, device)
     single = {'value': ks * n * T * world / sdt, 'unit': 'env-steps/s', 'kernel_ms_mean': skm[0], 'launches': sl,
               'frac_of_8TBs': n * (T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH) / (skm[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
               'note': 'one evaluation episode per launch (earl_tabletop_reset_rollout): what round 1 timed'}
@@ -584,7 +597,7 @@ def main():
     lib_.earl_debug_set_rollout_impl(38)
     try:
       ks = max(2, a.steps // 2)
-      qdt, qkm, _, _, ql = time_rollouts(torch, dist, env, acts, out, ks, 1, world, device)
+      qdt, qkm, _, _, ql = time_rollouts(torch, dist, env, act_sets, out, ks, 1, world, device)
     finally:
       lib_.earl_debug_set_rollout_impl(0)
     sequential = {'value': ks * E * n * T * world / qdt, 'unit': 'env-steps/s', 'kernel_ms_mean': qkm[0], 'launches': ql,
@@ -627,7 +640,8 @@ def main():
         'config': {'workload': f'tabletop_manipulation {a.reward}, {n} envs/GPU; bench step = 1 launch = {E} eval episodes (reset+{T} steps), own actions',
                    'envs_per_gpu': n, 'episodes_per_bench_step': E, 'episodes_in_flight': in_flight, 'env_instances_resident': n * in_flight,
                    'strict': strict, 'launches': launches, 'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': E * n * T * world,
-                   'actions': f'[{E}, {T}, {n}, 3] f32 per GPU, distinct per episode (act_episode_stride = T*n*3)',
+                   'actions': f'{R} x [{E}, {T}, {n}, 3] f32 per GPU ({R * E * T * n * 12 / 1e6:.0f} MB): distinct per episode, launches read the {R} tensors round-robin',
+                   'action_sets': R,
                    'next_rows': {k: (v or {}).get('value') for k, v in sawyer.items()},
                    'parallelism': f'env-range shard x{world}, no per-step collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

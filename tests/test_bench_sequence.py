@@ -55,7 +55,12 @@ class ValidatorEnv:
     self.st = _abi.TabletopState(self.qpos.data_ptr(), self.attached.data_ptr(), self.goal_idx.data_ptr(), self.goal_table.data_ptr(),
                                  self.i32[0].data_ptr(), self.i32[1].data_ptr(), self.i32[2].data_ptr(), self.lret.data_ptr())
 
+  def _check_set(self, acts):                              # launch j of the job reads action tensor j % R
+    sets = getattr(self, 'expect_sets', None)
+    assert sets is None or acts is sets[self.launches % len(sets)]
+
   def rollout(self, acts, out, reset_first):
+    self._check_set(acts)
     assert reset_first and acts.shape == (self.T, self.n, 3) and acts.dtype == torch.float32 and acts.is_contiguous()
     o = self._abi.TabletopOut(*(t.data_ptr() for t in out))
     rc = self.lib.earl_tabletop_reset_rollout(C.byref(self.cfg), C.byref(self.st), self.T, acts.data_ptr(), C.byref(o), None)
@@ -68,6 +73,7 @@ class ValidatorEnv:
 
 
   def rollout_episodes(self, acts, out, episodes=None):
+    self._check_set(acts)
     E = acts.shape[0]
     assert acts.shape == (E, self.T, self.n, 3) and acts.is_contiguous() and all(t.shape[0] == E for t in out) and episodes in (None, E)
     assert not torch.equal(acts[0], acts[-1])                      # every episode of the launch has its own actions
@@ -93,7 +99,9 @@ def _worker(rank, world, port, n, T, steps, warmup, out_dir, E=1):
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
     env = ValidatorEnv(n, T, rank * n, delay=0.02 * (rank + 1))        # rank 1 is the slow one: the job time is ITS time
-    acts = bench.synth_actions(torch, T, n, rank, 'cpu', E)          # [E, T, n, 3] distinct per episode (E > 1), as bench.main() feeds it
+    # [E, T, n, 3] distinct per episode (E > 1), two such tensors read round-robin by the launches, as bench.main() feeds them
+    acts = [bench.synth_actions(torch, T, n, rank + 1000 * r, 'cpu', E) for r in range(2)]
+    env.expect_sets = acts
     out = bench.alloc_out(torch, T, n, 'cpu', E)
     dt, kern_ms, table, traj, launches = bench.time_rollouts(torch, dist, env, acts, out, steps, warmup, world, device='cpu', gather_rollout=True)
     assert launches == steps and env.launches == steps + warmup       # a bench step is ONE launch, whatever E

@@ -18,7 +18,9 @@ T = 200
 L = eb.EARLEnvs('tabletop_manipulation', reward_type='sparse', num_envs=n, eval_horizon=T, scalar_api=False)
 _, env = L.get_envs()
 Emax = E * 2
-acts = (torch.rand(Emax, T, n, 3, device='cuda') * 2 - 1).contiguous()
+ROT = int(os.environ.get('ROTATE', '1'))      # distinct action tensors used round-robin by the timed launches (> 256 MB Infinity Cache in total)
+acts_r = [(torch.rand(Emax, T, n, 3, device='cuda') * 2 - 1).contiguous() for _ in range(ROT)]
+acts = acts_r[0]
 out = (torch.zeros(Emax, T, n, 12, device='cuda'), torch.zeros(Emax, T, n, device='cuda'), torch.zeros(Emax, T, n, dtype=torch.bool, device='cuda'),
        torch.zeros(Emax, T, n, dtype=torch.bool, device='cuda'))
 ref = None
@@ -37,15 +39,15 @@ for occ in occs:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(reps):
-          env.rollout_episodes(a, episodes=Ex, out=o)
+        for r_ in range(reps):
+          env.rollout_episodes(acts_r[r_ % ROT][:Ex] if own else a, episodes=Ex, out=o)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
         chk = float(o[0][:E].double().sum()) if own else None
         if own and occ == occs[0] and impl == impls[0]:
           ref = chk
-        print(os.environ.get('EARL_WS_TAG', 'ship'), f'n={n} E={Ex} wgs/cu={occ} own={int(own)} impl={impl:3d}: {us:8.1f} us/launch  {us / Ex:6.2f} us/episode  {Ex * T * n * 66 / us / 1e6:6.2f} TB/s'
+        print(os.environ.get('EARL_WS_TAG', 'ship'), f'rot={ROT} n={n} E={Ex} wgs/cu={occ} own={int(own)} impl={impl:3d}: {us:8.1f} us/launch  {us / Ex:6.2f} us/episode  {Ex * T * n * 66 / us / 1e6:6.2f} TB/s'
               + ('' if chk is None else f'  checksum {"ok" if chk == ref else "DIFF"}'), flush=True)
       finally:
         lib.earl_debug_set_rollout_impl(0)
