@@ -37,8 +37,8 @@ continuing_eval_config = {
     'minitaur': {'num_initial_state_samples': 1, 'num_goals': 4, 'train_horizon': int(1e5), 'goal_change_frequency': 2000},
 }
 
-_NOT_BUILT = ('{name}: this env\'s rigid-body dynamics (PyBullet; the robot\'s URDF is not in the reference tree) are not built; '
-              'only its config and the motor / leg / reward functions (earl_benchmark_amd.glue) are available. See DESIGN.md "out of scope".')
+_NOT_BUILT = ('{name}: the reference builds these from env.reset() observations and crashes (`set` of ndarrays, earl_benchmark/__init__.py:213-217); '
+              'this build returns nothing for it either.')
 
 
 class UnpinnedDynamicsWarning(UserWarning):
@@ -100,11 +100,12 @@ class EARLEnvs(object):
       return tabletop.TabletopManipulation(task_list='rc_r-rc_k-rc_g-rc_b', reward_type=self._reward_type,
                                            reset_at_goal=reset_at_goal,
                                            wide_init_distr=self._kwargs.get('wide_init_distr', False), **kw)
-    if self._env_name in ('sawyer_door', 'sawyer_peg', 'kitchen') and not self._kwargs.get('allow_unpinned_dynamics', False):
+    if self._env_name in ('sawyer_door', 'sawyer_peg', 'kitchen', 'minitaur') and not self._kwargs.get('allow_unpinned_dynamics', False):
       import warnings
       warnings.warn(f'{self._env_name}: the rigid-body dynamics are this build\'s own stepper and contact model; parity with the reference\'s '
-                    'MuJoCo 2.1 is UNPINNED (DESIGN.md sections 9-11: Sawyer envs agree with the recorded demonstrations at trajectory level, with '
-                    'two constants calibrated on them and checked on held-out episodes; the kitchen has no recordings at all).  Pass '
+                    'MuJoCo 2.1 / PyBullet is UNPINNED (DESIGN.md sections 9-11, 14: Sawyer envs agree with the recorded demonstrations at trajectory '
+                    'level, with two constants calibrated on them and checked on held-out episodes; the kitchen has no recordings at all; the '
+                    'minitaur\'s robot MODEL is this build\'s own authoring -- the reference ships no URDF).  Pass '
                     'allow_unpinned_dynamics=True to EARLEnvs to silence this.', UnpinnedDynamicsWarning,
                     stacklevel=3)
     if self._env_name == 'sawyer_door':
@@ -128,7 +129,14 @@ class EARLEnvs(object):
       kw['seed'] = int(kw.get('seed', 0)) + seed_salt
       cfg = continuing_eval_config if self._setup_as_lifelong_learning else deployment_eval_config
       return kitchen.Kitchen(task=self._kwargs.get('kitchen_task', cfg['kitchen']['task']), reward_type=self._reward_type, **kw)
-    raise NotImplementedError(_NOT_BUILT.format(name=self._env_name))
+    if self._env_name == 'minitaur':
+      # reference: earl_benchmark/__init__.py:119-125, :164-169 (minitaur_gym_env.GoalConditionedMinitaurBulletEnv(), no arguments); dynamics: this
+      # build's own stepper on this build's own robot model -- parity with PyBullet unpinned and model-less (envs/minitaur.py)
+      from .envs import minitaur
+      kw = dict(self._batch_kwargs)
+      kw['seed'] = int(kw.get('seed', 0)) + seed_salt
+      return minitaur.Minitaur(**kw)
+    raise KeyError(self._env_name)
 
   def get_train_env(self, lifelong=False):
     from . import wrappers

@@ -83,6 +83,24 @@ class KitchenOut(C.Structure):     # struct earl_kitchen_out
   _fields_ = [(k, C.c_void_p) for k in ('obs', 'reward', 'done', 'success', 'status')]
 
 
+class MinitaurCfg(C.Structure):    # struct earl_minitaur_cfg (include/earl_physics.h)
+  _fields_ = [('n', C.c_int32), ('env_offset', C.c_int32), ('horizon', C.c_int32), ('num_substeps', C.c_int32), ('settle_steps', C.c_int32),
+              ('randomize', C.c_int32), ('n_goals', C.c_int32), ('goal_change_frequency', C.c_int32), ('overheat_steps', C.c_int32),
+              ('motor_dof', C.c_int32 * 8), ('pad_', C.c_int32), ('motor_dir', C.c_double * 8), ('motor_kp', C.c_double), ('motor_kd', C.c_double),
+              ('motor_velocity_limit', C.c_double), ('overheat_torque', C.c_double), ('distance_weight', C.c_double), ('energy_weight', C.c_double),
+              ('success_radius', C.c_double), ('goal_table', C.c_void_p), ('reset_qpos', C.c_void_p),
+              ('seed', C.c_uint64), ('counter', C.c_uint64), ('step_counter', C.c_uint64)]
+
+
+class MinitaurState(C.Structure):  # struct earl_minitaur_state
+  _fields_ = [(k, C.c_void_p) for k in ('qpos', 'qvel', 'goal', 'motor_param', 'observed_torque', 'overheat', 'motor_enabled', 'steps_since_reset',
+                                        'steps_since_goal_change', 'fail_count', 'last_obs')]
+
+
+class MinitaurOut(C.Structure):    # struct earl_minitaur_out
+  _fields_ = [(k, C.c_void_p) for k in ('obs', 'reward', 'done', 'success', 'status')]
+
+
 _P = C.POINTER
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/earl_tabletop.h one to one
 SIGNATURES = {
@@ -124,6 +142,9 @@ SIGNATURES = {
     'earl_kitchen_step': [C.c_void_p, C.c_void_p, _P(KitchenParams), _P(KitchenCfg), _P(KitchenState), C.c_void_p, _P(KitchenOut), C.c_void_p],
     'earl_kitchen_rollout': [C.c_void_p, C.c_void_p, _P(KitchenParams), _P(KitchenCfg), _P(KitchenState), C.c_void_p, C.c_int32, _P(KitchenOut), C.c_void_p],
     'earl_sawyer_rollout': [C.c_void_p, C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_int32, _P(SawyerOut), C.c_void_p],
+    'earl_minitaur_rollout': [C.c_void_p, C.c_void_p, _P(MinitaurCfg), _P(MinitaurState), C.c_void_p, C.c_int32, _P(MinitaurOut), C.c_void_p],
+    'earl_minitaur_reset': [C.c_void_p, C.c_void_p, _P(MinitaurCfg), _P(MinitaurState), C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_minitaur_cfg_size': [],
     'earl_sawyer_reset': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState)] + [C.c_void_p] * 5,
     'earl_sawyer_observe': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_void_p],
     'earl_sawyer_door_reward': [_P(SawyerCfg), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],

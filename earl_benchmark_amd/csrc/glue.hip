@@ -8,6 +8,7 @@
 
 #include "../../include/earl_glue.h"
 #include "philox.h"
+#include "minitaur_device.h"
 
 namespace {
 constexpr int kB = 256;
@@ -33,43 +34,22 @@ __global__ __launch_bounds__(kB) void sawyer_sparse_kernel(int n, const T* __res
   if (reward) reward[i] = s ? 1.0f : 0.0f;
 }
 
-// minitaur.py:434-457
+// minitaur.py:434-457 (csrc/minitaur_device.h)
 __global__ __launch_bounds__(kB) void leg_to_motor_kernel(int n, const double* __restrict__ action, double* __restrict__ out) {
   const int t = blockIdx.x * kB + threadIdx.x;   // one lane per motor
   if (t >= n * 8) return;
-  const int r = t >> 3, i = t & 7, idx = i >> 1;
-  const double pi = 3.141592653589793, quater_pi = pi / 4;
-  const double* a = action + (size_t)r * 8;
-  const double fb = (-1 * quater_pi) * (a[idx + 4] + 1.5);
-  double ext = ((i & 1) ? -1.0 : 1.0) * quater_pi * a[idx];
-  if (i >= 4) ext = -ext;
-  out[t] = (pi + fb) + ext;
+  out[t] = earl::mt_leg_to_motor(action + (size_t)(t >> 3) * 8, t & 7);
 }
 
-__device__ __forceinline__ double interp7(double x) {   // np.interp on motor.py's current/torque table
-  const double xp[7] = {0, 10, 20, 30, 40, 50, 60}, fp[7] = {0, 1, 1.9, 2.45, 3.0, 3.25, 3.5};
-  if (x >= 60.0) return 3.5;
-  double x0 = 0, f0 = 0, x1 = 10, f1 = 1;
-#pragma unroll
-  for (int j = 1; j < 6; ++j)
-    if (x >= xp[j]) { x0 = xp[j]; f0 = fp[j]; x1 = xp[j + 1]; f1 = fp[j + 1]; }
-  const double slope = (f1 - f0) / (x1 - x0);
-  return slope * (x - x0) + f0;
-}
-// motor.py:49-94
+// motor.py:49-94 (csrc/minitaur_device.h)
 __global__ __launch_bounds__(kB) void motor_kernel(int m, earl_motor_params p, const double* __restrict__ command,
                                                    const double* __restrict__ angle, const double* __restrict__ velocity,
                                                    double* __restrict__ actual, double* __restrict__ observed) {
   const int i = blockIdx.x * kB + threadIdx.x;
   if (i >= m) return;
-  const double R = 0.186, Kt = 0.0954;
-  double pwm = p.torque_control ? command[i] : (-p.kp * (angle[i] - command[i]) - p.kd * velocity[i]);
-  pwm = clipd(pwm, -1.0, 1.0);
-  const double obs = clipd(Kt * (pwm * p.voltage / R), -5.7, 5.7);
-  const double vnet = clipd(pwm * p.voltage - (Kt + p.viscous_damping) * velocity[i], -50.0, 50.0);
-  const double current = vnet / R;
-  const double sign = current > 0 ? 1.0 : (current < 0 ? -1.0 : (current == 0 ? 0.0 : current));
-  if (actual) actual[i] = sign * interp7(fabs(current));
+  double act, obs;
+  earl::mt_motor_torque(p.kp, p.kd, p.voltage, p.viscous_damping, p.torque_control != 0, command[i], angle[i], velocity[i], act, obs);
+  if (actual) actual[i] = act;
   if (observed) observed[i] = obs;
 }
 

@@ -34,6 +34,12 @@
 
 #pragma clang fp contract(fast)
 
+// translation units: physics.hip (the main one: nv 10 / 15 / 23 models, every entry point but the two below), physics_w8.hip (the door model's
+// eight-waves-per-CU rollout) and physics_mt.hip (the minitaur: nv = 22) include this file under a variant macro and are compiled side by side
+#if defined(EARL_PHYS_VARIANT_W8) || defined(EARL_PHYS_VARIANT_MT)
+#define EARL_PHYS_NOT_MAIN 1
+#endif
+
 namespace {
 
 // Phase timing (tools/prof_physics.py builds this file with -DEARL_PHYS_PROF into a separate library); not in the product build
@@ -219,6 +225,7 @@ struct SymLds {
 // model table type by size: nv <= 16 the compact form, nv = 23 (kitchen) the 24-dof form with the extra joint tables
 template <int NV> struct ModelOf { using T = earl_link_model; };
 template <> struct ModelOf<23> { using T = earl_link_model24; };
+template <> struct ModelOf<22> { using T = earl_link_model24; };   // the minitaur: floating root + 16 hinges
 
 // Static bounds by model size: the door model (nv 10) keeps 8 contact slots and 16 collision blocks, which keeps its workgroup
 // under 40 KB of LDS (four workgroups per CU, one wave per SIMD); the peg model (nv 15) needs 12 / 32.
@@ -243,14 +250,20 @@ template <int NV> struct Lim {
                                                             // and free peg are separate trees (checked by the host side); the door model
                                                             // (9 + 1) is factorised densely -- the split did not pay there; the kitchen's arm (7 + 2)
                                                             // is one tree and each of its 14 fixtures its own (coupled at most in pairs)
-  static constexpr int NT = NV > 16 ? 9 : NV;               // links that can have ancestors / descendants other than themselves: all, except in the kitchen
+  static constexpr int NT = NV == 23 ? 9 : NV;               // links that can have ancestors / descendants other than themselves: all, except in the kitchen
                                                             // model, where only the arm's nine do (every fixture is a tree of one link; checked by the host
                                                             // side).  The masked ancestor / subtree sums run over [0, NT) plus the lane's own link.
   static constexpr int TS = NV == 15 ? 9 : NT;              // peg model: two trees, links [0, 9) = arm and [9, 15) = the free peg (checked by the host side, like NA): a
                                                             // lane's ancestor / subtree sums then run over its OWN tree only, 9 terms instead of 15 (the others had weight 0)
   static constexpr bool KBT = NV != 15;                     // take the rows' (k, b) from the per-launch table (stage_kb) instead of recomputing them in every timestep: door +0.9 %,
                                                             // kitchen +1.5 %; the peg build (512 registers, one wave per SIMD: the recomputation hides behind LDS latency) -4 %
-  static constexpr bool EXTRAS = NV > 16;                   // dry joint friction, joint springs, force-limited actuators, joint couplings (earl_link_model24)
+  static constexpr bool EXTRAS = NV == 23;                  // dry joint friction, joint springs, force-limited actuators, joint couplings (earl_link_model24), and
+                                                            // the kitchen's structured solver (arm block + fixtures)
+  // the minitaur (nv = 22): ONE tree (a free root body + 16 hinges), no mocap weld, connect constraints (the knee closures), generalized forces
+  // handed in per timestep (the motor model's torques), no joint damping; dense in-LDS factorisations (COOP)
+  static constexpr bool WELD = NV != 22;                    // six weld rows to the mocap body
+  static constexpr bool CONNECT = NV == 22;                 // connect constraints (earl_link_model24.n_con) and the external-force vector s.xt.ext
+  static constexpr bool DAMPED = NV != 22;                  // joint damping (K10's implicit step (M + dt B) a' = M a; without damping a' = a)
   static constexpr int LPE = NV > 16 ? 32 : 16;             // lanes per env instance (64 = one wavefront per env: measurement switch for nv <= 16)
 };
 
@@ -258,6 +271,15 @@ template <int NV> struct Lim {
 // registers across the whole active-set iteration (the nv = 23 kernel spilled 1.6 KB per lane into scratch)
 template <int NV, bool ON> struct HwStore {};
 template <int NV> struct HwStore<NV, true> { SymLds<NV> Hw; };
+
+// connect constraints (3 rows each) and the generalized forces applied from outside: only in the models that have them (the Sawyer workgroups fill a
+// CU's LDS to the last 200 bytes)
+template <int NV, bool ON> struct ConStore {};
+template <int NV> struct ConStore<NV, true> {
+  double JE[3 * EARL_MAXCONNECT][NV];   // Jacobian rows: Jp(att1) - Jp(att2)
+  double eD[3 * EARL_MAXCONNECT], ear[3 * EARL_MAXCONNECT], eres[3 * EARL_MAXCONNECT];
+  double ext[NV];
+};
 
 // Per-env LDS block.  The three phase groups of the union are live at disjoint times.
 template <int NV>
@@ -267,7 +289,8 @@ struct SharedData {
   double bq[4];                      // orientation of the free body (unit quaternion), identity if the model has none
   double Xq[NV][4], Xp[NV][3];       // world frame of every link (final buffer of the ancestor doubling)
   SymLds<NV> M;                      // mass matrix
-  HwStore<NV, (NV > 16)> hwst;
+  HwStore<NV, Lim<NV>::EXTRAS> hwst;
+  ConStore<NV, Lim<NV>::CONNECT> xt;
   union {
     struct { double Xq1[NV][4], Xp1[NV][3]; } k2;                    // second buffer of the doubling
     struct { double att[8][3]; } emit;                               // observation epilogue (after the last timestep of an env step)
@@ -842,7 +865,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     V3 wc = w, vc = v;
     if (m.ball_dof >= 0) {
       const uint32_t drop = amask & ~m.cd_mask[l];
-      for (int a = m.ball_dof; a < NV; ++a) {
+      for (int a = m.ball_dof; a < m.ball_dof + 3; ++a) {      // (the three rotation links of the free body)
         const double qd = ((drop >> a) & 1u) ? s.qv[a] : 0.0;
         const double* sa = s.dyn.S[a];
         wc = vsub(wc, scl(ld3(sa), qd));
@@ -905,6 +928,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         if constexpr (Lim<NV>::EXTRAS) frc = fmin(fmax(frc, m.act_forcerange[ac][0]), m.act_forcerange[ac][1]);   // forcelimited actuator
         t += frc;
       }
+    if constexpr (Lim<NV>::CONNECT) t += s.xt.ext[l];      // generalized force handed in for this timestep (the minitaur's motor torques)
     tau_l = t;
   }
   fence();                                             // dyn.* is dead from here on; col.* then con.* take its place
@@ -1026,7 +1050,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   // ------------------------------------------------------------------ K8: constraint rows
   double Jc[6];                                        // this lane's column of the weld Jacobian
   V3 rpos, rrot;
-  {
+  if constexpr (!Lim<NV>::WELD) {                      // no mocap weld: six empty rows (weight 0)
+#pragma unroll
+    for (int r = 0; r < 6; ++r) Jc[r] = 0.0;
+    rpos = V3{0, 0, 0}; rrot = V3{0, 0, 0};
+    if (isl) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s.con.J6[r][l] = 0.0;
+    }
+    if (sub < 6) { s.con.wD[sub] = 0.0; s.con.war[sub] = 0.0; }
+  } else {
     const int k = m.weld_att, la = m.att_link[k];
     const Q4 ql = ldq(s.Xq[la]);
     double R[3][3];
@@ -1055,7 +1088,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
   }
   fence();
-  {
+  if constexpr (Lim<NV>::WELD) {
     // weld rows: lane = row (< 6)
     const int r = sub < 6 ? sub : 5;
     double Jv = 0;
@@ -1067,6 +1100,37 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     else kbimp(m.weld_solref, m.weld_solimp, res, dt, kk, bb, dd);
     const double Rg = fmax((1 - dd) * m.weld_invweight[r < 3 ? 0 : 1] * rcp_nr(dd), 1e-15);
     if (sub < 6) { s.con.wD[r] = rcp_nr(Rg); s.con.war[r] = -bb * Jv - kk * dd * res; }
+  }
+  // connect constraints (reference: LinkModel.forward): attachments con_att1[e] / con_att2[e] coincide; rows 3 e + c, residual (p1 - p2)[c],
+  // Jacobian Jp(link1, p1) - Jp(link2, p2); this lane's column first, then lane = row for the reference accelerations
+  if constexpr (Lim<NV>::CONNECT) {
+    for (int e = 0; e < m.n_con; ++e) {
+      const int k1 = m.con_att1[e], k2 = m.con_att2[e], l1 = m.att_link[k1], l2 = m.att_link[k2];
+      double R[3][3];
+      qmat(ldq(s.Xq[l1]), R);
+      const V3 p1 = add(ld3(s.Xp[l1]), mulv(R, ld3(m.att_pos[k1])));
+      qmat(ldq(s.Xq[l2]), R);
+      const V3 p2 = add(ld3(s.Xp[l2]), mulv(R, ld3(m.att_pos[k2])));
+      const double w1 = (isl && ((m.anc_mask[l1] >> l) & 1u)) ? 1.0 : 0.0, w2 = (isl && ((m.anc_mask[l2] >> l) & 1u)) ? 1.0 : 0.0;
+      const V3 j1 = scl(add(Sv, cross(Sw, p1)), w1), j2 = scl(add(Sv, cross(Sw, p2)), w2);
+      if (isl) {
+        s.xt.JE[3 * e][l] = j1.x - j2.x; s.xt.JE[3 * e + 1][l] = j1.y - j2.y; s.xt.JE[3 * e + 2][l] = j1.z - j2.z;
+      }
+      if (sub == 0) { s.xt.eres[3 * e] = p1.x - p2.x; s.xt.eres[3 * e + 1] = p1.y - p2.y; s.xt.eres[3 * e + 2] = p1.z - p2.z; }
+    }
+    fence();
+    if (sub < 3 * m.n_con) {
+      const int e = sub / 3;
+      double Jv = 0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) Jv = fma(s.xt.JE[sub][j], s.qv[j], Jv);
+      const double res = s.xt.eres[sub];
+      double kk, bb, dd;
+      kbimp(m.con_solref[e], m.con_solimp[e], res, dt, kk, bb, dd);
+      s.xt.eD[sub] = rcp_nr(fmax((1 - dd) * m.con_invweight[e] * rcp_nr(dd), 1e-15));
+      s.xt.ear[sub] = -bb * Jv - kk * dd * res;
+    }
+    fence();
   }
   // limit row of this lane's dof: at most one side can be violated
   double lim_D, lim_aref;
@@ -1207,6 +1271,14 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         }
         if (i == l) h += m.drag_G[l];                     // soft velocity row of a permanent dragging contact
         hw[i] = h;
+      }
+      if constexpr (Lim<NV>::CONNECT) {                    // + JE' D JE (the connect rows are equalities: always active)
+        for (int r = 0; r < 3 * m.n_con; ++r) {
+          const double dj = s.xt.eD[r] * s.xt.JE[r][l];
+          g = fma(dj, s.xt.ear[r], g);
+#pragma unroll
+          for (int i = 0; i < NV; ++i) hw[i] = fma(s.xt.JE[r][i], dj, hw[i]);
+        }
       }
     }
     g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
@@ -1577,6 +1649,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
   } else {
     // ---------------------------------------------------------------- K10: Euler, joint damping implicit
+    if constexpr (Lim<NV>::DAMPED) {
     {
       double acc = 0;
 #pragma unroll
@@ -1608,6 +1681,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       load_tri<NV, NA>(L, s.M, [&](int i) { return s.con.dl[i]; });           // the mass matrix is block diagonal: two trees
       chol_regs<NV, NA>(L);
       solve_regs<NV, NA>(L, a);
+    }
     }
     double al = 0;
 #pragma unroll
@@ -1670,7 +1744,8 @@ template <int NV>
 __device__ __forceinline__ void load_state(Shared<NV>& s, const typename ModelOf<NV>::T& m, const double* __restrict__ qrow, const double* __restrict__ vrow, const int sub) {
   const int bd = m.ball_dof;
   if (sub < NV) {
-    s.qp[sub] = (bd < 0 || sub < bd) ? qrow[sub] : 0.0;
+    // (a free ROOT body -- the minitaur's base, ball_dof = 3 -- keeps MuJoCo's layout [xyz, quaternion, joints]: dof l > bd + 2 sits at qrow[l + 1])
+    s.qp[sub] = (bd < 0 || sub < bd) ? qrow[sub] : (sub > bd + 2 ? qrow[sub + 1] : 0.0);
     s.qv[sub] = vrow[sub];
     s.aprev[sub] = 0.0;              // (read, and discarded, by the cold first timestep)
   }
@@ -1683,11 +1758,19 @@ __device__ __forceinline__ void load_state(Shared<NV>& s, const typename ModelOf
     s.bq[sub] = v;
   }
 }
+// the orientation quaternion in LDS as load_state would read it back from a stored row (the same expression, compiled under the same contraction mode):
+// lets a fused rollout walk through the same bits as one launch per env step
+template <int NV>
+__device__ __forceinline__ double renormalised_quat_entry(const Shared<NV>& s, const int sub) {
+  const Q4 q = ldq(s.bq);
+  return s.bq[sub < 4 ? sub : 0] * rsq_nr(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+}
 template <int NV>
 __device__ __forceinline__ void store_state(const Shared<NV>& s, const typename ModelOf<NV>::T& m, double* __restrict__ qrow, double* __restrict__ vrow, const int sub) {
   const int bd = m.ball_dof;
   if (sub < NV) {
     if (bd < 0 || sub < bd) qrow[sub] = s.qp[sub];
+    else if (sub > bd + 2) qrow[sub + 1] = s.qp[sub];
     vrow[sub] = s.qv[sub];
   }
   if (bd >= 0 && sub < 4) qrow[bd + sub] = s.bq[sub];
@@ -2112,7 +2195,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const S
   }
 }
 
-#ifndef EARL_PHYS_VARIANT_W8
+#ifndef EARL_PHYS_NOT_MAIN
 // compute_reward / is_successful on given observations (sawyer_door.py:141-177), one lane per row
 __global__ void sawyer_door_reward_kernel(const int n, const double* __restrict__ obs, const earl_sawyer_cfg cfg, float* __restrict__ reward,
                                           uint8_t* __restrict__ success) {
@@ -2126,7 +2209,7 @@ __global__ void sawyer_door_reward_kernel(const int n, const double* __restrict_
 }
 #endif
 
-#ifndef EARL_PHYS_VARIANT_W8
+#ifndef EARL_PHYS_NOT_MAIN
 // ------------------------------------------------------------------------------------------------ kitchen env step (include/earl_physics.h)
 // small per-env kernels around the stepper; the numpy glue of the reference (action scaling, observation noise, reward) stays in csrc/glue.hip
 struct KitchenArgs {
@@ -2325,6 +2408,205 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
 }
 #endif
 
+#ifdef EARL_PHYS_VARIANT_MT
+// ------------------------------------------------------------------------------------------------ minitaur env (include/earl_physics.h; physics_mt.hip)
+// One launch = T env steps (or the reset incl. its settle steps) of every env: 32 lanes per env, two envs per wave; lanes 0-7 of a group are also
+// the eight MOTORS (Minitaur.ApplyAction per timestep: velocity-limited command, DC-motor model, overheat protection -- csrc/minitaur_device.h),
+// whose counters and flags live in those lanes' registers between timesteps.  Reference of every expression: oracle/minitaur_oracle.py.
+struct MinitaurArgs {
+  const void* m;
+  const earl_collision_model* col;
+  earl_minitaur_cfg cfg;
+  earl_minitaur_state st;
+  earl_minitaur_out out;
+  const float* action; int T;
+  const uint8_t* mask; double* reset_obs;
+};
+__device__ __forceinline__ double mt_draw(const earl_minitaur_cfg& cfg, const uint32_t stream, const int env, const uint64_t counter) {
+  const earl::U4 b = earl::philox4x32_10(earl::U4{stream, (uint32_t)(cfg.env_offset + env), (uint32_t)counter, (uint32_t)(counter >> 32)},
+                                         (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
+  return earl::u01(b.x, b.y);
+}
+template <bool RESET>
+__global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const MinitaurArgs a) {
+#pragma clang fp contract(off)
+  constexpr int NV = 22, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
+  __shared__ typename ModelOf<NV>::T m;
+  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
+  __shared__ Shared<NV> sh[EPW * WPB];
+  stage_blocks(bt, a.col);
+  stage_kb<NV>(bt, a.m, a.col);
+  stage_model(m, a.m);                                  // (ends with the workgroup barrier)
+  const earl_minitaur_cfg& cfg = a.cfg;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
+  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
+  const bool in_batch = env_raw < n;
+  const int env = in_batch ? env_raw : n - 1;           // idle groups shadow the last env and store nothing
+  const bool live = in_batch && (!RESET || !a.mask || a.mask[env] != 0);      // (a reset leaves the envs outside the mask alone: their groups compute and discard)
+  Shared<NV>& s = sh[wave * EPW + grp];
+  const int mi = sub < 8 ? sub : 7;                     // this lane's motor
+  const int mdof = cfg.motor_dof[mi];
+  const double mdir = cfg.motor_dir[mi];
+  const double lim = m.dt * cfg.motor_velocity_limit;
+  const Q4 mq{1, 0, 0, 0};
+  const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
+  double voltage, viscous, goal0, goal1;
+  int oh; bool en; double obs_t;                        // motor lanes: overheat counter, enabled flag, observed torque of the newest ApplyAction
+  if constexpr (RESET) {
+    // GoalConditionedMinitaurBulletEnv.reset (minitaur_gym_env.py:476-479, 222-270): goal, [UPSTREAM randomizer] battery voltage and viscous damping, pose
+    int gi = (int)(mt_draw(cfg, 0x4D00u, env, cfg.counter) * (double)cfg.n_goals);
+    gi = gi >= cfg.n_goals ? cfg.n_goals - 1 : gi;
+    goal0 = cfg.goal_table[2 * gi]; goal1 = cfg.goal_table[2 * gi + 1];
+    voltage = cfg.randomize ? 14.8 + (16.8 - 14.8) * mt_draw(cfg, 0x4D01u, env, cfg.counter) : 16.0;
+    viscous = cfg.randomize ? 0.01 * mt_draw(cfg, 0x4D02u, env, cfg.counter) : 0.0;
+    load_state<NV>(s, m, cfg.reset_qpos, a.st.qvel + (size_t)env * NV, sub);
+    if (sub < NV) s.qv[sub] = 0.0;
+    oh = 0; en = true; obs_t = 0.0;
+  } else {
+    goal0 = a.st.goal[(size_t)env * 2]; goal1 = a.st.goal[(size_t)env * 2 + 1];
+    voltage = a.st.motor_param[(size_t)env * 2]; viscous = a.st.motor_param[(size_t)env * 2 + 1];
+    load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+    oh = a.st.overheat[(size_t)env * 8 + mi]; en = a.st.motor_enabled[(size_t)env * 8 + mi] != 0; obs_t = a.st.observed_torque[(size_t)env * 8 + mi];
+  }
+  if (sub < NV) s.xt.ext[sub] = 0.0;
+  fence();
+  // Minitaur.ApplyAction (minitaur.py:326-390) of motor `mi`: the command clipped to what the velocity limit allows in one timestep, the DC-motor
+  // model, overheat protection, torque x motor direction -> s.xt.ext[dof]
+  auto apply_action = [&](const double cmd) {
+    if (sub < 8) {
+      const double q = s.qp[mdof] * mdir, qd = s.qv[mdof] * mdir;
+      const double c = earl::mt_clipd(cmd, q - lim, q + lim);
+      double act, obs;
+      earl::mt_motor_torque(cfg.motor_kp, cfg.motor_kd, voltage, viscous, false, c, q, qd, act, obs);
+      oh = fabs(act) > cfg.overheat_torque ? oh + 1 : 0;
+      if (oh > cfg.overheat_steps) en = false;
+      obs_t = obs;
+      s.xt.ext[mdof] = en ? act * mdir : 0.0;
+    }
+    fence();
+  };
+  // GetObservation + goal (minitaur.py:300-324, minitaur_gym_env.py:541-546): lane k holds entry k of the 32
+  auto observe = [&]() -> double {
+    if (sub < 8) s.kit.obs[16 + sub] = obs_t;
+    fence();
+    double v;
+    if (sub < 8) v = s.qp[mdof] * mdir;
+    else if (sub < 16) v = s.qv[cfg.motor_dof[sub - 8]] * cfg.motor_dir[sub - 8];
+    else if (sub < 24) v = s.kit.obs[sub];
+    else if (sub < 28) v = s.bq[sub == 27 ? 0 : sub - 23];       // Bullet's (x, y, z, w)
+    else if (sub < 30) v = s.qp[sub - 28];
+    else v = sub == 30 ? goal0 : goal1;
+    fence();
+    s.kit.obs[sub] = v;
+    fence();
+    return v;
+  };
+  if constexpr (RESET) {
+    const double half_pi = 3.141592653589793 / 2;
+    for (int ts = 0; ts < cfg.settle_steps; ++ts) {       // minitaur_gym_env.py:265-269
+      apply_action(half_pi);
+      substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);
+    }
+    const double v = observe();
+    if (live) {
+      store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+      if (a.reset_obs) a.reset_obs[(size_t)env * 32 + sub] = v;
+      if (a.st.last_obs) a.st.last_obs[(size_t)env * 32 + sub] = v;
+      if (sub < 8) {
+        a.st.overheat[(size_t)env * 8 + sub] = oh; a.st.motor_enabled[(size_t)env * 8 + sub] = en ? 1 : 0; a.st.observed_torque[(size_t)env * 8 + sub] = obs_t;
+      }
+      if (sub == 0) {
+        a.st.goal[(size_t)env * 2] = goal0; a.st.goal[(size_t)env * 2 + 1] = goal1;
+        a.st.motor_param[(size_t)env * 2] = voltage; a.st.motor_param[(size_t)env * 2 + 1] = viscous;
+        if (a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
+        if (a.st.steps_since_goal_change) a.st.steps_since_goal_change[env] = 0;
+      }
+    }
+  } else {
+    int steps = a.st.steps_since_reset ? a.st.steps_since_reset[env] : 0;
+    const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
+    int sgc = gcf > 0 ? a.st.steps_since_goal_change[env] : 0;
+    for (int t = 0; t < a.T; ++t) {
+      const size_t row = (size_t)t * n + env;
+      double a64[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a64[k] = earl::mt_clipd((double)a.action[row * 8 + k], -1.01, 1.01);      // (the front end raises beyond the reference's bound)
+      const double cmd = earl::mt_leg_to_motor(a64, mi);              // ConvertFromLegModel
+      for (int ts = 0; ts < cfg.num_substeps; ++ts) {                  // minitaur_gym_env.py:321-323
+        apply_action(cmd);
+        substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);
+      }
+      const bool bad_lane = (sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE)) || (sub < 4 && !(fabs(s.bq[sub]) < EARL_BAD_VALUE));
+      const bool failed = group_any<LPE>(bad_lane, grp);
+      ++steps;
+      double v;
+      if (failed) {
+        // rolled back to the env's last stable state (the rows in HBM); the row carries the last stable observation, reward 0
+        load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+        oh = a.st.overheat[(size_t)env * 8 + mi]; en = a.st.motor_enabled[(size_t)env * 8 + mi] != 0; obs_t = a.st.observed_torque[(size_t)env * 8 + mi];
+        v = t > 0 ? a.out.obs[(row - n) * 32 + sub] : (a.st.last_obs ? a.st.last_obs[(size_t)env * 32 + sub] : NAN);
+        if (live) {
+          a.out.obs[row * 32 + sub] = v;
+          if (sub == 0) {
+            a.out.reward[row] = 0.0; a.out.success[row] = 0;
+            if (a.st.fail_count) a.st.fail_count[env] += 1;
+          }
+        }
+        fence();
+      } else {
+        v = observe();
+        {
+          // the orientation quaternion as the next launch's load_state would read it back from the row stored below (re-normalised, the same
+          // expression): a fused rollout and T single-step launches then walk through the same bits
+          const double qn = renormalised_quat_entry<NV>(s, sub);
+          fence();
+          if (live) store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+          if (sub < 4) s.bq[sub] = qn;
+          fence();
+        }
+        if (live) {
+          if (sub < 8) {
+            a.st.overheat[(size_t)env * 8 + sub] = oh; a.st.motor_enabled[(size_t)env * 8 + sub] = en ? 1 : 0; a.st.observed_torque[(size_t)env * 8 + sub] = obs_t;
+          }
+          a.out.obs[row * 32 + sub] = v;
+          if (sub == 0) {                                 // _reward (minitaur_gym_env.py:505-521) = compute_reward (:529-535) on this observation; is_successful :495-503
+            const double* o = s.kit.obs;
+            const double xd = o[28] - goal0, yd = o[29] - goal1;
+            double dotp = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dotp = fma(o[16 + k], o[8 + k], dotp);
+            a.out.reward[row] = cfg.distance_weight * (-fabs(xd) - fabs(yd)) - cfg.energy_weight * (fabs(dotp) * m.dt);
+            a.out.success[row] = sqrt(xd * xd + yd * yd) < cfg.success_radius;
+          }
+        }
+      }
+      if (sub == 0 && live) {
+        if (a.out.status) a.out.status[row] = failed ? EARL_STEP_DIVERGED : 0;
+        a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
+      }
+      if (gcf > 0 && ++sgc >= gcf) {                      // LifelongWrapper.step (lifelong_wrapper.py:36-42): new goal, the observation re-read with it
+        sgc = 0;
+        int gi = (int)(mt_draw(cfg, 0xFFFEu, env, cfg.step_counter + (uint64_t)t) * (double)cfg.n_goals);
+        gi = gi >= cfg.n_goals ? cfg.n_goals - 1 : gi;
+        goal0 = cfg.goal_table[2 * gi]; goal1 = cfg.goal_table[2 * gi + 1];
+        if (live && sub >= 30) a.out.obs[row * 32 + sub] = sub == 30 ? goal0 : goal1;
+        if (live && sub == 0) { a.st.goal[(size_t)env * 2] = goal0; a.st.goal[(size_t)env * 2 + 1] = goal1; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // a later step of this launch may read this row / the state rows back (failure guard)
+      fence();
+    }
+    if (live) {
+      if (sub == 0) {
+        if (a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
+        if (gcf > 0) a.st.steps_since_goal_change[env] = sgc;
+      }
+      if (a.st.last_obs && a.T > 0) a.st.last_obs[(size_t)env * 32 + sub] = a.out.obs[((size_t)(a.T - 1) * n + env) * 32 + sub];
+    }
+  }
+}
+#endif   // EARL_PHYS_VARIANT_MT
+
+
 int launched(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -2352,7 +2634,7 @@ void launch_physics(const PArgs& a, hipStream_t st) {
 
 extern "C" {
 
-#ifndef EARL_PHYS_VARIANT_W8
+#ifndef EARL_PHYS_NOT_MAIN
 int earl_physics_step(const void* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
                       earl_stream_t stream) {
@@ -2380,7 +2662,30 @@ int earl_physics_forward(const void* model, const earl_collision_model* col, int
 }
 
 #endif
-#ifdef EARL_PHYS_VARIANT_W8
+#if defined(EARL_PHYS_VARIANT_MT)
+// This translation unit is physics_mt.hip: the minitaur's kernels (the nv = 22 instantiation of the stepper) and entry points.
+int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
+                          const float* action, int32_t T, const earl_minitaur_out* out, earl_stream_t stream) {
+  if (!model24 || !cfg || !st || !out || !action || T < 0 || cfg->n < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->goal || !st->motor_param || !st->observed_torque || !st->overheat || !st->motor_enabled) return EARL_ERR_ARG;
+  if (!out->obs || !out->reward || !out->done || !out->success || !cfg->goal_table || cfg->n_goals < 1 || cfg->num_substeps < 0) return EARL_ERR_ARG;
+  if (cfg->n == 0 || T == 0) return EARL_OK;
+  MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr};
+  minitaur_kernel<false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  return launched("minitaur_rollout");
+}
+int earl_minitaur_reset(const void* model24, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
+                        const uint8_t* mask, double* obs, earl_stream_t stream) {
+  if (!model24 || !cfg || !st || cfg->n < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->goal || !st->motor_param || !st->observed_torque || !st->overheat || !st->motor_enabled) return EARL_ERR_ARG;
+  if (!cfg->goal_table || !cfg->reset_qpos || cfg->n_goals < 1 || cfg->settle_steps < 0) return EARL_ERR_ARG;
+  if (cfg->n == 0) return EARL_OK;
+  MinitaurArgs a{model24, col, *cfg, *st, earl_minitaur_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0, mask, obs};
+  minitaur_kernel<true><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  return launched("minitaur_reset");
+}
+int earl_minitaur_cfg_size(void) { return (int)sizeof(earl_minitaur_cfg); }
+#elif defined(EARL_PHYS_VARIANT_W8)
 // This translation unit is physics_w8.hip: the door model's rollout kernel built with eight-wave workgroups (EARL_DOOR_WPB 8: 32 envs share one
 // copy of the tables, packed matrices, in-LDS factorisations, 256 registers per wave) = eight waves per CU.  Same arithmetic, bit-identical
 // outputs; chosen by earl_sawyer_rollout for batches of more than 4096 envs (one round of 8192 envs instead of two of 4096).

@@ -14,7 +14,7 @@ from .. import _abi
 
 MAXV, MAXATT, MAXACT = 16, 8, 4
 MAXSPH, MAXBOX, MAXPAIR, MAXCLS, MAXCON, MAXBLK = 96, 16, 512, 16, 12, 32
-MAXV24, MAXATT24, MAXJEQ = 24, 16, 8
+MAXV24, MAXATT24, MAXJEQ, MAXCONNECT = 24, 16, 8, 4
 MODEL_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'models')
 
 
@@ -52,7 +52,9 @@ class LinkModelStruct24(C.Structure):   # struct earl_link_model24: up to 24 dof
               ('cd_mask', C.c_uint32 * MAXV24), ('frictionloss', C.c_double * MAXV24), ('stiffness', C.c_double * MAXV24),
               ('springref', C.c_double * MAXV24), ('act_forcerange', C.c_double * 2 * MAXACT), ('jeq_coef', C.c_double * 2 * MAXJEQ),
               ('jeq_solref', C.c_double * 2 * MAXJEQ), ('jeq_solimp', C.c_double * 5 * MAXJEQ), ('jeq_invweight', C.c_double * MAXJEQ),
-              ('pair', C.c_int32 * MAXV24)]
+              ('pair', C.c_int32 * MAXV24),
+              ('n_con', C.c_int32), ('con_att1', C.c_int32 * MAXCONNECT), ('con_att2', C.c_int32 * MAXCONNECT), ('pad3_', C.c_int32 * 3),
+              ('con_solref', C.c_double * 2 * MAXCONNECT), ('con_solimp', C.c_double * 5 * MAXCONNECT), ('con_invweight', C.c_double * MAXCONNECT)]
 
 
 class PairRec(C.Structure):
@@ -91,7 +93,8 @@ def load_link_model(name):
   s.nv, s.n_att, s.n_act, s.weld_att = nv, natt, nact, int(d['weld_att'])
   s.ball_dof = int(d['ball_dof']) if 'ball_dof' in d else -1
   s.nq = nv + (1 if s.ball_dof >= 0 else 0)
-  assert s.ball_dof < 0 or s.ball_dof == nv - 3
+  # a free body's rotation dofs are the last three (the peg), or the free body is the ROOT (the minitaur's base: dofs 0-5, MuJoCo's qpos layout)
+  assert s.ball_dof < 0 or s.ball_dof == nv - 3 or (s.ball_dof == 3 and all(int(d['jtype'][k]) == t for k, t in enumerate((1, 1, 1, 2, 3, 3))))
   anc = np.zeros(nv, np.uint32)
   for l in range(nv):
     p = l
@@ -111,6 +114,7 @@ def load_link_model(name):
   depth = [bin(int(a)).count('1') for a in anc]
   s.n_jump = max(1, int(np.ceil(np.log2(max(depth)))))
   assert s.n_jump <= 4
+  assert int(d['weld_att']) >= 0 or big, 'models without a mocap weld use the 24-dof table form'
   jump = np.full((4, MAXV24 if big else MAXV), -1, np.int32)
   for l in range(nv):
     chain = []
@@ -135,7 +139,16 @@ def load_link_model(name):
   if 'dof_drag_G' in d:
     _fill(s.drag_G, d['dof_drag_G'])
     _fill(s.drag_b, d['dof_drag_b'])
-  if big:
+  if big and nv == 22:
+    # the minitaur: floating root + 16 hinges, no mocap weld, four connect constraints (csrc/physics.hip Lim<22>: dense factorisations)
+    s.n_jeq, s.n_con = 0, len(d['con_att1'])
+    assert s.n_con <= MAXCONNECT and s.weld_att < 0 and s.ball_dof == 3 and nact == 0
+    for dst, src in ((s.con_att1, d['con_att1']), (s.con_att2, d['con_att2']), (s.con_solref, d['con_solref']), (s.con_solimp, d['con_solimp']),
+                     (s.con_invweight, d['con_invweight'])):
+      _fill(dst, src)
+    _fill(s.pair, np.full(MAXV24, -1, np.int32))
+    _fill(s.act_forcerange, np.tile([-1e300, 1e300], (MAXACT, 1)))
+  elif big:
     s.n_jeq = len(d['jeq_joint1'])
     assert s.n_jeq <= MAXJEQ
     fr = np.array(d['act_forcerange'], float)
@@ -209,7 +222,7 @@ def check_layouts(lib):
   """the hand-mirrored ctypes layouts are memcpy'd to the device: refuse a library compiled against other struct layouts"""
   for fn, mirror in ((lib.earl_physics_model_size, LinkModelStruct), (lib.earl_physics_model24_size, LinkModelStruct24),
                      (lib.earl_collision_model_size, CollisionModelStruct),
-                     (lib.earl_sawyer_cfg_size, _abi.SawyerCfg)):
+                     (lib.earl_sawyer_cfg_size, _abi.SawyerCfg), (lib.earl_minitaur_cfg_size, _abi.MinitaurCfg)):
     if fn() != C.sizeof(mirror):
       raise _abi.EarlHipError(f'{mirror.__name__}: the library was built with sizeof = {fn()}, this binding expects {C.sizeof(mirror)} '
                               '(stale csrc/libearl_hip.so or header drift: rebuild with __graft_entry__.build())')

@@ -65,6 +65,7 @@ typedef struct earl_link_model {
 #define EARL_MAXV24 24
 #define EARL_MAXATT24 16
 #define EARL_MAXJEQ 8
+#define EARL_MAXCONNECT 4
 typedef struct earl_link_model24 {
   int32_t nv, n_att, n_act, weld_att;
   int32_t n_jump, ball_dof, nq, n_jeq;
@@ -91,6 +92,12 @@ typedef struct earl_link_model24 {
   double jeq_coef[EARL_MAXJEQ][2], jeq_solref[EARL_MAXJEQ][2], jeq_solimp[EARL_MAXJEQ][5], jeq_invweight[EARL_MAXJEQ];
   int32_t pair[EARL_MAXV24];                   /* the dof a coupling ties this dof to, -1 = none: dofs beyond the first tree (the arm: the first 9) are
                                                   their own trees, so without contacts the constraint Hessian is the arm's block plus 2 x 2 / 1 x 1 blocks */
+  /* connect constraints (MuJoCo mjEQ_CONNECT; Bullet JOINT_POINT2POINT): the world positions of attachments con_att1[e] and con_att2[e] coincide --
+   * three soft equality rows each (the minitaur's four knee closures, earl_benchmark/envs/minitaur.py:212-217).  Models with weld_att < 0 have no
+   * mocap weld.  A free ROOT body (ball_dof = 3: the minitaur's base) keeps MuJoCo's qpos layout [xyz, quaternion, joints]: the qpos slot of dof
+   * l > ball_dof + 2 is l + 1. */
+  int32_t n_con, con_att1[EARL_MAXCONNECT], con_att2[EARL_MAXCONNECT], pad3_[3];
+  double con_solref[EARL_MAXCONNECT][2], con_solimp[EARL_MAXCONNECT][5], con_invweight[EARL_MAXCONNECT];
 } earl_link_model24;
 
 /* Collision geometry of a link model: SPHERES (cylinders are chains of spheres; box corners are spheres of radius 0)
@@ -308,6 +315,68 @@ int earl_kitchen_step(const void* model24, const earl_collision_model* col, cons
  * over the T steps instead of T times the slowest wave of a step.  The lifelong wrapper's goal switch is not part of it (callers step those). */
 int earl_kitchen_rollout(const void* model24, const earl_collision_model* col, const struct earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
                          const earl_kitchen_state* st, const float* action /* [T, n, 9] */, int32_t T, const earl_kitchen_out* out, earl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Minitaur env (BASELINE configs[4]) on the same stepper: floating base + 16 hinges (nv = 22, nq = 23), four connect
+ * constraints (the knee closures), spheres against the ground and the wall tiles; the rigid-body MODEL is this build's own authoring
+ * (tools/minitaur_model.py: the reference's URDF is not in its tree) -- parity with the reference's PyBullet simulation is UNPINNED AND MODEL-LESS.
+ * Replaces, per env instance, PersistentStateWrapper.step (wrappers/persistent_state_wrapper.py:17-31) o GoalConditionedMinitaurBulletEnv.step
+ * (envs/minitaur_gym_env.py:505-546 over MinitaurBulletEnv.step :285-329): Minitaur.ConvertFromLegModel (envs/minitaur.py:434-457), then
+ * num_substeps x { Minitaur.ApplyAction (:326-390: velocity-limit clip of the command, MotorModel.convert_to_torque envs/motor.py:49-94, overheat
+ * protection, torque x motor direction); one timestep of the stepper }, _reward, is_successful, GetObservation (:300-324) + goal; and
+ * reset (:222-270, :476-479): goal drawn from goal_table, [UPSTREAM MinitaurEnvRandomizer, from memory] battery voltage U(14.8, 16.8) and motor viscous
+ * damping U(0, 0.01) when cfg.randomize (its mass / friction randomisation is not built), pose <- reset_qpos, settle_steps x (ApplyAction(pi / 2), timestep).
+ * obs [32] float64: motor angles 8, motor velocities 8, observed motor torques 8 (all in motor space = joint x direction), base orientation (x, y, z, w),
+ * base x y, goal x y. */
+typedef struct earl_minitaur_cfg {
+  int32_t n, env_offset;
+  int32_t horizon;                 /* <= 0: never done */
+  int32_t num_substeps;            /* 5  (minitaur_gym_env.py:25, 161-164) */
+  int32_t settle_steps;            /* 100 (:265-269) */
+  int32_t randomize;               /* per-reset battery voltage / viscous damping draws; 0: 16 V, 0 */
+  int32_t n_goals;                 /* rows of goal_table: 12 (:467-469) */
+  int32_t goal_change_frequency;   /* > 0: LifelongWrapper.step (lifelong_wrapper.py:30-44), as in earl_sawyer_cfg */
+  int32_t overheat_steps;          /* OVERHEAT_SHUTDOWN_TIME / time_step = 500 (minitaur.py:14-15, 356) */
+  int32_t motor_dof[8];            /* dof of motor i (MOTOR_NAMES order, minitaur.py:18-22) */
+  int32_t pad_;
+  double motor_dir[8];             /* minitaur.py:80 */
+  double motor_kp, motor_kd;       /* 1.0, 0.02 (minitaur_gym_env.py:85-86) */
+  double motor_velocity_limit;     /* 150 (:472) */
+  double overheat_torque;          /* 2.45 */
+  double distance_weight, energy_weight;   /* 2.0, 0.005 (:473, :71) */
+  double success_radius;           /* 0.1 (:500) */
+  const double* goal_table;        /* device, [n_goals, 2] */
+  const double* reset_qpos;        /* device, [23]: base (0, 0, 0.2), identity, motor joints dir pi / 2, knee joints dir -2.1834 (minitaur.py:10-11, 187-211) */
+  uint64_t seed, counter;          /* reset draws: Philox(seed; 0x4D00 + k, global env id, counter), k = 0 goal, 1 voltage, 2 damping */
+  uint64_t step_counter;           /* env steps taken before this launch (goal-switch draws: Philox(seed; 0xFFFE, global env id, step)) */
+} earl_minitaur_cfg;
+typedef struct earl_minitaur_state {
+  double* qpos;                    /* [n, 23] */
+  double* qvel;                    /* [n, 22] */
+  double* goal;                    /* [n, 2] */
+  double* motor_param;             /* [n, 2] battery voltage, motor viscous damping */
+  double* observed_torque;         /* [n, 8] Minitaur._observed_motor_torques of the newest ApplyAction */
+  int32_t* overheat;               /* [n, 8] Minitaur._overheat_counter */
+  uint8_t* motor_enabled;          /* [n, 8] Minitaur._motor_enabled_list */
+  int32_t* steps_since_reset;      /* [n] */
+  int32_t* steps_since_goal_change;   /* [n]; may be NULL when cfg.goal_change_frequency == 0 */
+  int32_t* fail_count;             /* [n] may be NULL */
+  double* last_obs;                /* [n, 32] may be NULL (as in earl_sawyer_state) */
+} earl_minitaur_state;
+typedef struct earl_minitaur_out {
+  double* obs;                     /* [T, n, 32] */
+  double* reward;                  /* [T, n] float64, like the reference's */
+  uint8_t* done; uint8_t* success;
+  uint8_t* status;                 /* [T, n] may be NULL: EARL_STEP_DIVERGED as in earl_sawyer_out (state rolled back, last stable observation, reward 0) */
+} earl_minitaur_out;
+/* T env steps of every env in ONE launch; action float32 [T, n, 8] in [-1, 1] (the reference raises ValueError beyond +-1.01: the Python front end
+ * checks; the kernel clips to +-1.01). */
+int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
+                          const float* action, int32_t T, const earl_minitaur_out* out, earl_stream_t stream);
+/* reset the envs with mask[i] != 0 (NULL = all); obs [n, 32] (may be NULL) is written for the reset envs only */
+int earl_minitaur_reset(const void* model24, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
+                        const uint8_t* mask, double* obs, earl_stream_t stream);
+int earl_minitaur_cfg_size(void);
 
 /* measurement / test switch for the door model's rollout: 0 (default) = by batch size (n > 4096: one eight-wave workgroup per CU, see
  * csrc/physics_w8.hip; otherwise four single-wave workgroups per CU), 1 / 2 force the one or the other.  Results are bit-identical. */

@@ -17,7 +17,7 @@
 #include "../include/earl_physics.h"
 
 #define NVMAX EARL_MAXV24
-#define NROWMAX (6 + 2 * EARL_MAXV24 + EARL_MAXV24 + EARL_MAXJEQ + 4 * EARL_MAXCON)
+#define NROWMAX (6 + 2 * EARL_MAXV24 + EARL_MAXV24 + EARL_MAXJEQ + 3 * EARL_MAXCONNECT + 4 * EARL_MAXCON)
 
 /* The stepper below works on the 24-dof table form (earl_link_model24: the kitchen's, with dry friction / springs / force limits / joint
  * couplings); a 16-dof model (the Sawyer envs') is widened into it first -- the extras empty. */
@@ -144,9 +144,12 @@ static Q4 qnormalize(Q4 q) {
 /* one timestep (integrate != 0) or the forward quantities only; reference: LinkModel.forward / step.
  * qp is a qpos row [nq] (the free body's quaternion at [ball_dof, ball_dof + 4)), qv a qvel row [nv]. */
 static void substep(const LM* m, const earl_collision_model* col, double* qp, double* qv, V3 mpos, Q4 mq, const double* ctrl,
-                    int integrate, StepOut* o) {
+                    int integrate, StepOut* o, const double* qfrc) {
+  /* qfrc: generalized forces applied from outside (the minitaur's motor torques), or NULL */
   const int nv = m->nv;
   const double dt = m->dt;
+  /* qpos slot of dof l (LinkModel.qadr): a free ROOT body (the minitaur's base) keeps MuJoCo's layout [xyz, quaternion, joints] */
+#define QA(l) ((l) + ((m->ball_dof >= 0 && (l) > m->ball_dof + 2) ? 1 : 0))
   double S[NVMAX][6], I10[NVMAX][10], Ic[NVMAX][10], M[NVMAX][NVMAX], tau[NVMAX];
   /* kinematics (parents precede children) */
   for (int l = 0; l < nv; ++l) {
@@ -162,7 +165,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     const V3 ax = ld3(m->jaxis[l]);
     const V3 anchor = add(x, mulv(R, ld3(m->jpos[l]))), axw = mulv(R, ax);
     if (m->jtype[l] == 0) {
-      const double h = 0.5 * qp[l], sn = sin(h), cs = cos(h);
+      const double h = 0.5 * qp[QA(l)], sn = sin(h), cs = cos(h);
       Q4 qj = {cs, sn * ax.x, sn * ax.y, sn * ax.z};
       q = qmul(q, qj);
       qmat(q, R);
@@ -182,7 +185,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       const V3 sv = cross(anchor, a2);
       S[l][0] = a2.x; S[l][1] = a2.y; S[l][2] = a2.z; S[l][3] = sv.x; S[l][4] = sv.y; S[l][5] = sv.z;
     } else {
-      x = add(x, scl(axw, qp[l]));
+      x = add(x, scl(axw, qp[QA(l)]));
       S[l][0] = S[l][1] = S[l][2] = 0; S[l][3] = axw.x; S[l][4] = axw.y; S[l][5] = axw.z;
     }
     o->Xq[l][0] = q.w; o->Xq[l][1] = q.x; o->Xq[l][2] = q.y; o->Xq[l][3] = q.z;
@@ -245,19 +248,20 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     for (int l = 0; l < nv; ++l) {
       double bias = 0;
       for (int e = 0; e < 6; ++e) bias += S[l][e] * F[l][e];
-      tau[l] = -m->damping[l] * qv[l] - bias - m->stiffness[l] * (qp[l] - m->springref[l]);     /* (+ joint spring, mj_passive) */
+      tau[l] = -m->damping[l] * qv[l] - bias - m->stiffness[l] * (qp[QA(l)] - m->springref[l]);     /* (+ joint spring, mj_passive) */
+      if (qfrc) tau[l] += qfrc[l];
     }
     for (int ac = 0; ac < m->n_act; ++ac) {
       const int j = m->act_joint[ac];
       const double c = fmin(fmax(ctrl[ac], m->act_ctrlrange[ac][0]), m->act_ctrlrange[ac][1]);
-      tau[j] += fmin(fmax(m->act_kp[ac] * (c - qp[j]), m->act_forcerange[ac][0]), m->act_forcerange[ac][1]);   /* forcelimited actuator */
+      tau[j] += fmin(fmax(m->act_kp[ac] * (c - qp[QA(j)]), m->act_forcerange[ac][0]), m->act_forcerange[ac][1]);   /* forcelimited actuator */
     }
   }
   /* constraint rows */
   double J[NROWMAX][NVMAX], aref[NROWMAX], D[NROWMAX];
   int iseq[NROWMAX], rowid[NROWMAX], nr = 0;       /* rowid: position in the efc output (weld 0..5, limits 6 + 2 j + side), -1 otherwise */
   memset(J, 0, sizeof(J));
-  {
+  if (m->weld_att >= 0) {                            /* (the minitaur model has no mocap weld) */
     const int k = m->weld_att, la = m->att_link[k];
     double R[3][3], Rh[3][3];
     const Q4 ql = ldq(o->Xq[la]);
@@ -291,7 +295,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
   for (int j = 0; j < nv; ++j) {
     if (!m->limited[j]) continue;
     for (int side = 0; side < 2; ++side) {
-      const double res = side == 0 ? qp[j] - m->range[j][0] : m->range[j][1] - qp[j];
+      const double res = side == 0 ? qp[QA(j)] - m->range[j][0] : m->range[j][1] - qp[QA(j)];
       if (!(res < 0)) continue;
       const double sg = side == 0 ? 1.0 : -1.0;
       double kk, bb, dd;
@@ -310,7 +314,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     }
   for (int e = 0; e < m->n_jeq; ++e) {              /* joint couplings q1 - c0 - c1 q2 = 0 (LinkModel.forward) */
     const int j1 = m->jeq_joint1[e], j2 = m->jeq_joint2[e];
-    const double c0 = m->jeq_coef[e][0], c1 = m->jeq_coef[e][1], res = qp[j1] - c0 - c1 * qp[j2];
+    const double c0 = m->jeq_coef[e][0], c1 = m->jeq_coef[e][1], res = qp[QA(j1)] - c0 - c1 * qp[QA(j2)];
     double kk, bb, dd;
     kbimp(m->jeq_solref[e], m->jeq_solimp[e], res, dt, &kk, &bb, &dd);
     J[nr][j1] = 1.0; J[nr][j2] = -c1;
@@ -318,6 +322,31 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     D[nr] = 1.0 / fmax((1 - dd) / dd * m->jeq_invweight[e], 1e-15);
     iseq[nr] = 1; rowid[nr] = -1;
     ++nr;
+  }
+  for (int e = 0; e < m->n_con; ++e) {              /* connect constraints: attachments con_att1 / con_att2 coincide (LinkModel.forward) */
+    V3 p[2];
+    for (int t = 0; t < 2; ++t) {
+      const int k = t == 0 ? m->con_att1[e] : m->con_att2[e], la = m->att_link[k];
+      double R[3][3];
+      qmat(ldq(o->Xq[la]), R);
+      p[t] = add(ld3(o->Xp[la]), mulv(R, ld3(m->att_pos[k])));
+      const double sg = t == 0 ? 1.0 : -1.0;
+      for (int j = la; j >= 0; j = m->parent[j]) {
+        const V3 pv = scl(add(ld3(S[j] + 3), cross(ld3(S[j]), p[t])), sg);
+        J[nr][j] += pv.x; J[nr + 1][j] += pv.y; J[nr + 2][j] += pv.z;
+      }
+    }
+    const V3 r3 = sub(p[0], p[1]);
+    for (int c = 0; c < 3; ++c) {
+      const double res = pick(r3, c);
+      double Jv = 0, kk, bb, dd;
+      for (int j = 0; j < nv; ++j) Jv += J[nr][j] * qv[j];
+      kbimp(m->con_solref[e], m->con_solimp[e], res, dt, &kk, &bb, &dd);
+      aref[nr] = -bb * Jv - kk * dd * res;
+      D[nr] = 1.0 / fmax((1 - dd) / dd * m->con_invweight[e], 1e-15);
+      iseq[nr] = 1; rowid[nr] = -1;
+      ++nr;
+    }
   }
   /* dry joint friction: rows with a bounded force (state 0 quadratic, +-1 saturated), kept apart from the unilateral rows */
   int fj[NVMAX], fs[NVMAX], nf = 0;
@@ -521,7 +550,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     }
     chol_solve(nv, H, rhs);
     const int bd = m->ball_dof;
-    for (int i = 0; i < nv; ++i) { qv[i] += dt * rhs[i]; if (bd < 0 || i < bd) qp[i] += dt * qv[i]; }
+    for (int i = 0; i < nv; ++i) { qv[i] += dt * rhs[i]; if (bd < 0 || i < bd || i > bd + 2) qp[QA(i)] += dt * qv[i]; }
     if (bd >= 0) {   /* mju_quatIntegrate (LinkModel.integrate_pos) */
       const V3 w = ld3(qv + bd);
       const double nw = sqrt(dot(w, w));
@@ -565,7 +594,7 @@ static int physics24(const LM* m, const earl_collision_model* col, int32_t n, in
     const V3 mpos = ld3(mocap_pos + 3 * (size_t)e);
     const Q4 mq = g_raw_mocap_quat ? ldq(mocap_quat + 4 * (size_t)e) : qnormalize(ldq(mocap_quat + 4 * (size_t)e));
     for (int ts = 0; ts < (integrate ? nsub : 1); ++ts)
-      substep(m, col, qpos + (size_t)e * m->nq, qvel + (size_t)e * nv, mpos, mq, ctrl + (size_t)e * m->n_act, integrate, &o);
+      substep(m, col, qpos + (size_t)e * m->nq, qvel + (size_t)e * nv, mpos, mq, ctrl + (size_t)e * m->n_act, integrate, &o, NULL);
     if (qacc) memcpy(qacc + (size_t)e * nv, o.qacc, sizeof(double) * nv);
     if (efc) memcpy(efc + (size_t)e * (6 + 2 * nv), o.efc, sizeof(double) * (6 + 2 * nv));
     if (ncon) ncon[e] = o.ncon;
@@ -631,7 +660,7 @@ int oracle_sawyer_rollout(const earl_link_model* m16, const earl_collision_model
         mp2[k] = fmin(fmax(mp[k] + (double)c, cfg->mocap_low[k]), cfg->mocap_high[k]);
       }
       o.warm = 0;                                     /* every env step starts cold: step-by-step and fused rollouts agree */
-      for (int ts = 0; ts < cfg->frame_skip; ++ts) substep(m, col, q2, v2, ld3(mp2), mq, ctrl, 1, &o);
+      for (int ts = 0; ts < cfg->frame_skip; ++ts) substep(m, col, q2, v2, ld3(mp2), mq, ctrl, 1, &o, NULL);
       const size_t row = (size_t)t * n + e;
       double* ob = out->obs + row * 14;
       int failed = 0;
@@ -686,6 +715,163 @@ int oracle_sawyer_rollout(const earl_link_model* m16, const earl_collision_model
     if (st->steps_since_reset) st->steps_since_reset[e] = steps;
     if (gcf > 0) st->steps_since_goal_change[e] = sgc;
     if (st->last_obs && T > 0) memcpy(st->last_obs + (size_t)e * 14, out->obs + ((size_t)(T - 1) * n + e) * 14, sizeof(double) * 14);
+  }
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------------
+ * Minitaur env on the same stepper (restates oracle/minitaur_oracle.py, which follows earl_benchmark/envs/minitaur_gym_env.py:222-329, 466-546 and
+ * envs/minitaur.py:300-457): host-array form of earl_minitaur_rollout / earl_minitaur_reset (include/earl_physics.h).  PARITY WITH THE REFERENCE'S
+ * PYBULLET SIMULATION IS UNPINNED AND MODEL-LESS: the robot model is this build's own (tools/minitaur_model.py). */
+int oracle_minitaur_leg_to_motor(int32_t n, const double* action, double* motor_angle);                       /* glue_oracle.c: minitaur.py:434-457 */
+struct earl_motor_params_ { double kp, kd, voltage, viscous_damping; int32_t torque_control; };              /* = earl_motor_params (include/earl_glue.h) */
+int oracle_minitaur_motor_torque(int32_t m, const struct earl_motor_params_* p, const double* command, const double* angle, const double* velocity,
+                                 double* actual_torque, double* observed_torque);                             /* glue_oracle.c: motor.py:49-94 */
+
+typedef struct { double voltage, viscous; double* observed; int32_t* overheat; uint8_t* enabled; } MtMotors;
+
+/* Minitaur.ApplyAction (minitaur.py:326-390) -> generalized forces qfrc [nv] */
+static void mt_apply_action(const LM* m, const earl_minitaur_cfg* cfg, const double* qp, const double* qv, const double* cmd, MtMotors* mt, double* qfrc) {
+  double q[8], qd[8], c[8], actual[8], observed[8];
+  const double lim = m->dt * cfg->motor_velocity_limit;
+  for (int i = 0; i < 8; ++i) {
+    const int d = cfg->motor_dof[i];
+    q[i] = qp[QA(d)] * cfg->motor_dir[i];                                  /* GetMotorAngles :392-404 */
+    qd[i] = qv[d] * cfg->motor_dir[i];
+    c[i] = fmin(fmax(cmd[i], q[i] - lim), q[i] + lim);                     /* :339-343 (np.clip) */
+  }
+  const struct earl_motor_params_ p = {cfg->motor_kp, cfg->motor_kd, mt->voltage, mt->viscous, 0};
+  oracle_minitaur_motor_torque(8, &p, c, q, qd, actual, observed);
+  for (int l = 0; l < m->nv; ++l) qfrc[l] = 0;
+  for (int i = 0; i < 8; ++i) {
+    if (fabs(actual[i]) > cfg->overheat_torque) mt->overheat[i] += 1; else mt->overheat[i] = 0;     /* :351-358 */
+    if (mt->overheat[i] > cfg->overheat_steps) mt->enabled[i] = 0;
+    mt->observed[i] = observed[i];
+    qfrc[cfg->motor_dof[i]] = mt->enabled[i] ? actual[i] * cfg->motor_dir[i] : 0.0;
+  }
+}
+static void mt_observe(const LM* m, const earl_minitaur_cfg* cfg, const double* qp, const double* qv, const double* observed, const double* goal, double* ob) {
+  for (int i = 0; i < 8; ++i) {
+    const int d = cfg->motor_dof[i];
+    ob[i] = qp[QA(d)] * cfg->motor_dir[i]; ob[8 + i] = qv[d] * cfg->motor_dir[i]; ob[16 + i] = observed[i];
+  }
+  const int bd = m->ball_dof;
+  ob[24] = qp[bd + 1]; ob[25] = qp[bd + 2]; ob[26] = qp[bd + 3]; ob[27] = qp[bd];      /* Bullet's (x, y, z, w) */
+  ob[28] = qp[0]; ob[29] = qp[1]; ob[30] = goal[0]; ob[31] = goal[1];
+}
+static double mt_draw(const earl_minitaur_cfg* cfg, int k, int e, uint64_t counter, uint32_t stream) {
+  const uint32_t ctr[4] = {stream + (uint32_t)k, (uint32_t)(cfg->env_offset + e), (uint32_t)counter, (uint32_t)(counter >> 32)};
+  const uint32_t key[2] = {(uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32)};
+  uint32_t b[4];
+  oracle_philox4x32_10(ctr, key, b);
+  return u01_(b[0], b[1]);
+}
+
+int oracle_minitaur_reset(const earl_link_model24* m, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
+                          const uint8_t* mask, double* obs) {
+  const int nv = m->nv, n = cfg->n;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < n; ++e) {
+    if (mask && !mask[e]) continue;
+    double* qp = st->qpos + (size_t)e * m->nq;
+    double* qv = st->qvel + (size_t)e * nv;
+    double* goal = st->goal + (size_t)e * 2;
+    int gi = (int)(mt_draw(cfg, 0, e, cfg->counter, 0x4D00u) * (double)cfg->n_goals);       /* get_next_goal :490-493 */
+    if (gi >= cfg->n_goals) gi = cfg->n_goals - 1;
+    goal[0] = cfg->goal_table[2 * gi]; goal[1] = cfg->goal_table[2 * gi + 1];
+    double* mp = st->motor_param + (size_t)e * 2;
+    if (cfg->randomize) { mp[0] = 14.8 + (16.8 - 14.8) * mt_draw(cfg, 1, e, cfg->counter, 0x4D00u); mp[1] = 0.01 * mt_draw(cfg, 2, e, cfg->counter, 0x4D00u); }
+    else { mp[0] = 16.0; mp[1] = 0.0; }
+    memcpy(qp, cfg->reset_qpos, sizeof(double) * m->nq);
+    for (int k = 0; k < nv; ++k) qv[k] = 0;
+    MtMotors mt = {mp[0], mp[1], st->observed_torque + (size_t)e * 8, st->overheat + (size_t)e * 8, st->motor_enabled + (size_t)e * 8};
+    for (int i = 0; i < 8; ++i) { mt.observed[i] = 0; mt.overheat[i] = 0; mt.enabled[i] = 1; }
+    StepOut o;
+    o.warm = 0;
+    double cmd[8], qfrc[NVMAX];
+    for (int i = 0; i < 8; ++i) cmd[i] = 3.141592653589793 / 2;
+    const Q4 mq = {1, 0, 0, 0};
+    for (int s = 0; s < cfg->settle_steps; ++s) {                                             /* minitaur_gym_env.py:265-269 */
+      mt_apply_action(m, cfg, qp, qv, cmd, &mt, qfrc);
+      substep(m, col, qp, qv, v3(0, 0, 0), mq, NULL, 1, &o, qfrc);
+    }
+    if (st->steps_since_reset) st->steps_since_reset[e] = 0;
+    if (st->steps_since_goal_change) st->steps_since_goal_change[e] = 0;
+    double ob[32];
+    mt_observe(m, cfg, qp, qv, mt.observed, goal, ob);
+    if (obs) memcpy(obs + (size_t)e * 32, ob, sizeof(ob));
+    if (st->last_obs) memcpy(st->last_obs + (size_t)e * 32, ob, sizeof(ob));
+  }
+  return 0;
+}
+
+int oracle_minitaur_rollout(const earl_link_model24* m, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
+                            const float* action, int32_t T, const earl_minitaur_out* out) {
+  const int nv = m->nv, n = cfg->n;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < n; ++e) {
+    StepOut o;
+    double* qp = st->qpos + (size_t)e * m->nq;
+    double* qv = st->qvel + (size_t)e * nv;
+    double* goal = st->goal + (size_t)e * 2;
+    const double* mp = st->motor_param + (size_t)e * 2;
+    int steps = st->steps_since_reset ? st->steps_since_reset[e] : 0;
+    const int gcf = st->steps_since_goal_change ? cfg->goal_change_frequency : 0;
+    int sgc = gcf > 0 ? st->steps_since_goal_change[e] : 0;
+    const Q4 mq = {1, 0, 0, 0};
+    for (int t = 0; t < T; ++t) {
+      const float* a = action + ((size_t)t * n + e) * 8;
+      double a64[8], cmd[8], qfrc[NVMAX];
+      for (int k = 0; k < 8; ++k) a64[k] = fmin(fmax((double)a[k], -1.01), 1.01);             /* (the front end raises beyond the reference's bound) */
+      oracle_minitaur_leg_to_motor(1, a64, cmd);
+      /* failure guard: work on copies, commit only when the env step ended finite */
+      double q2[NVMAX + 1], v2[NVMAX], obs2[8];
+      int32_t oh2[8];
+      uint8_t en2[8];
+      memcpy(q2, qp, sizeof(double) * m->nq); memcpy(v2, qv, sizeof(double) * nv);
+      memcpy(obs2, st->observed_torque + (size_t)e * 8, sizeof(obs2)); memcpy(oh2, st->overheat + (size_t)e * 8, sizeof(oh2)); memcpy(en2, st->motor_enabled + (size_t)e * 8, sizeof(en2));
+      MtMotors mt = {mp[0], mp[1], obs2, oh2, en2};
+      o.warm = 0;
+      for (int s = 0; s < cfg->num_substeps; ++s) {                                           /* minitaur_gym_env.py:321-323 */
+        mt_apply_action(m, cfg, q2, v2, cmd, &mt, qfrc);
+        substep(m, col, q2, v2, v3(0, 0, 0), mq, NULL, 1, &o, qfrc);
+      }
+      const size_t row = (size_t)t * n + e;
+      double* ob = out->obs + row * 32;
+      int failed = 0;
+      for (int k = 0; k < m->nq; ++k) failed |= !(fabs(q2[k]) < EARL_BAD_VALUE);
+      for (int k = 0; k < nv; ++k) failed |= !(fabs(v2[k]) < EARL_BAD_VALUE);
+      ++steps;
+      if (out->status) out->status[row] = failed ? EARL_STEP_DIVERGED : 0;
+      if (out->done) out->done[row] = (cfg->horizon > 0 && steps >= cfg->horizon) ? 1 : 0;
+      if (failed) {
+        const double* prev = t > 0 ? out->obs + ((size_t)(t - 1) * n + e) * 32 : (st->last_obs ? st->last_obs + (size_t)e * 32 : NULL);
+        for (int k = 0; k < 32; ++k) ob[k] = prev ? prev[k] : NAN;
+        if (out->reward) out->reward[row] = 0.0;
+        if (out->success) out->success[row] = 0;
+        if (st->fail_count) st->fail_count[e] += 1;
+      } else {
+        memcpy(qp, q2, sizeof(double) * m->nq); memcpy(qv, v2, sizeof(double) * nv);
+        memcpy(st->observed_torque + (size_t)e * 8, obs2, sizeof(obs2)); memcpy(st->overheat + (size_t)e * 8, oh2, sizeof(oh2)); memcpy(st->motor_enabled + (size_t)e * 8, en2, sizeof(en2));
+        mt_observe(m, cfg, qp, qv, obs2, goal, ob);
+        /* _reward :505-521 (= compute_reward :529-535 on this observation), is_successful :495-503 */
+        const double xd = ob[28] - goal[0], yd = ob[29] - goal[1];
+        double dotp = 0.0;
+        for (int k = 0; k < 8; ++k) dotp = fma(ob[16 + k], ob[8 + k], dotp);
+        if (out->reward) out->reward[row] = cfg->distance_weight * (-fabs(xd) - fabs(yd)) - cfg->energy_weight * (fabs(dotp) * m->dt);
+        if (out->success) out->success[row] = (uint8_t)(sqrt(xd * xd + yd * yd) < cfg->success_radius);
+      }
+      if (gcf > 0 && ++sgc >= gcf) {   /* LifelongWrapper.step, lifelong_wrapper.py:36-42: new goal, observation re-read with it */
+        sgc = 0;
+        int gi = (int)(mt_draw(cfg, 0, e, cfg->step_counter + (uint64_t)t, 0xFFFEu) * (double)cfg->n_goals);
+        if (gi >= cfg->n_goals) gi = cfg->n_goals - 1;
+        goal[0] = cfg->goal_table[2 * gi]; goal[1] = cfg->goal_table[2 * gi + 1];
+        ob[30] = goal[0]; ob[31] = goal[1];
+      }
+    }
+    if (st->steps_since_reset) st->steps_since_reset[e] = steps;
+    if (gcf > 0) st->steps_since_goal_change[e] = sgc;
+    if (st->last_obs && T > 0) memcpy(st->last_obs + (size_t)e * 32, out->obs + ((size_t)(T - 1) * n + e) * 32, sizeof(double) * 32);
   }
   return 0;
 }

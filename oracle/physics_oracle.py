@@ -658,6 +658,11 @@ class LinkModel:
     self.nv = len(self.parent)
     self.dt = float(self.timestep)
     self.max_contacts = int(self.max_contacts)
+    # qpos index of dof l: with a free body the orientation quaternion takes FOUR qpos slots at ball_dof .. ball_dof + 3 (MuJoCo's layout), so the
+    # dofs behind its three rotation dofs sit one slot further (a free ROOT body -- the minitaur's base: qpos = [xyz, quat, joints]); a free body whose
+    # rotation dofs are the last three (the peg) has none behind it
+    bd_ = int(getattr(self, 'ball_dof', -1))
+    self.qadr = np.array([l + 1 if (bd_ >= 0 and l > bd_ + 2) else l for l in range(self.nv)])
     self.anc = []
     for l in range(self.nv):
       a, p = [l], self.parent[l]
@@ -681,12 +686,12 @@ class LinkModel:
       R = quat_mat(q)
       anchor, axis = x + R @ self.jpos[l], R @ self.jaxis[l]
       if self.jtype[l] == 0:
-        h = 0.5 * qpos[l]
+        h = 0.5 * qpos[self.qadr[l]]
         q = quat_mul(q, np.concatenate([[np.cos(h)], np.sin(h) * self.jaxis[l]]))
         x = anchor - quat_mat(q) @ self.jpos[l]
         S[l, :3], S[l, 3:] = axis, np.cross(anchor, axis)
       elif self.jtype[l] == 1:
-        x = x + axis * qpos[l]
+        x = x + axis * qpos[self.qadr[l]]
         S[l, 3:] = axis
       else:
         if self.jtype[l] == 2:
@@ -704,7 +709,9 @@ class LinkModel:
     if bd < 0:
       return qpos + self.dt * qvel
     out = np.array(qpos, float)
-    out[:bd] = qpos[:bd] + self.dt * qvel[:bd]
+    for l in range(self.nv):
+      if not bd <= l <= bd + 2:
+        out[self.qadr[l]] = qpos[self.qadr[l]] + self.dt * qvel[l]
     w = qvel[bd:bd + 3]
     nw = np.sqrt(w @ w)
     qn = qpos[bd:bd + 4] / np.sqrt(qpos[bd:bd + 4] @ qpos[bd:bd + 4])
@@ -720,7 +727,8 @@ class LinkModel:
       return self.att_pos[k].copy(), self.att_quat[k].copy()
     return pos[l] + quat_mat(quat[l]) @ self.att_pos[k], quat_mul(quat[l], self.att_quat[k])
 
-  def forward(self, qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev=None):
+  def forward(self, qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev=None, qfrc=None):
+    """qfrc: generalized forces applied from outside (the minitaur's motor torques, computed by the env's motor model per timestep), or None"""
     nv = self.nv
     pos, quat, S = self.kinematics(qpos)
     I6 = []
@@ -762,10 +770,13 @@ class LinkModel:
       if hasattr(self, 'act_forcerange'):          # forcelimited actuators (mj_fwdActuation clamps the actuator force)
         frc = float(np.clip(frc, *self.act_forcerange[a]))
       tau[j] += frc
+    if qfrc is not None:
+      tau = tau + np.asarray(qfrc, float)
     a0 = np.linalg.solve(M, tau)
     # constraint rows: 6 weld rows (equalities), then lower / upper limit of every dof, then 4 pyramid edges per contact
     k = int(self.weld_att)
-    hp, hq = self.attachment(pos, quat, k)
+    has_weld = k >= 0                                        # (the minitaur model has no mocap weld: its six rows are never instantiated)
+    hp, hq = self.attachment(pos, quat, k) if has_weld else (np.zeros(3), np.array([1.0, 0, 0, 0]))
     nlim = 6 + 2 * nv
     J = np.zeros((nlim, nv)); res = np.zeros(nlim); inst = np.zeros(nlim, bool)
     solref = [self.weld_solref[0]] * 6; solimp = [self.weld_solimp[0]] * 6
@@ -777,16 +788,16 @@ class LinkModel:
     q1 = np.asarray(mocap_quat, dtype=np.float64)           # as given, not normalised (rule replacing round 1's rotational factor)
     e = quat_mul(quat_conj(hq), q1)
     Rh = quat_mat(hq)
-    for j in self.anc[self.att_link[k]]:
+    for j in (self.anc[self.att_link[k]] if has_weld else ()):
       J[0:3, j] = -(S[j, 3:] + np.cross(S[j, :3], hp))
       a = Rh.T @ S[j, :3]
       J[3:6, j] = -0.5 * (e[0] * a + np.cross(a, e[1:]))
-    res[0:3] = mocap_pos - hp
-    res[3:6] = e[1:]
-    inst[:6] = True
+    res[0:3] = (mocap_pos - hp) if has_weld else 0.0
+    res[3:6] = e[1:] if has_weld else 0.0
+    inst[:6] = has_weld
     for j in range(nv):
       J[6 + 2 * j, j], J[7 + 2 * j, j] = 1.0, -1.0
-      res[6 + 2 * j], res[7 + 2 * j] = qpos[j] - self.jnt_range[j, 0], self.jnt_range[j, 1] - qpos[j]
+      res[6 + 2 * j], res[7 + 2 * j] = qpos[self.qadr[j]] - self.jnt_range[j, 0], self.jnt_range[j, 1] - qpos[self.qadr[j]]
       inst[6 + 2 * j] = bool(self.jnt_limited[j]) and res[6 + 2 * j] < 0
       inst[7 + 2 * j] = bool(self.jnt_limited[j]) and res[7 + 2 * j] < 0
       solref += [self.jnt_solref[j]] * 2; solimp += [self.jnt_solimp[j]] * 2; invw += [self.dof_invweight0[j]] * 2
@@ -810,6 +821,21 @@ class LinkModel:
       kk, bb, dd = kbimp(self.jeq_solref[e], self.jeq_solimp[e], r_, self.dt)
       J = np.vstack([J, row]); aref = np.append(aref, -bb * (row @ qvel) - kk * dd * r_)
       Rg = np.append(Rg, max((1 - dd) / dd * self.jeq_invweight[e], 1e-15)); inst = np.append(inst, True); res = np.append(res, r_)
+    # connect constraints (MuJoCo mjEQ_CONNECT; Bullet's JOINT_POINT2POINT of the minitaur's four knee closures, envs/minitaur.py:212-217): the world
+    # positions of two attachments coincide -- three soft equality rows, residual p1 - p2, Jacobian Jp(link1, p1) - Jp(link2, p2)
+    for e in range(len(getattr(self, 'con_att1', ()))):
+      k1, k2 = int(self.con_att1[e]), int(self.con_att2[e])
+      p1, _ = self.attachment(pos, quat, k1)
+      p2, _ = self.attachment(pos, quat, k2)
+      Jp = np.zeros((3, nv))
+      for kk_, pp_, sg in ((k1, p1, 1.0), (k2, p2, -1.0)):
+        for j in self.anc[self.att_link[kk_]]:
+          Jp[:, j] += sg * (S[j, 3:] + np.cross(S[j, :3], pp_))
+      r3 = p1 - p2
+      for c in range(3):
+        kk, bb, dd = kbimp(self.con_solref[e], self.con_solimp[e], r3[c], self.dt)
+        J = np.vstack([J, Jp[c]]); aref = np.append(aref, -bb * (Jp[c] @ qvel) - kk * dd * r3[c])
+        Rg = np.append(Rg, max((1 - dd) / dd * self.con_invweight[e], 1e-15)); inst = np.append(inst, True); res = np.append(res, r3[c])
     n_eq_extra = len(aref) - nlim
     # dry joint friction (mjCNSTR_FRICTION_DOF): one row per dof with frictionloss, residual 0, force bounded by +- frictionloss
     fric = []
@@ -821,7 +847,7 @@ class LinkModel:
       Jc, arc, Rc = self.contact_rows(contacts, S, qvel)
       J, aref, Rg = np.vstack([J, Jc]), np.concatenate([aref, arc]), np.concatenate([Rg, Rc])
       inst = np.concatenate([inst, np.ones(len(arc), bool)])
-    is_eq = np.zeros(len(aref), bool); is_eq[:6] = True; is_eq[nlim:nlim + n_eq_extra] = True
+    is_eq = np.zeros(len(aref), bool); is_eq[:6] = has_weld; is_eq[nlim:nlim + n_eq_extra] = True
     qacc, act = self.solve_primal(M, tau, J[inst], aref[inst], 1.0 / Rg[inst], is_eq[inst], fric=fric, **({} if a_prev is None else dict(a_prev=a_prev)))
     f = np.zeros(len(aref)); active = np.zeros(len(aref), bool)
     idx = np.nonzero(inst)[0]
@@ -989,9 +1015,9 @@ class LinkModel:
         R.append(2 * mu * mu * R0)
     return np.array(J), np.array(aref), np.array(R)
 
-  def step(self, qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev=None):
+  def step(self, qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev=None, qfrc=None):
     """a_prev: out['qacc'] of the previous timestep of the same env step (warm start of the active-set iteration), None = cold"""
-    out = self.forward(qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev)
+    out = self.forward(qpos, qvel, ctrl, mocap_pos, mocap_quat, a_prev, qfrc)
     M = out['M']
     qacc = np.linalg.solve(M + self.dt * np.diag(self.jnt_damping), M @ out['qacc'])
     qvel = qvel + self.dt * qacc

@@ -1,0 +1,125 @@
+"""Minitaur env on the HIP stepper (csrc/physics_mt.hip) against this build's CPU statement (oracle/physics_oracle.c via oracle.physics_c.CMinitaur,
+itself checked against the numpy statement in tests/test_minitaur.py), through the C ABI / the env class.  PARITY WITH THE REFERENCE'S PYBULLET
+SIMULATION IS UNPINNED AND MODEL-LESS: these tests pin the kernel to the CPU statement of the same model, nothing more."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+@pytest.fixture(scope='module')
+def torch():
+  import torch
+  return torch
+
+
+def make(n, **kw):
+  from earl_benchmark_amd.envs.minitaur import Minitaur
+  return Minitaur(num_envs=n, scalar_api=False, **kw)
+
+
+def test_reset_and_steps_match_the_cpu_statement(torch):
+  from oracle import physics_c
+  n, T = 37, 30
+  env = make(n, seed=5, env_offset=3)
+  c = physics_c.CMinitaur(n, seed=5, env_offset=3)
+  c.reset()                                                    # (the constructor's reset)
+  np.testing.assert_allclose(env.last_obs.cpu().numpy(), c.last_obs, rtol=0, atol=TOL)
+  np.testing.assert_array_equal(env.goal_t.cpu().numpy(), c.goal)
+  np.testing.assert_array_equal(env.motor_param.cpu().numpy(), c.motor_param)      # Philox draws: identical bits
+  o = env.reset()
+  oc = c.reset()
+  np.testing.assert_allclose(o.cpu().numpy(), oc, rtol=0, atol=TOL)
+  rng = np.random.default_rng(0)
+  acts = rng.uniform(-1, 1, (T, n, 8)).astype(np.float32)
+  worst = 0.0
+  for t in range(T):                                           # per-step launches, re-synchronised per step (chaotic contacts: no long open-loop comparison)
+    ob, r, done, info = env.step(torch.from_numpy(acts[t]).cuda())
+    c.qpos[:], c.qvel[:] = c.qpos, c.qvel
+    res = c.rollout(acts[t:t + 1])
+    d = np.abs(ob.cpu().numpy() - res['obs'][0]).max()
+    worst = max(worst, d)
+    assert d < TOL, (t, d)
+    np.testing.assert_allclose(r.cpu().numpy(), res['reward'][0], rtol=0, atol=TOL)
+    np.testing.assert_array_equal(info['success'].cpu().numpy(), res['success'][0])
+    # re-synchronise the CPU statement to the kernel's state
+    c.qpos[:] = env.qpos.cpu().numpy(); c.qvel[:] = env.qvel.cpu().numpy()
+    c.observed_torque[:] = env.observed_torque.cpu().numpy(); c.overheat[:] = env.overheat.cpu().numpy(); c.motor_enabled[:] = env.motor_enabled.cpu().numpy()
+  assert not bool(done.any()) and int(env.fail_count.sum()) == 0
+  z = env.qpos[:, 2]
+  assert float(z.min()) > 0.05 and float(z.max()) < 0.3        # on the ground, not through it
+
+
+def test_fused_rollout_equals_stepping_bit_for_bit_and_shards_equal_the_batch(torch):
+  n, T = 48, 25
+  a, b = make(n, seed=11), make(n, seed=11)
+  g = torch.Generator(device='cuda').manual_seed(2)
+  acts = (torch.rand(T, n, 8, generator=g, device='cuda') * 2 - 1)
+  ra = a.rollout(acts)
+  rows = [b.step(acts[t]) for t in range(T)]
+  assert torch.equal(ra['obs'], torch.stack([r[0] for r in rows])) and torch.equal(ra['reward'], torch.stack([r[1] for r in rows]))
+  assert torch.equal(ra['success'], torch.stack([r[3]['success'] for r in rows]))
+  for k in ('qpos', 'qvel', 'overheat', 'motor_enabled', 'observed_torque', 'steps_since_reset'):
+    assert torch.equal(getattr(a, k), getattr(b, k)), k
+  # two half shards == one batch (Philox keyed by the global env id)
+  s0, s1 = make(n // 2, seed=11), make(n // 2, seed=11, env_offset=n // 2)
+  r0, r1 = s0.rollout(acts[:, :n // 2]), s1.rollout(acts[:, n // 2:])
+  assert torch.equal(torch.cat([r0['obs'], r1['obs']], 1), ra['obs'])
+
+
+def test_loader_wrappers_goal_switch_and_action_bounds(torch):
+  import earl_benchmark_amd as eb
+  n = 16
+  L = eb.EARLEnvs('minitaur', reward_type='dense', num_envs=n, seed=1, eval_horizon=4, allow_unpinned_dynamics=True)
+  train, ev = L.get_envs()
+  assert L.get_goal_states() is None and not L.has_demos()
+  o = ev.reset()
+  assert o.shape == (n, 32) and o.dtype == torch.float64
+  with pytest.raises(ValueError, match='out of bounds'):
+    ev.step(torch.full((n, 8), 1.5))
+  for t in range(4):
+    o, r, done, info = ev.step(torch.zeros(n, 8))
+  assert bool(done.all()) and int(ev.num_interventions[0]) == 1 and ev.total_steps == 4
+  assert torch.equal(ev.compute_reward(o), r)                                  # _reward == compute_reward on the returned observation
+  assert torch.equal(ev.is_successful(o), info['success'])
+  Ll = eb.EARLEnvs('minitaur', num_envs=n, seed=1, setup_as_lifelong_learning=True, goal_change_frequency=3, allow_unpinned_dynamics=True)
+  lenv = Ll.get_envs()
+  lenv.reset()
+  g0 = lenv.unwrapped.goal_t.clone()
+  res = lenv.rollout(torch.zeros(3, n, 8))
+  assert torch.equal(res['obs'][1, :, 30:], g0) and torch.equal(res['obs'][2, :, 30:], lenv.unwrapped.goal_t)
+  assert not torch.equal(lenv.unwrapped.goal_t, g0) and float(lenv.lifelong_return.abs().sum()) > 0
+
+
+def test_failure_guard_rolls_back_one_env(torch):
+  n = 8
+  env = make(n, seed=4)
+  ref = make(n, seed=4)
+  env.qvel[3, 7] = float('nan')                                                # poison one env
+  acts = torch.zeros(2, n, 8, device='cuda')
+  ra, rb = env.rollout(acts), ref.rollout(acts)
+  assert ra['status'][:, 3].tolist() == [1, 1] and int(ra['status'].sum()) == 2 and int(env.fail_count[3]) == 2
+  keep = [i for i in range(n) if i != 3]
+  assert torch.equal(ra['obs'][:, keep], rb['obs'][:, keep])                   # the neighbours are bit-identical to an unpoisoned run
+  assert torch.equal(ra['obs'][0, 3], env.last_obs[3]) and float(ra['reward'][:, 3].abs().sum()) == 0.0
+
+
+def test_full_size_soak_4096_envs_1000_steps(torch):
+  """BASELINE configs[4] at size: 4096 envs, the reference's eval horizon (1000 env steps = 5000 timesteps), random actions"""
+  from earl_benchmark_amd.wrappers import PersistentStateWrapper
+  n, T = 4096, 1000
+  env = PersistentStateWrapper(make(n, seed=77), T)
+  g = torch.Generator(device='cuda').manual_seed(5)
+  out = None
+  for k in range(4):                                                           # four launches of 250 steps (obs rows: 262 MB each)
+    acts = (torch.rand(T // 4, n, 8, generator=g, device='cuda') * 2 - 1)
+    out = env.rollout(acts, out=out)
+    assert bool(torch.isfinite(out['obs']).all())
+  u = env.unwrapped
+  assert bool(out['done'][-1].all()) and not bool(out['done'][:-1].any())
+  assert int(u.fail_count.sum()) <= 4 and int((u.steps_since_reset == T).sum()) == n
+  z = u.qpos[:, 2]
+  assert float(z.min()) > 0.02 and float(z.max()) < 0.6                        # nobody fell through the ground or flew off
+  assert float(u.qpos[:, :2].abs().max()) < 1.6                                # ... or through a wall

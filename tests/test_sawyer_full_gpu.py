@@ -179,6 +179,7 @@ def test_stale_library_layout_is_refused(monkeypatch):
     earl_physics_model24_size = lib.earl_physics_model24_size
     earl_collision_model_size = lib.earl_collision_model_size
     earl_sawyer_cfg_size = lib.earl_sawyer_cfg_size
+    earl_minitaur_cfg_size = lib.earl_minitaur_cfg_size
   with pytest.raises(_abi.EarlHipError, match='sizeof'):
     physics.check_layouts(Fake)
 
