@@ -51,7 +51,8 @@ def parse():
   p.add_argument('--no-sawyer', action='store_true', help='skip the sawyer_door / sawyer_peg (BASELINE configs[2]) legs of the default line')
   p.add_argument('--sawyer-cpu-seconds', type=float, default=2.0, help='seconds per repetition and thread count of the Sawyer CPU baselines')
   p.add_argument('--no-kitchen', action='store_true', help='skip the kitchen (BASELINE configs[3]) leg of the default line')
-  p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door', 'sawyer_peg', 'kitchen'],
+  p.add_argument('--no-minitaur', action='store_true', help='skip the minitaur (BASELINE configs[4]) leg of the default line')
+  p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door', 'sawyer_peg', 'kitchen', 'minitaur'],
                  help='tabletop = BASELINE configs[1] (the default, the quoted metric); sawyer_door / sawyer_peg = configs[2] shape, N=8192 each (next rows)')
   return p.parse_args()
 
@@ -516,6 +517,97 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
           'cpu_baseline': None if cpu_seconds is None else kitchen_cpu_baseline(cpu_seconds)}
 
 
+def minitaur_cpu_baseline(seconds, n=4096, reps=2):
+  """The C restatement of the same stepper and env loop (oracle/physics_oracle.c: oracle_minitaur_rollout, OpenMP over envs) on the host cores: the
+  bench's own 4096-env batch at every thread count, whole env steps (leg model, 5 x (motor model + timestep), observation, reward) of random actions
+  from the reset state, >= `seconds` per repetition, fastest of `reps`.  PyBullet itself is not available on this host."""
+  import numpy as np
+  from oracle import physics_c
+  rng = np.random.default_rng(0)
+  c = physics_c.CMinitaur(n, seed=1234)
+  physics_c.set_threads(len(os.sched_getaffinity(0)))
+  c.reset()
+  q0, v0 = c.qpos.copy(), c.qvel.copy()
+
+  def run(threads, steps):
+    physics_c.set_threads(threads)
+    c.qpos[:], c.qvel[:] = q0, v0
+    c.overheat[:] = 0; c.motor_enabled[:] = 1
+    acts = rng.uniform(-1, 1, (steps, n, 8)).astype(np.float32)
+    t0 = time.perf_counter()
+    c.rollout(acts)
+    return time.perf_counter() - t0
+  ncpu = len(os.sched_getaffinity(0))
+  sweep, detail = {}, {}
+  for k in sorted({1, min(16, ncpu), min(64, ncpu), min(128, ncpu), ncpu}):
+    probe = run(k, 1)
+    steps = max(1, int(np.ceil(seconds / probe)))
+    best = min(run(k, steps) for _ in range(reps))
+    sweep[k] = n * steps / best
+    detail[k] = {'env_steps': steps, 'best_s': round(best, 3)}
+  best = max(sweep, key=sweep.get)
+  return {'value': sweep[best], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
+          'sample': f'{n} envs x {detail[best]["env_steps"]} env steps (5 timesteps each + motor model / observation / reward), fastest of {reps} repetitions of >= {seconds:g} s, '
+                    f'through the C restatement of the same stepper (oracle/physics_oracle.c, OpenMP static over envs); the same {n}-env batch at every thread count: '
+                    f'{({k: round(v) for k, v in sweep.items()})}; PyBullet itself is not available on this host',
+          'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}}
+
+
+def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=4096, T=1000, cpu_seconds=None):
+  """BASELINE configs[4]: minitaur, 4096 envs in total range-sharded over the GPUs (STRONG scaling, like the kitchen line), one bench step = reset
+  (incl. its 100 settle timesteps) + T = 1000 env steps (the reference's eval horizon) of 5 timesteps each in ONE fused launch (earl_minitaur_rollout).
+  Own robot model and stepper: parity with the reference's PyBullet simulation is unpinned and model-less (envs/minitaur.py).  -> result dict on rank 0"""
+  from earl_benchmark_amd.envs.minitaur import Minitaur
+  from earl_benchmark_amd.wrappers import PersistentStateWrapper
+  from earl_benchmark_amd import sharding
+  kw = sharding.shard_kwargs(n_global, rank, world)
+  n = kw['num_envs']
+  env = PersistentStateWrapper(Minitaur(num_envs=n, seed=1234, env_offset=kw['env_offset'], scalar_api=False), T)
+  g = torch.Generator(device=device).manual_seed(55 + rank)
+  acts = (torch.rand(T, n, 8, generator=g, device=device) * 2 - 1).to(torch.float32)
+  out = env.unwrapped._new_out((T,))
+
+  def episode():
+    env.reset()
+    return env.rollout(acts, out=out)
+  for _ in range(warmup):
+    episode()
+  clk = _Clock(torch, device)
+  clk.sync()
+  if world > 1:
+    dist.barrier()
+  clk.sync()
+  t0 = time.perf_counter()
+  clk.start()
+  for _ in range(steps):
+    res = episode()
+  clk.stop()
+  clk.sync()
+  if world > 1:
+    dist.barrier()
+  clk.sync()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  assert bool(res['done'][-1].all()) and not bool(res['done'][:-1].any()) and bool(torch.isfinite(res['obs']).all())
+  fails = int(env.unwrapped.fail_count.sum())
+  if rank != 0:
+    return None
+  prof = {}
+  tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+  if os.path.exists(tpath) and (n_global, T, world) == (4096, 1000, 1):
+    prof = json.load(open(tpath)).get('minitaur', {})
+  roof = pipe_roofline(prof, 'minitaur_kernel', clk.elapsed_ms() / steps)
+  return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
+          'valu_frac': roof['frac'], 'roofline': roof, 'timesteps_per_s': steps * n_global * T * 5 / dt, 'scaling': 'strong', 'diverged_env_steps': fails,
+          'config': {'workload': f'minitaur dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 5 '
+                                 'timesteps per bench step; own robot model (nv = 22, four loop closures) and stepper, parity with PyBullet unpinned and model-less',
+                     'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'launches_per_episode': 2},
+          'cpu_baseline': None if cpu_seconds is None else minitaur_cpu_baseline(cpu_seconds)}
+
+
 def main_sawyer(a, torch, dist, world, rank, device):
   n = a.envs if a.envs != 4096 else 8192
   T = a.horizon if a.horizon != 200 else None
@@ -551,6 +643,17 @@ def main():
     dist.init_process_group('nccl', device_id=torch.device(device))
   if a.workload in ('sawyer_door', 'sawyer_peg'):
     return main_sawyer(a, torch, dist, world, rank, device)
+  if a.workload == 'minitaur':
+    r = run_minitaur(a, torch, dist, world, rank, device, min(a.steps, 3), min(a.warmup, 1), cpu_seconds=None if a.no_cpu else 5.0)
+    if rank == 0:
+      print(json.dumps({'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world,
+                        'steps': r['steps'], 'warmup': r['warmup'], 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
+                        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'config': r['config'], 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline'],
+                        'timesteps_per_s': r['timesteps_per_s'], 'diverged_env_steps': r['diverged_env_steps']}), flush=True)
+    if world > 1:
+      dist.barrier()
+      dist.destroy_process_group()
+    return
   if a.workload == 'kitchen':
     r = run_kitchen(a, torch, dist, world, rank, device, min(a.steps, 3), min(a.warmup, 1), cpu_seconds=None if a.no_cpu else 5.0)
     if rank == 0:
@@ -615,6 +718,8 @@ def main():
                              cpu_seconds=None if (a.no_cpu or world > 1) else a.sawyer_cpu_seconds)
   if not a.no_kitchen:      # BASELINE configs[3] in the same run (2048 envs in total, sharded over the ranks)
     sawyer['kitchen'] = run_kitchen(a, torch, dist, world, rank, device, steps=2, warmup=1, cpu_seconds=None if (a.no_cpu or world > 1) else 2.0)
+  if not a.no_minitaur:     # BASELINE configs[4] in the same run (4096 envs in total, sharded over the ranks)
+    sawyer['minitaur'] = run_minitaur(a, torch, dist, world, rank, device, steps=2, warmup=1, cpu_seconds=None if (a.no_cpu or world > 1) else 2.0)
   res = None
   if rank == 0:
     kmean = sum(kern_ms) / len(kern_ms)

@@ -289,7 +289,7 @@ struct SharedData {
   double bq[4];                      // orientation of the free body (unit quaternion), identity if the model has none
   double Xq[NV][4], Xp[NV][3];       // world frame of every link (final buffer of the ancestor doubling)
   SymLds<NV> M;                      // mass matrix
-  HwStore<NV, Lim<NV>::EXTRAS> hwst;
+  HwStore<NV, (Lim<NV>::EXTRAS || Lim<NV>::CONNECT)> hwst;
   ConStore<NV, Lim<NV>::CONNECT> xt;
   union {
     struct { double Xq1[NV][4], Xp1[NV][3]; } k2;                    // second buffer of the doubling
@@ -424,6 +424,9 @@ __device__ __forceinline__ void chol_coop(SymLds<NV>& H, const double (&dl)[NV],
 #ifndef EARL_KITCHEN_DENSE
 #define EARL_KITCHEN_DENSE 0
 #endif
+#ifndef EARL_MT_LOOP_SOLVER
+#define EARL_MT_LOOP_SOLVER 0       // nv = 22: the looping in-LDS factorisation / substitution instead of the unrolled ones (measurement switch: 70 k against ~10 k cycles per solve)
+#endif
 // Looping form of the two for the big model (nv = 23): fully unrolled, chol_coop + solve_lds keep two 23-entry vectors in registers and made the
 // kernel spill 1.4 KB per lane into scratch.  Here the lane's row of L stays where it is (in H), the right-hand side / solution stays in LDS
 // (every lane of the env runs the same substitution on the same numbers, so the redundant stores agree), and nothing is indexed dynamically in
@@ -464,6 +467,69 @@ __device__ __forceinline__ void solve_lds_loop(const SymLds<NV>& H, double (&x)[
     for (int p = i + 1; p < NV; ++p) s = fma(-H.v[p * (p + 1) / 2 + i], x[p], s);
     x[i] = s * H.v[i * (i + 1) / 2 + i];
   }
+}
+
+// Dense SPD solve for the one-tree model (nv = 22, 32 lanes per env, two envs per wave): H (packed lower triangle in LDS, column l written by lane l)
+// plus dl on the diagonal, right-hand side b_l in this lane -> this lane's entry of the solution.  Lane = row.  The lane keeps ITS ROW of L in
+// registers (r[]); a column of the left-looking factorisation costs one broadcast read of the pivot row from LDS and one cross-lane broadcast of the
+// pivot's inverse root (v_readlane with a constant lane per env group, no LDS round trip); the two substitutions exchange one solution entry per step the
+// same way and read nothing but the lane's own row (forward) / own column (backward, fetched from LDS in one batch).  The unrolled chol_coop +
+// solve_lds pair reads the whole factor back per lane (462 loads the compiler hoists: 1.3 KB of scratch per lane here); their looping forms walk through
+// LDS one dependent round trip at a time (70 k cycles per solve, measured: 57 % of the minitaur's timestep).
+template <int J>
+__device__ __forceinline__ double group_bcast(const double v, const int grp) {      // v of lane J of this lane's 32-lane group
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo0 = __builtin_amdgcn_readlane(lo, J), hi0 = __builtin_amdgcn_readlane(hi, J);
+  const int lo1 = __builtin_amdgcn_readlane(lo, 32 + J), hi1 = __builtin_amdgcn_readlane(hi, 32 + J);
+  return __hiloint2double(grp ? hi1 : hi0, grp ? lo1 : lo0);
+}
+template <int NV, int J>
+struct CholRows {
+  // column J of the factorisation, then the later ones
+  static __device__ __forceinline__ void factor(SymLds<NV>& H, double (&r)[NV], double& inv_l, const int l, const int ltri, const bool isl, const int grp) {
+    // s_l = H[l][J] - sum_{p < J} L[l][p] L[J][p]  (meaningful for l >= J); two partial sums halve the dependent chain
+    double s0 = r[J], s1 = 0.0;
+#pragma unroll
+    for (int p = 0; p < J; ++p) {
+      const double pj = H.v[J * (J + 1) / 2 + p];              // pivot row: the same address in every lane of the env (LDS broadcast)
+      if (p & 1) s1 = fma(-r[p], pj, s1); else s0 = fma(-r[p], pj, s0);
+    }
+    const double sj = s0 + s1;
+    const double inv = group_bcast<J>(rsq_nr(sj), grp);        // 1 / L[J][J], from the pivot's own lane
+    r[J] = sj * inv;                                           // L[l][J] (lane J: L[J][J] itself)
+    inv_l = l == J ? inv : inv_l;
+    if (isl && l > J) H.v[ltri + J] = r[J];                    // my row's entry: lane l's row is the pivot row of column l
+    fence();
+    if constexpr (J + 1 < NV) CholRows<NV, J + 1>::factor(H, r, inv_l, l, ltri, isl, grp);
+  }
+  // forward substitution L y = b: step J hands y_J to the rows below
+  static __device__ __forceinline__ void forward(const double (&r)[NV], const double inv_l, double& t, const int l, const int grp) {
+    const double yj = group_bcast<J>(t * inv_l, grp);
+    t = l > J ? fma(-r[J], yj, t) : (l == J ? yj : t);
+    if constexpr (J + 1 < NV) CholRows<NV, J + 1>::forward(r, inv_l, t, l, grp);
+  }
+  // backward substitution L' x = y: step J (from the last row up) hands x_J to the rows above; c[] = this lane's COLUMN of L
+  static __device__ __forceinline__ void backward(const double (&c)[NV], const double inv_l, double& t, const int l, const int grp) {
+    const double xj = group_bcast<J>(t * inv_l, grp);
+    t = l < J ? fma(-c[J], xj, t) : (l == J ? xj : t);
+    if constexpr (J > 0) CholRows<NV, J - 1>::backward(c, inv_l, t, l, grp);
+  }
+};
+template <int NV>
+__device__ __forceinline__ double chol_solve_rows(SymLds<NV>& H, const double (&dl)[NV], const double b_l, const int l, const bool isl, const int grp) {
+  static_assert(SymLds<NV>::PACKED, "packed storage");
+  const int ltri = l * (l + 1) / 2;
+  double r[NV], inv_l = 1.0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) r[j] = H.v[(j <= l ? ltri + j : j * (j + 1) / 2 + l)] + (j == l ? dl[l] : 0.0);     // row l of H (symmetric: entry (l, j))
+  fence();
+  CholRows<NV, 0>::factor(H, r, inv_l, l, ltri, isl, grp);
+  double t = b_l;
+  CholRows<NV, 0>::forward(r, inv_l, t, l, grp);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) r[k] = H.v[k * (k + 1) / 2 + (k > l ? l : 0)];     // column l of L: entries (k, l), k > l (the others are not used)
+  CholRows<NV, NV - 1>::backward(r, inv_l, t, l, grp);
+  return t;
 }
 
 // the same on the leading N x N block only (a model whose first N dofs are one tree and whose other dofs are decoupled from it: the kitchen's arm)
@@ -1252,7 +1318,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   fence();
   PSTAMP(6);
   // ------------------------------------------------------------------ K9: Hessian of the equality part, then the active-set Newton
-  double hw[Lim<NV>::EXTRAS ? 1 : NV], rw;             // this lane's column of M + J6' D J6 (+ drag) and its right-hand side: registers, all iterations
+  double hw[(Lim<NV>::EXTRAS || Lim<NV>::CONNECT) ? 1 : NV], rw;             // this lane's column of M + J6' D J6 (+ drag) and its right-hand side: registers, all iterations
                                                        // (big model: the column goes straight to LDS, s.hwst.Hw)
   {
     double DJ[6], g = tau_l;
@@ -1261,7 +1327,23 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       DJ[r] = s.con.wD[r] * Jc[r];
       g = fma(DJ[r], s.con.war[r], g);
     }
-    if constexpr (!Lim<NV>::EXTRAS) {
+    if constexpr (Lim<NV>::CONNECT) {
+      // nv = 22: column l (its lower part) of M + JE' D JE -- the connect rows are equalities, always active -- goes straight to LDS (s.hwst.Hw): a
+      // 22-entry register column kept across the whole active-set iteration is what made this kernel spill 1.3 KB per lane
+      double dj[3 * EARL_MAXCONNECT];
+#pragma unroll
+      for (int r = 0; r < 3 * EARL_MAXCONNECT; ++r) {
+        dj[r] = r < 3 * m.n_con ? s.xt.eD[r] * s.xt.JE[r][l] : 0.0;
+        g = fma(dj[r], r < 3 * m.n_con ? s.xt.ear[r] : 0.0, g);
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double h = s.M.sym(i, l, ltri);
+#pragma unroll
+        for (int r = 0; r < 3 * EARL_MAXCONNECT; ++r) h = fma(s.xt.JE[r][i], dj[r], h);
+        if (isl && i >= l) s.hwst.Hw.lo(i, l) = h;
+      }
+    } else if constexpr (!Lim<NV>::EXTRAS) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         double h = s.M.sym(i, l, ltri);
@@ -1271,14 +1353,6 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         }
         if (i == l) h += m.drag_G[l];                     // soft velocity row of a permanent dragging contact
         hw[i] = h;
-      }
-      if constexpr (Lim<NV>::CONNECT) {                    // + JE' D JE (the connect rows are equalities: always active)
-        for (int r = 0; r < 3 * m.n_con; ++r) {
-          const double dj = s.xt.eD[r] * s.xt.JE[r][l];
-          g = fma(dj, s.xt.ear[r], g);
-#pragma unroll
-          for (int i = 0; i < NV; ++i) hw[i] = fma(s.xt.JE[r][i], dj, hw[i]);
-        }
       }
     }
     g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
@@ -1384,6 +1458,25 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         }
       }
       if (isl) s.con.rc[l] = rr;
+    } else if constexpr (Lim<NV>::CONNECT) {
+      // column l of the iteration's Hessian: the stored equality part + the active contact edges, summed in registers, stored once (lower part)
+      double hcol[NV], rr = rw;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) hcol[i] = s.hwst.Hw.lo(i >= l ? i : l, l);
+      for (int c = 0; c < ncmax; ++c) {
+        const double* w = s.con.cw[c];
+        const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
+        const bool cv = c < nct;
+        const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+        rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+      }
+      if (isl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) if (i >= l) s.con.Hc.lo(i, l) = hcol[i];
+        s.con.rc[l] = rr;
+      }
     } else if constexpr (Lim<NV>::COOP) {
       // (in-LDS factorisation, i.e. the eight-waves-per-CU door build: the same column built in place, from the register copy of the equality part --
       // one 10-entry register vector less under the 256-register cap)
@@ -1545,6 +1638,26 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
         for (int i = NA; i < NV; ++i) a[i] = s.con.rc[i];
       }
+    } else if constexpr (Lim<NV>::CONNECT) {
+      // nv = 22, dense: the LOOPING forms of the lane-cooperative factorisation and substitution (row of L and right-hand side stay in LDS): fully
+      // unrolled, chol_coop + solve_lds keep two 22-entry vectors in registers over 231 column steps and spilled 1.3 KB per lane into scratch
+#if EARL_MT_LOOP_SOLVER
+      if (isl) s.con.rc[l] += s.con.rl[l];
+      chol_coop_loop<NV>(s.con.Hc, s.con.dl, l, isl);
+      solve_lds_loop<NV>(s.con.Hc, s.con.rc);
+      fence();
+#pragma unroll
+      for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i];
+#else
+      {
+        const double xl = chol_solve_rows<NV>(s.con.Hc, s.con.dl, s.con.rc[l] + s.con.rl[l], l, isl, grp);
+        fence();
+        if (isl) s.con.rc[l] = xl;
+        fence();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i];
+      }
+#endif
     } else if constexpr (Lim<NV>::COOP) {
       chol_coop<NV>(s.con.Hc, s.con.dl, l, isl);
       solve_lds<NV>(s.con.Hc, a);
@@ -2685,6 +2798,16 @@ int earl_minitaur_reset(const void* model24, const earl_collision_model* col, co
   return launched("minitaur_reset");
 }
 int earl_minitaur_cfg_size(void) { return (int)sizeof(earl_minitaur_cfg); }
+#ifdef EARL_PHYS_PROF
+int earl_debug_read_phys_profile_mt(unsigned long long* out, int reset) {          // this unit's own copy of the phase counters (tools/prof_minitaur.py)
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_prof), sizeof(unsigned long long) * 32) != hipSuccess) return EARL_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phys_prof), z, sizeof(z)) != hipSuccess) return EARL_ERR_LAUNCH;
+  }
+  return EARL_OK;
+}
+#endif
 #elif defined(EARL_PHYS_VARIANT_W8)
 // This translation unit is physics_w8.hip: the door model's rollout kernel built with eight-wave workgroups (EARL_DOOR_WPB 8: 32 envs share one
 // copy of the tables, packed matrices, in-LDS factorisations, 256 registers per wave) = eight waves per CU.  Same arithmetic, bit-identical
