@@ -76,7 +76,7 @@ class KitchenCfg(C.Structure):     # struct earl_kitchen_cfg (include/earl_physi
 
 class KitchenState(C.Structure):   # struct earl_kitchen_state
   _fields_ = [(k, C.c_void_p) for k in ('qpos', 'qvel', 'mocap_pos', 'goal', 'last_qp_robot', 'att_xpos', 'steps_since_reset', 'fail_count', 'last_obs',
-                                        'action64', 'ctrl9', 'noise', 'qpos_bak', 'qvel_bak', 'sites', 'bad')]
+                                        'action64', 'ctrl9', 'noise', 'qpos_bak', 'qvel_bak', 'sites', 'bad', 'mocap_bak', 'att_bak')]
 
 
 class KitchenOut(C.Structure):     # struct earl_kitchen_out

@@ -2340,6 +2340,8 @@ __global__ void kitchen_pre_kernel(const KitchenArgs a) {
   a.st.qpos_bak[i] = a.st.qpos[i];
   a.st.qvel_bak[i] = a.st.qvel[i];
   if (j < 9) a.st.action64[e * 9 + j] = (double)a.action[e * 9 + j];
+  if (j < 3) a.st.mocap_bak[e * 3 + j] = a.st.mocap_pos[e * 3 + j];      // (before earl_kitchen_action moves the target)
+  for (int k = j; k < a.n_att * 3; k += 23) a.st.att_bak[(size_t)e * a.n_att * 3 + k] = a.st.att_xpos[(size_t)e * a.n_att * 3 + k];
 }
 // after the stepper: failure guard (roll a diverged env back), the eight task sites gathered for the reward
 __global__ void kitchen_guard_kernel(const KitchenArgs a) {
@@ -2348,7 +2350,10 @@ __global__ void kitchen_guard_kernel(const KitchenArgs a) {
   bool bad = false;
   for (int j = 0; j < 23; ++j) bad = bad || !(fabs(a.st.qpos[e * 23 + j]) < EARL_BAD_VALUE) || !(fabs(a.st.qvel[e * 23 + j]) < EARL_BAD_VALUE);
   if (bad) {
+    // rolled back: state, the mocap target the diverged step was pulled towards, the attachment positions (possibly NaN) the stepper left
     for (int j = 0; j < 23; ++j) { a.st.qpos[e * 23 + j] = a.st.qpos_bak[e * 23 + j]; a.st.qvel[e * 23 + j] = a.st.qvel_bak[e * 23 + j]; }
+    for (int j = 0; j < 3; ++j) a.st.mocap_pos[e * 3 + j] = a.st.mocap_bak[e * 3 + j];
+    for (int k = 0; k < a.n_att * 3; ++k) a.st.att_xpos[(size_t)e * a.n_att * 3 + k] = a.st.att_bak[(size_t)e * a.n_att * 3 + k];
     if (a.st.fail_count) a.st.fail_count[e] += 1;
   }
   if (a.out.status) a.out.status[e] = bad ? EARL_STEP_DIVERGED : 0;
@@ -2423,6 +2428,7 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
   for (int t = 0; t < a.T; ++t) {
     const size_t row = (size_t)t * n + env;
     // ---- KitchenV0.step up to do_simulation (kitchen_action_kernel): mocap target, the nine position targets
+    const double mocap_prev = s.mocap[sub < 3 ? sub : 0];      // the target before this step's action: a diverged step goes back to it
     {
       const double x = (double)a.action[row * 9 + kk];
       const double c = x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x);
@@ -2442,17 +2448,15 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
     if (sub < 3 && live) a.st.mocap_pos[(size_t)env * 3 + sub] = s.mocap[sub];
     fence();
     for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);
-    // ---- attachments at the kinematics of the last timestep's start; the eight task sites for the reward
-    if (sub < m.n_att && live) {
-      const V3 p = attachment<NV>(s, m, sub);
-      double* o = a.st.att_xpos + ((size_t)env * m.n_att + sub) * 3;
-      o[0] = p.x; o[1] = p.y; o[2] = p.z;
-    }
     const bool bad_lane = sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE);
     const bool failed = group_any<LPE>(bad_lane, grp);
     if (failed) {
       // rolled back to the last stable state (the rows in HBM); returns its last stable observation, reward 0 (kitchen_guard / finish kernels)
       load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
+      if (sub < 3) {                                      // ... incl. the mocap target that pulled it there (att_xpos keeps the last stable positions)
+        s.mocap[sub] = mocap_prev;
+        if (live) a.st.mocap_pos[(size_t)env * 3 + sub] = mocap_prev;
+      }
       if (live) {
         for (int k = sub; k < 46; k += LPE) a.out.obs[row * 46 + k] = a.st.last_obs[(size_t)env * 46 + k];
         if (sub == 0) {
@@ -2462,6 +2466,12 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
       }
     } else {
       if (live) store_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
+      // attachments at the kinematics of the last timestep's start (written only for a step that ended finite); the eight task sites for the reward
+      if (sub < m.n_att && live) {
+        const V3 p = attachment<NV>(s, m, sub);
+        double* o = a.st.att_xpos + ((size_t)env * m.n_att + sub) * 3;
+        o[0] = p.x; o[1] = p.y; o[2] = p.z;
+      }
       if (sub < 8) {
         const V3 p = attachment<NV>(s, m, cfg.site_att[sub]);
         s.kit.sites[sub][0] = p.x; s.kit.sites[sub][1] = p.y; s.kit.sites[sub][2] = p.z;
@@ -2895,7 +2905,7 @@ int earl_kitchen_step(const void* model, const earl_collision_model* col, const 
                       const earl_kitchen_state* st, const float* action, const earl_kitchen_out* out, earl_stream_t stream) {
   if (!model || !params || !cfg || !st || !action || !out || cfg->n < 0 || cfg->n_att < 10 || cfg->frame_skip < 0) return EARL_ERR_ARG;
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !st->last_qp_robot || !st->att_xpos || !st->steps_since_reset || !st->last_obs) return EARL_ERR_ARG;
-  if (!st->action64 || !st->ctrl9 || !st->qpos_bak || !st->qvel_bak || !st->sites || !st->bad || (cfg->sensor_noise && !st->noise)) return EARL_ERR_ARG;
+  if (!st->action64 || !st->ctrl9 || !st->qpos_bak || !st->qvel_bak || !st->sites || !st->bad || !st->mocap_bak || !st->att_bak || (cfg->sensor_noise && !st->noise)) return EARL_ERR_ARG;
   if (!out->obs || !out->reward || !out->done || !out->success) return EARL_ERR_ARG;
   for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
   const int n = cfg->n;

@@ -95,7 +95,8 @@ class Kitchen:
     self.last_obs = torch.zeros(n, self.OBS_DIM, **kw)
     # scratch of earl_kitchen_step (caller-owned like the state) and its argument structs
     self._scr = dict(action64=torch.zeros(n, 9, **kw), ctrl9=torch.zeros(n, 9, **kw), noise=torch.zeros(n, 46, **kw), qpos_bak=torch.zeros(n, self.NV, **kw),
-                     qvel_bak=torch.zeros(n, self.NV, **kw), sites=torch.zeros(n, 8, 3, **kw), bad=torch.zeros(n, dtype=torch.uint8, device=dev))
+                     qvel_bak=torch.zeros(n, self.NV, **kw), sites=torch.zeros(n, 8, 3, **kw), bad=torch.zeros(n, dtype=torch.uint8, device=dev),
+                     mocap_bak=torch.zeros(n, 3, **kw), att_bak=torch.zeros(n, self.model.n_att, 3, **kw))
     self._mq1 = self.mocap_quat[0].clone().contiguous()
     self._cfg = _Cfg(n=n, env_offset=self._env_offset, horizon=INT32_MAX, frame_skip=FRAME_SKIP, sensor_noise=int(self.sensor_noise), n_att=self.model.n_att,
                      seed=self._seed, counter=0, mocap_quat_dev=self._mq1.data_ptr())
@@ -239,7 +240,11 @@ class Kitchen:
       self._last_success = res['success'][-1]
       return res
     res = out if out is not None else {}
-    rows = [self.step(a[t]) for t in range(T)]
+    sc, self.scalar_api = self.scalar_api, False          # (the step loop stacks batched tensors; with scalar_api step() returns numpy / python scalars)
+    try:
+      rows = [self.step(a[t].reshape(self.num_envs, self.N_ROBOT)) for t in range(T)]
+    finally:
+      self.scalar_api = sc
     res['obs'] = torch.stack([r[0] for r in rows]); res['reward'] = torch.stack([r[1] for r in rows]); res['done'] = torch.stack([r[2] for r in rows])
     res['success'] = torch.stack([r[3]['success'] for r in rows]); res['status'] = torch.stack([r[3]['status'] for r in rows])
     return res
@@ -261,7 +266,12 @@ class Kitchen:
     return float(r[0]) if self.scalar_api else r
 
   def is_successful(self, obs=None):
-    o = self.last_obs if obs is None else torch.as_tensor(obs, dtype=torch.float64, device=self.device).reshape(-1, self.OBS_DIM)
+    if obs is None:                                                               # kitchen.py:180-182: obs = self._get_obs(): a FRESH noisy reading
+      with torch.cuda.device(self.device):
+        o = self._observe(noise=True)
+      self._counter += 1
+    else:
+      o = torch.as_tensor(obs, dtype=torch.float64, device=self.device).reshape(-1, self.OBS_DIM)
     s = (o[:, 9:23] - o[:, 32:46]).norm(dim=1) <= 0.3                             # kitchen.py:180-183
     return bool(s[0]) if self.scalar_api else s
 

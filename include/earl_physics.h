@@ -299,12 +299,15 @@ typedef struct earl_kitchen_state {
   double* qpos_bak; double* qvel_bak;   /* [n, 23] the state a diverged step is rolled back to */
   double* sites;                 /* [n, 8, 3] */
   uint8_t* bad;                  /* [n] */
+  double* mocap_bak;             /* [n, 3] the mocap target before this step's action: a diverged step restores it (like earl_sawyer_out.status) */
+  double* att_bak;               /* [n, n_att, 3] attachment positions before this step: a diverged step leaves att_xpos at them */
 } earl_kitchen_state;
 typedef struct earl_kitchen_out {
   double* obs;                   /* [n, 46] */
   double* reward;                /* [n] float64, like the reference's */
   uint8_t* done; uint8_t* success;
-  uint8_t* status;               /* [n] may be NULL: EARL_STEP_DIVERGED as in earl_sawyer_out */
+  uint8_t* status;               /* [n] may be NULL: EARL_STEP_DIVERGED as in earl_sawyer_out: state, mocap target and attachment positions are
+                                    rolled back to the env's last stable ones, the row carries the last stable observation, reward 0 */
 } earl_kitchen_out;
 int earl_kitchen_step(const void* model24, const earl_collision_model* col, const struct earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
                       const earl_kitchen_state* st, const float* action /* [n, 9] */, const earl_kitchen_out* out, earl_stream_t stream);

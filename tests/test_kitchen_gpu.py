@@ -198,6 +198,11 @@ def test_fused_rollout_equals_stepping_bit_for_bit():
   assert torch.equal(fused['done'], torch.stack([r[2] for r in rows])) and torch.equal(fused['success'], torch.stack([r[3]['success'] for r in rows]))
   assert torch.equal(fused['status'], torch.stack([r[3]['status'] for r in rows]))
   assert int(fused['status'][3, 7]) == 1 and int(fused['status'].sum()) >= 1 and int(a_env.fail_count[7]) >= 1
+  # the diverged step is rolled back INCLUDING its mocap target (it used to stay NaN and pull every later step of the env into the guard):
+  # env 7 carries on from its last stable state at step 4, its attachment positions never hold the NaN the stepper left
+  assert int(fused['status'][:, 7].sum()) == 1 and int(a_env.fail_count[7]) == 1 and bool(torch.isfinite(a_env.mocap_pos).all())
+  assert bool(torch.isfinite(a_env.att).all()) and torch.equal(a_env.att.view(torch.int64), b_env.att.view(torch.int64))
+  assert bool(torch.isfinite(a_env.compute_reward(a_env.last_obs)).all())
   for k in ('qpos', 'qvel', 'mocap_pos', 'last_qp_robot', 'last_obs', 'steps_since_reset', 'fail_count'):
     x, y = getattr(a_env, k), getattr(b_env, k)
     assert torch.equal(x.view(torch.int64) if x.dtype == torch.float64 else x, y.view(torch.int64) if y.dtype == torch.float64 else y), k
