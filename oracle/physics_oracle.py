@@ -475,7 +475,7 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
     box.append(dict(link=l, pos=p, quat=q, half=half, accept=tuple(spec.get('plates_accept', ('chain',))), **params(m.geom_id(names[-1]))))
   # boxes given explicitly (a finger built from a dozen capsules and a box is stood in for by ONE box): dict(body, pos, quat, half, like = geom
   # whose contact parameters it carries, accept); with 'corners': its eight corner points also become a sphere set of that name
-  for e in spec.get('explicit_boxes', ()):
+  for e in [x for x in spec.get('explicit_boxes', ()) if not x.get('late')]:
     b = m.body_id(e['body'])
     l, p, q = int(link_of_body[b]), rel_pos[b] + quat_mat(rel_quat[b]) @ np.asarray(e['pos'], float), quat_mul(rel_quat[b], np.asarray(e.get('quat', [1.0, 0, 0, 0]), float))
     box.append(dict(link=l, pos=p, quat=q, half=np.asarray(e['half'], float), accept=tuple(e['accept']), **params(e['like'])))
@@ -548,6 +548,16 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
         for sz in (0, 1):
           c = np.array([hi[0] if sx else lo[0], hi[1] if sy else lo[1], hi[2] if sz else lo[2]])
           sph.append(dict(link=l, pos=Rq @ c, r=0.0, set=sname, **params(gs[0])))
+  # additions of later rounds come LAST in both lists, so that the pair and block order of everything before them -- the priority order of the
+  # contact slots -- stays what it was: explicit boxes flagged `late`, and spheres given explicitly (a mesh hull stood in for by a few spheres:
+  # dict(body, pos, r, set, like = geom whose contact parameters they carry))
+  for e in [x for x in spec.get('explicit_boxes', ()) if x.get('late')]:
+    b = m.body_id(e['body'])
+    box.append(dict(link=int(link_of_body[b]), pos=rel_pos[b] + quat_mat(rel_quat[b]) @ np.asarray(e['pos'], float),
+                    quat=quat_mul(rel_quat[b], np.asarray(e.get('quat', [1.0, 0, 0, 0]), float)), half=np.asarray(e['half'], float), accept=tuple(e['accept']), **params(e['like'])))
+  for e in spec.get('explicit_spheres', ()):
+    b = m.body_id(e['body'])
+    sph.append(dict(link=int(link_of_body[b]), pos=rel_pos[b] + quat_mat(rel_quat[b]) @ np.asarray(e['pos'], float), r=float(e['r']), set=e['set'], **params(e['like'])))
   # Permanent deep box-in-box contacts (the door panel stands 2.3 cm inside the table top: obj_init_pos z = 0.1, panel
   # half height 0.123).  Such a contact has all four pyramid edges active and a constant depth, and the moving box has
   # one dof, so its 4 x 4 edges reduce EXACTLY to one soft velocity row on that dof (tests/test_physics.py checks the

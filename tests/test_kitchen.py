@@ -207,3 +207,22 @@ def test_task_rows_follow_the_references_rule():
       want[comp[part][0]] = comp[part][1]
     assert rows.shape == (1, 23)
     np.testing.assert_array_equal(rows[0], want)
+
+
+def test_hand_against_static_boxes_collision_tables():
+  """Round 3: the declared collision set grew by the hand (eight spheres on link 7) against six static boxes taken from the MJCF's own collision geoms
+  (counter-top slab, oven / stove body, back wall, hood) or hulls of them (microwave body, cabinet bottoms); the round-2 set is an unchanged PREFIX
+  of the pair / block lists, so states without hand contacts give the results they gave before."""
+  z = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'models', 'kitchen_links.npz'))
+  assert len(z['col_pair']) == 238 and len(z['col_blk_begin']) == 32 and len(z['col_box_link']) == 12 and len(z['col_sph_link']) == 87
+  assert int(z['col_blk_begin'][26]) == 190 and (z['col_blk_box'][26:] == np.arange(6, 12)).all() and (z['col_blk_cap'][26:] == 3).all()
+  hand = np.arange(79, 87)
+  assert (z['col_sph_link'][hand] == 6).all() and sorted(np.round(z['col_sph_r'][hand], 3).tolist()) == [0.02] * 4 + [0.035] * 3 + [0.05]
+  assert (z['col_box_link'][6:] == -1).all()                                     # world-fixed
+  m = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'models', 'kitchen.npz'))
+  names = [str(x) for x in m['body_names']]
+  # the four boxes taken as they stand: size = a colliding box geom of that static body (oven_asset.xml:34-35 etc. via the compiled model)
+  for j, body in ((6, 'counters'), (7, 'ovenroot'), (8, 'wallroot'), (9, 'hoodroot')):
+    gs = [g for g in range(len(m['geom_body'])) if names[m['geom_body'][g]] == body and m['geom_type'][g] == 4 and (m['geom_contype'][g] or m['geom_conaffinity'][g])]
+    assert any(np.allclose(m['geom_size'][g][:3], z['col_box_half'][j]) for g in gs), body
+  np.testing.assert_allclose(z['col_box_pos'][6][2] + z['col_box_half'][6][2], 1.60, atol=1e-6)      # counter top

@@ -525,11 +525,33 @@ def main():
     sets = tuple(c['set'] for c in chains)
     fingers = [dict(body='panda0_leftfinger', pos=[0.0, 0.0125, 0.0475], half=[0.0185, 0.0125, 0.0475], like=finger_geom['panda0_leftfinger'], accept=sets, corners='tipl'),
                dict(body='panda0_rightfinger', pos=[0.0, -0.0125, 0.0475], half=[0.0185, 0.0125, 0.0475], like=finger_geom['panda0_rightfinger'], accept=sets, corners='tipr')]
+    # Round 3: the HAND against the kitchen's big static boxes.  The hand (link 7: the wrist flange, the hand's hull and the
+    # envelope the two fingers sweep) is stood in for by eight spheres -- this build's own fit to the panda_col hulls' extents (flange r 0.05 at
+    # z 0.08; hand body 0.2 x 0.065 x 0.06 centred at z 0.131 as three spheres r 0.035 along the fingers' slide axis; finger envelope to the tips at
+    # z 0.26 as four spheres r 0.02) -- tested against SIX static boxes taken from the MJCF's own collision geoms: the counter-top slab, the oven /
+    # stove body, the back wall, the microwave's body (hull of its six plates), the bottom plates of the slide and hinge cabinets (as one box) and the
+    # hood.  The block limit (32) is what bounds the set: the upper arm's hulls, the right counter and the floor stay uncollided.
+    world_box = lambda body, sel: [g for g in on(body) if gt[g] == 4 and sel(g)]
+    kin0 = po.kinematics(pm, np.zeros(len(m['jnt_body'])))
+    gcen = lambda g: kin0['xpos'][gb[g]] + kin0['xmat'][gb[g]] @ m['geom_pos'][g]
+    pick = lambda body, centre: min(world_box(body, lambda g: True), key=lambda g: float(np.abs(gcen(g) - np.asarray(centre)).sum()))
+    statics = [pick('counters', (-0.955, 0.242, 1.57)), pick('ovenroot', (0.0, 0.738, 0.808)), pick('wallroot', (-0.151, 1.394, 2.187)), pick('hoodroot', (0.0, 1.011, 2.284))]
+
+    def hull(geoms):                                   # axis-aligned hull of world-fixed boxes (they are all unrotated) -> explicit box in the world frame
+      lo = np.min([gcen(g) - gs[g][:3] for g in geoms], 0); hi = np.max([gcen(g) + gs[g][:3] for g in geoms], 0)
+      return dict(body='world', pos=0.5 * (lo + hi), half=0.5 * (hi - lo), like=geoms[0], accept=('hand',), late=True)
+    micro_body = hull(world_box('microroot', lambda g: True))
+    cab_bottoms = hull(world_box('slide', lambda g: abs(gcen(g)[2] - 2.42) < 0.01) + world_box('hingecab', lambda g: abs(gcen(g)[2] - 2.42) < 0.01))
+    yf = np.array([np.sin(np.pi / 4), np.cos(np.pi / 4), 0.0])       # the fingers' slide axis in the frame of link 7 (the finger frames are turned -45 deg about z)
+    hand = [dict(body='panda0_link7', pos=[0, 0, 0.08], r=0.05, set='hand', like=finger_geom['panda0_leftfinger'])]
+    hand += [dict(body='panda0_link7', pos=list(t * yf + [0, 0, 0.131]), r=0.035, set='hand', like=finger_geom['panda0_leftfinger']) for t in (-0.07, 0.0, 0.07)]
+    hand += [dict(body='panda0_link7', pos=list(t * yf + [0, 0, z]), r=0.02, set='hand', like=finger_geom['panda0_leftfinger']) for t in (-0.04, 0.04) for z in (0.21, 0.245)]
     red = po.reduce_model(pm, None, attach_bodies=['panda0_link7'],
                           attach_sites=['end_effector', 'knob1_site', 'knob2_site', 'knob3_site', 'knob4_site', 'light_site', 'slide_site', 'hinge_site2', 'microhandle_site'],
                           weld_translation_calibration=1.0,        # no recordings of this env exist: the derived value, not the Sawyer calibration
-                          collision=dict(max_contacts=12, explicit_boxes=fingers, chains=chains, big_boxes=[dict(geom=g, accept=('tipl', 'tipr')) for g in panels],
-                                         set_priority=sets, set_cap=dict({c['set']: 4 for c in chains}, tipl=2, tipr=2)))
+                          collision=dict(max_contacts=12, explicit_boxes=fingers + [micro_body, cab_bottoms], chains=chains, explicit_spheres=hand,
+                                         big_boxes=[dict(geom=g, accept=('tipl', 'tipr')) for g in panels] + [dict(geom=g, accept=('hand',)) for g in statics],
+                                         set_priority=sets, set_cap=dict({c['set']: 4 for c in chains}, tipl=2, tipr=2, hand=3)))
     red['key_qpos'] = m['key_qpos']
     np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
     print('links:', len(red['parent']), 'spheres', len(red['col_sph_link']), 'boxes', len(red['col_box_link']), 'pairs', len(red['col_pair']),
