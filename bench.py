@@ -196,6 +196,23 @@ def time_step_api(torch, env, acts, steps, warmup, graph=False):
   return dt, e0.elapsed_time(e1) * 1e-3
 
 
+def host_cpu_info():
+  """what bounds the CPU baselines on this host: CPUs this process may run on, the cgroup CPU quota (a 256-CPU box with a quota of 16 CPUs' worth of
+  time explains a thread sweep that peaks at 16), the OpenMP placement in force"""
+  info = {'affinity_cpus': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count(), 'os_cpu_count': os.cpu_count(),
+          'OMP_PROC_BIND': os.environ.get('OMP_PROC_BIND'), 'OMP_PLACES': os.environ.get('OMP_PLACES'), 'cgroup_cpu_quota_cpus': None}
+  try:
+    if os.path.exists('/sys/fs/cgroup/cpu.max'):                          # cgroup v2: "<quota> <period>" or "max <period>"
+      q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+      info['cgroup_cpu_quota_cpus'] = None if q == 'max' else float(q) / float(per)
+    elif os.path.exists('/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):           # cgroup v1
+      q, per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()), int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+      info['cgroup_cpu_quota_cpus'] = None if q < 0 else q / per
+  except Exception as e:      # noqa: BLE001  (diagnostic only)
+    info['cgroup_cpu_quota_cpus'] = f'unreadable: {e}'
+  return info
+
+
 def cpu_baseline(n, T, reward, seconds):
   """oracle/ (C restatement of the reference, OpenMP over envs) on the host cores: bounded sample of the same
   workload.  Thread counts 1, 8, 16, ... up to the CPUs this process may use are each timed briefly; the fastest is
@@ -243,7 +260,7 @@ def cpu_baseline(n, T, reward, seconds):
           'sample': f'{reps} rollouts of {n} envs x {T} steps ({reps * n * T} env-steps, {dt:.1f} s) through oracle/tabletop_oracle.c, '
                     f'OpenMP static over envs, {best} threads (fastest of {sorted(trials)}; host exposes {avail} CPUs)',
           'single_thread': trials[1], 'by_threads': {str(k): v for k, v in trials.items()},
-          'scalar_python_loop_1env': scalar_rate}
+          'scalar_python_loop_1env': scalar_rate, 'host': host_cpu_info()}
 
 
 def sawyer_profile(workload, n, T):
@@ -321,7 +338,7 @@ def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door', n=8192, reps=3):
           'sample': f'{n} envs x {detail[best]["T"]} env steps (5 timesteps each, random actions from the reset state), fastest of {reps} repetitions of '
                     f'>= {seconds:g} s each, through the C restatement of the same stepper (oracle/physics_oracle.c, OpenMP static over envs); the same '
                     f'{n}-env batch at every thread count: {({k: round(v) for k, v in sweep.items()})}; MuJoCo itself is not available on this host',
-          'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}}
+          'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
 def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8192, T=None, cpu_seconds=None):
@@ -441,7 +458,7 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
           'sample': f'{n} envs x {detail[best]["env_steps"]} env steps (40 timesteps each + the glue), fastest of {reps} repetitions of >= {seconds:g} s, through the C '
                     f'restatement of the same stepper (oracle/physics_oracle.c, OpenMP static over envs) and of the reference\'s numpy glue; the same {n}-env batch at '
                     f'every thread count: {({k: round(v) for k, v in sweep.items()})}; MuJoCo itself is not available on this host',
-          'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}}
+          'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
 def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=2048, T=400, cpu_seconds=None):
@@ -550,7 +567,7 @@ def minitaur_cpu_baseline(seconds, n=4096, reps=2):
           'sample': f'{n} envs x {detail[best]["env_steps"]} env steps (5 timesteps each + motor model / observation / reward), fastest of {reps} repetitions of >= {seconds:g} s, '
                     f'through the C restatement of the same stepper (oracle/physics_oracle.c, OpenMP static over envs); the same {n}-env batch at every thread count: '
                     f'{({k: round(v) for k, v in sweep.items()})}; PyBullet itself is not available on this host',
-          'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}}
+          'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
 def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=4096, T=1000, cpu_seconds=None):
@@ -626,6 +643,10 @@ def main_sawyer(a, torch, dist, world, rank, device):
 def main():
   a = parse()
   os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC for RCCL: must be in the environment before the HIP runtime starts
+  # OpenMP placement of the CPU baselines (the oracle's C library): one thread per core, spread over the sockets; must be in the environment before
+  # libgomp initialises.  (a thread sweep that collapses past 16 threads is a placement / quota artefact unless shown otherwise.)
+  os.environ.setdefault('OMP_PROC_BIND', 'spread')
+  os.environ.setdefault('OMP_PLACES', 'cores')
   import torch
   import torch.distributed as dist
   world = int(os.environ.get('WORLD_SIZE', '1'))

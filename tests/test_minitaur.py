@@ -130,3 +130,26 @@ def test_goal_switch_of_the_lifelong_wrapper_in_the_c_rollout():
   np.testing.assert_allclose(res['reward'][2], r_old, rtol=0, atol=1e-12)
   np.testing.assert_array_equal(res['obs'][6, :, 30:], c.goal)
   assert (c.steps_since_goal_change == 1).all()
+
+
+def test_two_shards_equal_one_batch_on_the_cpu_statement():
+  """env-range sharding: Philox streams are keyed by the GLOBAL env id, so two half shards (env_offset) reproduce the batch bit for bit --
+  reset draws (goal, battery voltage, viscous damping) and rollouts alike"""
+  from earl_benchmark_amd import sharding
+  n, T = 6, 4
+  full = physics_c.CMinitaur(n, seed=21)
+  full.reset()
+  rng = np.random.default_rng(2)
+  acts = rng.uniform(-1, 1, (T, n, 8)).astype(np.float32)
+  rf = full.rollout(acts)
+  parts = []
+  for rank in range(2):
+    kw = sharding.shard_kwargs(n, rank, 2)
+    sh = physics_c.CMinitaur(kw['num_envs'], seed=21, env_offset=kw['env_offset'])
+    sh.reset()
+    lo = kw['env_offset']
+    np.testing.assert_array_equal(sh.goal, full.goal[lo:lo + kw['num_envs']])
+    np.testing.assert_array_equal(sh.motor_param, full.motor_param[lo:lo + kw['num_envs']])
+    parts.append(sh.rollout(acts[:, lo:lo + kw['num_envs']]))
+  np.testing.assert_array_equal(np.concatenate([p['obs'] for p in parts], 1), rf['obs'])
+  np.testing.assert_array_equal(np.concatenate([p['reward'] for p in parts], 1), rf['reward'])
