@@ -511,7 +511,8 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
   fails = int(env.unwrapped.fail_count.sum())
   clk.sync()
   t1 = time.perf_counter()
-  stepped(T)
+  if not a.no_step_api:                                # (profiling runs skip it: env.step() launches the same kernel with T = 1, which would mix into its statistics)
+    stepped(T)
   clk.sync()
   dt_step = time.perf_counter() - t1
   if rank != 0:
@@ -525,7 +526,7 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
           'valu_frac': roof['frac'], 'roofline': roof,
           'timesteps_per_s': steps * n_global * T * 40 / dt, 'gpu_ms_per_env_step': clk.elapsed_ms() / (steps * T), 'scaling': 'strong',
           'diverged_env_steps': fails,
-          'step_api': {'value': n * T / dt_step, 'unit': 'env-steps/s (this rank)', 'ms_per_env_step': dt_step / T * 1e3,
+          'step_api': None if a.no_step_api else {'value': n * T / dt_step, 'unit': 'env-steps/s (this rank)', 'ms_per_env_step': dt_step / T * 1e3,
                        'note': 'the same episode through env.step(): one launch per env step (the rollout kernel with T = 1); every launch lasts as long as '
                                'its slowest wave, which the fused rollout only pays once per episode'},
           'config': {'workload': f'kitchen dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 40 '

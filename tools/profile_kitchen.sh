@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-ARGS="bench.py --workload kitchen --steps 1 --warmup 1 --no-cpu"
+ARGS="bench.py --workload kitchen --steps 1 --warmup 1 --no-cpu --no-step-api"
 rm -rf $OUT/prof_kitchen_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kitchen_stats -- python3 $ARGS > $OUT/prof_kitchen_stats.log 2>&1
 echo "stats rc=$?"; tail -1 $OUT/prof_kitchen_stats.log | cut -c1-160
