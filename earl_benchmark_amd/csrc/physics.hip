@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <type_traits>
 
 #include "../../include/earl_physics.h"
 #include "../../include/earl_glue.h"
@@ -231,7 +232,7 @@ template <> struct ModelOf<22> { using T = earl_link_model24; };   // the minita
 // under 40 KB of LDS (four workgroups per CU, one wave per SIMD); the peg model (nv 15) needs 12 / 32.
 template <int NV> struct Lim {
   static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
-  static constexpr int MB = NV <= 10 ? 16 : 32;             // collision blocks (<= EARL_MAXBLK; the peg model has 29, the kitchen 26)
+  static constexpr int MB = NV <= 10 ? 16 : (NV == 23 ? 64 : 32);   // collision blocks (<= EARL_MAXBLK; the peg model has 29, the kitchen 56 since round 3: 64-bit near masks)
 #ifndef EARL_DOOR_WPB
 #define EARL_DOOR_WPB 1
 #endif
@@ -740,8 +741,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
   }
   // ------------------------------------------------------------------ C0: collision bounding tests (world frames are final)
-  unsigned int nearw = 0;                              // blocks with a near bounding test in ANY env of the wave
-  unsigned int nearg = 0;                              // ... in this env
+  using BlkMask = std::conditional_t<(Lim<NV>::MB > 32), unsigned long long, unsigned int>;
+  BlkMask nearw = 0;                                   // blocks with a near bounding test in ANY env of the wave
+  BlkMask nearg = 0;                                   // ... in this env
   for (int cb = 0; cb < bt.n_blk; cb += LPE) {
     // C0: bounding test per block, lane = block (LPE blocks per pass)
     const int b = cb + sub < bt.n_blk ? cb + sub : 0;
@@ -795,11 +797,11 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     const bool nearb = cb + sub < bt.n_blk && dot(d, d) < bt.reach[b] * bt.reach[b] && !separated;
     const unsigned long long bal = __ballot(nearb);
     if constexpr (LPE == 64) {
-      nearg |= (unsigned int)bal; nearw |= (unsigned int)bal;
+      nearg |= (BlkMask)bal; nearw |= (BlkMask)bal;
     } else {
-      nearg |= (unsigned int)((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull)) << cb;
-      if constexpr (LPE == 32) nearw |= (unsigned int)((bal | (bal >> 32)) & 0xFFFFFFFFull) << cb;
-      else nearw |= (unsigned int)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull) << cb;
+      nearg |= (BlkMask)((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull)) << cb;
+      if constexpr (LPE == 32) nearw |= (BlkMask)((bal | (bal >> 32)) & 0xFFFFFFFFull) << cb;
+      else nearw |= (BlkMask)((bal | (bal >> 16) | (bal >> 32) | (bal >> 48)) & 0xFFFFull) << cb;
     }
   }
   // prefetch this lane's pair record of the first near block: its latency hides behind K3-K7
@@ -810,7 +812,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #define EARL_NO_PREFETCH 0
 #endif
   if (nearw && !(EARL_NO_PREFETCH && NV <= 10)) {      // (two waves per SIMD hide that latency themselves; the registers are worth more there)
-    pf_blk = __builtin_ctz(nearw);
+    pf_blk = sizeof(BlkMask) == 8 ? __builtin_ctzll((unsigned long long)nearw) : __builtin_ctz((unsigned int)nearw);
     const int pend = bt.end[pf_blk], pi0 = bt.begin[pf_blk] + sub;
     const int pi = pi0 < pend ? pi0 : pend - 1;
     pf_link = col->pair_rec[pi].sph_link; pf_cls = col->pair_rec[pi].cls;
@@ -1003,8 +1005,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   int nct = 0;                                         // contacts of this env (same value in every lane of the group)
   if (nearw) {
     // C2: pair tests of the near blocks, in pair order; the box frame once per block, the sphere centre per test
-    for (unsigned int rest = nearw; rest; rest &= rest - 1u) {
-      const int b = __builtin_ctz(rest);
+    for (BlkMask rest = nearw; rest; rest &= rest - 1u) {
+      const int b = sizeof(BlkMask) == 8 ? __builtin_ctzll((unsigned long long)rest) : __builtin_ctz((unsigned int)rest);
       const bool mine = (nearg >> b) & 1u;
       const int pend = bt.end[b], xl = bt.box_link[b];
       V3 pb = ld3(bt.box_pos[b]);
@@ -1102,7 +1104,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   }
   PSTAMP(2);
   // most over the wave (uniform loop bound for the contact phases)
-  PCOUNT(20, 1); PCOUNT(21, nearw ? 1 : 0); PCOUNT(22, __popc(nearw));
+  PCOUNT(20, 1); PCOUNT(21, nearw ? 1 : 0); PCOUNT(22, __popcll((unsigned long long)nearw));
   int ncmax = 0;
   if (nearw && __any(nct > 0)) {
 #pragma unroll

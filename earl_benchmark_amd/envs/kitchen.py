@@ -15,8 +15,8 @@ plus the per-env failure guard and the wrapper bookkeeping as small kernels.
 STATUS of the dynamics: this build's own articulated-body stepper on tables compiled from the reference's MJCF (tools/mjcf_compile.py kitchen):
 Franka arm (link inertias from the collision hulls and the given masses), 14 single-dof fixtures, the mocap weld on panda0_link7, joint limits,
 the five knob / burner and switch / light couplings, dry friction and springs on the fixture joints, force-limited finger actuators, and a
-DECLARED, reduced collision set (each finger one box; handles as sphere chains; door panels against the finger corners; since round 3 the hand --
-eight spheres on link 7 -- against the counter top, oven body, back wall, hood, microwave body and cabinet bottoms; the upper-arm links' hulls, the
+DECLARED, reduced collision set (each finger one box; handles as sphere chains; door panels against the finger corners; since round 3 hand, wrist,
+forearm (13 spheres) and the finger corners against the counter top, oven body, back wall, hood, microwave body and cabinet bottoms; links 1-4, the
 right counter and the floor are not collided).  **PARITY WITH MUJOCO IS UNPINNED**: the reference ships no recording of this env and MuJoCo cannot
 run here.  What is pinned: the numpy glue around the simulator (bit-exact on goldens recorded from the reference's own methods),
 the model tables' provenance, and the kernel against this build's CPU statement (oracle/physics_oracle.LinkModel).

@@ -13,7 +13,7 @@ import torch
 from .. import _abi
 
 MAXV, MAXATT, MAXACT = 16, 8, 4
-MAXSPH, MAXBOX, MAXPAIR, MAXCLS, MAXCON, MAXBLK = 96, 16, 512, 16, 12, 32
+MAXSPH, MAXBOX, MAXPAIR, MAXCLS, MAXCON, MAXBLK = 96, 16, 512, 16, 12, 64
 MAXV24, MAXATT24, MAXJEQ, MAXCONNECT = 24, 16, 8, 4
 MODEL_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'models')
 
@@ -188,7 +188,8 @@ def load_collision_model(d):
   c.max_con = int(d['max_contacts']) if 'max_contacts' in d else 8
   small = len(d['parent']) <= 10                # csrc/physics.hip Lim<NV>: 8 contact slots / 16 blocks for nv <= 10
   assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS
-  assert c.n_blk <= (16 if small else 32) and 0 < c.max_con <= (8 if small else MAXCON)      # Lim<NV>::MB, ::MC
+  nvm = len(d['parent'])
+  assert c.n_blk <= (16 if small else (64 if nvm == 23 else 32)) and 0 < c.max_con <= (8 if small else MAXCON)      # Lim<NV>::MB, ::MC
   for dst, src in ((c.blk_begin, d['col_blk_begin']), (c.blk_end, d['col_blk_end']), (c.blk_box, d['col_blk_box']),
                    (c.blk_link, d['col_blk_link']), (c.blk_center, d['col_blk_center']), (c.blk_reach, d['col_blk_reach']),
                    (c.blk_cap, d['col_blk_cap'] if 'col_blk_cap' in d else np.full(c.n_blk, c.max_con, np.int32)),

@@ -109,7 +109,7 @@ typedef struct earl_link_model24 {
 #define EARL_MAXPAIR 512
 #define EARL_MAXCLS 16
 #define EARL_MAXCON 12
-#define EARL_MAXBLK 32
+#define EARL_MAXBLK 64     /* kernels: 16 for nv <= 10, 64 for the kitchen (nv = 23), 32 otherwise (csrc/physics.hip Lim<NV>::MB) */
 typedef struct earl_collision_model {
   int32_t n_sph, n_box, n_pair, n_cls;
   /* pairs are stored box-major in blocks (one box x one set of spheres); a block is skipped when the bounding sphere of its

@@ -18,8 +18,9 @@ _lib = None
 
 
 def build(force=False):
-  deps = [os.path.join(HERE, 'tabletop_oracle.c'), os.path.join(HERE, 'glue_oracle.c'),
-          os.path.join(HERE, '..', 'include', 'earl_tabletop.h'), os.path.join(HERE, '..', 'include', 'earl_glue.h')]
+  deps = [os.path.join(HERE, 'tabletop_oracle.c'), os.path.join(HERE, 'glue_oracle.c'), os.path.join(HERE, 'physics_oracle.c'),
+          os.path.join(HERE, '..', 'include', 'earl_tabletop.h'), os.path.join(HERE, '..', 'include', 'earl_glue.h'),
+          os.path.join(HERE, '..', 'include', 'earl_physics.h')]      # (a library built against other struct layouts reads the host structs wrongly)
   stale = (not os.path.exists(SO)) or any(os.path.getmtime(p) > os.path.getmtime(SO) for p in deps)
   if force or stale:
     subprocess.run(['make', '-C', HERE, '-B', 'libearl_oracle.so'], check=True, capture_output=True)

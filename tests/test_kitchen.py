@@ -209,15 +209,18 @@ def test_task_rows_follow_the_references_rule():
     np.testing.assert_array_equal(rows[0], want)
 
 
-def test_hand_against_static_boxes_collision_tables():
-  """Round 3: the declared collision set grew by the hand (eight spheres on link 7) against six static boxes taken from the MJCF's own collision geoms
-  (counter-top slab, oven / stove body, back wall, hood) or hulls of them (microwave body, cabinet bottoms); the round-2 set is an unchanged PREFIX
-  of the pair / block lists, so states without hand contacts give the results they gave before."""
+def test_arm_against_static_boxes_collision_tables():
+  """Round 3: the declared collision set grew by the hand (eight spheres on link 7), the wrist (two on link 6), the forearm (three on link 5) and the
+  finger boxes' corner points against six static boxes taken from the MJCF's own collision geoms (counter-top slab, oven / stove body, back wall,
+  hood) or hulls of them (microwave body, cabinet bottoms); the round-2 set is an unchanged PREFIX of the pair / block lists, so states without such
+  contacts give the results they gave before."""
   z = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'models', 'kitchen_links.npz'))
-  assert len(z['col_pair']) == 238 and len(z['col_blk_begin']) == 32 and len(z['col_box_link']) == 12 and len(z['col_sph_link']) == 87
-  assert int(z['col_blk_begin'][26]) == 190 and (z['col_blk_box'][26:] == np.arange(6, 12)).all() and (z['col_blk_cap'][26:] == 3).all()
-  hand = np.arange(79, 87)
-  assert (z['col_sph_link'][hand] == 6).all() and sorted(np.round(z['col_sph_r'][hand], 3).tolist()) == [0.02] * 4 + [0.035] * 3 + [0.05]
+  assert len(z['col_pair']) == 364 and len(z['col_blk_begin']) == 56 and len(z['col_box_link']) == 12 and len(z['col_sph_link']) == 92
+  assert int(z['col_blk_begin'][26]) == 190 and set(z['col_blk_box'][26:].tolist()) == set(range(6, 12))
+  assert sorted(set(z['col_blk_link'][26:].tolist())) == [4, 5, 6, 7, 8]            # forearm, wrist, hand, the two fingers
+  new = np.arange(79, 92)
+  assert sorted(z['col_sph_link'][new].tolist()) == [4] * 3 + [5] * 2 + [6] * 8
+  assert sorted(np.round(z['col_sph_r'][new], 3).tolist()) == [0.02] * 4 + [0.035] * 3 + [0.05] + [0.055] * 2 + [0.06] * 3
   assert (z['col_box_link'][6:] == -1).all()                                     # world-fixed
   m = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'models', 'kitchen.npz'))
   names = [str(x) for x in m['body_names']]

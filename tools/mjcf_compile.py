@@ -530,7 +530,8 @@ def main():
     # z 0.08; hand body 0.2 x 0.065 x 0.06 centred at z 0.131 as three spheres r 0.035 along the fingers' slide axis; finger envelope to the tips at
     # z 0.26 as four spheres r 0.02) -- tested against SIX static boxes taken from the MJCF's own collision geoms: the counter-top slab, the oven /
     # stove body, the back wall, the microwave's body (hull of its six plates), the bottom plates of the slide and hinge cabinets (as one box) and the
-    # hood.  The block limit (32) is what bounds the set: the upper arm's hulls, the right counter and the floor stay uncollided.
+    # hood; likewise the wrist (link 6), the forearm (link 5) and the finger boxes' corner points.  Links 1-4, the right counter and the floor stay uncollided.
+    ARM_SETS = ('hand', 'wrist', 'forearm', 'tipl', 'tipr')      # what meets the static boxes: three links' sphere sets and the two fingers' corner points
     world_box = lambda body, sel: [g for g in on(body) if gt[g] == 4 and sel(g)]
     kin0 = po.kinematics(pm, np.zeros(len(m['jnt_body'])))
     gcen = lambda g: kin0['xpos'][gb[g]] + kin0['xmat'][gb[g]] @ m['geom_pos'][g]
@@ -539,19 +540,24 @@ def main():
 
     def hull(geoms):                                   # axis-aligned hull of world-fixed boxes (they are all unrotated) -> explicit box in the world frame
       lo = np.min([gcen(g) - gs[g][:3] for g in geoms], 0); hi = np.max([gcen(g) + gs[g][:3] for g in geoms], 0)
-      return dict(body='world', pos=0.5 * (lo + hi), half=0.5 * (hi - lo), like=geoms[0], accept=('hand',), late=True)
+      return dict(body='world', pos=0.5 * (lo + hi), half=0.5 * (hi - lo), like=geoms[0], accept=ARM_SETS, late=True)
     micro_body = hull(world_box('microroot', lambda g: True))
     cab_bottoms = hull(world_box('slide', lambda g: abs(gcen(g)[2] - 2.42) < 0.01) + world_box('hingecab', lambda g: abs(gcen(g)[2] - 2.42) < 0.01))
     yf = np.array([np.sin(np.pi / 4), np.cos(np.pi / 4), 0.0])       # the fingers' slide axis in the frame of link 7 (the finger frames are turned -45 deg about z)
     hand = [dict(body='panda0_link7', pos=[0, 0, 0.08], r=0.05, set='hand', like=finger_geom['panda0_leftfinger'])]
     hand += [dict(body='panda0_link7', pos=list(t * yf + [0, 0, 0.131]), r=0.035, set='hand', like=finger_geom['panda0_leftfinger']) for t in (-0.07, 0.0, 0.07)]
     hand += [dict(body='panda0_link7', pos=list(t * yf + [0, 0, z]), r=0.02, set='hand', like=finger_geom['panda0_leftfinger']) for t in (-0.04, 0.04) for z in (0.21, 0.245)]
+    # ... and the two links above it, fitted to the extents of their collision hulls (third_party/franka/meshes/collision/link5.stl: x +-0.055, y -0.055 .. 0.13,
+    # z -0.265 .. 0.052; link6.stl: x -0.048 .. 0.132, y -0.051 .. 0.082, z +-0.05): the forearm as three spheres r 0.06 along its length, the wrist as two r 0.055.
+    # (Links 1-4 cannot reach any of the six boxes and stay uncollided.)
+    hand += [dict(body='panda0_link5', pos=[0.0, 0.02, z], r=0.06, set='forearm', like=finger_geom['panda0_leftfinger']) for z in (-0.21, -0.105, 0.0)]
+    hand += [dict(body='panda0_link6', pos=p_, r=0.055, set='wrist', like=finger_geom['panda0_leftfinger']) for p_ in ([0.0, 0.01, 0.0], [0.085, 0.02, 0.0])]
     red = po.reduce_model(pm, None, attach_bodies=['panda0_link7'],
                           attach_sites=['end_effector', 'knob1_site', 'knob2_site', 'knob3_site', 'knob4_site', 'light_site', 'slide_site', 'hinge_site2', 'microhandle_site'],
                           weld_translation_calibration=1.0,        # no recordings of this env exist: the derived value, not the Sawyer calibration
                           collision=dict(max_contacts=12, explicit_boxes=fingers + [micro_body, cab_bottoms], chains=chains, explicit_spheres=hand,
-                                         big_boxes=[dict(geom=g, accept=('tipl', 'tipr')) for g in panels] + [dict(geom=g, accept=('hand',)) for g in statics],
-                                         set_priority=sets, set_cap=dict({c['set']: 4 for c in chains}, tipl=2, tipr=2, hand=3)))
+                                         big_boxes=[dict(geom=g, accept=('tipl', 'tipr')) for g in panels] + [dict(geom=g, accept=ARM_SETS) for g in statics],
+                                         set_priority=sets, set_cap=dict({c['set']: 4 for c in chains}, tipl=2, tipr=2, hand=3, wrist=2, forearm=2)))
     red['key_qpos'] = m['key_qpos']
     np.savez_compressed(os.path.join(OUT, name + '_links.npz'), **red)
     print('links:', len(red['parent']), 'spheres', len(red['col_sph_link']), 'boxes', len(red['col_box_link']), 'pairs', len(red['col_pair']),
