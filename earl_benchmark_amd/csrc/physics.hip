@@ -280,6 +280,7 @@ template <int NV> struct ConStore<NV, true> {
   double JE[3 * EARL_MAXCONNECT][NV];   // Jacobian rows: Jp(att1) - Jp(att2)
   double eD[3 * EARL_MAXCONNECT], ear[3 * EARL_MAXCONNECT], eres[3 * EARL_MAXCONNECT];
   double ext[NV];
+  signed char crow[EARL_MAXCON][2];      // per contact: the (at most two) dofs beyond the root body's six that its Jacobian touches, -1 = none (K9's column update)
 };
 
 // Per-env LDS block.  The three phase groups of the union are live at disjoint times.
@@ -1298,6 +1299,15 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         for (int j = 0; j < NV; ++j) rows(j);
       }
       const int cls = cv ? ((int)rec[7] & 63) : 0;
+      if constexpr (Lim<NV>::CONNECT) {
+        // one-tree model with a free root body (dofs 0-5) and chains of at most two hinges, colliding with world-fixed boxes only (checked by the host
+        // side): a contact Jacobian has entries in the root's six dofs and in the sphere's own chain -- nothing else.  K9 updates only those rows.
+        if (sub < MC) {
+          const int ls = cv ? (((int)rec[7] >> 6) & 63) - 1 : -1;
+          const int d2 = ls >= 6 ? ls : -1, d1 = (d2 >= 0 && m.parent[d2] >= 6) ? m.parent[d2] : -1;
+          s.xt.crow[sub][0] = (signed char)d1; s.xt.crow[sub][1] = (signed char)d2;
+        }
+      }
       const double margin = bt.cls_margin[cls];
       cmu = bt.cls_mu[cls];
       double kk = bt.kb_cls[Lim<NV>::KBT ? cls : 0][0], bb = bt.kb_cls[Lim<NV>::KBT ? cls : 0][1];
@@ -1462,9 +1472,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       if (isl) s.con.rc[l] = rr;
     } else if constexpr (Lim<NV>::CONNECT) {
       // column l of the iteration's Hessian: the stored equality part + the active contact edges, summed in registers, stored once (lower part)
-      double hcol[NV], rr = rw;
+      // Rows touched by a contact: the root body's six (accumulated in registers) and the at most two dofs of the sphere's own chain (s.xt.crow, updated in
+      // place): 8 of the 22 rows per contact instead of all 22 (the others' Jacobian entries are exact zeros).
+      double acc[6] = {0, 0, 0, 0, 0, 0}, rr = rw;
+      if (isl) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) hcol[i] = s.hwst.Hw.lo(i >= l ? i : l, l);
+        for (int i = 0; i < NV; ++i) if (i >= l) s.con.Hc.lo(i, l) = s.hwst.Hw.lo(i, l);
+      }
       for (int c = 0; c < ncmax; ++c) {
         const double* w = s.con.cw[c];
         const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
@@ -1472,11 +1486,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
         rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+        for (int i = 0; i < 6; ++i) acc[i] += s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int d = (int)s.xt.crow[c][k];
+          if (cv && isl && d >= l) s.con.Hc.lo(d, l) += s.con.CJ[c][0][d] * v0 + s.con.CJ[c][1][d] * v1 + s.con.CJ[c][2][d] * v2;
+        }
       }
       if (isl) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) if (i >= l) s.con.Hc.lo(i, l) = hcol[i];
+        for (int i = 0; i < 6; ++i) if (i >= l) s.con.Hc.lo(i, l) += acc[i];
         s.con.rc[l] = rr;
       }
     } else if constexpr (Lim<NV>::COOP) {

@@ -190,6 +190,12 @@ def load_collision_model(d):
   assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS
   nvm = len(d['parent'])
   assert c.n_blk <= (16 if small else (64 if nvm == 23 else 32)) and 0 < c.max_con <= (8 if small else MAXCON)      # Lim<NV>::MB, ::MC
+  if nvm == 22:
+    # csrc/physics.hip (Lim<22>::CONNECT, K9): a contact's Jacobian is taken to touch the root body's six dofs and the sphere's own chain of at most
+    # two hinges -- spheres ride on the root body or on such a chain, boxes are fixed to the world
+    par = [int(x) for x in d['parent']]
+    assert all(int(b) < 0 for b in d['col_box_link']), 'minitaur collision model: world-fixed boxes only'
+    assert all(int(l) == 5 or (int(l) >= 6 and (par[int(l)] == 5 or (par[int(l)] >= 6 and par[par[int(l)]] == 5))) for l in d['col_sph_link']), 'sphere links: root body or a chain of <= 2 hinges'
   for dst, src in ((c.blk_begin, d['col_blk_begin']), (c.blk_end, d['col_blk_end']), (c.blk_box, d['col_blk_box']),
                    (c.blk_link, d['col_blk_link']), (c.blk_center, d['col_blk_center']), (c.blk_reach, d['col_blk_reach']),
                    (c.blk_cap, d['col_blk_cap'] if 'col_blk_cap' in d else np.full(c.n_blk, c.max_con, np.int32)),
