@@ -573,3 +573,34 @@ def test_eval_episodes_groups_of_several_episodes_against_the_oracle(hx, orc, n,
   assert_same_state(o, h)
   assert h.cfg.counter == o.cfg.counter
   assert len(goals) == 4 and (E < 3 or not torch.equal(got[0][0], got[0][E - 1]))
+
+
+@pytest.mark.parametrize('case', range(24))
+def test_eval_episodes_fuzz_against_the_oracle(hx, orc, case):
+  """randomised launch geometries of earl_tabletop_eval_episodes (batch sizes around the workgroup / group-count boundaries, episode lengths on and off
+  the 8-step chunk grid, 2-40 episodes, every reset mode, both reward types, replayed or per-episode actions): every episode against the oracle"""
+  import torch
+  rng = np.random.default_rng(1000 + case)
+  n = int(rng.choice([1, 63, 64, 65, 127, 1000, 2048, 4095, 4096, 4097, 8191, 8192, 8193, 12000]))
+  T = int(rng.choice([16, 24, 32, 40, 56, 64, 72, 200] if rng.random() < 0.8 else [5, 17, 30]))       # (off-grid lengths take the launch-per-episode fallback)
+  E = int(rng.integers(2, 41 if n * T < 400000 else 9))
+  mode = int(rng.integers(0, 3))
+  kw = dict(reward_type='dense' if rng.random() < 0.3 else 'sparse', wide_init=mode == 1, reset_at_goal=mode == 2, seed=int(rng.integers(0, 2**31)),
+            env_offset=int(rng.integers(0, 1000)), horizon=T)
+  o, h = orc.OracleTabletop(n, **kw), hx.HipTabletop(n, **kw)
+  o.qpos[:] = rng.uniform(-2.8, 2.8, size=o.qpos.shape); o.attached[:] = rng.integers(-1, 1, size=n)
+  o.steps_since_reset[:] = rng.integers(0, T, size=n); o.num_interventions[:] = rng.integers(0, 3, size=n)
+  o.cfg.counter = int(rng.integers(0, 2**40))
+  h.set_from(o)
+  shared = rng.random() < 0.25
+  g = torch.Generator(device='cuda').manual_seed(case)
+  acts = (torch.rand(1 if shared else E, T, n, 3, generator=g, device='cuda') * 2 - 1).contiguous()
+  acts[..., 2] = acts[..., 2].abs() * (torch.rand(acts.shape[:-1], generator=g, device='cuda') > 0.2)
+  got = h.eval_episodes(acts[0], episodes=E) if shared else h.eval_episodes(acts)
+  dense = kw['reward_type'] == 'dense'
+  for e in range(E):
+    o.reset()
+    want = o.rollout(acts[0 if shared else e].cpu().numpy())
+    assert_same_out(tuple(x[e].cpu().numpy() for x in got), want, dense)
+  assert_same_state(o, h)
+  assert h.cfg.counter == o.cfg.counter
