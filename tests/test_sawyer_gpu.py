@@ -282,3 +282,26 @@ def test_masked_reset_state_dict_and_lifelong_loader():
   for _ in range(2):
     o3, r3, d3, _ = env.step(acts[0])
   assert d3.tolist() == [True] * 5                                # horizon 7 reached
+
+
+def test_the_references_literal_reset_recipe_is_available():
+  """reset_hand_timesteps=250: sim.reset() + 50 x (mocap at hand_init_pos, 5 timesteps) [UPSTREAM _reset_hand], the state the reference's episodes start
+  from -- still moving.  The reference's own comment records its reset observation, hand = (0.00591636, 0.39968333, 0.19493164) (sawyer_door.py:45-47):
+  5.9 mm off the mocap in x.  This stepper's 250-timestep state: 4.3 mm off in x, every coordinate within 3 mm of that constant (the converged
+  default is 5.9 mm away in x); kernel == C restatement; the arm is not at rest (joint speeds of 0.5 rad/s)."""
+  import torch
+  from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
+  from oracle import physics_c
+  env = SawyerDoor(num_envs=3, seed=2, reset_hand_timesteps=250)
+  obs = env.reset().cpu().numpy()
+  rec = np.array([0.00591636, 0.39968333, 0.19493164])
+  assert np.abs(obs[:, :3] - rec).max() < 3.2e-3 and (obs[:, 0] > 3e-3).all()
+  assert 0.3 < float(env.qvel[:, :7].abs().max()) < 1.0
+  cm = physics_c.CModel('sawyer_door')
+  r = cm.run(np.zeros((1, cm.nv)), np.zeros((1, cm.nv)), np.array([0, 0.4, 0.2], np.float32).astype(float), [1, 0, 1, 0], [-1, 1], nsub=250)
+  np.testing.assert_allclose(env.qpos[0, :9].cpu().numpy(), r['qpos'][0, :9], rtol=0, atol=1e-8)
+  np.testing.assert_allclose(env.qvel[0, :9].cpu().numpy(), r['qvel'][0, :9], rtol=0, atol=1e-7)
+  out = env.rollout(torch.zeros(5, 3, 4, device='cuda'))              # and it steps from there
+  assert np.isfinite(out['obs'].cpu().numpy()).all() and int(out['status'].sum()) == 0
+  conv = SawyerDoor(num_envs=1, seed=2)
+  assert abs(float(conv.reset()[0]) - rec[0]) > 5e-3                # the default: converged, x on the mocap
