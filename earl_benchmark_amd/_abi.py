@@ -89,7 +89,8 @@ class MinitaurCfg(C.Structure):    # struct earl_minitaur_cfg (include/earl_phys
               ('motor_dof', C.c_int32 * 8), ('pad_', C.c_int32), ('motor_dir', C.c_double * 8), ('motor_kp', C.c_double), ('motor_kd', C.c_double),
               ('motor_velocity_limit', C.c_double), ('overheat_torque', C.c_double), ('distance_weight', C.c_double), ('energy_weight', C.c_double),
               ('success_radius', C.c_double), ('goal_table', C.c_void_p), ('reset_qpos', C.c_void_p),
-              ('seed', C.c_uint64), ('counter', C.c_uint64), ('step_counter', C.c_uint64)]
+              ('base_mass_err', C.c_double * 2), ('leg_mass_err', C.c_double * 2), ('leg_mass', C.c_double), ('motor_mass', C.c_double),
+              ('foot_friction', C.c_double * 2), ('seed', C.c_uint64), ('counter', C.c_uint64), ('step_counter', C.c_uint64)]
 
 
 class MinitaurState(C.Structure):  # struct earl_minitaur_state

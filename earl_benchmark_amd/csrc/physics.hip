@@ -232,7 +232,7 @@ template <> struct ModelOf<22> { using T = earl_link_model24; };   // the minita
 // under 40 KB of LDS (four workgroups per CU, one wave per SIMD); the peg model (nv 15) needs 12 / 32.
 template <int NV> struct Lim {
   static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
-  static constexpr int MB = NV <= 10 ? 16 : (NV == 23 ? 64 : 32);   // collision blocks (<= EARL_MAXBLK; the peg model has 29, the kitchen 56 since round 3: 64-bit near masks)
+  static constexpr int MB = NV <= 10 ? 16 : (NV == 23 ? 64 : (NV == 22 ? 8 : 32));   // collision blocks (<= EARL_MAXBLK; the peg model has 29, the kitchen 56 since round 3: 64-bit near masks, the minitaur 7)
 #ifndef EARL_DOOR_WPB
 #define EARL_DOOR_WPB 1
 #endif
@@ -281,6 +281,8 @@ template <int NV> struct ConStore<NV, true> {
   double eD[3 * EARL_MAXCONNECT], ear[3 * EARL_MAXCONNECT], eres[3 * EARL_MAXCONNECT];
   double ext[NV];
   signed char crow[EARL_MAXCON][2];      // per contact: the (at most two) dofs beyond the root body's six that its Jacobian touches, -1 = none (K9's column update)
+  double mscale[3], foot_mu;             // the minitaur's per-env randomisation (earl_minitaur_state.motor_param[2..5]): mass / inertia factor of the root body, the upper links,
+                                         // the lower links; friction of the lower links' contacts (<= 0: the classes' own).  Unused (1, 1, 1, -1) elsewhere.
 };
 
 // Per-env LDS block.  The three phase groups of the union are live at disjoint times.
@@ -832,10 +834,15 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     const bool hinge = m.jtype[l] != 1;               // rotation axes of a free body: body axes after the rotation, like a hinge's
     Sw = selv(hinge, aw, V3{0, 0, 0});
     Sv = selv(hinge, cross(anchor, aw), aw);
-    const double mass = m.mass[l];
+    double ms = 1.0;                                 // the env's own mass / inertia factor of this link (minitaur: what the randomizer set at the last reset)
+    if constexpr (Lim<NV>::CONNECT) {
+      const int root = m.ball_dof + 2;
+      ms = l < root ? 1.0 : (l == root ? s.xt.mscale[0] : (m.parent[l] == root ? s.xt.mscale[1] : s.xt.mscale[2]));
+    }
+    const double mass = m.mass[l] * ms;
     const V3 c = add(P, mulv(R, ld3(m.com[l])));
     const double* in = m.inertia[l];
-    const double I[3][3] = {{in[0], in[3], in[4]}, {in[3], in[1], in[5]}, {in[4], in[5], in[2]}};
+    const double I[3][3] = {{in[0] * ms, in[3] * ms, in[4] * ms}, {in[3] * ms, in[1] * ms, in[5] * ms}, {in[4] * ms, in[5] * ms, in[2] * ms}};
     double T[3][3], W[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -1310,6 +1317,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       }
       const double margin = bt.cls_margin[cls];
       cmu = bt.cls_mu[cls];
+      if constexpr (Lim<NV>::CONNECT) {                 // Minitaur.SetFootFriction: every contact of a lower-leg link (a link behind the root body whose parent is not the root)
+        const int lsf = cv ? (((int)rec[7] >> 6) & 63) - 1 : -1, root = m.ball_dof + 2;
+        if (s.xt.foot_mu > 0 && lsf > root && m.parent[lsf] != root) cmu = s.xt.foot_mu;
+      }
       double kk = bt.kb_cls[Lim<NV>::KBT ? cls : 0][0], bb = bt.kb_cls[Lim<NV>::KBT ? cls : 0][1];
       double dd;
       if constexpr (Lim<NV>::KBT) dd = imp_of(bt.cls_solimp[cls], rec[0] - margin);
@@ -1486,7 +1497,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
         rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[i] += s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2;
+        for (int i = 0; i < 6; ++i) acc[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;   // (a slot beyond this env's count holds whatever
+                                                                                   // LDS held: 0 x NaN would poison the column -- tests/test_lds_hygiene_gpu.py)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int d = (int)s.xt.crow[c][k];
@@ -2595,24 +2607,38 @@ __global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const Minit
   const Q4 mq{1, 0, 0, 0};
   const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
   double voltage, viscous, goal0, goal1;
+  double ms0 = 1.0, ms1 = 1.0, ms2 = 1.0, fmu = -1.0;   // mass factors (root body, upper links, lower links), foot friction: motor_param[2..5]
   int oh; bool en; double obs_t;                        // motor lanes: overheat counter, enabled flag, observed torque of the newest ApplyAction
   if constexpr (RESET) {
     // GoalConditionedMinitaurBulletEnv.reset (minitaur_gym_env.py:476-479, 222-270): goal, [UPSTREAM randomizer] battery voltage and viscous damping, pose
     int gi = (int)(mt_draw(cfg, 0x4D00u, env, cfg.counter) * (double)cfg.n_goals);
     gi = gi >= cfg.n_goals ? cfg.n_goals - 1 : gi;
     goal0 = cfg.goal_table[2 * gi]; goal1 = cfg.goal_table[2 * gi + 1];
-    voltage = cfg.randomize ? 14.8 + (16.8 - 14.8) * mt_draw(cfg, 0x4D01u, env, cfg.counter) : 16.0;
-    viscous = cfg.randomize ? 0.01 * mt_draw(cfg, 0x4D02u, env, cfg.counter) : 0.0;
+    // MinitaurEnvRandomizer.randomize_env [UPSTREAM] through Minitaur.SetBatteryVoltage / SetMotorViscousDamping / SetBaseMass / SetLegMasses / SetFootFriction
+    // (minitaur.py:468-508); include/earl_physics.h: earl_minitaur_cfg.randomize
+    voltage = (cfg.randomize & 1) ? 14.8 + (16.8 - 14.8) * mt_draw(cfg, 0x4D01u, env, cfg.counter) : 16.0;
+    viscous = (cfg.randomize & 1) ? 0.01 * mt_draw(cfg, 0x4D02u, env, cfg.counter) : 0.0;
+    if (cfg.randomize & 2) {
+      const int root = m.ball_dof + 2;
+      const double leg = cfg.leg_mass * (1.0 + cfg.leg_mass_err[0] + (cfg.leg_mass_err[1] - cfg.leg_mass_err[0]) * mt_draw(cfg, 0x4D04u, env, cfg.counter));
+      const double motor = cfg.motor_mass * (1.0 + cfg.leg_mass_err[0] + (cfg.leg_mass_err[1] - cfg.leg_mass_err[0]) * mt_draw(cfg, 0x4D05u, env, cfg.counter));
+      ms0 = 1.0 + cfg.base_mass_err[0] + (cfg.base_mass_err[1] - cfg.base_mass_err[0]) * mt_draw(cfg, 0x4D03u, env, cfg.counter);
+      ms1 = (motor + leg) / m.mass[root + 1];
+      ms2 = leg / m.mass[root + 2];
+    }
+    if (cfg.randomize & 4) fmu = cfg.foot_friction[0] + (cfg.foot_friction[1] - cfg.foot_friction[0]) * mt_draw(cfg, 0x4D06u, env, cfg.counter);
     load_state<NV>(s, m, cfg.reset_qpos, a.st.qvel + (size_t)env * NV, sub);
     if (sub < NV) s.qv[sub] = 0.0;
     oh = 0; en = true; obs_t = 0.0;
   } else {
     goal0 = a.st.goal[(size_t)env * 2]; goal1 = a.st.goal[(size_t)env * 2 + 1];
-    voltage = a.st.motor_param[(size_t)env * 2]; viscous = a.st.motor_param[(size_t)env * 2 + 1];
+    const double* mp = a.st.motor_param + (size_t)env * 6;
+    voltage = mp[0]; viscous = mp[1]; ms0 = mp[2]; ms1 = mp[3]; ms2 = mp[4]; fmu = mp[5];
     load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
     oh = a.st.overheat[(size_t)env * 8 + mi]; en = a.st.motor_enabled[(size_t)env * 8 + mi] != 0; obs_t = a.st.observed_torque[(size_t)env * 8 + mi];
   }
   if (sub < NV) s.xt.ext[sub] = 0.0;
+  if (sub == 0) { s.xt.mscale[0] = ms0; s.xt.mscale[1] = ms1; s.xt.mscale[2] = ms2; s.xt.foot_mu = fmu; }
   fence();
   // Minitaur.ApplyAction (minitaur.py:326-390) of motor `mi`: the command clipped to what the velocity limit allows in one timestep, the DC-motor
   // model, overheat protection, torque x motor direction -> s.xt.ext[dof]
@@ -2661,7 +2687,8 @@ __global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const Minit
       }
       if (sub == 0) {
         a.st.goal[(size_t)env * 2] = goal0; a.st.goal[(size_t)env * 2 + 1] = goal1;
-        a.st.motor_param[(size_t)env * 2] = voltage; a.st.motor_param[(size_t)env * 2 + 1] = viscous;
+        double* mp = a.st.motor_param + (size_t)env * 6;
+        mp[0] = voltage; mp[1] = viscous; mp[2] = s.xt.mscale[0]; mp[3] = s.xt.mscale[1]; mp[4] = s.xt.mscale[2]; mp[5] = s.xt.foot_mu;
         if (a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
         if (a.st.steps_since_goal_change) a.st.steps_since_goal_change[env] = 0;
       }

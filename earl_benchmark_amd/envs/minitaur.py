@@ -9,8 +9,9 @@ The numpy the reference wraps around Bullet is followed line by line in the kern
 overheat protection, reward, success; the first three are pinned bit-exact by tests/test_glue*.py against goldens recorded from the reference's own
 functions).  **THE RIGID-BODY PART IS UNPINNED AND MODEL-LESS**: the reference simulates pybullet_data's minitaur.urdf in PyBullet 3.2.0, neither of
 which is in its tree; the robot model here (tools/minitaur_model.py: 22 dofs, four loop closures, spheres against the ground and the wall tiles) is
-this build's own authoring on this build's own stepper (MuJoCo-style soft constraints, not Bullet's sequential-impulse solver), and of the env
-randomizer [UPSTREAM pybullet_envs] only the battery-voltage and motor-damping draws are built.  DESIGN.md section 14.
+this build's own authoring on this build's own stepper (MuJoCo-style soft constraints, not Bullet's sequential-impulse solver).  The env randomizer
+[UPSTREAM pybullet_envs.bullet.minitaur_env_randomizer, restated from memory] is built in the reset kernel: battery voltage, motor damping, base /
+leg-link / motor masses, foot friction, through the semantics of the reference's own setters (envs/minitaur.py:468-508).  DESIGN.md section 14.
 """
 import ctypes as C
 
@@ -29,17 +30,21 @@ ACTION_BOUND, ACTION_EPS = 1.0, 0.01                      # minitaur_gym_env.py:
 GOAL_LOCATIONS = np.array([[0.4, 0.2], [0.2, 0.2], [-0.2, 0.2], [-0.4, 0.2], [0.4, 0.0], [0.2, 0.0], [-0.2, 0.0], [-0.4, 0.0],
                            [0.4, 0.4], [0.2, 0.4], [-0.2, 0.4], [-0.4, 0.4]])   # :467-469
 OBS_DIM, ACT_DIM = 32, 8
+BASE_MASS_ERR, LEG_MASS_ERR, FOOT_FRICTION = (-0.2, 0.2), (-0.2, 0.2), (0.8, 1.5)   # [UPSTREAM] the randomizer's ranges
+N_PARAM = 6                                              # earl_minitaur_state.motor_param row: voltage, damping, three mass factors, foot friction
 
 
 def make_cfg(tables, n=0, env_offset=0, horizon=0, randomize=True, seed=0, goal_table_ptr=None, reset_qpos_ptr=None):
   """struct earl_minitaur_cfg from the model tables (shared with the oracle's front end, which passes host pointers)"""
   dt = float(tables['timestep'])
-  cfg = _abi.MinitaurCfg(n=n, env_offset=env_offset, horizon=horizon, num_substeps=NUM_SUBSTEPS, settle_steps=SETTLE_STEPS, randomize=int(bool(randomize)),
+  cfg = _abi.MinitaurCfg(n=n, env_offset=env_offset, horizon=horizon, num_substeps=NUM_SUBSTEPS, settle_steps=SETTLE_STEPS, randomize=(7 if randomize is True else (int(randomize) if randomize else 0)),
                          n_goals=len(GOAL_LOCATIONS), goal_change_frequency=0, overheat_steps=int(OVERHEAT_SHUTDOWN_TIME / dt),
                          motor_kp=MOTOR_KP, motor_kd=MOTOR_KD, motor_velocity_limit=MOTOR_VELOCITY_LIMIT, overheat_torque=OVERHEAT_SHUTDOWN_TORQUE,
                          distance_weight=DISTANCE_WEIGHT, energy_weight=ENERGY_WEIGHT, success_radius=0.1, goal_table=goal_table_ptr,
                          reset_qpos=reset_qpos_ptr, seed=int(seed) & (2**64 - 1), counter=0, step_counter=0)
   cfg.motor_dof[:] = [int(x) for x in tables['motor_dof']]
+  cfg.base_mass_err[:], cfg.leg_mass_err[:], cfg.foot_friction[:] = BASE_MASS_ERR, LEG_MASS_ERR, FOOT_FRICTION
+  cfg.leg_mass, cfg.motor_mass = float(tables['rand_leg_mass']), float(tables['rand_motor_mass'])
   cfg.motor_dir[:] = [float(x) for x in tables['motor_direction']]
   return cfg
 
@@ -73,7 +78,7 @@ class Minitaur:
     kw = dict(dtype=torch.float64, device=dev)
     self.qpos, self.qvel = torch.zeros(n, self.NQ, **kw), torch.zeros(n, self.NV, **kw)
     self.goal_t = torch.tensor(GOAL_LOCATIONS[0], **kw).repeat(n, 1).contiguous()
-    self.motor_param = torch.tensor([16.0, 0.0], **kw).repeat(n, 1).contiguous()
+    self.motor_param = torch.tensor([16.0, 0.0, 1.0, 1.0, 1.0, -1.0], **kw).repeat(n, 1).contiguous()   # [n, N_PARAM], written by the reset kernel
     self.observed_torque = torch.zeros(n, 8, **kw)
     self.overheat = torch.zeros(n, 8, dtype=torch.int32, device=dev)
     self.motor_enabled = torch.ones(n, 8, dtype=torch.uint8, device=dev)

@@ -189,7 +189,7 @@ def load_collision_model(d):
   small = len(d['parent']) <= 10                # csrc/physics.hip Lim<NV>: 8 contact slots / 16 blocks for nv <= 10
   assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS
   nvm = len(d['parent'])
-  assert c.n_blk <= (16 if small else (64 if nvm == 23 else 32)) and 0 < c.max_con <= (8 if small else MAXCON)      # Lim<NV>::MB, ::MC
+  assert c.n_blk <= (16 if small else (64 if nvm == 23 else (8 if nvm == 22 else 32))) and 0 < c.max_con <= (8 if small else MAXCON)      # Lim<NV>::MB, ::MC
   if nvm == 22:
     # csrc/physics.hip (Lim<22>::CONNECT, K9): a contact's Jacobian is taken to touch the root body's six dofs and the sphere's own chain of at most
     # two hinges -- spheres ride on the root body or on such a chain, boxes are fixed to the world

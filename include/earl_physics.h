@@ -336,7 +336,8 @@ typedef struct earl_minitaur_cfg {
   int32_t horizon;                 /* <= 0: never done */
   int32_t num_substeps;            /* 5  (minitaur_gym_env.py:25, 161-164) */
   int32_t settle_steps;            /* 100 (:265-269) */
-  int32_t randomize;               /* per-reset battery voltage / viscous damping draws; 0: 16 V, 0 */
+  int32_t randomize;               /* MinitaurEnvRandomizer [UPSTREAM pybullet_envs.bullet.minitaur_env_randomizer] per reset, bit mask: 1 battery voltage U(14.8, 16.8) and
+                                      motor viscous damping U(0, 0.01) (else 16 V, 0); 2 base / leg-link / motor masses (minitaur.py:468-488); 4 foot friction (:490-498) */
   int32_t n_goals;                 /* rows of goal_table: 12 (:467-469) */
   int32_t goal_change_frequency;   /* > 0: LifelongWrapper.step (lifelong_wrapper.py:30-44), as in earl_sawyer_cfg */
   int32_t overheat_steps;          /* OVERHEAT_SHUTDOWN_TIME / time_step = 500 (minitaur.py:14-15, 356) */
@@ -350,14 +351,22 @@ typedef struct earl_minitaur_cfg {
   double success_radius;           /* 0.1 (:500) */
   const double* goal_table;        /* device, [n_goals, 2] */
   const double* reset_qpos;        /* device, [23]: base (0, 0, 0.2), identity, motor joints dir pi / 2, knee joints dir -2.1834 (minitaur.py:10-11, 187-211) */
-  uint64_t seed, counter;          /* reset draws: Philox(seed; 0x4D00 + k, global env id, counter), k = 0 goal, 1 voltage, 2 damping */
+  double base_mass_err[2];         /* (-0.2, 0.2): SetBaseMass(U(m (1 + lo), m (1 + hi))) -> the root body's mass and inertia x that factor */
+  double leg_mass_err[2];          /* (-0.2, 0.2): SetLegMasses([U of the leg-link mass, U of the motor mass]): minitaur.py:472-488 writes the FIRST to all 16 leg links --
+                                      upper AND lower -- and the second to the 8 motors.  This build's links: upper = motor + upper leg link -> mass (and inertia) x
+                                      (motor' + leg') / model mass; lower -> x leg' / model mass (the reference's quirk kept: a lower leg then weighs what an upper one does) */
+  double leg_mass, motor_mass;     /* the two masses the randomizer reads back from the URDF (minitaur.py:101-107): leg link LEG_LINK_ID[0], motor MOTOR_LINK_ID[0] */
+  double foot_friction[2];         /* (0.8, 1.5): SetFootFriction -> friction of every contact of a lower-leg link's spheres (FOOT_LINK_ID = the lower links) */
+  uint64_t seed, counter;          /* reset draws: Philox(seed; 0x4D00 + k, global env id, counter), k = 0 goal, 1 voltage, 2 damping, 3 base mass, 4 leg-link mass,
+                                      5 motor mass, 6 foot friction */
   uint64_t step_counter;           /* env steps taken before this launch (goal-switch draws: Philox(seed; 0xFFFE, global env id, step)) */
 } earl_minitaur_cfg;
 typedef struct earl_minitaur_state {
   double* qpos;                    /* [n, 23] */
   double* qvel;                    /* [n, 22] */
   double* goal;                    /* [n, 2] */
-  double* motor_param;             /* [n, 2] battery voltage, motor viscous damping */
+  double* motor_param;             /* [n, 6] what the randomizer set at the last reset: battery voltage, motor viscous damping, mass factor of the base, of the upper
+                                      links, of the lower links, foot friction (<= 0: the contact classes' own) */
   double* observed_torque;         /* [n, 8] Minitaur._observed_motor_torques of the newest ApplyAction */
   int32_t* overheat;               /* [n, 8] Minitaur._overheat_counter */
   uint8_t* motor_enabled;          /* [n, 8] Minitaur._motor_enabled_list */

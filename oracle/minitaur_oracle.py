@@ -9,8 +9,9 @@ What IS the reference's own code and is followed line by line (and pinned bit-ex
   MinitaurBulletEnv.step (action check, leg model, action_repeat x (ApplyAction, stepSimulation)), reset (100 settle steps)   :222-270, 276-329
   Minitaur.ApplyAction (velocity-limit clip, motor model, overheat protection, torque with motor direction), GetObservation   envs/minitaur.py:300-390
   Minitaur.ConvertFromLegModel :434-457;  MotorModel.convert_to_torque  envs/motor.py:49-94   (oracle.glue_oracle: leg_to_motor, motor_torque)
-  MinitaurEnvRandomizer [UPSTREAM pybullet_envs, from memory]: battery voltage U(14.8, 16.8) and motor viscous damping U(0, 0.01) per reset are
-  drawn here; its mass / foot-friction randomisation is NOT built (one model table for the batch).
+  MinitaurEnvRandomizer.randomize_env [UPSTREAM pybullet_envs.bullet.minitaur_env_randomizer, from memory] per reset: base mass x U(0.8, 1.2), leg-link
+  and motor mass x U(0.8, 1.2) each, battery voltage U(14.8, 16.8), motor viscous damping U(0, 0.01), foot friction U(0.8, 1.5) -- through the
+  reference's own setters Minitaur.SetBaseMass / SetLegMasses / SetFootFriction / SetBatteryVoltage / SetMotorViscousDamping (envs/minitaur.py:468-508).
 """
 import os
 
@@ -31,7 +32,8 @@ OVERHEAT_SHUTDOWN_TORQUE, OVERHEAT_SHUTDOWN_TIME = 2.45, 1.0   # minitaur.py:14-
 SETTLE_STEPS = 100                               # minitaur_gym_env.py:265-269
 GOAL_LOCATIONS = np.array([[0.4, 0.2], [0.2, 0.2], [-0.2, 0.2], [-0.4, 0.2], [0.4, 0.0], [0.2, 0.0], [-0.2, 0.0], [-0.4, 0.0],
                            [0.4, 0.4], [0.2, 0.4], [-0.2, 0.4], [-0.4, 0.4]])   # :467-469
-STREAM_RESET = 0x4D00                            # Philox draw ids of the reset: goal index, battery voltage, viscous damping
+STREAM_RESET = 0x4D00                            # Philox draw ids of the reset: goal index, battery voltage, viscous damping, base / leg-link / motor mass, foot friction
+BASE_MASS_ERR, LEG_MASS_ERR, FOOT_FRICTION = (-0.2, 0.2), (-0.2, 0.2), (0.8, 1.5)   # [UPSTREAM] MINITAUR_BASE_MASS_ERROR_RANGE, ..._LEG_MASS_..., MINITAUR_LEG_FRICTION
 ACTION_BOUND, ACTION_EPS = 1.0, 0.01             # :144, 30
 
 
@@ -45,7 +47,14 @@ class MinitaurOracle:
   def __init__(self, env_id=0, seed=0, randomize=True, contacts=True):
     self.lm = LinkModel(MODEL)
     self.lm.contacts = contacts
-    self.env_id, self.seed, self.counter, self.randomize = int(env_id), int(seed), 0, bool(randomize)
+    self.mass0, self.inertia0 = self.lm.mass.copy(), self.lm.inertia.copy()       # the model's own: the randomizer scales from these at every reset
+    root = int(self.lm.ball_dof) + 2
+    self.base_link = root
+    self.upper_links = [l for l in range(root + 1, self.lm.nv) if self.lm.parent[l] == root]          # motor + upper leg link
+    self.lower_links = [l for l in range(root + 1, self.lm.nv) if self.lm.parent[l] != root]          # FOOT_LINK_ID (minitaur.py:25)
+    self.scale = np.ones(3)
+    self.foot_mu = -1.0
+    self.env_id, self.seed, self.counter, self.randomize = int(env_id), int(seed), 0, randomize          # True = everything (7), or the bit mask of earl_minitaur_cfg.randomize
     self.motor_dof = [int(x) for x in self.lm.motor_dof]
     self.dir = np.asarray(self.lm.motor_direction, float)
     self.goal = GOAL_LOCATIONS[0].copy()
@@ -98,9 +107,23 @@ class MinitaurOracle:
     gi = min(int(self.draw(0) * len(GOAL_LOCATIONS)), len(GOAL_LOCATIONS) - 1) if goal_idx is None else int(goal_idx)    # get_next_goal :490-493
     self.goal = GOAL_LOCATIONS[gi].copy()
     self.goal_idx = gi
-    if self.randomize:                                   # MinitaurEnvRandomizer.randomize_env [UPSTREAM]: battery voltage, motor viscous damping
+    rnd = 7 if self.randomize is True else (int(self.randomize) if self.randomize else 0)
+    if rnd & 1:                                          # SetBatteryVoltage, SetMotorViscousDamping (minitaur.py:500-508)
       self.voltage = 14.8 + (16.8 - 14.8) * self.draw(1)
       self.viscous = 0.01 * self.draw(2)
+    if rnd & 2:                                          # SetBaseMass, SetLegMasses (:468-488): the first leg mass goes to ALL 16 leg links, upper and lower
+      lm = self.lm
+      leg0, motor0 = float(lm.rand_leg_mass), float(lm.rand_motor_mass)
+      s_base = 1.0 + BASE_MASS_ERR[0] + (BASE_MASS_ERR[1] - BASE_MASS_ERR[0]) * self.draw(3)
+      leg = leg0 * (1.0 + LEG_MASS_ERR[0] + (LEG_MASS_ERR[1] - LEG_MASS_ERR[0]) * self.draw(4))
+      motor = motor0 * (1.0 + LEG_MASS_ERR[0] + (LEG_MASS_ERR[1] - LEG_MASS_ERR[0]) * self.draw(5))
+      self.scale = np.array([s_base, (motor + leg) / self.mass0[self.upper_links[0]], leg / self.mass0[self.lower_links[0]]])
+      for links, f in (([self.base_link], self.scale[0]), (self.upper_links, self.scale[1]), (self.lower_links, self.scale[2])):
+        for l in links:
+          lm.mass[l], lm.inertia[l] = self.mass0[l] * f, self.inertia0[l] * f
+    if rnd & 4:                                          # SetFootFriction (:490-498): every contact of a lower-leg link
+      self.foot_mu = FOOT_FRICTION[0] + (FOOT_FRICTION[1] - FOOT_FRICTION[0]) * self.draw(6)
+      self.lm.link_mu = {l: self.foot_mu for l in self.lower_links}
     self.counter += 1
     self.qpos, self.qvel = np.array(self.lm.qpos0, float), np.zeros(self.lm.nv)             # Minitaur.Reset(reload_urdf=False) :170-176
     self.overheat, self.enabled = np.zeros(8, int), [True] * 8                               # :178-179

@@ -75,7 +75,7 @@ class CMinitaur:
                            goal_table_ptr=self.goal_table.ctypes.data, reset_qpos_ptr=self.reset_qpos.ctypes.data)
     self.cfg.goal_change_frequency = goal_change_frequency
     self.qpos, self.qvel = np.zeros((n, 23)), np.zeros((n, 22))
-    self.goal, self.motor_param = np.zeros((n, 2)), np.tile([16.0, 0.0], (n, 1))
+    self.goal, self.motor_param = np.zeros((n, 2)), np.tile([16.0, 0.0, 1.0, 1.0, 1.0, -1.0], (n, 1))
     self.observed_torque, self.overheat, self.motor_enabled = np.zeros((n, 8)), np.zeros((n, 8), np.int32), np.ones((n, 8), np.uint8)
     self.steps_since_reset, self.steps_since_goal_change, self.fail_count = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
     self.last_obs = np.zeros((n, 32))

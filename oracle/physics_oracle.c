@@ -143,6 +143,9 @@ static Q4 qnormalize(Q4 q) {
 
 /* one timestep (integrate != 0) or the forward quantities only; reference: LinkModel.forward / step.
  * qp is a qpos row [nq] (the free body's quaternion at [ball_dof, ball_dof + 4)), qv a qvel row [nv]. */
+/* the minitaur's randomised foot friction (Minitaur.SetFootFriction, minitaur.py:490-498): friction of every contact of a LOWER-leg link's spheres
+ * (links behind the root body whose parent is not the root); <= 0: the contact classes' own.  Set per env by the minitaur front end below. */
+static _Thread_local double g_foot_mu = -1.0;
 static void substep(const LM* m, const earl_collision_model* col, double* qp, double* qv, V3 mpos, Q4 mq, const double* ctrl,
                     int integrate, StepOut* o, const double* qfrc) {
   /* qfrc: generalized forces applied from outside (the minitaur's motor torques), or NULL */
@@ -453,7 +456,8 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
             Jn[j] += dot(n, Jp); Jt1[j] += dot(t1, Jp); Jt2[j] += dot(t2, Jp);
           }
         }
-        const double mu = col->cls_mu[cls];
+        const int root_ = m->ball_dof + 2;
+        const double mu = (g_foot_mu > 0 && m->ball_dof == 3 && lk > root_ && m->parent[lk] != root_) ? g_foot_mu : col->cls_mu[cls];
         double kk, bb, dd;
         kbimp(col->cls_solref[cls], col->cls_solimp[cls], dist - margin, dt, &kk, &bb, &dd);
         const double R0 = fmax((1 - dd) / dd * col->cls_invw[cls], 1e-15);
@@ -767,21 +771,46 @@ static double mt_draw(const earl_minitaur_cfg* cfg, int k, int e, uint64_t count
   return u01_(b[0], b[1]);
 }
 
-int oracle_minitaur_reset(const earl_link_model24* m, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
+/* the env's own copy of the model tables with what the randomizer set at its last reset (earl_minitaur_state.motor_param row: voltage, damping, mass
+ * factor of the root body / the upper links / the lower links, foot friction): mass and inertia x factor, centre of mass kept */
+static void mt_env_model(const earl_link_model24* m, const double* mp, earl_link_model24* d) {
+  *d = *m;
+  const int root = m->ball_dof + 2;
+  for (int l = root; l < m->nv; ++l) {
+    const double f = l == root ? mp[2] : (m->parent[l] == root ? mp[3] : mp[4]);
+    d->mass[l] = m->mass[l] * f;
+    for (int k = 0; k < 6; ++k) d->inertia[l][k] = m->inertia[l][k] * f;
+  }
+  g_foot_mu = mp[5];
+}
+int oracle_minitaur_reset(const earl_link_model24* m0, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
                           const uint8_t* mask, double* obs) {
-  const int nv = m->nv, n = cfg->n;
+  const int nv = m0->nv, n = cfg->n;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < n; ++e) {
     if (mask && !mask[e]) continue;
-    double* qp = st->qpos + (size_t)e * m->nq;
+    double* qp = st->qpos + (size_t)e * m0->nq;
     double* qv = st->qvel + (size_t)e * nv;
     double* goal = st->goal + (size_t)e * 2;
     int gi = (int)(mt_draw(cfg, 0, e, cfg->counter, 0x4D00u) * (double)cfg->n_goals);       /* get_next_goal :490-493 */
     if (gi >= cfg->n_goals) gi = cfg->n_goals - 1;
     goal[0] = cfg->goal_table[2 * gi]; goal[1] = cfg->goal_table[2 * gi + 1];
-    double* mp = st->motor_param + (size_t)e * 2;
-    if (cfg->randomize) { mp[0] = 14.8 + (16.8 - 14.8) * mt_draw(cfg, 1, e, cfg->counter, 0x4D00u); mp[1] = 0.01 * mt_draw(cfg, 2, e, cfg->counter, 0x4D00u); }
-    else { mp[0] = 16.0; mp[1] = 0.0; }
+    double* mp = st->motor_param + (size_t)e * 6;
+    /* MinitaurEnvRandomizer.randomize_env [UPSTREAM] through Minitaur.SetBatteryVoltage / SetMotorViscousDamping / SetBaseMass / SetLegMasses / SetFootFriction */
+    mp[0] = 16.0; mp[1] = 0.0; mp[2] = mp[3] = mp[4] = 1.0; mp[5] = -1.0;
+    if (cfg->randomize & 1) { mp[0] = 14.8 + (16.8 - 14.8) * mt_draw(cfg, 1, e, cfg->counter, 0x4D00u); mp[1] = 0.01 * mt_draw(cfg, 2, e, cfg->counter, 0x4D00u); }
+    if (cfg->randomize & 2) {
+      const int root = m0->ball_dof + 2;
+      const double leg = cfg->leg_mass * (1.0 + cfg->leg_mass_err[0] + (cfg->leg_mass_err[1] - cfg->leg_mass_err[0]) * mt_draw(cfg, 4, e, cfg->counter, 0x4D00u));
+      const double motor = cfg->motor_mass * (1.0 + cfg->leg_mass_err[0] + (cfg->leg_mass_err[1] - cfg->leg_mass_err[0]) * mt_draw(cfg, 5, e, cfg->counter, 0x4D00u));
+      mp[2] = 1.0 + cfg->base_mass_err[0] + (cfg->base_mass_err[1] - cfg->base_mass_err[0]) * mt_draw(cfg, 3, e, cfg->counter, 0x4D00u);
+      mp[3] = (motor + leg) / m0->mass[root + 1];          /* the first upper link (parent = root) and its lower link: every leg has the same two masses */
+      mp[4] = leg / m0->mass[root + 2];
+    }
+    if (cfg->randomize & 4) mp[5] = cfg->foot_friction[0] + (cfg->foot_friction[1] - cfg->foot_friction[0]) * mt_draw(cfg, 6, e, cfg->counter, 0x4D00u);
+    earl_link_model24 me;
+    mt_env_model(m0, mp, &me);
+    const earl_link_model24* m = &me;
     memcpy(qp, cfg->reset_qpos, sizeof(double) * m->nq);
     for (int k = 0; k < nv; ++k) qv[k] = 0;
     MtMotors mt = {mp[0], mp[1], st->observed_torque + (size_t)e * 8, st->overheat + (size_t)e * 8, st->motor_enabled + (size_t)e * 8};
@@ -805,16 +834,19 @@ int oracle_minitaur_reset(const earl_link_model24* m, const earl_collision_model
   return 0;
 }
 
-int oracle_minitaur_rollout(const earl_link_model24* m, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
+int oracle_minitaur_rollout(const earl_link_model24* m0, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
                             const float* action, int32_t T, const earl_minitaur_out* out) {
-  const int nv = m->nv, n = cfg->n;
+  const int nv = m0->nv, n = cfg->n;
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < n; ++e) {
     StepOut o;
-    double* qp = st->qpos + (size_t)e * m->nq;
+    double* qp = st->qpos + (size_t)e * m0->nq;
     double* qv = st->qvel + (size_t)e * nv;
     double* goal = st->goal + (size_t)e * 2;
-    const double* mp = st->motor_param + (size_t)e * 2;
+    const double* mp = st->motor_param + (size_t)e * 6;
+    earl_link_model24 me;
+    mt_env_model(m0, mp, &me);
+    const earl_link_model24* m = &me;
     int steps = st->steps_since_reset ? st->steps_since_reset[e] : 0;
     const int gcf = st->steps_since_goal_change ? cfg->goal_change_frequency : 0;
     int sgc = gcf > 0 ? st->steps_since_goal_change[e] : 0;

@@ -1008,7 +1008,7 @@ class LinkModel:
     J, aref, R = [], [], []
     for c in contacts:
       cls = c['cls']
-      mu = float(self.col_cls_mu[cls])
+      mu = float(getattr(self, 'link_mu', {}).get(c['ls'], self.col_cls_mu[cls]))       # link_mu: per-link override (the minitaur's randomised foot friction)
       Jp = np.zeros((3, nv))
       for l, sgn in ((c['ls'], 1.0), (c['lb'], -1.0)):
         if l >= 0:

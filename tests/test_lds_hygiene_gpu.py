@@ -1,0 +1,82 @@
+"""Do the env kernels read LDS they never wrote?
+
+LDS keeps its contents from one kernel to the next.  A slot that is read before it is written and then multiplied by a zero weight is harmless while
+the left-over bits are finite and poisons the env when they are NaN or Inf -- e.g. after the failure guard rolled back a diverged env that ran on
+the same CU.  (Found in round 3 as a once-in-ten flake of the minitaur soak: one accumulation over contact slots lacked the validity select the
+others have.)  The test fills every CU's LDS with a pattern (tests/lds_poison.hip), runs reset / step / fused rollout of every env, and asks for
+bit-identical results with zeros, NaNs and Infs left behind."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+NAN, ZERO, INF = 0x7FF8000000000000, 0, 0x7FF0000000000000
+
+
+@pytest.fixture(scope='module')
+def poison():
+  import torch
+  src, so = os.path.join(REPO, 'tests', 'lds_poison.hip'), os.path.join(REPO, 'tests', 'liblds_poison.so')
+  if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', '-o', so, src])
+  lib = C.CDLL(so)
+  lib.lds_poison.argtypes = [C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+  sink = torch.zeros(8, dtype=torch.int64, device='cuda')
+
+  def fill(pattern):
+    rc = lib.lds_poison(pattern, 2048, sink.data_ptr(), torch.cuda.current_stream().cuda_stream)      # 8 rounds of one 160 KB workgroup per CU
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+  return fill
+
+
+def _cases():
+  from earl_benchmark_amd.envs.kitchen import Kitchen
+  from earl_benchmark_amd.envs.minitaur import Minitaur
+  from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  from earl_benchmark_amd.envs.tabletop import TabletopManipulation
+  return {'minitaur': (lambda: Minitaur(num_envs=2048, scalar_api=False, seed=3), 40, 8),
+          'kitchen': (lambda: Kitchen(num_envs=1024, scalar_api=False, seed=3), 12, 9),
+          'sawyer_door': (lambda: SawyerDoor(num_envs=4096, scalar_api=False, seed=3), 30, 4),
+          'sawyer_door_8waves': (lambda: SawyerDoor(num_envs=8192, scalar_api=False, seed=3), 20, 4),
+          'sawyer_peg': (lambda: SawyerPeg(num_envs=4096, scalar_api=False, seed=3), 30, 4),
+          # the reverse tasks start in contact: hand at the door handle, peg inside the hole (contact slots in use, different counts per env of a wave)
+          'sawyer_door_at_goal': (lambda: SawyerDoor(num_envs=4096, scalar_api=False, seed=3, reset_at_goal=True), 40, 4),
+          'sawyer_peg_at_goal': (lambda: SawyerPeg(num_envs=4096, scalar_api=False, seed=3, reset_at_goal=True), 30, 4),
+          'tabletop': (lambda: TabletopManipulation(num_envs=4096, reward_type='sparse', seed=3), 200, 3)}
+
+
+@pytest.mark.parametrize('name', ['minitaur', 'kitchen', 'sawyer_door', 'sawyer_door_8waves', 'sawyer_peg', 'sawyer_door_at_goal', 'sawyer_peg_at_goal', 'tabletop'])
+def test_results_do_not_depend_on_what_lds_held_before(poison, name):
+  import torch
+  make, T, adim = _cases()[name]
+  runs = {}
+  for tag, pat in (('zero', ZERO), ('nan', NAN), ('inf', INF)):
+    poison(pat)
+    env = make()                                              # (the constructor resets: the reset kernel and, for the Sawyer envs / kitchen, the settle)
+    poison(pat)
+    obs0 = env.reset()
+    g = torch.Generator(device='cuda').manual_seed(1)
+    acts = torch.rand(T + 2, env.num_envs, adim, generator=g, device='cuda') * 2 - 1
+    stepped = []
+    for t in range(2):                                        # the per-step kernels
+      poison(pat)
+      stepped.append(env.step(acts[t])[0].clone())
+    poison(pat)
+    out = env.rollout(acts[2:])                               # the fused kernel
+    o = out['obs'] if isinstance(out, dict) else out[0]
+    fails = int(env.fail_count.sum()) if hasattr(env, 'fail_count') else 0
+    runs[tag] = (torch.as_tensor(obs0).clone(), stepped, o.clone(), fails)
+    del env
+  ref = runs['zero']
+  assert ref[3] == 0 and bool(torch.isfinite(ref[2]).all())
+  for tag in ('nan', 'inf'):
+    r = runs[tag]
+    assert r[3] == 0, (name, tag, 'steps rolled back by the failure guard', r[3])
+    assert torch.equal(ref[0], r[0]) and all(torch.equal(a, b) for a, b in zip(ref[1], r[1])) and torch.equal(ref[2], r[2]), (name, tag)

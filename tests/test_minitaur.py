@@ -99,7 +99,12 @@ def test_c_restatement_matches_the_numpy_statement():
   on = np.stack([o.observation() for o in os_])
   np.testing.assert_allclose(oc, on, rtol=0, atol=1e-10)
   np.testing.assert_array_equal(c.goal, np.stack([o.goal for o in os_]))
-  np.testing.assert_array_equal(c.motor_param, np.stack([[o.voltage, o.viscous] for o in os_]))
+  np.testing.assert_array_equal(c.motor_param, np.stack([[o.voltage, o.viscous, *o.scale, o.foot_mu] for o in os_]))      # the randomizer's six draws: identical bits
+  mp = c.motor_param
+  assert ((mp[:, 2] > 0.8) & (mp[:, 2] < 1.2)).all() and len(np.unique(mp[:, 2])) == n                                   # SetBaseMass: the model's base x U(0.8, 1.2)
+  assert ((mp[:, 3] * 0.275 > 0.8 * 0.275) & (mp[:, 3] * 0.275 < 1.2 * 0.275)).all()                                    # upper link = motor' + leg link'
+  assert ((mp[:, 4] * 0.086 > 0.8 * 0.034) & (mp[:, 4] * 0.086 < 1.2 * 0.034)).all()                                    # SetLegMasses' quirk: a lower leg gets the LEG-LINK mass
+  assert ((mp[:, 5] > 0.8) & (mp[:, 5] < 1.5)).all()                                                                     # SetFootFriction
   rng = np.random.default_rng(1)
   acts = rng.uniform(-1, 1, (T, n, 8)).astype(np.float32)
   res = c.rollout(acts)

@@ -123,3 +123,32 @@ def test_full_size_soak_4096_envs_1000_steps(torch):
   z = u.qpos[:, 2]
   assert float(z.min()) > 0.02 and float(z.max()) < 0.6                        # nobody fell through the ground or flew off
   assert float(u.qpos[:, :2].abs().max()) < 1.6                                # ... or through a wall
+
+
+def test_the_env_randomizer_sets_masses_and_foot_friction_per_env(torch):
+  """MinitaurEnvRandomizer [UPSTREAM] through the reference's own setters (minitaur.py:468-508): six parameters per env and reset (identical bits in the
+  kernel and the CPU statement), each inside its range, different between envs and between resets; a heavier base sinks the stance lower; without
+  the randomizer every env is the nominal model and the whole batch settles to ONE pose."""
+  from oracle import physics_c
+  n = 64
+  env = make(n, seed=3)
+  p0 = env.motor_param.cpu().numpy().copy()
+  c = physics_c.CMinitaur(n, seed=3); c.reset()
+  np.testing.assert_array_equal(p0, c.motor_param)
+  assert ((p0[:, 0] >= 14.8) & (p0[:, 0] <= 16.8) & (p0[:, 1] >= 0) & (p0[:, 1] <= 0.01)).all()
+  assert ((p0[:, 2] > 0.8) & (p0[:, 2] < 1.2)).all() and ((p0[:, 5] > 0.8) & (p0[:, 5] < 1.5)).all()
+  up, lo = p0[:, 3] * 0.275, p0[:, 4] * 0.086                                      # masses of an upper / a lower link after SetLegMasses
+  assert ((up > 0.8 * 0.275) & (up < 1.2 * 0.275)).all() and ((lo > 0.8 * 0.034) & (lo < 1.2 * 0.034)).all()
+  assert all(len(np.unique(p0[:, k])) == n for k in range(6))
+  z0 = env.qpos[:, 2].cpu().numpy().copy()
+  assert np.corrcoef(p0[:, 2], z0)[0, 1] < -0.5                                    # heavier base -> lower stance after the 100 settle timesteps
+  env.reset()
+  p1 = env.motor_param.cpu().numpy()
+  assert (p1 != p0).all()                                                          # new draws at every reset
+  plain = make(n, seed=3, env_randomizer=None)
+  pp = plain.motor_param.cpu().numpy()
+  np.testing.assert_array_equal(pp, np.tile([16.0, 0.0, 1.0, 1.0, 1.0, -1.0], (n, 1)))
+  assert float(plain.qpos.std(0).max()) < 1e-12
+  only_motors = make(8, seed=3, env_randomizer=1)                                  # bit mask: 1 = voltage + damping only (what round 3's first minitaur build drew)
+  pm = only_motors.motor_param.cpu().numpy()
+  np.testing.assert_array_equal(pm[:, :2], p0[:8, :2]); np.testing.assert_array_equal(pm[:, 2:], np.tile([1.0, 1.0, 1.0, -1.0], (8, 1)))

@@ -99,7 +99,10 @@ def build():
            con_att1=np.array(con1, np.int32), con_att2=np.array(con2, np.int32), con_solref=np.tile([0.01, 1.0], (4, 1)),
            con_solimp=np.tile([0.95, 0.99, 0.001, 0.5, 2.0], (4, 1)), con_invweight=np.ones(4),
            motor_dof=np.array(motor_dofs, np.int32), knee_dof=np.array(knee_dofs, np.int32), motor_direction=MOTOR_DIR,
-           link_names=np.array(names), leg_l1=np.float64(L1), leg_l2=np.float64(L2))
+           link_names=np.array(names), leg_l1=np.float64(L1), leg_l2=np.float64(L2),
+           # what the env randomizer reads back as "URDF masses" (minitaur.py:101-107: leg link LEG_LINK_ID[0], motor MOTOR_LINK_ID[0]): the two parts of this
+           # model's 0.275 kg upper link (own authoring, like the link itself)
+           rand_leg_mass=np.float64(0.034), rand_motor_mass=np.float64(0.241))
   # reset pose (minitaur.py:10-11, 187-211)
   q0 = np.zeros(NV + 1)
   q0[0:3], q0[3:7] = INIT_POSITION, (1, 0, 0, 0)
