@@ -830,6 +830,7 @@ int oracle_minitaur_reset(const earl_link_model24* m0, const earl_collision_mode
     mt_observe(m, cfg, qp, qv, mt.observed, goal, ob);
     if (obs) memcpy(obs + (size_t)e * 32, ob, sizeof(ob));
     if (st->last_obs) memcpy(st->last_obs + (size_t)e * 32, ob, sizeof(ob));
+    g_foot_mu = -1.0;                                    /* (the override is this env's only) */
   }
   return 0;
 }
@@ -904,6 +905,7 @@ int oracle_minitaur_rollout(const earl_link_model24* m0, const earl_collision_mo
     if (st->steps_since_reset) st->steps_since_reset[e] = steps;
     if (gcf > 0) st->steps_since_goal_change[e] = sgc;
     if (st->last_obs && T > 0) memcpy(st->last_obs + (size_t)e * 32, out->obs + ((size_t)(T - 1) * n + e) * 32, sizeof(double) * 32);
+    g_foot_mu = -1.0;
   }
   return 0;
 }
