@@ -80,3 +80,41 @@ def test_results_do_not_depend_on_what_lds_held_before(poison, name):
     r = runs[tag]
     assert r[3] == 0, (name, tag, 'steps rolled back by the failure guard', r[3])
     assert torch.equal(ref[0], r[0]) and all(torch.equal(a, b) for a, b in zip(ref[1], r[1])) and torch.equal(ref[2], r[2]), (name, tag)
+
+
+@pytest.mark.parametrize('name', ['minitaur', 'kitchen', 'sawyer_door_at_goal', 'sawyer_peg_at_goal', 'tabletop'])
+def test_results_do_not_depend_on_what_uninitialised_device_buffers_held(name, monkeypatch):
+  """the same question for HBM: every buffer the front ends take with torch.empty (outputs, scratch) is pre-filled with 0xFF bytes (NaNs as floats,
+  255 as flags) instead of whatever the allocator hands out -- reset, steps and the fused rollout must not change by a bit"""
+  import torch
+  make, T, adim = _cases()[name]
+  real_empty, real_empty_like = torch.empty, torch.empty_like
+
+  def run(fill):
+    def empty(*a, **kw):
+      t = real_empty(*a, **kw)
+      if fill is not None and t.is_cuda:
+        t.view(torch.uint8).fill_(fill)
+      return t
+
+    def empty_like(x, **kw):
+      t = real_empty_like(x, **kw)
+      if fill is not None and t.is_cuda:
+        t.view(torch.uint8).fill_(fill)
+      return t
+    monkeypatch.setattr(torch, 'empty', empty); monkeypatch.setattr(torch, 'empty_like', empty_like)
+    try:
+      env = make()
+      obs0 = torch.as_tensor(env.reset()).clone()
+      g = torch.Generator(device='cuda').manual_seed(1)
+      acts = torch.rand(T + 2, env.num_envs, adim, generator=g, device='cuda') * 2 - 1
+      stepped = [env.step(acts[t])[0].clone() for t in range(2)]
+      out = env.rollout(acts[2:])
+      o = (out['obs'] if isinstance(out, dict) else out[0]).clone()
+      fails = int(env.fail_count.sum()) if hasattr(env, 'fail_count') else 0
+    finally:
+      monkeypatch.setattr(torch, 'empty', real_empty); monkeypatch.setattr(torch, 'empty_like', real_empty_like)
+    return obs0, stepped, o, fails
+  ref, got = run(0), run(0xFF)
+  assert ref[3] == 0 and got[3] == 0
+  assert torch.equal(ref[0], got[0]) and all(torch.equal(a, b) for a, b in zip(ref[1], got[1])) and torch.equal(ref[2], got[2])
