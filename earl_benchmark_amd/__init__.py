@@ -72,7 +72,7 @@ class EARLEnvs(object):
       self._num_initial_state_samples = kwargs.get('num_initial_state_samples', cfg['num_initial_state_samples'])
       self._goal_change_frequency = kwargs.get('goal_change_frequency', cfg['goal_change_frequency'])
     # The reference builds its envs here.  This build defers that to the first get_envs(): the tables and demonstrations of EVERY env
-    # name (incl. the ones whose dynamics are not built, and on machines without a GPU) stay reachable through the real constructor.
+    # name (also on machines without a GPU) stay reachable through the real constructor.
     self._envs = None
 
   def _build_envs(self):

@@ -1,7 +1,7 @@
 """Batched (GPU) versions of the pure-numpy glue of EARL's physics-backed envs -- include/earl_glue.h.
 
-The dynamics of sawyer_door / sawyer_peg / minitaur are MuJoCo / Bullet and are NOT built; these are
-the functions the reference itself evaluates in numpy around them, at parity with the reference
+The dynamics of sawyer_door / sawyer_peg / kitchen / minitaur are MuJoCo / Bullet in the reference and this build's own stepper here (include/earl_physics.h,
+parity unpinned: DESIGN.md sections 9-11, 14); these are the functions the reference itself evaluates in numpy around the dynamics, at parity with the reference
 (tests/test_glue.py, tests/test_glue_gpu.py):
   sawyer_sparse_reward  SawyerDoorV2 / SawyerPegV2 .is_successful and the sparse compute_reward branch
   leg_to_motor          Minitaur.ConvertFromLegModel

@@ -327,8 +327,8 @@ int earl_kitchen_rollout(const void* model24, const earl_collision_model* col, c
  * (envs/minitaur_gym_env.py:505-546 over MinitaurBulletEnv.step :285-329): Minitaur.ConvertFromLegModel (envs/minitaur.py:434-457), then
  * num_substeps x { Minitaur.ApplyAction (:326-390: velocity-limit clip of the command, MotorModel.convert_to_torque envs/motor.py:49-94, overheat
  * protection, torque x motor direction); one timestep of the stepper }, _reward, is_successful, GetObservation (:300-324) + goal; and
- * reset (:222-270, :476-479): goal drawn from goal_table, [UPSTREAM MinitaurEnvRandomizer, from memory] battery voltage U(14.8, 16.8) and motor viscous
- * damping U(0, 0.01) when cfg.randomize (its mass / friction randomisation is not built), pose <- reset_qpos, settle_steps x (ApplyAction(pi / 2), timestep).
+ * reset (:222-270, :476-479): goal drawn from goal_table, [UPSTREAM MinitaurEnvRandomizer, ranges from memory] per cfg.randomize: battery voltage, motor viscous
+ * damping, base / leg-link / motor masses, foot friction (the setters are the reference's own, envs/minitaur.py:468-508), pose <- reset_qpos, settle_steps x (ApplyAction(pi / 2), timestep).
  * obs [32] float64: motor angles 8, motor velocities 8, observed motor torques 8 (all in motor space = joint x direction), base orientation (x, y, z, w),
  * base x y, goal x y. */
 typedef struct earl_minitaur_cfg {
