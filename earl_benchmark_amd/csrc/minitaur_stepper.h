@@ -1,0 +1,673 @@
+// minitaur_stepper.h -- the minitaur's timestep written ON THE MODEL'S TREE: a floating root body (dofs 0-5) carrying four legs
+// of four hinges each (leg k = dofs 6 + 4 k ... 9 + 4 k: upper / lower link of the L chain, upper / lower link of the R chain, the two lower links tied
+// by the leg's connect constraint).  Included by physics.hip inside its anonymous namespace when built as physics_mt.hip (EARL_PHYS_VARIANT_MT).
+//
+// Same algorithm and the same numbers (to rounding) as the generic substep<22> of physics.hip, which it replaces on the product path (the generic
+// one stays selectable: earl_debug_set_minitaur_stepper, tests/test_minitaur_gpu.py compares the two); reference: oracle/physics_oracle.py
+// LinkModel.forward / step, oracle/physics_oracle.c.  What the structure buys (cycles per timestep of a wave = two envs, round-3 generic kernel
+// in brackets; tools/prof_minitaur.py):
+//   * frames, velocities, bias forces: a link's ancestors are the root body and at most one hinge -- everything about the root body is computed
+//     in registers from qpos / qvel by every lane, parent <-> child values move by DPP quad permutes (legs sit on aligned lane quads:
+//     lane 8 + 4 k + j), and the only LDS exchanges are the two subtree sums of the root body (composite inertia, bias force) [K1-K7 37 k]
+//   * the constraint Hessian M + J' D J is an ARROW matrix: root block R (6 x 6), leg blocks A_k (4 x 4), couplings B_k (4 x 6), nothing between
+//     different legs (closures and contacts touch the root body and one leg).  Only those 157 of the 253 entries exist here, the equality part
+//     stays in registers (11 numbers per lane), and contact terms are accumulated in registers per pass [K9a 8 k, Hessian columns 11 k per pass]
+//   * elimination order legs -> root has no fill-in: four 4 x 4 factorisations side by side, a Schur complement onto the root block, one 6 x 6
+//     factorisation redundantly per lane in registers -- three wave-level LDS exchanges per solve instead of one per column (22) plus one per
+//     substitution step [factor + solve 15.6 k per pass]
+//   * contact rows: lane = contact, all contacts at once; a contact's Jacobian has the root body's six entries and the two of its own chain
+//     (12 x 3 x 8 numbers instead of 12 x 3 x 22) [C3 6.5 k]
+// The structure is CHECKED by the host side (earl_benchmark_amd/physics/__init__.py load_link_model / load_collision_model, nv == 22); the kernels
+// assume it.
+#pragma once
+
+// ---- DPP moves within an aligned quad of lanes (a leg): CTRL = quad_perm selector (lane i of the quad reads lane (CTRL >> 2 i) & 3)
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ V3 dpp_quad(const V3& v) { return {dpp_quad<CTRL>(v.x), dpp_quad<CTRL>(v.y), dpp_quad<CTRL>(v.z)}; }
+template <int CTRL> __device__ __forceinline__ Q4 dpp_quad(const Q4& q) { return {dpp_quad<CTRL>(q.w), dpp_quad<CTRL>(q.x), dpp_quad<CTRL>(q.y), dpp_quad<CTRL>(q.z)}; }
+constexpr int QP_PARENT = 0xA0;     // [0, 0, 2, 2]: a lower link's lane reads its upper link's lane
+constexpr int QP_CHILD = 0xF5;      // [1, 1, 3, 3]: an upper link's lane reads its lower link's lane
+constexpr int QP_SWAP1 = 0xB1;      // [1, 0, 3, 2]
+constexpr int QP_SWAP2 = 0x4E;      // [2, 3, 0, 1]
+template <int P> constexpr int qp_bcast() { return P * 0x55; }   // every lane of the quad reads lane P
+
+struct MTDims {
+  static constexpr int NV = 22, NR = 6, NLEG = 4, LS = 4, NH = 16, LPE = 32, MC = EARL_MAXCON, MB = 8;
+};
+
+// Per-env LDS block of the minitaur stepper.  (xt / kit keep the member names the env kernel uses with the generic block.)
+struct SharedMTData {
+  static constexpr int NV = MTDims::NV, MC = MTDims::MC;
+  double qp[NV], qv[NV];
+  double bq[4];
+  double Xq[NV][4], Xp[NV][3];       // world frames (collision, attachments)
+  double aprev[NV];                  // solution of the newest solve (warm start of the next timestep; exchange buffer of the row tests)
+  struct { double ext[NV]; double mscale[3], foot_mu; } xt;
+  struct { double obs[46]; } kit;
+  double Sh[MTDims::NH][6];          // motion subspace of the hinges (contact Jacobians)
+  double redI[9][10];                // composite inertias of the eight upper links + the root body's own: summed by every lane
+  double redF[9][6];                 // the same for the bias forces
+  double eres[12], eD[12], ear[12];  // closure rows: residual, weight, reference acceleration
+  union {
+    double ct[MC][8];                // contact records (pair tests -> contact rows)
+    double cw[MC][8];                // per-pass edge weights
+  };
+  double CJr[MC][3][6];              // contact Jacobians (normal, tangent 1, tangent 2): the root body's six entries ...
+  double CJh[MC][3][2];              // ... and the (at most two) hinges of the sphere's own chain
+  int crow[MC][2];                   // those hinges' dofs (-1: none)
+  // the pass's Hessian, by blocks, and right-hand side
+  double HA[MTDims::NLEG][10];       // leg blocks, packed lower triangle (p, q) at p (p + 1) / 2 + q
+  double HB[MTDims::NH][6];          // couplings: row = hinge, column = root dof
+  double HR[6][6];                   // root block (both triangles)
+  double rc[NV];
+  // exchange buffers of the solve
+  double Wl[6][16];                  // W = B' L^-T, row = root dof
+  double part[6][4];                 // W_k y_k per root dof and leg
+  double Y[16];                      // y = L^-1 b of the legs
+  double LL[MTDims::NLEG][10];       // the legs' Cholesky factors (diagonal inverted)
+  double SS[22];                     // Schur complement of the root block, packed lower triangle (21)
+};
+struct SharedMT : SharedMTData {
+  static constexpr int R = (int)(sizeof(SharedMTData) % 256);
+  static constexpr int PAD = R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R);      // the two env blocks of a wave on different banks (physics.hip Shared<NV>)
+  char bank_pad[PAD == 0 ? 8 : PAD];
+};
+
+// One timestep of one env by its 32-lane group.  Lane roles: sub 0-5 = the root body's dofs, sub 8 + 4 k + j = hinge j of leg k (dof 6 + 4 k + j),
+// the other lanes idle (they shadow a hinge and store nothing).  INTEGRATE = false stops after qacc.
+template <bool INTEGRATE>
+__device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24& m, const BlkTable<MTDims::MB, true>& bt, const earl_collision_model* __restrict__ col,
+                                           const int sub, const int grp, const bool warm, double* qacc_out) {
+  constexpr int NV = MTDims::NV, MC = MTDims::MC, LPE = MTDims::LPE;
+  const int maxcon = bt.max_con < MC ? bt.max_con : MC;
+  const double dt = m.dt;
+  const bool isroot = sub < 6, ishinge = sub >= 8 && sub < 24, isl = isroot || ishinge;
+  const int l = isroot ? sub : (ishinge ? sub - 2 : NV - 1);      // this lane's dof
+  const int hq = (sub - 8) & 3;                                    // hinge lanes: position in the leg
+  const int leg = ishinge ? (sub - 8) >> 2 : 0;
+  const bool lower = ishinge && (hq & 1), upper = ishinge && !(hq & 1);
+  PSTART();
+  // ------------------------------------------------------------------ K1-K2: world frames, in registers
+  const V3 Pb = ld3(s.qp);
+  const Q4 Qb = ldq(s.bq);
+  double Rb[3][3];
+  qmat(Qb, Rb);
+  Q4 Q; V3 P;
+  const V3 ax = ld3(m.jaxis[l]);
+  const int jt = m.jtype[l];
+  const double ql_ = s.qp[l], qd = s.qv[l];
+  {
+    const Q4 tq = ldq(m.tquat[l]);
+    const V3 tp = ld3(m.tpos[l]);
+    double sn, cs;
+    sincos_mod(jt == 0 ? 0.5 * ql_ : 0.0, sn, cs);
+    const Q4 qloc = qmul(tq, Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z});
+    const Q4 Qu = qmul(Qb, qloc);                                   // as a link hanging off the root body
+    const V3 Pu = add(Pb, mulv(Rb, tp));
+    const Q4 Qp = dpp_quad<QP_PARENT>(Qu);                          // a lower link: its upper link's frame from the lane before
+    const V3 Pp = dpp_quad<QP_PARENT>(Pu);
+    double Rp[3][3];
+    qmat(Qp, Rp);
+    const Q4 Qw = qmul(Qp, qloc);
+    const V3 Pw = add(Pp, mulv(Rp, tp));
+    // root body: three slides along the world axes (identity orientation, the translation so far), then the orientation quaternion
+    const Q4 Qr = selq(sub < 3, Q4{1, 0, 0, 0}, Qb);
+    const V3 Pr{Pb.x, sub >= 1 ? Pb.y : 0.0, sub >= 2 ? Pb.z : 0.0};
+    Q = selq(isroot, Qr, selq(lower, Qw, Qu));
+    P = selv(isroot, Pr, selv(lower, Pw, Pu));
+  }
+  if (isl) {
+    double* oq = s.Xq[l];
+    double* op = s.Xp[l];
+    oq[0] = Q.w; oq[1] = Q.x; oq[2] = Q.y; oq[3] = Q.z; op[0] = P.x; op[1] = P.y; op[2] = P.z;
+  }
+  fence();
+  // ------------------------------------------------------------------ C0: collision bounding tests (lane = block; world-fixed boxes)
+  unsigned int nearw = 0, nearg = 0;
+  {
+    const int b = sub < bt.n_blk ? sub : 0;
+    const int bl = bt.link[b];
+    V3 cs = ld3(bt.center[b]);
+    {
+      double Rl[3][3];
+      qmat(ldq(s.Xq[bl < 0 ? 0 : bl]), Rl);
+      cs = selv(bl < 0, cs, add(ld3(s.Xp[bl < 0 ? 0 : bl]), mulv(Rl, cs)));
+    }
+    double Rbx[3][3];
+    qmat(ldq(bt.box_quat[b]), Rbx);
+    const V3 x = mulvT(Rbx, vsub(cs, ld3(bt.box_pos[b]))), h = ld3(bt.box_half[b]);
+    const V3 d{x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z)};
+    const bool nearb = sub < bt.n_blk && dot(d, d) < bt.reach[b] * bt.reach[b];
+    const unsigned long long bal = __ballot(nearb);
+    nearg = (unsigned int)((bal >> (grp * 32)) & 0xFFFFFFFFull);
+    nearw = (unsigned int)((bal | (bal >> 32)) & 0xFFFFFFFFull);
+  }
+  PSTAMP(0);
+  // ------------------------------------------------------------------ K3: motion subspace + spatial inertia of this lane's link
+  V3 Sw, Sv;
+  double I10[10];
+  double R[3][3];
+  qmat(Q, R);
+  {
+    const V3 aw = mulv(R, ax);
+    const V3 anchor = add(P, mulv(R, ld3(m.jpos[l])));
+    const bool rot = jt != 1;
+    Sw = selv(rot, aw, V3{0, 0, 0});
+    Sv = selv(rot, cross(anchor, aw), aw);
+    const int root = m.ball_dof + 2;
+    const double ms = l < root ? 1.0 : (l == root ? s.xt.mscale[0] : (m.parent[l] == root ? s.xt.mscale[1] : s.xt.mscale[2]));
+    const double mass = m.mass[l] * ms;
+    const V3 c = add(P, mulv(R, ld3(m.com[l])));
+    const double* in = m.inertia[l];
+    const double I[3][3] = {{in[0] * ms, in[3] * ms, in[4] * ms}, {in[3] * ms, in[1] * ms, in[5] * ms}, {in[4] * ms, in[5] * ms, in[2] * ms}};
+    double T[3][3], W[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) T[r][cc] = R[r][0] * I[0][cc] + R[r][1] * I[1][cc] + R[r][2] * I[2][cc];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = r; cc < 3; ++cc) W[r][cc] = T[r][0] * R[cc][0] + T[r][1] * R[cc][1] + T[r][2] * R[cc][2];
+    const double c2 = dot(c, c);
+    I10[0] = mass;
+    I10[1] = mass * c.x; I10[2] = mass * c.y; I10[3] = mass * c.z;
+    I10[4] = W[0][0] + mass * (c2 - c.x * c.x);
+    I10[5] = W[1][1] + mass * (c2 - c.y * c.y);
+    I10[6] = W[2][2] + mass * (c2 - c.z * c.z);
+    I10[7] = W[0][1] - mass * c.x * c.y;
+    I10[8] = W[0][2] - mass * c.x * c.z;
+    I10[9] = W[1][2] - mass * c.y * c.z;
+    if (ishinge) {
+      double* o = s.Sh[l - 6];
+      o[0] = Sw.x; o[1] = Sw.y; o[2] = Sw.z; o[3] = Sv.x; o[4] = Sv.y; o[5] = Sv.z;
+    }
+  }
+  PSTAMP(1);
+  // ------------------------------------------------------------------ K4: composite inertia (own + child by DPP; the root body: everything, through LDS)
+  double Ic[10];
+#pragma unroll
+  for (int e = 0; e < 10; ++e) {
+    const double ch = dpp_quad<QP_CHILD>(I10[e]);
+    Ic[e] = upper ? I10[e] + ch : I10[e];
+  }
+  if (upper || sub == 5) {
+    double* o = s.redI[upper ? (l - 6) >> 1 : 8];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) o[e] = Ic[e];
+  }
+  fence();
+  {
+    double tot[10];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) tot[e] = s.redI[8][e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 10; ++e) tot[e] += s.redI[u][e];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) Ic[e] = isroot ? tot[e] : Ic[e];
+  }
+  PSTAMP(3);
+  // ------------------------------------------------------------------ K5: this lane's entries of the mass matrix
+  // g6 = row l of the six root columns: M[l][r] = S_r . (Ic_l S_l) = [f ; Rb' (n + f x Pb)] with [n; f] = Ic_l S_l  (hinge: its row of B; root dof: its row of R);
+  // hinge lanes: the diagonal entry and, an upper link, the entry it shares with its lower link
+  double g6[6], Add, Ach;
+  {
+    V3 n, f;
+    iapply(Ic, Sw, Sv, n, f);
+    const V3 mo = mulvT(Rb, add(n, cross(f, Pb)));
+    g6[0] = f.x; g6[1] = f.y; g6[2] = f.z; g6[3] = mo.x; g6[4] = mo.y; g6[5] = mo.z;
+    Add = dot(Sw, n) + dot(Sv, f) + m.armature[l];
+    const V3 nc = dpp_quad<QP_CHILD>(n), fc = dpp_quad<QP_CHILD>(f);
+    Ach = dot(Sw, nc) + dot(Sv, fc);
+  }
+  PSTAMP(4);
+  // ------------------------------------------------------------------ K6-K7: bias forces
+  const V3 vlin = ld3(s.qv), om = ld3(s.qv + 3);
+  const V3 wb = mulv(Rb, om);                            // the root body's velocity [wb; vb] = sum of its six dofs' S qd
+  const V3 vb = add(vlin, cross(Pb, wb));
+  double tau_l;
+  {
+    const V3 wu = add(wb, scl(Sw, qd)), vu = add(vb, scl(Sv, qd));
+    const V3 wpar = dpp_quad<QP_PARENT>(wu), vpar = dpp_quad<QP_PARENT>(vu);
+    const V3 w = selv(isroot, wb, selv(lower, add(wpar, scl(Sw, qd)), wu));
+    const V3 v = selv(isroot, vb, selv(lower, add(vpar, scl(Sv, qd)), vu));
+    // d/dt of the axis: hinges use their link's velocity (the own term cancels), the root body's three rotation axes the velocity before any of them
+    // (mj_comVel), the slides have none
+    const V3 cwh = scl(cross(w, Sw), qd), cvh = scl(add(cross(v, Sw), cross(w, Sv)), qd);
+    const V3 cw = selv(ishinge, cwh, V3{0, 0, 0});
+    const V3 cv = selv(ishinge, cvh, scl(cross(vlin, Sw), qd));           // (slides: Sw = 0)
+    const V3 ab{-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    const V3 avb = add(ab, cross(vlin, wb));                                // root body: gravity + the three rotation dofs' terms
+    const V3 awu = cw, avu = add(avb, cv);
+    const V3 awp = dpp_quad<QP_PARENT>(awu), avp = dpp_quad<QP_PARENT>(avu);
+    const V3 aw = selv(isroot, V3{0, 0, 0}, selv(lower, add(awp, cw), awu));
+    const V3 av = selv(isroot, avb, selv(lower, add(avp, cv), avu));
+    V3 n1, f1, n2, f2;
+    iapply(I10, aw, av, n1, f1);
+    iapply(I10, w, v, n2, f2);
+    const V3 n = add(n1, add(cross(w, n2), cross(v, f2)));
+    const V3 f = add(f1, cross(w, f2));
+    const V3 nch = dpp_quad<QP_CHILD>(n), fch = dpp_quad<QP_CHILD>(f);
+    V3 ns = selv(upper, add(n, nch), n), fs = selv(upper, add(f, fch), f);
+    if (upper || sub == 5) {
+      double* o = s.redF[upper ? (l - 6) >> 1 : 8];
+      o[0] = ns.x; o[1] = ns.y; o[2] = ns.z; o[3] = fs.x; o[4] = fs.y; o[5] = fs.z;
+    }
+    fence();
+    V3 nt = ld3(s.redF[8]), ft = ld3(s.redF[8] + 3);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { nt = add(nt, ld3(s.redF[u])); ft = add(ft, ld3(s.redF[u] + 3)); }
+    ns = selv(isroot, nt, ns); fs = selv(isroot, ft, fs);
+    tau_l = -m.damping[l] * qd - (dot(Sw, ns) + dot(Sv, fs)) + s.xt.ext[l];
+  }
+  PSTAMP(5);
+  // ------------------------------------------------------------------ C1-C2: pair tests of the near blocks (lane = pair; spheres vs world-fixed boxes)
+  int nct = 0;
+  if (nearw) {
+    for (unsigned int rest = nearw; rest; rest &= rest - 1u) {
+      const int b = __builtin_ctz(rest);
+      const bool mine = (nearg >> b) & 1u;
+      const int pend = bt.end[b];
+      const V3 pb = ld3(bt.box_pos[b]);
+      double Rbx[3][3];
+      qmat(ldq(bt.box_quat[b]), Rbx);
+      const V3 h = ld3(bt.box_half[b]);
+      int room = bt.cap[b] & 255;
+      for (int base = bt.begin[b]; base < pend; base += LPE) {
+        const int pi = base + sub < pend ? base + sub : pend - 1;
+        const bool valid = mine && base + sub < pend;
+        const int lk = col->pair_rec[pi].sph_link, cls = col->pair_rec[pi].cls;
+        const double r = col->pair_rec[pi].r, margin = col->pair_rec[pi].margin;
+        V3 c = ld3(col->pair_rec[pi].pos);
+        {
+          double Rl[3][3];
+          qmat(ldq(s.Xq[lk < 0 ? 0 : lk]), Rl);
+          c = selv(lk < 0, c, add(ld3(s.Xp[lk < 0 ? 0 : lk]), mulv(Rl, c)));
+        }
+        const V3 x = mulvT(Rbx, vsub(c, pb));
+        V3 q{fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z)};
+        const bool outside = fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z;
+        const V3 dd = vsub(x, q);
+        const double d2 = dot(dd, dd);
+        const double inv = rsq_nr(outside ? d2 : 1.0);
+        const double gx = h.x - fabs(x.x), gy = h.y - fabs(x.y), gz = h.z - fabs(x.z);
+        const int axn = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
+        const double xa = pick3(x, axn), ha = pick3(h, axn), sg = xa >= 0 ? 1.0 : -1.0;
+        const V3 ni{axn == 0 ? sg : 0.0, axn == 1 ? sg : 0.0, axn == 2 ? sg : 0.0};
+        const V3 qi{axn == 0 ? sg * ha : x.x, axn == 1 ? sg * ha : x.y, axn == 2 ? sg * ha : x.z};
+        const double dist = outside ? d2 * inv - r : -(ha - fabs(xa)) - r;
+        const V3 nl = selv(outside, scl(dd, inv), ni);
+        q = selv(outside, q, qi);
+        const bool hit = valid && dist < margin;
+        const unsigned long long bal = __ballot(hit);
+        const unsigned int gb = (unsigned int)((bal >> (grp * 32)) & 0xFFFFFFFFull);
+        const int before = __popc(gb & ((1u << sub) - 1u));
+        const int total = __popc(gb);
+        const int slot = nct + before;
+        if (hit && slot < maxcon && before < room) {
+          const V3 n = mulv(Rbx, nl);
+          const V3 p = add(add(pb, mulv(Rbx, q)), scl(n, 0.5 * dist));
+          double* o = s.ct[slot];
+          o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
+          o[7] = (double)(cls + 64 * (lk + 1));
+        }
+        const int took = total < room ? total : room;
+        room -= took;
+        nct = nct + took < maxcon ? nct + took : maxcon;
+      }
+    }
+    fence();
+  }
+  PSTAMP(2);
+  PCOUNT(20, 1); PCOUNT(21, nearw ? 1 : 0); PCOUNT(22, __popc(nearw));
+  int ncmax = 0;
+  if (nearw && __any(nct > 0)) {
+#pragma unroll
+    for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
+  }
+  // ------------------------------------------------------------------ K8: closure rows (connect constraints; leg k carries constraint k: attachment 1 on its
+  // hinge 3, attachment 2 on its hinge 1) and the equality part of the Hessian -- this lane's entries, kept in registers over the passes
+  double Bw[6], Aw[4], rw;
+  {
+    const int k1 = m.con_att1[leg], k2 = m.con_att2[leg];
+    const V3 pa = add(P, mulv(R, ld3(m.att_pos[hq == 3 ? k1 : k2])));
+    const V3 p1 = dpp_quad<qp_bcast<3>()>(pa), p2 = dpp_quad<qp_bcast<1>()>(pa);
+    const V3 d = vsub(p1, p2);
+    const double w1 = (ishinge && hq >= 2) ? 1.0 : 0.0, w2 = (ishinge && hq < 2) ? 1.0 : 0.0;
+    const V3 JE = vsub(scl(add(Sv, cross(Sw, p1)), w1), scl(add(Sv, cross(Sw, p2)), w2));      // this hinge's column of the closure's three rows
+    // J qvel of the three rows: the leg's four hinges (summed over the quad) + the root body (its columns are Sw_r x d, so their sum is wb x d)
+    V3 jv = scl(JE, qd);
+    jv = add(jv, dpp_quad<QP_SWAP1>(jv));
+    jv = add(jv, dpp_quad<QP_SWAP2>(jv));
+    jv = add(jv, cross(wb, d));
+    const int c = hq < 3 ? hq : 2;                          // hinge j < 3 works out row j
+    const double res = pick3(d, c);
+    double kk, bb, dd;
+    kbimp(m.con_solref[leg], m.con_solimp[leg], res, dt, kk, bb, dd);
+    const double eDm = rcp_nr(fmax((1 - dd) * m.con_invweight[leg] * rcp_nr(dd), 1e-15));
+    const double earm = -bb * pick3(jv, c) - kk * dd * res;
+    if (ishinge && hq < 3) { s.eres[3 * leg + hq] = res; s.eD[3 * leg + hq] = eDm; s.ear[3 * leg + hq] = earm; }
+    const V3 eDv{dpp_quad<qp_bcast<0>()>(eDm), dpp_quad<qp_bcast<1>()>(eDm), dpp_quad<qp_bcast<2>()>(eDm)};
+    const V3 earv{dpp_quad<qp_bcast<0>()>(earm), dpp_quad<qp_bcast<1>()>(earm), dpp_quad<qp_bcast<2>()>(earm)};
+    const V3 dj{eDv.x * JE.x, eDv.y * JE.y, eDv.z * JE.z};
+    // hinge lanes: row of B (mass matrix + closure: sum_c (Sw_r x d)_c dj_c = Sw_r . (d x dj)), column of the leg block
+    const V3 bx = mulvT(Rb, cross(d, dj));
+    double Bh[6] = {g6[0], g6[1], g6[2], g6[3] + bx.x, g6[4] + bx.y, g6[5] + bx.z};
+    double Ah[4];
+    {
+      const V3 j0 = dpp_quad<qp_bcast<0>()>(JE), j1 = dpp_quad<qp_bcast<1>()>(JE), j2 = dpp_quad<qp_bcast<2>()>(JE), j3 = dpp_quad<qp_bcast<3>()>(JE);
+      Ah[0] = dot(j0, dj); Ah[1] = dot(j1, dj); Ah[2] = dot(j2, dj); Ah[3] = dot(j3, dj);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) Ah[p] += p == hq ? Add : ((upper && p == hq + 1) ? Ach : 0.0);
+    }
+    const double gh = tau_l + dot(dj, earv);
+    fence();                                                // eres / eD / ear of all four legs
+    // root lanes: row of R, right-hand side
+    V3 T{0, 0, 0}, G{0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < MTDims::NLEG; ++e) {
+      const V3 de = ld3(s.eres + 3 * e), De = ld3(s.eD + 3 * e), are = ld3(s.ear + 3 * e);
+      const V3 sd = cross(Sw, de);
+      const V3 u{De.x * sd.x, De.y * sd.y, De.z * sd.z};
+      T = add(T, cross(de, u));
+      G = add(G, cross(de, V3{De.x * are.x, De.y * are.y, De.z * are.z}));
+    }
+    const V3 rx = mulvT(Rb, T);
+    double Br[6] = {g6[0], g6[1], g6[2], g6[3] + rx.x, g6[4] + rx.y, g6[5] + rx.z};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Br[i] += sub == i ? m.armature[l] : 0.0;
+    const double gr = tau_l + dot(Sw, G);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Bw[i] = isroot ? Br[i] : Bh[i];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Aw[p] = Ah[p];
+    rw = isroot ? gr : gh;
+  }
+  PSTAMP(7);
+  // ------------------------------------------------------------------ C3: contact rows, lane = contact (all contacts of the env at once)
+  double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};
+  unsigned int cact = 0;
+  int cd1 = -1, cd2 = -1;                               // lane c: the hinges of its contact's chain
+  if (ncmax > 0) {
+    const int c = sub < MC ? sub : MC - 1;
+    const bool cv = sub < nct;
+    double rec[8];                                        // (a lane reads its own record only, and later writes its own edge weights over it: no exchange.  Slots
+#pragma unroll                                            // beyond the env's count hold whatever LDS held: taken as zeros -- tests/test_lds_hygiene_gpu.py)
+    for (int k = 0; k < 8; ++k) rec[k] = cv ? s.ct[c][k] : 0.0;
+    const V3 n = selv(cv, V3{rec[1], rec[2], rec[3]}, V3{0, 0, 1}), p = selv(cv, V3{rec[4], rec[5], rec[6]}, V3{0, 0, 0});
+    const int pk = cv ? (int)rec[7] : 0;
+    const int cls = pk & 63, ls = ((pk >> 6) & 63) - 1;
+    const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
+    const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
+    const V3 e{ia == 0 ? 1.0 : 0.0, ia == 1 ? 1.0 : 0.0, ia == 2 ? 1.0 : 0.0};
+    V3 t1 = cross(n, e);
+    t1 = scl(t1, rsq_nr(dot(t1, t1)));
+    const V3 t2 = cross(n, t1);
+    cd2 = ls >= 6 ? ls : -1;
+    cd1 = (cd2 >= 0 && m.parent[cd2] >= 6) ? m.parent[cd2] : -1;
+    // Jacobian of the contact point, direction t: root dofs [t ; Rb' ((p - Pb) x t)], hinge d: t . (Sv_d + Sw_d x p)
+    const V3 rp = vsub(p, Pb);
+    const V3 dirs[3] = {n, t1, t2};
+    double Jr[3][6], Jh[3][2];
+    const double* s1 = s.Sh[cd1 >= 0 ? cd1 - 6 : 0];
+    const double* s2 = s.Sh[cd2 >= 0 ? cd2 - 6 : 0];
+    const V3 jp1 = add(ld3(s1 + 3), cross(ld3(s1), p)), jp2 = add(ld3(s2 + 3), cross(ld3(s2), p));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const V3 t = dirs[k];
+      const V3 mo = mulvT(Rb, cross(rp, t));
+      Jr[k][0] = cv ? t.x : 0.0; Jr[k][1] = cv ? t.y : 0.0; Jr[k][2] = cv ? t.z : 0.0;
+      Jr[k][3] = cv ? mo.x : 0.0; Jr[k][4] = cv ? mo.y : 0.0; Jr[k][5] = cv ? mo.z : 0.0;
+      Jh[k][0] = cd1 >= 0 ? dot(t, jp1) : 0.0;
+      Jh[k][1] = cd2 >= 0 ? dot(t, jp2) : 0.0;
+    }
+    if (sub < MC) {                                       // (slots beyond the env's count are written too, as zeros: the passes read every slot up to ncmax)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s.CJr[c][k][r] = Jr[k][r];
+        s.CJh[c][k][0] = Jh[k][0]; s.CJh[c][k][1] = Jh[k][1];
+      }
+      s.crow[c][0] = cd1; s.crow[c][1] = cd2;
+    }
+    // J qvel and J a_prev (warm start)
+    double jv[3], jp[3];
+    {
+      const double q1 = cd1 >= 0 ? s.qv[cd1 >= 0 ? cd1 : 0] : 0.0, q2 = cd2 >= 0 ? s.qv[cd2 >= 0 ? cd2 : 0] : 0.0;
+      const double a1 = cd1 >= 0 ? s.aprev[cd1 >= 0 ? cd1 : 0] : 0.0, a2 = cd2 >= 0 ? s.aprev[cd2 >= 0 ? cd2 : 0] : 0.0;
+      double qr[6], ar[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { qr[r] = s.qv[r]; ar[r] = s.aprev[r]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double a_ = 0, b_ = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { a_ = fma(Jr[k][r], qr[r], a_); b_ = fma(Jr[k][r], ar[r], b_); }
+        a_ = fma(Jh[k][0], q1, a_); a_ = fma(Jh[k][1], q2, a_);
+        b_ = fma(Jh[k][0], a1, b_); b_ = fma(Jh[k][1], a2, b_);
+        jv[k] = a_; jp[k] = b_;
+      }
+    }
+    const double margin = bt.cls_margin[cls];
+    cmu = bt.cls_mu[cls];
+    {
+      const int root = m.ball_dof + 2;                    // Minitaur.SetFootFriction: every contact of a lower-leg link
+      if (s.xt.foot_mu > 0 && ls > root && m.parent[ls > 0 ? ls : 0] != root) cmu = s.xt.foot_mu;
+    }
+    const double kk = bt.kb_cls[cls][0], bb = bt.kb_cls[cls][1];
+    const double dd = imp_of(bt.cls_solimp[cls], rec[0] - margin);
+    const double R0 = fmax((1 - dd) * bt.cls_invw[cls] * rcp_nr(dd), 1e-15);
+    cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
+    const double basea = -kk * dd * (rec[0] - margin);
+    car[0] = -bb * (jv[0] + cmu * jv[1]) + basea; car[1] = -bb * (jv[0] - cmu * jv[1]) + basea;
+    car[2] = -bb * (jv[0] + cmu * jv[2]) + basea; car[3] = -bb * (jv[0] - cmu * jv[2]) + basea;
+    unsigned int wbits = 0;
+    wbits |= (jp[0] + cmu * jp[1] - car[0] < 0) ? 1u : 0u;
+    wbits |= (jp[0] - cmu * jp[1] - car[1] < 0) ? 2u : 0u;
+    wbits |= (jp[0] + cmu * jp[2] - car[2] < 0) ? 4u : 0u;
+    wbits |= (jp[0] - cmu * jp[2] - car[3] < 0) ? 8u : 0u;
+    cact = cv ? (warm ? wbits : 0xFu) : 0u;
+  }
+  PSTAMP(6);
+  PSTAMP(9);
+  // ------------------------------------------------------------------ K9: active-set Newton on the arrow-shaped Hessian
+  double al = 0.0;                                       // this lane's entry of the solution
+  PCOUNT(23, ncmax > 0 ? 1 : 0); PCOUNT(24, ncmax);
+  for (int it = 0; it < 8; ++it) {
+    PCOUNT(25, 1);
+    KSTART();
+    if (ncmax > 0) {
+      if (sub < MC) {
+        const double a1 = (cact & 1u) ? cD : 0.0, a2 = (cact & 2u) ? cD : 0.0, a3 = (cact & 4u) ? cD : 0.0, a4 = (cact & 8u) ? cD : 0.0;
+        double* w = s.cw[sub];
+        w[0] = a1 + a2 + a3 + a4; w[1] = cmu * (a1 - a2); w[2] = cmu * (a3 - a4); w[3] = cmu * cmu * (a1 + a2); w[4] = cmu * cmu * (a3 + a4);
+        w[5] = a1 * car[0] + a2 * car[1] + a3 * car[2] + a4 * car[3];
+        w[6] = cmu * (a1 * car[0] - a2 * car[1]);
+        w[7] = cmu * (a3 * car[2] - a4 * car[3]);
+      }
+      fence();
+    }
+    KSTAMP(16);
+    {
+      // this lane's entries of the pass's Hessian: equality part + the active contact edges
+      double acc6[6] = {0, 0, 0, 0, 0, 0}, accd = 0, accc = 0, rr = rw;
+      for (int c = 0; c < ncmax; ++c) {
+        const double* w = s.cw[c];
+        const int d1 = s.crow[c][0], d2 = s.crow[c][1];
+        const int slot = l == d2 ? 1 : 0;
+        const bool touch = isroot || l == d1 || l == d2;
+        double j[3], jc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double jr = s.CJr[c][k][isroot ? l : 0], jh = s.CJh[c][k][slot];
+          j[k] = touch ? (isroot ? jr : jh) : 0.0;
+          jc[k] = s.CJh[c][k][1];
+        }
+        const double v0 = w[0] * j[0] + w[1] * j[1] + w[2] * j[2], v1 = w[1] * j[0] + w[3] * j[1], v2 = w[2] * j[0] + w[4] * j[2];
+        rr += w[5] * j[0] + w[6] * j[1] + w[7] * j[2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc6[i] += s.CJr[c][0][i] * v0 + s.CJr[c][1][i] * v1 + s.CJr[c][2][i] * v2;
+        accd += j[0] * v0 + j[1] * v1 + j[2] * v2;
+        accc += (l == d1) ? jc[0] * v0 + jc[1] * v1 + jc[2] * v2 : 0.0;
+      }
+      if (isroot) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s.HR[l][i] = Bw[i] + acc6[i];
+      }
+      if (ishinge) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s.HB[l - 6][i] = Bw[i] + acc6[i];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (p >= hq) s.HA[leg][p * (p + 1) / 2 + hq] = Aw[p] + (p == hq ? accd : ((upper && p == hq + 1) ? accc : 0.0));
+      }
+      if (isl) s.rc[l] = rr;
+    }
+    fence();
+    KSTAMP(17);
+    // ---- solve H x = rc.  Lanes 0-23 = (root dof i, leg k): factor the leg block (redundantly, six lanes per leg), row i of W_k = B_k' L_k^-T, y_k, W_k y_k
+    double xr[6];
+    {
+      const int t = sub < 24 ? sub : 23;
+      const int i = t % 6, k = t / 6;
+      double L[10], Bc[4], bk[4];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) L[e] = s.HA[k][e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { Bc[j] = s.HB[4 * k + j][i]; bk[j] = s.rc[6 + 4 * k + j]; }
+      chol_regs<4, 4>(L);
+      double W[4], y[4], pt = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double sw = Bc[j], sy = bk[j];
+#pragma unroll
+        for (int p = 0; p < j; ++p) { sw = fma(-W[p], L[j * (j + 1) / 2 + p], sw); sy = fma(-y[p], L[j * (j + 1) / 2 + p], sy); }
+        W[j] = sw * L[j * (j + 1) / 2 + j];
+        y[j] = sy * L[j * (j + 1) / 2 + j];
+        pt = fma(W[j], y[j], pt);
+      }
+      if (sub < 24) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.Wl[i][4 * k + j] = W[j];
+        s.part[i][k] = pt;
+        if (i == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s.Y[4 * k + j] = y[j];
+#pragma unroll
+          for (int e = 0; e < 10; ++e) s.LL[k][e] = L[e];
+        }
+      }
+    }
+    fence();
+    {
+      // Schur complement of the root block, lane = entry (i, c), c <= i
+      const int e = sub < 21 ? sub : 20;
+      const int i = e >= 15 ? 5 : (e >= 10 ? 4 : (e >= 6 ? 3 : (e >= 3 ? 2 : (e >= 1 ? 1 : 0))));
+      const int c = e - i * (i + 1) / 2;
+      double s0 = s.HR[i][c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int p = 0; p < 16; p += 4) {
+        s0 = fma(-s.Wl[i][p], s.Wl[c][p], s0); s1 = fma(-s.Wl[i][p + 1], s.Wl[c][p + 1], s1);
+        s2 = fma(-s.Wl[i][p + 2], s.Wl[c][p + 2], s2); s3 = fma(-s.Wl[i][p + 3], s.Wl[c][p + 3], s3);
+      }
+      if (sub < 21) s.SS[e] = (s0 + s1) + (s2 + s3);
+    }
+    fence();
+    {
+      // every lane: the root block's 6 x 6 system in registers
+      double Lr[21];
+#pragma unroll
+      for (int e = 0; e < 21; ++e) Lr[e] = s.SS[e];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xr[i] = s.rc[i] - ((s.part[i][0] + s.part[i][1]) + (s.part[i][2] + s.part[i][3]));
+      chol_regs<6, 6>(Lr);
+      solve_regs<6, 6>(Lr, xr);
+      // hinge lanes: back-substitution of their leg, x_k = L_k^-T (y_k - W_k' x_root)
+      double Lk[10], z[4];
+#pragma unroll
+      for (int e = 0; e < 10; ++e) Lk[e] = s.LL[leg][e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double zz = s.Y[4 * leg + j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) zz = fma(-s.Wl[i][4 * leg + j], xr[i], zz);
+        z[j] = zz;
+      }
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {
+        double zz = z[j];
+#pragma unroll
+        for (int p = j + 1; p < 4; ++p) zz = fma(-Lk[p * (p + 1) / 2 + j], z[p], zz);
+        z[j] = zz * Lk[j * (j + 1) / 2 + j];
+      }
+      const double xh = hq == 0 ? z[0] : (hq == 1 ? z[1] : (hq == 2 ? z[2] : z[3]));
+      double xo = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xo = sub == i ? xr[i] : xo;
+      al = isroot ? xo : xh;
+      if (isl) s.aprev[l] = al;
+    }
+    KSTAMP(18);
+    bool changed = false;
+    if (ncmax > 0) {
+      fence();                                            // the hinges' entries of the solution
+      const int c = sub < MC ? sub : MC - 1;
+      const double a1 = cd1 >= 0 ? s.aprev[cd1 >= 0 ? cd1 : 0] : 0.0, a2 = cd2 >= 0 ? s.aprev[cd2 >= 0 ? cd2 : 0] : 0.0;
+      double an[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double a_ = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a_ = fma(s.CJr[c][k][r], xr[r], a_);
+        a_ = fma(s.CJh[c][k][0], a1, a_); a_ = fma(s.CJh[c][k][1], a2, a_);
+        an[k] = a_;
+      }
+      unsigned int nb = 0;
+      nb |= (an[0] + cmu * an[1] - car[0] < 0) ? 1u : 0u;
+      nb |= (an[0] - cmu * an[1] - car[1] < 0) ? 2u : 0u;
+      nb |= (an[0] + cmu * an[2] - car[2] < 0) ? 4u : 0u;
+      nb |= (an[0] - cmu * an[2] - car[3] < 0) ? 8u : 0u;
+      nb = sub < nct ? nb : 0u;
+      changed = nb != cact;
+      cact = nb;
+    }
+    KSTAMP(19);
+    if (!__any(changed)) break;
+  }
+  PSTAMP(8);
+  if constexpr (!INTEGRATE) {
+    if (qacc_out && isl) qacc_out[l] = al;
+  } else {
+    // ---------------------------------------------------------------- K10: semi-implicit Euler (no joint damping in this model: checked by the host side)
+    fence();
+    if (isl) {
+      const double nv_ = qd + dt * al;
+      s.qv[l] = nv_;
+      s.qp[l] = ql_ + dt * nv_;                           // (unused for the rotation dofs of the root body)
+    }
+    fence();
+    {
+      const int bd = m.ball_dof;
+      const V3 wbd{s.qv[bd], s.qv[bd + 1], s.qv[bd + 2]};
+      Q4 q0 = Qb;
+      const double n0 = rsq_nr(q0.w * q0.w + q0.x * q0.x + q0.y * q0.y + q0.z * q0.z);
+      q0 = Q4{q0.w * n0, q0.x * n0, q0.y * n0, q0.z * n0};
+      const double w2 = dot(wbd, wbd);
+      const double iw = w2 > 0 ? rsq_nr(w2 > 0 ? w2 : 1.0) : 0.0;
+      double sn, cs;
+      sincos_mod(0.5 * dt * (w2 * iw), sn, cs);
+      const Q4 q1 = qmul(q0, Q4{cs, sn * wbd.x * iw, sn * wbd.y * iw, sn * wbd.z * iw});
+      const double n1 = rsq_nr(q1.w * q1.w + q1.x * q1.x + q1.y * q1.y + q1.z * q1.z);
+      if (sub == 0) { s.bq[0] = q1.w * n1; s.bq[1] = q1.x * n1; s.bq[2] = q1.y * n1; s.bq[3] = q1.z * n1; }
+      fence();
+    }
+    PSTAMP(11);
+  }
+}

@@ -1886,8 +1886,8 @@ __device__ __forceinline__ void stage_model(MT& dst, const void* __restrict__ sr
 
 // state rows <-> LDS.  qpos rows are [nq]: one entry per dof, except that the free body's orientation quaternion sits at
 // [ball_dof, ball_dof + 4) (normalised on load, as mj_kinematics does)
-template <int NV>
-__device__ __forceinline__ void load_state(Shared<NV>& s, const typename ModelOf<NV>::T& m, const double* __restrict__ qrow, const double* __restrict__ vrow, const int sub) {
+template <int NV, typename SH>
+__device__ __forceinline__ void load_state(SH& s, const typename ModelOf<NV>::T& m, const double* __restrict__ qrow, const double* __restrict__ vrow, const int sub) {
   const int bd = m.ball_dof;
   if (sub < NV) {
     // (a free ROOT body -- the minitaur's base, ball_dof = 3 -- keeps MuJoCo's layout [xyz, quaternion, joints]: dof l > bd + 2 sits at qrow[l + 1])
@@ -1906,13 +1906,13 @@ __device__ __forceinline__ void load_state(Shared<NV>& s, const typename ModelOf
 }
 // the orientation quaternion in LDS as load_state would read it back from a stored row (the same expression, compiled under the same contraction mode):
 // lets a fused rollout walk through the same bits as one launch per env step
-template <int NV>
-__device__ __forceinline__ double renormalised_quat_entry(const Shared<NV>& s, const int sub) {
+template <int NV, typename SH>
+__device__ __forceinline__ double renormalised_quat_entry(const SH& s, const int sub) {
   const Q4 q = ldq(s.bq);
   return s.bq[sub < 4 ? sub : 0] * rsq_nr(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
 }
-template <int NV>
-__device__ __forceinline__ void store_state(const Shared<NV>& s, const typename ModelOf<NV>::T& m, double* __restrict__ qrow, double* __restrict__ vrow, const int sub) {
+template <int NV, typename SH>
+__device__ __forceinline__ void store_state(const SH& s, const typename ModelOf<NV>::T& m, double* __restrict__ qrow, double* __restrict__ vrow, const int sub) {
   const int bd = m.ball_dof;
   if (sub < NV) {
     if (bd < 0 || sub < bd) qrow[sub] = s.qp[sub];
@@ -2565,6 +2565,7 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
 #endif
 
 #ifdef EARL_PHYS_VARIANT_MT
+#include "minitaur_stepper.h"
 // ------------------------------------------------------------------------------------------------ minitaur env (include/earl_physics.h; physics_mt.hip)
 // One launch = T env steps (or the reset incl. its settle steps) of every env: 32 lanes per env, two envs per wave; lanes 0-7 of a group are also
 // the eight MOTORS (Minitaur.ApplyAction per timestep: velocity-limited command, DC-motor model, overheat protection -- csrc/minitaur_device.h),
@@ -2583,13 +2584,16 @@ __device__ __forceinline__ double mt_draw(const earl_minitaur_cfg& cfg, const ui
                                          (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
   return earl::u01(b.x, b.y);
 }
-template <bool RESET>
+// ARROW: the timestep written on the model's tree (minitaur_stepper.h: substep_mt, the product path) or the generic substep<22> above (kept for
+// comparison: earl_debug_set_minitaur_stepper(0); same numbers to rounding)
+template <bool RESET, bool ARROW>
 __global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const MinitaurArgs a) {
 #pragma clang fp contract(off)
   constexpr int NV = 22, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
+  using SH = std::conditional_t<ARROW, SharedMT, Shared<NV>>;
   __shared__ typename ModelOf<NV>::T m;
   __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ Shared<NV> sh[EPW * WPB];
+  __shared__ SH sh[EPW * WPB];
   stage_blocks(bt, a.col);
   stage_kb<NV>(bt, a.m, a.col);
   stage_model(m, a.m);                                  // (ends with the workgroup barrier)
@@ -2599,13 +2603,16 @@ __global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const Minit
   const bool in_batch = env_raw < n;
   const int env = in_batch ? env_raw : n - 1;           // idle groups shadow the last env and store nothing
   const bool live = in_batch && (!RESET || !a.mask || a.mask[env] != 0);      // (a reset leaves the envs outside the mask alone: their groups compute and discard)
-  Shared<NV>& s = sh[wave * EPW + grp];
+  SH& s = sh[wave * EPW + grp];
+  const double ctrl0[EARL_MAXACT] = {0, 0, 0, 0};
+  auto timestep = [&](const bool warm) {
+    if constexpr (ARROW) substep_mt<true>(s, m, bt, a.col, sub, grp, warm, nullptr);
+    else substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, Q4{1, 0, 0, 0}, ctrl0, warm, nullptr, nullptr);
+  };
   const int mi = sub < 8 ? sub : 7;                     // this lane's motor
   const int mdof = cfg.motor_dof[mi];
   const double mdir = cfg.motor_dir[mi];
   const double lim = m.dt * cfg.motor_velocity_limit;
-  const Q4 mq{1, 0, 0, 0};
-  const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
   double voltage, viscous, goal0, goal1;
   double ms0 = 1.0, ms1 = 1.0, ms2 = 1.0, fmu = -1.0;   // mass factors (root body, upper links, lower links), foot friction: motor_param[2..5]
   int oh; bool en; double obs_t;                        // motor lanes: overheat counter, enabled flag, observed torque of the newest ApplyAction
@@ -2675,7 +2682,7 @@ __global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const Minit
     const double half_pi = 3.141592653589793 / 2;
     for (int ts = 0; ts < cfg.settle_steps; ++ts) {       // minitaur_gym_env.py:265-269
       apply_action(half_pi);
-      substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);
+      timestep(ts > 0);
     }
     const double v = observe();
     if (live) {
@@ -2705,7 +2712,7 @@ __global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const Minit
       const double cmd = earl::mt_leg_to_motor(a64, mi);              // ConvertFromLegModel
       for (int ts = 0; ts < cfg.num_substeps; ++ts) {                  // minitaur_gym_env.py:321-323
         apply_action(cmd);
-        substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);
+        timestep(ts > 0);
       }
       const bool bad_lane = (sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE)) || (sub < 4 && !(fabs(s.bq[sub]) < EARL_BAD_VALUE));
       const bool failed = group_any<LPE>(bad_lane, grp);
@@ -2787,6 +2794,9 @@ int launched(const char* what) {
   return EARL_OK;
 }
 
+#ifdef EARL_PHYS_VARIANT_MT
+int g_mt_stepper = 1;     // earl_debug_set_minitaur_stepper: 1 = the tree-structured timestep (minitaur_stepper.h), 0 = the generic substep<22>
+#endif
 int g_door_variant = 0;   // earl_debug_set_door_variant: 0 = by batch size, 1 = four single-wave workgroups per CU, 2 = one eight-wave workgroup per CU
 int g_lpe = 16;   // lanes per env (earl_debug_set_physics_lanes): 16 = four envs per wavefront, 64 = one wavefront per env
 
@@ -2842,7 +2852,8 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
   if (!out->obs || !out->reward || !out->done || !out->success || !cfg->goal_table || cfg->n_goals < 1 || cfg->num_substeps < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
   MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr};
-  minitaur_kernel<false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  if (g_mt_stepper) minitaur_kernel<false, true><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  else minitaur_kernel<false, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_rollout");
 }
 int earl_minitaur_reset(const void* model24, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
@@ -2852,10 +2863,16 @@ int earl_minitaur_reset(const void* model24, const earl_collision_model* col, co
   if (!cfg->goal_table || !cfg->reset_qpos || cfg->n_goals < 1 || cfg->settle_steps < 0) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
   MinitaurArgs a{model24, col, *cfg, *st, earl_minitaur_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0, mask, obs};
-  minitaur_kernel<true><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  if (g_mt_stepper) minitaur_kernel<true, true><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  else minitaur_kernel<true, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_reset");
 }
 int earl_minitaur_cfg_size(void) { return (int)sizeof(earl_minitaur_cfg); }
+int earl_debug_set_minitaur_stepper(int tree) {          // 1 (default): minitaur_stepper.h, 0: the generic substep<22> (comparison / measurement)
+  if (tree != 0 && tree != 1) return EARL_ERR_ARG;
+  g_mt_stepper = tree;
+  return EARL_OK;
+}
 #ifdef EARL_PHYS_PROF
 int earl_debug_read_phys_profile_mt(unsigned long long* out, int reset) {          // this unit's own copy of the phase counters (tools/prof_minitaur.py)
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_prof), sizeof(unsigned long long) * 32) != hipSuccess) return EARL_ERR_LAUNCH;

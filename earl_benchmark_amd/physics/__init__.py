@@ -148,6 +148,17 @@ def load_link_model(name):
       _fill(dst, src)
     _fill(s.pair, np.full(MAXV24, -1, np.int32))
     _fill(s.act_forcerange, np.tile([-1e300, 1e300], (MAXACT, 1)))
+    # the tree the minitaur's own timestep is written on (csrc/minitaur_stepper.h): a root body of six one-dof links with identity frames, then four legs
+    # of four hinges -- leg k = dofs 6 + 4 k + (0: upper link of the first chain, 1: its lower link, 2: upper link of the second chain, 3: its lower
+    # link), hinge frames without a joint offset; closure k ties attachment con_att1[k] on hinge 3 of leg k to con_att2[k] on its hinge 1; no joint
+    # limits, no damping, no dragging contact (their rows are not built there)
+    par, jt = [int(x) for x in d['parent']], [int(x) for x in d['jtype']]
+    assert par[:6] == [-1, 0, 1, 2, 3, 4] and jt[:6] == [1, 1, 1, 2, 3, 3], 'minitaur tree: the root body'
+    assert np.array_equal(d['jaxis'][:6], np.vstack([np.eye(3), np.eye(3)])) and not np.any(d['tpos'][:6]) and np.array_equal(d['tquat'][:6], np.tile([1.0, 0, 0, 0], (6, 1)))
+    assert all(par[6 + 4 * k + j] == (5, 6 + 4 * k, 5, 8 + 4 * k)[j] and jt[6 + 4 * k + j] == 0 for k in range(4) for j in range(4)), 'minitaur tree: the legs'
+    assert not np.any(d['jpos']) and not np.any(d['jnt_limited']) and not np.any(d['jnt_damping']) and 'dof_drag_G' not in d
+    assert s.n_con == 4 and all(int(d['att_link'][int(d['con_att1'][k])]) == 9 + 4 * k and int(d['att_link'][int(d['con_att2'][k])]) == 7 + 4 * k for k in range(4)), \
+        'minitaur tree: closure k between hinge 3 and hinge 1 of leg k'
   elif big:
     s.n_jeq = len(d['jeq_joint1'])
     assert s.n_jeq <= MAXJEQ

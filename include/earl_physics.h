@@ -389,6 +389,10 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
 int earl_minitaur_reset(const void* model24, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
                         const uint8_t* mask, double* obs, earl_stream_t stream);
 int earl_minitaur_cfg_size(void);
+/* measurement / test switch for the minitaur kernels: 1 (default) = the timestep written on the model's tree (csrc/minitaur_stepper.h: arrow-shaped
+ * constraint Hessian eliminated legs -> root body, parent / child exchanges by DPP), 0 = the generic nv = 22 instantiation of the stepper (dense
+ * factorisation).  Same algorithm; results agree to rounding (tests/test_minitaur_gpu.py). */
+int earl_debug_set_minitaur_stepper(int tree);
 
 /* measurement / test switch for the door model's rollout: 0 (default) = by batch size (n > 4096: one eight-wave workgroup per CU, see
  * csrc/physics_w8.hip; otherwise four single-wave workgroups per CU), 1 / 2 force the one or the other.  Results are bit-identical. */

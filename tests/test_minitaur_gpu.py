@@ -69,6 +69,41 @@ def test_fused_rollout_equals_stepping_bit_for_bit_and_shards_equal_the_batch(to
   assert torch.equal(torch.cat([r0['obs'], r1['obs']], 1), ra['obs'])
 
 
+def test_tree_stepper_matches_the_generic_stepper(torch):
+  """csrc/minitaur_stepper.h (arrow-shaped Hessian, legs eliminated before the root body, DPP exchanges) against the generic nv = 22 instantiation of
+  csrc/physics.hip (dense factorisation): same algorithm, so the same numbers to rounding -- reset (100 settle timesteps) and env steps from
+  identical states, re-synchronised per step (chaotic contacts amplify the last bits over long open loops)."""
+  from earl_benchmark_amd import _abi
+  lib = _abi.load()
+  n, T = 64, 40
+  g = torch.Generator(device='cuda').manual_seed(5)
+  acts = torch.rand(T, n, 8, generator=g, device='cuda') * 2 - 1
+  try:
+    lib.earl_debug_set_minitaur_stepper(0)
+    ref = make(n, seed=21)
+    o_ref = ref.reset().clone()
+    lib.earl_debug_set_minitaur_stepper(1)
+    new = make(n, seed=21)
+    o_new = new.reset().clone()
+    assert float((o_new - o_ref).abs().max()) < 1e-8, float((o_new - o_ref).abs().max())
+    worst = 0.0
+    for t in range(T):
+      for k in ('qpos', 'qvel', 'overheat', 'motor_enabled', 'observed_torque'):
+        getattr(ref, k).copy_(getattr(new, k))
+      lib.earl_debug_set_minitaur_stepper(0)
+      a = ref.step(acts[t])
+      lib.earl_debug_set_minitaur_stepper(1)
+      b = new.step(acts[t])
+      torch.cuda.synchronize()
+      d = max(float((a[0] - b[0]).abs().max()), float((ref.qpos - new.qpos).abs().max()), float((ref.qvel - new.qvel).abs().max()) * 1e-2)
+      worst = max(worst, d)
+      assert d < 1e-8, (t, d)
+      assert torch.equal(a[3]['success'], b[3]['success']) and float((a[1] - b[1]).abs().max()) < 1e-8
+  finally:
+    lib.earl_debug_set_minitaur_stepper(1)
+  assert int(new.fail_count.sum()) == 0
+
+
 def test_loader_wrappers_goal_switch_and_action_bounds(torch):
   import earl_benchmark_amd as eb
   n = 16
