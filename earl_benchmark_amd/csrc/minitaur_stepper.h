@@ -36,22 +36,100 @@ constexpr int QP_SWAP1 = 0xB1;      // [1, 0, 3, 2]
 constexpr int QP_SWAP2 = 0x4E;      // [2, 3, 0, 1]
 template <int P> constexpr int qp_bcast() { return P * 0x55; }   // every lane of the quad reads lane P
 
+// A constant the compiler may not hoist out of the rollout loop: it is materialised into a scalar register pair where it is used (two s_mov).  Hoisted,
+// the coefficient sets below sat in registers across the whole kernel, were spilled, and every timestep reloaded them from scratch memory one dependent
+// round trip after the other (seen in the ISA: five serial scratch loads inside one sincos).
+__device__ __forceinline__ double kc(double x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+// sincos_mod of physics.hip with such constants (same operations in the same order: identical results)
+__device__ __forceinline__ void sincos_kc(double x, double& sn, double& cs) {
+  const double k = rint(x * kc(6.36619772367581382433e-01));
+  double r = fma(-k, kc(1.57079632673412561417e+00), x);
+  r = fma(-k, kc(6.07710050650619224932e-11), r);
+  const double z = r * r;
+  double ps = fma(z, kc(1.58969099521155010221e-10), kc(-2.50507602534068634195e-08));
+  ps = fma(z, ps, kc(2.75573137070700676789e-06));
+  ps = fma(z, ps, kc(-1.98412698298579493134e-04));
+  ps = fma(z, ps, kc(8.33333333332248946124e-03));
+  ps = fma(z, ps, kc(-1.66666666666666324348e-01));
+  const double sr = fma(r * z, ps, r);
+  double pc = fma(z, kc(-1.13596475577881948265e-11), kc(2.08757232129817482790e-09));
+  pc = fma(z, pc, kc(-2.75573143513906633035e-07));
+  pc = fma(z, pc, kc(2.48015872894767294178e-05));
+  pc = fma(z, pc, kc(-1.38888888888741095749e-03));
+  pc = fma(z, pc, kc(4.16666666666666019037e-02));
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = (int)k & 3;
+  sn = (q == 0) ? sr : ((q == 1) ? cr : ((q == 2) ? -sr : -cr));
+  cs = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
+}
+
 struct MTDims {
   static constexpr int NV = 22, NR = 6, NLEG = 4, LS = 4, NH = 16, LPE = 32, MC = EARL_MAXCON, MB = 8;
 };
 
-// Per-env LDS block of the minitaur stepper.  (xt / kit keep the member names the env kernel uses with the generic block.)
+// The collision model's pair records, once per workgroup in LDS (the generic kernels read them from global memory inside the timestep: one L2 round trip per
+// near block -- 6.2 k of this model's 56 k cycles per timestep)
+struct PairTabMT {
+  static constexpr int MP = 64;          // (the model has 52 pairs; checked by the host side)
+  double pos[MP][3], r[MP], margin[MP];
+  int link[MP], cls[MP];
+};
+__device__ __forceinline__ void stage_pairs_mt(PairTabMT& t, const earl_collision_model* __restrict__ col) {
+  const int i = threadIdx.x;
+  if (col && i < PairTabMT::MP && i < col->n_pair) {
+    t.pos[i][0] = col->pair_rec[i].pos[0]; t.pos[i][1] = col->pair_rec[i].pos[1]; t.pos[i][2] = col->pair_rec[i].pos[2];
+    t.r[i] = col->pair_rec[i].r; t.margin[i] = col->pair_rec[i].margin;
+    t.link[i] = col->pair_rec[i].sph_link; t.cls[i] = col->pair_rec[i].cls;
+  }
+}
+// MuJoCo's impedance for solimp powers 1 and 2 only (this model's; checked by the host side): imp_of / kbimp of physics.hip without their pow() branches,
+// which are never taken here but are a quarter of the timestep's code
+__device__ __forceinline__ double imp_p2(const double* solimp, double r) {
+  const double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  const double x = width > 0 ? fmin(fabs(r) * rcp_nr(width), 1.0) : 1.0;
+  const double y2 = x <= mid ? x * x * rcp_nr(mid) : 1 - (1 - x) * (1 - x) * rcp_nr(1 - mid);
+  const double y = (power == 1 || d0 == dw) ? x : y2;
+  return d0 + y * (dw - d0);
+}
+// 1 / sqrt(x): hardware seed (2^-26 or better) + two Newton steps
+__device__ __forceinline__ double rsq2(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
+// chol_regs of physics.hip (dense, diagonal left inverted) with the two-step reciprocal root
+template <int N>
+__device__ __forceinline__ void chol_small(double (&L)[N * (N + 1) / 2]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double d = L[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int p = 0; p < j; ++p) d = fma(-L[j * (j + 1) / 2 + p], L[j * (j + 1) / 2 + p], d);
+    const double inv = rsq2(d);
+    L[j * (j + 1) / 2 + j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double t = L[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int p = 0; p < j; ++p) t = fma(-L[i * (i + 1) / 2 + p], L[j * (j + 1) / 2 + p], t);
+      L[i * (i + 1) / 2 + j] = t * inv;
+    }
+  }
+}
+
+// Per-env LDS block of the minitaur stepper.  (xt / kit keep the member names the env kernel uses with the generic block.)  The buffers of the dynamics
+// phases (frames ... contact rows), of the active-set passes and of the env step's observation are live at disjoint times.
 struct SharedMTData {
   static constexpr int NV = MTDims::NV, MC = MTDims::MC;
   double qp[NV], qv[NV];
   double bq[4];
-  double Xq[NV][4], Xp[NV][3];       // world frames (collision, attachments)
   double aprev[NV];                  // solution of the newest solve (warm start of the next timestep; exchange buffer of the row tests)
   struct { double ext[NV]; double mscale[3], foot_mu; } xt;
-  struct { double obs[46]; } kit;
-  double Sh[MTDims::NH][6];          // motion subspace of the hinges (contact Jacobians)
-  double redI[9][10];                // composite inertias of the eight upper links + the root body's own: summed by every lane
-  double redF[9][6];                 // the same for the bias forces
   double eres[12], eD[12], ear[12];  // closure rows: residual, weight, reference acceleration
   union {
     double ct[MC][8];                // contact records (pair tests -> contact rows)
@@ -60,17 +138,28 @@ struct SharedMTData {
   double CJr[MC][3][6];              // contact Jacobians (normal, tangent 1, tangent 2): the root body's six entries ...
   double CJh[MC][3][2];              // ... and the (at most two) hinges of the sphere's own chain
   int crow[MC][2];                   // those hinges' dofs (-1: none)
-  // the pass's Hessian, by blocks, and right-hand side
-  double HA[MTDims::NLEG][10];       // leg blocks, packed lower triangle (p, q) at p (p + 1) / 2 + q
-  double HB[MTDims::NH][6];          // couplings: row = hinge, column = root dof
-  double HR[6][6];                   // root block (both triangles)
-  double rc[NV];
-  // exchange buffers of the solve
-  double Wl[6][16];                  // W = B' L^-T, row = root dof
-  double part[6][4];                 // W_k y_k per root dof and leg
-  double Y[16];                      // y = L^-1 b of the legs
-  double LL[MTDims::NLEG][10];       // the legs' Cholesky factors (diagonal inverted)
-  double SS[22];                     // Schur complement of the root block, packed lower triangle (21)
+  union {
+    struct { double obs[46]; } kit;    // env step: observation (between timesteps)
+    struct {
+      double Xq[NV][4], Xp[NV][3];       // world frames (collision)
+      double Sh[MTDims::NH][6];          // motion subspace of the hinges (contact Jacobians)
+      double redI[9][10];                // composite inertias of the eight upper links + the root body's own: summed by every lane
+      double redF[9][6];                 // the same for the bias forces
+    } dyn;
+    struct {
+      // the pass's Hessian, by blocks, and right-hand side
+      double HA[MTDims::NLEG][10];       // leg blocks, packed lower triangle (p, q) at p (p + 1) / 2 + q
+      double HB[MTDims::NH][6];          // couplings: row = hinge, column = root dof
+      double HR[6][6];                   // root block (both triangles)
+      double rc[NV];
+      // exchange buffers of the solve
+      double Wl[6][16];                  // W = B' L^-T, row = root dof
+      double part[6][4];                 // W_k y_k per root dof and leg
+      double Y[16];                      // y = L^-1 b of the legs
+      double LL[MTDims::NLEG][10];       // the legs' Cholesky factors (diagonal inverted)
+      double SS[22];                     // Schur complement of the root block, packed lower triangle (21)
+    } pas;
+  };
 };
 struct SharedMT : SharedMTData {
   static constexpr int R = (int)(sizeof(SharedMTData) % 256);
@@ -81,7 +170,7 @@ struct SharedMT : SharedMTData {
 // One timestep of one env by its 32-lane group.  Lane roles: sub 0-5 = the root body's dofs, sub 8 + 4 k + j = hinge j of leg k (dof 6 + 4 k + j),
 // the other lanes idle (they shadow a hinge and store nothing).  INTEGRATE = false stops after qacc.
 template <bool INTEGRATE>
-__device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24& m, const BlkTable<MTDims::MB, true>& bt, const earl_collision_model* __restrict__ col,
+__device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24& m, const BlkTable<MTDims::MB, true>& bt, const PairTabMT& pt,
                                            const int sub, const int grp, const bool warm, double* qacc_out) {
   constexpr int NV = MTDims::NV, MC = MTDims::MC, LPE = MTDims::LPE;
   const int maxcon = bt.max_con < MC ? bt.max_con : MC;
@@ -105,7 +194,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     const Q4 tq = ldq(m.tquat[l]);
     const V3 tp = ld3(m.tpos[l]);
     double sn, cs;
-    sincos_mod(jt == 0 ? 0.5 * ql_ : 0.0, sn, cs);
+    sincos_kc(jt == 0 ? 0.5 * ql_ : 0.0, sn, cs);
     const Q4 qloc = qmul(tq, Q4{cs, sn * ax.x, sn * ax.y, sn * ax.z});
     const Q4 Qu = qmul(Qb, qloc);                                   // as a link hanging off the root body
     const V3 Pu = add(Pb, mulv(Rb, tp));
@@ -122,8 +211,8 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     P = selv(isroot, Pr, selv(lower, Pw, Pu));
   }
   if (isl) {
-    double* oq = s.Xq[l];
-    double* op = s.Xp[l];
+    double* oq = s.dyn.Xq[l];
+    double* op = s.dyn.Xp[l];
     oq[0] = Q.w; oq[1] = Q.x; oq[2] = Q.y; oq[3] = Q.z; op[0] = P.x; op[1] = P.y; op[2] = P.z;
   }
   fence();
@@ -135,8 +224,8 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     V3 cs = ld3(bt.center[b]);
     {
       double Rl[3][3];
-      qmat(ldq(s.Xq[bl < 0 ? 0 : bl]), Rl);
-      cs = selv(bl < 0, cs, add(ld3(s.Xp[bl < 0 ? 0 : bl]), mulv(Rl, cs)));
+      qmat(ldq(s.dyn.Xq[bl < 0 ? 0 : bl]), Rl);
+      cs = selv(bl < 0, cs, add(ld3(s.dyn.Xp[bl < 0 ? 0 : bl]), mulv(Rl, cs)));
     }
     double Rbx[3][3];
     qmat(ldq(bt.box_quat[b]), Rbx);
@@ -184,7 +273,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     I10[8] = W[0][2] - mass * c.x * c.z;
     I10[9] = W[1][2] - mass * c.y * c.z;
     if (ishinge) {
-      double* o = s.Sh[l - 6];
+      double* o = s.dyn.Sh[l - 6];
       o[0] = Sw.x; o[1] = Sw.y; o[2] = Sw.z; o[3] = Sv.x; o[4] = Sv.y; o[5] = Sv.z;
     }
   }
@@ -197,7 +286,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     Ic[e] = upper ? I10[e] + ch : I10[e];
   }
   if (upper || sub == 5) {
-    double* o = s.redI[upper ? (l - 6) >> 1 : 8];
+    double* o = s.dyn.redI[upper ? (l - 6) >> 1 : 8];
 #pragma unroll
     for (int e = 0; e < 10; ++e) o[e] = Ic[e];
   }
@@ -205,11 +294,11 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   {
     double tot[10];
 #pragma unroll
-    for (int e = 0; e < 10; ++e) tot[e] = s.redI[8][e];
+    for (int e = 0; e < 10; ++e) tot[e] = s.dyn.redI[8][e];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int e = 0; e < 10; ++e) tot[e] += s.redI[u][e];
+      for (int e = 0; e < 10; ++e) tot[e] += s.dyn.redI[u][e];
 #pragma unroll
     for (int e = 0; e < 10; ++e) Ic[e] = isroot ? tot[e] : Ic[e];
   }
@@ -257,13 +346,13 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     const V3 nch = dpp_quad<QP_CHILD>(n), fch = dpp_quad<QP_CHILD>(f);
     V3 ns = selv(upper, add(n, nch), n), fs = selv(upper, add(f, fch), f);
     if (upper || sub == 5) {
-      double* o = s.redF[upper ? (l - 6) >> 1 : 8];
+      double* o = s.dyn.redF[upper ? (l - 6) >> 1 : 8];
       o[0] = ns.x; o[1] = ns.y; o[2] = ns.z; o[3] = fs.x; o[4] = fs.y; o[5] = fs.z;
     }
     fence();
-    V3 nt = ld3(s.redF[8]), ft = ld3(s.redF[8] + 3);
+    V3 nt = ld3(s.dyn.redF[8]), ft = ld3(s.dyn.redF[8] + 3);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { nt = add(nt, ld3(s.redF[u])); ft = add(ft, ld3(s.redF[u] + 3)); }
+    for (int u = 0; u < 8; ++u) { nt = add(nt, ld3(s.dyn.redF[u])); ft = add(ft, ld3(s.dyn.redF[u] + 3)); }
     ns = selv(isroot, nt, ns); fs = selv(isroot, ft, fs);
     tau_l = -m.damping[l] * qd - (dot(Sw, ns) + dot(Sv, fs)) + s.xt.ext[l];
   }
@@ -283,20 +372,20 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       for (int base = bt.begin[b]; base < pend; base += LPE) {
         const int pi = base + sub < pend ? base + sub : pend - 1;
         const bool valid = mine && base + sub < pend;
-        const int lk = col->pair_rec[pi].sph_link, cls = col->pair_rec[pi].cls;
-        const double r = col->pair_rec[pi].r, margin = col->pair_rec[pi].margin;
-        V3 c = ld3(col->pair_rec[pi].pos);
+        const int lk = pt.link[pi], cls = pt.cls[pi];
+        const double r = pt.r[pi], margin = pt.margin[pi];
+        V3 c = ld3(pt.pos[pi]);
         {
           double Rl[3][3];
-          qmat(ldq(s.Xq[lk < 0 ? 0 : lk]), Rl);
-          c = selv(lk < 0, c, add(ld3(s.Xp[lk < 0 ? 0 : lk]), mulv(Rl, c)));
+          qmat(ldq(s.dyn.Xq[lk < 0 ? 0 : lk]), Rl);
+          c = selv(lk < 0, c, add(ld3(s.dyn.Xp[lk < 0 ? 0 : lk]), mulv(Rl, c)));
         }
         const V3 x = mulvT(Rbx, vsub(c, pb));
         V3 q{fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z)};
         const bool outside = fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z;
         const V3 dd = vsub(x, q);
         const double d2 = dot(dd, dd);
-        const double inv = rsq_nr(outside ? d2 : 1.0);
+        const double inv = rsq2(outside ? d2 : 1.0);
         const double gx = h.x - fabs(x.x), gy = h.y - fabs(x.y), gz = h.z - fabs(x.z);
         const int axn = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
         const double xa = pick3(x, axn), ha = pick3(h, axn), sg = xa >= 0 ? 1.0 : -1.0;
@@ -349,8 +438,9 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     jv = add(jv, cross(wb, d));
     const int c = hq < 3 ? hq : 2;                          // hinge j < 3 works out row j
     const double res = pick3(d, c);
-    double kk, bb, dd;
-    kbimp(m.con_solref[leg], m.con_solimp[leg], res, dt, kk, bb, dd);
+    double kk, bb;
+    kb_of(m.con_solref[leg], m.con_solimp[leg], dt, kk, bb);
+    const double dd = imp_p2(m.con_solimp[leg], res);
     const double eDm = rcp_nr(fmax((1 - dd) * m.con_invweight[leg] * rcp_nr(dd), 1e-15));
     const double earm = -bb * pick3(jv, c) - kk * dd * res;
     if (ishinge && hq < 3) { s.eres[3 * leg + hq] = res; s.eD[3 * leg + hq] = eDm; s.ear[3 * leg + hq] = earm; }
@@ -408,7 +498,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
     const V3 e{ia == 0 ? 1.0 : 0.0, ia == 1 ? 1.0 : 0.0, ia == 2 ? 1.0 : 0.0};
     V3 t1 = cross(n, e);
-    t1 = scl(t1, rsq_nr(dot(t1, t1)));
+    t1 = scl(t1, rsq2(dot(t1, t1)));
     const V3 t2 = cross(n, t1);
     cd2 = ls >= 6 ? ls : -1;
     cd1 = (cd2 >= 0 && m.parent[cd2] >= 6) ? m.parent[cd2] : -1;
@@ -416,8 +506,8 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     const V3 rp = vsub(p, Pb);
     const V3 dirs[3] = {n, t1, t2};
     double Jr[3][6], Jh[3][2];
-    const double* s1 = s.Sh[cd1 >= 0 ? cd1 - 6 : 0];
-    const double* s2 = s.Sh[cd2 >= 0 ? cd2 - 6 : 0];
+    const double* s1 = s.dyn.Sh[cd1 >= 0 ? cd1 - 6 : 0];
+    const double* s2 = s.dyn.Sh[cd2 >= 0 ? cd2 - 6 : 0];
     const V3 jp1 = add(ld3(s1 + 3), cross(ld3(s1), p)), jp2 = add(ld3(s2 + 3), cross(ld3(s2), p));
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -462,7 +552,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       if (s.xt.foot_mu > 0 && ls > root && m.parent[ls > 0 ? ls : 0] != root) cmu = s.xt.foot_mu;
     }
     const double kk = bt.kb_cls[cls][0], bb = bt.kb_cls[cls][1];
-    const double dd = imp_of(bt.cls_solimp[cls], rec[0] - margin);
+    const double dd = imp_p2(bt.cls_solimp[cls], rec[0] - margin);
     const double R0 = fmax((1 - dd) * bt.cls_invw[cls] * rcp_nr(dd), 1e-15);
     cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
     const double basea = -kk * dd * (rec[0] - margin);
@@ -498,37 +588,44 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     {
       // this lane's entries of the pass's Hessian: equality part + the active contact edges
       double acc6[6] = {0, 0, 0, 0, 0, 0}, accd = 0, accc = 0, rr = rw;
-      for (int c = 0; c < ncmax; ++c) {
-        const double* w = s.cw[c];
-        const int d1 = s.crow[c][0], d2 = s.crow[c][1];
-        const int slot = l == d2 ? 1 : 0;
-        const bool touch = isroot || l == d1 || l == d2;
-        double j[3], jc[3];
+      // (four contacts per iteration, their loads side by side: slots beyond the wave's count hold zero rows and zero weights -- C3 and the weights
+      // above write all MC slots -- so they are simply summed; one contact per iteration paid an LDS round trip each, 1.3 k cycles per contact)
+      static_assert(MC % 4 == 0, "contact slots in groups of four");
+      for (int c4 = 0; c4 < ncmax; c4 += 4) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double jr = s.CJr[c][k][isroot ? l : 0], jh = s.CJh[c][k][slot];
-          j[k] = touch ? (isroot ? jr : jh) : 0.0;
-          jc[k] = s.CJh[c][k][1];
+        for (int u = 0; u < 4; ++u) {
+          const int c = c4 + u;
+          const double* w = s.cw[c];
+          const int d1 = s.crow[c][0], d2 = s.crow[c][1];
+          const int slot = l == d2 ? 1 : 0;
+          const bool touch = isroot || l == d1 || l == d2;
+          double j[3], jc[3];
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double jr = s.CJr[c][k][isroot ? l : 0], jh = s.CJh[c][k][slot];
+            j[k] = touch ? (isroot ? jr : jh) : 0.0;
+            jc[k] = s.CJh[c][k][1];
+          }
+          const double v0 = w[0] * j[0] + w[1] * j[1] + w[2] * j[2], v1 = w[1] * j[0] + w[3] * j[1], v2 = w[2] * j[0] + w[4] * j[2];
+          rr += w[5] * j[0] + w[6] * j[1] + w[7] * j[2];
+  #pragma unroll
+          for (int i = 0; i < 6; ++i) acc6[i] += s.CJr[c][0][i] * v0 + s.CJr[c][1][i] * v1 + s.CJr[c][2][i] * v2;
+          accd += j[0] * v0 + j[1] * v1 + j[2] * v2;
+          accc += (l == d1) ? jc[0] * v0 + jc[1] * v1 + jc[2] * v2 : 0.0;
         }
-        const double v0 = w[0] * j[0] + w[1] * j[1] + w[2] * j[2], v1 = w[1] * j[0] + w[3] * j[1], v2 = w[2] * j[0] + w[4] * j[2];
-        rr += w[5] * j[0] + w[6] * j[1] + w[7] * j[2];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc6[i] += s.CJr[c][0][i] * v0 + s.CJr[c][1][i] * v1 + s.CJr[c][2][i] * v2;
-        accd += j[0] * v0 + j[1] * v1 + j[2] * v2;
-        accc += (l == d1) ? jc[0] * v0 + jc[1] * v1 + jc[2] * v2 : 0.0;
       }
       if (isroot) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s.HR[l][i] = Bw[i] + acc6[i];
+        for (int i = 0; i < 6; ++i) s.pas.HR[l][i] = Bw[i] + acc6[i];
       }
       if (ishinge) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s.HB[l - 6][i] = Bw[i] + acc6[i];
+        for (int i = 0; i < 6; ++i) s.pas.HB[l - 6][i] = Bw[i] + acc6[i];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          if (p >= hq) s.HA[leg][p * (p + 1) / 2 + hq] = Aw[p] + (p == hq ? accd : ((upper && p == hq + 1) ? accc : 0.0));
+          if (p >= hq) s.pas.HA[leg][p * (p + 1) / 2 + hq] = Aw[p] + (p == hq ? accd : ((upper && p == hq + 1) ? accc : 0.0));
       }
-      if (isl) s.rc[l] = rr;
+      if (isl) s.pas.rc[l] = rr;
     }
     fence();
     KSTAMP(17);
@@ -539,10 +636,10 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       const int i = t % 6, k = t / 6;
       double L[10], Bc[4], bk[4];
 #pragma unroll
-      for (int e = 0; e < 10; ++e) L[e] = s.HA[k][e];
+      for (int e = 0; e < 10; ++e) L[e] = s.pas.HA[k][e];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { Bc[j] = s.HB[4 * k + j][i]; bk[j] = s.rc[6 + 4 * k + j]; }
-      chol_regs<4, 4>(L);
+      for (int j = 0; j < 4; ++j) { Bc[j] = s.pas.HB[4 * k + j][i]; bk[j] = s.pas.rc[6 + 4 * k + j]; }
+      chol_small<4>(L);
       double W[4], y[4], pt = 0.0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -555,13 +652,13 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       }
       if (sub < 24) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s.Wl[i][4 * k + j] = W[j];
-        s.part[i][k] = pt;
+        for (int j = 0; j < 4; ++j) s.pas.Wl[i][4 * k + j] = W[j];
+        s.pas.part[i][k] = pt;
         if (i == 0) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) s.Y[4 * k + j] = y[j];
+          for (int j = 0; j < 4; ++j) s.pas.Y[4 * k + j] = y[j];
 #pragma unroll
-          for (int e = 0; e < 10; ++e) s.LL[k][e] = L[e];
+          for (int e = 0; e < 10; ++e) s.pas.LL[k][e] = L[e];
         }
       }
     }
@@ -571,33 +668,33 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       const int e = sub < 21 ? sub : 20;
       const int i = e >= 15 ? 5 : (e >= 10 ? 4 : (e >= 6 ? 3 : (e >= 3 ? 2 : (e >= 1 ? 1 : 0))));
       const int c = e - i * (i + 1) / 2;
-      double s0 = s.HR[i][c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      double s0 = s.pas.HR[i][c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
       for (int p = 0; p < 16; p += 4) {
-        s0 = fma(-s.Wl[i][p], s.Wl[c][p], s0); s1 = fma(-s.Wl[i][p + 1], s.Wl[c][p + 1], s1);
-        s2 = fma(-s.Wl[i][p + 2], s.Wl[c][p + 2], s2); s3 = fma(-s.Wl[i][p + 3], s.Wl[c][p + 3], s3);
+        s0 = fma(-s.pas.Wl[i][p], s.pas.Wl[c][p], s0); s1 = fma(-s.pas.Wl[i][p + 1], s.pas.Wl[c][p + 1], s1);
+        s2 = fma(-s.pas.Wl[i][p + 2], s.pas.Wl[c][p + 2], s2); s3 = fma(-s.pas.Wl[i][p + 3], s.pas.Wl[c][p + 3], s3);
       }
-      if (sub < 21) s.SS[e] = (s0 + s1) + (s2 + s3);
+      if (sub < 21) s.pas.SS[e] = (s0 + s1) + (s2 + s3);
     }
     fence();
     {
       // every lane: the root block's 6 x 6 system in registers
       double Lr[21];
 #pragma unroll
-      for (int e = 0; e < 21; ++e) Lr[e] = s.SS[e];
+      for (int e = 0; e < 21; ++e) Lr[e] = s.pas.SS[e];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) xr[i] = s.rc[i] - ((s.part[i][0] + s.part[i][1]) + (s.part[i][2] + s.part[i][3]));
-      chol_regs<6, 6>(Lr);
+      for (int i = 0; i < 6; ++i) xr[i] = s.pas.rc[i] - ((s.pas.part[i][0] + s.pas.part[i][1]) + (s.pas.part[i][2] + s.pas.part[i][3]));
+      chol_small<6>(Lr);
       solve_regs<6, 6>(Lr, xr);
       // hinge lanes: back-substitution of their leg, x_k = L_k^-T (y_k - W_k' x_root)
       double Lk[10], z[4];
 #pragma unroll
-      for (int e = 0; e < 10; ++e) Lk[e] = s.LL[leg][e];
+      for (int e = 0; e < 10; ++e) Lk[e] = s.pas.LL[leg][e];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        double zz = s.Y[4 * leg + j];
+        double zz = s.pas.Y[4 * leg + j];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) zz = fma(-s.Wl[i][4 * leg + j], xr[i], zz);
+        for (int i = 0; i < 6; ++i) zz = fma(-s.pas.Wl[i][4 * leg + j], xr[i], zz);
         z[j] = zz;
       }
 #pragma unroll
@@ -657,14 +754,14 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       const int bd = m.ball_dof;
       const V3 wbd{s.qv[bd], s.qv[bd + 1], s.qv[bd + 2]};
       Q4 q0 = Qb;
-      const double n0 = rsq_nr(q0.w * q0.w + q0.x * q0.x + q0.y * q0.y + q0.z * q0.z);
+      const double n0 = rsq2(q0.w * q0.w + q0.x * q0.x + q0.y * q0.y + q0.z * q0.z);
       q0 = Q4{q0.w * n0, q0.x * n0, q0.y * n0, q0.z * n0};
       const double w2 = dot(wbd, wbd);
-      const double iw = w2 > 0 ? rsq_nr(w2 > 0 ? w2 : 1.0) : 0.0;
+      const double iw = w2 > 0 ? rsq2(w2 > 0 ? w2 : 1.0) : 0.0;
       double sn, cs;
-      sincos_mod(0.5 * dt * (w2 * iw), sn, cs);
+      sincos_kc(0.5 * dt * (w2 * iw), sn, cs);
       const Q4 q1 = qmul(q0, Q4{cs, sn * wbd.x * iw, sn * wbd.y * iw, sn * wbd.z * iw});
-      const double n1 = rsq_nr(q1.w * q1.w + q1.x * q1.x + q1.y * q1.y + q1.z * q1.z);
+      const double n1 = rsq2(q1.w * q1.w + q1.x * q1.x + q1.y * q1.y + q1.z * q1.z);
       if (sub == 0) { s.bq[0] = q1.w * n1; s.bq[1] = q1.x * n1; s.bq[2] = q1.y * n1; s.bq[3] = q1.z * n1; }
       fence();
     }

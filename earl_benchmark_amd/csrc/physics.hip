@@ -2586,16 +2586,25 @@ __device__ __forceinline__ double mt_draw(const earl_minitaur_cfg& cfg, const ui
 }
 // ARROW: the timestep written on the model's tree (minitaur_stepper.h: substep_mt, the product path) or the generic substep<22> above (kept for
 // comparison: earl_debug_set_minitaur_stepper(0); same numbers to rounding)
+#ifndef EARL_MT_WPB
+#define EARL_MT_WPB 4            // wavefronts per workgroup of the tree-structured kernels
+#endif
+#ifndef EARL_MT_BLOCKS
+#define EARL_MT_BLOCKS 1         // ... and workgroups per CU the register budget is set for (2 = two waves per SIMD, 256 registers each: spills 1.4 KB per lane and runs 1.5 x slower, tools/bench_mt_variant.py)
+#endif
+template <bool ARROW> constexpr int mt_wpb() { return ARROW ? EARL_MT_WPB : Lim<22>::WPB; }
 template <bool RESET, bool ARROW>
-__global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const MinitaurArgs a) {
+__global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) void minitaur_kernel(const MinitaurArgs a) {
 #pragma clang fp contract(off)
-  constexpr int NV = 22, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
+  constexpr int NV = 22, LPE = 32, EPW = 64 / LPE, WPB = mt_wpb<ARROW>();
   using SH = std::conditional_t<ARROW, SharedMT, Shared<NV>>;
   __shared__ typename ModelOf<NV>::T m;
   __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
   __shared__ SH sh[EPW * WPB];
+  __shared__ std::conditional_t<ARROW, PairTabMT, char> ptab;
   stage_blocks(bt, a.col);
   stage_kb<NV>(bt, a.m, a.col);
+  if constexpr (ARROW) stage_pairs_mt(ptab, a.col);
   stage_model(m, a.m);                                  // (ends with the workgroup barrier)
   const earl_minitaur_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
@@ -2606,7 +2615,15 @@ __global__ __launch_bounds__(64 * Lim<22>::WPB) void minitaur_kernel(const Minit
   SH& s = sh[wave * EPW + grp];
   const double ctrl0[EARL_MAXACT] = {0, 0, 0, 0};
   auto timestep = [&](const bool warm) {
-    if constexpr (ARROW) substep_mt<true>(s, m, bt, a.col, sub, grp, warm, nullptr);
+    if constexpr (ARROW) {
+      // (the lane index passes through an empty asm: everything derived from it -- the lane's rows of the model tables, its LDS addresses -- is then
+      // read / recomputed inside the timestep instead of being hoisted out of the rollout loop into registers that live across the whole kernel and
+      // end up in scratch memory; see sawyer_rollout_kernel)
+      int sub_ = sub;
+      asm volatile("" : "+v"(sub_));
+      __builtin_assume(sub_ >= 0 && sub_ < LPE);
+      substep_mt<true>(s, m, bt, ptab, sub_, grp, warm, nullptr);
+    }
     else substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, Q4{1, 0, 0, 0}, ctrl0, warm, nullptr, nullptr);
   };
   const int mi = sub < 8 ? sub : 7;                     // this lane's motor
@@ -2852,7 +2869,7 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
   if (!out->obs || !out->reward || !out->done || !out->success || !cfg->goal_table || cfg->n_goals < 1 || cfg->num_substeps < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
   MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr};
-  if (g_mt_stepper) minitaur_kernel<false, true><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  if (g_mt_stepper) minitaur_kernel<false, true><<<(cfg->n + 2 * EARL_MT_WPB - 1) / (2 * EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
   else minitaur_kernel<false, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_rollout");
 }
@@ -2863,7 +2880,7 @@ int earl_minitaur_reset(const void* model24, const earl_collision_model* col, co
   if (!cfg->goal_table || !cfg->reset_qpos || cfg->n_goals < 1 || cfg->settle_steps < 0) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
   MinitaurArgs a{model24, col, *cfg, *st, earl_minitaur_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0, mask, obs};
-  if (g_mt_stepper) minitaur_kernel<true, true><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  if (g_mt_stepper) minitaur_kernel<true, true><<<(cfg->n + 2 * EARL_MT_WPB - 1) / (2 * EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
   else minitaur_kernel<true, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_reset");
 }
