@@ -17,13 +17,21 @@ vs 8 TB/s), "cpu_baseline" (the C oracle on the host cores, bounded sample), "st
 through per-step launches of the gym-style step()), and with --sweep "sweep" (throughput vs N).
 """
 import argparse
+import importlib.util
 import json
 import os
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+
+# CPUs this process may run on, recorded BEFORE anything is imported: with OMP_PROC_BIND set, libgomp's load-time initialisation (it comes in with torch)
+# binds the main thread to one place and a later sched_getaffinity() reports 1-2 CPUs (ADVICE r03: the CPU sweeps then topped out at 2 threads)
+AVAIL_CPUS = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+# the reference's own simulators (SURVEY 8(d)(3)): probed, never assumed
+REFERENCE_SIMULATORS = ('mujoco', 'mujoco_py', 'pybullet', 'pybullet_envs', 'dm_control', 'metaworld', 'gym')
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 BYTES_PER_ENV_STEP_ROLLOUT = 66  # act 12 B in; obs 48 + reward 4 + done 1 + success 1 B out (SURVEY 8d)
@@ -52,6 +60,11 @@ def parse():
   p.add_argument('--sawyer-cpu-seconds', type=float, default=2.0, help='seconds per repetition and thread count of the Sawyer CPU baselines')
   p.add_argument('--no-kitchen', action='store_true', help='skip the kitchen (BASELINE configs[3]) leg of the default line')
   p.add_argument('--no-minitaur', action='store_true', help='skip the minitaur (BASELINE configs[4]) leg of the default line')
+  p.add_argument('--settle-launches', type=int, default=40,
+                 help='untimed launches of the headline shape BEFORE the --warmup ones: the board reaches its sustained power state (the first ~30 launches of a '
+                      'process run 5-15 %% faster), so that `value` and `roofline.frac` are the sustained figures')
+  p.add_argument('--cpu-child', default=None, help=argparse.SUPPRESS)        # internal: run one CPU baseline in this (fresh, torch-free) process and print its JSON
+  p.add_argument('--cpu-child-args', default='{}', help=argparse.SUPPRESS)
   p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door', 'sawyer_peg', 'kitchen', 'minitaur'],
                  help='tabletop = BASELINE configs[1] (the default, the quoted metric); sawyer_door / sawyer_peg = configs[2] shape, N=8192 each (next rows)')
   return p.parse_args()
@@ -196,10 +209,94 @@ def time_step_api(torch, env, acts, steps, warmup, graph=False):
   return dt, e0.elapsed_time(e1) * 1e-3
 
 
+def probe_reference_simulators():
+  """is any of the simulators the reference binds (env.yml:11-15: mujoco-py -> MuJoCo 2.1, pybullet, metaworld; plus their modern names)
+  importable on THIS host?  find_spec first (no side effects), then a real import of what was found, in a child process (mujoco_py compiles at import)."""
+  found, errors = [], {}
+  for name in REFERENCE_SIMULATORS:
+    try:
+      if importlib.util.find_spec(name) is None:
+        continue
+    except (ImportError, ValueError) as e:
+      errors[name] = repr(e)
+      continue
+    r = subprocess.run([sys.executable, '-c', f'import {name}; print(getattr({name}, "__version__", "?"))'], capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+      found.append({'module': name, 'version': r.stdout.strip().splitlines()[-1] if r.stdout.strip() else '?'})
+    else:
+      errors[name] = (r.stderr.strip().splitlines() or ['import failed'])[-1][:200]
+  names = [f['module'] for f in found]
+  return {'probed': list(REFERENCE_SIMULATORS), 'found': found, 'import_errors': errors,
+          'mujoco': any(n in names for n in ('mujoco', 'mujoco_py')), 'pybullet': 'pybullet' in names,
+          'note': ('none of the reference\'s simulators is importable on this host: the CPU baselines below run this build\'s C restatement of its own stepper, and the '
+                   'dynamics stay unpinned against MuJoCo / PyBullet (DESIGN.md)') if not found else
+                  ('found ' + ', '.join(names) + ': tools/pin_with_simulator.py steps the build\'s own model description in it next to the HIP stepper')}
+
+
+def simulator_sentence(sim, which):
+  """the clause the CPU-baseline samples carry about the real simulator, derived from the probe (never a constant)"""
+  if sim is None:
+    return f'{which} was not probed in this process'
+  have = sim.get('mujoco') if which == 'MuJoCo' else sim.get('pybullet')
+  return (f'{which} IS importable on this host (see reference_simulator)' if have else
+          f'{which} itself is not importable on this host (probed: {", ".join(sim["probed"])}; found: {[f["module"] for f in sim["found"]] or "none"})')
+
+
+def run_cpu_baseline_child(kind, **kw):
+  """One CPU baseline in a FRESH child process (never a re-exec of this one): the OpenMP placement variables live in the child's environment only -- in
+  the GPU process they would make libgomp pin the main thread, and every thread created after it (HIP runtime, RCCL proxy), to one core --
+  and the child sizes its thread sweep from the CPUs it may use before it imports anything.  -> the baseline's dict"""
+  env = dict(os.environ)
+  env.setdefault('OMP_PROC_BIND', 'spread')
+  env.setdefault('OMP_PLACES', 'cores')
+  r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-child', kind, '--cpu-child-args', json.dumps(kw)], env=env, capture_output=True, text=True,
+                     timeout=1800)
+  lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+  if r.returncode != 0 or not lines:
+    return {'value': None, 'unit': 'env-steps/s', 'cores': None, 'kind': 'port', 'sample': f'CPU baseline child failed (rc {r.returncode}): {r.stderr.strip()[-300:]}'}
+  return json.loads(lines[-1])
+
+
+def cpu_child_main(kind, kw):
+  """body of the child: no torch unless an imported module brings it; the main thread's affinity is restored after the imports"""
+  sim = kw.pop('simulators', None)
+  global SIMULATORS
+  SIMULATORS = sim
+  fn = {'tabletop': cpu_baseline, 'sawyer_door': lambda **k: sawyer_cpu_baseline(task='sawyer_door', **k), 'sawyer_peg': lambda **k: sawyer_cpu_baseline(task='sawyer_peg', **k),
+        'kitchen': kitchen_cpu_baseline, 'minitaur': minitaur_cpu_baseline}[kind]
+  res = fn(**kw)
+  print(json.dumps(res), flush=True)
+
+
+SIMULATORS = None                # result of probe_reference_simulators(), set by main() / handed to the children
+CPU_RESULTS = {}                 # kind -> CPU baseline dict, filled by collect_cpu_baselines() BEFORE this process touches the GPU
+
+
+def collect_cpu_baselines(a):
+  """Every CPU leg of this run, each in its own fresh child process, BEFORE torch is imported here: child processes are started while this process has
+  no GPU state, and the GPU process itself never carries the OpenMP placement variables.  (rank 0 of a single-GPU run only.)"""
+  sim = SIMULATORS
+  jobs = []
+  if a.workload == 'tabletop':
+    jobs.append(('tabletop', dict(n=a.envs, T=a.horizon, reward=a.reward, seconds=a.cpu_seconds)))
+    if not a.no_sawyer:
+      jobs += [(w, dict(T_sample=0, seconds=a.sawyer_cpu_seconds, n=8192, simulators=sim)) for w in ('sawyer_door', 'sawyer_peg')]
+    if not a.no_kitchen:
+      jobs.append(('kitchen', dict(seconds=2.0, simulators=sim)))
+    if not a.no_minitaur:
+      jobs.append(('minitaur', dict(seconds=2.0, simulators=sim)))
+  elif a.workload in ('sawyer_door', 'sawyer_peg'):
+    jobs.append((a.workload, dict(T_sample=0, seconds=max(2.0, a.cpu_seconds / 5), n=a.envs if a.envs != 4096 else 8192, simulators=sim)))
+  else:
+    jobs.append((a.workload, dict(seconds=5.0, simulators=sim)))
+  for kind, kw in jobs:
+    CPU_RESULTS[kind] = run_cpu_baseline_child(kind, **kw)
+
+
 def host_cpu_info():
   """what bounds the CPU baselines on this host: CPUs this process may run on, the cgroup CPU quota (a 256-CPU box with a quota of 16 CPUs' worth of
   time explains a thread sweep that peaks at 16), the OpenMP placement in force"""
-  info = {'affinity_cpus': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count(), 'os_cpu_count': os.cpu_count(),
+  info = {'affinity_cpus': len(AVAIL_CPUS), 'os_cpu_count': os.cpu_count(),
           'OMP_PROC_BIND': os.environ.get('OMP_PROC_BIND'), 'OMP_PLACES': os.environ.get('OMP_PLACES'), 'cgroup_cpu_quota_cpus': None}
   try:
     if os.path.exists('/sys/fs/cgroup/cpu.max'):                          # cgroup v2: "<quota> <period>" or "max <period>"
@@ -222,7 +319,7 @@ def cpu_baseline(n, T, reward, seconds):
   o = orc.OracleTabletop(n, reward_type=reward, horizon=T, seed=0)
   rng = np.random.default_rng(1234)
   acts = rng.uniform(-1, 1, size=(T, n, 3)).astype(np.float32)
-  avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  avail = len(AVAIL_CPUS)
 
   out = (np.zeros((T, n, 12), np.float32), np.zeros((T, n), np.float32), np.zeros((T, n), np.uint8), np.zeros((T, n), np.uint8))
 
@@ -293,7 +390,7 @@ def pipe_roofline(prof, kernel, gpu_ms, hbm=None):
 
 def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door', n=8192, reps=3):
   """The C restatement of the same stepper and env loop (oracle/physics_oracle.c, OpenMP over envs) on the host cores.  MuJoCo itself
-  is not available on this host; this port runs the same algorithm the kernel runs.  Method: FIXED batch (n envs, the bench's own
+  availability is probed (probe_reference_simulators); this port runs the same algorithm the kernel runs.  Method: FIXED batch (n envs, the bench's own
   size) at every thread count; per count a short probe sizes a run of >= `seconds` (T env steps of random actions from the reset
   state), which is repeated `reps` times and the fastest repetition kept; the best count is reported."""
   import numpy as np
@@ -323,7 +420,7 @@ def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door', n=8192, reps=3):
     t0 = time.perf_counter()
     cm.sawyer_rollout(cfg, q, v, mp, goal, steps, acts)
     return time.perf_counter() - t0
-  ncpu = len(os.sched_getaffinity(0))
+  ncpu = len(AVAIL_CPUS)
   cands = sorted({1, min(16, ncpu), min(64, ncpu), min(128, ncpu), ncpu})
   sweep, detail = {}, {}
   for c in cands:
@@ -337,7 +434,7 @@ def sawyer_cpu_baseline(T_sample, seconds, task='sawyer_door', n=8192, reps=3):
   return {'value': sweep[best], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
           'sample': f'{n} envs x {detail[best]["T"]} env steps (5 timesteps each, random actions from the reset state), fastest of {reps} repetitions of '
                     f'>= {seconds:g} s each, through the C restatement of the same stepper (oracle/physics_oracle.c, OpenMP static over envs); the same '
-                    f'{n}-env batch at every thread count: {({k: round(v) for k, v in sweep.items()})}; MuJoCo itself is not available on this host',
+                    f'{n}-env batch at every thread count: {({k: round(v) for k, v in sweep.items()})}; ' + simulator_sentence(SIMULATORS, 'MuJoCo'),
           'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
@@ -407,7 +504,7 @@ def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8
                     'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
                     'parallelism': f'env-range shard x{world}, no per-step collective'},
          'valu_frac': roof['frac'], 'roofline': roof,
-         'cpu_baseline': None if cpu_seconds is None else sawyer_cpu_baseline(T, cpu_seconds, workload, n=n)}
+         'cpu_baseline': CPU_RESULTS.get(workload) if cpu_seconds is not None else None}
   del env, acts, out
   torch.cuda.empty_cache()
   return res
@@ -416,7 +513,7 @@ def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8
 def kitchen_cpu_baseline(seconds, n=2048, reps=2):
   """The C restatement of the same stepper (oracle/physics_oracle.c, OpenMP over envs) and of the reference's numpy glue (oracle/glue_oracle.c)
   on the host cores: the bench's own 2048-env batch at every thread count, whole env steps (40 timesteps + action / observation / reward
-  glue) of random actions from the reset state, >= `seconds` per repetition, fastest of `reps`.  MuJoCo itself is not available on this host."""
+  glue) of random actions from the reset state, >= `seconds` per repetition, fastest of `reps`."""
   import numpy as np
   from earl_benchmark_amd.envs.kitchen import INIT_QPOS, MIDPOINT_POS
   from earl_benchmark_amd import tables
@@ -445,7 +542,7 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
       go.kitchen_reward(obs, mp, np.ascontiguousarray(r['att'][:, site_idx]))
       last = obs[:, :9].copy()
     return time.perf_counter() - t0
-  ncpu = len(os.sched_getaffinity(0))
+  ncpu = len(AVAIL_CPUS)
   sweep, detail = {}, {}
   for c in sorted({1, min(16, ncpu), min(64, ncpu), min(128, ncpu), ncpu}):
     probe = run(c, 1)
@@ -457,7 +554,7 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
   return {'value': sweep[best], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
           'sample': f'{n} envs x {detail[best]["env_steps"]} env steps (40 timesteps each + the glue), fastest of {reps} repetitions of >= {seconds:g} s, through the C '
                     f'restatement of the same stepper (oracle/physics_oracle.c, OpenMP static over envs) and of the reference\'s numpy glue; the same {n}-env batch at '
-                    f'every thread count: {({k: round(v) for k, v in sweep.items()})}; MuJoCo itself is not available on this host',
+                    f'every thread count: {({k: round(v) for k, v in sweep.items()})}; ' + simulator_sentence(SIMULATORS, 'MuJoCo'),
           'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
@@ -532,18 +629,18 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
           'config': {'workload': f'kitchen dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 40 '
                                  'timesteps per bench step; own stepper (nv = 23, 32 lanes per env), reduced collision set, parity with MuJoCo unpinned',
                      'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 40, 'launches_per_episode': 1},
-          'cpu_baseline': None if cpu_seconds is None else kitchen_cpu_baseline(cpu_seconds)}
+          'cpu_baseline': CPU_RESULTS.get('kitchen') if cpu_seconds is not None else None}
 
 
 def minitaur_cpu_baseline(seconds, n=4096, reps=2):
   """The C restatement of the same stepper and env loop (oracle/physics_oracle.c: oracle_minitaur_rollout, OpenMP over envs) on the host cores: the
   bench's own 4096-env batch at every thread count, whole env steps (leg model, 5 x (motor model + timestep), observation, reward) of random actions
-  from the reset state, >= `seconds` per repetition, fastest of `reps`.  PyBullet itself is not available on this host."""
+  from the reset state, >= `seconds` per repetition, fastest of `reps`."""
   import numpy as np
   from oracle import physics_c
   rng = np.random.default_rng(0)
   c = physics_c.CMinitaur(n, seed=1234)
-  physics_c.set_threads(len(os.sched_getaffinity(0)))
+  physics_c.set_threads(len(AVAIL_CPUS))
   c.reset()
   q0, v0 = c.qpos.copy(), c.qvel.copy()
 
@@ -555,7 +652,7 @@ def minitaur_cpu_baseline(seconds, n=4096, reps=2):
     t0 = time.perf_counter()
     c.rollout(acts)
     return time.perf_counter() - t0
-  ncpu = len(os.sched_getaffinity(0))
+  ncpu = len(AVAIL_CPUS)
   sweep, detail = {}, {}
   for k in sorted({1, min(16, ncpu), min(64, ncpu), min(128, ncpu), ncpu}):
     probe = run(k, 1)
@@ -567,7 +664,7 @@ def minitaur_cpu_baseline(seconds, n=4096, reps=2):
   return {'value': sweep[best], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
           'sample': f'{n} envs x {detail[best]["env_steps"]} env steps (5 timesteps each + motor model / observation / reward), fastest of {reps} repetitions of >= {seconds:g} s, '
                     f'through the C restatement of the same stepper (oracle/physics_oracle.c, OpenMP static over envs); the same {n}-env batch at every thread count: '
-                    f'{({k: round(v) for k, v in sweep.items()})}; PyBullet itself is not available on this host',
+                    f'{({k: round(v) for k, v in sweep.items()})}; ' + simulator_sentence(SIMULATORS, 'PyBullet'),
           'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
@@ -623,7 +720,7 @@ def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=40
           'config': {'workload': f'minitaur dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 5 '
                                  'timesteps per bench step; own robot model (nv = 22, four loop closures) and stepper, parity with PyBullet unpinned and model-less',
                      'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'launches_per_episode': 2},
-          'cpu_baseline': None if cpu_seconds is None else minitaur_cpu_baseline(cpu_seconds)}
+          'cpu_baseline': CPU_RESULTS.get('minitaur') if cpu_seconds is not None else None}
 
 
 def main_sawyer(a, torch, dist, world, rank, device):
@@ -634,7 +731,8 @@ def main_sawyer(a, torch, dist, world, rank, device):
     res = {'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world, 'steps': a.steps,
            'warmup': a.warmup, 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
            'data': 'synthetic', 'config': r['config'], 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline'],
-           'kernel_ms': r['kernel_ms'], 'valu_frac': r['valu_frac'], 'diverged_env_steps_last_rollout': r['diverged_env_steps_last_rollout']}
+           'kernel_ms': r['kernel_ms'], 'valu_frac': r['valu_frac'], 'diverged_env_steps_last_rollout': r['diverged_env_steps_last_rollout'],
+           'reference_simulator': SIMULATORS}
     print(json.dumps(res), flush=True)
   if world > 1:
     dist.barrier()
@@ -643,16 +741,27 @@ def main_sawyer(a, torch, dist, world, rank, device):
 
 def main():
   a = parse()
+  if a.cpu_child:                                             # a CPU baseline child of another bench.py: never touches the GPU
+    cpu_child_main(a.cpu_child, json.loads(a.cpu_child_args))
+    if hasattr(os, 'sched_setaffinity'):
+      os.sched_setaffinity(0, AVAIL_CPUS)
+    return
   os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC for RCCL: must be in the environment before the HIP runtime starts
-  # OpenMP placement of the CPU baselines (the oracle's C library): one thread per core, spread over the sockets; must be in the environment before
-  # libgomp initialises.  (a thread sweep that collapses past 16 threads is a placement / quota artefact unless shown otherwise.)
-  os.environ.setdefault('OMP_PROC_BIND', 'spread')
-  os.environ.setdefault('OMP_PLACES', 'cores')
-  import torch
-  import torch.distributed as dist
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  # The reference's simulators: probed, and the CPU baselines: run -- each in a fresh child process that alone carries the OpenMP placement variables
+  # (OMP_PROC_BIND / OMP_PLACES never enter THIS process: with them libgomp binds the main thread and everything created after it to one core) -- before
+  # torch is imported here, i.e. before this process has any GPU state.
+  global SIMULATORS
+  if rank == 0:
+    SIMULATORS = probe_reference_simulators()
+    if world == 1 and not a.no_cpu:
+      collect_cpu_baselines(a)
+  import torch
+  import torch.distributed as dist
+  if hasattr(os, 'sched_setaffinity') and 'OMP_PROC_BIND' not in os.environ:
+    assert sorted(os.sched_getaffinity(0)) == AVAIL_CPUS, 'importing torch changed this process\'s CPU affinity'
   if world != a.gpus:
     if world == 1 and a.gpus > 1:
       sys.exit(f'--gpus {a.gpus} needs the torch.distributed.run launcher (one process per GPU)')
@@ -671,7 +780,7 @@ def main():
       print(json.dumps({'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world,
                         'steps': r['steps'], 'warmup': r['warmup'], 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
                         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'config': r['config'], 'roofline': r['roofline'], 'cpu_baseline': r['cpu_baseline'],
-                        'timesteps_per_s': r['timesteps_per_s'], 'diverged_env_steps': r['diverged_env_steps']}), flush=True)
+                        'timesteps_per_s': r['timesteps_per_s'], 'diverged_env_steps': r['diverged_env_steps'], 'reference_simulator': SIMULATORS}), flush=True)
     if world > 1:
       dist.barrier()
       dist.destroy_process_group()
@@ -682,7 +791,7 @@ def main():
       print(json.dumps({'metric': 'env steps/sec (aggregate) at N parallel envs', 'value': r['value'], 'unit': 'env-steps/s', 'n_gpus': world,
                         'steps': r['steps'], 'warmup': r['warmup'], 'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'strong',
                         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'config': r['config'], 'cpu_baseline': r['cpu_baseline'],
-                        'timesteps_per_s': r['timesteps_per_s'], 'gpu_ms_per_env_step': r['gpu_ms_per_env_step']}), flush=True)
+                        'timesteps_per_s': r['timesteps_per_s'], 'gpu_ms_per_env_step': r['gpu_ms_per_env_step'], 'reference_simulator': SIMULATORS}), flush=True)
     if world > 1:
       dist.barrier()
       dist.destroy_process_group()
@@ -699,7 +808,12 @@ def main():
   acts = act_sets[0]
   acts1 = acts[0] if E > 1 else acts
   out = alloc_out(torch, T, n, device, E)
-  dt, kern_ms, gathered, _, launches = time_rollouts(torch, dist, env, act_sets, out, a.steps, a.warmup, world, device)
+  # the process's first launches (what rounds 1-3 quoted as `value`): 5-15 % faster than the sustained power state; kept as a side key
+  edt, ekm, _, _, el = time_rollouts(torch, dist, env, act_sets, out, a.steps, a.warmup, world, device)
+  early = {'value': a.steps * E * n * T * world / edt, 'unit': 'env-steps/s', 'kernel_ms_mean': ekm[0], 'launches': el,
+           'note': f'the first launches of the process ({a.warmup} warm-up + {a.steps} timed), before the board settles into its sustained power state: NOT the headline'}
+  # headline: --settle-launches more untimed launches first (about 10 ms of back-to-back traffic), then the --warmup ones, then EXACTLY --steps timed
+  dt, kern_ms, gathered, _, launches = time_rollouts(torch, dist, env, act_sets, out, a.steps, a.warmup + max(0, a.settle_launches), world, device)
   if world > 1:
     assert gathered.shape == (n * world, 2)
   dn = out[2] if E > 1 else out[2][None]
@@ -731,14 +845,14 @@ def main():
                           'after the other on the batch\'s 64 workgroups -- the reference\'s evaluation loop taken literally'}
   total_env_steps = a.steps * E * n * T * world
   value = total_env_steps / dt
-  # SUSTAINED rate of the same launches (tools/placement_experiment.py: the first ~30 launches of a process run 5-15 % faster than the ones after ~10 ms
-  # of back-to-back traffic -- the board settles into its sustained power state): 60 more launches, the last 40 timed; reported beside `value`, never as it
+  # cross-check of the headline: 60 more of the same launches, the last 40 timed (tools/placement_experiment.py: the first ~30 launches of a process run
+  # 5-15 % faster than the ones after ~10 ms of back-to-back traffic); `value` itself is measured after --settle-launches + --warmup untimed launches
   sustained = None
   if E > 1 and not a.no_single:
     sdt2, skm2, _, _, _ = time_rollouts(torch, dist, env, act_sets, out, 40, 20, world, device)
     sustained = {'value': 40 * E * n * T * world / sdt2, 'unit': 'env-steps/s', 'kernel_ms_mean': skm2[0],
                  'frac_of_8TBs': n * (E * T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH) / (skm2[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 'note': 'the same launches after ~45 earlier ones back to back (20 more warm-up + 40 timed): the board\'s sustained power state'}
+                 'note': 'cross-check of `value`: 40 more of the same launches timed after 20 more untimed ones'}
 
   # BASELINE configs[2] in the same run (every rank takes part: same barrier / max-over-ranks timing; the CPU legs at N = 1 only)
   sawyer = {}
@@ -775,7 +889,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'tabletop_manipulation {a.reward}, {n} envs/GPU; bench step = 1 launch = {E} eval episodes (reset+{T} steps), own actions',
                    'envs_per_gpu': n, 'episodes_per_bench_step': E, 'episodes_in_flight': in_flight, 'env_instances_resident': n * in_flight,
-                   'strict': strict, 'launches': launches, 'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': E * n * T * world,
+                   'strict': strict, 'launches': launches, 'settle_launches': max(0, a.settle_launches), 'untimed_launches_before_the_timed_region': a.warmup + a.steps + a.warmup + max(0, a.settle_launches),
+                   'early_window': early['value'], 'global_envs': n * world, 'horizon': T, 'env_steps_per_bench_step': E * n * T * world,
                    'actions': f'{R} x [{E}, {T}, {n}, 3] f32 per GPU ({R * E * T * n * 12 / 1e6:.0f} MB): distinct per episode, launches read the {R} tensors round-robin',
                    'action_sets': R,
                    'next_rows': {k: (v or {}).get('value') for k, v in sawyer.items()},
@@ -786,6 +901,8 @@ def main():
                      'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT, 'episodes_per_launch': E, 'launches': launches,
                      'strict_frac': strict['one_episode_in_flight_frac']},
     }
+    res['early_window'] = early
+    res['reference_simulator'] = SIMULATORS
     if single is not None:
       res['single_episode_launch'] = single
     if sequential is not None:
@@ -821,7 +938,7 @@ def main():
         torch.cuda.empty_cache()
       res['sweep'] = sw
     if not a.no_cpu:
-      res['cpu_baseline'] = cpu_baseline(n, T, a.reward, a.cpu_seconds)
+      res['cpu_baseline'] = CPU_RESULTS.get('tabletop')
     else:
       res['cpu_baseline'] = None
     res.update(sawyer)            # "sawyer_door": {...}, "sawyer_peg": {...}: value, kernel_ms, issue_frac, roofline, cpu_baseline

@@ -255,8 +255,10 @@ def mesh_inertia(path, scale, mass):
 
 
 # ------------------------------------------------------------------ the compiler
-def compile_model(name):
-  path = os.path.join(REF_ENVS, MODELS[name])
+def compile_model(name, path=None):
+  """path: an MJCF file to read instead of the reference's (tests/test_pin_tool.py feeds the text tools/pin_with_simulator.py emits from this build's own
+  tables back through this compiler)"""
+  path = path or os.path.join(REF_ENVS, MODELS[name])
   root = load(path)
   dfl = Defaults(root)
   comp = {}
