@@ -46,15 +46,17 @@ namespace {
 // Phase timing (tools/prof_physics.py builds this file with -DEARL_PHYS_PROF into a separate library); not in the product build
 #ifdef EARL_PHYS_PROF
 __device__ unsigned long long g_phys_prof[32];
+__device__ int g_prof_sel[2];                            // the wave whose phases are clocked: (workgroup, first thread of the wave); earl_debug_set_prof_wave*
+#define PROF_ME (blockIdx.x == g_prof_sel[0] && threadIdx.x == g_prof_sel[1])
 #define PSTAMP(i)                                                                          \
   do {                                                                                     \
     const unsigned long long t_ = __builtin_readcyclecounter();                            \
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_phys_prof[i] += t_ - p_last;                \
+    if (PROF_ME) g_phys_prof[i] += t_ - p_last;                                            \
     p_last = t_;                                                                           \
   } while (0)
 #define PSTART() unsigned long long p_last = __builtin_readcyclecounter()
 __device__ unsigned long long g_wave_cycles[4096];      // duration of every wave of the last rollout launch (load balance)
-#define PCOUNT(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phys_prof[i] += (v); } while (0)
+#define PCOUNT(i, v) do { if (PROF_ME) g_phys_prof[i] += (v); } while (0)
 #define PCOUNT_ALL(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_phys_prof[i], (unsigned long long)(v)); } while (0)   // every wave
 #define RSTAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); PCOUNT(i, t_ - r_last); r_last = t_; } while (0)
 #define RSTART() unsigned long long r_last = __builtin_readcyclecounter()
@@ -427,6 +429,9 @@ __device__ __forceinline__ void chol_coop(SymLds<NV>& H, const double (&dl)[NV],
 }
 #ifndef EARL_KITCHEN_DENSE
 #define EARL_KITCHEN_DENSE 0
+#endif
+#if EARL_KITCHEN_DENSE
+#error "EARL_KITCHEN_DENSE: since round 4 the nv = 23 Hessian is stored by its structure only (arm block, fixture rows against the arm, fixture diagonal / pairs); the dense path would read entries nobody writes"
 #endif
 #ifndef EARL_MT_LOOP_SOLVER
 #define EARL_MT_LOOP_SOLVER 0       // nv = 22: the looping in-LDS factorisation / substitution instead of the unrolled ones (measurement switch: 70 k against ~10 k cycles per solve)
@@ -1463,24 +1468,38 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fence();
     KSTAMP(16);
     if constexpr (Lim<NV>::EXTRAS) {
-      // column l of the iteration's Hessian, built in place in LDS: the stored equality part, then the active contact edges
-      double rr = rw;
-      if (isl) {
+      // The iteration's Hessian = the stored equality part + the active contact edges, by the model's structure (checked by the host side): a contact joins arm
+      // links (dofs < NA) and at most ONE fixture (a single-dof tree), so its J' W J has entries in the arm's block, in that fixture's row against the arm
+      // and on that fixture's diagonal -- nothing between two fixtures.  Every lane accumulates, in registers, v = W J_l for its own dof and the NA arm rows
+      // J_i . v: an arm lane keeps rows i >= l of its column, a fixture lane f gets its row (f, i) against the arm (its own J entry is zero unless the
+      // contact touches it) and its diagonal.  (The earlier form walked all NV rows of the column per contact with a read-modify-write in LDS each:
+      // 20 k cycles per timestep in the wave whose fingers are on a fixture -- the wave the launch waits for.)
+      double rr = rw, acc[NA], accd = 0.0;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) if (i >= l) s.con.Hc.lo(i, l) = s.hwst.Hw.lo(i, l);
-      }
+      for (int i = 0; i < NA; ++i) acc[i] = 0.0;
       for (int c = 0; c < ncmax; ++c) {
         const double* w = s.con.cw[c];
         const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
         const bool cv = c < nct;
         const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
         rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
-        if (isl) {
 #pragma unroll
-          for (int i = 0; i < NV; ++i) if (i >= l) s.con.Hc.lo(i, l) += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
-        }
+        for (int i = 0; i < NA; ++i) acc[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+        accd += cv ? j0 * v0 + j1 * v1 + j2 * v2 : 0.0;
       }
-      if (isl) s.con.rc[l] = rr;
+      if (isl) {
+        if (l < NA) {
+#pragma unroll
+          for (int i = 0; i < NA; ++i) if (i >= l) s.con.Hc.lo(i, l) = s.hwst.Hw.lo(i, l) + acc[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < NA; ++i) s.con.Hc.lo(l, i) = acc[i];                 // (the equality part has no entries between the arm and a fixture)
+          s.con.Hc.lo(l, l) = s.hwst.Hw.lo(l, l) + accd;
+          const int pl = m.pair[l];
+          if (pl > l) s.con.Hc.lo(pl, l) = s.hwst.Hw.lo(pl, l);
+        }
+        s.con.rc[l] = rr;
+      }
     } else if constexpr (Lim<NV>::CONNECT) {
       // column l of the iteration's Hessian: the stored equality part + the active contact edges, summed in registers, stored once (lower part)
       // Rows touched by a contact: the root body's six (accumulated in registers) and the at most two dofs of the sphere's own chain (s.xt.crow, updated in
@@ -1628,8 +1647,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         fence();
 #pragma unroll
         for (int i = 0; i < NA; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
-        chol_coop_lead<NV, NA>(s.con.Hc, s.con.dl, l, isl);
-        solve_lds_lead<NV, NA>(s.con.Hc, a);
+        // (the Schur complement is factorised and solved in registers, redundantly per lane, like the arm's block without contacts: the lane-cooperative
+        // in-LDS form -- chol_coop_lead + solve_lds_lead, nine plus eighteen dependent LDS round trips -- was a third of this path)
+        solve_lead_regs<NV, NA>(s.con.Hc, [&](int i) { return s.con.dl[i]; }, a);
         if (isl && l >= NA) {                             // t_f = B_f . x_arm
           double t = 0;
 #pragma unroll
@@ -2458,6 +2478,9 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
   const Q4 mq = ldq(cfg.mocap_quat_dev);
   int steps = a.st.steps_since_reset[env];
   const int kk = sub < 9 ? sub : 8;                     // this lane's action component
+#ifdef EARL_PHYS_PROF
+  const unsigned long long wave_t0 = __builtin_readcyclecounter();
+#endif
   for (int t = 0; t < a.T; ++t) {
     const size_t row = (size_t)t * n + env;
     // ---- KitchenV0.step up to do_simulation (kitchen_action_kernel): mocap target, the nine position targets
@@ -2560,6 +2583,9 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");    // the next step reads last_qp_robot (and, after a failure, the state rows) back through global memory
     fence();
   }
+#ifdef EARL_PHYS_PROF
+  if (lane == 0 && blockIdx.x * WPB + wave < 4096) g_wave_cycles[blockIdx.x * WPB + wave] = __builtin_readcyclecounter() - wave_t0;
+#endif
   if (sub == 0 && live) a.st.steps_since_reset[env] = steps;
 }
 #endif
@@ -3029,6 +3055,10 @@ int earl_debug_set_physics_lanes(int lanes_per_env) {
 }
 
 #ifdef EARL_PHYS_PROF
+int earl_debug_set_prof_wave(int block, int thread) {     // the wave whose phases the profiling build clocks (default: workgroup 0, thread 0)
+  const int v[2] = {block, thread};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_sel), v, sizeof(v)) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
 int earl_debug_read_wave_cycles(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_cycles), sizeof(unsigned long long) * 4096) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
 }
