@@ -94,14 +94,6 @@ __device__ __forceinline__ double imp_p2(const double* solimp, double r) {
   const double y = (power == 1 || d0 == dw) ? x : y2;
   return d0 + y * (dw - d0);
 }
-// 1 / sqrt(x): hardware seed (2^-26 or better) + two Newton steps
-__device__ __forceinline__ double rsq2(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  return y;
-}
-
 // chol_regs of physics.hip (dense, diagonal left inverted) with the two-step reciprocal root
 template <int N>
 __device__ __forceinline__ void chol_small(double (&L)[N * (N + 1) / 2]) {

@@ -136,6 +136,16 @@ __device__ __forceinline__ double rsq_nr(double x) {
   return y;
 }
 
+// the same with TWO Newton steps: the hardware seed is good to 2^-26 or better, so two steps already reach double precision (~1 ulp); used by the
+// factorisations of the bigger models (nv > 10), where fifteen to thirty of these chains stand in a row on the timestep's critical path.  (The
+// door model keeps rsq_nr: its two builds are pinned bit for bit against round 2's outputs.)
+__device__ __forceinline__ double rsq2(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
 // sin / cos for moderate arguments (|x| < ~1e3; joint half-angles are < 3): Cody-Waite reduction by pi/2 and the usual
 // minimax kernels on [-pi/4, pi/4] (the coefficient sets are the classic fdlibm ones), quadrant fix-up by selects
 __device__ __forceinline__ void sincos_mod(double x, double& sn, double& cs) {
@@ -268,7 +278,57 @@ template <int NV> struct Lim {
   static constexpr bool CONNECT = NV == 22;                 // connect constraints (earl_link_model24.n_con) and the external-force vector s.xt.ext
   static constexpr bool DAMPED = NV != 22;                  // joint damping (K10's implicit step (M + dt B) a' = M a; without damping a' = a)
   static constexpr int LPE = NV > 16 ? 32 : 16;             // lanes per env instance (64 = one wavefront per env: measurement switch for nv <= 16)
+  // Models whose first tree is the ARM of these robots -- a serial chain of seven hinges (links 0-6) with the two finger slides (7, 8) on the hand -- and whose
+  // other links are a free body's chain of six (the peg: links 9-14) or single-link trees (the kitchen's fixtures); checked by the host side.  For them the
+  // world frames, velocities, bias accelerations and the two subtree sums (composite inertia, bias force) are SCANS along the chain, done in registers with
+  // DPP row shifts (the arm sits in lanes 0-8 of one 16-lane row) instead of masked sums over every link through LDS: K1-K7 were 20 k cycles per timestep.
+#ifndef EARL_NO_ARMSCAN
+#define EARL_NO_ARMSCAN 0
+#endif
+  static constexpr bool ARMSCAN = (NV == 15 || NV == 23) && !EARL_NO_ARMSCAN;
+  static constexpr int BODY0 = NV == 15 ? 9 : -100;         // first link of the free body's chain (its six links: three slides, the quaternion link, two rigid ones)
 };
+
+// DPP moves within a 16-lane row: lane l reads lane l - K (shr) / l + K (shl) of its row, 0 beyond the row
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ V3 dpp_row(const V3& v) { return {dpp_row<CTRL>(v.x), dpp_row<CTRL>(v.y), dpp_row<CTRL>(v.z)}; }
+template <int CTRL> __device__ __forceinline__ Q4 dpp_row(const Q4& q) { return {dpp_row<CTRL>(q.w), dpp_row<CTRL>(q.x), dpp_row<CTRL>(q.y), dpp_row<CTRL>(q.z)}; }
+constexpr int DPP_SHR(int k) { return 0x110 + k; }
+constexpr int DPP_SHL(int k) { return 0x100 + k; }
+// chain membership of a lane: the arm's serial part [0, 6], the free body's chain [BODY0, BODY0 + 5]
+template <int NV> __device__ __forceinline__ bool scan_from_below(const int sub, const int k) {     // lane sub - k is sub's ancestor at distance k
+  return (sub <= 6 && sub >= k) || (Lim<NV>::BODY0 >= 0 && sub >= Lim<NV>::BODY0 + k && sub <= Lim<NV>::BODY0 + 5);
+}
+template <int NV> __device__ __forceinline__ bool scan_from_above(const int sub, const int k) {     // lane sub + k is sub's descendant at distance k
+  return (sub + k <= 6) || (Lim<NV>::BODY0 >= 0 && sub >= Lim<NV>::BODY0 && sub + k <= Lim<NV>::BODY0 + 5);
+}
+// inclusive prefix sums along the chains (ancestors incl. the link itself), then the fingers take the hand's
+template <int NV>
+__device__ __forceinline__ void scan_anc(V3& a, V3& b, const int sub) {
+#define EARL_SCAN_ROUND(K) { const V3 as_ = dpp_row<DPP_SHR(K)>(a), bs_ = dpp_row<DPP_SHR(K)>(b); const bool on = scan_from_below<NV>(sub, K); a = selv(on, add(a, as_), a); b = selv(on, add(b, bs_), b); }
+  EARL_SCAN_ROUND(1) EARL_SCAN_ROUND(2) EARL_SCAN_ROUND(4)
+#undef EARL_SCAN_ROUND
+  const V3 a1 = dpp_row<DPP_SHR(1)>(a), a2 = dpp_row<DPP_SHR(2)>(a), b1 = dpp_row<DPP_SHR(1)>(b), b2 = dpp_row<DPP_SHR(2)>(b);
+  a = selv(sub == 7, add(a1, a), selv(sub == 8, add(a2, a), a));
+  b = selv(sub == 7, add(b1, b), selv(sub == 8, add(b2, b), b));
+}
+// inclusive suffix sums (the link's subtree): the fingers fold into the hand first
+template <int NV, int N>
+__device__ __forceinline__ void scan_desc(double (&x)[N], const int sub) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    const double f1 = dpp_row<DPP_SHL(1)>(x[e]), f2 = dpp_row<DPP_SHL(2)>(x[e]);
+    x[e] = sub == 6 ? x[e] + f1 + f2 : x[e];
+  }
+#define EARL_SCAN_ROUND(K) { _Pragma("unroll") for (int e = 0; e < N; ++e) { const double xs_ = dpp_row<DPP_SHL(K)>(x[e]); x[e] = scan_from_above<NV>(sub, K) ? x[e] + xs_ : x[e]; } }
+  EARL_SCAN_ROUND(1) EARL_SCAN_ROUND(2) EARL_SCAN_ROUND(4)
+#undef EARL_SCAN_ROUND
+}
 
 // the equality part of the Hessian (M + weld / coupling / drag rows), kept in LDS for the big model: its 23-entry columns would otherwise sit in
 // registers across the whole active-set iteration (the nv = 23 kernel spilled 1.6 KB per lane into scratch)
@@ -352,7 +412,7 @@ struct Shared : SharedData<NV> {
 // are then never read or written (their registers are dead on that path).
 // (every multiply-subtract is an explicit fma in the same order as chol_coop / solve_lds below: the register-resident and the in-LDS
 // factorisation then produce the same bits, which is what lets earl_sawyer_rollout switch between its two door builds by batch size)
-template <int NV, int NA>
+template <int NV, int NA, bool FAST = false>
 __device__ __forceinline__ void chol_regs(double (&L)[NV * (NV + 1) / 2]) {
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -360,7 +420,7 @@ __device__ __forceinline__ void chol_regs(double (&L)[NV * (NV + 1) / 2]) {
     double d = L[j * (j + 1) / 2 + j];
 #pragma unroll
     for (int p = p0; p < j; ++p) d = fma(-L[j * (j + 1) / 2 + p], L[j * (j + 1) / 2 + p], d);
-    const double inv = rsq_nr(d);
+    const double inv = FAST ? rsq2(d) : rsq_nr(d);       // (FAST: the peg and kitchen models; the door's two builds stay pinned bit for bit)
     L[j * (j + 1) / 2 + j] = inv;
 #pragma unroll
     for (int i = j + 1; i < (j < NA ? NA : NV); ++i) {
@@ -595,7 +655,7 @@ __device__ __forceinline__ void solve_lead_regs(const SymLds<NV>& H, D diag, dou
     L[i * (i + 1) / 2 + i] = H.lo(i, i) + diag(i);
     y[i] = x[i];
   }
-  chol_regs<N, N>(L);
+  chol_regs<N, N, true>(L);
   solve_regs<N, N>(L, y);
 #pragma unroll
   for (int i = 0; i < N; ++i) x[i] = y[i];
@@ -616,6 +676,78 @@ __device__ __forceinline__ void solve_lds(const SymLds<NV>& H, double (&x)[NV]) 
     for (int p = i + 1; p < NV; ++p) s = fma(-H.lo(p, i), x[p], s);
     x[i] = s * H.lo(i, i);
   }
+}
+
+// Two-tree model (arm [0, NA) + free object [NA, NV)) in the timesteps in which a contact JOINS the trees: H = [A B'; B P] is dense.  Instead of the shared
+// in-LDS factorisation of all NV columns (chol_coop + solve_lds: one LDS round trip per column and per substitution step -- 52 k cycles per timestep in the
+// waves whose gripper holds the peg, the waves the launch waits for), eliminate the object's block first, everything in registers and redundantly per lane
+// like the contact-free path: P = Lp Lp', W = B' Lp^-T, S = A - W W' = La La', x_A = S^-1 (b_A - W Lp^-1 b_P), x_P = Lp^-T (Lp^-1 b_P - W' x_A).
+// No exchange between lanes at all: every lane reads the same Hessian from LDS and ends up with the whole solution.
+template <int NV, int NA, typename D>
+__device__ __forceinline__ void solve_schur_regs(const SymLds<NV>& H, D diag, double (&x)[NV]) {
+  constexpr int NP = NV - NA;
+  double Lp[NP * (NP + 1) / 2], yp[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+#pragma unroll
+    for (int j = 0; j < i; ++j) Lp[i * (i + 1) / 2 + j] = H.lo(NA + i, NA + j);
+    Lp[i * (i + 1) / 2 + i] = H.lo(NA + i, NA + i) + diag(NA + i);
+    yp[i] = x[NA + i];
+  }
+  chol_regs<NP, NP, true>(Lp);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {                        // yp = Lp^-1 b_P
+    double t = yp[i];
+#pragma unroll
+    for (int p = 0; p < i; ++p) t = fma(-Lp[i * (i + 1) / 2 + p], yp[p], t);
+    yp[i] = t * Lp[i * (i + 1) / 2 + i];
+  }
+  double W[NA][NP];                                     // W[i][j] = (B[j][i] - sum_{p < j} W[i][p] Lp[j][p]) / Lp[j][j]
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      double t = H.lo(NA + j, i);
+#pragma unroll
+      for (int p = 0; p < j; ++p) t = fma(-W[i][p], Lp[j * (j + 1) / 2 + p], t);
+      W[i][j] = t * Lp[j * (j + 1) / 2 + j];
+    }
+  }
+  double La[NA * (NA + 1) / 2], xa[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int c = 0; c <= i; ++c) {
+      double t = H.lo(i, c) + (c == i ? diag(i) : 0.0);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) t = fma(-W[i][j], W[c][j], t);
+      La[i * (i + 1) / 2 + c] = t;
+    }
+    double t = x[i];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) t = fma(-W[i][j], yp[j], t);
+    xa[i] = t;
+  }
+  chol_regs<NA, NA, true>(La);
+  solve_regs<NA, NA>(La, xa);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {                        // z = yp - W' x_A
+    double t = yp[j];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) t = fma(-W[i][j], xa[i], t);
+    yp[j] = t;
+  }
+#pragma unroll
+  for (int j = NP - 1; j >= 0; --j) {                   // x_P = Lp^-T z
+    double t = yp[j];
+#pragma unroll
+    for (int p = j + 1; p < NP; ++p) t = fma(-Lp[p * (p + 1) / 2 + j], yp[p], t);
+    yp[j] = t * Lp[j * (j + 1) / 2 + j];
+  }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) x[i] = xa[i];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) x[NA + j] = yp[j];
 }
 
 // block table of the collision model (bounding tests), staged once per workgroup
@@ -720,7 +852,33 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     P = add(add(ld3(m.tpos[l]), vsub(mulv(Rt, jp), mulv(Rl, jp))), scl(mulv(Rt, ax), jt == 1 ? q : 0.0));
   }
   // ------------------------------------------------------------------ K2: world frames by ancestor doubling
-  {
+  if constexpr (Lim<NV>::ARMSCAN) {
+    // inclusive prefix PRODUCT of the local transforms along the chains (X_l <- X_{l-k} o X_l, k = 1, 2, 4), in registers; then the fingers on the hand
+    auto compose = [](const Q4& qa, const V3& pa, Q4& q, V3& p) {
+      double Ra[3][3];
+      qmat(qa, Ra);
+      p = add(pa, mulv(Ra, p));
+      q = qmul(qa, q);
+    };
+#define EARL_SCAN_ROUND(K) { const Q4 qs_ = dpp_row<DPP_SHR(K)>(Q); const V3 ps_ = dpp_row<DPP_SHR(K)>(P); Q4 qn_ = Q; V3 pn_ = P; compose(qs_, ps_, qn_, pn_); \
+                             const bool on = scan_from_below<NV>(sub, K); Q = selq(on, qn_, Q); P = selv(on, pn_, P); }
+    EARL_SCAN_ROUND(1) EARL_SCAN_ROUND(2) EARL_SCAN_ROUND(4)
+#undef EARL_SCAN_ROUND
+    {
+      const Q4 q1 = dpp_row<DPP_SHR(1)>(Q), q2 = dpp_row<DPP_SHR(2)>(Q);
+      const V3 p1 = dpp_row<DPP_SHR(1)>(P), p2 = dpp_row<DPP_SHR(2)>(P);
+      Q4 qn_ = Q; V3 pn_ = P;
+      compose(selq(sub == 7, q1, q2), selv(sub == 7, p1, p2), qn_, pn_);
+      const bool on = sub == 7 || sub == 8;
+      Q = selq(on, qn_, Q); P = selv(on, pn_, P);
+    }
+    if (isl) {
+      double* oq = s.Xq[l];
+      double* op = s.Xp[l];
+      oq[0] = Q.w; oq[1] = Q.x; oq[2] = Q.y; oq[3] = Q.z; op[0] = P.x; op[1] = P.y; op[2] = P.z;
+    }
+    fence();
+  } else {
     const int rounds = m.n_jump;
     int buf = rounds & 1;                           // so that the last round lands in Xq / Xp
     if (isl) {
@@ -831,6 +989,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   PSTAMP(0);
   // ------------------------------------------------------------------ K3: motion subspace + compact spatial inertia
   V3 Sw, Sv;                                         // this lane's column of S
+  double I10r[10];                                   // this lane's link: compact spatial inertia about the world origin
   {
     double R[3][3];
     qmat(Q, R);
@@ -858,28 +1017,43 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
       for (int cc = r; cc < 3; ++cc) W[r][cc] = T[r][0] * R[cc][0] + T[r][1] * R[cc][1] + T[r][2] * R[cc][2];
     const double c2 = dot(c, c);
-    if (isl) {
-      double* o = s.dyn.S[l];
-      o[0] = Sw.x; o[1] = Sw.y; o[2] = Sw.z; o[3] = Sv.x; o[4] = Sv.y; o[5] = Sv.z;
-      double* i10 = s.dyn.I10[l];
-      i10[0] = mass;
-      i10[1] = mass * c.x; i10[2] = mass * c.y; i10[3] = mass * c.z;
-      i10[4] = W[0][0] + mass * (c2 - c.x * c.x);
-      i10[5] = W[1][1] + mass * (c2 - c.y * c.y);
-      i10[6] = W[2][2] + mass * (c2 - c.z * c.z);
-      i10[7] = W[0][1] - mass * c.x * c.y;
-      i10[8] = W[0][2] - mass * c.x * c.z;
-      i10[9] = W[1][2] - mass * c.y * c.z;
+    I10r[0] = mass;
+    I10r[1] = mass * c.x; I10r[2] = mass * c.y; I10r[3] = mass * c.z;
+    I10r[4] = W[0][0] + mass * (c2 - c.x * c.x);
+    I10r[5] = W[1][1] + mass * (c2 - c.y * c.y);
+    I10r[6] = W[2][2] + mass * (c2 - c.z * c.z);
+    I10r[7] = W[0][1] - mass * c.x * c.y;
+    I10r[8] = W[0][2] - mass * c.x * c.z;
+    I10r[9] = W[1][2] - mass * c.y * c.z;
+    if constexpr (!Lim<NV>::ARMSCAN) {                   // (the scans below keep both in registers)
+      if (isl) {
+        double* o = s.dyn.S[l];
+        o[0] = Sw.x; o[1] = Sw.y; o[2] = Sw.z; o[3] = Sv.x; o[4] = Sv.y; o[5] = Sv.z;
+        double* i10 = s.dyn.I10[l];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) i10[e] = I10r[e];
+      }
     }
   }
-  fence();
+  if constexpr (!Lim<NV>::ARMSCAN) fence();
   PSTAMP(1);
   const uint32_t amask = m.anc_mask[l], dmask = m.desc_mask[l];
   // the links this lane's masked sums visit: [tbase, tend), KT of them at most (all of [0, NT) unless the model has two multi-link trees)
   constexpr int TS = Lim<NV>::TS, KT = TS < NT ? (TS > NT - TS ? TS : NT - TS) : NT;
   const int tbase = (TS < NT && l >= TS) ? TS : 0, tend = (TS < NT && l < TS) ? TS : NT;
   // ------------------------------------------------------------------ K4: composite inertia = masked subtree sum; FS = Ic S
-  {
+  if constexpr (Lim<NV>::ARMSCAN) {
+    double acc[10];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) acc[e] = I10r[e];
+    scan_desc<NV, 10>(acc, sub);                         // suffix sums along the chains, in registers
+    V3 n, f;
+    iapply(acc, Sw, Sv, n, f);
+    if (isl) {
+      double* o = s.dyn.crb.FS[l];
+      o[0] = n.x; o[1] = n.y; o[2] = n.z; o[3] = f.x; o[4] = f.y; o[5] = f.z;
+    }
+  } else {
     double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -923,7 +1097,43 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   PSTAMP(4);
   // ------------------------------------------------------------------ K6: bias forces (RNE by masked sums)
   double tau_l;                                        // this lane's applied + passive - bias force
-  {
+  if constexpr (Lim<NV>::ARMSCAN) {
+    // velocities V_l = sum over the ancestors of S_a qd_a, bias accelerations A_l = -g + sum of crossm(V) S_a qd_a, and the subtree sums of the bias forces:
+    // prefix / suffix scans along the chains in registers (no LDS, no fence)
+    const double qdl = s.qv[l];
+    V3 w = scl(Sw, isl ? qdl : 0.0), v = scl(Sv, isl ? qdl : 0.0);
+    scan_anc<NV>(w, v, sub);
+    // d/dt of the axis uses the link's own velocity (the own term cancels); the three rotation axes of a free body use the velocity before any of them
+    // (mj_comVel): that of its third slide = the translation velocity (world axes, checked by the host side)
+    V3 wc = w, vc = v;
+    if (m.ball_dof >= 0) {
+      const int bd = m.ball_dof;
+      const V3 vt{s.qv[bd - 3], s.qv[bd - 2], s.qv[bd - 1]};
+      const bool rot = l >= bd && l < bd + 3;
+      wc = selv(rot, V3{0, 0, 0}, wc);
+      vc = selv(rot, vt, vc);
+    }
+    V3 cw = scl(cross(wc, Sw), isl ? qdl : 0.0), cv = scl(add(cross(vc, Sw), cross(wc, Sv)), isl ? qdl : 0.0);
+    scan_anc<NV>(cw, cv, sub);
+    const V3 aw = cw, av = add(cv, V3{-m.gravity[0], -m.gravity[1], -m.gravity[2]});
+    V3 n1, f1, n2, f2;
+    iapply(I10r, aw, av, n1, f1);
+    iapply(I10r, w, v, n2, f2);
+    const V3 n = add(n1, add(cross(w, n2), cross(v, f2)));
+    const V3 f = add(f1, cross(w, f2));
+    double nf[6] = {n.x, n.y, n.z, f.x, f.y, f.z};
+    scan_desc<NV, 6>(nf, sub);
+    double t = -m.damping[l] * qdl - (Sw.x * nf[0] + Sw.y * nf[1] + Sw.z * nf[2] + Sv.x * nf[3] + Sv.y * nf[4] + Sv.z * nf[5]);
+    if constexpr (Lim<NV>::EXTRAS) t -= m.stiffness[l] * (s.qp[l] - m.springref[l]);
+    for (int ac = 0; ac < m.n_act; ++ac)
+      if (m.act_joint[ac] == l) {
+        const double c = fmin(fmax(ctrl[ac], m.act_ctrlrange[ac][0]), m.act_ctrlrange[ac][1]);
+        double frc = m.act_kp[ac] * (c - s.qp[l]);
+        if constexpr (Lim<NV>::EXTRAS) frc = fmin(fmax(frc, m.act_forcerange[ac][0]), m.act_forcerange[ac][1]);
+        t += frc;
+      }
+    tau_l = t;
+  } else {
     V3 w{0, 0, 0}, v{0, 0, 0};
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -1477,15 +1687,20 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       double rr = rw, acc[NA], accd = 0.0;
 #pragma unroll
       for (int i = 0; i < NA; ++i) acc[i] = 0.0;
-      for (int c = 0; c < ncmax; ++c) {
-        const double* w = s.con.cw[c];
-        const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
-        const bool cv = c < nct;
-        const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
-        rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
+      static_assert(MC % 2 == 0, "contact slots in pairs");
+      for (int c2 = 0; c2 < ncmax; c2 += 2) {               // two contacts per iteration, their loads side by side (a slot beyond the count is selected away, not multiplied)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) acc[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
-        accd += cv ? j0 * v0 + j1 * v1 + j2 * v2 : 0.0;
+        for (int u = 0; u < 2; ++u) {
+          const int c = c2 + u;
+          const double* w = s.con.cw[c];
+          const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
+          const bool cv = c < nct;
+          const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+          rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
+#pragma unroll
+          for (int i = 0; i < NA; ++i) acc[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+          accd += cv ? j0 * v0 + j1 * v1 + j2 * v2 : 0.0;
+        }
       }
       if (isl) {
         if (l < NA) {
@@ -1716,14 +1931,18 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       solve_lds<NV>(s.con.Hc, a);
     } else if constexpr (NA == NV) {                   // small model: dense, in registers
       load_tri<NV, NV>(L, s.con.Hc, [&](int i) { return s.con.dl[i]; });
-      chol_regs<NV, NV>(L);
+      chol_regs<NV, NV, (NV > 10)>(L);
       solve_regs<NV, NV>(L, a);
-    } else if (coupled) {                              // a contact joins the arm and the object (uniform over the wave): shared dense factorisation in LDS
+    } else if (coupled) {                              // a contact joins the arm and the object (uniform over the wave): the object's block eliminated first
+#ifdef EARL_PEG_COUPLED_LDS                            // (measurement switch: round 3's shared dense factorisation in LDS)
       chol_coop<NV>(s.con.Hc, s.con.dl, l, isl);
       solve_lds<NV>(s.con.Hc, a);
+#else
+      solve_schur_regs<NV, NA>(s.con.Hc, [&](int i) { return s.con.dl[i]; }, a);
+#endif
     } else {
       load_tri<NV, NA>(L, s.con.Hc, [&](int i) { return s.con.dl[i]; });
-      chol_regs<NV, NA>(L);
+      chol_regs<NV, NA, (NV > 10)>(L);
       solve_regs<NV, NA>(L, a);
     }
     KSTAMP(18);
@@ -1845,7 +2064,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       solve_lds<NV>(s.M, a);
     } else {
       load_tri<NV, NA>(L, s.M, [&](int i) { return s.con.dl[i]; });           // the mass matrix is block diagonal: two trees
-      chol_regs<NV, NA>(L);
+      chol_regs<NV, NA, (NV > 10)>(L);
       solve_regs<NV, NA>(L, a);
     }
     }

@@ -175,6 +175,7 @@ def load_link_model(name):
       assert pair[j1] < 0 and pair[j2] < 0 and j1 >= 9 and j2 >= 9
       pair[j1], pair[j2] = j2, j1
     assert nv == 23 and all(int(d['parent'][l]) == (l - 1 if 0 < l < 7 else (6 if l in (7, 8) else -1)) for l in range(nv)), 'kitchen tree shape'
+    assert not np.any(d['jpos']), 'csrc/physics.hip Lim<23>::ARMSCAN: frames are composed as tpos / tquat o joint (no joint offsets)'
     _fill(s.pair, pair)
   else:
     assert not np.any(d.get('jnt_frictionloss', 0)) and not np.any(d.get('jnt_stiffness', 0)) and len(d.get('jeq_joint1', ())) == 0, \
@@ -186,6 +187,11 @@ def load_link_model(name):
       root = lambda l: l if par[l] < 0 else root(par[l])
       assert all(root(l) == 0 for l in range(9)) and all(root(l) == 9 for l in range(9, 15)), 'peg model: trees [0, 9) and [9, 15)'
       assert int(d['att_link'][int(d['weld_att'])]) < 9, 'peg model: the weld sits on the first tree'
+      # csrc/physics.hip Lim<15>::ARMSCAN: the scans along the chains assume the arm = seven hinges in series (links 0-6) + the two fingers on the hand, and
+      # the free body = links 9-14 in series: three slides along the world axes from the origin, the quaternion link, two rigid links; the mass on the last
+      assert par == [-1, 0, 1, 2, 3, 4, 5, 6, 6, -1, 9, 10, 11, 12, 13] and [int(x) for x in d['jtype']][9:] == [1, 1, 1, 2, 3, 3] and int(d['ball_dof']) == 12
+      assert np.array_equal(d['jaxis'][9:12], np.eye(3)) and not np.any(d['tpos'][9:]) and np.array_equal(d['tquat'][9:], np.tile([1.0, 0, 0, 0], (6, 1)))
+      assert not np.any(d['jpos']) and not np.any(d['mass'][9:14])
   return s, d
 
 

@@ -17,7 +17,7 @@ def build():
   subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-o', LIB] + srcs, check=True)
 
 
-def rollout_counters(n, T):
+def rollout_counters(n, T, sel=None):
   """event counters of wave 0 over a random-action rollout of the Sawyer door (or, with --peg, peg) env (profiling build of the whole library)"""
   import torch
   sys.path.insert(0, ROOT)
@@ -29,10 +29,13 @@ def rollout_counters(n, T):
   _abi.SIGNATURES['earl_debug_read_wave_cycles_w8' if w8 else 'earl_debug_read_wave_cycles'] = [C.c_void_p]
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
   from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
-  env = (SawyerPeg if '--peg' in sys.argv else SawyerDoor)(num_envs=n)
+  _abi.SIGNATURES['earl_debug_set_prof_wave'] = [C.c_int, C.c_int]
+  env = (SawyerPeg if '--peg' in sys.argv else SawyerDoor)(num_envs=n, seed=1234)
   lib = _abi.load()
   if w8:
     lib.earl_debug_set_door_variant(2)
+  elif sel is not None:
+    lib.earl_debug_set_prof_wave(sel // 4, (sel % 4) * 64)       # (four-wave workgroups: the peg build; the door's single-wave build has one wave per workgroup)
   read = getattr(lib, reader)
   out = (C.c_ulonglong * 32)()
   torch.manual_seed(0)
@@ -55,7 +58,7 @@ def rollout_counters(n, T):
   print(f'  wave durations, cycles per timestep: min {w.min():.0f}  p10 {np.percentile(w, 10):.0f}  median {np.median(w):.0f}  mean {w.mean():.0f}  p90 {np.percentile(w, 90):.0f}  '
         f'p99 {np.percentile(w, 99):.0f}  max {w.max():.0f}   (the launch lasts as long as its slowest wave)')
   ts = max(1, out[20])
-  print(f'rollout N={n} T={T}: timesteps of wave 0: {out[20]}; with a near block {out[21] / ts:.3f} (blocks per timestep {out[22] / ts:.2f}); '
+  print(f'rollout N={n} T={T}: timesteps of wave {sel or 0}: {out[20]}; with a near block {out[21] / ts:.3f} (blocks per timestep {out[22] / ts:.2f}); '
         f'with contacts {out[23] / ts:.3f} (max contacts per env, mean {out[24] / ts:.2f}); Newton iterations per timestep {out[25] / ts:.2f}')
   nc = out[26]
   print(f'  timesteps in which a contact joins the arm and the object (shared dense factorisation): {nc / ts:.3f}; active-set phase: {out[27] / max(1, nc):.0f} cycles in those, '
@@ -68,13 +71,19 @@ def rollout_counters(n, T):
         f'state store + bookkeeping {out[15] / es:.0f}')
   tot = sum(out[:12])
   print(f'  cycles per timestep {tot / ts:.0f}: ' + ', '.join(f'{NAMES[i].split()[0]} {out[i] / ts:.0f}' for i in range(12) if NAMES[i] != '-'))
+  return int(np.argmax(w))
 
 
 def main():
   if '--build' in sys.argv:
     return build()
   if '--rollout' in sys.argv:
-    return rollout_counters(8192 if ('--w8' in sys.argv or '--full' in sys.argv) else 1024, 200 if '--peg' in sys.argv else 300)
+    n, T = 8192 if ('--w8' in sys.argv or '--full' in sys.argv) else 1024, 200 if '--peg' in sys.argv else 300
+    slow = rollout_counters(n, T)
+    if '--slowest' in sys.argv and '--peg' in sys.argv:     # the same launch again, clocking the wave that took longest
+      print(f'--- slowest wave: #{slow}')
+      rollout_counters(n, T, sel=slow)
+    return
   import numpy as np
   import torch
   sys.path.insert(0, ROOT)
