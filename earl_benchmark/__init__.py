@@ -14,15 +14,18 @@ from earl_benchmark_amd import *  # noqa: F401,F403
 from earl_benchmark_amd import (EARLEnvs, UnpinnedDynamicsWarning, continuing_eval_config, deployment_eval_config, load_demo,  # noqa: F401
                                 __version__)
 
-# the reference's sub-packages by their own names: `from earl_benchmark.envs import tabletop_manipulation`, `earl_benchmark.wrappers`
-# (wrappers imports torch, so it is resolved on first use, not here: tables and demonstrations work on machines without a GPU stack)
-_ALIASES = {'wrappers': 'earl_benchmark_amd.wrappers', 'envs': 'earl_benchmark_amd.envs', 'tables': 'earl_benchmark_amd.tables',
-            'sharding': 'earl_benchmark_amd.sharding', 'glue': 'earl_benchmark_amd.glue'}
+# The reference's sub-packages are REAL packages here (earl_benchmark/envs/, earl_benchmark/wrappers/): `from earl_benchmark.envs import tabletop_manipulation`,
+# `from earl_benchmark.wrappers import persistent_state_wrapper` (reference earl_benchmark/__init__.py:7-8, :114-136) work as written.  (A module-level
+# __getattr__ is not consulted by the import system for submodules: ADVICE r03.)  They import torch, so they are resolved on first use, not here: tables
+# and demonstrations work on machines without a GPU stack.
+_ALIASES = {'tables': 'earl_benchmark_amd.tables', 'sharding': 'earl_benchmark_amd.sharding', 'glue': 'earl_benchmark_amd.glue'}
 
 
 def __getattr__(name):
+  import importlib
+  if name in ('envs', 'wrappers'):
+    return importlib.import_module(__name__ + '.' + name)
   if name in _ALIASES:
-    import importlib
     mod = importlib.import_module(_ALIASES[name])
     _sys.modules[__name__ + '.' + name] = mod
     return mod

@@ -136,8 +136,11 @@ class Minitaur:
   def _actions(self, a, lead):
     a = torch.as_tensor(np.asarray(a, dtype=np.float32) if not torch.is_tensor(a) else a, device=self.device).to(torch.float32)
     a = a.reshape(*lead, self.num_envs, ACT_DIM).contiguous()
-    if bool(((a < -ACTION_BOUND - ACTION_EPS) | (a > ACTION_BOUND + ACTION_EPS)).any()):      # minitaur_gym_env.py:276-281
-      bad = int(torch.nonzero(((a < -ACTION_BOUND - ACTION_EPS) | (a > ACTION_BOUND + ACTION_EPS)).reshape(-1, ACT_DIM).any(0))[0])
+    # minitaur_gym_env.py:276-281: `if not (-bound - eps <= a_i <= bound + eps): raise` -- the NEGATED in-range test, so a NaN raises too (the
+    # mirrored out-of-range test let NaN through; the motor model then carried it into the state and the env sat in its failure guard)
+    out_of_bounds = ~((a >= -ACTION_BOUND - ACTION_EPS) & (a <= ACTION_BOUND + ACTION_EPS))
+    if bool(out_of_bounds.any()):
+      bad = int(torch.nonzero(out_of_bounds.reshape(-1, ACT_DIM).any(0))[0])
       raise ValueError('{}th action out of bounds.'.format(bad))
     return a
 

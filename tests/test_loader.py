@@ -85,3 +85,33 @@ def test_reference_import_name_works_unchanged():
   assert set(fwd) == set(rev) == {'observations', 'actions', 'rewards', 'terminals', 'next_observations', 'infos'}
   assert earl_benchmark.wrappers.PersistentStateWrapper is earl_benchmark_amd.wrappers.PersistentStateWrapper
   assert earl_benchmark.tables is earl_benchmark_amd.tables
+
+
+def test_the_references_literal_import_statements_resolve():
+  """reference earl_benchmark/__init__.py:7-8 and :114-136 import sub-MODULES by name; they are real packages of the shim (a module-level
+  __getattr__ is not consulted for `import a.b` / `from a.b import c`)"""
+  pytest = __import__('pytest')
+  pytest.importorskip('torch')
+  from earl_benchmark.wrappers import persistent_state_wrapper
+  from earl_benchmark.wrappers import lifelong_wrapper
+  from earl_benchmark.envs import tabletop_manipulation
+  from earl_benchmark.envs import sawyer_door
+  from earl_benchmark.envs import sawyer_peg
+  from earl_benchmark.envs import kitchen
+  from earl_benchmark.envs import minitaur_gym_env
+  import earl_benchmark.wrappers
+  import earl_benchmark_amd
+  assert persistent_state_wrapper.PersistentStateWrapper is earl_benchmark_amd.wrappers.PersistentStateWrapper
+  assert lifelong_wrapper.LifelongWrapper is earl_benchmark_amd.wrappers.LifelongWrapper
+  assert earl_benchmark.wrappers.PersistentStateWrapper is earl_benchmark_amd.wrappers.PersistentStateWrapper
+  assert tabletop_manipulation.TabletopManipulation.__module__ == 'earl_benchmark_amd.envs.tabletop'
+  assert sawyer_door.SawyerDoorV2.__name__ == 'SawyerDoor' and sawyer_peg.SawyerPegV2.__name__ == 'SawyerPeg'
+  assert kitchen.Kitchen.__module__ == 'earl_benchmark_amd.envs.kitchen' and minitaur_gym_env.GoalConditionedMinitaurBulletEnv.__name__ == 'Minitaur'
+  # the module-level tables the reference's loader reads (`sawyer_door.initial_states`, ...: reference earl_benchmark/__init__.py:194-237)
+  import numpy as np
+  for mod, name in ((tabletop_manipulation, 'tabletop_manipulation'), (sawyer_door, 'sawyer_door'), (sawyer_peg, 'sawyer_peg')):
+    loader = earl_benchmark_amd.EARLEnvs(name, reward_type='sparse')
+    np.testing.assert_array_equal(mod.initial_states, loader.get_initial_states())
+    np.testing.assert_array_equal(mod.goal_states, loader.get_goal_states())
+  np.testing.assert_array_equal(kitchen.goal_states, earl_benchmark_amd.EARLEnvs('kitchen', reward_type='dense').get_goal_states())
+  assert set(kitchen.initial_states) >= {'microwave', 'light_switch', 'slide_cabinet', 'hinge_cabinet', 'all_pairs'}

@@ -114,6 +114,10 @@ def test_loader_wrappers_goal_switch_and_action_bounds(torch):
   assert o.shape == (n, 32) and o.dtype == torch.float64
   with pytest.raises(ValueError, match='out of bounds'):
     ev.step(torch.full((n, 8), 1.5))
+  nan_action = torch.zeros(n, 8)
+  nan_action[3, 5] = float('nan')                                              # minitaur_gym_env.py:279: `not (lo <= x <= hi)` is True for NaN
+  with pytest.raises(ValueError, match='5th action out of bounds'):
+    ev.step(nan_action)
   for t in range(4):
     o, r, done, info = ev.step(torch.zeros(n, 8))
   assert bool(done.all()) and int(ev.num_interventions[0]) == 1 and ev.total_steps == 4
