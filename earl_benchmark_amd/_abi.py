@@ -63,9 +63,11 @@ class SawyerState(C.Structure):
 
 
 class SawyerOut(C.Structure):
-  _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p), ('status', C.c_void_p)]
+  _fields_ = [('obs', C.c_void_p), ('reward', C.c_void_p), ('done', C.c_void_p), ('success', C.c_void_p), ('status', C.c_void_p), ('info', C.c_void_p)]
 
 
+SAWYER_INFO = 8       # EARL_SAWYER_INFO; slots EARL_INFO_* (include/earl_physics.h)
+SAWYER_INFO_KEYS = ('success', 'near_object', 'grasp_success', 'grasp_reward', 'in_place_reward', 'obj_to_target', 'unscaled_reward')
 STEP_DIVERGED = 1     # EARL_STEP_DIVERGED (include/earl_physics.h)
 
 
@@ -150,6 +152,7 @@ SIGNATURES = {
     'earl_sawyer_reset': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState)] + [C.c_void_p] * 5,
     'earl_sawyer_observe': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_void_p],
     'earl_sawyer_door_reward': [_P(SawyerCfg), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    'earl_sawyer_door_info': [_P(SawyerCfg), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_version': [],
     'earl_last_error': [],
     'earl_device_count': [],

@@ -2236,19 +2236,29 @@ __device__ __forceinline__ double tolerance_gaussian(double x, double hi, double
 }
 
 // reward + success of one observation row (sawyer_door.py:141-177)
-__device__ __forceinline__ void door_reward(const earl_sawyer_cfg& cfg, const V3 tcp, const V3 obj, const V3 target, double& r, bool& ok) {
+__device__ __forceinline__ void door_reward(const earl_sawyer_cfg& cfg, const V3 tcp, const V3 obj, const V3 target, double& r, bool& ok, double* info = nullptr) {
 #pragma clang fp contract(off)
   const V3 d = vsub(obj, target);
   const double obj_to_target = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);     // np.linalg.norm in f64
   ok = obj_to_target <= cfg.success_radius;
   r = ok ? 1.0 : 0.0;
-  if (cfg.reward_type != 0) {
+  if (cfg.reward_type != 0 || info) {
     const V3 e = vsub(tcp, obj);
     const V3 oi = vsub(ld3(cfg.obj_init_pos), target), hi = vsub(ld3(cfg.hand_init_pos), obj);
     const double in_place = tolerance_gaussian(obj_to_target, 0.05, sqrt(oi.x * oi.x + oi.y * oi.y + oi.z * oi.z));
     const double hand_in_place = tolerance_gaussian(sqrt(e.x * e.x + e.y * e.y + e.z * e.z), 0.25 * 0.05, sqrt(hi.x * hi.x + hi.y * hi.y + hi.z * hi.z) + 0.1);
-    r = 3 * hand_in_place + 6 * in_place;
-    if (obj_to_target < 0.05) r = 10;
+    if (cfg.reward_type != 0) {
+      r = 3 * hand_in_place + 6 * in_place;
+      if (obj_to_target < 0.05) r = 10;
+    }
+    if (info) {
+      // SawyerDoorV2.evaluate_state (sawyer_door.py:127-139); compute_reward returns [reward, obj_to_target, hand_in_place] (:171), so the dict's
+      // 'in_place_reward' is the hand's term
+      info[EARL_INFO_SUCCESS] = obj_to_target <= 0.08 ? 1.0 : 0.0;
+      info[EARL_INFO_NEAR_OBJECT] = 0.0; info[EARL_INFO_GRASP_SUCCESS] = 1.0; info[EARL_INFO_GRASP_REWARD] = 1.0;
+      info[EARL_INFO_IN_PLACE_REWARD] = hand_in_place; info[EARL_INFO_OBJ_TO_TARGET] = obj_to_target; info[EARL_INFO_UNSCALED_REWARD] = r;
+      info[7] = 0.0;
+    }
   }
 }
 
@@ -2275,9 +2285,11 @@ __device__ __forceinline__ double hamacher(double a, double b) {
   return den > 0 ? (a * b) / den : 0.0;
 }
 // SawyerPegV2.compute_reward, reward_type 'dense' (sawyer_peg.py:231-299); head = obs[4:7] (site pegHead), tcp = obs[:3] (hand)
+// dense = false: reward_type 'sparse' (sawyer_peg.py:284-285: object_grasped = 0 unless lifted); the terms are still worked out, for the info dict (terms[]:
+// tcp_to_obj, obj_to_target (axis-scaled), object_grasped, in_place; may be NULL)
 __device__ __forceinline__ double peg_dense_reward(const earl_sawyer_cfg& cfg, const V3 tcp, const double tcp_opened, const V3 head, const V3 grasp,
                                                    const V3 lpad, const V3 rpad, const V3 tcpc, const V3 target, const double* __restrict__ oi,
-                                                   const double effort) {
+                                                   const double effort, const bool dense = true, double* terms = nullptr) {
 #pragma clang fp contract(off)
   const V3 obj = grasp;                                   // obs[4:7] - pegHead + pegGrasp with obs[4:7] == pegHead
   const V3 e = vsub(obj, tcp);
@@ -2290,7 +2302,8 @@ __device__ __forceinline__ double peg_dense_reward(const earl_sawyer_cfg& cfg, c
   in_place = hamacher(in_place, hamacher(box2, box1));
   const bool lifted = tcp_to_obj < 0.08 && tcp_opened > 0 && obj.z - 0.01 > oi[2];
   double grasped = 1.0;
-  if (!lifted) {
+  if (!lifted && !dense) grasped = 0.0;
+  if (!lifted && dense) {
     // _gripper_caging_reward(action, obj, obj_radius 0.0075, pad_success_thresh 0.03, object_reach_radius 0.01, xz_thresh 0.005, high_density)
     const double pl = fabs(lpad.y - obj.y), pr = fabs(rpad.y - obj.y);
     const double ml = fabs(fabs(lpad.y - oi[1]) - 0.03), mr = fabs(fabs(rpad.y - oi[1]) - 0.03);
@@ -2306,6 +2319,7 @@ __device__ __forceinline__ double peg_dense_reward(const earl_sawyer_cfg& cfg, c
   double r = hamacher(grasped, in_place);
   if (lifted) r += 1.0 + 5 * in_place;
   if (obj_to_target <= 0.05) r = 10.0;
+  if (terms) { terms[0] = tcp_to_obj; terms[1] = obj_to_target; terms[2] = grasped; terms[3] = in_place; }
   return r;
 }
 
@@ -2321,11 +2335,14 @@ __device__ __forceinline__ bool group_any(const bool pred, const int grp) {
 template <int NV>
 __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const typename ModelOf<NV>::T& m, const earl_sawyer_cfg& cfg, const int sub, const bool live,
                                             const double* __restrict__ goal, double* __restrict__ obs, float* reward, uint8_t* success,
-                                            const double* __restrict__ obj_init = nullptr, const double effort = 0.0, double* __restrict__ obs2 = nullptr) {
+                                            const double* __restrict__ obj_init = nullptr, const double effort = 0.0, double* __restrict__ obs2 = nullptr,
+                                            double* __restrict__ info = nullptr) {
 #pragma clang fp contract(off)
-  // (compiled into the peg model's kernels only: in the door kernel this code cost 35 more AGPR spills and 10 % of its throughput)
-  const bool peg_dense = NV >= 15 && cfg.obj_kind >= 1 && cfg.reward_type != 0 && obj_init != nullptr;
-  if (sub < (peg_dense ? 7 : 4)) {
+  // (compiled into the peg model's kernels only: in the door kernel this code cost 35 more AGPR spills and 10 % of its throughput.  The door's info dict is a
+  // function of the observation alone: earl_sawyer_door_info works it out from the emitted rows.)
+  const bool peg_terms = NV >= 15 && cfg.obj_kind >= 1 && obj_init != nullptr && (cfg.reward_type != 0 || info != nullptr);
+  const bool peg_dense = peg_terms && cfg.reward_type != 0;
+  if (sub < (peg_terms ? 7 : 4)) {
     const int k = sub == 0 ? cfg.att_hand : (sub == 1 ? cfg.att_right : (sub == 2 ? cfg.att_left : (sub == 3 ? cfg.att_obj :
                   (sub == 4 ? cfg.att_grasp : (sub == 5 ? cfg.att_lpad : cfg.att_rpad)))));
     const V3 p = attachment<NV>(s, m, k);
@@ -2346,11 +2363,22 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const typename ModelO
   if (sub == 0 && live) {
     double r; bool ok;
     door_reward(cfg, ld3(s.emit.att[0]), ld3(s.emit.att[3]), ld3(goal + 4), r, ok);
-    if constexpr (NV >= 15) if (peg_dense) {
+    if constexpr (NV >= 15) if (peg_terms) {
       const V3 rr = ld3(s.emit.att[1]), ll = ld3(s.emit.att[2]), dg = vsub(rr, ll);
       const double opened = fmin(fmax(sqrt(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z) / 0.1, 0.0), 1.0);      // obs[3]
-      r = peg_dense_reward(cfg, ld3(s.emit.att[0]), opened, ld3(s.emit.att[3]), ld3(s.emit.att[4]), ld3(s.emit.att[5]), ld3(s.emit.att[6]),
-                           scl(add(rr, ll), 0.5), ld3(goal + 4), obj_init, effort);
+      double terms[4];
+      const double rd = peg_dense_reward(cfg, ld3(s.emit.att[0]), opened, ld3(s.emit.att[3]), ld3(s.emit.att[4]), ld3(s.emit.att[5]), ld3(s.emit.att[6]),
+                                         scl(add(rr, ll), 0.5), ld3(goal + 4), obj_init, effort, peg_dense, terms);
+      if (peg_dense) r = rd;
+      if (info) {
+        // SawyerPegV2.evaluate_state (sawyer_peg.py:165-184): tcp_to_obj to the pegGrasp site, obj = the observation's pegHead, TARGET_RADIUS 0.05
+        const double headz = s.emit.att[3][2];
+        info[EARL_INFO_SUCCESS] = terms[1] <= 0.05 ? 1.0 : 0.0;
+        info[EARL_INFO_NEAR_OBJECT] = terms[0] <= 0.03 ? 1.0 : 0.0;
+        info[EARL_INFO_GRASP_SUCCESS] = (terms[0] < 0.02 && opened > 0 && headz - 0.01 > obj_init[2]) ? 1.0 : 0.0;
+        info[EARL_INFO_GRASP_REWARD] = terms[2]; info[EARL_INFO_IN_PLACE_REWARD] = terms[3]; info[EARL_INFO_OBJ_TO_TARGET] = terms[1];
+        info[EARL_INFO_UNSCALED_REWARD] = r; info[7] = 0.0;
+      }
     }
     if (reward) *reward = (float)r;
     if (success) *success = ok ? 1 : 0;
@@ -2424,7 +2452,8 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     const bool bad_lane = (sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE)) || (sub < 4 && !(fabs(s.bq[sub]) < 2.0));
     const bool failed = group_any<LPE>(bad_lane, grp);
     sawyer_emit<NV>(s, m, cfg, sub, live && !failed, a.st.goal + (size_t)env * 7, a.out.obs + row * 14, a.out.reward ? a.out.reward + row : nullptr,
-                    a.out.success ? a.out.success + row : nullptr, a.st.obj_init ? a.st.obj_init + (size_t)env * 6 : nullptr, (double)act.w);
+                    a.out.success ? a.out.success + row : nullptr, a.st.obj_init ? a.st.obj_init + (size_t)env * 6 : nullptr, (double)act.w, nullptr,
+                    (NV >= 15 && a.out.info) ? a.out.info + row * EARL_SAWYER_INFO : nullptr);
     RSTAMP(14);
     if (sub == 0 && live && a.out.status) a.out.status[row] = failed ? EARL_STEP_DIVERGED : 0;
     if (!failed) {
@@ -2444,6 +2473,7 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
           if (a.out.success) a.out.success[row] = 0;
           if (a.st.fail_count) a.st.fail_count[env] += 1;
         }
+        if (NV >= 15 && a.out.info && sub < EARL_SAWYER_INFO) a.out.info[row * EARL_SAWYER_INFO + sub] = 0.0;
       }
     }
     fence();
@@ -2591,6 +2621,21 @@ __global__ void sawyer_door_reward_kernel(const int n, const double* __restrict_
   door_reward(cfg, ld3(o), ld3(o + 4), ld3(o + 11), r, ok);
   if (reward) reward[i] = (float)r;
   if (success) success[i] = ok ? 1 : 0;
+}
+#endif
+
+#ifndef EARL_PHYS_NOT_MAIN
+// SawyerDoorV2.evaluate_state's info dict (sawyer_door.py:127-139) of given observation rows: every entry is a function of the observation (and of the
+// reward type), so the rollout kernel need not carry it; one lane per row
+__global__ void sawyer_door_info_kernel(const int n, const double* __restrict__ obs, const earl_sawyer_cfg cfg, const uint8_t* __restrict__ status, double* __restrict__ info) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* o = obs + (size_t)i * 14;
+  double r, row[EARL_SAWYER_INFO]; bool ok;
+  door_reward(cfg, ld3(o), ld3(o + 4), ld3(o + 11), r, ok, row);
+  const bool rolled_back = status && status[i] != 0;
+#pragma unroll
+  for (int k = 0; k < EARL_SAWYER_INFO; ++k) info[(size_t)i * EARL_SAWYER_INFO + k] = rolled_back ? 0.0 : row[k];
 }
 #endif
 
@@ -3226,6 +3271,13 @@ int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double*
   if (n == 0) return EARL_OK;
   sawyer_door_reward_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, obs, *cfg, reward, success);
   return launched("sawyer_door_reward");
+}
+
+int earl_sawyer_door_info(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, const uint8_t* status, double* info, earl_stream_t stream) {
+  if (!cfg || n < 0 || !obs || !info) return EARL_ERR_ARG;
+  if (n == 0) return EARL_OK;
+  sawyer_door_info_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, obs, *cfg, status, info);
+  return launched("sawyer_door_info");
 }
 
 int earl_kitchen_step(const void* model, const earl_collision_model* col, const earl_kitchen_params* params, const earl_kitchen_cfg* cfg,

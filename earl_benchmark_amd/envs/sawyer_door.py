@@ -167,15 +167,22 @@ class SawyerDoor:
             'reward': torch.empty(*lead, self.num_envs, dtype=torch.float32, **kw),
             'done': torch.empty(*lead, self.num_envs, dtype=torch.bool, **kw),
             'success': torch.empty(*lead, self.num_envs, dtype=torch.bool, **kw),
-            'status': torch.empty(*lead, self.num_envs, dtype=torch.uint8, **kw)}
+            'status': torch.empty(*lead, self.num_envs, dtype=torch.uint8, **kw),
+            # the reference's per-step info dict (evaluate_state: sawyer_door.py:127-139 / sawyer_peg.py:165-184), slots _abi.SAWYER_INFO_KEYS
+            'info': torch.empty(*lead, self.num_envs, _abi.SAWYER_INFO, dtype=torch.float64, **kw)}
 
   def _launch_rollout(self, actions, T, out):
+    info = out.get('info')
+    in_kernel = info is not None and self.nv >= 15        # the peg's dict needs simulator state: the rollout kernel's epilogue writes it
     o = _abi.SawyerOut(obs=out['obs'].data_ptr(), reward=_ptr(out.get('reward')), done=_ptr(out.get('done')),
-                       success=_ptr(out.get('success')), status=_ptr(out.get('status')))
+                       success=_ptr(out.get('success')), status=_ptr(out.get('status')), info=_ptr(info) if in_kernel else None)
     self._cfg.step_counter = self.total_step_count
     with torch.cuda.device(self.device):
       _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.model.col_ptr, self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),
                                                T, C.byref(o), self._stream()), 'earl_sawyer_rollout')
+      if info is not None and not in_kernel:               # the door's dict is a function of the emitted observation rows
+        _abi.check(self._lib.earl_sawyer_door_info(self._cfg_ref, T * self.num_envs, out['obs'].data_ptr(), _ptr(out.get('status')), info.data_ptr(),
+                                                   self._stream()), 'earl_sawyer_door_info')
     self.total_step_count += T
     if self._cfg.goal_change_frequency:
       self.lifelong_return_t += out['reward'].reshape(T, -1).sum(0, dtype=torch.float64)
@@ -208,9 +215,31 @@ class SawyerDoor:
   def step(self, action, out=None):
     out = out if out is not None else self._new_out(())
     self._launch_rollout(self._actions(action, ()), 1, out)
+    return (out['obs'][0].cpu().numpy(), float(out['reward'][0]), bool(out['done'][0]), self._info_dict(out)) if self.scalar_api else \
+        (out['obs'], out['reward'], out['done'], self._info_dict(out))
+
+  def info_from_obs(self, obs):
+    """the reference's info dict (door: evaluate_state, sawyer_door.py:127-139) of given observation rows [M, 14] -> dict of [M] float64 tensors"""
+    if self.nv >= 15:
+      raise NotImplementedError('the peg\'s info dict reads simulator state (pegGrasp site, pads): it comes with step() / rollout() only')
+    o = torch.as_tensor(obs, device=self.device).to(torch.float64).reshape(-1, self.OBS_DIM).contiguous()
+    info = torch.empty(o.shape[0], _abi.SAWYER_INFO, dtype=torch.float64, device=self.device)
+    with torch.cuda.device(self.device):
+      _abi.check(self._lib.earl_sawyer_door_info(self._cfg_ref, o.shape[0], o.data_ptr(), None, info.data_ptr(), self._stream()), 'earl_sawyer_door_info')
+    return {k: info[:, i] for i, k in enumerate(_abi.SAWYER_INFO_KEYS)}
+
+  def _info_dict(self, out):
+    """The dict the reference's step() returns (SawyerDoorV2 / SawyerPegV2.evaluate_state: 'success', 'near_object', 'grasp_success', 'grasp_reward',
+    'in_place_reward', 'obj_to_target', 'unscaled_reward' -- NB its 'success' is a looser test than is_successful(), see include/earl_physics.h), as floats
+    (scalar_api) or [N] float64 tensors, plus this build's own keys: 'is_successful' = is_successful(obs) of every env, 'status' = the failure guard."""
+    info = out.get('info')
+    d = {}
+    if info is not None:
+      d = {k: (float(info[0, i]) if self.scalar_api else info[..., i]) for i, k in enumerate(_abi.SAWYER_INFO_KEYS)}
     if self.scalar_api:
-      return out['obs'][0].cpu().numpy(), float(out['reward'][0]), bool(out['done'][0]), {}
-    return out['obs'], out['reward'], out['done'], {'success': out['success'], 'status': out['status']}
+      return d
+    d['is_successful'], d['status'] = out['success'], out['status']
+    return d
 
   def rollout(self, actions, out=None):
     """T steps in one launch: actions [T,N,4] -> dict of obs [T,N,14] f64, reward [T,N] f32, done / success [T,N] bool."""

@@ -235,7 +235,20 @@ typedef struct earl_sawyer_out {
                          back: state, mocap target <- the env's last stable ones, the row carries the last stable observation, reward 0,
                          success 0 (SawyerXYZEnv.step on MujocoException [UPSTREAM]: `return self._last_stable_obs, 0.0, False, info`);
                          the step still counts for the horizon.  Other envs of the batch are unaffected. */
+  double* info;       /* [T, n, EARL_SAWYER_INFO] may be NULL (no cost then): the numbers of the `info` dict the reference's step() returns through evaluate_state --
+                         door earl_benchmark/envs/sawyer_door.py:127-139, peg sawyer_peg.py:165-184 -- at the EARL_INFO_* slots below.  NB the reference's
+                         info['success'] is NOT is_successful(): the door uses obj_to_target <= 0.08 (is_successful: 0.02), the peg the axis-scaled distance
+                         <= 0.05; and the door's 'in_place_reward' is the HAND's tolerance term (its compute_reward returns hand_in_place in that slot).
+                         A rolled-back step carries zeros. */
 } earl_sawyer_out;
+#define EARL_SAWYER_INFO 8
+#define EARL_INFO_SUCCESS 0
+#define EARL_INFO_NEAR_OBJECT 1
+#define EARL_INFO_GRASP_SUCCESS 2
+#define EARL_INFO_GRASP_REWARD 3
+#define EARL_INFO_IN_PLACE_REWARD 4
+#define EARL_INFO_OBJ_TO_TARGET 5
+#define EARL_INFO_UNSCALED_REWARD 6
 #define EARL_BAD_VALUE 1e10
 #define EARL_STEP_DIVERGED 1
 
@@ -259,6 +272,10 @@ int earl_sawyer_observe(const earl_link_model* model, int32_t nv, const earl_saw
  * With reward_type sparse this is also SawyerPegV2's rule (sawyer_peg.py:295-305: radius 0.05 in cfg.success_radius). */
 int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, float* reward, uint8_t* success,
                             earl_stream_t stream);
+/* the info dict of SawyerDoorV2.step (evaluate_state, earl_benchmark/envs/sawyer_door.py:127-139) for n observation rows [n, 14] -> info [n, EARL_SAWYER_INFO]
+ * (slots EARL_INFO_*); every entry is a function of the observation and the reward type.  status (may be NULL): rows of rolled-back steps get zeros.
+ * (The peg's dict needs simulator state -- the pegGrasp site, the pads: earl_sawyer_out.info of earl_sawyer_rollout carries it.) */
+int earl_sawyer_door_info(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, const uint8_t* status, double* info, earl_stream_t stream);
 
 /* measurement switch: lanes of a wavefront that work on one env instance -- 16 (default: four envs per wavefront) or 64 (one
  * wavefront per env).  Results are identical; DESIGN.md quotes both timings. */

@@ -52,6 +52,18 @@ def compute_reward(obs, reward_type, hand_init_pos):
   return float(r), ok
 
 
+def door_info(obs, reward_type, hand_init_pos):
+  """the info dict of SawyerDoorV2.step = evaluate_state (reference sawyer_door.py:127-139): compute_reward returns [reward, obj_to_target, hand_in_place]
+  (:171), so 'in_place_reward' carries the HAND's tolerance term; 'success' is obj_to_target <= 0.08, not is_successful()'s 0.02"""
+  tcp, obj, target = obs[:3], obs[4:7], obs[11:14]
+  obj_to_target = float(np.sqrt(np.sum((obj - target) ** 2)))
+  tcp_to_obj = float(np.sqrt(np.sum((tcp - obj) ** 2)))
+  hand_in_place = tolerance_gaussian(tcp_to_obj, 0.25 * 0.05, float(np.sqrt(np.sum((hand_init_pos - obj) ** 2))) + 0.1)
+  reward, _ = compute_reward(obs, reward_type, hand_init_pos)
+  return {'obj_to_target': obj_to_target, 'in_place_reward': hand_in_place, 'success': float(obj_to_target <= 0.08), 'near_object': 0.0,
+          'grasp_success': 1.0, 'grasp_reward': 1.0, 'unscaled_reward': reward}
+
+
 class SawyerDoorOracle:
   """one env instance (global id `env_id`), scalar loops"""
 
@@ -176,9 +188,23 @@ def gripper_caging_reward(action, obj_pos, left_pad, right_pad, tcp, obj_init_po
   return (caging_and_gripping + caging) / 2          # high_density
 
 
-def peg_dense_reward(obs, action, grasp_site, head_site, left_pad, right_pad, tcp_center, obj_init_pos, peg_head_pos_init, init_tcp, corners):
+def peg_info(obs, action, reward_type, grasp_site, head_site, left_pad, right_pad, tcp_center, obj_init_pos, peg_head_pos_init, init_tcp, corners):
+  """the info dict of SawyerPegV2.step = evaluate_state (reference sawyer_peg.py:165-184) around compute_reward (:231-299), either reward type"""
+  terms = {}
+  dense = peg_dense_reward(obs, action, grasp_site, head_site, left_pad, right_pad, tcp_center, obj_init_pos, peg_head_pos_init, init_tcp, corners,
+                           dense=reward_type == 'dense', terms=terms)
+  ok = bool(np.sqrt(np.sum((obs[4:7] - obs[11:14]) ** 2)) <= 0.05)                      # is_successful :301-305
+  reward = dense if reward_type == 'dense' else float(ok)                             # :296-297
+  return {'success': float(terms['obj_to_target'] <= 0.05), 'near_object': float(terms['tcp_to_obj'] <= 0.03),
+          'grasp_success': float(terms['tcp_to_obj'] < 0.02 and obs[3] > 0 and obs[6] - 0.01 > obj_init_pos[2]),
+          'grasp_reward': terms['object_grasped'], 'in_place_reward': terms['in_place'], 'obj_to_target': terms['obj_to_target'], 'unscaled_reward': reward}
+
+
+def peg_dense_reward(obs, action, grasp_site, head_site, left_pad, right_pad, tcp_center, obj_init_pos, peg_head_pos_init, init_tcp, corners, dense=True,
+                     terms=None):
   """SawyerPegV2.compute_reward with reward_type='dense' (sawyer_peg.py:231-299); obs[4:7] is the pegHead site, so
-  obj = obs[4:7] - pegHead + pegGrasp (:233-234)"""
+  obj = obs[4:7] - pegHead + pegGrasp (:233-234).  dense=False: the 'sparse' branch of :284-285 (object_grasped = 0 unless lifted) -- the value the
+  function then returns is NOT the sparse reward (that is float(is_successful), :296-297), only the terms are of interest."""
   tcp, obj_head, tcp_opened, target = obs[:3], obs[4:7], obs[3], obs[11:14]
   obj = obs[4:7] - head_site + grasp_site
   tcp_to_obj = np.sqrt(np.sum((obj - tcp) ** 2))
@@ -192,14 +218,18 @@ def peg_dense_reward(obs, action, grasp_site, head_site, left_pad, right_pad, tc
   lifted = tcp_to_obj < 0.08 and tcp_opened > 0 and obj[2] - 0.01 > obj_init_pos[2]
   if lifted:
     object_grasped = 1.0
-  else:
+  elif dense:
     # the caging reward reads self.tcp_center (midpoint of the two finger sites), not the hand position of the observation
     object_grasped = gripper_caging_reward(action, obj, left_pad, right_pad, tcp_center, obj_init_pos, init_tcp, 0.0075, 0.03, 0.005)
+  else:
+    object_grasped = 0.0
   reward = hamacher_product(object_grasped, in_place)
   if lifted:
     reward += 1.0 + 5 * in_place
   if obj_to_target <= 0.05:
     reward = 10.0
+  if terms is not None:
+    terms.update(tcp_to_obj=float(tcp_to_obj), obj_to_target=float(obj_to_target), object_grasped=float(object_grasped), in_place=float(in_place))
   return float(reward)
 
 
@@ -292,12 +322,14 @@ class SawyerPegOracle(SawyerDoorOracle):
       self.last_obs = obs.copy()
     ok = (not failed) and bool(np.sqrt(np.sum((obs[4:7] - obs[11:14]) ** 2)) <= 0.05)             # is_successful :301-305
     rew = float(ok)
-    if self.reward_type == 'dense' and not failed:
+    self.last_info = None
+    if not failed:
       names = [str(x) for x in self.lm.att_names]
       at = lambda n: self.lm.attachment(out['pos'], out['quat'], names.index(n))[0]
-      rew = peg_dense_reward(obs, a, at('pegGrasp'), at('pegHead'), at('leftpad'), at('rightpad'),
-                             0.5 * (at('rightEndEffector') + at('leftEndEffector')), self.obj_init_pos, self.peg_head_pos_init,
-                             self.init_tcp, self.lm.peg_box_corners)
+      sites = (at('pegGrasp'), at('pegHead'), at('leftpad'), at('rightpad'), 0.5 * (at('rightEndEffector') + at('leftEndEffector')))
+      if self.reward_type == 'dense':
+        rew = peg_dense_reward(obs, a, *sites, self.obj_init_pos, self.peg_head_pos_init, self.init_tcp, self.lm.peg_box_corners)
+      self.last_info = peg_info(obs, a, self.reward_type, *sites, self.obj_init_pos, self.peg_head_pos_init, self.init_tcp, self.lm.peg_box_corners)
     self.steps += 1
     if self.gcf > 0:                                    # LifelongWrapper.step (lifelong_wrapper.py:30-44)
       self.sgc += 1

@@ -84,7 +84,7 @@ def test_full_size_episode_properties_shards_and_oracle_subset(task):
     worst = max(worst, err, float(np.abs(su.qpos.cpu().numpy() - q).max()))
     assert err < 2e-6, (task, t, err)
     np.testing.assert_allclose(su.qvel.cpu().numpy(), v, rtol=0, atol=2e-4, err_msg=f'{task} step {t}')
-    assert (r.cpu().numpy() == r_ref[0]).all() and (d.cpu().numpy() == d_ref[0]).all() and (info['success'].cpu().numpy() == ok_ref[0]).all()
+    assert (r.cpu().numpy() == r_ref[0]).all() and (d.cpu().numpy() == d_ref[0]).all() and (info['is_successful'].cpu().numpy() == ok_ref[0]).all()
   assert worst < 2e-6, worst
 
 
