@@ -558,7 +558,22 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
           'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
-def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=2048, T=400, cpu_seconds=None):
+def predicted_strong_scaling(workload, n_global, world):
+  """What the kernels' own layout predicts for the STRONG-scaling lines (configs[3] / [4]: a fixed global batch range-sharded over the GPUs), stated in the
+  line so that nobody reads 'x8' into it.  An env is a serial chain of T x frame_skip timesteps walked by ONE wave; a launch lasts as
+  long as its slowest wave.  Sharding the batch over more GPUs shortens a launch only while a GPU has more waves than wave slots (kitchen: 8 envs per CU x 256
+  CUs = 2048 envs fill exactly one round on ONE GPU; minitaur: 8 envs per CU per round, 4096 envs = two rounds)."""
+  per_round = 2048                                      # both kernels: 2 envs per wave, 4 waves per CU, 256 CUs
+  rounds_1 = -(-n_global // per_round)
+  rounds_w = -(-(-(-n_global // world)) // per_round)
+  return {'envs_per_gpu': -(-n_global // world), 'launch_rounds_on_1_gpu': rounds_1, f'launch_rounds_on_{world}_gpus': rounds_w,
+          'predicted_speedup_vs_1_gpu': rounds_1 / rounds_w,
+          'note': (f'{workload}: {n_global} envs = {rounds_1} round(s) of 2048 resident envs on one MI355X; on {world} GPU(s) every shard is {rounds_w} round, so the launch '
+                   f'is predicted {rounds_1 / rounds_w:.1f}x shorter at best (a round lasts as long as its slowest env chain; fewer waves per CU also contend less for '
+                   'LDS and issue slots, measured separately in DESIGN.md section 6).  The scaling lever of these workloads is MORE envs, not more GPUs per env.')}
+
+
+def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=2048, T=400, cpu_seconds=None, env_factory=None):
   """BASELINE configs[3]: kitchen, 2048 envs in total range-sharded over the GPUs (n_global / world per GPU: STRONG scaling), one bench step =
   reset + T = 400 env steps (the reference's eval horizon) of 40 timesteps each in ONE fused launch (earl_kitchen_rollout); the per-step surface
   (env.step(): one launch per env step) is timed beside it as `step_api`.
@@ -568,7 +583,8 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
   from earl_benchmark_amd import sharding
   kw = sharding.shard_kwargs(n_global, rank, world)
   n = kw['num_envs']
-  env = PersistentStateWrapper(Kitchen(num_envs=n, seed=1234, env_offset=kw['env_offset']), T)
+  env = PersistentStateWrapper((env_factory or Kitchen)(num_envs=n, seed=1234, env_offset=kw['env_offset']), T)     # (env_factory: tests/test_bench_sequence.py's CPU stand-in)
+  sizes = [sharding.shard_kwargs(n_global, r, world)['num_envs'] for r in range(world)]
   g = torch.Generator(device=device).manual_seed(77 + rank)
   acts = (torch.rand(T, n, 9, generator=g, device=device) * 2 - 1).to(torch.float32)
 
@@ -595,6 +611,10 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
   for _ in range(steps):
     o, r, done, info = episode()
   clk.stop()
+  gathered = None
+  if world > 1:                 # the ONE collective of the job: per-env return and final success of the last evaluation episode -> every rank ([N_global, 2])
+    gathered = sharding.gather_summary(sharding.rollout_summary(outbuf['reward'].to(torch.float32), outbuf['success']), sizes=sizes)
+    assert gathered.shape == (n_global, 2)
   clk.sync()
   if world > 1:
     dist.barrier()
@@ -628,7 +648,10 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
                                'its slowest wave, which the fused rollout only pays once per episode'},
           'config': {'workload': f'kitchen dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 40 '
                                  'timesteps per bench step; own stepper (nv = 23, 32 lanes per env), reduced collision set, parity with MuJoCo unpinned',
-                     'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 40, 'launches_per_episode': 1},
+                     'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 40, 'launches_per_episode': 1,
+                     'parallelism': f'env-range shard x{world} of a FIXED {n_global}-env batch (strong scaling), no per-step collective, one all-gather of the [N, 2] '
+                                    'evaluation summary per job', 'predicted_scaling': predicted_strong_scaling('kitchen', n_global, world)},
+          'gathered_rows': None if gathered is None else int(gathered.shape[0]),
           'cpu_baseline': CPU_RESULTS.get('kitchen') if cpu_seconds is not None else None}
 
 
@@ -668,7 +691,7 @@ def minitaur_cpu_baseline(seconds, n=4096, reps=2):
           'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
-def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=4096, T=1000, cpu_seconds=None):
+def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=4096, T=1000, cpu_seconds=None, env_factory=None):
   """BASELINE configs[4]: minitaur, 4096 envs in total range-sharded over the GPUs (STRONG scaling, like the kitchen line), one bench step = reset
   (incl. its 100 settle timesteps) + T = 1000 env steps (the reference's eval horizon) of 5 timesteps each in ONE fused launch (earl_minitaur_rollout).
   Own robot model and stepper: parity with the reference's PyBullet simulation is unpinned and model-less (envs/minitaur.py).  -> result dict on rank 0"""
@@ -677,7 +700,8 @@ def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=40
   from earl_benchmark_amd import sharding
   kw = sharding.shard_kwargs(n_global, rank, world)
   n = kw['num_envs']
-  env = PersistentStateWrapper(Minitaur(num_envs=n, seed=1234, env_offset=kw['env_offset'], scalar_api=False), T)
+  env = PersistentStateWrapper((env_factory or Minitaur)(num_envs=n, seed=1234, env_offset=kw['env_offset'], scalar_api=False), T)
+  sizes = [sharding.shard_kwargs(n_global, r, world)['num_envs'] for r in range(world)]
   g = torch.Generator(device=device).manual_seed(55 + rank)
   acts = (torch.rand(T, n, 8, generator=g, device=device) * 2 - 1).to(torch.float32)
   out = env.unwrapped._new_out((T,))
@@ -697,6 +721,10 @@ def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=40
   for _ in range(steps):
     res = episode()
   clk.stop()
+  gathered = None
+  if world > 1:                 # the ONE collective of the job (see run_kitchen)
+    gathered = sharding.gather_summary(sharding.rollout_summary(res['reward'].to(torch.float32), res['success']), sizes=sizes)
+    assert gathered.shape == (n_global, 2)
   clk.sync()
   if world > 1:
     dist.barrier()
@@ -718,8 +746,11 @@ def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=40
   return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
           'valu_frac': roof['frac'], 'roofline': roof, 'timesteps_per_s': steps * n_global * T * 5 / dt, 'scaling': 'strong', 'diverged_env_steps': fails,
           'config': {'workload': f'minitaur dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 5 '
-                                 'timesteps per bench step; own robot model (nv = 22, four loop closures) and stepper, parity with PyBullet unpinned and model-less',
-                     'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'launches_per_episode': 2},
+                                 'timesteps per bench step; own robot model (nv = 22, four loop closures) and tree-structured stepper (csrc/minitaur_stepper.h), parity with PyBullet unpinned and model-less',
+                     'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'launches_per_episode': 2,
+                     'parallelism': f'env-range shard x{world} of a FIXED {n_global}-env batch (strong scaling), no per-step collective, one all-gather of the [N, 2] '
+                                    'evaluation summary per job', 'predicted_scaling': predicted_strong_scaling('minitaur', n_global, world)},
+          'gathered_rows': None if gathered is None else int(gathered.shape[0]),
           'cpu_baseline': CPU_RESULTS.get('minitaur') if cpu_seconds is not None else None}
 
 

@@ -38,6 +38,10 @@ INIT_QPOS = np.array([1.48388023e-01, -1.76848573e+00, 1.84390296e+00, -2.476857
                       -4.22629655e-05, 6.28065475e-05, 4.04984708e-05, 4.62730939e-04, -2.26906415e-04, -4.65501369e-04, -6.44129196e-03,
                       -1.77048263e-03, 1.08009684e-03])
 STREAM_NOISE, STREAM_RESET = 0x4B00, 0x4B80               # Philox stream ids (csrc/glue.hip earl_philox_uniform)
+# Robot.get_obs's velocity noise amplitudes (reference adept_envs/franka/robot/franka_config.xml:17-43, attribute vel_noise_amp of qpos0 ... qpos22: the
+# robot's nine joints 0.1; the fixtures 0.005, the three hinge joints at the end 0.1); the position amplitudes are in earl_kitchen_params
+VEL_NOISE_AMP = np.array([0.1] * 9 + [0.005] * 11 + [0.1] * 3)
+RESET_ROBOT_STEPS = 10                                    # KitchenV0.reset_model: ten zero-action robot steps after sim.reset() (kitchen_multitask_v0.py:150-153)
 
 
 class _Cfg(_abi.KitchenCfg):
@@ -209,12 +213,39 @@ class Kitchen:
         self.steps_since_goal_change[sw] = 0
         self.goal_t[sw] = torch.tensor(self.get_next_goal(), dtype=torch.float64, device=self.device)
         obs = torch.cat([obs[:, :23], torch.where(sw[:, None], self.goal_t, obs[:, 23:])], 1)
+    info = self._env_info(obs, rew, suc, out['status'], self._counter)
     self._counter += 1
     self.total_step_count += 1
     self._last_success = suc
     if self.scalar_api:
-      return obs[0].cpu().numpy(), float(rew[0]), bool(done[0]), {}
-    return obs, rew, done, {'success': suc, 'status': out['status']}
+      return obs[0].cpu().numpy(), float(rew[0]), bool(done[0]), info
+    return obs, rew, done, info
+
+  def _env_info(self, obs, rew, suc, status, counter):
+    """The env_info dict of KitchenV0.step (reference adept_envs/franka/kitchen_multitask_v0.py:116-123): 'time' (simulation time of the observation: sim.reset()
+    at the last reset, ten robot steps there, then one per step), 'obs_dict' (t, qp, qv, obj_qp, obj_qv, goal: Robot.get_obs's noisy readings, franka_robot.py:137-168 --
+    the velocities get draws 9-17 and 32-45 of the step's 46 uniforms, the positions are the observation's), 'rewards' (Kitchen._get_reward_n_score, envs/kitchen.py:141-175:
+    true_reward = r_total = the step's reward), 'score' (0.), 'images' ([]); plus this build's own 'success' / 'is_successful' (is_successful of every env) and 'status'."""
+    dt = float(self.model.tables['timestep'])
+    t = (RESET_ROBOT_STEPS + self.steps_since_reset.to(torch.float64)) * (FRAME_SKIP * dt)
+    qv = self.qvel
+    if self.sensor_noise:
+      c = self._counter
+      self._counter = counter                              # the draws of THIS step (earl_kitchen_cfg.counter): the same Philox stream the observation used
+      try:
+        u = self._uniform(46, STREAM_NOISE, -1.0, 1.0)
+      finally:
+        self._counter = c
+      amp = torch.as_tensor(float(self._params.robot_noise_ratio) * VEL_NOISE_AMP, dtype=torch.float64, device=self.device)
+      qv = qv + amp * torch.cat([u[:, 9:18], u[:, 32:46]], 1)
+    if self.scalar_api:
+      od = {'t': float(t[0]), 'qp': obs[0, :9].cpu().numpy(), 'qv': qv[0, :9].cpu().numpy(), 'obj_qp': obs[0, 9:23].cpu().numpy(), 'obj_qv': qv[0, 9:].cpu().numpy(),
+            'goal': obs[0, 23:].cpu().numpy()}
+      r = float(rew[0])
+      return {'time': od['t'], 'obs_dict': od, 'rewards': {'true_reward': r, 'r_total': r}, 'score': 0.0, 'images': []}
+    od = {'t': t, 'qp': obs[:, :9], 'qv': qv[:, :9], 'obj_qp': obs[:, 9:23], 'obj_qv': qv[:, 9:], 'goal': obs[:, 23:]}
+    return {'time': t, 'obs_dict': od, 'rewards': {'true_reward': rew, 'r_total': rew}, 'score': torch.zeros_like(rew), 'images': [],
+            'success': suc, 'is_successful': suc, 'status': status}
 
   def rollout(self, actions, out=None):
     """T steps: actions [T, N, 9] -> dict(obs [T,N,46], reward [T,N], done, success, status).  ONE launch (earl_kitchen_rollout: every wave walks its

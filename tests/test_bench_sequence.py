@@ -178,3 +178,96 @@ def _ragged_worker(rank, world, port, sizes, out_dir):
     np.save(os.path.join(out_dir, f'ragged_{rank}.npy'), a.numpy())
   finally:
     dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------
+# bench.run_kitchen / bench.run_minitaur with world = 2: the STRONG-scaling lines -- a fixed global batch range-sharded over the
+# ranks, reset + ONE fused launch per bench step, the job's one collective (gather_summary of the last episode), barrier, MAX over ranks.  The env is a CPU
+# stand-in with the product env's surface (num_envs / env_offset constructor, _cfg.horizon set by the wrapper, reset(), rollout(acts, out=...), fail_count)
+# whose "launch" writes a deterministic function of the GLOBAL env id: the plumbing is under test, not the arithmetic.
+class _Cfg:
+  horizon = 0
+
+
+class StandInEnv:
+  OBS_DIM = 5
+  scalar_api = False
+
+  def __init__(self, num_envs=1, seed=0, env_offset=0, scalar_api=False, obs_dim=5, act_dim=9):
+    self.num_envs, self.env_offset, self.OBS_DIM, self.act_dim = num_envs, env_offset, obs_dim, act_dim
+    self._cfg = _Cfg()
+    self.fail_count = torch.zeros(num_envs, dtype=torch.int32)
+    self.resets = self.launches = 0
+    self.delay = 0.0
+
+  @property
+  def unwrapped(self):
+    return self
+
+  def reset(self, mask=None):
+    self.resets += 1
+    return torch.zeros(self.num_envs, self.OBS_DIM, dtype=torch.float64)
+
+  def _new_out(self, lead):
+    return {}
+
+  def rollout(self, actions, out=None):
+    T, n = actions.shape[0], self.num_envs
+    assert actions.shape == (T, n, self.act_dim) and actions.dtype == torch.float32 and T == self._cfg.horizon
+    res = out if out is not None else {}
+    gid = torch.arange(self.env_offset, self.env_offset + n, dtype=torch.float64)
+    t = torch.arange(T, dtype=torch.float64)[:, None]
+    res['obs'] = (gid[None, :, None] + t[..., None] * 0.5 + torch.zeros(self.OBS_DIM, dtype=torch.float64)).contiguous()
+    res['reward'] = -(gid[None, :] * 0.25 + t)
+    res['done'] = (t == T - 1).expand(T, n).contiguous()
+    res['success'] = ((gid[None, :].to(torch.int64) + t.to(torch.int64)) % 7 == 0)
+    res['status'] = torch.zeros(T, n, dtype=torch.uint8)
+    self.launches += 1
+    time.sleep(self.delay)
+    return res
+
+
+def _strong_worker(rank, world, port, which, n_global, T, steps, warmup, out_dir):
+  sys.path.insert(0, REPO)
+  import argparse
+  import torch.distributed as dist
+  import bench
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    made = []
+
+    def factory(**kw):
+      e = StandInEnv(act_dim=9 if which == 'kitchen' else 8, **kw)
+      e.delay = 0.02 * (rank + 1)                                     # rank 1 is the slow one
+      made.append(e)
+      return e
+    a = argparse.Namespace(no_step_api=True)
+    fn = bench.run_kitchen if which == 'kitchen' else bench.run_minitaur
+    res = fn(a, torch, dist, world, rank, 'cpu', steps, warmup, n_global=n_global, T=T, cpu_seconds=None, env_factory=factory)
+    env = made[0]
+    lo, hi = __import__('earl_benchmark_amd.sharding', fromlist=['x']).shard_range(n_global, rank, world)
+    assert env.num_envs == hi - lo and env.env_offset == lo and env._cfg.horizon == T          # its own contiguous range, the wrapper's horizon
+    assert env.launches == steps + warmup and env.resets == steps + warmup                      # a bench step = reset + ONE launch
+    assert (res is None) == (rank != 0)
+    if rank == 0:
+      json.dump({k: res[k] for k in ('value', 'ms_per_step', 'scaling', 'gathered_rows', 'config')}, open(os.path.join(out_dir, f'{which}.json'), 'w'))
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('which, n_global', [('kitchen', 21), ('minitaur', 32)])      # (21: ragged shards, 11 + 10)
+def test_two_rank_strong_scaling_lines(tmp_path, which, n_global):
+  import bench
+  world, T, steps, warmup = 2, 6, 2, 1
+  mp.spawn(_strong_worker, args=(world, _free_port(), which, n_global, T, steps, warmup, str(tmp_path)), nprocs=world, join=True)
+  res = json.load(open(tmp_path / f'{which}.json'))
+  assert res['scaling'] == 'strong' and res['gathered_rows'] == n_global                       # every rank held the whole [N_global, 2] summary
+  assert res['ms_per_step'] >= 40.0 - 1e-6                                                      # MAX over ranks: the slow rank's 2 x 20 ms per step
+  assert abs(res['value'] - n_global * T / (res['ms_per_step'] * 1e-3)) < 1e-6 * res['value']  # whole-job env steps over the max-over-ranks time
+  cfg = res['config']
+  assert cfg['envs_global'] == n_global and cfg['envs_per_gpu'] == -(-n_global // world) and 'strong scaling' in cfg['parallelism']
+  # what the kernels' layout predicts for the real shapes (one round of 2048 resident envs per GPU): stated in the line
+  assert bench.predicted_strong_scaling('kitchen', 2048, 8)['predicted_speedup_vs_1_gpu'] == 1.0
+  assert bench.predicted_strong_scaling('minitaur', 4096, 8)['predicted_speedup_vs_1_gpu'] == 2.0
+  assert cfg['predicted_scaling']['envs_per_gpu'] == -(-n_global // world)
