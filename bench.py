@@ -384,6 +384,8 @@ def pipe_roofline(prof, kernel, gpu_ms, hbm=None):
           'waves_per_simd': wps, 'per_wave': {'valu': issue.get('valu'), 'lds': issue.get('lds'), 'scalar': issue.get('scalar'),
                                               'wait_s_waitcnt': issue.get('wait_any'), 'issue_stall': issue.get('wait_inst'), 'any_issue': issue.get('issue_any')},
           'lane_occupancy': issue.get('lane_occupancy'),
+          # share of the SIMD's fp64 lane-cycles doing work: VALU issue share x lanes active per VALU instruction (the figure to raise)
+          'valu_x_lane_occupancy': None if (valu is None or issue.get('lane_occupancy') is None) else valu * issue['lane_occupancy'],
           'source': (prof.get('source', '') + ' (static: SQ counters collected by rocprofv3 --pmc in separate runs of this workload, not measured in this run)') if issue else None,
           'kernel': kernel, 'kernel_ms_mean': gpu_ms, 'hbm': hbm}
 

@@ -363,8 +363,9 @@ def test_info_dict_with_the_sparse_reward_type(lm):
   env = SawyerPeg(reward_type='sparse', num_envs=n, seed=9)
   o0 = env.reset().cpu().numpy()
   refs = [SawyerPegOracle(lm, 'sparse', seed=9, env_id=i) for i in range(n)]
-  for r_ in refs:
-    r_._settled = refs[0].settle(); r_.reset()
+  for j, r_ in enumerate(refs):
+    r_._settled = refs[0].settle(); r_.counter = 1                              # (the env's constructor has drawn the reset of counter 0)
+    np.testing.assert_allclose(r_.reset(), o0[j], rtol=0, atol=1e-6)
   rng = np.random.default_rng(4)
   acts = rng.uniform(-1, 1, (T, n, 4)).astype(np.float32)
   acts[:, :, 2] = -np.abs(acts[:, :, 2])                                       # towards the table: the fingers reach the peg's height
