@@ -209,6 +209,39 @@ def time_step_api(torch, env, acts, steps, warmup, graph=False):
   return dt, e0.elapsed_time(e1) * 1e-3
 
 
+def time_policy_in_the_loop(torch, n, T, reward, rank, device, steps, hidden=64):
+  """The reference's TRAIN-env loop with a policy in it: LifelongWrapper(PersistentStateWrapper(env)) stepped one step() at a time, the action of step t + 1
+  computed from the observation of step t by a 2-layer MLP (12 -> hidden -> 3, tanh) whose kernels are captured between the steps; T steps per replay, goal
+  switches (every 50 steps) drawn inside the captured loop (device-resident Philox base).  -> dict for the `policy_in_the_loop` key"""
+  import earl_benchmark_amd as eb
+  L = eb.EARLEnvs('tabletop_manipulation', reward_type=reward, num_envs=n, device=device, seed=4321 + rank, setup_as_lifelong_learning=True, goal_change_frequency=50)
+  env = L.get_envs()
+  gen = torch.Generator(device=device).manual_seed(7 + rank)
+  w1 = torch.randn(12, hidden, generator=gen, device=device) * 0.3
+  w2 = torch.randn(hidden, 3, generator=gen, device=device) * 0.3
+
+  def policy(ob):
+    return torch.tanh(torch.tanh(ob @ w1) @ w2)
+  env.reset()
+  g = env.unwrapped.make_step_graph(T, policy=policy)
+  g.replay()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(steps):
+    g.replay()
+  e1.record()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  sgpu = e0.elapsed_time(e1) * 1e-3
+  switched = int((env.unwrapped.steps_since_goal_change < 50).all())
+  return {'value': steps * n * T / dt, 'unit': 'env-steps/s', 'launches': steps * T, 'us_per_env_step_wall': dt / (steps * T) * 1e6, 'us_per_env_step_gpu': sgpu / (steps * T) * 1e6,
+          'policy': f'2-layer MLP 12 -> {hidden} -> 3 (tanh), fp32, torch kernels captured between the steps', 'goal_change_frequency': 50, 'goal_switch_bookkeeping_ok': bool(switched),
+          'note': 'closed loop: the lifelong train env (wrappers/lifelong_wrapper.py:30-44) stepped by a captured policy; one replay = ' + str(T) + ' env steps; what a learner '
+                  'in the loop sees, next to the open-loop evaluation figure `value` and the policy-free `step_api`'}
+
+
 def probe_reference_simulators():
   """is any of the simulators the reference binds (env.yml:11-15: mujoco-py -> MuJoCo 2.1, pybullet, metaworld; plus their modern names)
   importable on THIS host?  find_spec first (no side effects), then a real import of what was found, in a child process (mujoco_py compiles at import)."""
@@ -955,6 +988,7 @@ def main():
                                  'env.make_step_graph(T) and replayed with one host call (closed-loop users capture their policy in between)')
       res['step_api']['eager'] = leg(False)
       res['step_api']['eager']['note'] = 'one eager step() call per env step from Python (host-launch bound at N=4096)'
+      res['policy_in_the_loop'] = time_policy_in_the_loop(torch, n, T, a.reward, rank, device, max(2, a.steps // 4))
     if a.sweep:
       sw = []
       for ns in (64, 1024, 4096, 16384, 65536, 262144, 1048576):

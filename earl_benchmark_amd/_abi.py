@@ -22,7 +22,7 @@ class TabletopCfg(C.Structure):
 class TabletopState(C.Structure):
   _fields_ = [('qpos', C.c_void_p), ('attached', C.c_void_p), ('goal_idx', C.c_void_p), ('goal_table', C.c_void_p),
               ('steps_since_reset', C.c_void_p), ('num_interventions', C.c_void_p),
-              ('steps_since_goal_change', C.c_void_p), ('lifelong_return', C.c_void_p)]
+              ('steps_since_goal_change', C.c_void_p), ('lifelong_return', C.c_void_p), ('counter_base', C.c_void_p)]
 
 
 class TabletopOut(C.Structure):

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const KArgs a) {
   float reward;
   bool done, succ;
   double r64;
-  wrapped_step<NOBJ, GENERAL>(a, i, a.cfg.counter, L, g, ap[0], ap[1], ap[2], o, reward, done, succ, &r64);
+  const uint64_t counter = a.cfg.counter + (a.st.counter_base ? *a.st.counter_base : 0ull);      // (counter_base: captured step loops, include/earl_tabletop.h)
+  wrapped_step<NOBJ, GENERAL>(a, i, counter, L, g, ap[0], ap[1], ap[2], o, reward, done, succ, &r64);
   if (a.out.obs) store_obs<NOBJ>(a.out.obs + (size_t)i * Dims<NOBJ>::NOBS, o);
   if (a.out.reward) a.out.reward[i] = reward;
   if (a.out.reward_f64) a.out.reward_f64[i] = r64;

@@ -473,15 +473,13 @@ class StepGraph:
                                                 #   step of a replay starts from and is refreshed by the graph's last node
     g.replay()                                  # obs / reward / done / success of the T steps are in g.obs[t], g.reward[t], ...
 
-  Each captured step is exactly `step()` (same kernel, same state tensors), so a replay is bit-identical to T eager calls.  The Philox
-  counter of a launch is a kernel ARGUMENT, frozen at capture time; it is only read by lifelong goal switching and auto-reset, so
-  those two modes are refused here (resets between replays run eagerly and draw fresh goals as usual)."""
+  Each captured step is exactly `step()` (same kernel, same state tensors), so a replay is bit-identical to T eager calls -- also with lifelong goal
+  switching (the reference's train-env loop, wrappers/lifelong_wrapper.py:30-44) and auto-reset, whose draws use the launch's Philox counter: a kernel
+  ARGUMENT would be frozen at capture time, so the captured launch of step t carries the OFFSET t and adds a base it reads from one device word
+  (earl_tabletop_state.counter_base), which replay() refreshes from the env's counter before every replay."""
 
   def __init__(self, env, T, policy=None):
     u = env.unwrapped if hasattr(env, 'unwrapped') else env
-    if u._cfg.goal_change_frequency > 0 or u._cfg.auto_reset:
-      raise NotImplementedError('make_step_graph: lifelong goal switching / auto_reset draw from a per-launch Philox counter, which a captured '
-                                'graph would freeze; use step() or rollout() for those modes')
     if u.scalar_api:
       raise ValueError('make_step_graph is for the batched API (scalar_api=False)')
     self.env, self.T, self.policy = u, int(T), policy
@@ -493,8 +491,11 @@ class StepGraph:
       structs = [_abi.TabletopOut(self.obs[t].data_ptr(), self.reward[t].data_ptr(), self.done[t].data_ptr(), self.success[t].data_ptr())
                  for t in range(self.T)]
       step_fn = u._lib.earl_tabletop_step if u.NOBJ == 1 else u._lib.earl_tabletop3_step
+      self.counter_dev = torch.zeros(1, dtype=torch.int64, device=dev)      # the Philox counter of the replay's first step (two's complement of the uint64)
+      host_counter = int(u._cfg.counter)
 
       def launch(t):
+        u._cfg.counter = t                                     # the captured launch draws with *counter_base + t
         if u.NOBJ == 1:
           rc = step_fn(u._cfg_ref, u._st_ref, self.actions[t].data_ptr(), None, C.byref(structs[t]), u._stream())
         else:
@@ -508,19 +509,26 @@ class StepGraph:
           policy(self.obs_in)
         torch.cuda.current_stream(dev).wait_stream(side)
       self.graph = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(self.graph):
-        prev = self.obs_in
-        for t in range(self.T):
+      u._st.counter_base = self.counter_dev.data_ptr()
+      try:
+        with torch.cuda.graph(self.graph):
+          prev = self.obs_in
+          for t in range(self.T):
+            if policy is not None:
+              self.actions[t].copy_(policy(prev).to(torch.float32).reshape(n, 3))
+            launch(t)
+            prev = self.obs[t]
           if policy is not None:
-            self.actions[t].copy_(policy(prev).to(torch.float32).reshape(n, 3))
-          launch(t)
-          prev = self.obs[t]
-        if policy is not None:
-          self.obs_in.copy_(self.obs[self.T - 1])
+            self.obs_in.copy_(self.obs[self.T - 1])
+      finally:                                                 # eager calls keep the counter as their argument
+        u._st.counter_base = None
+        u._cfg.counter = host_counter
 
   def replay(self):
     """run the T captured steps (asynchronous, on torch's current stream); -> (obs, reward, done, {'success': success}), each [T, N, ...]"""
     u = self.env
+    c = int(u._cfg.counter)
+    self.counter_dev.fill_(c - (1 << 64) if c >= (1 << 63) else c)
     self.graph.replay()
     u._cfg.counter += self.T
     u.total_step_count += self.T

@@ -64,6 +64,10 @@ typedef struct earl_tabletop_state {
   int32_t* num_interventions;       /* [n]  PersistentStateWrapper._num_interventions */
   int32_t* steps_since_goal_change; /* [n]  LifelongWrapper, may be NULL when goal_change_frequency == 0 */
   double* lifelong_return;          /* [n]  LifelongWrapper._lifelong_return, may be NULL likewise */
+  const uint64_t* counter_base;     /* may be NULL.  Device word ADDED to cfg.counter by earl_tabletop_step / earl_tabletop3_step (only): the Philox counter of a
+                                       step launch captured into a HIP graph is a kernel argument frozen at capture time; with the base in device memory the
+                                       captured launch of step t (cfg.counter = t) draws with base + t, and the host refreshes the one word before each replay
+                                       -- lifelong goal switching and auto-reset inside a captured step loop (envs/tabletop.py StepGraph) */
 } earl_tabletop_state;
 
 /* Outputs of one step (rows = envs) or of one rollout (rows = [T, n]). */

@@ -261,10 +261,55 @@ def test_step_graph_ring_and_closed_loop_policy(torch, orc):
       assert torch.equal(obs[t], ob) and torch.equal(rew[t], r) and torch.equal(info['success'][t], i['success'])
     assert torch.equal(g2.obs_in, ob)
   assert float(((obs[-1][:, 2:4] - obs[-1][:, 8:10]).norm(dim=1) < 0.3).float().mean()) > 0.9   # the scripted policy carried the mugs to their goals
-  lifelong = tabletop.TabletopManipulation(num_envs=4, scalar_api=False)
-  lifelong._cfg.goal_change_frequency = 10
-  with pytest.raises(NotImplementedError):
-    lifelong.make_step_graph(4)
+
+
+@pytest.mark.parametrize('mode', ['lifelong', 'auto_reset'])
+def test_captured_step_loop_with_goal_switches_and_auto_reset(torch, orc, mode):
+  """the reference's train-env loop (LifelongWrapper.step, wrappers/lifelong_wrapper.py:30-44: a new goal every goal_change_frequency steps,
+  drawn from the Philox counter of THAT step) captured into a HIP graph -- the launches read the counter's base from a device word the host refreshes per
+  replay -- against the oracle, step by step, over five goal switches and several replays, with an eager reset in between; likewise auto-reset."""
+  import earl_benchmark_amd as eb
+  from earl_benchmark_amd.envs import tabletop
+  n, T = 200, 12
+  if mode == 'lifelong':
+    L = eb.EARLEnvs('tabletop_manipulation', reward_type='dense', num_envs=n, seed=9, setup_as_lifelong_learning=True, goal_change_frequency=7)
+    env = L.get_envs()
+  else:
+    env = tabletop.TabletopManipulation(reward_type='sparse', num_envs=n, seed=9, scalar_api=False, auto_reset=True)
+    env._cfg.horizon = 9
+  u = env.unwrapped
+  env.reset()
+  o = mirror(orc, env)
+  g = env.make_step_graph(T)
+  assert u._st.counter_base is None                                   # eager calls keep the counter as their argument
+  rng = np.random.default_rng(3)
+  goals_seen = set()
+  for rep in range(4):
+    if rep == 2:                                                      # an eager call between replays advances the counter: the next replay follows it
+      env.reset(); o.reset()
+    a = rng.uniform(-1, 1, size=(T, n, 3)).astype(np.float32)
+    g.actions.copy_(torch.from_numpy(a))
+    before = np.array(u.goal_idx.cpu().numpy())
+    obs, rew, done, info = g.replay()
+    torch.cuda.synchronize()
+    for t in range(T):
+      r = o.step(a[t])
+      np.testing.assert_array_equal(obs[t].cpu().numpy(), r[0])
+      if mode == 'lifelong':
+        np.testing.assert_allclose(rew[t].cpu().numpy(), r[1], rtol=2e-6, atol=2e-6)      # (dense reward: float32 of the same fp64 expression)
+      else:
+        np.testing.assert_array_equal(rew[t].cpu().numpy(), r[1])
+      np.testing.assert_array_equal(done[t].cpu().numpy(), r[2].astype(bool)); np.testing.assert_array_equal(info['success'][t].cpu().numpy(), r[3].astype(bool))
+    np.testing.assert_array_equal(u.goal_idx.cpu().numpy(), o.goal_idx)
+    goals_seen.update(np.unique(u.goal_idx.cpu().numpy()).tolist())
+    assert (before != u.goal_idx.cpu().numpy()).any()                 # goals were redrawn inside the captured loop
+  assert len(goals_seen) == 4 and int(u._cfg.counter) == o.cfg.counter
+  np.testing.assert_array_equal(u.qpos.cpu().numpy(), o.qpos)
+  if mode == 'lifelong':
+    np.testing.assert_allclose(u.lifelong_return_t.cpu().numpy(), o.lifelong_return, rtol=1e-9)
+    assert u.total_step_count == 4 * T                                # 48 steps / 7: six goal switches
+  else:
+    assert int(u.interventions.min()) >= 1 + 4                        # the constructor's and the eager reset + auto-resets every 9 steps
 
 
 def test_demonstrations_seed_a_device_replay_buffer(torch):
