@@ -215,8 +215,8 @@ def test_arm_against_static_boxes_collision_tables():
   hood) or hulls of them (microwave body, cabinet bottoms); the round-2 set is an unchanged PREFIX of the pair / block lists, so states without such
   contacts give the results they gave before."""
   z = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'models', 'kitchen_links.npz'))
-  assert len(z['col_pair']) == 364 and len(z['col_blk_begin']) == 56 and len(z['col_box_link']) == 12 and len(z['col_sph_link']) == 92
-  assert int(z['col_blk_begin'][26]) == 190 and set(z['col_blk_box'][26:].tolist()) == set(range(6, 12))
+  assert len(z['col_pair']) == 393 and len(z['col_blk_begin']) == 61 and len(z['col_box_link']) == 13 and len(z['col_sph_link']) == 92
+  assert int(z['col_blk_begin'][26]) == 190 and set(z['col_blk_box'][26:56].tolist()) == set(range(6, 12)) and set(z['col_blk_box'][56:].tolist()) == {12}   # (round 4: the right-hand counter, appended)
   assert sorted(set(z['col_blk_link'][26:].tolist())) == [4, 5, 6, 7, 8]            # forearm, wrist, hand, the two fingers
   new = np.arange(79, 92)
   assert sorted(z['col_sph_link'][new].tolist()) == [4] * 3 + [5] * 2 + [6] * 8

@@ -162,7 +162,7 @@ def test_the_hand_stops_at_the_counter_top_and_at_the_hood():
   cm = physics_c.CModel('kitchen')
   tb = dm.tables
   hand = [i for i in range(len(tb['col_sph_link'])) if tb['col_sph_link'][i] == 6 and tb['col_sph_r'][i] > 0.015]
-  assert len(hand) == 8 and len(tb['col_blk_begin']) == 56 and len(tb['col_box_link']) == 12
+  assert len(hand) == 8 and len(tb['col_blk_begin']) == 61 and len(tb['col_box_link']) == 13      # (round 4: + the right-hand counter, five blocks)
   lm = po.LinkModel({k: tb[k] for k in tb})
   kw = dict(dtype=torch.float64, device='cuda')
   mq = torch.tensor(tb['weld_mocap_quat'], **kw)[None].contiguous()
@@ -175,8 +175,14 @@ def test_the_hand_stops_at_the_counter_top_and_at_the_hood():
   # boxes 6 and 9 of the table: the counter-top slab (top face z = 1.60), the hood (front face y = 0.675, z in [2.164, 2.404])
   slab, hood = (tb['col_box_pos'][6], tb['col_box_half'][6]), (tb['col_box_pos'][9], tb['col_box_half'][9])
   assert abs(slab[0][2] + slab[1][2] - 1.60) < 1e-6 and abs(hood[0][1] - hood[1][1] - 0.675) < 1e-3
+  # box 12 (round 4): the right-hand counter, hull of its body and the slab pieces around the sink (top face z = 1.60, x from 0.498)
+  rc = (tb['col_box_pos'][12], tb['col_box_half'][12])
+  assert abs(rc[0][2] + rc[1][2] - 1.60) < 1e-6 and abs(rc[0][0] - rc[1][0] - 0.498) < 2e-3
   cases = (('counter top', lambda f: (-0.7, 0.1, 2.226 + (1.50 - 2.226) * f),
             lambda c: 1.60 - (c[:, 2] - rad).min()),
+           ('right counter', lambda f: (-0.2 + (0.58 + 0.2) * min(1.0, 2 * f), 0.1 + (0.30 - 0.1) * min(1.0, 2 * f), 2.226 + (1.50 - 2.226) * max(0.0, 2 * f - 1)),   # over it, then down
+                                                                                                         # (beyond the env's clip box x <= 0.4: the raw stepper)
+            None),      # (at that reach the arm is stretched and tilted: whichever of forearm / wrist / hand / finger corners is lowest over the counter touches)
            ('hood front', lambda f: (-0.2, 0.1 + (0.725 - 0.1) * f, 2.226 + (2.28 - 2.226) * f),
             lambda c: ((c[:, 1] + rad)[(c[:, 2] > hood[0][2] - hood[1][2]) & (c[:, 2] < hood[0][2] + hood[1][2])]).max() - 0.675))
   for name, target, penetration in cases:
@@ -191,8 +197,15 @@ def test_the_hand_stops_at_the_counter_top_and_at_the_hood():
         r = cm.run(qc, vc, mp.cpu().numpy()[0], tb['weld_mocap_quat'], [0.04, 0.0], nsub=40)
         assert r['ncon'][0] >= 1
         worst = max(worst, float(np.abs(r['qpos'] - q.cpu().numpy()).max()))
-    pen = float(penetration(centres(q.cpu().numpy()[0])))
-    assert 0.0 < pen < (5e-3 if name == 'counter top' else 8e-3), (name, pen)   # resting AT the surface: in contact; 5-10 cm of weld pull give millimetres of
+    if penetration is None:
+      pos, quat, _ = lm.kinematics(q.cpu().numpy()[0])
+      arm = [i for i in range(len(tb['col_sph_link'])) if tb['col_sph_link'][i] >= 4 and tb['col_sph_link'][i] <= 8]     # forearm, wrist, hand spheres + the finger boxes' corner points
+      c = np.array([pos[tb['col_sph_link'][i]] + po.quat_mat(quat[tb['col_sph_link'][i]]) @ tb['col_sph_pos'][i] for i in arm])
+      over = (np.abs(c[:, 0] - rc[0][0]) < rc[1][0]) & (np.abs(c[:, 1] - rc[0][1]) < rc[1][1])
+      pen = float(1.60 - (c[over, 2] - tb['col_sph_r'][arm][over]).min())
+    else:
+      pen = float(penetration(centres(q.cpu().numpy()[0])))
+    assert 0.0 < pen < (8e-3 if name == 'hood front' else 5e-3), (name, pen)   # resting AT the surface: in contact; 5-10 cm of weld pull give millimetres of
                                                         # soft-constraint penetration (counter 3.6 mm, hood 7 mm: MuJoCo-style impedance rows, not rigid stops)
     assert worst < 1e-6, (name, worst)
     assert bool(torch.isfinite(q).all())

@@ -545,6 +545,12 @@ def main():
       return dict(body='world', pos=0.5 * (lo + hi), half=0.5 * (hi - lo), like=geoms[0], accept=ARM_SETS, late=True)
     micro_body = hull(world_box('microroot', lambda g: True))
     cab_bottoms = hull(world_box('slide', lambda g: abs(gcen(g)[2] - 2.42) < 0.01) + world_box('hingecab', lambda g: abs(gcen(g)[2] - 2.42) < 0.01))
+    # Round 4: the RIGHT-hand counter -- its body and the eight slab / rim pieces around the sink (adept_models/kitchen/assets/counters_asset.xml
+    # through counters_chain.xml; world x 0.50 .. 1.11, y 0.09 .. 1.32, top at z 1.60) as ONE box, the hull of the nine (the sink's hole is filled: declared).
+    # Appended after the round-3 set, whose pairs and blocks keep their places.  What stays uncollided, with the reason: the FLOOR (z = 0) and the left counter's
+    # body under its slab lie outside the arm's reach (base at z = 1.80, shoulder at 2.13, reach 0.86 + 0.2 m of hand: nothing of the arm gets below z = 1.07, and
+    # the slab overhangs the body); links 1-4 (shoulder 2.13, elbow within 0.40 m of it) stay >= 0.2 m clear of every box of the scene in every pose.
+    right_counter = hull(world_box('counters', lambda g: gcen(g)[0] > 0.4))
     yf = np.array([np.sin(np.pi / 4), np.cos(np.pi / 4), 0.0])       # the fingers' slide axis in the frame of link 7 (the finger frames are turned -45 deg about z)
     hand = [dict(body='panda0_link7', pos=[0, 0, 0.08], r=0.05, set='hand', like=finger_geom['panda0_leftfinger'])]
     hand += [dict(body='panda0_link7', pos=list(t * yf + [0, 0, 0.131]), r=0.035, set='hand', like=finger_geom['panda0_leftfinger']) for t in (-0.07, 0.0, 0.07)]
@@ -557,7 +563,7 @@ def main():
     red = po.reduce_model(pm, None, attach_bodies=['panda0_link7'],
                           attach_sites=['end_effector', 'knob1_site', 'knob2_site', 'knob3_site', 'knob4_site', 'light_site', 'slide_site', 'hinge_site2', 'microhandle_site'],
                           weld_translation_calibration=1.0,        # no recordings of this env exist: the derived value, not the Sawyer calibration
-                          collision=dict(max_contacts=12, explicit_boxes=fingers + [micro_body, cab_bottoms], chains=chains, explicit_spheres=hand,
+                          collision=dict(max_contacts=12, explicit_boxes=fingers + [micro_body, cab_bottoms, right_counter], chains=chains, explicit_spheres=hand,
                                          big_boxes=[dict(geom=g, accept=('tipl', 'tipr')) for g in panels] + [dict(geom=g, accept=ARM_SETS) for g in statics],
                                          set_priority=sets, set_cap=dict({c['set']: 4 for c in chains}, tipl=2, tipr=2, hand=3, wrist=2, forearm=2)))
     red['key_qpos'] = m['key_qpos']
