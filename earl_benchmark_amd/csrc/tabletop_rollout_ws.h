@@ -289,7 +289,8 @@ __device__ __forceinline__ void ws_step_adj_exact(double& f, double& o, int& att
 
 // PROF = diagnostic build only (tools/prof_ws.py): s_memtime stamps per role, summed per workgroup into
 // g_ws_prof; never used by the shipped configuration and its timings are not quoted.
-__device__ unsigned long long g_ws_prof[64 * 16];
+__device__ unsigned long long g_ws_prof[64 * 16];      // rows are indexed by the ENV block (`bid`, after the XCD-aware remap), so rows 0 .. wgs - 1 are episode group 0
+                                                        // (indexed by the hardware blockIdx they mixed the groups)
 __device__ __forceinline__ unsigned long long ws_clock() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -492,11 +493,11 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       WS_STAMP(p_bar)
     }
     if constexpr (PROF) {
-      if (lane == 0 && blockIdx.x < 64 && wave == 0) {
-        unsigned long long* op = g_ws_prof + blockIdx.x * 16;
+      if (lane == 0 && bid < 64 && wave == 0) {
+        unsigned long long* op = g_ws_prof + bid * 16;
         op[0] = p_first; op[1] = p_read; op[2] = p_comp; op[3] = p_bar; op[4] = p_x - p_t0;
       }
-      if (lane == 0 && blockIdx.x < 64 && wave == 1) g_ws_prof[blockIdx.x * 16 + 13] = p_bar;      // the second compute wave's barrier wait
+      if (lane == 0 && bid < 64 && wave == 1) g_ws_prof[bid * 16 + 13] = p_bar;      // the second compute wave's barrier wait
     }
     if (alive && leaves_state) {
       a.qpos[(size_t)ie * 4 + h] = f;
@@ -587,8 +588,8 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       WS_STAMP(p_bar)
     }
     if constexpr (PROF) {
-      if (lane == 0 && blockIdx.x < 64 && wave == 0) {
-        unsigned long long* op = g_ws_prof + blockIdx.x * 16;
+      if (lane == 0 && bid < 64 && wave == 0) {
+        unsigned long long* op = g_ws_prof + bid * 16;
         op[0] = p_first; op[1] = p_read; op[2] = p_comp; op[3] = p_bar; op[4] = p_x - p_t0;
       }
     }
@@ -684,8 +685,8 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       WS_STAMP(p_bar)
     }
     if constexpr (PROF) {
-      if (lane == 0 && blockIdx.x < 64) {
-        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+      if (lane == 0 && bid < 64) {
+        unsigned long long* o = g_ws_prof + bid * 16;
         o[0] = p_first; o[1] = p_read; o[2] = p_comp; o[3] = p_bar; o[4] = p_x - p_t0;
       }
     }
@@ -822,12 +823,12 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
       if ((r + 1) * LEAD < nch + 2) run_trip(rawB, rawA, r + 1);
     }
     if constexpr (PROF) {
-      if (lane == 0 && blockIdx.x < 64 && w == 0) {
-        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+      if (lane == 0 && bid < 64 && w == 0) {
+        unsigned long long* o = g_ws_prof + bid * 16;
         o[5] = p_proc; o[6] = p_bar; o[7] = p_x - p_t0;
       }
-      if (lane == 0 && blockIdx.x < 64 && w == NL - 1 && NL > 1) {      // the last loader wave too
-        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+      if (lane == 0 && bid < 64 && w == NL - 1 && NL > 1) {      // the last loader wave too
+        unsigned long long* o = g_ws_prof + bid * 16;
         o[14] = p_proc; o[15] = p_bar;
       }
     }
@@ -1021,16 +1022,16 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
     }
     store(nch - 1);
     if constexpr (PROF) {
-      if (lane == 0 && blockIdx.x < 64 && s == 0) {
-        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+      if (lane == 0 && bid < 64 && s == 0) {
+        unsigned long long* o = g_ws_prof + bid * 16;
         o[8] = p_st; o[9] = p_bar; o[10] = ws_clock() - p_t0;
       }
-      if (lane == 0 && blockIdx.x == 0 && gridDim.x <= 32) {             // (small grids: every storer wave of workgroup 0, rows 32 .. 32 + NS)
+      if (lane == 0 && bid == 0 && gridDim.x <= 32) {             // (small grids: every storer wave of workgroup 0, rows 32 .. 32 + NS)
         unsigned long long* o = g_ws_prof + (32 + s) * 16;
         o[8] = p_st; o[9] = p_bar;
       }
-      if (lane == 0 && blockIdx.x < 64 && s == NS - 1 && NS > 1) {      // the last storer wave too
-        unsigned long long* o = g_ws_prof + blockIdx.x * 16;
+      if (lane == 0 && bid < 64 && s == NS - 1 && NS > 1) {      // the last storer wave too
+        unsigned long long* o = g_ws_prof + bid * 16;
         o[11] = p_st; o[12] = p_bar;
       }
     }
