@@ -59,7 +59,7 @@ class SawyerCfg(C.Structure):   # struct earl_sawyer_cfg (include/earl_physics.h
 class SawyerState(C.Structure):
   _fields_ = [('qpos', C.c_void_p), ('qvel', C.c_void_p), ('mocap_pos', C.c_void_p), ('goal', C.c_void_p),
               ('steps_since_reset', C.c_void_p), ('steps_since_goal_change', C.c_void_p), ('obj_init', C.c_void_p),
-              ('last_obs', C.c_void_p), ('fail_count', C.c_void_p)]
+              ('last_obs', C.c_void_p), ('fail_count', C.c_void_p), ('sched', C.c_void_p)]
 
 
 class SawyerOut(C.Structure):
@@ -142,6 +142,7 @@ SIGNATURES = {
     'earl_sawyer_cfg_size': [],
     'earl_debug_set_physics_lanes': [C.c_int],
     'earl_debug_set_door_variant': [C.c_int],
+    'earl_debug_set_peg_schedule': [C.c_int],
     'earl_kitchen_step': [C.c_void_p, C.c_void_p, _P(KitchenParams), _P(KitchenCfg), _P(KitchenState), C.c_void_p, _P(KitchenOut), C.c_void_p],
     'earl_kitchen_rollout': [C.c_void_p, C.c_void_p, _P(KitchenParams), _P(KitchenCfg), _P(KitchenState), C.c_void_p, C.c_int32, _P(KitchenOut), C.c_void_p],
     'earl_sawyer_rollout': [C.c_void_p, C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_int32, _P(SawyerOut), C.c_void_p],

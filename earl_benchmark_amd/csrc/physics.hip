@@ -2223,7 +2223,58 @@ struct SawyerArgs {
   earl_sawyer_out out;
   const double* reset_qpos; const double* reset_qvel; const uint8_t* mask; double* reset_obs;
   int observe_only;
+  int slice;                     // SLICED rollout: env steps per work item (0: one item = the whole rollout of a group)
 };
+
+// Work queue of the time-sliced rollout (earl_sawyer_state.sched: progress[G] then lock[G], zero on entry).  An env group's state is in HBM after every env
+// step (the failure guard's "last stable state"), so ANY wave can take the group's next slice of env steps; a wave claims the unlocked group that has come
+// LEAST far.  The groups whose envs are in contact -- the slow chains a statically scheduled launch waits for at the end of its second round -- are then
+// re-claimed the moment they are released and run without a break from the start, while the fast groups share the other wave slots: the launch tends to
+// total work / wave slots instead of (typical wave) + (slowest wave).  Results do not depend on the schedule: an env's arithmetic is its own.
+// `home`: where this wave starts looking among groups that have come equally far (its own index in the launch x 2): at the start every group stands at 0, and
+// a thousand waves going for group 0 at once would fight over every lock in turn
+__device__ __forceinline__ int sched_claim(int32_t* sched, const int G, const int T, const int lane, const int home, int& t0) {
+  int32_t* progress = sched;
+  int32_t* lock = sched + G;
+  for (;;) {
+    unsigned long long best = ~0ull;
+    for (int gi = lane; gi < G; gi += 64) {
+      const int p = __hip_atomic_load(progress + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int l = __hip_atomic_load(lock + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int rot = gi >= home ? gi - home : gi - home + G;                 // distance from `home`, going up and around
+      const unsigned long long key = ((unsigned long long)(unsigned int)p << 32) | (unsigned int)rot;
+      best = (l == 0 && p < T && key < best) ? key : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(best, off);
+      best = o < best ? o : best;
+    }
+    if (best == ~0ull) return -1;                       // every unfinished group is in some wave's hands: nothing to do for this one
+    const int rot_ = (int)(best & 0xFFFFFFFFull);
+    const int gi = rot_ + home < G ? rot_ + home : rot_ + home - G;
+    int ok = 0;
+    if (lane == 0) ok = atomicCAS(lock + gi, 0, 1) == 0 ? 1 : 0;
+    ok = __shfl(ok, 0);
+    if (!ok) continue;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows the previous holder of this group wrote
+    const int p = __hip_atomic_load(progress + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p >= T) {                                       // (finished between the scan and the lock)
+      if (lane == 0) __hip_atomic_store(lock + gi, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    t0 = p;
+    return gi;
+  }
+}
+__device__ __forceinline__ void sched_release(int32_t* sched, const int G, const int g, const int t1, const int lane) {
+  fence();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // state rows, output rows, goal rows of this slice -> visible to the next holder
+  if (lane == 0) {
+    __hip_atomic_store(sched + g, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(sched + G + g, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 // metaworld reward_utils.tolerance(x, bounds=(0, hi), margin, sigmoid='gaussian') [UPSTREAM, dm_control semantics; unpinned]
 __device__ __forceinline__ double tolerance_gaussian(double x, double hi, double margin) {
@@ -2389,7 +2440,9 @@ __device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const typename ModelO
 #ifndef EARL_WAVES_PER_EU
 #define EARL_WAVES_PER_EU 1
 #endif
-template <int NV, int LPE>
+// SLICED: the launch's work is a queue of (env group, slice of a.slice env steps) items (sched_claim above) taken by persistent waves, instead of one
+// whole rollout of one group per wave
+template <int NV, int LPE, bool SLICED = false>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_rollout_kernel(const SawyerArgs a) {
   static_assert(LPE >= 14, "the observation is written by 14 lanes");
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
@@ -2404,23 +2457,31 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
 #ifdef EARL_PHYS_PROF
   const unsigned long long wave_t0 = __builtin_readcyclecounter();
 #endif
-  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
-  const bool live = env_raw < n;
-  const int env = live ? env_raw : n - 1;
   Shared<NV>& s = sh[wave * EPW + grp];
-  load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   if constexpr (Lim<NV>::TS < Lim<NV>::NT) {            // the mass-matrix entries between the two trees are never written (K5): zero, once
     for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
   }
+  const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
+  const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
+  const float scale = (float)cfg.action_scale;
+  const int G = (n + EPW - 1) / EPW;                     // env groups (one per wave at a time)
+  for (;;) {
+  int group = blockIdx.x * WPB + wave, t_begin = 0, t_end = a.T;
+  if constexpr (SLICED) {
+    group = sched_claim(a.st.sched, G, a.T, lane, (int)(((blockIdx.x * WPB + wave) * 2) % G), t_begin);
+    if (group < 0) break;
+    t_end = t_begin + a.slice < a.T ? t_begin + a.slice : a.T;
+  }
+  const int env_raw = group * EPW + grp;
+  const bool live = env_raw < n;
+  const int env = live ? env_raw : n - 1;
+  load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
   if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
   fence();
-  const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
   int steps = a.st.steps_since_reset ? a.st.steps_since_reset[env] : 0;
-  const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
   int sgc = gcf > 0 ? a.st.steps_since_goal_change[env] : 0;
-  const float scale = (float)cfg.action_scale;
   RSTART();
-  for (int t = 0; t < a.T; ++t) {
+  for (int t = t_begin; t < t_end; ++t) {
     const float4 act = *reinterpret_cast<const float4*>(a.action + ((size_t)t * n + env) * 4);
     // set_xyz_action [UPSTREAM]: clip, float32 product with the scale, float64 add, box clip
     const float cx = fminf(fmaxf(act.x, -1.f), 1.f) * scale, cy = fminf(fmaxf(act.y, -1.f), 1.f) * scale, cz = fminf(fmaxf(act.z, -1.f), 1.f) * scale;
@@ -2497,14 +2558,18 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next step's observation reads the goal row back through global memory
     }
   }
+  if (live) {
+    // (qpos / qvel / mocap_pos were written back after the last stable step)
+    if (t_end == a.T && a.st.last_obs && a.T > 0 && sub < 14) a.st.last_obs[(size_t)env * 14 + sub] = a.out.obs[((size_t)(a.T - 1) * n + env) * 14 + sub];
+    if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
+    if (sub == 0 && gcf > 0) a.st.steps_since_goal_change[env] = sgc;
+  }
+  if constexpr (SLICED) sched_release(a.st.sched, G, group, t_end, lane);
+  else break;
+  }
 #ifdef EARL_PHYS_PROF
   if (lane == 0 && blockIdx.x * WPB + wave < 4096) g_wave_cycles[blockIdx.x * WPB + wave] = __builtin_readcyclecounter() - wave_t0;
 #endif
-  if (!live) return;
-  // (qpos / qvel / mocap_pos were written back after the last stable step)
-  if (a.st.last_obs && a.T > 0 && sub < 14) a.st.last_obs[(size_t)env * 14 + sub] = a.out.obs[((size_t)(a.T - 1) * n + env) * 14 + sub];
-  if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
-  if (sub == 0 && gcf > 0) a.st.steps_since_goal_change[env] = sgc;
 }
 
 // reset (masked) / observe: both end with the kinematics of the current state and the observation
@@ -2903,6 +2968,9 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
   const int env = in_batch ? env_raw : n - 1;           // idle groups shadow the last env and store nothing
   const bool live = in_batch && (!RESET || !a.mask || a.mask[env] != 0);      // (a reset leaves the envs outside the mask alone: their groups compute and discard)
   SH& s = sh[wave * EPW + grp];
+#ifdef EARL_PHYS_PROF
+  const unsigned long long wave_t0 = __builtin_readcyclecounter();
+#endif
   const double ctrl0[EARL_MAXACT] = {0, 0, 0, 0};
   auto timestep = [&](const bool warm) {
     if constexpr (ARROW) {
@@ -3087,6 +3155,9 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
       }
       if (a.st.last_obs && a.T > 0) a.st.last_obs[(size_t)env * 32 + sub] = a.out.obs[((size_t)(a.T - 1) * n + env) * 32 + sub];
     }
+#ifdef EARL_PHYS_PROF
+    if (lane == 0 && blockIdx.x * WPB + wave < 4096) g_wave_cycles[blockIdx.x * WPB + wave] = __builtin_readcyclecounter() - wave_t0;
+#endif
   }
 }
 #endif   // EARL_PHYS_VARIANT_MT
@@ -3104,6 +3175,10 @@ int launched(const char* what) {
 #ifdef EARL_PHYS_VARIANT_MT
 int g_mt_stepper = 1;     // earl_debug_set_minitaur_stepper: 1 = the tree-structured timestep (minitaur_stepper.h), 0 = the generic substep<22>
 #endif
+#ifndef EARL_PEG_SLICE
+#define EARL_PEG_SLICE 10   // env steps per work item (tools/bench_peg_schedule.py: 5 and 10: 43.1 ms, 20: 44.3, 40: 47.0, 100: 50.9, one group per wave: 54.8) of the peg's time-sliced schedule (a slice is ~1 ms; claiming one costs a scan of the queue: microseconds)
+#endif
+int g_peg_sliced = 1;     // earl_debug_set_peg_schedule
 int g_door_variant = 0;   // earl_debug_set_door_variant: 0 = by batch size, 1 = four single-wave workgroups per CU, 2 = one eight-wave workgroup per CU
 int g_lpe = 16;   // lanes per env (earl_debug_set_physics_lanes): 16 = four envs per wavefront, 64 = one wavefront per env
 
@@ -3181,6 +3256,9 @@ int earl_debug_set_minitaur_stepper(int tree) {          // 1 (default): minitau
   return EARL_OK;
 }
 #ifdef EARL_PHYS_PROF
+int earl_debug_read_wave_cycles_mt(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_cycles), sizeof(unsigned long long) * 4096) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
 int earl_debug_read_phys_profile_mt(unsigned long long* out, int reset) {          // this unit's own copy of the phase counters (tools/prof_minitaur.py)
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_prof), sizeof(unsigned long long) * 32) != hipSuccess) return EARL_ERR_LAUNCH;
   if (reset) {
@@ -3232,7 +3310,15 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
     else sawyer_rollout_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
   } else if (nv == 15) {
     if (g_lpe == 64) sawyer_rollout_kernel<15, 64><<<grid_for<15, 64>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
-    else sawyer_rollout_kernel<15, 16><<<grid_for<15, 16>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
+    else {
+      // more workgroups than the GPU holds at once (one four-wave workgroup = 16 envs per CU): time-sliced schedule, one persistent workgroup per CU
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (st->sched && g_peg_sliced && grid_for<15, 16>(cfg->n) > cus && T > 1) {
+        a.slice = g_peg_sliced >= 2 ? g_peg_sliced : EARL_PEG_SLICE;
+        sawyer_rollout_kernel<15, 16, true><<<cus, block_for<15>(), 0, (hipStream_t)stream>>>(a);
+      } else sawyer_rollout_kernel<15, 16><<<grid_for<15, 16>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
+    }
   } else return EARL_ERR_ARG;
   return launched("sawyer_rollout");
 }
@@ -3348,6 +3434,11 @@ int earl_physics_model24_size(void) { return (int)sizeof(earl_link_model24); }
 int earl_collision_model_size(void) { return (int)sizeof(earl_collision_model); }
 int earl_sawyer_cfg_size(void) { return (int)sizeof(earl_sawyer_cfg); }
 
+int earl_debug_set_peg_schedule(int sliced) {          // 0: one group per wave; 1: time-sliced, EARL_PEG_SLICE env steps per item; k >= 2: time-sliced, k env steps per item
+  if (sliced < 0) return EARL_ERR_ARG;
+  g_peg_sliced = sliced;
+  return EARL_OK;
+}
 int earl_debug_set_door_variant(int v) {
   if (v < 0 || v > 2) return EARL_ERR_ARG;
   g_door_variant = v;

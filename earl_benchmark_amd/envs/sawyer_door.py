@@ -109,6 +109,10 @@ class SawyerDoor:
                                 goal=self.goal_t.data_ptr(), steps_since_reset=self.steps_since_reset.data_ptr(),
                                 steps_since_goal_change=self.steps_since_goal_change.data_ptr(), obj_init=self.obj_init.data_ptr(),
                                 last_obs=self.last_obs.data_ptr(), fail_count=self.fail_count.data_ptr())
+    # scratch of the time-sliced schedule (include/earl_physics.h earl_sawyer_state.sched; used by the peg model's rollout for batches larger than one round)
+    self.sched = torch.zeros(2 * ((self.num_envs + 3) // 4), dtype=torch.int32, device=dev) if self.nv >= 15 else None
+    if self.sched is not None:
+      self._st.sched = self.sched.data_ptr()
     self._cfg_ref, self._st_ref = C.byref(self._cfg), C.byref(self._st)
 
     self.action_space = Box(-1.0, 1.0, (4,), np.float32)
@@ -178,6 +182,8 @@ class SawyerDoor:
                        success=_ptr(out.get('success')), status=_ptr(out.get('status')), info=_ptr(info) if in_kernel else None)
     self._cfg.step_counter = self.total_step_count
     with torch.cuda.device(self.device):
+      if self.sched is not None and T > 1:
+        self.sched.zero_()                                 # (the queue of the time-sliced schedule: zero on entry)
       _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.model.col_ptr, self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),
                                                T, C.byref(o), self._stream()), 'earl_sawyer_rollout')
       if info is not None and not in_kernel:               # the door's dict is a function of the emitted observation rows

@@ -223,6 +223,11 @@ typedef struct earl_sawyer_state {
                                    written by earl_sawyer_reset and at the end of earl_sawyer_rollout, read when the FIRST step of a launch
                                    diverges (later steps copy the previous row of the launch's own output) */
   int32_t* fail_count;          /* [n] may be NULL: env steps that diverged and were rolled back (see earl_sawyer_out.status) */
+  int32_t* sched;               /* may be NULL.  Scratch of the TIME-SLICED schedule of earl_sawyer_rollout: 2 * ceil(n / 4) int32, ZERO on entry (the caller clears it
+                                   before every call).  When given, and the batch is larger than what the GPU holds at once (peg model: more than 16 envs per CU),
+                                   the launch is a queue of (group of 4 envs, slice of 10 env steps) items taken by persistent waves, least-advanced group first,
+                                   instead of one whole rollout per wave: the slow groups (envs in contact) run without a break while the fast ones share the other
+                                   wave slots.  Same results (an env's arithmetic does not depend on who runs it, tests/test_sawyer_full_gpu.py); NULL = one group per wave */
 } earl_sawyer_state;
 
 typedef struct earl_sawyer_out {
@@ -414,6 +419,9 @@ int earl_debug_set_minitaur_stepper(int tree);
 /* measurement / test switch for the door model's rollout: 0 (default) = by batch size (n > 4096: one eight-wave workgroup per CU, see
  * csrc/physics_w8.hip; otherwise four single-wave workgroups per CU), 1 / 2 force the one or the other.  Results are bit-identical. */
 int earl_debug_set_door_variant(int variant);
+/* measurement / test switch for the peg model's rollout: 1 (default) = time-sliced schedule when earl_sawyer_state.sched is given and the batch exceeds one round,
+ * 0 = always one group per wave, k >= 2 = time-sliced with k env steps per work item.  Results are bit-identical. */
+int earl_debug_set_peg_schedule(int sliced);
 
 /* sizeof(earl_link_model) as compiled into the library (bindings check their struct layout against it) */
 int earl_physics_model_size(void);

@@ -23,6 +23,7 @@ import torch
 from earl_benchmark_amd import _abi
 _abi.LIB_PATH = LIB
 _abi.SIGNATURES['earl_debug_read_phys_profile_mt'] = [C.c_void_p, C.c_int]
+_abi.SIGNATURES['earl_debug_read_wave_cycles_mt'] = [C.c_void_p]
 from earl_benchmark_amd.envs.minitaur import Minitaur
 args = [int(x) for x in sys.argv[1:] if x.isdigit()]
 n, T = (args + [4096, 100])[:2] if len(args) < 2 else args[:2]
@@ -40,6 +41,11 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 lib.earl_debug_read_phys_profile_mt(out, 1)
+import numpy as np
+wc = (C.c_ulonglong * 4096)()
+lib.earl_debug_read_wave_cycles_mt(wc)
+w = np.array(wc[:min(4096, (n + 1) // 2)], dtype=np.float64) / (T * 5)
+print(f'  wave durations, cycles per timestep: min {w.min():.0f}  p10 {np.percentile(w, 10):.0f}  median {np.median(w):.0f}  mean {w.mean():.0f}  p90 {np.percentile(w, 90):.0f}  p99 {np.percentile(w, 99):.0f}  max {w.max():.0f}')
 ts = max(1, out[20])
 print(f'minitaur N={n} T={T}: launch {ms:.1f} ms = {n * T / ms / 1e3:.2f} M env-steps/s; wave 0: {out[20]} timesteps, with contacts {out[23] / ts:.3f} '
       f'(max contacts per env, mean {out[24] / ts:.2f}), Newton iterations per timestep {out[25] / ts:.2f}')
