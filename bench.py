@@ -536,6 +536,8 @@ def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8
          'kernel_ms': gpu_ms, 'timesteps_per_s': steps * n * T * world * 5 / dt, 'diverged_env_steps_last_rollout': diverged,
          'config': {'workload': f'{workload} {a.reward} reward, {n} batched envs per MI355X, reset + fused {T}-step rollout '
                                 f'(5 timesteps per env step) per bench step; own stepper incl. contacts, parity with MuJoCo unpinned',
+                    'schedule': ('one launch; persistent waves take (group of 4 envs, 10-step slice) items from a queue, least-advanced group first (csrc/physics.hip sched_claim)'
+                                 if (peg and n > 4096) else 'one launch; one env group per wave' + (' (eight waves per CU)' if n > 4096 else '')),
                     'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
                     'parallelism': f'env-range shard x{world}, no per-step collective'},
          'valu_frac': roof['frac'], 'roofline': roof,

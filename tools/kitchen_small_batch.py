@@ -1,0 +1,37 @@
+"""how long does a SHARD of the kitchen / minitaur strong-scaling batches take on one GPU?  reset + one fused launch of the full horizon for
+n = the 8-, 4-, 2- and 1-GPU shard sizes (same seeds per env id: the shard's envs are the batch's first n).   python tools/kitchen_small_batch.py > profiles/r04_kitchen_small_batch.txt"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from earl_benchmark_amd.envs.kitchen import Kitchen
+from earl_benchmark_amd.envs.minitaur import Minitaur
+from earl_benchmark_amd.wrappers import PersistentStateWrapper
+
+
+def run(make, n, T, adim, reps=2):
+  env = PersistentStateWrapper(make(n), T)
+  g = torch.Generator(device='cuda').manual_seed(77)
+  acts = (torch.rand(T, n, adim, generator=g, device='cuda') * 2 - 1).float()
+  out = {}
+  env.reset(); env.unwrapped.rollout(acts, out=out)
+  torch.cuda.synchronize()
+  best = 1e9
+  for _ in range(reps):
+    t0 = time.perf_counter()
+    env.reset(); env.unwrapped.rollout(acts, out=out)
+    torch.cuda.synchronize()
+    best = min(best, time.perf_counter() - t0)
+  return best
+
+
+print(f'device: {torch.cuda.get_device_name(0)}')
+for name, make, N, T, adim in (('kitchen', lambda n: Kitchen(num_envs=n, seed=1234), 2048, 400, 9),
+                               ('minitaur', lambda n: Minitaur(num_envs=n, seed=1234, scalar_api=False), 4096, 1000, 8)):
+  full = None
+  for w in (1, 2, 4, 8):
+    n = N // w
+    dt = run(make, n, T, adim)
+    full = dt if full is None else full
+    print(f'{name}: shard of {w} GPU(s) = {n:5d} envs x {T} steps: {dt * 1e3:8.1f} ms per reset + launch = {dt / full:5.2f} x the {N}-env launch; '
+          f'{w} such GPUs would deliver {N * T / dt / 1e6:6.2f} M env-steps/s ({full / dt:4.2f} x one GPU)')
