@@ -13,8 +13,7 @@ def run(make, n, T, adim, reps=2):
   env = PersistentStateWrapper(make(n), T)
   g = torch.Generator(device='cuda').manual_seed(77)
   acts = (torch.rand(T, n, adim, generator=g, device='cuda') * 2 - 1).float()
-  out = {}
-  env.reset(); env.unwrapped.rollout(acts, out=out)
+  env.reset(); out = env.unwrapped.rollout(acts)
   torch.cuda.synchronize()
   best = 1e9
   for _ in range(reps):
