@@ -2523,6 +2523,16 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
         store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
         if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = s.mocap[sub];
       }
+      if constexpr (NV >= 15) {
+        // the free body's orientation as load_state would read it back from the row just stored (re-normalised, the same expression): a rollout, its
+        // time slices taken by different waves, and T single-step launches then walk through the same bits (like the minitaur kernel)
+        if (m.ball_dof >= 0) {
+          const double qn = renormalised_quat_entry<NV>(s, sub);
+          fence();
+          if (sub < 4) s.bq[sub] = qn;
+          fence();
+        }
+      }
     } else {
       load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
       if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];

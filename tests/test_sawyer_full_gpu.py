@@ -207,3 +207,41 @@ def test_door_rollout_variants_are_bit_identical():
     assert bool((res[0][0][key] == res[1][0][key]).all()), key
   assert bool((res[0][1] == res[1][1]).all()) and bool((res[0][2] == res[1][2]).all())
   assert lib.earl_debug_set_door_variant(3) != 0
+
+
+def test_peg_time_sliced_schedule_is_bit_identical_to_one_group_per_wave():
+  """Round 4: for batches larger than one round the peg rollout is a queue of (env group, 10-step slice) items taken by persistent waves (csrc/physics.hip sched_claim;
+  include/earl_physics.h earl_sawyer_state.sched).  An env's arithmetic does not depend on who runs it or when: every output and the final state equal the static
+  schedule's bit for bit, for slice lengths that do and do not divide the rollout, with the lifelong goal switch on (its goal rows travel through HBM between slices)."""
+  import torch
+  from earl_benchmark_amd import _abi
+  from earl_benchmark_amd.envs.sawyer_peg import SawyerPeg
+  from earl_benchmark_amd.wrappers import LifelongWrapper, PersistentStateWrapper
+  lib = _abi.load()
+  n, T = 8192, 23
+  g = torch.Generator(device='cuda').manual_seed(31)
+  acts = (torch.rand(T, n, 4, generator=g, device='cuda') * 2 - 1).float()
+  acts[:, :, 2] = -acts[:, :, 2].abs()                                          # down to the table: contacts, grasps
+  ref = None
+  try:
+    for k in (0, 1, 7, 2):                                                      # static; queue with slices of 10 (default), 7 and 2 env steps
+      lib.earl_debug_set_peg_schedule(k)
+      env = LifelongWrapper(PersistentStateWrapper(SawyerPeg(num_envs=n, seed=77, reset_at_goal=True), 100), 9)
+      env.reset()
+      out = env.rollout(acts)
+      torch.cuda.synchronize()
+      got = {kk: out[kk].clone() for kk in ('obs', 'reward', 'done', 'success', 'status', 'info')}
+      got.update(qpos=env.unwrapped.qpos.clone(), qvel=env.unwrapped.qvel.clone(), goal=env.unwrapped.goal_t.clone(), steps=env.unwrapped.steps_since_reset.clone(),
+                 last_obs=env.unwrapped.last_obs.clone(), lret=env.unwrapped.lifelong_return_t.clone())
+      assert bool(torch.isfinite(got['obs']).all())
+      if ref is None:
+        ref = got
+      else:
+        for kk in ref:
+          assert torch.equal(ref[kk], got[kk]), (k, kk)
+    assert int((ref['goal'] != ref['goal'][0]).any()) == 1                       # goals were switched along the way (reverse task: 15 goal rows)
+    sched = env.unwrapped.sched.cpu().numpy()
+    G = (n + 3) // 4
+    assert (sched[:G] == T).all() and (sched[G:] == 0).all()                     # every group ran to the end, every lock released
+  finally:
+    lib.earl_debug_set_peg_schedule(1)
