@@ -207,6 +207,8 @@ def load_collision_model(d):
   assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS
   nvm = len(d['parent'])
   assert c.n_blk <= (16 if small else (64 if nvm == 23 else (8 if nvm == 22 else 32))) and 0 < c.max_con <= (8 if small else MAXCON)      # Lim<NV>::MB, ::MC
+  if nvm == 23:      # csrc/physics.hip Lim<23>::PACK: several near blocks share a pass of the group's 32 lanes; a block must fit one pass
+    assert int(np.max(np.asarray(d['col_blk_end']) - np.asarray(d['col_blk_begin']))) <= 32, 'kitchen collision blocks: at most 32 pairs each'
   if nvm == 22:
     # csrc/physics.hip (Lim<22>::CONNECT, K9): a contact's Jacobian is taken to touch the root body's six dofs and the sphere's own chain of at most
     # two hinges -- spheres ride on the root body or on such a chain, boxes are fixed to the world
