@@ -89,7 +89,7 @@ def synth_actions(torch, T, n, rank, device, episodes=1):
 
 def alloc_out(torch, T, n, device, episodes=1):
   # zeros, not empty: the buffers are written once here, at allocation (a launch that is the FIRST to write a region of device memory runs
-  # measurably slower, tools/repro20.py); every warm-up launch then writes every row again -- the launch shape does not depend on --steps
+  # measurably slower, tools/archive/repro20.py); every warm-up launch then writes every row again -- the launch shape does not depend on --steps
   lead = (T, n) if episodes == 1 else (episodes, T, n)
   return (torch.zeros(*lead, 12, dtype=torch.float32, device=device), torch.zeros(*lead, dtype=torch.float32, device=device),
           torch.zeros(*lead, dtype=torch.bool, device=device), torch.zeros(*lead, dtype=torch.bool, device=device))
@@ -913,7 +913,7 @@ def main():
                           'after the other on the batch\'s 64 workgroups -- the reference\'s evaluation loop taken literally'}
   total_env_steps = a.steps * E * n * T * world
   value = total_env_steps / dt
-  # cross-check of the headline: 60 more of the same launches, the last 40 timed (tools/placement_experiment.py: the first ~30 launches of a process run
+  # cross-check of the headline: 60 more of the same launches, the last 40 timed (tools/archive/placement_experiment.py: the first ~30 launches of a process run
   # 5-15 % faster than the ones after ~10 ms of back-to-back traffic); `value` itself is measured after --settle-launches + --warmup untimed launches
   sustained = None
   if E > 1 and not a.no_single:

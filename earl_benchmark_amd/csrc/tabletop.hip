@@ -419,7 +419,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
 #define EARL_WSM(RT, NC, NL, NS, K, LEAD) \
   rollout_ws_kernel<RT, NC, NL, NS, K, LEAD, false, true><<<grid, 64 * (((NC) == 3 ? 2 : (NC)) + NL + NS), g_rollout_lds_pad, hs>>>(w)
       if (cfg->reward_type == EARL_REWARD_SPARSE) {
-        switch (g_rollout_impl) {   // tuning variants (tools/tune_rollout.py); 0 = the shipped configuration
+        switch (g_rollout_impl) {   // tuning variants (tools/archive/tune_rollout.py); 0 = the shipped configuration
           case 2: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 4, 6); break;
           case 3: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 8, 3); break;
           case 4: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 4, 6); break;
@@ -449,7 +449,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 9: rollout_ws_kernel<EARL_REWARD_SPARSE, 2, 4, 4, 8, 3, true><<<grid, 64 * 10, 0, hs>>>(w); break;  // stamps
           case 19: rollout_ws_kernel<EARL_REWARD_SPARSE, 1, 4, 4, 8, 3, true><<<grid, 64 * 9, 0, hs>>>(w); break;  // stamps
 #define EARL_WSX(K, LEAD, NT) rollout_ws_kernel<EARL_REWARD_SPARSE, 3, 2, 8, K, LEAD, false, true, NT><<<grid, 64 * 12, g_rollout_lds_pad, hs>>>(w)
-          // experiments on the multi-episode launch with per-episode actions (tools/own_actions_experiment.py): prefetch depth, chunk length, nt loads
+          // experiments on the multi-episode launch with per-episode actions (tools/archive/own_actions_experiment.py): prefetch depth, chunk length, nt loads
           case 40: if (episodes > 1) { EARL_WSX(16, 3, false); break; } [[fallthrough]];
           case 41: if (episodes > 1) { EARL_WSX(8, 3, false); break; } [[fallthrough]];
           case 42: if (episodes > 1) { EARL_WSX(8, 4, false); break; } [[fallthrough]];
@@ -462,7 +462,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 38:
           default:
             // 2 compute waves with x / y in adjacent lanes (DPP, VGPR-only masks) + 2 loaders + 8 storers, 8-step chunks:
-            // fastest of the variants above at N = 4096 and not slower at any larger N measured (tools/tune_rollout.py;
+            // fastest of the variants above at N = 4096 and not slower at any larger N measured (tools/archive/tune_rollout.py;
             // profiles/r01_tune_rollout.txt).  Variant 11 is the previous default (lane-half layout, 4 storers).
             // Two loaders, not four: fewer waves compete with the compute waves for issue slots (4 loaders: 30.4 us, 2: 29.0 us
             // at N = 4096, T = 200).  Large grids (more than one workgroup per CU) prefer shorter loader trips (LEAD 2):
