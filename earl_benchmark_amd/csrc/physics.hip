@@ -3397,6 +3397,14 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
   SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
   if (cfg->obj_kind >= 1 && cfg->reward_type != 0 && (!st->obj_init || cfg->att_grasp < 0 || cfg->att_lpad < 0 || cfg->att_rpad < 0))
     return EARL_ERR_ARG;                                  // the peg's dense reward needs the reset-time state and the pad / grasp attachments
+  if (nv == 10 && g_lpe != 64 && g_door_variant == 3 && st->sched && T > 1) {
+    // (measurement switch: the single-wave build, four workgroups per CU, under the time-sliced work queue of the peg -- tools/bench_variant.py)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    a.slice = g_peg_sliced >= 2 ? g_peg_sliced : EARL_PEG_SLICE;
+    sawyer_rollout_kernel<10, 16, true><<<4 * cus, block_for<10>(), 0, (hipStream_t)stream>>>(a);
+    return launched("sawyer_rollout (door, time-sliced)");
+  }
   if (nv == 10 && g_lpe != 64 && (g_door_variant == 2 || (g_door_variant == 0 && cfg->n > 4096)))
     return earl_sawyer_rollout_door_w8(model, col, cfg, st, action, T, out, stream);      // eight waves per CU: wins from two rounds of 4096 envs on
   if (nv == 10) {
@@ -3534,7 +3542,7 @@ int earl_debug_set_peg_schedule(int sliced) {          // 0: one group per wave;
   return EARL_OK;
 }
 int earl_debug_set_door_variant(int v) {
-  if (v < 0 || v > 2) return EARL_ERR_ARG;
+  if (v < 0 || v > 3) return EARL_ERR_ARG;
   g_door_variant = v;
   return EARL_OK;
 }

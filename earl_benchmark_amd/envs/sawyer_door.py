@@ -110,7 +110,7 @@ class SawyerDoor:
                                 steps_since_goal_change=self.steps_since_goal_change.data_ptr(), obj_init=self.obj_init.data_ptr(),
                                 last_obs=self.last_obs.data_ptr(), fail_count=self.fail_count.data_ptr())
     # scratch of the time-sliced schedule (include/earl_physics.h earl_sawyer_state.sched; used by the peg model's rollout for batches larger than one round)
-    self.sched = torch.zeros(2 * ((self.num_envs + 3) // 4), dtype=torch.int32, device=dev) if self.nv >= 15 else None
+    self.sched = torch.zeros(2 * ((self.num_envs + 3) // 4), dtype=torch.int32, device=dev)
     if self.sched is not None:
       self._st.sched = self.sched.data_ptr()
     self._cfg_ref, self._st_ref = C.byref(self._cfg), C.byref(self._st)

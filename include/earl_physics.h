@@ -417,7 +417,8 @@ int earl_minitaur_cfg_size(void);
 int earl_debug_set_minitaur_stepper(int tree);
 
 /* measurement / test switch for the door model's rollout: 0 (default) = by batch size (n > 4096: one eight-wave workgroup per CU, see
- * csrc/physics_w8.hip; otherwise four single-wave workgroups per CU), 1 / 2 force the one or the other.  Results are bit-identical. */
+ * csrc/physics_w8.hip; otherwise four single-wave workgroups per CU), 1 / 2 force the one or the other, 3 = single-wave workgroups under the time-sliced work
+ * queue of the peg (needs earl_sawyer_state.sched; slower than 2 at N = 8192, tools/bench_door_schedule.py).  Results are bit-identical. */
 int earl_debug_set_door_variant(int variant);
 /* measurement / test switch for the peg model's rollout: 1 (default) = time-sliced schedule when earl_sawyer_state.sched is given and the batch exceeds one round,
  * 0 = always one group per wave, k >= 2 = time-sliced with k env steps per work item.  Results are bit-identical. */
