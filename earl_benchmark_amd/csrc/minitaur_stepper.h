@@ -729,6 +729,8 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     }
     KSTAMP(19);
     if (!__any(changed)) break;
+    PCOUNT(10, it == 2 ? 1 : 0);                          // (profiling build: timesteps that go beyond three passes ...
+    PCOUNT(12, it == 6 ? 1 : 0);                          //  ... and those that use all eight)
   }
   PSTAMP(8);
   if constexpr (!INTEGRATE) {

@@ -49,6 +49,7 @@ print(f'  wave durations, cycles per timestep: min {w.min():.0f}  p10 {np.percen
 ts = max(1, out[20])
 print(f'minitaur N={n} T={T}: launch {ms:.1f} ms = {n * T / ms / 1e3:.2f} M env-steps/s; wave 0: {out[20]} timesteps, with contacts {out[23] / ts:.3f} '
       f'(max contacts per env, mean {out[24] / ts:.2f}), Newton iterations per timestep {out[25] / ts:.2f}')
+print(f'  timesteps with more than three passes {out[10] / ts:.3f}, with all eight {out[12] / ts:.4f}')
 print(f'  active-set pass, cycles per timestep: edge weights {out[16] / ts:.0f}, Hessian columns {out[17] / ts:.0f}, factor + solve {out[18] / ts:.0f}, row test {out[19] / ts:.0f}')
-tot = sum(out[:12])
+tot = sum(out[i] for i in range(12) if NAMES[i] != '-')   # slot 10 holds a pass-count tally, not cycles
 print(f'  cycles per timestep {tot / ts:.0f}: ' + ', '.join(f'{NAMES[i].split()[0]} {out[i] / ts:.0f}' for i in range(12) if NAMES[i] != '-'))
