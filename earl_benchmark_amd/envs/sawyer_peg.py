@@ -35,6 +35,7 @@ class SawyerPeg(SawyerDoor):
   """N independent Sawyer peg-insertion envs; state (qpos [N,16], qvel [N,15], mocap) lives in HBM."""
 
   MODEL = 'sawyer_peg'
+  RECORDED_HAND_INIT = (0.0, 0.6, 0.2)       # sawyer_peg.py:70: both variants reset the hand here
   TARGET_RADIUS = 0.05                    # sawyer_peg.py:62
 
   def __init__(self, reward_type='sparse', reset_at_goal=False, wide_init=False, **kw):

@@ -135,6 +135,9 @@ void oracle_newton_stats(long long* out, int reset) {
  * and Jacobian of the orientation rows scale by sqrt 2); 0 = normalised first (round 1, kept as an experiment switch for tools/heldout_eval.py) */
 static int g_raw_mocap_quat = 1;
 int oracle_set_raw_mocap_quat(int raw) { const int prev = g_raw_mocap_quat; g_raw_mocap_quat = raw; return prev; }
+/* experiment hook (tools/weld_free_motion_fit.py): per-row factors on the six weld regularisers, 1 = the tables' value */
+static double g_weld_row_scale[6] = {1, 1, 1, 1, 1, 1};
+void oracle_set_weld_row_scale(const double* s6) { for (int r = 0; r < 6; ++r) g_weld_row_scale[r] = s6 ? s6[r] : 1.0; }
 static Q4 qnormalize(Q4 q) {
   const double s = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   Q4 r = {q.w * s, q.x * s, q.y * s, q.z * s};
@@ -290,7 +293,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       for (int j = 0; j < nv; ++j) Jv += J[r][j] * qv[j];
       kbimp(m->weld_solref, m->weld_solimp, res, dt, &kk, &bb, &dd);
       aref[r] = -bb * Jv - kk * dd * res;
-      D[r] = 1.0 / fmax((1 - dd) / dd * m->weld_invweight[r < 3 ? 0 : 1], 1e-15);
+      D[r] = 1.0 / fmax((1 - dd) / dd * m->weld_invweight[r < 3 ? 0 : 1] * g_weld_row_scale[r], 1e-15);
       iseq[r] = 1; rowid[r] = r;
     }
     nr = 6;

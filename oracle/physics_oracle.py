@@ -28,24 +28,26 @@ def quat_conj(q):
   return np.array([q[0], -q[1], -q[2], -q[3]])
 
 
-# Regulariser of the three TRANSLATIONAL rows of the mocap weld, as a multiple of the value this file derives from the MJCF
-# (R = (1 - d) / d * body_invweight0[hand].translation).  A CALIBRATION against the MuJoCo recordings, declared as such; three
-# independent measurements on two models agree on it ("weld calibration"):
-#   * static sag of the hand under the arm's weight at reset (recorded obs[2] vs mocap z = 0.2): door 5.07 mm -> factor 3.9,
-#     peg 5.70 mm -> factor 4.1 (the derived value gives 1.30 / 1.39 mm);
-#   * hand path over the contact-free first steps of all demonstrations: RMS error minimal at 4 (door 12.3 -> 7.3 mm, peg 6.1 -> 5.0 mm);
-#   * speed of the door while the gripper drags it: with 1.0 the door moves 1.5x faster than recorded, with 4.0 the replayed handle stays
-#     within 5 mm of the recorded one for 9-22 env steps after the door starts to move in all ten door demonstrations (1.0: 0-5 steps).
-# Which MuJoCo 2.1 rule accounts for the factor is not identified.
-WELD_TRANSLATION_CALIBRATION = 4.0
-# The three ROTATIONAL rows carry the derived value.  Round 1 carried a fitted 0.5 here; round 2 replaced it by a RULE: the mocap
-# quaternion enters the weld rows AS GIVEN.  metaworld sets mocap_quat = [1, 0, 1, 0] (norm sqrt 2, SawyerXYZEnv.set_xyz_action
-# [UPSTREAM]); taken unnormalised, the orientation residual vec(conj(q_hand) * q_mocap) and its Jacobian are both scaled by sqrt 2, which
-# doubles the rows' weight -- the same thing as halving their regulariser.  On the recorded episodes the rule and the fitted factor are
-# indistinguishable (tools/heldout_eval.py, profiles/r02_heldout_eval.json: fit-set score 9.51 mm vs 9.52 mm, held-out 14.81 vs 14.79),
-# and a re-fit on the even-numbered episodes alone picks the rule.  Whether MuJoCo 2.1's mj_kinematics really leaves mocap_quat
-# unnormalised cannot be checked here (no MuJoCo source or binary): it is the rule that explains the recordings.
-# The translational factor above has no such explanation; it is FROZEN at 4.0 and justified on held-out episodes (same file).
+# Regularisers of the mocap weld's rows as multiples of the values this file derives from the MJCF
+# (R = (1 - d) / d * body_invweight0[hand], translational / rotational part).  CALIBRATIONS against the MuJoCo recordings, declared as such.
+#
+# Round 4 (tools/weld_free_motion_fit.py -> profiles/r04_weld_free_motion_fit.json): both factors are identified on the
+# CONTACT-FREE prefixes of the recorded Sawyer episodes (door 13 / 38 env steps, peg 11), where the hand path depends only on the arm's
+# MJCF constants, the weld and the state the episode starts from.  Least squares over the start state (one per task) and the two factors,
+# FIT-set episodes (even-numbered) only, door and peg jointly: translation x 3.35, rotation x 0.07; replayed hand path within 0.95 / 0.81 mm
+# RMS of the recorded one (held-out prefixes 1.01 / 0.92 mm; with round 2's (4.0, 1.0): 4.8 / 1.6 mm even with the start state free).  The
+# two tasks fitted separately agree (door 3.2 / 0.06, peg 3.6 / 0.08); freeing the arm's joint damping as well leaves it at 0.9 x the MJCF
+# value, i.e. the arm model is not what absorbs the factors.  What the rotational factor means physically: the wrist's three weld rows are
+# 14 x stiffer than derived, the hand tilts 2 - 3 degrees under the loads of the door pull instead of round 3's 18.
+# Which MuJoCo 2.1 rule produces either factor is not identified (3.35 is close to what body_invweight0 becomes if J M^-1 J^T is replaced
+# by J diag(dof_invweight0) J^T at qpos0, 3.52 -- but the same rule applied to the contact rows makes every replay worse, so it is not adopted).
+# Round 1 - 3 values, for the record: translation 4.0 (read off the hand's sag at reset, which round 4 found to be a transient, not a static
+# quantity), rotation 0.5 (round 1, fitted) = "mocap quaternion unnormalised" (round 2, a rule with the same effect; the quaternion is still
+# taken as given, the factor below is on top of it).
+# Models without recordings (the kitchen) keep the round-2 values: tools/mjcf_compile.py passes them explicitly.
+WELD_TRANSLATION_CALIBRATION = 3.35
+WELD_ROTATION_CALIBRATION = 0.07
+LEGACY_WELD_CALIBRATION = (4.0, 1.0)          # rounds 2 - 3; what a model file without the key 'weld_calibration' was compiled with
 
 
 def quat_mat(q):
@@ -68,6 +70,8 @@ class Model:
       setattr(self, k, np.array(d[k]))
     self.nb, self.nv = len(self.body_parent), len(self.jnt_body)
     self.dt = float(self.timestep)
+    if not hasattr(self, 'weld_calibration'):
+      self.weld_calibration = np.array(LEGACY_WELD_CALIBRATION)
     # ancestors of each dof (dofs whose motion moves the dof's body), incl. itself
     self.body_dofs = [[] for _ in range(self.nb)]
     for j in range(self.nv):
@@ -230,7 +234,7 @@ def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
   for w in range(len(m.weld_body1)):
     b1, b2 = int(m.weld_body1[w]), int(m.weld_body2[w])
     assert m.body_mocap[b1], 'weld body1 is the mocap body in these models'
-    p1, q1 = mocap_pos, np.asarray(mocap_quat, dtype=np.float64)       # as given: NOT normalised (see the note above WELD_TRANSLATION_CALIBRATION)
+    p1, q1 = mocap_pos, np.asarray(mocap_quat, dtype=np.float64)       # as given: NOT normalised (round 2's rule, see the note above WELD_TRANSLATION_CALIBRATION)
     p2, q2 = kin['xpos'][b2], kin['xquat'][b2]
     Jb = body_jacobian(m, S, b2, p2)
     # mj_instantiateEqual, weld with relpose = identity (metaworld's reset_mocap_welds): position error body1 - body2;
@@ -239,11 +243,11 @@ def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
     e = quat_mul(quat_conj(q2), q1)
     R2 = quat_mat(q2)
     for a in range(3):
-      rows.append((-Jb[3 + a], rpos[a], m.weld_solref[w], m.weld_solimp[w], WELD_TRANSLATION_CALIBRATION * m.body_invweight0[b2, 0], True))
+      rows.append((-Jb[3 + a], rpos[a], m.weld_solref[w], m.weld_solimp[w], float(m.weld_calibration[0]) * m.body_invweight0[b2, 0], True))
     A = R2.T @ Jb[0:3]                                        # 3 x nv, angular Jacobian in body2 axes
     Jq = -0.5 * (e[0] * A + np.cross(A.T, e[1:]).T)
     for a in range(3):
-      rows.append((Jq[a], e[1 + a], m.weld_solref[w], m.weld_solimp[w], m.body_invweight0[b2, 1], True))
+      rows.append((Jq[a], e[1 + a], m.weld_solref[w], m.weld_solimp[w], float(m.weld_calibration[1]) * m.body_invweight0[b2, 1], True))
   for j in range(m.nv):
     if m.jnt_limited[j]:
       lo, hi = m.jnt_range[j]
@@ -264,16 +268,22 @@ def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
   return J, res, aref, R, np.array([r[5] for r in rows])
 
 
-def solve_constraints(A, R, rhs, is_eq, iters=50):
-  """(A + R) f = rhs with f >= 0 on the inequality rows: projected Gauss-Seidel"""
+def solve_constraints(A, R, rhs, is_eq, iters=5000):
+  """(A + R) f = rhs with f >= 0 on the inequality rows: projected Gauss-Seidel, swept until the forces stop changing (round 4: the rotational weld rows carry a
+  14 x smaller regulariser, with which the 50 sweeps of rounds 1 - 3 are not enough)"""
   n = len(rhs)
   f = np.zeros(n)
   AR = A + np.diag(R)
   for _ in range(iters):
+    change = 0.0
     for i in range(n):
-      f[i] += (rhs[i] - AR[i] @ f) / AR[i, i]
-      if not is_eq[i] and f[i] < 0:
-        f[i] = 0.0
+      fi = f[i] + (rhs[i] - AR[i] @ f) / AR[i, i]
+      if not is_eq[i] and fi < 0:
+        fi = 0.0
+      change = max(change, abs(fi - f[i]))
+      f[i] = fi
+    if change <= 1e-12 * (1.0 + np.abs(f).max()):
+      break
   return f
 
 
@@ -350,6 +360,7 @@ def inverse_weights(m):
 # the HIP stepper consumes (earl_benchmark_amd/csrc/physics.hip); `LinkModel.step` is its line-by-line reference.
 # ======================================================================================================================
 def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geoms=(), collision=None, weld_translation_calibration=None):
+  # (weld factors: m.weld_calibration, set by tools/mjcf_compile.py; weld_translation_calibration overrides the first one -- experiments)
   """-> dict of arrays: links in an order where parents precede children (the dof order of these models)"""
   bp = m.body_pos if body_pos is None else body_pos
   link_of_body = np.full(m.nb, -1)          # nearest moving ancestor-or-self link of each body (-1: world-fixed)
@@ -420,8 +431,9 @@ def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geo
   out['jeq_invweight'] = np.array([m.dof_invweight0[out['jeq_joint1'][e]] + m.dof_invweight0[out['jeq_joint2'][e]] for e in range(neq)])
   wb = int(m.weld_body2[0])
   out['weld_att'] = np.int32(list(out['att_names']).index(str(m.body_names[wb])))
-  ftr = WELD_TRANSLATION_CALIBRATION if weld_translation_calibration is None else float(weld_translation_calibration)
-  out['weld_invweight'] = m.body_invweight0[wb] * np.array([ftr, 1.0])
+  ftr = float(m.weld_calibration[0]) if weld_translation_calibration is None else float(weld_translation_calibration)
+  out['weld_invweight'] = m.body_invweight0[wb] * np.array([ftr, float(m.weld_calibration[1])])
+  out['weld_calibration'] = np.array(m.weld_calibration, float)
   out['weld_mocap_quat'] = np.array(m.body_quat[int(m.weld_body1[0])])          # the mocap body's orientation in the model (its mocap_quat after sim.reset())
   out['weld_mocap_pos'] = np.array(m.body_pos[int(m.weld_body1[0])])
   # generalized coordinates: qpos has one entry per dof, except that a free body's orientation is a unit quaternion

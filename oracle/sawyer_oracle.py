@@ -18,6 +18,16 @@ MOCAP_QUAT = np.array([1.0, 0.0, 1.0, 0.0])
 # timesteps of the reset settle: the converged pose, not the reference's 250-timestep transient (see earl_benchmark_amd/envs/sawyer_door.py:
 # the demonstrations show MuJoCo ending that transient with a vertical gripper; this stepper's transient takes 1,000 timesteps to get there)
 SETTLE_TIMESTEPS = 2000
+
+
+def recorded_reset(lm, hand_init_pos, default_hand, q, v, reset_state):
+  """Round 4: the arm's seven angles and speeds at the start of every recorded episode of the task (tables reset_qpos_recorded / reset_qvel_recorded,
+  tools/weld_free_motion_fit.py) replace the converged ones when the env resets the hand where the recordings do; fingers and object keep the settled values.
+  Mirrors earl_benchmark_amd/envs/sawyer_door.py _settle_reset_hand."""
+  if reset_state == 'recorded' and hasattr(lm, 'reset_qpos_recorded') and np.allclose(hand_init_pos, default_hand):
+    q, v = q.copy(), v.copy()
+    q[:7], v[:7] = lm.reset_qpos_recorded, lm.reset_qvel_recorded
+  return q, v
 OBJ_INIT_POS = np.array([0.1, 0.95, 0.1], dtype=np.float32).astype(np.float64)                     # :36
 BAD_VALUE = 1e10            # EARL_BAD_VALUE (MuJoCo's mjMAXVAL): beyond it, or NaN, an env step is rolled back
 
@@ -67,8 +77,9 @@ def door_info(obs, reward_type, hand_init_pos):
 class SawyerDoorOracle:
   """one env instance (global id `env_id`), scalar loops"""
 
-  def __init__(self, link_model, reward_type='sparse', reset_at_goal=False, seed=0, env_id=0, horizon=0, frame_skip=5):
+  def __init__(self, link_model, reward_type='sparse', reset_at_goal=False, seed=0, env_id=0, horizon=0, frame_skip=5, reset_state='recorded'):
     self.lm, self.reward_type, self.seed, self.env_id, self.horizon, self.frame_skip = link_model, reward_type, seed, env_id, horizon, frame_skip
+    self.reset_state = reset_state
     names = [str(x) for x in link_model.att_names]
     self.k_hand, self.k_right, self.k_left, self.k_obj = (names.index(x) for x in ('hand', 'rightEndEffector', 'leftEndEffector', 'handle'))
     self.obj_dof = link_model.nv - 1
@@ -84,7 +95,7 @@ class SawyerDoorOracle:
       q, v = np.zeros(self.lm.nv), np.zeros(self.lm.nv)
       for _ in range(SETTLE_TIMESTEPS):
         q, v, _ = self.lm.step(q, v, np.array([-1.0, 1.0]), self.hand_init_pos, MOCAP_QUAT)
-      self._settled = (q, v)
+      self._settled = recorded_reset(self.lm, self.hand_init_pos, [0, 0.4, 0.2], q, v, self.reset_state)
     return self._settled
 
   def obs_from(self, pos, quat):
@@ -239,8 +250,9 @@ class SawyerPegOracle(SawyerDoorOracle):
      is_successful :301-305 (radius 0.05); SawyerXYZEnv.step / _reset_hand / _set_obj_xyz are upstream metaworld."""
 
   def __init__(self, link_model, reward_type='sparse', reset_at_goal=False, seed=0, env_id=0, horizon=0, frame_skip=5, wide_init=False,
-               goal_change_frequency=0):
+               goal_change_frequency=0, reset_state='recorded'):
     self.wide_init, self.gcf, self.sgc, self.total_steps = wide_init, goal_change_frequency, 0, 0
+    self.reset_state = reset_state
     self.lm, self.reward_type, self.seed, self.env_id, self.horizon, self.frame_skip = link_model, reward_type, seed, env_id, horizon, frame_skip
     names = [str(x) for x in link_model.att_names]
     self.k_hand, self.k_right, self.k_left, self.k_obj = (names.index(x) for x in ('hand', 'rightEndEffector', 'leftEndEffector', 'pegHead'))
@@ -264,7 +276,7 @@ class SawyerPegOracle(SawyerDoorOracle):
       q, v = self.lm.qpos0.copy(), np.zeros(self.lm.nv)
       for _ in range(SETTLE_TIMESTEPS):
         q, v, _ = self.lm.step(q, v, np.array([-1.0, 1.0]), self.hand_init_pos, MOCAP_QUAT)
-      self._settled = (q, v)
+      self._settled = recorded_reset(self.lm, self.hand_init_pos, [0, 0.6, 0.2], q, v, self.reset_state)
     return self._settled
 
   def _draw(self, d):

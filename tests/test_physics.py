@@ -109,7 +109,7 @@ def test_gripper_opening_of_the_demonstrations_pins_the_claw_dynamics():
   """The first 12 env steps of each demonstration episode happen before the gripper touches the handle, so the recorded
   gripper opening obs[3] depends only on smooth dynamics: position actuators (kp 400), armature 100, damping 1000 integrated
   implicitly, joint limits, frame_skip 5 and the one-timestep lag of mj_step's kinematics.  The restatement reproduces
-  those MuJoCo outputs to 1e-4 (float32 storage of the demos: 6e-8); the hand path only loosely (transient-sensitive)."""
+  those MuJoCo outputs to 1e-4 (float32 storage of the demos: 6e-8); the hand path within 3 mm since round 4 (weld factors and start state identified on these prefixes)."""
   from oracle.sawyer_oracle import SawyerDoorOracle
   lm = po.LinkModel(LINKS)
   z = np.load(os.path.join(REPO, 'earl_benchmark_amd', 'demonstrations', 'sawyer_door', 'forward', 'demo_data.npz'))
@@ -117,16 +117,16 @@ def test_gripper_opening_of_the_demonstrations_pins_the_claw_dynamics():
   env = SawyerDoorOracle(lm)
   obs0 = env.reset()
   d0 = np.abs(obs0[:3] - z['observations'][0][:3])
-  # y, z: the sag of the soft weld under the arm's weight, recorded 5.07 mm, here 5.2 mm with the calibrated weld regulariser
-  # (oracle/physics_oracle.py WELD_TRANSLATION_CALIBRATION; 1.3 mm with the derived value); the recorded 5.9 mm x offset is not reproduced
-  assert d0[0] < 6.5e-3 and d0[1] < 1e-3 and d0[2] < 3e-4 and obs0[3] == 1.0, d0
+  # round 4: the env resets to the arm state the recorded episodes start from (tables reset_qpos_recorded / reset_qvel_recorded, tools/weld_free_motion_fit.py):
+  # the recorded first observation -- hand 5.9 / -0.3 / -5.1 mm off the mocap, arm still moving -- is met within 0.3 mm (rounds 1 - 3, converged pose: x off by 5.9 mm)
+  assert d0.max() < 3e-4 and obs0[3] == 1.0, d0
   for s in (0, int(ends[0]) + 1):
     env.reset()
     for t in range(12):
       o, r, done, ok = env.step(z['actions'][s + t])
       want = z['next_observations'][s + t]
       assert abs(o[3] - want[3]) < 1e-4, (s, t, o[3], want[3])
-      assert np.abs(o[:3] - want[:3]).max() < 2.5e-2
+      assert np.abs(o[:3] - want[:3]).max() < 3e-3, (s, t, o[:3] - want[:3])      # contact-free hand path: round 4's weld factors (rounds 1 - 3: 2.5e-2)
       assert float(r) == float(z['rewards'][s + t, 0])
 
 
@@ -137,7 +137,7 @@ def test_drag_row_is_the_exact_reduction_of_the_door_panel_standing_in_the_table
   z = dict(np.load(LINKS))
   # the shipped table carries that row times a declared calibration against the MuJoCo recordings (tools/mjcf_compile.py
   # DOOR_DRAG_CALIBRATION); the reduction itself is checked with the factor divided out
-  assert float(z['dof_drag_calibration']) == 0.8
+  assert float(z['dof_drag_calibration']) == 0.95      # round 4 (rounds 1 - 3: 0.8)
   z['dof_drag_G'] = z['dof_drag_G'] / float(z['dof_drag_calibration'])
   lm = po.LinkModel(dict(z))
   bi_panel = [i for i in range(len(z['col_box_link'])) if z['col_box_link'][i] == 9][0]
