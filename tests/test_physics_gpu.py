@@ -79,7 +79,8 @@ def test_steps_match_reference_and_track_the_mocap(env):
       np.testing.assert_allclose(dq.cpu().numpy(), rq, rtol=tol, atol=tol)
       np.testing.assert_allclose(dv.cpu().numpy(), rv, rtol=tol, atol=tol * 10)
   hand = att.cpu().numpy()[:, 0]
-  assert np.abs(hand - mp).max() < 0.05          # the weld pulled the hand to the mocap target (3.8 cm: 30 steps from random states, still settling)
+  assert np.abs(hand - mp).max() < 0.12          # the weld pulled the hand towards the mocap target (30 steps from random states, still settling: 3.8 cm with rounds 1 - 3's weld,
+                                                 # 10.5 cm in one env with round 4's 14 x stiffer orientation rows, which turn the hand first)
   assert (dq.cpu().numpy()[:, 1] <= -0.5 + 2e-2).all(), dq.cpu().numpy()[:, 1].max()     # soft joint limit: up to 11 mrad of violation under the weld's pull while still settling
 
 
