@@ -257,6 +257,9 @@ template <int NV> struct Lim {
 #endif
   static constexpr bool COOP = (NV <= 10 && EARL_DOOR_COOP) || NV > 16;  // every factorisation shared in LDS instead of per lane in registers: an experiment for
                                                             // the small model, the only possibility for nv = 23 (a register-resident factor would need 552 VGPRs)
+  static constexpr bool ELLIPTIC = NV <= 16;               // friction cone of the model's MJCF: the Sawyer door and peg (metaworld's basic_scene.xml: cone="elliptic") carry the contact rows
+                                                            // (normal, t1, t2) with MuJoCo's three-zone cost (round 4); the kitchen and the minitaur keep the four pyramid edges.  The host
+                                                            // side refuses tables of the other kind (earl_collision_model.cone, physics/__init__.py)
   static constexpr bool CAPS = NV <= 10;                    // edge-vs-capsule blocks compiled in (the door model's handle rods; the peg model has none, and
                                                             // its kernel has no registers to spare: the host side refuses such tables for it)
   static constexpr int NA = (NV == 15 || NV == 23) ? 9 : NV;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
@@ -292,6 +295,24 @@ template <int NV> struct Lim {
   static constexpr bool PACK = NV == 23 && !EARL_NO_PACK;   // pair tests: several near blocks per pass (blocks of <= 10 pairs on 32 lanes); results unchanged
   static constexpr int BODY0 = NV == 15 ? 9 : -100;         // first link of the free body's chain (its six links: three slides, the quaternion link, two rigid ones)
 };
+
+// v = W (j0, j1, j2) for one contact's weight record w (K9).  Pyramid: W = [[w0, w1, w2], [w1, w3, 0], [w2, 0, w4]] (sums over the active edges).  Elliptic cone: the record is
+// (K, m1, m2, q, 1 / mu^2): W = K (1, m1, m2)(1, m1, m2)' + q (I2 - m m' / mu^2) on the tangential block -- the bottom zone is (D, 0, 0, D, .), the top zone all zeros
+// (reference: LinkModel.solve_primal_elliptic)
+template <bool ELL>
+__device__ __forceinline__ void cone_apply(const double* w, const double j0, const double j1, const double j2, double& v0, double& v1, double& v2) {
+  if constexpr (ELL) {
+    const double K = w[0], m1 = w[1], m2 = w[2], q = w[3], i2 = w[4];
+    const double h01 = K * m1, h02 = K * m2, h11 = K * m1 * m1 + q * (1.0 - m1 * m1 * i2), h22 = K * m2 * m2 + q * (1.0 - m2 * m2 * i2), h12 = m1 * m2 * (K - q * i2);
+    v0 = K * j0 + h01 * j1 + h02 * j2; v1 = h01 * j0 + h11 * j1 + h12 * j2; v2 = h02 * j0 + h12 * j1 + h22 * j2;
+  } else {
+    v0 = w[0] * j0 + w[1] * j1 + w[2] * j2; v1 = w[1] * j0 + w[3] * j1; v2 = w[2] * j0 + w[4] * j2;
+  }
+}
+__device__ __forceinline__ int cone_zone(const double r0, const double r1, const double r2, const double mu) {      // 0 top (separating), 1 bottom (sticking), 2 middle (sliding)
+  const double rho = sqrt(r1 * r1 + r2 * r2);
+  return r0 >= mu * rho ? 0 : (rho <= -mu * r0 ? 1 : 2);
+}
 
 // DPP moves within a 16-lane row: lane l reads lane l - K (shr) / l + K (shl) of its row, 0 beyond the row
 template <int CTRL>
@@ -816,6 +837,8 @@ __device__ __forceinline__ void stage_kb(BlkTable<MB, KB>& t, const void* __rest
     if (i >= 56 && i < 64 && i - 56 < mg->n_jeq) kb_of(mg->jeq_solref[i - 56], mg->jeq_solimp[i - 56], dt, t.kb_jeq[i - 56][0], t.kb_jeq[i - 56][1]);
   }
 }
+
+template <int LPE> __device__ __forceinline__ bool group_any(const bool pred, const int grp);
 
 // One timestep of one env by its LPE-lane group (`sub` = lane within the group; every lane of the wave runs this, the
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
@@ -1542,7 +1565,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   PSTAMP(7);
   // ------------------------------------------------------------------ C3: contact rows (reference: LinkModel.contact_rows)
   double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};       // lane c (< nct) owns contact c: edge weights and reference accelerations
-  unsigned int cact = 0;                               // active pyramid edges of that contact (bits 0..3)
+  unsigned int cact = 0;                               // active pyramid edges of that contact (bits 0..3); elliptic models: its zone
+  double cja[3] = {0, 0, 0};                           // elliptic models: J a (normal, t1, t2) of the iterate the zone was read from
   bool coupled = false;                                // some contact of some env of the wave joins the two trees (arm / object)
   bool ctA = true, ctP = true;                         // ... and of the contact this lane owns
   unsigned int armmask = 0, pegmask = 0;               // two-tree model: contact slots whose Jacobian has entries in the first / second tree in SOME env of the wave
@@ -1625,8 +1649,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       if constexpr (Lim<NV>::KBT) dd = imp_of(bt.cls_solimp[cls], rec[0] - margin);
       else kbimp(bt.cls_solref[cls], bt.cls_solimp[cls], rec[0] - margin, dt, kk, bb, dd);
       const double R0 = fmax((1 - dd) * bt.cls_invw[cls] * rcp_nr(dd), 1e-15);
-      cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
       const double basea = -kk * dd * (rec[0] - margin);
+      if constexpr (Lim<NV>::ELLIPTIC) {
+        // rows (normal, t1, t2), one regulariser (impratio 1), the position term on the normal row only; cact = the contact's ZONE (0 top, 1 bottom, 2 middle),
+        // cja = J a of the iterate the zone was read from (a_prev at a warm start; a cold start puts every contact in the bottom zone)
+        cD = cv ? rcp_nr(R0) : 0.0;
+        car[0] = -bb * vn + basea; car[1] = -bb * vt1; car[2] = -bb * vt2;
+        cja[0] = pn; cja[1] = pt1; cja[2] = pt2;
+        cact = cv ? (warm ? (unsigned int)cone_zone(pn - car[0], pt1 - car[1], pt2 - car[2], cmu) : 1u) : 0u;
+      } else {
+      cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
       car[0] = -bb * (vn + cmu * vt1) + basea; car[1] = -bb * (vn - cmu * vt1) + basea;
       car[2] = -bb * (vn + cmu * vt2) + basea; car[3] = -bb * (vn - cmu * vt2) + basea;
       unsigned int wb = 0;                              // the edges that pull at a_prev
@@ -1635,6 +1667,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       wb |= (pn + cmu * pt2 - car[2] < 0) ? 4u : 0u;
       wb |= (pn - cmu * pt2 - car[3] < 0) ? 8u : 0u;
       cact = cv ? (warm ? wb : 0xFu) : 0u;
+      }
     }
   }
   fence();
@@ -1735,6 +1768,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #ifdef EARL_PHYS_PROF
   const unsigned long long k9_t0 = __builtin_readcyclecounter();
 #endif
+  bool frozen = false;                                 // elliptic models: this env reached its fixed point in an earlier pass (its solution is parked in s.aprev; the wave goes on
+                                                       // for the envs that have not) -- an env's result must not depend on which envs share its wave
   for (int it = 0; it < 8; ++it) {
     PCOUNT(25, 1);
     KSTART();
@@ -1752,12 +1787,30 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
     if (ncmax > 0 && sub < MC) {
       // edges (n + mu t1, n - mu t1, n + mu t2, n - mu t2): sum_e D a_e u_e u_e' on (Jn, Jt1, Jt2) and sum_e D a_e aref_e u_e
-      const double a1 = (cact & 1u) ? cD : 0.0, a2 = (cact & 2u) ? cD : 0.0, a3 = (cact & 4u) ? cD : 0.0, a4 = (cact & 8u) ? cD : 0.0;
       double* w = s.con.cw[sub];
+      if constexpr (Lim<NV>::ELLIPTIC) {
+        // the record cone_apply reads: (K, m1, m2, q, 1 / mu^2) and the right-hand side h = W (J a_k) - grad.  Bottom zone: W = D I, h = D aref.  Middle zone, with
+        // r = J a_k - aref, rho = |r_t|, sl = r_n - mu rho < 0: K = D / (1 + mu^2), m = -mu r_t / rho, q = -K mu sl / rho, grad = K sl (1, m1, m2)
+        double K = 0, m1 = 0, m2 = 0, q = 0, h0 = 0, h1 = 0, h2 = 0;
+        const double i2 = rcp_nr(cmu * cmu);
+        if (cact == 1u) {
+          K = cD; q = cD; h0 = cD * car[0]; h1 = cD * car[1]; h2 = cD * car[2];
+        } else if (cact == 2u) {
+          const double r0 = cja[0] - car[0], r1 = cja[1] - car[1], r2 = cja[2] - car[2];
+          const double rho = sqrt(r1 * r1 + r2 * r2), ir = 1.0 / rho, sl = r0 - cmu * rho;
+          K = cD / (1.0 + cmu * cmu); m1 = -cmu * r1 * ir; m2 = -cmu * r2 * ir; q = -K * cmu * sl * ir;
+          const double rec_[5] = {K, m1, m2, q, i2};
+          cone_apply<true>(rec_, cja[0], cja[1], cja[2], h0, h1, h2);
+          h0 -= K * sl; h1 -= K * sl * m1; h2 -= K * sl * m2;
+        }
+        w[0] = K; w[1] = m1; w[2] = m2; w[3] = q; w[4] = i2; w[5] = h0; w[6] = h1; w[7] = h2;
+      } else {
+      const double a1 = (cact & 1u) ? cD : 0.0, a2 = (cact & 2u) ? cD : 0.0, a3 = (cact & 4u) ? cD : 0.0, a4 = (cact & 8u) ? cD : 0.0;
       w[0] = a1 + a2 + a3 + a4; w[1] = cmu * (a1 - a2); w[2] = cmu * (a3 - a4); w[3] = cmu * cmu * (a1 + a2); w[4] = cmu * cmu * (a3 + a4);
       w[5] = a1 * car[0] + a2 * car[1] + a3 * car[2] + a4 * car[3];
       w[6] = cmu * (a1 * car[0] - a2 * car[1]);
       w[7] = cmu * (a3 * car[2] - a4 * car[3]);
+      }
     }
     fence();
     KSTAMP(16);
@@ -1779,7 +1832,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           const double* w = s.con.cw[c];
           const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
           const bool cv = c < nct;
-          const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+          double v0, v1, v2;
+        cone_apply<Lim<NV>::ELLIPTIC>(w, j0, j1, j2, v0, v1, v2);
+        v0 = cv ? v0 : 0.0; v1 = cv ? v1 : 0.0; v2 = cv ? v2 : 0.0;
           rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
 #pragma unroll
           for (int i = 0; i < NA; ++i) acc[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
@@ -1812,7 +1867,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const double* w = s.con.cw[c];
         const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
         const bool cv = c < nct;
-        const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+        double v0, v1, v2;
+        cone_apply<Lim<NV>::ELLIPTIC>(w, j0, j1, j2, v0, v1, v2);
+        v0 = cv ? v0 : 0.0; v1 = cv ? v1 : 0.0; v2 = cv ? v2 : 0.0;
         rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;   // (a slot beyond this env's count holds whatever
@@ -1840,7 +1897,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const double* w = s.con.cw[c];
         const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
         const bool cv = c < nct;
-        const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+        double v0, v1, v2;
+        cone_apply<Lim<NV>::ELLIPTIC>(w, j0, j1, j2, v0, v1, v2);
+        v0 = cv ? v0 : 0.0; v1 = cv ? v1 : 0.0; v2 = cv ? v2 : 0.0;
         rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
         if (isl) {
 #pragma unroll
@@ -1860,7 +1919,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const double* w = s.con.cw[c];
         const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
         const bool cv = c < nct;
-        const double v0 = cv ? w[0] * j0 + w[1] * j1 + w[2] * j2 : 0.0, v1 = cv ? w[1] * j0 + w[3] * j1 : 0.0, v2 = cv ? w[2] * j0 + w[4] * j2 : 0.0;
+        double v0, v1, v2;
+        cone_apply<Lim<NV>::ELLIPTIC>(w, j0, j1, j2, v0, v1, v2);
+        v0 = cv ? v0 : 0.0; v1 = cv ? v1 : 0.0; v2 = cv ? v2 : 0.0;
         rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
         if constexpr (TS < NT) {
           // the rows of a tree that slot c touches in no env of the wave hold exact zeros (C3 wrote them): skipped.  A peg lying on the table gives
@@ -2035,7 +2096,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
     const bool want = lim_inst && ((lim_lo ? al : -al) - lim_aref < 0);
     bool changed = want != act;
-    act = want;
+    act = frozen ? act : want;
     if constexpr (Lim<NV>::EXTRAS) {
       if (fr_loss > 0) {
         const double x = al - fr_aref;
@@ -2063,17 +2124,47 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         }
       }
       unsigned int nb = 0;
+      if constexpr (Lim<NV>::ELLIPTIC) {
+        // the contact's zone at the new iterate; a sliding contact is linearised again until its row values stand still (LinkModel.ELL_TOL)
+        nb = sub < nct ? (unsigned int)cone_zone(an - car[0], at1 - car[1], at2 - car[2], cmu) : 0u;
+        const double big = fmax(fmax(fabs(cja[0]), fabs(cja[1])), fabs(cja[2])), dif = fmax(fmax(fabs(an - cja[0]), fabs(at1 - cja[1])), fabs(at2 - cja[2]));
+        changed = changed || nb != cact || (nb == 2u && dif > 1e-8 * (1.0 + big));
+        if (!frozen) { cja[0] = an; cja[1] = at1; cja[2] = at2; }
+        nb = frozen ? cact : nb;
+      } else {
       nb |= (an + cmu * at1 - car[0] < 0) ? 1u : 0u;
       nb |= (an - cmu * at1 - car[1] < 0) ? 2u : 0u;
       nb |= (an + cmu * at2 - car[2] < 0) ? 4u : 0u;
       nb |= (an - cmu * at2 - car[3] < 0) ? 8u : 0u;
       nb = sub < nct ? nb : 0u;
       changed = changed || nb != cact;
+      }
       cact = nb;
+    }
+    if constexpr (Lim<NV>::ELLIPTIC) {
+      // A sliding contact is a Newton iteration stopped at a tolerance: one more pass would move the solution in its last digits.  So an env stops at ITS OWN fixed point
+      // (pyramid models reach theirs exactly: more passes for a wave-mate's sake rebuild the same Hessian from the same set and change no bit)
+      const bool env_changed = group_any<LPE>(changed, grp);
+      if (!frozen && !env_changed) {
+        if (isl) s.aprev[l] = al;
+        frozen = true;
+      }
+      changed = !frozen;
     }
     fence();
     KSTAMP(19);
     if (!__any(changed)) break;
+  }
+  if constexpr (Lim<NV>::ELLIPTIC) {
+    if (!frozen && isl) {                               // (the cap of eight passes: the last iterate stands)
+      double al = 0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) al = l == i ? a[i] : al;
+      s.aprev[l] = al;
+    }
+    fence();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] = s.aprev[i];
   }
   if constexpr (INTEGRATE) {
     double al = 0;

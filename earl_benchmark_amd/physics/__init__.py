@@ -64,7 +64,7 @@ class PairRec(C.Structure):
 
 class CollisionModelStruct(C.Structure):   # struct earl_collision_model
   _fields_ = [('n_sph', C.c_int32), ('n_box', C.c_int32), ('n_pair', C.c_int32), ('n_cls', C.c_int32),
-              ('n_blk', C.c_int32), ('max_con', C.c_int32), ('pad_', C.c_int32 * 2), ('blk_begin', C.c_int32 * MAXBLK), ('blk_end', C.c_int32 * MAXBLK),
+              ('n_blk', C.c_int32), ('max_con', C.c_int32), ('cone', C.c_int32), ('pad_', C.c_int32), ('blk_begin', C.c_int32 * MAXBLK), ('blk_end', C.c_int32 * MAXBLK),
               ('blk_box', C.c_int32 * MAXBLK), ('blk_link', C.c_int32 * MAXBLK), ('blk_cap', C.c_int32 * MAXBLK), ('blk_center', C.c_double * 3 * MAXBLK),
               ('blk_reach', C.c_double * MAXBLK), ('blk_obb_center', C.c_double * 3 * MAXBLK), ('blk_obb_half', C.c_double * 3 * MAXBLK),
               ('sph_link', C.c_int32 * MAXSPH), ('box_link', C.c_int32 * MAXBOX),
@@ -203,6 +203,8 @@ def load_collision_model(d):
   c.n_sph, c.n_box, c.n_pair, c.n_cls = len(d['col_sph_link']), len(d['col_box_link']), len(d['col_pair']), len(d['col_cls_mu'])
   c.n_blk = len(d['col_blk_begin'])
   c.max_con = int(d['max_contacts']) if 'max_contacts' in d else 8
+  c.cone = int(d['cone_elliptic']) if 'cone_elliptic' in d else 0
+  assert c.cone == (1 if len(d['parent']) <= 16 else 0), 'csrc/physics.hip Lim<NV>::ELLIPTIC: the Sawyer models (nv 10, 15) are compiled with the elliptic cone, the others with the pyramid'
   small = len(d['parent']) <= 10                # csrc/physics.hip Lim<NV>: 8 contact slots / 16 blocks for nv <= 10
   assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS
   nvm = len(d['parent'])

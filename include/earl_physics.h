@@ -116,7 +116,10 @@ typedef struct earl_collision_model {
    * set (centre given in the frame of blk_link, -1 = world) is farther than blk_reach from the box centre */
   int32_t n_blk;
   int32_t max_con;                           /* contacts kept per env and timestep (<= EARL_MAXCON; <= 8 for models with nv <= 10): the first active pairs */
-  int32_t pad_[2];
+  int32_t cone;                              /* friction cone of the model's MJCF: 0 = pyramidal (four edge rows per contact), 1 = elliptic (rows normal, t1, t2 with one regulariser,
+                                                MuJoCo's three-zone cost; round 4).  The kernels compile the cone per model size (csrc/physics.hip Lim<NV>::ELLIPTIC: nv <= 16, the
+                                                Sawyer door and peg, metaworld_assets/scene/basic_scene.xml:2); an entry point given the other kind returns EARL_ERR_ARG */
+  int32_t pad_;
   int32_t blk_begin[EARL_MAXBLK], blk_end[EARL_MAXBLK], blk_box[EARL_MAXBLK], blk_link[EARL_MAXBLK];
   int32_t blk_cap[EARL_MAXBLK];              /* bits 0-7: contacts a block may contribute (its first ones in pair order); the block order is the
                                                 priority order of the max_con slots.  bit 8: KIND of the block, 0 = spheres / points vs a box,

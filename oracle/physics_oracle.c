@@ -365,8 +365,11 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       ++nf;
     }
   o->ncon = 0;
+  double cone_mu[EARL_MAXCON];
+  int nr_contacts0 = -1;           /* index of the first contact row */
   if (col) {
     int ncon = 0;
+    nr_contacts0 = nr;
     for (int b = 0; b < col->n_blk && ncon < col->max_con; ++b) {
       const int bi = col->blk_box[b], bl = col->blk_link[b], xl = col->box_link[bi];
       V3 cs = ld3(col->blk_center[b]), pb = ld3(col->box_pos[bi]);
@@ -464,6 +467,18 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
         double kk, bb, dd;
         kbimp(col->cls_solref[cls], col->cls_solimp[cls], dist - margin, dt, &kk, &bb, &dd);
         const double R0 = fmax((1 - dd) / dd * col->cls_invw[cls], 1e-15);
+        if (col->cone == 1) {   /* elliptic cone: rows (normal, t1, t2), one regulariser (impratio 1), only the normal row has a position term */
+          for (int e = 0; e < 3; ++e) {
+            const double* Je = e == 0 ? Jn : (e == 1 ? Jt1 : Jt2);
+            double vel = 0;
+            for (int j = 0; j < nv; ++j) { J[nr][j] = Je[j]; vel += Je[j] * qv[j]; }
+            aref[nr] = -bb * vel - (e == 0 ? kk * dd * (dist - margin) : 0.0);
+            D[nr] = 1.0 / R0;
+            iseq[nr] = 0; rowid[nr] = -1;
+            ++nr;
+          }
+          cone_mu[ncon] = mu;
+        } else
         for (int e = 0; e < 4; ++e) {
           const double s1 = e == 0 ? mu : (e == 1 ? -mu : 0.0), s2 = e == 2 ? mu : (e == 3 ? -mu : 0.0);
           double vel = 0;
@@ -478,17 +493,31 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     }
     o->ncon = ncon;
   }
-  /* primal active-set Newton (LinkModel.solve_primal) */
+  /* primal active-set Newton (LinkModel.solve_primal; elliptic models: LinkModel.solve_primal_elliptic) */
   int act[NROWMAX];
   double a[NVMAX];
+  const int ell = col && col->cone == 1 && o->ncon > 0;
+  const int nc = ell ? o->ncon : 0, nru = ell ? nr_contacts0 : nr;       /* rows [nru, nr) are the contacts' (n, t1, t2) triples */
+  int zone[EARL_MAXCON];                                                  /* 0 top (no force), 1 bottom (sticking: quadratic), 2 middle (sliding: on the cone) */
+  double Jak[EARL_MAXCON][3];                                             /* J a of the iterate the zone was read from */
   for (int r = 0; r < nr; ++r) act[r] = 1;
+  for (int c = 0; c < nc; ++c) { zone[c] = 1; Jak[c][0] = Jak[c][1] = Jak[c][2] = 0; }
+#define CONE_ZONE(r0, r1, r2, mu) ((r0) >= (mu) * sqrt((r1) * (r1) + (r2) * (r2)) ? 0 : (sqrt((r1) * (r1) + (r2) * (r2)) <= -(mu) * (r0) ? 1 : 2))
   if (g_warm_start && o->warm) {
     /* (the dry-friction rows keep their cold start, the quadratic zone: started from a_prev's zones the three-state iteration cycled 18 times
      * as often in the kitchen model -- 3,295 against 181 of 1 M timesteps used all 8 iterations; with this rule 33) */
-    for (int r = 0; r < nr; ++r) {
+    for (int r = 0; r < nru; ++r) {
       double x = -aref[r];
       for (int j = 0; j < nv; ++j) x += J[r][j] * o->qacc[j];
       act[r] = iseq[r] || x < 0;
+    }
+    for (int c = 0; c < nc; ++c) {
+      for (int k = 0; k < 3; ++k) {
+        double x = 0;
+        for (int j = 0; j < nv; ++j) x += J[nru + 3 * c + k][j] * o->qacc[j];
+        Jak[c][k] = x;
+      }
+      zone[c] = CONE_ZONE(Jak[c][0] - aref[nru + 3 * c], Jak[c][1] - aref[nru + 3 * c + 1], Jak[c][2] - aref[nru + 3 * c + 2], cone_mu[c]);
     }
   }
   int iters = 0, converged = 0;
@@ -496,13 +525,37 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     ++iters;
     double H[NVMAX][NVMAX];
     for (int i = 0; i < nv; ++i) { a[i] = tau[i]; for (int j = 0; j < nv; ++j) H[i][j] = M[i][j]; }
-    for (int r = 0; r < nr; ++r) {
+    for (int r = 0; r < nru; ++r) {
       if (!act[r]) continue;
       for (int i = 0; i < nv; ++i) {
         if (J[r][i] == 0) continue;
         const double w = D[r] * J[r][i];
         a[i] += w * aref[r];
         for (int j = 0; j < nv; ++j) H[i][j] += w * J[r][j];
+      }
+    }
+    for (int c = 0; c < nc; ++c) {
+      if (zone[c] == 0) continue;
+      const int r0 = nru + 3 * c;
+      const double Dn = D[r0], mu = cone_mu[c];
+      double Hc[3][3] = {{0}}, h[3];
+      if (zone[c] == 1) {
+        for (int k = 0; k < 3; ++k) { Hc[k][k] = Dn; h[k] = Dn * aref[r0 + k]; }
+      } else {
+        const double q0 = Jak[c][0] - aref[r0], q1 = Jak[c][1] - aref[r0 + 1], q2 = Jak[c][2] - aref[r0 + 2];
+        const double rho = sqrt(q1 * q1 + q2 * q2), K = Dn / (1 + mu * mu), sl = q0 - mu * rho, u1 = q1 / rho, u2 = q2 / rho;
+        const double v[3] = {1.0, -mu * u1, -mu * u2}, q = -K * mu * sl / rho;
+        for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) Hc[k][l] = K * v[k] * v[l];
+        Hc[1][1] += q * (1 - u1 * u1); Hc[1][2] -= q * u1 * u2; Hc[2][1] -= q * u1 * u2; Hc[2][2] += q * (1 - u2 * u2);
+        for (int k = 0; k < 3; ++k) h[k] = Hc[k][0] * Jak[c][0] + Hc[k][1] * Jak[c][1] + Hc[k][2] * Jak[c][2] - K * sl * v[k];
+      }
+      for (int i = 0; i < nv; ++i) {
+        const double w0 = Hc[0][0] * J[r0][i] + Hc[0][1] * J[r0 + 1][i] + Hc[0][2] * J[r0 + 2][i];
+        const double w1 = Hc[1][0] * J[r0][i] + Hc[1][1] * J[r0 + 1][i] + Hc[1][2] * J[r0 + 2][i];
+        const double w2 = Hc[2][0] * J[r0][i] + Hc[2][1] * J[r0 + 1][i] + Hc[2][2] * J[r0 + 2][i];
+        if (w0 == 0 && w1 == 0 && w2 == 0 && J[r0][i] == 0 && J[r0 + 1][i] == 0 && J[r0 + 2][i] == 0) continue;
+        a[i] += J[r0][i] * h[0] + J[r0 + 1][i] * h[1] + J[r0 + 2][i] * h[2];
+        for (int j = 0; j < nv; ++j) H[i][j] += w0 * J[r0][j] + w1 * J[r0 + 1][j] + w2 * J[r0 + 2][j];
       }
     }
     for (int k = 0; k < nf; ++k) {
@@ -517,12 +570,25 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       changed |= ns != fs[k];
       fs[k] = ns;
     }
-    for (int r = 0; r < nr; ++r) {
+    for (int r = 0; r < nru; ++r) {
       double x = -aref[r];
       for (int j = 0; j < nv; ++j) x += J[r][j] * a[j];
       const int want = iseq[r] || x < 0;
       changed |= want != act[r];
       act[r] = want;
+    }
+    for (int c = 0; c < nc; ++c) {
+      double Jn_[3], big = 0, dif = 0;
+      for (int k = 0; k < 3; ++k) {
+        double x = 0;
+        for (int j = 0; j < nv; ++j) x += J[nru + 3 * c + k][j] * a[j];
+        Jn_[k] = x;
+        big = fmax(big, fabs(Jak[c][k])); dif = fmax(dif, fabs(x - Jak[c][k]));
+      }
+      const int z = CONE_ZONE(Jn_[0] - aref[nru + 3 * c], Jn_[1] - aref[nru + 3 * c + 1], Jn_[2] - aref[nru + 3 * c + 2], cone_mu[c]);
+      if (z != zone[c] || (z == 2 && dif > 1e-8 * (1.0 + big))) changed = 1;      /* LinkModel.ELL_TOL */
+      zone[c] = z;
+      for (int k = 0; k < 3; ++k) { Jak[c][k] = Jn_[k]; act[nru + 3 * c + k] = z != 0; }
     }
     if (!changed) { converged = 1; break; }
   }

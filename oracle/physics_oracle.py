@@ -434,6 +434,7 @@ def reduce_model(m, body_pos=None, attach_bodies=(), attach_sites=(), attach_geo
   ftr = float(m.weld_calibration[0]) if weld_translation_calibration is None else float(weld_translation_calibration)
   out['weld_invweight'] = m.body_invweight0[wb] * np.array([ftr, float(m.weld_calibration[1])])
   out['weld_calibration'] = np.array(m.weld_calibration, float)
+  out['cone_elliptic'] = np.int32(getattr(m, 'cone_elliptic', 0))        # <option cone=...>: the contact rows' friction cone (LinkModel.solve_primal)
   out['weld_mocap_quat'] = np.array(m.body_quat[int(m.weld_body1[0])])          # the mocap body's orientation in the model (its mocap_quat after sim.reset())
   out['weld_mocap_pos'] = np.array(m.body_pos[int(m.weld_body1[0])])
   # generalized coordinates: qpos has one entry per dof, except that a free body's orientation is a unit quaternion
@@ -680,6 +681,7 @@ class LinkModel:
     self.nv = len(self.parent)
     self.dt = float(self.timestep)
     self.max_contacts = int(self.max_contacts)
+    self.elliptic = bool(int(getattr(self, 'cone_elliptic', 0)))       # table 'cone_elliptic': the MJCF's <option cone="elliptic"> (door, peg: metaworld's basic_scene.xml:2)
     # qpos index of dof l: with a free body the orientation quaternion takes FOUR qpos slots at ball_dof .. ball_dof + 3 (MuJoCo's layout), so the
     # dofs behind its three rotation dofs sit one slot further (a free ROOT body -- the minitaur's base: qpos = [xyz, quat, joints]); a free body whose
     # rotation dofs are the last three (the peg) has none behind it
@@ -865,12 +867,18 @@ class LinkModel:
       kk, bb, dd = kbimp(self.jnt_solref[j], self.jnt_solimp[j], 0.0, self.dt)
       fric.append((int(j), -bb * qvel[j], max((1 - dd) / dd * self.dof_invweight0[j], 1e-15), float(self.jnt_frictionloss[j])))
     contacts = self.collide(pos, quat) if (self.contacts and hasattr(self, 'col_pair')) else []
+    cone_mu = None
     if contacts:
       Jc, arc, Rc = self.contact_rows(contacts, S, qvel)
       J, aref, Rg = np.vstack([J, Jc]), np.concatenate([aref, arc]), np.concatenate([Rg, Rc])
       inst = np.concatenate([inst, np.ones(len(arc), bool)])
+      if self.elliptic:
+        cone_mu = [float(getattr(self, 'link_mu', {}).get(c['ls'], self.col_cls_mu[c['cls']])) for c in contacts]     # the last 3 rows per contact are (n, t1, t2)
     is_eq = np.zeros(len(aref), bool); is_eq[:6] = has_weld; is_eq[nlim:nlim + n_eq_extra] = True
-    qacc, act = self.solve_primal(M, tau, J[inst], aref[inst], 1.0 / Rg[inst], is_eq[inst], fric=fric, **({} if a_prev is None else dict(a_prev=a_prev)))
+    kw = {} if a_prev is None else dict(a_prev=a_prev)
+    if cone_mu is not None:
+      kw['cone_mu'] = cone_mu
+    qacc, act = self.solve_primal(M, tau, J[inst], aref[inst], 1.0 / Rg[inst], is_eq[inst], fric=fric, **kw)
     f = np.zeros(len(aref)); active = np.zeros(len(aref), bool)
     idx = np.nonzero(inst)[0]
     f[idx] = np.where(act, -(J[idx] @ qacc - aref[idx]) / Rg[idx], 0.0)
@@ -881,13 +889,21 @@ class LinkModel:
   contacts = True          # class-level switch: LinkModel.contacts = False gives the contact-free stepper
   max_contacts = 8         # the kernel's cap (tables: 'max_contacts' = earl_collision_model.max_con): the first max_contacts active pairs in pair order
 
-  def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8, fric=(), a_prev=None):
+  def solve_primal(self, M, tau, J, aref, D, is_eq, iters=8, fric=(), a_prev=None, cone_mu=None):
     """MuJoCo's primal problem  min_a 1/2 (a-a0)' M (a-a0) + sum_r 1/2 D_r [J_r a - aref_r]_-^2  (equalities: both signs)
     by the active-set Newton iteration the kernel runs: rows start active, then active <=> J_r a < aref_r.
     fric: dry-friction rows (dof j, aref, R, loss): cost 1/2 x^2 / R for |x| <= R loss, loss (|x| - R loss / 2) beyond (x = a_j - aref): a
     row is QUADRATIC (state 0: it adds 1 / R to the diagonal) or saturated (state +-1: it pushes with -+loss); rows start quadratic.
     a_prev (warm start; the kernels pass the previous timestep's solution within one env step): the iteration starts from the set the rows
-    take AT a_prev instead.  The fixed point is the same, so is the result; only the number of iterations changes."""
+    take AT a_prev instead.  The fixed point is the same, so is the result; only the number of iterations changes.
+    cone_mu (round 4, models compiled from an MJCF with cone="elliptic"): the last 3 len(cone_mu) rows are contacts as (normal, t1, t2) triples with ONE
+    regulariser each (impratio 1) and MuJoCo's elliptic cost: with r = J a - aref, rho = |r_t|: nothing for r_n >= mu rho (top zone: separating), 1/2 D |r|^2 for
+    rho <= -mu r_n (bottom zone: sticking), 1/2 D / (1 + mu^2) (r_n - mu rho)^2 in between (middle zone: sliding, force on the cone's surface).  A contact carries its zone and
+    the row values J a of the iterate the zone was read from; the middle zone is linearised there (exact Hessian of the cost, Newton without line search); the iteration
+    stops when no row, no friction row and no zone changes and every sliding contact's row values moved by less than ELL_TOL (relative) -- or after `iters` passes.
+    Cold start: every contact in the bottom zone."""
+    if cone_mu is not None:
+      return self.solve_primal_elliptic(M, tau, J, aref, D, is_eq, iters, fric, a_prev, cone_mu)
     act = np.ones(len(aref), bool)
     fs = np.zeros(len(fric), int)
     if a_prev is not None:
@@ -910,6 +926,71 @@ class LinkModel:
         break
       act, fs = want, nfs
     return a, act
+
+  ELL_TOL = 1e-8
+
+  @staticmethod
+  def cone_zone(r, mu):
+    rho = np.sqrt(r[1] * r[1] + r[2] * r[2])
+    return 0 if r[0] >= mu * rho else (1 if rho <= -mu * r[0] else 2)
+
+  def solve_primal_elliptic(self, M, tau, J, aref, D, is_eq, iters, fric, a_prev, cone_mu):
+    nc = len(cone_mu); nr = len(aref) - 3 * nc
+    Ju, aru, Du, eq = J[:nr], aref[:nr], D[:nr], is_eq[:nr]
+    warm = a_prev is not None
+    act = (eq | (Ju @ a_prev - aru < 0)) if warm else np.ones(nr, bool)
+    fs = np.zeros(len(fric), int)
+    zone = np.ones(nc, int); Jak = np.zeros((nc, 3))
+    if warm:
+      for c in range(nc):
+        Jak[c] = J[nr + 3 * c: nr + 3 * c + 3] @ a_prev
+        zone[c] = self.cone_zone(Jak[c] - aref[nr + 3 * c: nr + 3 * c + 3], cone_mu[c])
+    a = None
+    for _ in range(iters):
+      Ja = Ju[act]
+      H = M + Ja.T @ (Du[act, None] * Ja)
+      g = tau + Ja.T @ (Du[act] * aru[act])
+      for k, (j, ar, R, loss) in enumerate(fric):
+        if fs[k] == 0:
+          H[j, j] += 1.0 / R
+          g[j] += ar / R
+        else:
+          g[j] -= fs[k] * loss
+      for c in range(nc):
+        if zone[c] == 0:
+          continue
+        Jc, ac, Dn, mu = J[nr + 3 * c: nr + 3 * c + 3], aref[nr + 3 * c: nr + 3 * c + 3], D[nr + 3 * c], cone_mu[c]
+        if zone[c] == 1:
+          Hc, h = Dn * np.eye(3), Dn * ac
+        else:
+          r = Jak[c] - ac
+          rho = np.sqrt(r[1] * r[1] + r[2] * r[2])
+          K, sl = Dn / (1 + mu * mu), r[0] - mu * rho
+          u1, u2 = r[1] / rho, r[2] / rho
+          v = np.array([1.0, -mu * u1, -mu * u2])
+          q = -K * mu * sl / rho                       # > 0: curvature of the cone's surface across the sliding direction
+          Hc = K * np.outer(v, v)
+          Hc[1, 1] += q * (1 - u1 * u1); Hc[1, 2] -= q * u1 * u2; Hc[2, 1] -= q * u1 * u2; Hc[2, 2] += q * (1 - u2 * u2)
+          h = Hc @ Jak[c] - K * sl * v
+        H += Jc.T @ Hc @ Jc
+        g += Jc.T @ h
+      a = np.linalg.solve(H, g)
+      want = eq | (Ju @ a - aru < 0)
+      nfs = np.array([0 if abs(a[j] - ar) <= R * loss else (1 if a[j] - ar > 0 else -1) for (j, ar, R, loss) in fric], int)
+      changed = not ((want == act).all() and (nfs == fs).all())
+      for c in range(nc):
+        Jn_ = J[nr + 3 * c: nr + 3 * c + 3] @ a
+        z = self.cone_zone(Jn_ - aref[nr + 3 * c: nr + 3 * c + 3], cone_mu[c])
+        if z != zone[c] or (z == 2 and np.abs(Jn_ - Jak[c]).max() > self.ELL_TOL * (1.0 + np.abs(Jak[c]).max())):
+          changed = True
+        zone[c], Jak[c] = z, Jn_
+      act, fs = want, nfs
+      if not changed:
+        break
+    full = np.ones(len(aref), bool); full[:nr] = act
+    for c in range(nc):
+      full[nr + 3 * c: nr + 3 * c + 3] = zone[c] != 0
+    return a, full
 
   def obb_separated(self, b, bl, pos, quat, cb, Rb, hb):
     """the block's second bounding test: one of the six face axes of (set box, block box) separates them (the margin is part of the set box)"""
@@ -1015,7 +1096,7 @@ class LinkModel:
     return t1, np.cross(n, t1)
 
   def contact_rows(self, contacts, S, qvel):
-    """4 pyramid edges per contact: (n +- mu t1, n +- mu t2) . (v_sphere_point - v_box_point)"""
+    """4 pyramid edges per contact: (n +- mu t1, n +- mu t2) . (v_sphere_point - v_box_point); elliptic models: the three rows (n, t1, t2)"""
     nv = self.nv
     J, aref, R = [], [], []
     for c in contacts:
@@ -1030,6 +1111,13 @@ class LinkModel:
       margin = float(self.col_cls_margin[cls])
       kk, bb, dd = kbimp(self.col_cls_solref[cls], self.col_cls_solimp[cls], c['dist'] - margin, self.dt)
       R0 = max((1 - dd) / dd * float(self.col_cls_invw[cls]), 1e-15)
+      if self.elliptic:                       # (normal, t1, t2), one regulariser (impratio 1); only the normal row has a position term
+        for k, d in enumerate((c['n'], t1, t2)):
+          row = d @ Jp
+          J.append(row)
+          aref.append(-bb * (row @ qvel) - (kk * dd * (c['dist'] - margin) if k == 0 else 0.0))
+          R.append(R0)
+        continue
       for d in (c['n'] + mu * t1, c['n'] - mu * t1, c['n'] + mu * t2, c['n'] - mu * t2):
         row = d @ Jp
         J.append(row)

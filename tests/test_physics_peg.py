@@ -114,7 +114,7 @@ def test_c_restatement_equals_the_numpy_statement_on_the_peg_model():
   for _ in range(100):
     q, v, out = lm.step(q, v, np.array([-1.0, 1.0]), MP, MQ)
   np.testing.assert_allclose(r['qpos'][0], q, atol=1e-12); np.testing.assert_allclose(r['qvel'][0], v, atol=1e-11)
-  assert abs(q[11] - 0.015) < 1e-4 and r['ncon'][0] >= 2                                 # the dropped peg rests on the table top
+  assert abs(q[11] - 0.015) < 2e-4 and r['ncon'][0] >= 2                                 # the dropped peg rests on the table top
 
 
 def test_block_cull_never_drops_a_contact_on_the_peg_model():

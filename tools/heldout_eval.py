@@ -137,7 +137,13 @@ def final():
   reps = [Replayer('sawyer_door'), Replayer('sawyer_peg')]
   res = dict(protocol='even episodes of every (task, direction) = fit set, odd = held out; metric = RMS distance replayed vs recorded object path, open loop over the whole episode; '
                       'score = mean over the four (task, direction) groups.  Round-4 constants: weld factors identified on the CONTACT-FREE prefixes of the fit set '
-                      '(tools/weld_free_motion_fit.py --joint), door drag on the fit-set door episodes, reset state = the one identified with the weld factors', results={})
+                      '(tools/weld_free_motion_fit.py --joint), door drag on the fit-set door episodes, reset state = the one identified with the weld factors.  '
+                      'ALL rows of this file run with the friction cone of the shipped tables (elliptic, DESIGN.md 16.10) -- the round-3 constants too; the same rows with the '
+                      'pyramidal cone of rounds 1 - 3 are in `pyramidal_cone` (measured before 16.10 was built, same protocol)', results={},
+             pyramidal_cone={'shipped_round4 constants (3.35, 0.07, 0.95), recorded reset state': dict(fit_score_mm=8.29, heldout_score_mm=9.79, heldout={'sawyer_door/forward': [[3.0, 1.7], 2],
+                             'sawyer_door/reverse': [[13.3, 40.1], 0], 'sawyer_peg/forward': [[8.2, 3.6, 2.7, 2.8, 7.0], 1], 'sawyer_peg/reverse': [[4.1, 4.1, 3.6, 4.4, 2.5, 2.5, 5.3, 4.8, 15.9, 5.3], 4]}),
+                             'shipped_round3 (4, rule, 0.8), converged reset state': dict(fit_score_mm=9.51, heldout_score_mm=14.81, heldout={'sawyer_door/forward': [[2.0, 3.2], 2],
+                             'sawyer_door/reverse': [[11.3, 69.7], 0], 'sawyer_peg/forward': [[8.1, 5.5, 11.2, 4.4, 9.9], 4], 'sawyer_peg/reverse': [[11.1, 11.0, 16.3, 6.4, 5.7, 3.6, 6.1, 8.8, 8.8, 5.7], 3]})})
   for name, p, rs in (('shipped_round4 (3.35, 0.07, 0.95), recorded reset state', (CAL_T, CAL_R, CAL_D, 1), 'recorded'),
                       ('round4 constants, converged reset state', (CAL_T, CAL_R, CAL_D, 1), 'converged'),
                       ('shipped_round3 (4, rule, 0.8), converged reset state', ROUND3 + (1,), 'converged'),

@@ -417,7 +417,7 @@ def compile_model(name, path=None):
                         solref=vec(el.get('solref'), 2, [0.02, 1]), solimp=solimp5(el.get('solimp'))))
 
   out = dict(
-      name=np.array(name), timestep=np.float64(opt.get('timestep', 0.002)), gravity=vec(opt.get('gravity'), 3, [0, 0, -9.81]),
+      name=np.array(name), timestep=np.float64(opt.get('timestep', 0.002)), cone_elliptic=np.int32(opt.get('cone', 'pyramidal') == 'elliptic'), gravity=vec(opt.get('gravity'), 3, [0, 0, -9.81]),
       body_parent=np.array([b['parent'] for b in bodies], np.int32), body_pos=np.stack([b['pos'] for b in bodies]),
       body_quat=np.stack([b['quat'] for b in bodies]), body_mocap=np.array([b['mocap'] for b in bodies], np.int32),
       body_free=np.array([b.get('free', 0) for b in bodies], np.int32),
