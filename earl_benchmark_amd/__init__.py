@@ -104,7 +104,7 @@ class EARLEnvs(object):
       import warnings
       warnings.warn(f'{self._env_name}: the rigid-body dynamics are this build\'s own stepper and contact model; parity with the reference\'s '
                     'MuJoCo 2.1 / PyBullet is UNPINNED (DESIGN.md sections 9-11, 14: Sawyer envs agree with the recorded demonstrations at trajectory '
-                    'level, with two constants calibrated on them and checked on held-out episodes; the kitchen has no recordings at all; the '
+                    'level, with three constants and the episodes\' start state calibrated on them and checked on held-out episodes (DESIGN.md 16.9); the kitchen has no recordings at all; the '
                     'minitaur\'s robot MODEL is this build\'s own authoring -- the reference ships no URDF).  Pass '
                     'allow_unpinned_dynamics=True to EARLEnvs to silence this.', UnpinnedDynamicsWarning,
                     stacklevel=3)

@@ -2,8 +2,9 @@
  * sawyer_door and sawyer_peg).
  *
  * STATUS: smooth dynamics, weld / joint-limit constraints, frictional contacts (spheres / points vs boxes, plate edges vs
- * capsules, pyramidal friction).  The weld's translational regulariser carries a factor calibrated against the reference's
- * MuJoCo recordings.  Parity with MuJoCo is UNPINNED (the
+ * capsules; friction cone per model: elliptic for the Sawyer scenes, as their MJCF asks, pyramidal for the kitchen and the minitaur -- earl_collision_model.cone,
+ * DESIGN.md 16.10).  The weld's regularisers carry two factors identified on the contact-free prefixes of the reference's MuJoCo recordings (translation x 3.35,
+ * rotation x 0.07: DESIGN.md 16.9; rounds 1 - 3: 4.0 and the "mocap quaternion as given" rule, section 9).  Parity with MuJoCo is UNPINNED (the
  * simulator is not available to this build): the kernel is tested against this build's own CPU reference
  * (oracle/physics_oracle.py: LinkModel) which follows MuJoCo's documented pipeline and is checked by first principles;
  * the model tables and forward kinematics ARE pinned by numbers recorded in the reference (tests/test_physics.py).
