@@ -1792,7 +1792,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         // the record cone_apply reads: (K, m1, m2, q, 1 / mu^2) and the right-hand side h = W (J a_k) - grad.  Bottom zone: W = D I, h = D aref.  Middle zone, with
         // r = J a_k - aref, rho = |r_t|, sl = r_n - mu rho < 0: K = D / (1 + mu^2), m = -mu r_t / rho, q = -K mu sl / rho, grad = K sl (1, m1, m2)
         double K = 0, m1 = 0, m2 = 0, q = 0, h0 = 0, h1 = 0, h2 = 0;
-        const double i2 = rcp_nr(cmu * cmu);
+        const double i2 = cmu > 0 ? rcp_nr(cmu * cmu) : 0.0;      // (a frictionless class: m = 0 and q = 0, the record is the normal row alone)
         if (cact == 1u) {
           K = cD; q = cD; h0 = cD * car[0]; h1 = cD * car[1]; h2 = cD * car[2];
         } else if (cact == 2u) {
