@@ -173,3 +173,31 @@ def test_peg_steps_match_reference(peg):
     q1, v1, _ = lm.step(q1, v1, ctrl[0], mp[0], mq[0])
   r1 = cm.run(qpos[:1], qvel[:1], mp[:1], mq[:1], ctrl[:1], nsub=nsub)
   np.testing.assert_allclose(q1, r1['qpos'][0], atol=1e-12)
+
+
+def test_peg_elliptic_cone_sliding_friction_through_the_kernel(peg):
+  """Round 4 (CPU twin: tests/test_physics_peg.py): the peg at rest on the table top, set sliding at 0.3 - 2 m/s in seven directions -- the kernel's
+  accelerations equal the numpy statement's and obey a_xy = -mu (a_z + g) v / |v|: the friction force is on the cone's surface, opposite to the motion, in every direction."""
+  torch, dm, lm = peg
+  assert lm.elliptic
+  kw = dict(dtype=torch.float64, device='cuda')
+  hand, mq, ctrl = torch.tensor([[0.0, 0.6, 0.2]], **kw), torch.tensor([[1.0, 0, 1.0, 0]], **kw), torch.tensor([[-1.0, 1.0]], **kw)
+  q = torch.tensor(lm.qpos0, **kw).reshape(1, -1).contiguous(); v = torch.zeros(1, 15, **kw)
+  dm.step(q, v, hand, mq, ctrl, nsub=1500)
+  q[0, 9:12] = torch.tensor([0.1, 0.6, 0.0152], **kw); v[0, 9:] = 0
+  dm.step(q, v, hand, mq, ctrl, nsub=400)                                   # the peg comes to rest on its four bottom corners
+  assert float(v[0, 9:].abs().max()) < 1e-5
+  cases = [(s, a) for s in (0.3, 1.0, 2.0) for a in (0.0, 0.5, np.pi / 4, 1.2, np.pi / 2, 2.5, 4.0)]
+  n = len(cases)
+  Q, V = q.repeat(n, 1).contiguous(), v.repeat(n, 1).contiguous()
+  D = np.array([[np.cos(a), np.sin(a)] for _, a in cases])
+  V[:, 9:11] = torch.tensor(D * np.array([[s] for s, _ in cases]), **kw)
+  qacc, _, _ = dm.forward(Q, V, hand.repeat(n, 1).contiguous(), mq.repeat(n, 1).contiguous(), ctrl.repeat(n, 1).contiguous())
+  A = qacc.cpu().numpy()[:, 9:12]
+  qn, Vn = Q.cpu().numpy(), V.cpu().numpy()
+  for i in range(n):
+    ref = lm.forward(qn[i], Vn[i], np.array([-1.0, 1.0]), np.array([0.0, 0.6, 0.2]), np.array([1.0, 0, 1.0, 0]))['qacc'][9:12]
+    np.testing.assert_allclose(A[i], ref, rtol=0, atol=1e-7 * (1 + np.abs(ref).max()))
+    fn = A[i, 2] + 9.81
+    assert fn > 0.5 * 9.81
+    np.testing.assert_allclose(A[i, :2], -fn * D[i], rtol=0, atol=2e-3 * fn, err_msg=str(cases[i]))

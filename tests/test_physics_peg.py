@@ -211,3 +211,33 @@ def test_retaining_walls_keep_a_pushed_peg_on_the_table():
     assert min(zs) > 0.012 and abs(v[0, 10]) < 0.05                       # still lying on the table top, at rest
     assert (max(ys) < wall - 0.005) if vy > 0 else (min(ys) > wall + 0.005)
     assert abs(ys[-1] - wall) < 0.03                                        # ... right at the wall
+
+
+def test_elliptic_cone_sliding_friction_is_coulomb_and_isotropic():
+  """Round 4: the Sawyer scenes declare cone="elliptic".  A peg resting on the table top (mu = 1) and set sliding: whatever the direction and the speed, the
+  friction force lies on the cone's surface opposite to the motion -- with all contacts sliding the same way, momentum balance gives a_xy = -mu (a_z + g) v / |v| exactly (the
+  middle zone of MuJoCo's cost; a contact slower than mu g / b stays in the sticking zone and follows its reference acceleration instead).  The four pyramid edges of rounds 1 - 3 bound |f_t1| + |f_t2| instead: along a diagonal of the tangent basis the peg slid with mu / sqrt 2 and
+  the force was not opposite to the motion.  Same check through the HIP kernel: tests/test_physics_gpu.py."""
+  from oracle import physics_c
+  cm = physics_c.CModel('sawyer_peg')
+  lm = po.LinkModel(LINKS)
+  assert int(cm.col.cone) == 1 and lm.elliptic
+  hand = np.array([0, 0.6, 0.2])
+  r = cm.run(cm.tables['qpos0'][None], np.zeros((1, 15)), hand, [1, 0, 1, 0], [-1, 1], nsub=1500)
+  q, v = r['qpos'].copy(), r['qvel'].copy()
+  q[0, 9:12] = [0.1, 0.6, 0.0152]; v[0, 9:] = 0
+  rr = cm.run(q, v, hand, [1, 0, 1, 0], [-1, 1], nsub=400)                       # the peg comes to rest on its four bottom corners
+  q, v = rr['qpos'], rr['qvel']
+  assert int(rr['ncon'][0]) == 4 and np.abs(v[0, 9:]).max() < 1e-5
+  g = 9.81
+  for speed in (0.3, 1.0, 2.0):          # (fast enough that the reference deceleration b v exceeds mu g: below 0.09 m/s a soft contact follows its reference inside the cone)
+    for ang in (0.0, 0.5, np.pi / 4, 1.2, np.pi / 2, 2.5, 4.0):
+      d = np.array([np.cos(ang), np.sin(ang)])
+      v1 = v.copy(); v1[0, 9:11] = speed * d
+      a = cm.run(q, v1, hand, [1, 0, 1, 0], [-1, 1], integrate=False)['qacc'][0, 9:12]
+      ref = lm.forward(q[0], v1[0], np.array([-1.0, 1.0]), hand, np.array([1.0, 0, 1, 0]))['qacc'][9:12]
+      np.testing.assert_allclose(a, ref, rtol=0, atol=1e-7 * (1 + np.abs(ref).max()))
+      fn = a[2] + g                                                               # sum of the normal forces per unit mass
+      assert fn > 0.5 * g, (speed, ang, fn)
+      np.testing.assert_allclose(a[:2], -1.0 * fn * d, rtol=0, atol=2e-3 * fn, err_msg=f'speed {speed} angle {ang}')    # (2e-3: the slides carry the body's frame origin, the friction
+                                                                                                                # at the bottom corners also pitches the peg; the pyramid was off by up to 29 %)
