@@ -1,7 +1,7 @@
 /* physics_oracle.c -- plain C restatement of the articulated-body stepper, one env at a time (scalar loops).
  *
  * TEST INFRASTRUCTURE, NOT PRODUCT.  It restates oracle/physics_oracle.py (LinkModel.forward / step / collide /
- * contact_rows / solve_primal), which remains the readable statement; this file exists (a) as a third implementation to
+ * contact_rows / solve_primal / solve_primal_elliptic -- the friction cone is the model's: earl_collision_model.cone), which remains the readable statement; this file exists (a) as a third implementation to
  * cross-check the numpy one and the HIP kernels, (b) as the CPU baseline of `bench.py --workload sawyer_door` (OpenMP over
  * envs).  PARITY WITH MUJOCO IS UNPINNED, exactly as for the numpy statement (see its header and DESIGN.md section 9);
  * the env glue follows oracle/sawyer_oracle.py (reference: earl_benchmark/envs/sawyer_door.py:86-177, metaworld upstream).

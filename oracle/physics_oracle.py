@@ -9,7 +9,12 @@ qpos0).  **Parity with MuJoCo is UNPINNED**: MuJoCo 2.1 / metaworld are not in /
   solref / solimp impedance and the dual problem (A + R) f = aref - J a0 solved by projected Gauss-Seidel ->
   semi-implicit Euler with implicit joint damping.
 
-What IS pinned by the reference's own data: the model tables + forward kinematics reproduce the two door-handle
+(That paragraph describes the body-level functions at the top of this file.  The reduced LinkModel further down -- the statement the HIP kernels follow -- adds the
+frictional contacts, with the cone the model's MJCF declares: four pyramid edges per contact, or MuJoCo's elliptic three-zone cost, solve_primal_elliptic, for the Sawyer
+scenes since round 4; its constraint solve is the primal active-set Newton iteration the kernels run.)
+
+What IS pinned by the reference's own data: since round 4 the arm + weld dynamics on the contact-free prefixes of the 40 recorded Sawyer episodes (hand path within 1 mm RMS,
+tools/weld_free_motion_fit.py; two weld factors calibrated there, declared below); and the model tables + forward kinematics reproduce the two door-handle
 positions recorded in envs/sawyer_door.py:46-47 to 1e-8 (tests/test_physics.py).
 All joints are 1-dof (hinge / slide), so nq == nv.
 """
