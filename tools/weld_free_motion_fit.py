@@ -9,6 +9,8 @@ the FIT-set episodes (even-numbered, tools/heldout_eval.py's split) plus the rec
 
   python tools/weld_free_motion_fit.py sawyer_door            # joint fit -> profiles/r04_weld_free_motion_fit.json (door and peg separately; they agree)
   python tools/weld_free_motion_fit.py sawyer_door --scan     # RMS over a grid of factors, start state re-fitted at every point
+  python tools/weld_free_motion_fit.py sawyer_door --axes     # six per-row factors free (oracle_set_weld_row_scale): is the translational factor isotropic?
+  python tools/weld_free_motion_fit.py --joint                # one pair for both tasks: the shipped values
 
 CPU, test infrastructure (imports oracle/); reads the demonstrations shipped under earl_benchmark_amd/demonstrations."""
 import ctypes as C
@@ -111,8 +113,32 @@ def joint_fit():
   return out
 
 
+def axes_fit(task):
+  """the six weld rows with a factor each (on top of the derived values): translation x, y, z (world axes), rotation x, y, z (hand axes)"""
+  f = FreeMotion(task, 'all'); f.set(1.0, 1.0)
+  def res(x):
+    lib().oracle_set_weld_row_scale((C.c_double * 6)(*np.exp(x[14:20])))
+    return f.residuals(x[:14])
+  x0 = np.concatenate([f.qc[:7], f.vc[:7], np.log([3.35] * 3 + [0.07] * 3)])
+  try:
+    sol = least_squares(res, x0, diff_step=1e-4, x_scale=np.concatenate([np.full(7, 0.1), np.full(7, 1.0), np.full(6, 0.3)]), max_nfev=200)
+    e = res(sol.x)[3:]
+  finally:
+    lib().oracle_set_weld_row_scale(None)
+  out = dict(row_factors=np.exp(sol.x[14:20]).tolist(), rms_mm=float(np.sqrt((e ** 2).mean() * 3)))
+  print(task, 'per-row factors (translation x y z, rotation x y z)', np.round(out['row_factors'], 3), 'RMS %.2f mm (all episodes)' % out['rms_mm'])
+  return out
+
+
 def main():
   physics_c.set_threads(min(8, os.cpu_count() or 1))
+  if '--axes' in sys.argv:
+    task = ([a for a in sys.argv[1:] if not a.startswith('-')] or ['sawyer_door'])[0]
+    path = os.path.join(ROOT, 'profiles', 'r04_weld_free_motion_fit.json')
+    prev = json.load(open(path)) if os.path.exists(path) else {}
+    prev.setdefault('per_row', {})[task] = axes_fit(task)
+    json.dump(prev, open(path, 'w'), indent=1)
+    return
   if '--joint' in sys.argv:
     path = os.path.join(ROOT, 'profiles', 'r04_weld_free_motion_fit.json')
     prev = json.load(open(path)) if os.path.exists(path) else {}
