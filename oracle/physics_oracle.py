@@ -41,7 +41,7 @@ def quat_conj(q):
 # MJCF constants, the weld and the state the episode starts from.  Least squares over the start state (one per task) and the two factors,
 # FIT-set episodes (even-numbered) only, door and peg jointly: translation x 3.35, rotation x 0.07; replayed hand path within 0.95 / 0.81 mm
 # RMS of the recorded one (held-out prefixes 1.01 / 0.92 mm; with round 2's (4.0, 1.0): 4.8 / 1.6 mm even with the start state free).  The
-# two tasks fitted separately agree (door 3.2 / 0.06, peg 3.6 / 0.08); freeing the arm's joint damping as well leaves it at 0.9 x the MJCF
+# two tasks fitted separately agree (door 3.2 / 0.06, peg 3.6 / 0.08); freeing the arm's joint damping as well leaves it within 10 % of the MJCF
 # value, i.e. the arm model is not what absorbs the factors.  What the rotational factor means physically: the wrist's three weld rows are
 # 14 x stiffer than derived, the hand tilts 2 - 3 degrees under the loads of the door pull instead of round 3's 18.
 # Which MuJoCo 2.1 rule produces either factor is not identified (3.35 is close to what body_invweight0 becomes if J M^-1 J^T is replaced

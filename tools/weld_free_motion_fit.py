@@ -10,6 +10,7 @@ the FIT-set episodes (even-numbered, tools/heldout_eval.py's split) plus the rec
   python tools/weld_free_motion_fit.py sawyer_door            # joint fit -> profiles/r04_weld_free_motion_fit.json (door and peg separately; they agree)
   python tools/weld_free_motion_fit.py sawyer_door --scan     # RMS over a grid of factors, start state re-fitted at every point
   python tools/weld_free_motion_fit.py sawyer_door --axes     # six per-row factors free (oracle_set_weld_row_scale): is the translational factor isotropic?
+  python tools/weld_free_motion_fit.py sawyer_door --damping  # the two weld factors AND the arm's joint damping (joints 0-3, 4-6) free: is the arm model what absorbs the factors?
   python tools/weld_free_motion_fit.py --joint                # one pair for both tasks: the shipped values
 
 CPU, test infrastructure (imports oracle/); reads the demonstrations shipped under earl_benchmark_amd/demonstrations."""
@@ -130,8 +131,36 @@ def axes_fit(task):
   return out
 
 
+def damping_fit(task):
+  """the weld factors and two factors on the MJCF's joint damping (10 N m s / rad on every arm joint): proximal joints 0-3, wrist joints 4-6"""
+  f = FreeMotion(task, 'all'); st = f.cm.struct
+  base = np.array(st.damping[:7])
+  def res(x):
+    for j in range(7):
+      st.damping[j] = base[j] * np.exp(x[16 if j < 4 else 17])
+    return f.residuals(x[:16])
+  x0 = np.concatenate([f.qc[:7], f.vc[:7], np.log([3.35, 0.07]), [0.0, 0.0]])
+  try:
+    sol = least_squares(res, x0, diff_step=1e-4, x_scale=np.concatenate([np.full(7, 0.1), np.full(7, 1.0), np.full(4, 0.3)]), max_nfev=200)
+    e = res(sol.x)[3:]
+  finally:
+    for j in range(7):
+      st.damping[j] = base[j]
+  out = dict(weld_translation=float(np.exp(sol.x[14])), weld_rotation=float(np.exp(sol.x[15])), damping_proximal=float(np.exp(sol.x[16])), damping_wrist=float(np.exp(sol.x[17])),
+             rms_mm=float(np.sqrt((e ** 2).mean() * 3)))
+  print(task, out)
+  return out
+
+
 def main():
   physics_c.set_threads(min(8, os.cpu_count() or 1))
+  if '--damping' in sys.argv:
+    task = ([a for a in sys.argv[1:] if not a.startswith('-')] or ['sawyer_door'])[0]
+    path = os.path.join(ROOT, 'profiles', 'r04_weld_free_motion_fit.json')
+    prev = json.load(open(path)) if os.path.exists(path) else {}
+    prev.setdefault('damping_free', {})[task] = damping_fit(task)
+    json.dump(prev, open(path, 'w'), indent=1)
+    return
   if '--axes' in sys.argv:
     task = ([a for a in sys.argv[1:] if not a.startswith('-')] or ['sawyer_door'])[0]
     path = os.path.join(ROOT, 'profiles', 'r04_weld_free_motion_fit.json')
