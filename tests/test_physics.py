@@ -405,3 +405,35 @@ def test_warm_start_changes_the_passes_not_the_results(task):
   steps = T * n * 5
   assert passes[0][3] <= 0.01 * steps and passes[1][3] <= 0.01 * steps, (passes, steps)      # (nearly) every timestep ends within the 8 passes
   assert passes[1][0] <= passes[0][0] and passes[0][1] > 0     # never more passes warm; contacts were in play
+
+
+@pytest.mark.parametrize('task,bound', [('sawyer_door', 1.3e-3), ('sawyer_peg', 1.2e-3)])
+def test_contact_free_prefixes_of_the_recordings_replay_within_a_millimetre(task, bound):
+  """Round 4: before the gripper touches anything the recorded hand path depends only on the arm, the weld and the start state.  With the shipped weld factors
+  and the shipped start state (tables reset_*_recorded) the HELD-OUT episodes' prefixes (odd-numbered; door 13 / 38 env steps, peg 11) replay within 1.0 / 0.9 mm RMS of MuJoCo's
+  recording on the C restatement (rounds 1 - 3: 5 - 7 mm), and the first observation within 0.4 mm."""
+  import sys
+  sys.path.insert(0, os.path.join(REPO, 'tools'))
+  import weld_free_motion_fit as wf
+  f = wf.FreeMotion(task, 'heldout')
+  f.set(wf.he.CAL_T, wf.he.CAL_R)
+  t = f.cm.tables
+  assert np.allclose(t['weld_calibration'], [wf.he.CAL_T, wf.he.CAL_R])
+  x = np.concatenate([t['reset_qpos_recorded'], t['reset_qvel_recorded']])
+  r = f.residuals(x)
+  first, e = r[:3] / 3, r[3:]
+  assert np.abs(first).max() < 0.4, first                                  # mm
+  rms = np.sqrt((e ** 2).mean() * 3) * 1e-3
+  assert rms < bound, rms
+
+
+def test_loader_refuses_tables_of_the_other_friction_cone():
+  """csrc/physics.hip compiles the cone per model size (Lim<NV>::ELLIPTIC: the Sawyer door and peg); tables saying otherwise must not reach the kernels"""
+  from earl_benchmark_amd import physics
+  _, tables = physics.load_link_model('sawyer_door')
+  assert int(tables['cone_elliptic']) == 1 and physics.load_collision_model(tables).cone == 1
+  wrong = dict(tables); wrong['cone_elliptic'] = np.int32(0)
+  with pytest.raises(AssertionError):
+    physics.load_collision_model(wrong)
+  _, kt = physics.load_link_model('kitchen')
+  assert physics.load_collision_model(kt).cone == 0                         # the kitchen's MJCF has MuJoCo's default (pyramidal) cone
