@@ -539,6 +539,7 @@ def run_sawyer(a, torch, dist, world, rank, device, workload, steps, warmup, n=8
                     'schedule': ('one launch; persistent waves take (group of 4 envs, 10-step slice) items from a queue, least-advanced group first (csrc/physics.hip sched_claim)'
                                  if (peg and n > 4096) else 'one launch; one env group per wave' + (' (eight waves per CU)' if n > 4096 else '')),
                     'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'env_steps_per_bench_step': n * T * world,
+                    'friction_cone': 'elliptic (the scene\'s MJCF; DESIGN.md 16.10)', 'reset_state': 'recorded (DESIGN.md 16.9)',
                     'parallelism': f'env-range shard x{world}, no per-step collective'},
          'valu_frac': roof['frac'], 'roofline': roof,
          'cpu_baseline': CPU_RESULTS.get(workload) if cpu_seconds is not None else None}
