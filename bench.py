@@ -10,7 +10,8 @@ reset()), so a 4096-env batch (64 workgroups on 256 CUs) has four of them in fli
 flight per env is reported next to it (config.strict, and the `sequential_episodes` key).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 4096] [--horizon 200] [--sweep] [--no-cpu]
-  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+  N > 1: either under the launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...), or
+         plain `python bench.py --gpus N`: without WORLD_SIZE in the environment main() starts that launcher itself as a child process (self_launch)
 
 Prints ONE JSON line (rank 0).  Extra keys: "roofline" (fused rollout kernel: algorithmic bytes / HIP-event time
 vs 8 TB/s), "cpu_baseline" (the C oracle on the host cores, bounded sample), "step_api" (the same workload
@@ -39,7 +40,7 @@ BYTES_PER_ENV_STEP_STEP = 144    # + fp64 state in/out per launch: qpos 2x32, at
 STATE_BYTES_PER_ENV_LAUNCH = 2 * (32 + 1 + 4) + 4   # rollout: state read+written once per launch
 
 
-def parse():
+def parse(argv=None):
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
   p.add_argument('--steps', type=int, default=20)       # 20 launches of 28 evaluation episodes each (the command tools/profile_bench.sh profiles)
@@ -63,11 +64,15 @@ def parse():
   p.add_argument('--settle-launches', type=int, default=40,
                  help='untimed launches of the headline shape BEFORE the --warmup ones: the board reaches its sustained power state (the first ~30 launches of a '
                       'process run 5-15 %% faster), so that `value` and `roofline.frac` are the sustained figures')
+  p.add_argument('--roofline-windows', type=int, default=5,
+                 help='timed windows of --steps launches each the roofline figure is taken over (median, with min / max); the FIRST window is the one `value` is timed in')
+  p.add_argument('--test-env-factory', default=None, help=argparse.SUPPRESS)   # internal (tests/test_bench_launch.py): 'module:callable' -> the tabletop env of this rank; the launch
+  p.add_argument('--test-backend', default=None, help=argparse.SUPPRESS)       # path (self-launch -> torch.distributed.run -> main) then runs over gloo on host tensors.  Never a product path.
   p.add_argument('--cpu-child', default=None, help=argparse.SUPPRESS)        # internal: run one CPU baseline in this (fresh, torch-free) process and print its JSON
   p.add_argument('--cpu-child-args', default='{}', help=argparse.SUPPRESS)
   p.add_argument('--workload', default='tabletop', choices=['tabletop', 'sawyer_door', 'sawyer_peg', 'kitchen', 'minitaur'],
                  help='tabletop = BASELINE configs[1] (the default, the quoted metric); sawyer_door / sawyer_peg = configs[2] shape, N=8192 each (next rows)')
-  return p.parse_args()
+  return p.parse_args(argv)
 
 
 def make_env(torch, n, horizon, reward, rank, device):
@@ -808,8 +813,31 @@ def main_sawyer(a, torch, dist, world, rank, device):
     dist.destroy_process_group()
 
 
-def main():
-  a = parse()
+def self_launch(a, argv):
+  """`python bench.py --gpus N` started WITHOUT a launcher (N > 1, no WORLD_SIZE in the environment): start the one-process-per-GPU job as a CHILD process
+  -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` --, relay its stdout
+  (rank 0's ONE JSON line) and return its exit code.  A fresh child, never an exec of this process; this process has not imported torch nor touched a GPU."""
+  import socket
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+         os.path.abspath(__file__), *argv]
+  print(f'bench.py: --gpus {a.gpus} without a launcher: starting {" ".join(cmd[1:8])} ... as a child process', file=sys.stderr, flush=True)
+  proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+  for line in proc.stdout:                                    # relay as it comes (stderr is inherited)
+    sys.stdout.write(line)
+    sys.stdout.flush()
+  return proc.wait()
+
+
+def main(argv=None):
+  argv = list(sys.argv[1:] if argv is None else argv)
+  a = parse(argv)
+  if a.gpus > 1 and 'WORLD_SIZE' not in os.environ and not a.cpu_child:
+    sys.exit(self_launch(a, argv))
   if a.cpu_child:                                             # a CPU baseline child of another bench.py: never touches the GPU
     cpu_child_main(a.cpu_child, json.loads(a.cpu_child_args))
     if hasattr(os, 'sched_setaffinity'):
@@ -831,16 +859,19 @@ def main():
   import torch.distributed as dist
   if hasattr(os, 'sched_setaffinity') and 'OMP_PROC_BIND' not in os.environ:
     assert sorted(os.sched_getaffinity(0)) == AVAIL_CPUS, 'importing torch changed this process\'s CPU affinity'
-  if world != a.gpus:
-    if world == 1 and a.gpus > 1:
-      sys.exit(f'--gpus {a.gpus} needs the torch.distributed.run launcher (one process per GPU)')
-    a.gpus = world
-  if not torch.cuda.is_available():
-    sys.exit('bench.py needs an MI355X (the hot path has no CPU fallback)')
-  torch.cuda.set_device(local_rank)
-  device = f'cuda:{local_rank}'
-  if world > 1:
-    dist.init_process_group('nccl', device_id=torch.device(device))
+  a.gpus = world                                             # (the launcher's WORLD_SIZE is what runs; main() self-launches when --gpus N > 1 came without one)
+  stub = a.test_env_factory is not None                        # tests/test_bench_launch.py only: host tensors, gloo
+  if stub:
+    device = 'cpu'
+    if world > 1:
+      dist.init_process_group(a.test_backend or 'gloo')
+  else:
+    if not torch.cuda.is_available():
+      sys.exit('bench.py needs an MI355X (the hot path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+    if world > 1:
+      dist.init_process_group('nccl', device_id=torch.device(device))
   if a.workload in ('sawyer_door', 'sawyer_peg'):
     return main_sawyer(a, torch, dist, world, rank, device)
   if a.workload == 'minitaur':
@@ -870,7 +901,11 @@ def main():
   wgs = (n + 63) // 64
   in_flight = min(E, max(1, 256 // wgs)) if (E > 1 and wgs * 2 <= 256) else 1     # csrc/tabletop.hip do_rollout: episode groups side by side
 
-  env = make_env(torch, n, T, a.reward, rank, device)
+  if a.test_env_factory:
+    mod, fn = a.test_env_factory.split(':')
+    env = getattr(importlib.import_module(mod), fn)(n=n, T=T, rank=rank, world=world)
+  else:
+    env = make_env(torch, n, T, a.reward, rank, device)
   R = max(1, a.action_sets)
   # [E, T, n, 3] x R: every episode of a launch has its own actions, and consecutive launches read different tensors
   act_sets = [synth_actions(torch, T, n, rank + 1000 * r, device, E) for r in range(R)]
@@ -885,6 +920,12 @@ def main():
   dt, kern_ms, gathered, _, launches = time_rollouts(torch, dist, env, act_sets, out, a.steps, a.warmup + max(0, a.settle_launches), world, device)
   if world > 1:
     assert gathered.shape == (n * world, 2)
+  # roofline: the kernel's launch duration over several timed windows of the same shape (the first is the headline's own), median with min / max: one window
+  # moved 0.64 <-> 0.71 of peak between boxes / runs in round 4
+  window_ms = [kern_ms[0]]
+  for _ in range(max(0, a.roofline_windows - 1)):
+    _, wkm, _, _, _ = time_rollouts(torch, dist, env, act_sets, out, a.steps, 0, world, device)
+    window_ms.append(wkm[0])
   dn = out[2] if E > 1 else out[2][None]
   assert bool(dn[:, -1].all()) and not bool(dn[:, :-1].any())        # done fires exactly at the horizon, in every episode
   if E > 1:
@@ -935,17 +976,23 @@ def main():
     sawyer['minitaur'] = run_minitaur(a, torch, dist, world, rank, device, steps=2, warmup=1, cpu_seconds=None if (a.no_cpu or world > 1) else 2.0)
   res = None
   if rank == 0:
-    kmean = sum(kern_ms) / len(kern_ms)
+    kmean = sorted(window_ms)[len(window_ms) // 2]             # median launch duration over the timed windows
     # algorithmic bytes of a launch = bytes that cross the HBM interface: its E episodes x T steps x (12 B of actions in -- each episode
     # has its own --, obs 48 + reward 4 + done 1 + success 1 out) + the env state once (66 B per env-step fused)
     bytes_per_launch = n * (E * T * BYTES_PER_ENV_STEP_ROLLOUT + STATE_BYTES_PER_ENV_LAUNCH)
     achieved = bytes_per_launch / (kmean * 1e-3) / 1e9
-    traffic, traffic_source = None, None
+    traffic, traffic_source, compare = None, None, None
     tpath = os.path.join(REPO, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
       tj = json.load(open(tpath))
       key = f'eval_n{n}_T{T}_E{E}_own_actions' if E > 1 else f'rollout_n{n}_T{T}'
       traffic = tj.get(key, {}).get('hbm_bytes_per_launch')
+      pns = tj.get(key, {}).get('rocprof_kernel_average_ns')
+      if pns:                                                   # the committed rocprofv3 --kernel-trace --stats figure this line's `frac` is to be compared with
+        compare = {'profile': tj[key].get('stats', tj[key].get('source')), 'kernel_avg_us': pns / 1e3,
+                   'frac': bytes_per_launch / (pns * 1e-9) / 1e9 / HBM_PEAK_GBS,
+                   'note': 'STATIC: average launch duration of this kernel in the committed rocprofv3 --kernel-trace --stats run of this same command (another box, another '
+                           'day); this run\'s live figure is `frac` (median of `windows_ms`, min / max beside it)'}
       if traffic is not None:
         traffic_source = f"profiles/traffic.json <- {tj[key].get('source')} (static: FETCH_SIZE / WRITE_SIZE passes of rocprofv3 --pmc over this command -- same launch shape --, not measured in this run)"
     strict = {'one_episode_in_flight': None if sequential is None else sequential['value'],
@@ -963,12 +1010,20 @@ def main():
                    'actions': f'{R} x [{E}, {T}, {n}, 3] f32 per GPU ({R * E * T * n * 12 / 1e6:.0f} MB): distinct per episode, launches read the {R} tensors round-robin',
                    'action_sets': R,
                    'next_rows': {k: (v or {}).get('value') for k, v in sawyer.items()},
+                   # BASELINE configs[2..4] timed in this same run, compact (the full objects are the top-level keys of the same names)
+                   'other_workloads': {k: {'value': v.get('value'), 'unit': 'env-steps/s', 'ms': v.get('ms_per_step'), 'envs': v['config'].get('envs_per_gpu'),
+                                           'horizon': v['config'].get('horizon'), 'valu_x_lanes': (v.get('roofline') or {}).get('valu_x_lane_occupancy'),
+                                           'cpu': ((v.get('cpu_baseline') or {}).get('value')), 'cpu_cores': ((v.get('cpu_baseline') or {}).get('cores'))}
+                                       for k, v in sawyer.items() if v},
                    'parallelism': f'env-range shard x{world}, no per-step collective'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source, 'kernel': 'rollout_ws_kernel',
-                     'kernel_ms_mean': kmean, 'algorithmic_bytes_per_launch': bytes_per_launch,
+                     'kernel_ms_mean': kmean, 'kernel_ms_median': kmean, 'windows_ms': window_ms, 'windows': len(window_ms), 'launches_per_window': a.steps,
+                     'frac_min': bytes_per_launch / (max(window_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 'frac_max': bytes_per_launch / (min(window_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     'frac_headline_window': bytes_per_launch / (window_ms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 'compare_with_profile': compare,
+                     'algorithmic_bytes_per_launch': bytes_per_launch,
                      'bytes_per_env_step': BYTES_PER_ENV_STEP_ROLLOUT, 'episodes_per_launch': E, 'launches': launches,
-                     'strict_frac': strict['one_episode_in_flight_frac']},
+                     'strict_frac': strict['one_episode_in_flight_frac'], 'strict_value': strict['one_episode_in_flight']},
     }
     res['early_window'] = early
     res['reference_simulator'] = SIMULATORS
