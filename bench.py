@@ -300,7 +300,7 @@ def cpu_child_main(kind, kw):
   sim = kw.pop('simulators', None)
   global SIMULATORS
   SIMULATORS = sim
-  fn = {'tabletop': cpu_baseline, 'sawyer_door': lambda **k: sawyer_cpu_baseline(task='sawyer_door', **k), 'sawyer_peg': lambda **k: sawyer_cpu_baseline(task='sawyer_peg', **k),
+  fn = {'tabletop': cpu_baseline, 'tabletop_host': host_build_leg, 'sawyer_door': lambda **k: sawyer_cpu_baseline(task='sawyer_door', **k), 'sawyer_peg': lambda **k: sawyer_cpu_baseline(task='sawyer_peg', **k),
         'kitchen': kitchen_cpu_baseline, 'minitaur': minitaur_cpu_baseline}[kind]
   res = fn(**kw)
   print(json.dumps(res), flush=True)
@@ -317,6 +317,7 @@ def collect_cpu_baselines(a):
   jobs = []
   if a.workload == 'tabletop':
     jobs.append(('tabletop', dict(n=a.envs, T=a.horizon, reward=a.reward, seconds=a.cpu_seconds)))
+    jobs.append(('tabletop_host', dict(n=a.envs, T=a.horizon, reward=a.reward, seconds=2.0)))
     if not a.no_sawyer:
       jobs += [(w, dict(T_sample=0, seconds=a.sawyer_cpu_seconds, n=8192, simulators=sim)) for w in ('sawyer_door', 'sawyer_peg')]
     if not a.no_kitchen:
@@ -396,6 +397,43 @@ def cpu_baseline(n, T, reward, seconds):
                     f'OpenMP static over envs, {best} threads (fastest of {sorted(trials)}; host exposes {avail} CPUs)',
           'single_thread': trials[1], 'by_threads': {str(k): v for k, v in trials.items()},
           'scalar_python_loop_1env': scalar_rate, 'host': host_cpu_info()}
+
+
+def host_build_leg(n, T, reward, seconds):
+  """BASELINE configs[0] ("tabletop_manipulation sparse reward, 1 env, CPU ... plumbing, no GPU") on the PRODUCT's own host build (csrc/libearl_host.so: the
+  kernels' per-env functions compiled by g++, include/earl_tabletop.h `_cpu` entry points; NOT the oracle): (a) EARLEnvs(num_envs=1, device='cpu'), the
+  reference-shaped scalar loop -- reset() + T step() calls per episode, numpy in / the gym 4-tuple out; (b) the same library on the bench's own n-env batch,
+  reset + fused T-step rollout, all threads."""
+  import numpy as np
+  import torch
+  import earl_benchmark_amd as eb
+  from earl_benchmark_amd import _abi
+  _, env = eb.EARLEnvs('tabletop_manipulation', reward_type=reward, num_envs=1, device='cpu', eval_horizon=T).get_envs()
+  rng = np.random.default_rng(0)
+  acts = rng.uniform(-1, 1, (T, 3)).astype(np.float32)
+  episodes, t0 = 0, time.perf_counter()
+  while time.perf_counter() - t0 < seconds:
+    env.reset()
+    for t in range(T):
+      ob, rw, dn, info = env.step(acts[t])
+    episodes += 1
+  dt1 = time.perf_counter() - t0
+  assert dn is True and isinstance(rw, float) and ob.shape == (12,)
+  lib = _abi.load_host()
+  threads = lib.set_threads(len(AVAIL_CPUS))
+  _, benv = eb.EARLEnvs('tabletop_manipulation', reward_type=reward, num_envs=n, device='cpu', eval_horizon=T, scalar_api=False).get_envs()
+  a = torch.from_numpy(rng.uniform(-1, 1, (T, n, 3)).astype(np.float32))
+  out = benv.unwrapped._new_out((T, n))[0]
+  benv.rollout(a, out=out, reset_first=True)
+  reps, t0 = 0, time.perf_counter()
+  while time.perf_counter() - t0 < seconds:
+    benv.rollout(a, out=out, reset_first=True)
+    reps += 1
+  dtn = time.perf_counter() - t0
+  return {'scalar_env_steps_per_s': episodes * T / dt1, 'scalar_sample': f'{episodes} episodes of reset() + {T} step() calls on EARLEnvs(num_envs=1, device="cpu") ({dt1:.1f} s)',
+          'batch_env_steps_per_s': reps * n * T / dtn, 'batch_sample': f'{reps} x (reset + {T}-step rollout) of {n} envs, {threads} OpenMP threads ({dtn:.1f} s)',
+          'unit': 'env-steps/s', 'library': 'earl_benchmark_amd/csrc/libearl_host.so (csrc/tabletop_device.h compiled for the host; include/earl_tabletop.h *_cpu)',
+          'workload': f'BASELINE configs[0]: tabletop_manipulation {reward} reward, 1 env, CPU'}
 
 
 def sawyer_profile(workload, n, T):
@@ -1064,6 +1102,9 @@ def main(argv=None):
       res['sweep'] = sw
     if not a.no_cpu:
       res['cpu_baseline'] = CPU_RESULTS.get('tabletop')
+      res['config0_host_build'] = CPU_RESULTS.get('tabletop_host')          # BASELINE configs[0] on the product's own `_cpu` entry points
+      hb = CPU_RESULTS.get('tabletop_host') or {}
+      res['config']['config0_cpu_1env'] = {'scalar_env_steps_per_s': hb.get('scalar_env_steps_per_s'), 'batch_env_steps_per_s': hb.get('batch_env_steps_per_s')}
     else:
       res['cpu_baseline'] = None
     res.update(sawyer)            # "sawyer_door": {...}, "sawyer_peg": {...}: value, kernel_ms, issue_frac, roofline, cpu_baseline

@@ -188,7 +188,45 @@ def load():
   return _lib
 
 
-def check(rc, what):
+# ---- the host build of the tabletop per-env functions (csrc/tabletop_host.cpp -> csrc/libearl_host.so): the `_cpu` entry points of
+# include/earl_tabletop.h.  Loaded ONLY when a caller asks for device='cpu' (BASELINE configs[0]: "1 env, CPU ... plumbing, no GPU");
+# nothing falls back to it -- without a GPU the default device still raises EarlHipError.
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libearl_host.so')
+HOST_SIGNATURES = {name + '_cpu': argtypes[:-1] for name, argtypes in SIGNATURES.items()
+                   if name.startswith(('earl_tabletop_', 'earl_tabletop3_'))}            # same arguments minus the stream
+_host = None
+
+
+class HostLib:
+  """libearl_host.so behind the names (and argument lists) of the HIP library: `lib.earl_tabletop_step(..., stream)` calls
+  `earl_tabletop_step_cpu(...)` -- host pointers, no stream -- so that envs/tabletop.py drives either with the same code."""
+
+  def __init__(self, cdll):
+    self._cdll = cdll
+    for name, argtypes in HOST_SIGNATURES.items():
+      fn = getattr(cdll, name)                 # AttributeError here = header/library mismatch
+      fn.argtypes, fn.restype = argtypes, C.c_int
+      setattr(self, name, fn)
+      setattr(self, name[:-4], (lambda f: (lambda *a: f(*a[:-1])))(fn))
+    cdll.earl_host_last_error.restype = C.c_char_p
+    cdll.earl_host_version.restype = C.c_char_p
+    cdll.earl_host_set_threads.argtypes = [C.c_int]
+    self.earl_last_error = cdll.earl_host_last_error
+    self.earl_version = cdll.earl_host_version
+    self.set_threads = cdll.earl_host_set_threads
+
+
+def load_host():
+  """Load csrc/libearl_host.so (g++ build of csrc/tabletop_device.h + tabletop_step.h; `make -C earl_benchmark_amd/csrc`)."""
+  global _host
+  if _host is None:
+    if not os.path.exists(HOST_LIB_PATH):
+      raise EarlHipError(f'{HOST_LIB_PATH} not found: build it with `make -C earl_benchmark_amd/csrc libearl_host.so`')
+    _host = HostLib(C.CDLL(HOST_LIB_PATH))
+  return _host
+
+
+def check(rc, what, lib=None):
   if rc != EARL_OK:
-    msg = load().earl_last_error()
+    msg = (lib or load()).earl_last_error()
     raise EarlHipError(f'{what} failed with code {rc}: {msg.decode() if msg else "?"}')

@@ -1,6 +1,6 @@
 // philox.h -- Philox4x32-10 counter-based RNG shared by the env kernels (draw layout: see the callers and the oracle)
 #pragma once
-#include <hip/hip_runtime.h>
+#include "earl_rt.h"
 
 #include <cstdint>
 

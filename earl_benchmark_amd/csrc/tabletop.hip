@@ -14,124 +14,16 @@
 #include <cstring>
 
 #include "tabletop_device.h"
+#include "tabletop_hostside.h"
 #include "tabletop_rollout_ws.h"
+#include "tabletop_step.h"
 
 using namespace earl;
+using namespace earl::hostside;
 
 namespace {
 
 constexpr int kBlock = 256;
-
-struct KArgs {
-  earl_tabletop_cfg cfg;
-  earl_tabletop_state st;
-  earl_tabletop_out out;
-  const float* act;
-  const int32_t* next_goal_idx;
-  const uint8_t* mask;
-  float* obs_only;
-  int32_t T;
-  Thresholds th;
-};
-
-// ------------------------------------------------------------------------------------------------
-// per-lane state I/O
-// ------------------------------------------------------------------------------------------------
-template <int NOBJ>
-struct Lane {
-  Env<NOBJ> e;
-  int goal_idx;
-  int steps;
-  int sgc;      // steps since goal change (lifelong)
-  double lret;  // lifelong return
-  int resets;   // resets performed inside this launch (auto_reset)
-};
-
-template <int NOBJ>
-__device__ __forceinline__ void load_lane(const KArgs& a, int i, Lane<NOBJ>& L) {
-  constexpr int NQ = Dims<NOBJ>::NQ;
-  const double2* q2 = reinterpret_cast<const double2*>(a.st.qpos + (size_t)i * NQ);
-#pragma unroll
-  for (int k = 0; k < NQ / 2; ++k) {
-    const double2 v = q2[k];
-    L.e.q[2 * k] = v.x;
-    L.e.q[2 * k + 1] = v.y;
-  }
-  L.e.attached = a.st.attached[i];
-  L.goal_idx = a.st.goal_idx[i];
-  L.steps = a.st.steps_since_reset[i];
-  L.resets = 0;
-  if (a.cfg.goal_change_frequency > 0) {
-    L.sgc = a.st.steps_since_goal_change[i];
-    L.lret = a.st.lifelong_return[i];
-  } else {
-    L.sgc = 0;
-    L.lret = 0.0;
-  }
-}
-
-template <int NOBJ>
-__device__ __forceinline__ void store_lane(const KArgs& a, int i, const Lane<NOBJ>& L) {
-  constexpr int NQ = Dims<NOBJ>::NQ;
-  double2* q2 = reinterpret_cast<double2*>(a.st.qpos + (size_t)i * NQ);
-#pragma unroll
-  for (int k = 0; k < NQ / 2; ++k) q2[k] = double2{L.e.q[2 * k], L.e.q[2 * k + 1]};
-  a.st.attached[i] = (int8_t)L.e.attached;
-  a.st.steps_since_reset[i] = L.steps;
-  if (a.cfg.goal_change_frequency > 0) {
-    a.st.steps_since_goal_change[i] = L.sgc;
-    a.st.lifelong_return[i] = L.lret;
-    a.st.goal_idx[i] = L.goal_idx;
-  }
-  if (L.resets) {
-    a.st.goal_idx[i] = L.goal_idx;
-    a.st.num_interventions[i] += L.resets;
-  }
-}
-
-template <int NOBJ>
-__device__ __forceinline__ void store_obs(float* __restrict__ dst, const float (&o)[Dims<NOBJ>::NOBS]) {
-  float4* d4 = reinterpret_cast<float4*>(dst);  // rows are 48 B / 80 B: 16-byte aligned
-#pragma unroll
-  for (int k = 0; k < Dims<NOBJ>::NOBS / 4; ++k) d4[k] = float4{o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]};
-}
-
-// One wrapped step on register state.  `counter` is the Philox counter of THIS step.
-// GENERAL = lifelong goal switching and auto-reset compiled in (they drag the Philox generator into the loop).
-template <int NOBJ, bool GENERAL>
-__device__ __forceinline__ void wrapped_step(const KArgs& a, int i, uint64_t counter, Lane<NOBJ>& L,
-                                             float (&g)[Dims<NOBJ>::NG], float a0, float a1, float a2,
-                                             float (&o)[Dims<NOBJ>::NOBS], float& reward, bool& done, bool& succ, double* r64 = nullptr) {
-  move<NOBJ>(L.e, rescale_action(a0), rescale_action(a1), rescale_action(a2), a.th);
-  make_obs<NOBJ>(L.e, g, o);
-  double r;
-  reward_success<NOBJ>(o, a.cfg.reward_type, a.cfg.wide_init, a.th, r, succ);
-  reward = (float)r;
-  if (r64) *r64 = r;
-  L.steps += 1;                       // persistent_state_wrapper.py:25-26
-  done = L.steps >= a.cfg.horizon;    // :28-29
-  if constexpr (NOBJ == 1 && GENERAL) {
-    if (a.cfg.goal_change_frequency > 0) {  // lifelong_wrapper.py:30-44
-      L.sgc += 1;
-      L.lret += r;
-      if (L.sgc >= a.cfg.goal_change_frequency) {
-        L.sgc = 0;
-        L.goal_idx = sample_goal(a.cfg, counter, i, a.next_goal_idx);
-        load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
-#pragma unroll
-        for (int k = 0; k < Dims<NOBJ>::NG; ++k) o[Dims<NOBJ>::NQ + 2 + k] = g[k];  // obs re-read with the new goal
-      }
-    }
-  }
-  if constexpr (GENERAL)
-  if (done && a.cfg.auto_reset) {  // batched-only extension; the outputs above stay the terminal ones
-    L.goal_idx = reset_env<NOBJ>(L.e, a.cfg, counter, i, a.st.goal_table, a.next_goal_idx, a.th);
-    load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
-    L.steps = 0;
-    L.sgc = 0;
-    L.resets += 1;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -139,101 +31,24 @@ __device__ __forceinline__ void wrapped_step(const KArgs& a, int i, uint64_t cou
 template <int NOBJ, bool GENERAL>
 __global__ __launch_bounds__(kBlock) void step_kernel(const KArgs a) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.cfg.n) return;
-  Lane<NOBJ> L;
-  load_lane<NOBJ>(a, i, L);
-  float g[Dims<NOBJ>::NG];
-  load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
-  const float* ap = a.act + (size_t)i * 3;
-  float o[Dims<NOBJ>::NOBS];
-  float reward;
-  bool done, succ;
-  double r64;
-  const uint64_t counter = a.cfg.counter + (a.st.counter_base ? *a.st.counter_base : 0ull);      // (counter_base: captured step loops, include/earl_tabletop.h)
-  wrapped_step<NOBJ, GENERAL>(a, i, counter, L, g, ap[0], ap[1], ap[2], o, reward, done, succ, &r64);
-  if (a.out.obs) store_obs<NOBJ>(a.out.obs + (size_t)i * Dims<NOBJ>::NOBS, o);
-  if (a.out.reward) a.out.reward[i] = reward;
-  if (a.out.reward_f64) a.out.reward_f64[i] = r64;
-  if (a.out.done) a.out.done[i] = done;
-  if (a.out.success) a.out.success[i] = succ;
-  store_lane<NOBJ>(a, i, L);
+  if (i < a.cfg.n) step_body<NOBJ, GENERAL>(a, i);
 }
 
 template <int NOBJ, bool GENERAL>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const KArgs a) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  const int n = a.cfg.n;
-  if (i >= n) return;
-  Lane<NOBJ> L;
-  load_lane<NOBJ>(a, i, L);
-  float g[Dims<NOBJ>::NG];
-  load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
-  constexpr int PF = 8;  // actions are state-independent: fetch PF steps ahead to keep loads in flight
-  for (int t0 = 0; t0 < a.T; t0 += PF) {
-    float av[PF][3];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-      const int t = t0 + k < a.T ? t0 + k : a.T - 1;
-      const float* ap = a.act + ((size_t)t * n + i) * 3;
-      av[k][0] = ap[0];
-      av[k][1] = ap[1];
-      av[k][2] = ap[2];
-    }
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-      const int t = t0 + k;
-      if (t < a.T) {
-        float o[Dims<NOBJ>::NOBS];
-        float reward;
-        bool done, succ;
-        wrapped_step<NOBJ, GENERAL>(a, i, a.cfg.counter + (uint64_t)t, L, g, av[k][0], av[k][1], av[k][2], o, reward, done, succ);
-        const size_t row = (size_t)t * n + i;
-        if (a.out.obs) store_obs<NOBJ>(a.out.obs + row * Dims<NOBJ>::NOBS, o);
-        if (a.out.reward) a.out.reward[row] = reward;
-        if (a.out.done) a.out.done[row] = done;
-        if (a.out.success) a.out.success[row] = succ;
-      }
-    }
-  }
-  store_lane<NOBJ>(a, i, L);
+  if (i < a.cfg.n) rollout_body<NOBJ, GENERAL>(a, i);
 }
 
 template <int NOBJ>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const KArgs a) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.cfg.n) return;
-  Lane<NOBJ> L;
-  load_lane<NOBJ>(a, i, L);
-  if (!a.mask || a.mask[i]) {
-    L.goal_idx = reset_env<NOBJ>(L.e, a.cfg, a.cfg.counter, i, a.st.goal_table, a.next_goal_idx, a.th);
-    L.steps = 0;   // persistent_state_wrapper.py:18-19
-    L.sgc = 0;     // lifelong_wrapper.py:26-27
-    L.resets = 1;
-    store_lane<NOBJ>(a, i, L);
-  }
-  if (a.obs_only) {
-    float g[Dims<NOBJ>::NG], o[Dims<NOBJ>::NOBS];
-    load_goal<NOBJ>(a.st.goal_table, L.goal_idx, g);
-    make_obs<NOBJ>(L.e, g, o);
-    store_obs<NOBJ>(a.obs_only + (size_t)i * Dims<NOBJ>::NOBS, o);
-  }
+  if (i < a.cfg.n) reset_body<NOBJ>(a, i);
 }
 
 __global__ __launch_bounds__(kBlock) void observe_kernel(const KArgs a) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.cfg.n) return;
-  Lane<1> L;
-  load_lane<1>(a, i, L);
-  float g[6], o[12];
-  load_goal<1>(a.st.goal_table, L.goal_idx, g);
-  make_obs<1>(L.e, g, o);
-  double r;
-  bool succ;
-  reward_success<1>(o, a.cfg.reward_type, a.cfg.wide_init, a.th, r, succ);
-  if (a.out.obs) store_obs<1>(a.out.obs + (size_t)i * 12, o);
-  if (a.out.reward) a.out.reward[i] = (float)r;
-  if (a.out.success) a.out.success[i] = succ;
-  if (a.out.done) a.out.done[i] = L.steps >= a.cfg.horizon;
+  if (i < a.cfg.n) observe_body(a, i);
 }
 
 template <int NOBJ>
@@ -241,106 +56,21 @@ __global__ __launch_bounds__(kBlock) void reward_kernel(int n, const float* __re
                                                         float* __restrict__ reward, uint8_t* __restrict__ success,
                                                         const Thresholds th) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  constexpr int NOBS = Dims<NOBJ>::NOBS;
-  float o[NOBS];
-  const float4* s4 = reinterpret_cast<const float4*>(obs + (size_t)i * NOBS);
-#pragma unroll
-  for (int k = 0; k < NOBS / 4; ++k) {
-    const float4 v = s4[k];
-    o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
-  }
-  double r;
-  bool succ;
-  reward_success<NOBJ>(o, reward_type, wide, th, r, succ);
-  if (reward) reward[i] = (float)r;
-  if (success) success[i] = succ;
+  if (i < n) reward_body<NOBJ>(i, obs, reward_type, wide, reward, success, th);
 }
 
 __global__ __launch_bounds__(kBlock) void valid_init_kernel(int n, const double* __restrict__ cand,
                                                             uint8_t* __restrict__ valid, const Thresholds th) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const double2* c2 = reinterpret_cast<const double2*>(cand + (size_t)i * 4);
-  const double2 u = c2[0], v = c2[1];
-  const double s[4] = {u.x, u.y, v.x, v.y};
-  valid[i] = valid_init(s, th);
+  if (i < n) valid_init_body(i, cand, valid, th);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-thread_local char g_err[512] = "";
 int g_rollout_lds_pad = 0;  // extra dynamic LDS per workgroup of the wave-specialised kernel (limits co-residency; tuning)
 int g_rollout_wgs_per_cu = 1;  // (tuning) workgroups per CU the episode groups of a multi-episode launch may fill
 int g_rollout_impl = 0;  // 0 = auto (wave-specialised when applicable), 1 = force the plain one-lane-per-env kernel
-
-int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof g_err, fmt, ap);
-  va_end(ap);
-  return code;
-}
-
-// smallest double s with sqrt(s) >= c  (so that  sqrt(d2) < c  <=>  d2 < s)
-double lt_threshold_f64(double c) {
-  double s = c * c;
-  while (std::sqrt(s) >= c) s = std::nextafter(s, 0.0);
-  while (std::sqrt(s) < c) s = std::nextafter(s, INFINITY);
-  return s;
-}
-// largest float s with (double)sqrtf(s) <= c  (so that  (double)sqrtf(x) <= c  <=>  x <= s)
-float le_threshold_f32(double c) {
-  float s = (float)(c * c);
-  while ((double)std::sqrt(s) <= c) s = std::nextafterf(s, INFINITY);
-  while ((double)std::sqrt(s) > c) s = std::nextafterf(s, 0.0f);
-  return s;
-}
-const Thresholds& thresholds() {
-  static const Thresholds th = {lt_threshold_f64(0.4), lt_threshold_f64(1.0), le_threshold_f32(0.2), le_threshold_f32(0.4)};
-  return th;
-}
-
-// smallest float x with rescale_action(x) > 0: the grip test `rescaled a[2] > 0` (:144) on the RAW action.
-// rescale is monotone, so a bisection over the (ordered) non-negative float bit patterns finds it exactly.
-float grip_threshold() {
-  static const float thr = [] {
-    auto rescaled_positive = [](float x) {
-      const double c = x < -1.0f ? -1.0 : (x > 1.0f ? 1.0 : (double)x);
-      volatile double v = -0.2 + ((c + 1.) * 0.5) * (0.2 - -0.2);
-      return v > 0;
-    };
-    uint32_t lo = 0u, hi = 0x3f800000u;  // +0.0f (not positive) .. 1.0f (positive)
-    while (hi - lo > 1) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      float f;
-      memcpy(&f, &mid, 4);
-      if (rescaled_positive(f)) hi = mid; else lo = mid;
-    }
-    float f;
-    memcpy(&f, &hi, 4);
-    return f;
-  }();
-  return thr;
-}
-
-int check_common(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int nobj) {
-  if (!cfg || !st) return fail(EARL_ERR_ARG, "cfg/state is NULL");
-  if (cfg->n < 0) return fail(EARL_ERR_ARG, "n = %d < 0", cfg->n);
-  if (!st->qpos || !st->attached || !st->goal_idx || !st->goal_table || !st->steps_since_reset || !st->num_interventions)
-    return fail(EARL_ERR_ARG, "state has a NULL array");
-  if (cfg->n_goals < 1 || cfg->n_sample_goals < 1 || cfg->n_sample_goals > cfg->n_goals)
-    return fail(EARL_ERR_ARG, "bad goal table sizes n_goals=%d n_sample_goals=%d", cfg->n_goals, cfg->n_sample_goals);
-  if (cfg->reward_type != EARL_REWARD_SPARSE && cfg->reward_type != EARL_REWARD_DENSE)
-    return fail(EARL_ERR_ARG, "reward_type = %d", cfg->reward_type);
-  if (cfg->goal_change_frequency < 0 || cfg->horizon < 0) return fail(EARL_ERR_ARG, "negative horizon/frequency");
-  if (cfg->goal_change_frequency > 0 && (!st->steps_since_goal_change || !st->lifelong_return))
-    return fail(EARL_ERR_ARG, "lifelong mode needs steps_since_goal_change and lifelong_return");
-  if (nobj == 3 && (cfg->wide_init || cfg->goal_change_frequency))
-    return fail(EARL_ERR_ARG, "3-object variant: wide_init / lifelong do not exist in the reference class");
-  return EARL_OK;
-}
 
 int launched(const char* what) {
   const hipError_t e = hipGetLastError();
@@ -420,6 +150,12 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
   rollout_ws_kernel<RT, NC, NL, NS, K, LEAD, false, true><<<grid, 64 * (((NC) == 3 ? 2 : (NC)) + NL + NS), g_rollout_lds_pad, hs>>>(w)
       if (cfg->reward_type == EARL_REWARD_SPARSE) {
         switch (g_rollout_impl) {   // tuning variants (tools/archive/tune_rollout.py); 0 = the shipped configuration
+          // variants the parity tests cross-check against the shipped one (tests/test_tabletop_gpu.py): other lane layouts of the same arithmetic
+          case 11: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 8, 3); break;    // x / y in the two lane halves (v_permlane32_swap); round 1's default
+          case 13: EARL_WS(EARL_REWARD_SPARSE, 1, 4, 4, 8, 3); break;    // one lane per env, VGPR-only masks
+          case 20: EARL_WS(EARL_REWARD_SPARSE, 3, 4, 4, 8, 3); break;    // x / y in adjacent lanes (DPP), VGPR-only masks, other role counts
+          case 22: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3); break;    // = shipped for grids of up to 256 workgroups
+#ifdef EARL_WS_EXPERIMENTS   // tuning variants and the cycle-stamped builds: only in tools/build_ws_variant.sh's libraries (tools/ubench), not in libearl_hip.so
           case 2: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 4, 6); break;
           case 3: EARL_WS(EARL_REWARD_SPARSE, 1, 2, 4, 8, 3); break;
           case 4: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 4, 6); break;
@@ -427,14 +163,10 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 6: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 8, 8, 3); break;
           case 7: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 8, 8, 3); break;
           case 10: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 4, 8, 3); break;
-          case 11: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 8, 3); break;
           case 12: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 4, 4, 6); break;
-          case 13: EARL_WS(EARL_REWARD_SPARSE, 1, 4, 4, 8, 3); break;
           case 14: EARL_WS(EARL_REWARD_SPARSE, 2, 2, 2, 4, 6); break;
           case 8: EARL_WS(EARL_REWARD_SPARSE, 1, 1, 1, 4, 6); break;
-          case 20: EARL_WS(EARL_REWARD_SPARSE, 3, 4, 4, 8, 3); break;    // x / y in adjacent lanes (DPP), VGPR-only masks
           case 21: EARL_WS(EARL_REWARD_SPARSE, 3, 4, 8, 8, 3); break;
-          case 22: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 8, 8, 3); break;    // = shipped for grids of up to 256 workgroups
           case 23: EARL_WS(EARL_REWARD_SPARSE, 2, 4, 8, 8, 3); break;
           case 30: EARL_WS(EARL_REWARD_SPARSE, 3, 1, 8, 8, 3); break;
           case 31: EARL_WS(EARL_REWARD_SPARSE, 3, 2, 4, 8, 3); break;
@@ -458,6 +190,7 @@ int do_rollout(const earl_tabletop_cfg* cfg_in, const earl_tabletop_state* st, i
           case 45: if (episodes > 1) { EARL_WSX(8, 3, true); break; } [[fallthrough]];
           case 46: if (episodes > 1) { EARL_WSX(8, 2, false); break; } [[fallthrough]];
 #undef EARL_WSX
+#endif
           case 36:
           case 38:
           default:

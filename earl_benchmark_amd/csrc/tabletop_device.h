@@ -10,7 +10,7 @@
 // wrappers/lifelong_wrapper.py.
 #pragma once
 #include "philox.h"
-#include <hip/hip_runtime.h>
+#include "earl_rt.h"
 #include <stdint.h>
 
 #include "../../include/earl_tabletop.h"

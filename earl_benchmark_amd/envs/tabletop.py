@@ -13,6 +13,7 @@ torch tensors on the env's device.  With `num_envs == 1` and `scalar_api=True` t
 the reference returns (numpy obs `[12]`, python float reward, python bool done, `{}`), for code
 written against the reference.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -61,14 +62,19 @@ class TabletopManipulation:
 
   def __init__(self, task_list='rc_r-rc_k-rc_g-rc_b', reward_type='dense', reset_at_goal=False, wide_init_distr=False,
                num_envs=1, device='cuda', seed=0, env_offset=0, scalar_api=None, auto_reset=False):
-    self._lib = _abi.load()
     dev = torch.device(device)
-    if dev.type != 'cuda':
-      raise _abi.EarlHipError(f'device={device!r}: the tabletop hot path runs on MI355X only (no CPU fallback)')
-    if not torch.cuda.is_available():
-      raise _abi.EarlHipError('no HIP device visible (torch.cuda.is_available() is False)')
-    if dev.index is None:
-      dev = torch.device('cuda', torch.cuda.current_device())
+    if dev.type == 'cpu':
+      # asked for by name, never a fallback: the `_cpu` entry points of include/earl_tabletop.h -- this file's kernels' own per-env functions
+      # (csrc/tabletop_device.h, tabletop_step.h) compiled for the host (csrc/libearl_host.so), host tensors, no stream.  BASELINE configs[0].
+      self._lib = _abi.load_host()
+    elif dev.type != 'cuda':
+      raise _abi.EarlHipError(f'device={device!r}: the tabletop hot path runs on MI355X (device="cuda"), or on the host when asked for device="cpu"')
+    else:
+      self._lib = _abi.load()
+      if not torch.cuda.is_available():
+        raise _abi.EarlHipError('no HIP device visible (torch.cuda.is_available() is False)')
+      if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
     if reward_type not in _abi.REWARD_TYPES:
       raise ValueError(f'reward_type must be sparse|dense, got {reward_type!r}')
     self.device = dev
@@ -113,7 +119,7 @@ class TabletopManipulation:
     self.action_space = Box(-1.0, 1.0, (3,), np.float32)           # three ctrlrange=[-1,1] motors of the model
     self.observation_space = Box(-np.inf, np.inf, (self.OBS_DIM,), np.float32)
     # like gym's MujocoEnv constructor, leave the env in a reset state
-    with torch.cuda.device(self.device):
+    with self._ctx():
       self._reset_kernel(None, None, want_obs=False)
     self.interventions.zero_()
 
@@ -143,7 +149,15 @@ class TabletopManipulation:
     self._cfg.n_goals = self.goal_table.shape[0]
 
   def _stream(self):
-    return torch.cuda.current_stream(self.device).cuda_stream
+    return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == 'cuda' else None
+
+  def _ctx(self):
+    """launches go to the current device's runtime context (nothing to select on the host)"""
+    return torch.cuda.device(self.device) if self.device.type == 'cuda' else contextlib.nullcontext()
+
+  def _check(self, rc, what):
+    if rc:
+      _abi.check(rc, what, self._lib)
 
   def _next_counter(self, k=1):
     c = self._cfg.counter
@@ -163,7 +177,7 @@ class TabletopManipulation:
       rc = self._lib.earl_tabletop_reset(C.byref(self._cfg), C.byref(self._st), _ptr(m), _ptr(g), _ptr(obs), self._stream())
     else:
       rc = self._lib.earl_tabletop3_reset(C.byref(self._cfg), C.byref(self._st), _ptr(m), _ptr(obs), self._stream())
-    _abi.check(rc, 'reset')
+    self._check(rc, 'reset')
     self._next_counter()
     return obs
 
@@ -186,7 +200,7 @@ class TabletopManipulation:
   def reset(self, mask=None, goal_idx=None):
     """reset() of the reference for every env (or the envs selected by the bool tensor `mask`).  `goal_idx`
     (optional, [N]) injects the goal-table rows instead of sampling, like `reset_goal(goal)` in the reference."""
-    with torch.cuda.device(self.device):
+    with self._ctx():
       obs = self._reset_kernel(mask, goal_idx)
     return obs[0].cpu().numpy() if self.scalar_api else obs
 
@@ -219,7 +233,7 @@ class TabletopManipulation:
       r64 = torch.empty(n, dtype=torch.float64, device=self.device)
       ostruct.reward_f64 = r64.data_ptr()
     ctx = None
-    if torch.cuda.current_device() != self.device.index:   # launches go to the current device's runtime context
+    if self.device.type == 'cuda' and torch.cuda.current_device() != self.device.index:   # launches go to the current device's runtime context
       ctx = torch.cuda.device(self.device)
       ctx.__enter__()
     try:
@@ -232,7 +246,7 @@ class TabletopManipulation:
       if ctx is not None:
         ctx.__exit__(None, None, None)
     if rc:
-      _abi.check(rc, 'step')
+      self._check(rc, 'step')
     self._cfg.counter += 1          # every call uses the current Philox counter, then advances it
     self.total_step_count += 1
     obs, rew, done, succ = outs
@@ -248,7 +262,7 @@ class TabletopManipulation:
     rollout(actions, reset_first=True)."""
     if self.NOBJ != 1:
       raise NotImplementedError('rollout_episodes: single-object env only')
-    with torch.cuda.device(self.device):
+    with self._ctx():
       a = torch.as_tensor(actions, device=self.device)
       if a.dim() == 4:
         E, T = int(a.shape[0]), int(a.shape[1])
@@ -266,7 +280,7 @@ class TabletopManipulation:
         outs = tuple(out)
         ostruct = self._out_struct(outs, (E, T, self.num_envs))
       rc = self._lib.earl_tabletop_eval_episodes(self._cfg_ref, self._st_ref, E, T, act.data_ptr(), stride, C.byref(ostruct), self._stream())
-    _abi.check(rc, 'eval_episodes')
+    self._check(rc, 'eval_episodes')
     self._cfg.counter += E * (T + 1)
     self.total_step_count += E * T
     self._last_success = outs[3][-1, -1]
@@ -280,7 +294,7 @@ class TabletopManipulation:
     """T steps in one kernel launch: actions [T, N, 3] -> (obs [T,N,D], reward [T,N], done [T,N], success [T,N]).
     Bit-identical to T calls of step().  `out`: optional tuple of preallocated output tensors to write into.
     `reset_first=True` folds a reset() of every env into the same launch (one evaluation episode per call)."""
-    with torch.cuda.device(self.device):
+    with self._ctx():
       a = torch.as_tensor(actions, device=self.device)
       T = a.shape[0]
       act = self._actions(a, (T, self.num_envs))
@@ -296,7 +310,7 @@ class TabletopManipulation:
           self._reset_kernel(None, None, want_obs=False)
         fn = self._lib.earl_tabletop_rollout if self.NOBJ == 1 else self._lib.earl_tabletop3_rollout
       rc = fn(C.byref(self._cfg), C.byref(self._st), T, act.data_ptr(), C.byref(out), self._stream())
-    _abi.check(rc, 'rollout')
+    self._check(rc, 'rollout')
     self._cfg.counter += T + (1 if reset_first and self.NOBJ == 1 else 0)   # step t used counter (+1 after a fused reset) + t
     self.total_step_count += T
     self._last_success = outs[3][-1]
@@ -310,16 +324,16 @@ class TabletopManipulation:
     succ = torch.empty(n, dtype=torch.bool, **kw) if 'success' in want else None
     if self.NOBJ == 1:
       out = _abi.TabletopOut(_ptr(obs), _ptr(rew), None, _ptr(succ))
-      with torch.cuda.device(self.device):
-        _abi.check(self._lib.earl_tabletop_observe(C.byref(self._cfg), C.byref(self._st), C.byref(out), self._stream()), 'observe')
+      with self._ctx():
+        self._check(self._lib.earl_tabletop_observe(C.byref(self._cfg), C.byref(self._st), C.byref(out), self._stream()), 'observe')
     else:
       # 3obj: obs through a no-op masked reset, reward/success through the pure reward kernel
-      with torch.cuda.device(self.device):
+      with self._ctx():
         o = torch.empty(n, self.OBS_DIM, dtype=torch.float32, **kw)
         zero = torch.zeros(n, dtype=torch.uint8, **kw)
-        _abi.check(self._lib.earl_tabletop3_reset(C.byref(self._cfg), C.byref(self._st), zero.data_ptr(), o.data_ptr(), self._stream()), 'observe')
+        self._check(self._lib.earl_tabletop3_reset(C.byref(self._cfg), C.byref(self._st), zero.data_ptr(), o.data_ptr(), self._stream()), 'observe')
         if rew is not None or succ is not None:
-          _abi.check(self._lib.earl_tabletop3_reward(n, o.data_ptr(), self._cfg.reward_type, _ptr(rew), _ptr(succ), self._stream()), 'reward')
+          self._check(self._lib.earl_tabletop3_reward(n, o.data_ptr(), self._cfg.reward_type, _ptr(rew), _ptr(succ), self._stream()), 'reward')
         obs = o if obs is not None else None
     return obs, rew, succ
 
@@ -347,12 +361,12 @@ class TabletopManipulation:
     m = o.shape[0]
     r = torch.empty(m, dtype=torch.float32, device=self.device) if want_reward else None
     s = torch.empty(m, dtype=torch.bool, device=self.device) if want_success else None
-    with torch.cuda.device(self.device):
+    with self._ctx():
       if self.NOBJ == 1:
         rc = self._lib.earl_tabletop_reward(m, o.data_ptr(), self._cfg.reward_type, self._cfg.wide_init, _ptr(r), _ptr(s), self._stream())
       else:
         rc = self._lib.earl_tabletop3_reward(m, o.data_ptr(), self._cfg.reward_type, _ptr(r), _ptr(s), self._stream())
-    _abi.check(rc, 'reward')
+    self._check(rc, 'reward')
     return r, s
 
   # ------------------------------------------------------------------ goals / state injection
@@ -452,12 +466,12 @@ class TabletopStateScratch:
     st.steps_since_goal_change, st.lifelong_return = sgc.data_ptr(), lr.data_ptr()
     cfg = _abi.TabletopCfg.from_buffer_copy(e._cfg)
     cfg.wide_init, cfg.reset_at_goal = 0, 0
-    with torch.cuda.device(dev):
+    with e._ctx():
       if e.NOBJ == 1:
         rc = e._lib.earl_tabletop_reset(C.byref(cfg), C.byref(st), None, None, None, e._stream())
       else:
         rc = e._lib.earl_tabletop3_reset(C.byref(cfg), C.byref(st), None, None, e._stream())
-    _abi.check(rc, 'sample_goal')
+    e._check(rc, 'sample_goal')
     e._next_counter()
     return gi
 
@@ -482,6 +496,8 @@ class StepGraph:
     u = env.unwrapped if hasattr(env, 'unwrapped') else env
     if u.scalar_api:
       raise ValueError('make_step_graph is for the batched API (scalar_api=False)')
+    if u.device.type != 'cuda':
+      raise ValueError('make_step_graph captures HIP launches: device="cuda" only')
     self.env, self.T, self.policy = u, int(T), policy
     n, dev = u.num_envs, u.device
     with torch.cuda.device(dev):

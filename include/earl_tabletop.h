@@ -147,6 +147,32 @@ int earl_tabletop3_reset(const earl_tabletop_cfg* cfg, const earl_tabletop_state
 int earl_tabletop3_reward(int32_t n, const float* obs, int32_t reward_type, float* reward, uint8_t* success,
                           earl_stream_t stream);
 
+/* ---- host build: the `_cpu` entry points (BASELINE.json configs[0] "1 env, CPU ... plumbing, no GPU") ----
+ * csrc/libearl_host.so = the SAME per-env functions the gfx950 kernels run (csrc/tabletop_device.h, tabletop_step.h, philox.h), compiled for the host by
+ * g++ with -ffp-contract=off; one OpenMP iteration per env where a kernel has one lane per env.  Same structs, same arguments minus the stream, HOST
+ * pointers, synchronous.  Outputs are bit-identical to the device entry points for every discrete output, the fp64 state and the f32 observations; the
+ * dense reward differs by the device's exp() (1e-6, like device vs oracle).  Replaces the same reference calls as the twin of each name, for ONE env or a
+ * batch: envs/tabletop_manipulation.py:128-138 (step), :105-126 (reset), wrappers/persistent_state_wrapper.py:17-31, wrappers/lifelong_wrapper.py:30-44.
+ * Nothing in the library falls back to these: a caller asks for them (Python: EARLEnvs(..., device='cpu')).
+ * earl_host_last_error() holds the message of the last failure of THESE calls. */
+int earl_tabletop_step_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const float* act, const int32_t* next_goal_idx,
+                           const earl_tabletop_out* out);
+int earl_tabletop_rollout_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act, const earl_tabletop_out* out);
+int earl_tabletop_reset_rollout_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act, const earl_tabletop_out* out);
+int earl_tabletop_eval_episodes_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t episodes, int32_t T, const float* act,
+                                    int64_t act_episode_stride, const earl_tabletop_out* out);
+int earl_tabletop_reset_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const uint8_t* mask, const int32_t* next_goal_idx, float* obs);
+int earl_tabletop_observe_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const earl_tabletop_out* out);
+int earl_tabletop_reward_cpu(int32_t n, const float* obs, int32_t reward_type, int32_t wide_init, float* reward, uint8_t* success);
+int earl_tabletop_valid_init_cpu(int32_t n, const double* cand, uint8_t* valid);
+int earl_tabletop3_step_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const float* act, const earl_tabletop_out* out);
+int earl_tabletop3_rollout_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int32_t T, const float* act, const earl_tabletop_out* out);
+int earl_tabletop3_reset_cpu(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const uint8_t* mask, float* obs);
+int earl_tabletop3_reward_cpu(int32_t n, const float* obs, int32_t reward_type, float* reward, uint8_t* success);
+int earl_host_set_threads(int n);        /* OpenMP threads of the calls above (n <= 0: query); returns the count in force */
+const char* earl_host_version(void);
+const char* earl_host_last_error(void);
+
 /* ---- library ---- */
 /* Test/bench hook: which kernel earl_tabletop_rollout uses. 0 = automatic (the wave-specialised kernel whenever
  * lifelong switching and auto-reset are off and all four outputs are requested), 1 = always the plain

@@ -1,5 +1,7 @@
 """Drives csrc/libearl_hip.so through the C ABI (ctypes + raw device pointers) with the same call sequence and
-host-side (numpy) inputs/outputs as oracle.tabletop_oracle.OracleTabletop, so parity tests read the same on both."""
+host-side (numpy) inputs/outputs as oracle.tabletop_oracle.OracleTabletop, so parity tests read the same on both.
+With device='cpu' the same calls go to csrc/libearl_host.so (the `_cpu` entry points: the kernels' per-env functions compiled
+for the host) on host tensors -- tests/test_host_build.py."""
 import ctypes as C
 
 import numpy as np
@@ -17,8 +19,8 @@ class HipTabletop:
   def __init__(self, n, reward_type='sparse', wide_init=False, reset_at_goal=False, horizon=200,
                goal_change_frequency=0, auto_reset=False, seed=0, env_offset=0, goal_table=None, nobj=1,
                n_sample_goals=None, device='cuda:0'):
-    self.lib = _abi.load()
     self.dev = torch.device(device)
+    self.lib = _abi.load_host() if self.dev.type == 'cpu' else _abi.load()
     self.n, self.nobj = n, nobj
     self.nq = 2 + 2 * nobj
     self.obs_dim = 2 * self.nq + 4
@@ -38,7 +40,7 @@ class HipTabletop:
     self.steps_since_goal_change = torch.zeros(n, dtype=torch.int32, **kw)
     self.lifelong_return = torch.zeros(n, dtype=torch.float64, **kw)
     self._pfx = 'earl_tabletop_' if nobj == 1 else 'earl_tabletop3_'
-    self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+    self.stream = torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == 'cuda' else None
 
   STATE = ('qpos', 'attached', 'goal_idx', 'steps_since_reset', 'num_interventions', 'steps_since_goal_change',
            'lifelong_return')
@@ -71,8 +73,9 @@ class HipTabletop:
     return None if a is None else torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=self.dev)
 
   def _ok(self, rc, what):
-    _abi.check(rc, what)
-    torch.cuda.synchronize(self.dev)
+    _abi.check(rc, what, self.lib)
+    if self.dev.type == 'cuda':
+      torch.cuda.synchronize(self.dev)
 
   def reset(self, mask=None, next_goal_idx=None):
     obs = torch.full((self.n, self.obs_dim), float('nan'), dtype=torch.float32, device=self.dev)
@@ -135,29 +138,38 @@ class HipTabletop:
     return tuple(x.cpu().numpy() for x in arrs)
 
 
-def hip_reward(obs, reward_type='sparse', wide_init=False, nobj=1, device='cuda:0'):
-  lib = _abi.load()
+def _lib_stream(device):
   dev = torch.device(device)
+  if dev.type == 'cpu':
+    return dev, _abi.load_host(), None
+  return dev, _abi.load(), torch.cuda.current_stream(dev).cuda_stream
+
+
+def _sync(dev):
+  if dev.type == 'cuda':
+    torch.cuda.synchronize(dev)
+
+
+def hip_reward(obs, reward_type='sparse', wide_init=False, nobj=1, device='cuda:0'):
+  dev, lib, stream = _lib_stream(device)
   o = torch.tensor(np.ascontiguousarray(obs, np.float32), device=dev)
   n = len(o)
   r = torch.full((n,), float('nan'), dtype=torch.float32, device=dev)
   s = torch.full((n,), 7, dtype=torch.uint8, device=dev)
   rt = {'sparse': 0, 'dense': 1}[reward_type]
-  stream = torch.cuda.current_stream(dev).cuda_stream
   if nobj == 1:
     rc = lib.earl_tabletop_reward(n, o.data_ptr(), rt, int(wide_init), r.data_ptr(), s.data_ptr(), stream)
   else:
     rc = lib.earl_tabletop3_reward(n, o.data_ptr(), rt, r.data_ptr(), s.data_ptr(), stream)
-  _abi.check(rc, 'reward')
-  torch.cuda.synchronize(dev)
+  _abi.check(rc, 'reward', lib)
+  _sync(dev)
   return r.cpu().numpy(), s.cpu().numpy()
 
 
 def hip_valid_init(cand, device='cuda:0'):
-  lib = _abi.load()
-  dev = torch.device(device)
+  dev, lib, stream = _lib_stream(device)
   c = torch.tensor(np.ascontiguousarray(cand, np.float64), device=dev)
   v = torch.full((len(c),), 7, dtype=torch.uint8, device=dev)
-  _abi.check(lib.earl_tabletop_valid_init(len(c), c.data_ptr(), v.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), 'valid_init')
-  torch.cuda.synchronize(dev)
+  _abi.check(lib.earl_tabletop_valid_init(len(c), c.data_ptr(), v.data_ptr(), stream), 'valid_init', lib)
+  _sync(dev)
   return v.cpu().numpy()

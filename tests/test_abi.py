@@ -19,16 +19,27 @@ def declared_functions():
   return re.findall(r'^\s*(?:int|const char\*)\s+(earl_\w+)\s*\(', src, flags=re.M)
 
 
+HOST_ONLY = {'earl_host_set_threads', 'earl_host_version', 'earl_host_last_error'}      # libearl_host.so's own library functions
+
+
+def is_host(name):
+  return name.endswith('_cpu') or name in HOST_ONLY
+
+
 def test_header_declares_what_the_binding_expects():
   names = declared_functions()
   assert len(names) == len(set(names)) >= 20
-  assert set(names) == set(_abi.SIGNATURES), set(names) ^ set(_abi.SIGNATURES)
+  dev = {n for n in names if not is_host(n)}
+  assert dev == set(_abi.SIGNATURES), dev ^ set(_abi.SIGNATURES)
+  assert {n for n in names if n.endswith('_cpu')} == set(_abi.HOST_SIGNATURES)            # the `_cpu` twins: csrc/libearl_host.so
 
 
 def test_library_loads_and_exports_every_declared_symbol():
   lib = _abi.load()
+  host = C.CDLL(_abi.HOST_LIB_PATH)
   for name in declared_functions():
-    assert hasattr(lib, name), name
+    assert hasattr(host if is_host(name) else lib, name), name
+    assert not hasattr(lib if is_host(name) else host, name), f'{name} is exported by the wrong library'
   assert lib.earl_version().startswith(b'earl-hip')
 
 
@@ -86,7 +97,10 @@ def test_product_fails_loudly_without_a_gpu():
   with pytest.raises(_abi.EarlHipError):
     tabletop.TabletopManipulation(num_envs=4)
   with pytest.raises(_abi.EarlHipError):
-    tabletop.TabletopManipulation(num_envs=4, device='cpu')
+    tabletop.TabletopManipulation(num_envs=4, device='cuda:0')
+  with pytest.raises(_abi.EarlHipError):
+    tabletop.TabletopManipulation(num_envs=4, device='meta')
+  # device='cpu' is a build of its own that a caller asks for by name (include/earl_tabletop.h `_cpu` entry points, tests/test_host_build.py): never a fallback
   import earl_benchmark_amd
   loader = earl_benchmark_amd.EARLEnvs('tabletop_manipulation', num_envs=8)     # tables / demos need no GPU; the envs do
   with pytest.raises(_abi.EarlHipError):
