@@ -268,7 +268,9 @@ def probe_reference_simulators():
           'mujoco': any(n in names for n in ('mujoco', 'mujoco_py')), 'pybullet': 'pybullet' in names,
           'note': ('none of the reference\'s simulators is importable on this host: the CPU baselines below run this build\'s C restatement of its own stepper, and the '
                    'dynamics stay unpinned against MuJoCo / PyBullet (DESIGN.md)') if not found else
-                  ('found ' + ', '.join(names) + ': tools/pin_with_simulator.py steps the build\'s own model description in it next to the HIP stepper')}
+                  ('found ' + ', '.join(names) + (': tools/pin_with_simulator.py steps the build\'s own model description in it next to the HIP stepper'
+                                                   if any(n in names for n in ('mujoco', 'mujoco_py', 'pybullet')) else
+                                                   ': none of them is a simulator tools/pin_with_simulator.py can step a model in (it needs mujoco, mujoco_py or pybullet)'))}
 
 
 def simulator_sentence(sim, which):
@@ -420,7 +422,8 @@ def host_build_leg(n, T, reward, seconds):
   dt1 = time.perf_counter() - t0
   assert dn is True and isinstance(rw, float) and ob.shape == (12,)
   lib = _abi.load_host()
-  threads = lib.set_threads(len(AVAIL_CPUS))
+  quota = host_cpu_info().get('cgroup_cpu_quota_cpus')
+  threads = lib.set_threads(max(1, min(len(AVAIL_CPUS), int(quota) if isinstance(quota, float) and quota >= 1 else len(AVAIL_CPUS))))
   _, benv = eb.EARLEnvs('tabletop_manipulation', reward_type=reward, num_envs=n, device='cpu', eval_horizon=T, scalar_api=False).get_envs()
   a = torch.from_numpy(rng.uniform(-1, 1, (T, n, 3)).astype(np.float32))
   out = benv.unwrapped._new_out((T, n))[0]

@@ -58,6 +58,7 @@ class EARLEnvs(object):
     self._setup_as_lifelong_learning = setup_as_lifelong_learning
     self._kwargs = kwargs
     self._batch_kwargs = {k: kwargs[k] for k in ('num_envs', 'device', 'seed', 'env_offset', 'scalar_api', 'auto_reset') if k in kwargs}
+    self._info_kwargs = {'info': kwargs['info']} if 'info' in kwargs else {}     # 'full' | 'minimal' info dicts of the physics envs' step() (envs/sawyer_door.py, envs/kitchen.py)
 
     if env_name == 'kitchen' and reward_type != 'dense':
       raise ValueError('Kitchen environment only supports dense rewards.')  # reference: envs/kitchen.py:91-92 (raised while constructing)
@@ -114,13 +115,13 @@ class EARLEnvs(object):
       from .envs import sawyer_door
       kw = dict(self._batch_kwargs)
       kw['seed'] = int(kw.get('seed', 0)) + seed_salt
-      return sawyer_door.SawyerDoor(reward_type=self._reward_type, reset_at_goal=reset_at_goal, **kw)
+      return sawyer_door.SawyerDoor(reward_type=self._reward_type, reset_at_goal=reset_at_goal, **kw, **self._info_kwargs)
     if self._env_name == 'sawyer_peg':
       # reference: earl_benchmark/__init__.py:119-122, :146-148 (sawyer_peg.SawyerPegV2(reward_type=..., reset_at_goal=...))
       from .envs import sawyer_peg
       kw = dict(self._batch_kwargs)
       kw['seed'] = int(kw.get('seed', 0)) + seed_salt
-      return sawyer_peg.SawyerPeg(reward_type=self._reward_type, reset_at_goal=reset_at_goal, **kw)
+      return sawyer_peg.SawyerPeg(reward_type=self._reward_type, reset_at_goal=reset_at_goal, **kw, **self._info_kwargs)
     if self._env_name == 'kitchen':
       # reference: earl_benchmark/__init__.py:133-136, :159-162 (kitchen.Kitchen(task=kitchen_task, reward_type=...)); dynamics: this build's
       # own stepper on the compiled kitchen tables, reduced collision set -- parity with MuJoCo unpinned (envs/kitchen.py)
@@ -128,7 +129,7 @@ class EARLEnvs(object):
       kw = dict(self._batch_kwargs)
       kw['seed'] = int(kw.get('seed', 0)) + seed_salt
       cfg = continuing_eval_config if self._setup_as_lifelong_learning else deployment_eval_config
-      return kitchen.Kitchen(task=self._kwargs.get('kitchen_task', cfg['kitchen']['task']), reward_type=self._reward_type, **kw)
+      return kitchen.Kitchen(task=self._kwargs.get('kitchen_task', cfg['kitchen']['task']), reward_type=self._reward_type, **kw, **self._info_kwargs)
     if self._env_name == 'minitaur':
       # reference: earl_benchmark/__init__.py:119-125, :164-169 (minitaur_gym_env.GoalConditionedMinitaurBulletEnv(), no arguments); dynamics: this
       # build's own stepper on this build's own robot model -- parity with PyBullet unpinned and model-less (envs/minitaur.py)

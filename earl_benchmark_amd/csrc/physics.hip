@@ -27,7 +27,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "../../include/earl_physics.h"
 #include "../../include/earl_glue.h"
@@ -2737,6 +2739,13 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
         int grow = (int)(earl::u01(b.x, b.y) * (double)cfg.n_goal_rows);
         grow = grow < cfg.n_goal_rows ? grow : cfg.n_goal_rows - 1;
         const double gv = cfg.goal_table[(size_t)grow * 7 + (sub - 7)];
+        if (NV < 15 && a.out.info && sub >= 11) {
+          // the door's info dict is worked out after the launch from the emitted rows (earl_sawyer_door_info), whose goal block is about to change: this
+          // row's info slots 0-2 carry the target the row's reward was computed with, slot 7 marks it (evaluate_state runs before reset_goal:
+          // lifelong_wrapper.py:30-44; include/earl_physics.h)
+          a.out.info[row * EARL_SAWYER_INFO + (sub - 11)] = a.st.goal[(size_t)env * 7 + (sub - 7)];
+          if (sub == 11) a.out.info[row * EARL_SAWYER_INFO + 7] = 1.0;
+        }
         a.st.goal[(size_t)env * 7 + (sub - 7)] = gv;
         a.out.obs[row * 14 + sub] = gv;
       }
@@ -2882,7 +2891,9 @@ __global__ void sawyer_door_info_kernel(const int n, const double* __restrict__ 
   if (i >= n) return;
   const double* o = obs + (size_t)i * 14;
   double r, row[EARL_SAWYER_INFO]; bool ok;
-  door_reward(cfg, ld3(o), ld3(o + 4), ld3(o + 11), r, ok, row);
+  double* mine = info + (size_t)i * EARL_SAWYER_INFO;
+  const V3 target = mine[7] == 1.0 ? ld3(mine) : ld3(o + 11);      // a goal-switch row of a lifelong rollout: the target its reward used (the row's goal block holds the NEW goal)
+  door_reward(cfg, ld3(o), ld3(o + 4), target, r, ok, row);
   const bool rolled_back = status && status[i] != 0;
 #pragma unroll
   for (int k = 0; k < EARL_SAWYER_INFO; ++k) info[(size_t)i * EARL_SAWYER_INFO + k] = rolled_back ? 0.0 : row[k];
@@ -3357,6 +3368,33 @@ int launched(const char* what) {
   return EARL_OK;
 }
 
+// The kernels compile the friction cone per model size (Lim<NV>::ELLIPTIC) and the two cones lay the contact arrays out differently, so a collision table
+// compiled for the other cone must be refused (include/earl_physics.h: earl_collision_model.cone).  `col` is a DEVICE table: its cone word is copied to the
+// host ONCE per device address (4 bytes, a blocking copy -- never while the stream is being captured into a graph: the check is then skipped for an address
+// not yet seen) and remembered.  A caller that rewrites a table in place with the other cone must use a new allocation.
+int check_cone(const earl_collision_model* col, const bool want_elliptic, hipStream_t st, const char* what) {
+  if (!col) return EARL_OK;
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> seen;
+  std::lock_guard<std::mutex> lock(mu);
+  int cone = -1;
+  const auto it = seen.find(col);
+  if (it != seen.end()) cone = it->second;
+  else {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return EARL_OK; }
+    if (cs != hipStreamCaptureStatusNone) return EARL_OK;
+    if (hipMemcpy(&cone, &col->cone, sizeof cone, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return EARL_OK; }   // (not a device table: the launch reports it)
+    seen[col] = cone;
+  }
+  if (cone != (want_elliptic ? 1 : 0)) {
+    fprintf(stderr, "earl_physics: %s: the collision table is compiled for the %s friction cone, this model size runs the %s one (earl_collision_model.cone)\n", what,
+            cone == 1 ? "elliptic" : "pyramidal", want_elliptic ? "elliptic" : "pyramidal");
+    return EARL_ERR_ARG;
+  }
+  return EARL_OK;
+}
+
 #ifdef EARL_PHYS_VARIANT_MT
 int g_mt_stepper = 1;     // earl_debug_set_minitaur_stepper: 1 = the tree-structured timestep (minitaur_stepper.h), 0 = the generic substep<22>
 #endif
@@ -3388,6 +3426,8 @@ int earl_physics_step(const void* model, const earl_collision_model* col, int32_
                       earl_stream_t stream) {
   if (!model || n < 0 || nsub < 0 || !qpos || !qvel || !mocap_pos || !mocap_quat || !ctrl) return EARL_ERR_ARG;
   if (n == 0 || nsub == 0) return EARL_OK;
+  if (nv != 10 && nv != 15 && nv != 23) return EARL_ERR_ARG;
+  if (int rc = check_cone(col, nv <= 16, (hipStream_t)stream, "physics_step")) return rc;
   PArgs a{model, col, n, nsub, qpos, qvel, mocap_pos, mocap_quat, ctrl, att_xpos, nullptr, nullptr, 0, 4};
   if (nv == 10) launch_physics<10, true>(a, (hipStream_t)stream);
   else if (nv == 15) launch_physics<15, true>(a, (hipStream_t)stream);
@@ -3401,6 +3441,8 @@ int earl_physics_forward(const void* model, const earl_collision_model* col, int
                          double* efc_force, double* att_xpos, earl_stream_t stream) {
   if (!model || n < 0 || !qpos || !qvel || !mocap_pos || !mocap_quat || !ctrl || !qacc) return EARL_ERR_ARG;
   if (n == 0) return EARL_OK;
+  if (nv != 10 && nv != 15 && nv != 23) return EARL_ERR_ARG;
+  if (int rc = check_cone(col, nv <= 16, (hipStream_t)stream, "physics_forward")) return rc;
   PArgs a{model, col, n, 1, const_cast<double*>(qpos), const_cast<double*>(qvel), mocap_pos, mocap_quat, ctrl, att_xpos, qacc, efc_force, 0, 4};
   if (nv == 10) launch_physics<10, false>(a, (hipStream_t)stream);
   else if (nv == 15) launch_physics<15, false>(a, (hipStream_t)stream);
@@ -3418,6 +3460,7 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
   if (!st->qpos || !st->qvel || !st->goal || !st->motor_param || !st->observed_torque || !st->overheat || !st->motor_enabled) return EARL_ERR_ARG;
   if (!out->obs || !out->reward || !out->done || !out->success || !cfg->goal_table || cfg->n_goals < 1 || cfg->num_substeps < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
+  if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_rollout")) return rc;
   MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr};
   if (g_mt_stepper) minitaur_kernel<false, true><<<(cfg->n + 2 * EARL_MT_WPB - 1) / (2 * EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
   else minitaur_kernel<false, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
@@ -3429,6 +3472,7 @@ int earl_minitaur_reset(const void* model24, const earl_collision_model* col, co
   if (!st->qpos || !st->qvel || !st->goal || !st->motor_param || !st->observed_torque || !st->overheat || !st->motor_enabled) return EARL_ERR_ARG;
   if (!cfg->goal_table || !cfg->reset_qpos || cfg->n_goals < 1 || cfg->settle_steps < 0) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
+  if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_reset")) return rc;
   MinitaurArgs a{model24, col, *cfg, *st, earl_minitaur_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0, mask, obs};
   if (g_mt_stepper) minitaur_kernel<true, true><<<(cfg->n + 2 * EARL_MT_WPB - 1) / (2 * EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
   else minitaur_kernel<true, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
@@ -3485,6 +3529,8 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
   if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !out->obs) return EARL_ERR_ARG;
   if (cfg->frame_skip < 0 || cfg->att_hand < 0 || cfg->att_right < 0 || cfg->att_left < 0 || cfg->att_obj < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
+  if (nv != 10 && nv != 15) return EARL_ERR_ARG;
+  if (int rc = check_cone(col, true, (hipStream_t)stream, "sawyer_rollout")) return rc;
   SawyerArgs a{model, col, *cfg, *st, action, T, *out, nullptr, nullptr, nullptr, nullptr, 0};
   if (cfg->obj_kind >= 1 && cfg->reward_type != 0 && (!st->obj_init || cfg->att_grasp < 0 || cfg->att_lpad < 0 || cfg->att_rpad < 0))
     return EARL_ERR_ARG;                                  // the peg's dense reward needs the reset-time state and the pad / grasp attachments
@@ -3569,6 +3615,7 @@ int earl_kitchen_step(const void* model, const earl_collision_model* col, const 
   const int n = cfg->n;
   if (n == 0) return EARL_OK;
   const hipStream_t hs = (hipStream_t)stream;
+  if (int rc = check_cone(col, false, hs, "kitchen_step")) return rc;
   KitchenArgs k{*cfg, *st, *out, action, cfg->n_att};
   kitchen_pre_kernel<<<(n * 23 + 255) / 256, 256, 0, hs>>>(k);
   // KitchenV0.step up to do_simulation: mocap target, the nine position targets (csrc/glue.hip)
@@ -3593,6 +3640,7 @@ int earl_kitchen_rollout(const void* model, const earl_collision_model* col, con
   if (!out->obs || !out->reward || !out->done || !out->success || !cfg->mocap_quat_dev) return EARL_ERR_ARG;
   for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
+  if (int rc = check_cone(col, false, (hipStream_t)stream, "kitchen_rollout")) return rc;
   KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T};
   kitchen_rollout_kernel<<<grid_for<23, 32>(cfg->n), block_for<23>(), 0, (hipStream_t)stream>>>(k);
   return launched("kitchen_rollout");

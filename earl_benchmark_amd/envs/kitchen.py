@@ -53,7 +53,12 @@ class Kitchen:
   OBS_DIM, NV, N_ROBOT, N_OBJ = 46, 23, 9, 14
 
   def __init__(self, task='all_pairs', reward_type='dense', num_envs=1, device='cuda', seed=0, env_offset=0, scalar_api=None,
-               sensor_noise=True, contacts=True, reset_at_goal=False, auto_reset=False):
+               sensor_noise=True, contacts=True, reset_at_goal=False, auto_reset=False, info='full'):
+    """info: 'full' (default) = step() returns the reference's env_info (time, obs_dict incl. the noisy velocity readings, rewards, score, images);
+    'minimal' = only 'success' / 'is_successful' / 'status' (batched) or {} (scalar): no extra Philox draw, concatenation or host copies per step"""
+    if info not in ('full', 'minimal'):
+      raise ValueError(f"info must be 'full' or 'minimal', got {info!r}")
+    self.info_mode = info
     if reward_type != 'dense':
       raise ValueError('Kitchen environment only supports dense rewards.')      # kitchen.py:91-92
     if auto_reset or reset_at_goal:
@@ -213,7 +218,10 @@ class Kitchen:
         self.steps_since_goal_change[sw] = 0
         self.goal_t[sw] = torch.tensor(self.get_next_goal(), dtype=torch.float64, device=self.device)
         obs = torch.cat([obs[:, :23], torch.where(sw[:, None], self.goal_t, obs[:, 23:])], 1)
-    info = self._env_info(obs, rew, suc, out['status'], self._counter)
+    if self.info_mode == 'full':
+      info = self._env_info(obs, rew, suc, out['status'], self._counter)
+    else:
+      info = {} if self.scalar_api else {'success': suc, 'is_successful': suc, 'status': out['status']}
     self._counter += 1
     self.total_step_count += 1
     self._last_success = suc
@@ -239,9 +247,9 @@ class Kitchen:
       amp = torch.as_tensor(float(self._params.robot_noise_ratio) * VEL_NOISE_AMP, dtype=torch.float64, device=self.device)
       qv = qv + amp * torch.cat([u[:, 9:18], u[:, 32:46]], 1)
     if self.scalar_api:
-      od = {'t': float(t[0]), 'qp': obs[0, :9].cpu().numpy(), 'qv': qv[0, :9].cpu().numpy(), 'obj_qp': obs[0, 9:23].cpu().numpy(), 'obj_qv': qv[0, 9:].cpu().numpy(),
-            'goal': obs[0, 23:].cpu().numpy()}
-      r = float(rew[0])
+      h = torch.cat([obs[0], qv[0], t[:1], rew[:1].to(torch.float64)]).cpu().numpy()      # one copy to the host: obs 46, qv 23, t, reward
+      od = {'t': float(h[69]), 'qp': h[:9].copy(), 'qv': h[46:55].copy(), 'obj_qp': h[9:23].copy(), 'obj_qv': h[55:69].copy(), 'goal': h[23:46].copy()}
+      r = float(h[70])
       return {'time': od['t'], 'obs_dict': od, 'rewards': {'true_reward': r, 'r_total': r}, 'score': 0.0, 'images': []}
     od = {'t': t, 'qp': obs[:, :9], 'qv': qv[:, :9], 'obj_qp': obs[:, 9:23], 'obj_qv': qv[:, 9:], 'goal': obs[:, 23:]}
     return {'time': t, 'obs_dict': od, 'rewards': {'true_reward': rew, 'r_total': rew}, 'score': torch.zeros_like(rew), 'images': [],

@@ -52,8 +52,10 @@ class SawyerDoor:
   RECORDED_HAND_INIT = (0.0, 0.4, 0.2)       # where the recorded episodes reset the hand (sawyer_door.py:33; reset_at_goal=True resets it elsewhere)
 
   def __init__(self, reward_type='sparse', reset_at_goal=False, num_envs=1, device='cuda', seed=0, env_offset=0,
-               scalar_api=None, auto_reset=False, contacts=True, reset_hand_timesteps=None, reset_state='recorded'):
-    """reset_state: 'recorded' (default) = the arm state the reference's recorded episodes start from (RESET_STATES above; used when the task resets the hand
+               scalar_api=None, auto_reset=False, contacts=True, reset_hand_timesteps=None, reset_state='recorded', info='full'):
+    """info: 'full' (default) = step() returns the reference's seven-key evaluate_state dict; 'minimal' = only this build's own 'is_successful' / 'status'
+    (batched) or {} (scalar): no info buffer, no second launch on the latency-bound per-step path.
+    reset_state: 'recorded' (default) = the arm state the reference's recorded episodes start from (RESET_STATES above; used when the task resets the hand
     where the recordings do, otherwise the converged one); 'converged' = the post-_reset_hand state run to convergence (SETTLE_TIMESTEPS; rounds 1 - 3).
     reset_hand_timesteps: 250 = the reference's literal recipe, sim.reset() + 50 x 5 timesteps [UPSTREAM] on this stepper (its own transient, not MuJoCo's: hand
     4.3 mm off in x where the reference's observation has 5.9); given, it overrides reset_state."""
@@ -67,6 +69,9 @@ class SawyerDoor:
       dev = torch.device('cuda', torch.cuda.current_device())
     if reward_type not in _abi.REWARD_TYPES:
       raise ValueError(f'reward_type must be sparse|dense, got {reward_type!r}')
+    if info not in ('full', 'minimal'):
+      raise ValueError(f"info must be 'full' or 'minimal', got {info!r}")
+    self.info_mode = info
     self.device = dev
     self.num_envs = n = int(num_envs)
     self.scalar_api = (n == 1) if scalar_api is None else bool(scalar_api)
@@ -178,8 +183,19 @@ class SawyerDoor:
       v[0, :7] = torch.tensor(t['reset_qvel_recorded'], **kw)
     return q[0].contiguous(), v[0].contiguous()
 
-  def _new_out(self, lead):
+  door_queue = False      # tools/bench_door_schedule.py sets it with earl_debug_set_door_variant(3): the door under the peg's time-sliced schedule (measurement only)
+
+  def _uses_queue(self, T):
+    """does this launch take work items from earl_sawyer_state.sched (then the queue must be zero on entry)?  The peg model's rollouts of more than one round of
+    workgroups; the door never does in the shipped configuration."""
+    return T > 1 and (self.nv >= 15 or self.door_queue)
+
+  def _new_out(self, lead, info=None):
     kw = dict(device=self.device)
+    if not (self.info_mode == 'full' if info is None else info):
+      out = self._new_out(lead, info=True)
+      del out['info']
+      return out
     return {'obs': torch.empty(*lead, self.num_envs, self.OBS_DIM, dtype=torch.float64, **kw),
             'reward': torch.empty(*lead, self.num_envs, dtype=torch.float32, **kw),
             'done': torch.empty(*lead, self.num_envs, dtype=torch.bool, **kw),
@@ -191,11 +207,15 @@ class SawyerDoor:
   def _launch_rollout(self, actions, T, out):
     info = out.get('info')
     in_kernel = info is not None and self.nv >= 15        # the peg's dict needs simulator state: the rollout kernel's epilogue writes it
+    # door, lifelong goal switching: the kernel leaves the PRE-switch target on goal-switch rows (slots 0-2, marker in slot 7) for earl_sawyer_door_info
+    stash = info is not None and self.nv < 15 and bool(self._cfg.goal_change_frequency)
     o = _abi.SawyerOut(obs=out['obs'].data_ptr(), reward=_ptr(out.get('reward')), done=_ptr(out.get('done')),
-                       success=_ptr(out.get('success')), status=_ptr(out.get('status')), info=_ptr(info) if in_kernel else None)
+                       success=_ptr(out.get('success')), status=_ptr(out.get('status')), info=_ptr(info) if (in_kernel or stash) else None)
     self._cfg.step_counter = self.total_step_count
     with torch.cuda.device(self.device):
-      if self.sched is not None and T > 1:
+      if info is not None and not in_kernel:
+        info[..., 7] = 0.0                                 # (input column of earl_sawyer_door_info: no row marked)
+      if self.sched is not None and T > 1 and self._uses_queue(T):
         self.sched.zero_()                                 # (the queue of the time-sliced schedule: zero on entry)
       _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.model.col_ptr, self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),
                                                T, C.byref(o), self._stream()), 'earl_sawyer_rollout')
@@ -242,7 +262,7 @@ class SawyerDoor:
     if self.nv >= 15:
       raise NotImplementedError('the peg\'s info dict reads simulator state (pegGrasp site, pads): it comes with step() / rollout() only')
     o = torch.as_tensor(obs, device=self.device).to(torch.float64).reshape(-1, self.OBS_DIM).contiguous()
-    info = torch.empty(o.shape[0], _abi.SAWYER_INFO, dtype=torch.float64, device=self.device)
+    info = torch.zeros(o.shape[0], _abi.SAWYER_INFO, dtype=torch.float64, device=self.device)      # (column 7 is an input: no row marked)
     with torch.cuda.device(self.device):
       _abi.check(self._lib.earl_sawyer_door_info(self._cfg_ref, o.shape[0], o.data_ptr(), None, info.data_ptr(), self._stream()), 'earl_sawyer_door_info')
     return {k: info[:, i] for i, k in enumerate(_abi.SAWYER_INFO_KEYS)}
@@ -253,8 +273,11 @@ class SawyerDoor:
     (scalar_api) or [N] float64 tensors, plus this build's own keys: 'is_successful' = is_successful(obs) of every env, 'status' = the failure guard."""
     info = out.get('info')
     d = {}
+    if info is not None and self.scalar_api:
+      row = info.reshape(-1, _abi.SAWYER_INFO)[0].cpu().tolist()            # one copy to the host, not one per key
+      return dict(zip(_abi.SAWYER_INFO_KEYS, row))
     if info is not None:
-      d = {k: (float(info[0, i]) if self.scalar_api else info[..., i]) for i, k in enumerate(_abi.SAWYER_INFO_KEYS)}
+      d = {k: info[..., i] for i, k in enumerate(_abi.SAWYER_INFO_KEYS)}
     if self.scalar_api:
       return d
     d['is_successful'], d['status'] = out['success'], out['status']

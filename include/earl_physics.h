@@ -119,7 +119,9 @@ typedef struct earl_collision_model {
   int32_t max_con;                           /* contacts kept per env and timestep (<= EARL_MAXCON; <= 8 for models with nv <= 10): the first active pairs */
   int32_t cone;                              /* friction cone of the model's MJCF: 0 = pyramidal (four edge rows per contact), 1 = elliptic (rows normal, t1, t2 with one regulariser,
                                                 MuJoCo's three-zone cost; round 4).  The kernels compile the cone per model size (csrc/physics.hip Lim<NV>::ELLIPTIC: nv <= 16, the
-                                                Sawyer door and peg, metaworld_assets/scene/basic_scene.xml:2); an entry point given the other kind returns EARL_ERR_ARG */
+                                                Sawyer door and peg, metaworld_assets/scene/basic_scene.xml:2); an entry point given the other kind returns EARL_ERR_ARG
+                                                (the word is copied from the device table once per device address and remembered -- not while the stream is being captured
+                                                into a graph --, so a table is not to be rewritten in place with the other cone) */
   int32_t pad_;
   int32_t blk_begin[EARL_MAXBLK], blk_end[EARL_MAXBLK], blk_box[EARL_MAXBLK], blk_link[EARL_MAXBLK];
   int32_t blk_cap[EARL_MAXBLK];              /* bits 0-7: contacts a block may contribute (its first ones in pair order); the block order is the
@@ -283,6 +285,10 @@ int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double*
                             earl_stream_t stream);
 /* the info dict of SawyerDoorV2.step (evaluate_state, earl_benchmark/envs/sawyer_door.py:127-139) for n observation rows [n, 14] -> info [n, EARL_SAWYER_INFO]
  * (slots EARL_INFO_*); every entry is a function of the observation and the reward type.  status (may be NULL): rows of rolled-back steps get zeros.
+ * info[.][7] is also an INPUT: 1.0 marks a row whose slots 0-2 hold the target to evaluate against instead of the row's own goal block.  earl_sawyer_rollout
+ * (nv = 10, lifelong goal switching on, out->info given) leaves exactly that on goal-switch rows -- the reward of such a row was computed with the goal
+ * in force BEFORE the switch (wrappers/lifelong_wrapper.py:30-44: step(), i.e. evaluate_state, then reset_goal), while its observation already carries the new
+ * goal --; the caller zeroes column 7 before the rollout.  Any other value: the row's own goal block.
  * (The peg's dict needs simulator state -- the pegGrasp site, the pads: earl_sawyer_out.info of earl_sawyer_rollout carries it.) */
 int earl_sawyer_door_info(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, const uint8_t* status, double* info, earl_stream_t stream);
 

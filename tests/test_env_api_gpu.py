@@ -175,11 +175,25 @@ def test_3obj_env(torch, orc):
   np.testing.assert_array_equal(env.is_successful().cpu().numpy(), want[3][-1].astype(bool))
 
 
-def test_no_cpu_device():
+def test_host_build_and_device_build_agree(torch, orc):
+  """device='cpu' is a build of its own, asked for by name (csrc/libearl_host.so: these kernels' per-env functions compiled for the host; never a fallback --
+  any other non-cuda device still raises): the same seeded episode on both builds, every output and the state bit for bit (sparse reward)"""
   from earl_benchmark_amd import _abi
   from earl_benchmark_amd.envs import tabletop
   with pytest.raises(_abi.EarlHipError):
-    tabletop.TabletopManipulation(num_envs=2, device='cpu')
+    tabletop.TabletopManipulation(num_envs=2, device='meta')
+  n, T = 777, 50
+  rng = np.random.default_rng(3)
+  acts = rng.uniform(-1.2, 1.2, size=(T, n, 3)).astype(np.float32)
+  acts[..., 2] = np.where(rng.random((T, n)) < 0.7, np.abs(acts[..., 2]), acts[..., 2])
+  res = {}
+  for dev in ('cuda', 'cpu'):
+    env = tabletop.TabletopManipulation(reward_type='sparse', num_envs=n, seed=21, device=dev, wide_init_distr=True, scalar_api=False)
+    o0 = env.reset()
+    out = env.rollout(torch.from_numpy(acts).to(dev))
+    res[dev] = [o0.cpu().numpy()] + [x.cpu().numpy() for x in out] + [env.qpos.cpu().numpy(), env.attached.cpu().numpy(), env.steps_since_reset.cpu().numpy()]
+  for a, b in zip(res['cuda'], res['cpu']):
+    np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
 def test_launches_are_graph_capturable(torch, orc):

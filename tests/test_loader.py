@@ -115,3 +115,9 @@ def test_the_references_literal_import_statements_resolve():
     np.testing.assert_array_equal(mod.goal_states, loader.get_goal_states())
   np.testing.assert_array_equal(kitchen.goal_states, earl_benchmark_amd.EARLEnvs('kitchen', reward_type='dense').get_goal_states())
   assert set(kitchen.initial_states) >= {'microwave', 'light_switch', 'slide_cabinet', 'hinge_cabinet', 'all_pairs'}
+  # the 3-object variant's module has the same two tables (reference envs/tabletop_manipulation_3obj.py:11-17; values checked against the reference's by
+  # tests/golden/make_golden.py: the first goal row / the reset state of the recorded rollouts)
+  from earl_benchmark.envs import tabletop_manipulation_3obj as t3
+  assert t3.initial_states.shape == (1, 10) and t3.goal_states.shape == (1, 10) and t3.TabletopManipulation.NOBJ == 3
+  np.testing.assert_array_equal(t3.initial_states[0], [0.0, 0.0, 2.5, 0.0, 2.5, -1.0, 2.5, 1.0, -1., -1.])
+  np.testing.assert_array_equal(t3.goal_states[0], [0.0, 0.0, 0.0, -2.0, 0.0, 2.0, -2.5, 1.0, -1., -1.])

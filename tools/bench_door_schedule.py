@@ -15,6 +15,7 @@ ref = None
 for k in [int(x) for x in sys.argv[1:]] or [2, 1, 3]:
   lib.earl_debug_set_door_variant(k)
   env = PersistentStateWrapper(SawyerDoor(num_envs=n, seed=1234), T)
+  env.unwrapped.door_queue = k == 3
   out = env.unwrapped._new_out((T,))
   for _ in range(2):
     env.reset(); env.rollout(acts, out=out)
@@ -25,6 +26,7 @@ for k in [int(x) for x in sys.argv[1:]] or [2, 1, 3]:
   torch.cuda.synchronize()
   dt = (time.perf_counter() - t0) / 4
   env2 = PersistentStateWrapper(SawyerDoor(num_envs=n, seed=1234), T)      # (fresh env: the same Philox counters for the identity check)
+  env2.unwrapped.door_queue = k == 3
   env2.reset(); o2 = env2.rollout(acts)['obs'].clone()
   same = True if ref is None else bool(torch.equal(o2, ref))
   ref = o2 if ref is None else ref
