@@ -155,7 +155,7 @@ def test_info_dict_on_goal_switch_rows_uses_the_goal_the_reward_used():
       custom = env.unwrapped.goal_t.clone()
       custom[:, 4:7] = o0[:, 4:7]                                         # target = where the handle is
       env.unwrapped.reset_goal(custom)
-      default = torch.tensor(env.unwrapped.goal_states[0], dtype=torch.float64, device='cuda')
+      default = torch.tensor(env.unwrapped.goal_states[0], dtype=torch.float64, device='cuda').expand(n, 7).contiguous()
       acts = torch.zeros(T, n, 4)
       if mode == 'rollout':
         out = env.rollout(acts)
