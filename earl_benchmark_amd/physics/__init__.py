@@ -71,9 +71,9 @@ class CollisionModelStruct(C.Structure):   # struct earl_collision_model
               ('sph_pos', C.c_double * 3 * MAXSPH), ('sph_r', C.c_double * MAXSPH),
               ('box_pos', C.c_double * 3 * MAXBOX), ('box_quat', C.c_double * 4 * MAXBOX), ('box_half', C.c_double * 3 * MAXBOX),
               ('pair_sph', C.c_uint8 * MAXPAIR), ('pair_box', C.c_uint8 * MAXPAIR), ('pair_cls', C.c_uint8 * MAXPAIR),
-              ('pad2_', C.c_uint8 * MAXPAIR), ('pair_rec', PairRec * MAXPAIR),
+              ('pair_kind', C.c_uint8 * MAXPAIR), ('pair_rec', PairRec * MAXPAIR),
               ('cls_mu', C.c_double * MAXCLS), ('cls_solref', C.c_double * 2 * MAXCLS), ('cls_solimp', C.c_double * 5 * MAXCLS),
-              ('cls_margin', C.c_double * MAXCLS), ('cls_invw', C.c_double * MAXCLS)]
+              ('cls_margin', C.c_double * MAXCLS), ('cls_invw', C.c_double * MAXCLS), ('cls_mu_tor', C.c_double * MAXCLS)]
 
 
 def _fill(dst, src):
@@ -237,6 +237,11 @@ def load_collision_model(d):
     if 'col_sph_dir' in d:                      # edges (segments) of the edge-vs-capsule blocks; zero for spheres / points
       r.dir[:] = [float(x) for x in d['col_sph_dir'][si]]
       r.hl = float(d['col_sph_hl'][si])
+  if 'col_cls_mu_tor' in d:                     # condim-4 classes (round 5): torsional coefficient, 0 = none
+    _fill(c.cls_mu_tor, d['col_cls_mu_tor'])
+    assert c.cone == 1 or not np.any(d['col_cls_mu_tor']), 'torsional rows exist for the elliptic cone only'
+  if 'col_pair_kind' in d:                      # 2 = cylinder vs box (round 5); 0 / 1 as the block says
+    _fill(c.pair_kind, np.asarray(d['col_pair_kind']).astype(np.uint8))
   if 'col_box_kind' in d:                       # kind of each block = kind of its box (1: capsule), carried in bit 8 of blk_cap
     for b in range(c.n_blk):
       assert 0 < c.blk_cap[b] < 256

@@ -142,10 +142,16 @@ typedef struct earl_collision_model {
   double sph_pos[EARL_MAXSPH][3], sph_r[EARL_MAXSPH];
   double box_pos[EARL_MAXBOX][3], box_quat[EARL_MAXBOX][4], box_half[EARL_MAXBOX][3];
   uint8_t pair_sph[EARL_MAXPAIR], pair_box[EARL_MAXPAIR], pair_cls[EARL_MAXPAIR];
-  uint8_t pad2_[EARL_MAXPAIR];
+  uint8_t pair_kind[EARL_MAXPAIR];           /* 0 = sphere / point vs box, 1 = edge vs capsule (= bit 8 of the block's blk_cap), 2 = CYLINDER vs box (round 5): pair_rec.pos = the cylinder's
+                                                centre, .dir = its axis, .hl = half length, .r = radius, flat ends; ONE contact per pair from the box-cylinder narrow phase -- portal
+                                                refinement on the two shapes inflated by half the margin each, the routine MuJoCo sends this geom pair to (its general convex
+                                                collider); metaworld_assets/objects/assets/doorlockB.xml:17-20 */
   /* the same pairs, self-contained (one load per test): sphere link, class, local centre, radius, class margin */
   struct { int32_t sph_link, cls; double pos[3], r, margin, dir[3], hl; } pair_rec[EARL_MAXPAIR];
   double cls_mu[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS];
+  double cls_mu_tor[EARL_MAXCLS];            /* round 5: torsional friction coefficient [length] of a class whose contacts have condim 4 (MuJoCo: the larger condim and the elementwise larger
+                                                friction of the two geoms; the Sawyer claws and pads: xyz_base.xml:163-185, friction 2 0.1 0.002); 0 = condim 3, no torsional row.
+                                                Elliptic-cone models only: a fourth row per contact, the relative angular velocity about the normal scaled by mu_tor / mu */
 } earl_collision_model;
 
 /* nsub timesteps of every env.  model: DEVICE copy of an earl_link_model (nv <= 16) or of an earl_link_model24 (nv = 23); col: DEVICE copy of its earl_collision_model or

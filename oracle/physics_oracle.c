@@ -148,6 +148,130 @@ static Q4 qnormalize(Q4 q) {
  * qp is a qpos row [nq] (the free body's quaternion at [ball_dof, ball_dof + 4)), qv a qvel row [nv]. */
 /* the minitaur's randomised foot friction (Minitaur.SetFootFriction, minitaur.py:490-498): friction of every contact of a LOWER-leg link's spheres
  * (links behind the root body whose parent is not the root); <= 0: the contact classes' own.  Set per env by the minitaur front end below. */
+
+/* ---- box vs finite cylinder: ONE contact per pair (round 5) ---------------------------------------------------------------
+ * MuJoCo 2.1 has no analytic box-cylinder routine: the pair goes to its general convex collider (Minkowski portal refinement, one contact: deepest
+ * penetration along the portal's direction).  Restated from the published algorithm (G. Snethen, "XenoCollide: Complex Collision Made Simple", Game
+ * Programming Gems 7; the form used by libccd's ccdMPRPenetration): support mappings of the two shapes, each inflated by half the contact margin (so that
+ * the shapes overlap exactly when their distance is below the margin); interior point = difference of the centres; portal discovery; refinement until the
+ * support point in the portal's direction is within `tol` of the portal plane; depth / direction = distance and direction from the origin to the portal
+ * triangle; position = the origin's barycentric combination of the support points, midway between the two shapes.  dist = margin - depth.
+ * obj1 = box (centre pb, frame Rb, half sizes h), obj2 = cylinder (centre c, axis a, half length hl, radius r); the direction points from the box to the cylinder. */
+typedef struct { V3 v, p1, p2; } MprV;
+static MprV mpr_support(V3 pb, double Rb[3][3], V3 h, V3 c, V3 a, double hl, double r, double infl, V3 dir) {
+  MprV s;
+  const V3 dl = mulvT(Rb, dir);
+  s.p1 = add(add(pb, mulv(Rb, v3(dl.x > 0 ? h.x : -h.x, dl.y > 0 ? h.y : -h.y, dl.z > 0 ? h.z : -h.z))), scl(dir, infl));
+  const V3 nd = scl(dir, -1.0);
+  const double da = dot(nd, a);
+  const V3 rad = sub(nd, scl(a, da));
+  const double nr = sqrt(dot(rad, rad));
+  V3 q = add(c, scl(a, da > 0 ? hl : (da < 0 ? -hl : 0.0)));
+  if (nr > 1e-15) q = add(q, scl(rad, r / nr));
+  s.p2 = add(q, scl(nd, infl));
+  s.v = sub(s.p1, s.p2);
+  return s;
+}
+static V3 vnormalize(V3 v) { const double n = sqrt(dot(v, v)); return n > 0 ? scl(v, 1.0 / n) : v; }
+/* closest point of triangle (a, b, c) to the origin (Ericson, Real-Time Collision Detection 5.1.5) */
+static V3 tri_closest_to_origin(V3 a, V3 b, V3 c) {
+  const V3 ab = sub(b, a), ac = sub(c, a), ap = scl(a, -1.0);
+  const double d1 = dot(ab, ap), d2 = dot(ac, ap);
+  if (d1 <= 0 && d2 <= 0) return a;
+  const V3 bp = scl(b, -1.0);
+  const double d3 = dot(ab, bp), d4 = dot(ac, bp);
+  if (d3 >= 0 && d4 <= d3) return b;
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) return add(a, scl(ab, d1 / (d1 - d3)));
+  const V3 cp = scl(c, -1.0);
+  const double d5 = dot(ab, cp), d6 = dot(ac, cp);
+  if (d6 >= 0 && d5 <= d6) return c;
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) return add(a, scl(ac, d2 / (d2 - d6)));
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) return add(b, scl(sub(c, b), (d4 - d3) / ((d4 - d3) + (d5 - d6))));
+  const double den = 1.0 / (va + vb + vc);
+  return add(a, add(scl(ab, vb * den), scl(ac, vc * den)));
+}
+#define MPR_TOL 1e-10
+#define MPR_MAXIT 64
+static int mpr_box_cylinder(V3 pb, double Rb[3][3], V3 h, V3 c, V3 a, double hl, double r, double margin, double* dist, V3* n, V3* pos) {
+  const double infl = 0.5 * margin;
+#define SUP(d) mpr_support(pb, Rb, h, c, a, hl, r, infl, (d))
+  MprV v0, v1, v2, v3_, v4;
+  v0.p1 = pb; v0.p2 = c; v0.v = sub(pb, c);
+  if (dot(v0.v, v0.v) < 1e-30) v0.v = v3(1e-5, 0, 0);
+  V3 dir = vnormalize(scl(v0.v, -1.0));
+  v1 = SUP(dir);
+  if (dot(v1.v, dir) < 0) return 0;
+  dir = cross(v0.v, v1.v);
+  if (dot(dir, dir) < 1e-30) {                      /* the origin lies on the ray v0 -> v1: depth and direction along it */
+    const double d1 = sqrt(dot(v1.v, v1.v));
+    *dist = margin - d1;
+    *n = d1 > 0 ? scl(v1.v, 1.0 / d1) : vnormalize(scl(v0.v, -1.0));
+    *pos = scl(add(v1.p1, v1.p2), 0.5);
+    return 1;
+  }
+  dir = vnormalize(dir);
+  v2 = SUP(dir);
+  if (dot(v2.v, dir) < 0) return 0;
+  dir = vnormalize(cross(sub(v1.v, v0.v), sub(v2.v, v0.v)));
+  if (dot(dir, v0.v) > 0) { const MprV t = v1; v1 = v2; v2 = t; dir = scl(dir, -1.0); }
+  for (int it = 0;; ++it) {                          /* portal discovery */
+    if (it > MPR_MAXIT) return 0;
+    v3_ = SUP(dir);
+    if (dot(v3_.v, dir) < 0) return 0;
+    if (dot(cross(v1.v, v3_.v), v0.v) < -1e-300) { v2 = v3_; dir = vnormalize(cross(sub(v1.v, v0.v), sub(v2.v, v0.v))); continue; }
+    if (dot(cross(v3_.v, v2.v), v0.v) < -1e-300) { v1 = v3_; dir = vnormalize(cross(sub(v1.v, v0.v), sub(v2.v, v0.v))); continue; }
+    break;
+  }
+  int hit = 0;
+  for (int it = 0;; ++it) {                          /* portal refinement, then the penetration once the portal has passed the origin */
+    dir = vnormalize(cross(sub(v2.v, v1.v), sub(v3_.v, v1.v)));
+    if (!hit && dot(dir, v1.v) >= 0) hit = 1;        /* the portal encloses the origin: the shapes (inflated) overlap */
+    v4 = SUP(dir);
+    const double d4 = dot(v4.v, dir);
+    const double reach = fmin(fmin(d4 - dot(v1.v, dir), d4 - dot(v2.v, dir)), d4 - dot(v3_.v, dir));
+    if (!hit && d4 < 0) return 0;                    /* the support plane separates the origin */
+    if (reach <= MPR_TOL || it >= MPR_MAXIT) {
+      if (!hit) return 0;
+      const V3 w = tri_closest_to_origin(v1.v, v2.v, v3_.v);
+      const double depth = sqrt(dot(w, w));
+      *n = depth > 1e-14 ? scl(w, 1.0 / depth) : dir;
+      *dist = margin - depth;
+      /* barycentric coordinates of the origin ray in the portal (libccd findPos) */
+      double b0 = dot(cross(v1.v, v2.v), v3_.v), b1 = dot(cross(v3_.v, v2.v), v0.v), b2 = dot(cross(v0.v, v1.v), v3_.v), b3 = dot(cross(v2.v, v1.v), v0.v);
+      double sum = b0 + b1 + b2 + b3;
+      if (sum <= 0) { b0 = 0; b1 = dot(cross(v2.v, v3_.v), dir); b2 = dot(cross(v3_.v, v1.v), dir); b3 = dot(cross(v1.v, v2.v), dir); sum = b1 + b2 + b3; }
+      const double inv = 1.0 / sum;
+      const V3 p1 = add(add(scl(v0.p1, b0), scl(v1.p1, b1)), add(scl(v2.p1, b2), scl(v3_.p1, b3)));
+      const V3 p2 = add(add(scl(v0.p2, b0), scl(v1.p2, b1)), add(scl(v2.p2, b2), scl(v3_.p2, b3)));
+      *pos = scl(add(p1, p2), 0.5 * inv);
+      return 1;
+    }
+    /* expand the portal with v4 (libccd ccdMPR expandPortal) */
+    const V3 v4v0 = cross(v4.v, v0.v);
+    if (dot(v1.v, v4v0) > 0) { if (dot(v2.v, v4v0) > 0) v1 = v4; else v3_ = v4; }
+    else { if (dot(v3_.v, v4v0) > 0) v2 = v4; else v1 = v4; }
+  }
+#undef SUP
+}
+/* diagnostics (single-threaded use): the contacts of the most recent timestep -- pair index, distance, normal, position (tools/door_contact_ablation.py --trace) */
+static double g_dbg_contacts[EARL_MAXCON][8];
+static int g_dbg_ncon = 0;
+int oracle_debug_contacts(double* out) { for (int c = 0; c < g_dbg_ncon; ++c) for (int k = 0; k < 8; ++k) out[c * 8 + k] = g_dbg_contacts[c][k]; return g_dbg_ncon; }
+/* test hook: the narrow phase alone.  box: centre pb[3], rotation Rb[9] (row major, columns = box axes in the world), half h[3]; cylinder: centre c[3], unit axis a[3] */
+int oracle_mpr_box_cylinder(const double* pb, const double* Rb9, const double* h, const double* c, const double* a, double hl, double r, double margin, double* out7) {
+  double Rb[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rb[i][j] = Rb9[3 * i + j];
+  double dist = 0; V3 n = {0, 0, 0}, pos = {0, 0, 0};
+  const int hit = mpr_box_cylinder(ld3(pb), Rb, ld3(h), ld3(c), ld3(a), hl, r, margin, &dist, &n, &pos);
+  out7[0] = dist; out7[1] = n.x; out7[2] = n.y; out7[3] = n.z; out7[4] = pos.x; out7[5] = pos.y; out7[6] = pos.z;
+  return hit;
+}
+static double g_torsion_override = -1.0;      /* experiments: >= 0 replaces the classes' torsional coefficient on cylinder contacts (oracle_set_torsion) */
+void oracle_set_torsion(double mu_tor) { g_torsion_override = mu_tor; }
+
 static _Thread_local double g_foot_mu = -1.0;
 static void substep(const LM* m, const earl_collision_model* col, double* qp, double* qv, V3 mpos, Q4 mq, const double* ctrl,
                     int integrate, StepOut* o, const double* qfrc) {
@@ -366,6 +490,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     }
   o->ncon = 0;
   double cone_mu[EARL_MAXCON];
+  int cdim[EARL_MAXCON], crow[EARL_MAXCON];        /* rows of contact c: crow[c] .. crow[c] + cdim[c] (elliptic: 3, or 4 with the torsional row) */
   int nr_contacts0 = -1;           /* index of the first contact row */
   if (col) {
     int ncon = 0;
@@ -413,6 +538,13 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
         if (lk >= 0) { qmat(ldq(o->Xq[lk]), R); c = add(ld3(o->Xp[lk]), mulv(R, c)); }
         double dist;
         V3 n, p;
+        const int cylinder = col->pair_kind[pi] == 2;
+        if (cylinder) {                              /* finite cylinder vs box: one contact from the portal refinement above */
+          V3 ax = ld3(col->pair_rec[pi].dir);
+          if (lk >= 0) ax = mulv(R, ax);
+          if (!mpr_box_cylinder(pb, Rb, h, c, ax, col->pair_rec[pi].hl, r, margin, &dist, &n, &p)) continue;
+          if (!(dist < margin)) continue;
+        } else
         if (capsule) {                               /* edge (segment) vs capsule: closest points of two segments */
           V3 ed = ld3(col->pair_rec[pi].dir);
           if (lk >= 0) ed = mulv(R, ed);
@@ -448,6 +580,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
         n = mulv(Rb, nl);
         p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
         }
+        if (ncon < EARL_MAXCON) { double* dc_ = g_dbg_contacts[ncon]; dc_[0] = pi; dc_[1] = dist; dc_[2] = n.x; dc_[3] = n.y; dc_[4] = n.z; dc_[5] = p.x; dc_[6] = p.y; dc_[7] = p.z; }
         /* tangents: n x (the coordinate axis least aligned with n) */
         const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
         const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
@@ -468,8 +601,17 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
         kbimp(col->cls_solref[cls], col->cls_solimp[cls], dist - margin, dt, &kk, &bb, &dd);
         const double R0 = fmax((1 - dd) / dd * col->cls_invw[cls], 1e-15);
         if (col->cone == 1) {   /* elliptic cone: rows (normal, t1, t2), one regulariser (impratio 1), only the normal row has a position term */
-          for (int e = 0; e < 3; ++e) {
-            const double* Je = e == 0 ? Jn : (e == 1 ? Jt1 : Jt2);
+          /* condim 4 (round 5): a fourth row, the relative angular velocity about the normal, with torsional coefficient mu_t [length].  MuJoCo's elliptic
+           * cone scales friction row i by its coefficient (regulariser R0 mu^2 / mu_i^2, cone in the scaled coordinates): with the torsional row multiplied by
+           * mu_t / mu the contact is the same isotropic cone over THREE tangential coordinates */
+          const double mu_t = g_torsion_override >= 0 ? (cylinder ? g_torsion_override : 0.0) : col->cls_mu_tor[cls];
+          double Jtor[NVMAX] = {0};
+          if (mu_t > 0)
+            for (int pass = 0; pass < 2; ++pass)
+              for (int j = pass == 0 ? lk : xl; j >= 0; j = m->parent[j]) Jtor[j] += (pass == 0 ? 1.0 : -1.0) * (mu_t / mu) * dot(n, ld3(S[j]));
+          cdim[ncon] = mu_t > 0 ? 4 : 3; crow[ncon] = nr;
+          for (int e = 0; e < cdim[ncon]; ++e) {
+            const double* Je = e == 0 ? Jn : (e == 1 ? Jt1 : (e == 2 ? Jt2 : Jtor));
             double vel = 0;
             for (int j = 0; j < nv; ++j) { J[nr][j] = Je[j]; vel += Je[j] * qv[j]; }
             aref[nr] = -bb * vel - (e == 0 ? kk * dd * (dist - margin) : 0.0);
@@ -492,6 +634,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       }
     }
     o->ncon = ncon;
+    g_dbg_ncon = ncon;
   }
   /* primal active-set Newton (LinkModel.solve_primal; elliptic models: LinkModel.solve_primal_elliptic) */
   int act[NROWMAX];
@@ -499,10 +642,11 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
   const int ell = col && col->cone == 1 && o->ncon > 0;
   const int nc = ell ? o->ncon : 0, nru = ell ? nr_contacts0 : nr;       /* rows [nru, nr) are the contacts' (n, t1, t2) triples */
   int zone[EARL_MAXCON];                                                  /* 0 top (no force), 1 bottom (sticking: quadratic), 2 middle (sliding: on the cone) */
-  double Jak[EARL_MAXCON][3];                                             /* J a of the iterate the zone was read from */
+  double Jak[EARL_MAXCON][4];                                             /* J a of the iterate the zone was read from */
   for (int r = 0; r < nr; ++r) act[r] = 1;
-  for (int c = 0; c < nc; ++c) { zone[c] = 1; Jak[c][0] = Jak[c][1] = Jak[c][2] = 0; }
-#define CONE_ZONE(r0, r1, r2, mu) ((r0) >= (mu) * sqrt((r1) * (r1) + (r2) * (r2)) ? 0 : (sqrt((r1) * (r1) + (r2) * (r2)) <= -(mu) * (r0) ? 1 : 2))
+  for (int c = 0; c < nc; ++c) { zone[c] = 1; Jak[c][0] = Jak[c][1] = Jak[c][2] = Jak[c][3] = 0; }
+#define CONE_ZONE(r0, rho, mu) ((r0) >= (mu) * (rho) ? 0 : ((rho) <= -(mu) * (r0) ? 1 : 2))
+#define CONE_RHO(q, dimc) sqrt((q)[1] * (q)[1] + (q)[2] * (q)[2] + ((dimc) > 3 ? (q)[3] * (q)[3] : 0.0))
   if (g_warm_start && o->warm) {
     /* (the dry-friction rows keep their cold start, the quadratic zone: started from a_prev's zones the three-state iteration cycled 18 times
      * as often in the kitchen model -- 3,295 against 181 of 1 M timesteps used all 8 iterations; with this rule 33) */
@@ -512,12 +656,13 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       act[r] = iseq[r] || x < 0;
     }
     for (int c = 0; c < nc; ++c) {
-      for (int k = 0; k < 3; ++k) {
+      double q[4] = {0, 0, 0, 0};
+      for (int k = 0; k < cdim[c]; ++k) {
         double x = 0;
-        for (int j = 0; j < nv; ++j) x += J[nru + 3 * c + k][j] * o->qacc[j];
-        Jak[c][k] = x;
+        for (int j = 0; j < nv; ++j) x += J[crow[c] + k][j] * o->qacc[j];
+        Jak[c][k] = x; q[k] = x - aref[crow[c] + k];
       }
-      zone[c] = CONE_ZONE(Jak[c][0] - aref[nru + 3 * c], Jak[c][1] - aref[nru + 3 * c + 1], Jak[c][2] - aref[nru + 3 * c + 2], cone_mu[c]);
+      zone[c] = CONE_ZONE(q[0], CONE_RHO(q, cdim[c]), cone_mu[c]);
     }
   }
   int iters = 0, converged = 0;
@@ -536,26 +681,40 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
     }
     for (int c = 0; c < nc; ++c) {
       if (zone[c] == 0) continue;
-      const int r0 = nru + 3 * c;
+      const int r0 = crow[c], dc = cdim[c];
       const double Dn = D[r0], mu = cone_mu[c];
-      double Hc[3][3] = {{0}}, h[3];
+      double Hc[4][4] = {{0}}, h[4] = {0, 0, 0, 0};
       if (zone[c] == 1) {
-        for (int k = 0; k < 3; ++k) { Hc[k][k] = Dn; h[k] = Dn * aref[r0 + k]; }
+        for (int k = 0; k < dc; ++k) { Hc[k][k] = Dn; h[k] = Dn * aref[r0 + k]; }
       } else {
-        const double q0 = Jak[c][0] - aref[r0], q1 = Jak[c][1] - aref[r0 + 1], q2 = Jak[c][2] - aref[r0 + 2];
-        const double rho = sqrt(q1 * q1 + q2 * q2), K = Dn / (1 + mu * mu), sl = q0 - mu * rho, u1 = q1 / rho, u2 = q2 / rho;
-        const double v[3] = {1.0, -mu * u1, -mu * u2}, q = -K * mu * sl / rho;
-        for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) Hc[k][l] = K * v[k] * v[l];
-        Hc[1][1] += q * (1 - u1 * u1); Hc[1][2] -= q * u1 * u2; Hc[2][1] -= q * u1 * u2; Hc[2][2] += q * (1 - u2 * u2);
-        for (int k = 0; k < 3; ++k) h[k] = Hc[k][0] * Jak[c][0] + Hc[k][1] * Jak[c][1] + Hc[k][2] * Jak[c][2] - K * sl * v[k];
+        double q[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
+        for (int k = 0; k < dc; ++k) q[k] = Jak[c][k] - aref[r0 + k];
+        const double rho = CONE_RHO(q, dc), K = Dn / (1 + mu * mu), sl = q[0] - mu * rho;
+        for (int k = 1; k < dc; ++k) u[k] = q[k] / rho;
+        double v[4] = {1.0, 0, 0, 0};
+        for (int k = 1; k < dc; ++k) v[k] = -mu * u[k];
+        const double qq = -K * mu * sl / rho;
+        for (int k = 0; k < dc; ++k) for (int l = 0; l < dc; ++l) Hc[k][l] = K * v[k] * v[l];
+        for (int k = 1; k < dc; ++k) for (int l = 1; l < dc; ++l) Hc[k][l] += qq * ((k == l ? 1.0 : 0.0) - u[k] * u[l]);
+        for (int k = 0; k < dc; ++k) {
+          double x = 0;
+          for (int l = 0; l < dc; ++l) x += Hc[k][l] * Jak[c][l];
+          h[k] = x - K * sl * v[k];
+        }
       }
       for (int i = 0; i < nv; ++i) {
-        const double w0 = Hc[0][0] * J[r0][i] + Hc[0][1] * J[r0 + 1][i] + Hc[0][2] * J[r0 + 2][i];
-        const double w1 = Hc[1][0] * J[r0][i] + Hc[1][1] * J[r0 + 1][i] + Hc[1][2] * J[r0 + 2][i];
-        const double w2 = Hc[2][0] * J[r0][i] + Hc[2][1] * J[r0 + 1][i] + Hc[2][2] * J[r0 + 2][i];
-        if (w0 == 0 && w1 == 0 && w2 == 0 && J[r0][i] == 0 && J[r0 + 1][i] == 0 && J[r0 + 2][i] == 0) continue;
-        a[i] += J[r0][i] * h[0] + J[r0 + 1][i] * h[1] + J[r0 + 2][i] * h[2];
-        for (int j = 0; j < nv; ++j) H[i][j] += w0 * J[r0][j] + w1 * J[r0 + 1][j] + w2 * J[r0 + 2][j];
+        double w[4] = {0, 0, 0, 0}, any = 0;
+        for (int k = 0; k < dc; ++k) {
+          any += fabs(J[r0 + k][i]);
+          for (int l = 0; l < dc; ++l) w[k] += Hc[k][l] * J[r0 + l][i];
+        }
+        if (any == 0) continue;
+        for (int k = 0; k < dc; ++k) a[i] += J[r0 + k][i] * h[k];
+        for (int j = 0; j < nv; ++j) {
+          double x = 0;
+          for (int k = 0; k < dc; ++k) x += w[k] * J[r0 + k][j];
+          H[i][j] += x;
+        }
       }
     }
     for (int k = 0; k < nf; ++k) {
@@ -578,17 +737,17 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       act[r] = want;
     }
     for (int c = 0; c < nc; ++c) {
-      double Jn_[3], big = 0, dif = 0;
-      for (int k = 0; k < 3; ++k) {
+      double Jn_[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0}, big = 0, dif = 0;
+      for (int k = 0; k < cdim[c]; ++k) {
         double x = 0;
-        for (int j = 0; j < nv; ++j) x += J[nru + 3 * c + k][j] * a[j];
-        Jn_[k] = x;
+        for (int j = 0; j < nv; ++j) x += J[crow[c] + k][j] * a[j];
+        Jn_[k] = x; q[k] = x - aref[crow[c] + k];
         big = fmax(big, fabs(Jak[c][k])); dif = fmax(dif, fabs(x - Jak[c][k]));
       }
-      const int z = CONE_ZONE(Jn_[0] - aref[nru + 3 * c], Jn_[1] - aref[nru + 3 * c + 1], Jn_[2] - aref[nru + 3 * c + 2], cone_mu[c]);
+      const int z = CONE_ZONE(q[0], CONE_RHO(q, cdim[c]), cone_mu[c]);
       if (z != zone[c] || (z == 2 && dif > 1e-8 * (1.0 + big))) changed = 1;      /* LinkModel.ELL_TOL */
       zone[c] = z;
-      for (int k = 0; k < 3; ++k) { Jak[c][k] = Jn_[k]; act[nru + 3 * c + k] = z != 0; }
+      for (int k = 0; k < cdim[c]; ++k) { Jak[c][k] = Jn_[k]; act[crow[c] + k] = z != 0; }
     }
     if (!changed) { converged = 1; break; }
   }

@@ -469,7 +469,8 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
     if si[3] == 0 and si[4] == 0:                 # three-number solimp in the MJCF: midpoint / power keep their defaults
       si[3:] = [0.5, 2.0]
     return dict(mu=float(m.geom_friction[g][0]), solref=np.array(m.geom_solref[g], float), solimp=si,
-                margin=float(m.geom_margin[g]), invw=float(m.body_invweight0[int(m.geom_body[g])][0]))
+                margin=float(m.geom_margin[g]), invw=float(m.body_invweight0[int(m.geom_body[g])][0]),
+                condim=int(m.geom_condim[g]), mu_tor=float(m.geom_friction[g][1]))
 
   def union_box(names):
     """the (parallel) boxes `names` merged into one box in the first one's axes -> link, centre, quat, half sizes"""
@@ -489,6 +490,14 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
   # Which spheres meet which boxes: every sphere belongs to a named SET, every box ACCEPTS a tuple of sets.  Defaults
   # (the door task): cylinder chains are set 'chain' and meet the plates; box corners are set 'corner' and meet the big boxes.
   for names in spec.get('plates', ()):
+    if spec.get('plates_split'):
+      # round 5: every geom of a finger is its own box with its own contact parameters -- the claw plate (class base_col) and the pad
+      # (solimp 0.95 0.99 0.01, friction 2 0.1 0.002; metaworld_assets/objects/assets/xyz_base.xml:163,173,179,185), 3 mm apart, overlapping -- as MuJoCo sees them
+      for nm in names:
+        g = m.geom_id(nm)
+        l, p, q = gframe(g)
+        box.append(dict(link=l, pos=p, quat=q, half=np.array(m.geom_size[g][:3], float), accept=tuple(spec.get('plates_accept', ('chain',))), **params(g)))
+      continue
     l, p, q, half, _, _, _ = union_box(names)
     box.append(dict(link=l, pos=p, quat=q, half=half, accept=tuple(spec.get('plates_accept', ('chain',))), **params(m.geom_id(names[-1]))))
   # boxes given explicitly (a finger built from a dozen capsules and a box is stood in for by ONE box): dict(body, pos, quat, half, like = geom
@@ -522,6 +531,14 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
     k = 1 if span == 0 else int(np.ceil(2 * span / (spacing * r))) + 1
     for t in (np.linspace(-span, span, k) if k > 1 else [0.0]):
       sph.append(dict(link=l, pos=p + quat_mat(q) @ (d * t), r=r, set=sname, chain=(g, p.copy(), quat_mat(q) @ d, span), **params(g)))
+  # round 5: CYLINDERS as cylinders -- flat ends, one contact per (box, cylinder) pair from the box-cylinder narrow phase (MuJoCo sends
+  # this pair to its general convex routine, which returns one contact).  Stored in the sphere list: pos = centre, dir = axis, hl = half length, r = radius
+  # (an edge has r = 0, a sphere hl = 0); pairs of kind 2 (col_pair_kind).
+  for e in spec.get('cylinders', ()):
+    g, sname = (e['geom'], e.get('set', 'cyl')) if isinstance(e, dict) else (e, 'cyl')
+    l, p, q = gframe(g)
+    assert m.geom_type[g] == 3
+    sph.append(dict(link=l, pos=p, r=float(m.geom_size[g][0]), dir=quat_mat(q)[:, 2].copy(), hl=float(m.geom_size[g][1]), set=sname, cyl=True, **params(g)))
   if spec.get('drop_contained'):
     # a chain sphere that lies wholly inside ANOTHER chain's capsule on the same link (the door handle's thin rod runs through a fatter
     # sleeve) can only touch what the outer capsule already touches: dropped, which keeps the plate blocks at one 16-lane pass
@@ -651,6 +668,8 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
     a, b = sph[i], box[j]
     key = (max(a['mu'], b['mu']), tuple(0.5 * (a['solref'] + b['solref'])), tuple(0.5 * (a['solimp'] + b['solimp'])),
            max(a['margin'], b['margin']), a['invw'] + b['invw'])
+    if spec.get('torsion'):                      # condim 4 pairs (MuJoCo: max of the two geoms' condim, elementwise max of their friction): torsional coefficient; 0 = condim 3
+      key = key + ((max(a['mu_tor'], b['mu_tor']) if max(a['condim'], b['condim']) >= 4 else 0.0),)
     if key not in cls:
       cls.append(key)
     pair_cls.append(cls.index(key))
@@ -663,7 +682,8 @@ def collision_primitives(m, link_of_body, rel_pos, rel_quat, spec, body_pos_=Non
               col_pair=np.array(pairs, np.int32).reshape(-1, 2), col_pair_cls=np.array(pair_cls, np.int32),
               col_cls_mu=np.array([c[0] for c in cls]), col_cls_solref=np.array([c[1] for c in cls]),
               col_cls_solimp=np.array([c[2] for c in cls]), col_cls_margin=np.array([c[3] for c in cls]),
-              col_cls_invw=np.array([c[4] for c in cls]), dof_drag_G=drag_G, dof_drag_b=drag_b, dof_drag_calibration=np.float64(drag_calib),
+              col_cls_invw=np.array([c[4] for c in cls]), col_cls_mu_tor=np.array([(c[5] if len(c) > 5 else 0.0) for c in cls]),
+              col_pair_kind=np.array([(2 if sph[i].get('cyl') else (1 if box[j].get('kind', 0) == 1 else 0)) for i, j in pairs], np.int32), dof_drag_G=drag_G, dof_drag_b=drag_b, dof_drag_calibration=np.float64(drag_calib),
               col_blk_begin=np.array([b['begin'] for b in blocks], np.int32), col_blk_end=np.array([b['end'] for b in blocks], np.int32),
               col_blk_box=np.array([b['box'] for b in blocks], np.int32), col_blk_link=np.array([b['link'] for b in blocks], np.int32),
               col_blk_center=np.array([b['center'] for b in blocks]), col_blk_reach=np.array([b['reach'] for b in blocks]),

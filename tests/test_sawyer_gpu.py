@@ -269,20 +269,16 @@ def test_contact_dynamics_match_oracle_through_a_grasp(lm):
 
 
 def test_all_demo_episodes_open_loop_loose():
-  """the 10 demonstration episodes replayed OPEN LOOP from their recorded start (door angle inverted from
-  the first recorded handle position).  The demonstrations come from MuJoCo with a feedback policy; this build's
-  stepper is a different simulator (sphere-chain handle, pyramidal friction, 8-contact cap), so only loose agreement is
-  asserted -- the bounds are what round 1 measures plus margin, and DESIGN.md section 9 quotes the measured values
-  (tools/door_demo_eval.py prints them).  With the two declared calibrations against the recordings (weld regulariser:
-  oracle/physics_oracle.py WELD_TRANSLATION_CALIBRATION; door drag: tools/mjcf_compile.py DOOR_DRAG_CALIBRATION) and the edge-vs-capsule
-  contacts of the handle rods:
-  forward (close the door): in ALL 5 episodes the replayed handle follows the recorded one within 1 cm RMS over the WHOLE episode
-  (2-4 mm measured), the gripper opening within 0.005 (grasp, drag, release: the contact sequence is the recorded one), the hand
-  within 7 cm; at least 4 reach the goal;
-  reverse (pull the door open): the door is pulled in all 5, at least 3 follow the recorded handle within 2 cm RMS (1.0-1.4 cm measured);
-  two lose the rod on the way (handle path RMS < 10 cm).
-  Round 4 (weld identified on the contact-free prefixes, elliptic cones): forward 2.2 - 4.3 mm, three reach the goal (two end 9 mm short); reverse
-  7.0 / 10.3 mm on the two short episodes, the three long ones lose the recorded contact sequence (31 - 59 mm)."""
+  """the 10 demonstration episodes replayed OPEN LOOP from their recorded start (door angle inverted from the first recorded handle position).  The
+  demonstrations come from MuJoCo with a feedback policy; this build's stepper is a different simulator (handle rods as sphere chains + edge caps, one merged plate
+  per finger, elliptic friction cone, 8-contact cap), with three declared calibrations.  The bounds below TRACK THE SHIPPED BUILD (VERDICT r04 item 1:
+  never trail it): per-episode handle-path RMS as measured (profiles/r05_heldout_eval.json; the C restatement and the kernel agree to the tenth of a millimetre) plus
+  a quarter, and the goal counts as measured:
+  forward (close the door): 3.7 / 2.3 / 2.2 / 2.4 / 4.3 mm, three reach the goal (two end 9 mm short); gripper opening within 0.005, hand within 7 cm;
+  reverse (pull the door open): 7.0 / 10.3 mm on the two short episodes, the three long ones lose the recorded contact sequence (30.9 / 54.5 / 59.3 mm); all five pull
+  the door, one reaches the goal.
+  Round 5 tried the reference's own contact geometry (two boxes per finger, box-cylinder narrow phase with one contact per pair, torsional rows) on the C restatement:
+  forward unchanged within a millimetre, ALL FIVE reverse episodes lost (tests/test_contact_experiments.py) -- not shipped."""
   import torch
   from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
   eps = []
@@ -311,10 +307,14 @@ def test_all_demo_episodes_open_loop_loose():
   out = env.rollout(torch.from_numpy(acts).cuda())
   obs, suc = out['obs'].cpu().numpy(), out['success'].cpu().numpy()
   assert np.isfinite(obs).all()
-  reached = pulled = followed = 0
+  reached = pulled = followed = rev_reached = 0
+  SHIPPED_MM = {'forward': [3.7, 2.3, 2.2, 2.4, 4.3], 'reverse': [7.0, 10.3, 30.9, 54.5, 59.3]}      # profiles/r05_heldout_eval.json, episode order
+  k = {'forward': 0, 'reverse': 0}
   for i, e in enumerate(eps):
     L = len(e[2])
     o, w = obs[:L, i], e[3]
+    shipped = SHIPPED_MM[e[0]][k[e[0]]] * 1e-3
+    k[e[0]] += 1
     handle_rms = np.sqrt(((o[:, 4:7] - w[:, 4:7]) ** 2).sum(1).mean())
     hand_max = np.linalg.norm(o[:, :3] - w[:, :3], axis=1).max()
     grip_max = np.abs(o[:, 3] - w[:, 3]).max()
@@ -322,13 +322,14 @@ def test_all_demo_episodes_open_loop_loose():
     closest = np.linalg.norm(o[:, 4:7] - o[:, 11:14], axis=1).min()
     if e[0] == 'forward':
       reached += bool(suc[:L, i].any())
-      assert handle_rms < 0.01 and hand_max < 0.07 and grip_max < 0.005, (i, handle_rms, hand_max, grip_max)
+      assert handle_rms < 1.25 * shipped + 0.0005 and hand_max < 0.07 and grip_max < 0.005, (i, handle_rms, hand_max, grip_max)
     else:
       pulled += bool(closest < 0.95 * start)
       followed += bool(handle_rms < 0.02)
-      assert handle_rms < 0.10, (i, handle_rms, closest, start)
+      rev_reached += bool(suc[:L, i].any())
+      assert handle_rms < 1.25 * shipped + 0.0005, (i, handle_rms, closest, start)
     assert (o[:, 9 - 9 + 3] >= 0).all() and (np.abs(o[:, 6] - 0.10003595) < 1e-6).all()     # handle height never changes (hinge about z)
-  assert reached >= 3 and pulled == 5 and followed >= 2, (reached, pulled, followed)        # round 4 (identified weld, elliptic cones): 3, 5, 2; rounds 1 - 3: >= 4, 5, >= 3
+  assert reached >= 3 and pulled == 5 and followed >= 2 and rev_reached >= 1, (reached, pulled, followed, rev_reached)        # as shipped: 3, 5, 2, 1 (rounds 1 - 3: 4, 5, 3, 1)
 
 
 def test_shards_equal_one_batch_and_both_lane_layouts_agree():

@@ -132,7 +132,7 @@ def summarise(rows):
 
 def final():
   """Round 4: the shipped constants (weld factors from the contact-free prefixes of the fit set, drag from the fit-set door episodes, recorded reset state) against round 3's,
-  fit set and held-out set, whole episodes open loop -> profiles/r04_heldout_eval.json"""
+  fit set and held-out set, whole episodes open loop -> profiles/r05_heldout_eval.json (HELDOUT_OUT names another file; round 4's run: r04_heldout_eval.json)"""
   physics_c.set_threads(min(8, os.cpu_count() or 1))
   reps = [Replayer('sawyer_door'), Replayer('sawyer_peg')]
   res = dict(protocol='even episodes of every (task, direction) = fit set, odd = held out; metric = RMS distance replayed vs recorded object path, open loop over the whole episode; '
@@ -159,7 +159,7 @@ def final():
       print(name, which, res['results'][name][which]['score_mm'], json.dumps({k: (v['obj_rms_mm'], v['success']) for k, v in res['results'][name][which]['groups'].items()}), flush=True)
   for r in reps:
     r.reset_state = 'recorded'; r.set(CAL_T, CAL_R, CAL_D, 1)
-  json.dump(res, open(os.path.join(ROOT, 'profiles', 'r04_heldout_eval.json'), 'w'), indent=1)
+  json.dump(res, open(os.path.join(ROOT, 'profiles', os.environ.get('HELDOUT_OUT', 'r05_heldout_eval.json')), 'w'), indent=1)
 
 
 def main():

@@ -478,6 +478,23 @@ def main():
     big = [g for g in range(len(m['geom_body'])) if m['geom_body'][g] in (dl, frame, table) and m['geom_type'][g] == 4 and colliding(g)]
     panel = [g for g in big if m['geom_body'][g] == dl][0]
     tbl = [g for g in big if m['geom_body'][g] == table][0]
+    # DOOR_CONTACTS (environment, experiments of round 5 / VERDICT r04 item 1): 'chains' = rounds 1 - 4 (sphere chains + edge caps on the handle's four cylinders, one
+    # merged plate per finger); 'cyl' = the four cylinders as cylinders, one contact per (box, cylinder) pair; '+split' = claw plate and pad as two boxes with their own
+    # contact parameters; '+tor' = condim-4 torsional coefficient in the contact classes.  Output: sawyer_door_links.npz, or sawyer_door_<variant>_links.npz.
+    variant = os.environ.get('DOOR_CONTACTS', 'chains')
+    allcyl = [g for g in range(len(m['geom_body'])) if m['geom_body'][g] == dl and m['geom_type'][g] == 3 and colliding(g)]
+    if variant.startswith('cyl'):
+      fingers = [['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']]
+      red = po.reduce_model(pm, bp, attach_bodies=['hand'], attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector'], attach_geoms=['handle'],
+                            collision=dict(plates=fingers, plates_split='split' in variant, plates_accept=('cyl',), torsion='tor' in variant,
+                                           cylinders=[dict(geom=g) for g in allcyl], corner_sets=fingers, big_boxes=big,
+                                           set_priority=('cyl',), set_cap=dict(cyl=4),
+                                           drag=[(panel, tbl, -(bp[pm.body_id('door')][2] - m['geom_size'][panel][2]))], drag_calibration=DOOR_DRAG_CALIBRATION))
+      red['reset_qpos_recorded'], red['reset_qvel_recorded'] = (np.array(RECORDED_RESET[name][k]) for k in ('start_qpos', 'start_qvel'))
+      np.savez_compressed(os.path.join(OUT, f'{name}_{variant.replace("+", "_")}_links.npz'), **red)
+      print('door variant', variant, 'spheres', len(red['col_sph_link']), 'boxes', len(red['col_box_link']), 'pairs', len(red['col_pair']), 'blocks', len(red['col_blk_begin']),
+            'classes', len(red['col_cls_mu']), 'mu_tor', red['col_cls_mu_tor'])
+      return
     red = po.reduce_model(pm, bp, attach_bodies=['hand'], attach_sites=['rightEndEffector', 'leftEndEffector', 'endEffector'],
                           attach_geoms=['handle'],
                           collision=dict(plates=[['rightclaw_it', 'rightpad_geom'], ['leftclaw_it', 'leftpad_geom']],
