@@ -150,6 +150,8 @@ SIGNATURES = {
     'earl_minitaur_reset': [C.c_void_p, C.c_void_p, _P(MinitaurCfg), _P(MinitaurState), C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_minitaur_cfg_size': [],
     'earl_debug_set_minitaur_stepper': [C.c_int],
+    'earl_debug_set_solo': [C.c_int],
+    'earl_debug_set_solo_mt': [C.c_int],
     'earl_sawyer_reset': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState)] + [C.c_void_p] * 5,
     'earl_sawyer_observe': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState), C.c_void_p, C.c_void_p],
     'earl_sawyer_door_reward': [_P(SawyerCfg), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],

@@ -2969,6 +2969,9 @@ struct KitchenRolloutArgs {
   earl_kitchen_out out;          // rows [T, n, ...]
   const float* action;           // [T, n, 9]
   int T;
+  int solo;                      // small batches (round 5): 1 = ONE env per wave -- the wave's second 32-lane group shadows the first one's env (same state, same actions, same
+                                 // branches; stores nothing), so the env's chain of timesteps is not held up by a wave-mate on a longer path; 2 = also one wave per workgroup
+                                 // (waves 1-3 leave after the tables are staged): every env has a CU's LDS and issue slots to itself.  Same numbers as the packed launch.
 };
 __device__ __forceinline__ double kit_norm_diff(const double* a, const double* b, const int n) {     // glue.hip norm_diff
   double d = 0.0;
@@ -2991,9 +2994,10 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
   stage_model(m, a.m);                                  // (ends with the workgroup barrier)
   const earl_kitchen_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
-  const bool live = env_raw < n;
-  const int env = live ? env_raw : n - 1;
+  if (a.solo == 2 && wave != 0) return;                 // (after stage_model's barrier, the last one of the kernel)
+  const int env_raw = a.solo == 2 ? (int)blockIdx.x : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
+  const bool live = env_raw < n && (a.solo == 0 || grp == 0);
+  const int env = env_raw < n ? env_raw : n - 1;
   Shared<NV>& s = sh[wave * EPW + grp];
   load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
   for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;      // (entries between different trees are never written, K5)
@@ -3129,6 +3133,7 @@ struct MinitaurArgs {
   earl_minitaur_out out;
   const float* action; int T;
   const uint8_t* mask; double* reset_obs;
+  int solo;                      // as KitchenRolloutArgs::solo
 };
 __device__ __forceinline__ double mt_draw(const earl_minitaur_cfg& cfg, const uint32_t stream, const int env, const uint64_t counter) {
   const earl::U4 b = earl::philox4x32_10(earl::U4{stream, (uint32_t)(cfg.env_offset + env), (uint32_t)counter, (uint32_t)(counter >> 32)},
@@ -3159,9 +3164,10 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
   stage_model(m, a.m);                                  // (ends with the workgroup barrier)
   const earl_minitaur_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
-  const bool in_batch = env_raw < n;
-  const int env = in_batch ? env_raw : n - 1;           // idle groups shadow the last env and store nothing
+  if (a.solo == 2 && wave != 0) return;                 // (after stage_model's barrier, the last one of the kernel)
+  const int env_raw = a.solo == 2 ? (int)blockIdx.x : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
+  const bool in_batch = env_raw < n && (a.solo == 0 || grp == 0);
+  const int env = env_raw < n ? env_raw : n - 1;        // idle groups shadow the last env (solo: their wave-mate's) and store nothing
   const bool live = in_batch && (!RESET || !a.mask || a.mask[env] != 0);      // (a reset leaves the envs outside the mask alone: their groups compute and discard)
   SH& s = sh[wave * EPW + grp];
 #ifdef EARL_PHYS_PROF
@@ -3405,6 +3411,18 @@ int g_peg_sliced = 1;     // earl_debug_set_peg_schedule
 int g_door_variant = 0;   // earl_debug_set_door_variant: 0 = by batch size, 1 = four single-wave workgroups per CU, 2 = one eight-wave workgroup per CU
 int g_lpe = 16;   // lanes per env (earl_debug_set_physics_lanes): 16 = four envs per wavefront, 64 = one wavefront per env
 
+// Small batches of the 32-lanes-per-env kernels (kitchen, minitaur): an env is a serial chain of T x frame_skip timesteps walked by one wave, so a batch that leaves
+// wave slots empty gains nothing from them -- except by giving every env a wave (solo 1: up to 4 x CUs envs) or a whole CU (solo 2: up to CUs envs) to itself.
+// earl_debug_set_solo: -1 = by batch size (default), 0 / 1 / 2 = forced (measurement, tests)
+int g_solo = -1;
+int solo_mode(int n) {
+  if (g_solo >= 0) return g_solo;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return n <= cus ? 2 : (n <= 4 * cus ? 1 : 0);
+}
+int solo_grid(int n, int solo, int wpb) { return solo == 2 ? n : (solo == 1 ? (n + wpb - 1) / wpb : (n + 2 * wpb - 1) / (2 * wpb)); }
+
 // launch geometry: Lim<NV>::WPB wavefronts per workgroup, 64 / LPE envs per wavefront
 template <int NV, int LPE> int grid_for(int n) { constexpr int epb = (64 / LPE) * Lim<NV>::WPB; return (n + epb - 1) / epb; }
 template <int NV> constexpr int block_for() { return 64 * Lim<NV>::WPB; }
@@ -3461,8 +3479,8 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
   if (!out->obs || !out->reward || !out->done || !out->success || !cfg->goal_table || cfg->n_goals < 1 || cfg->num_substeps < 0) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
   if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_rollout")) return rc;
-  MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr};
-  if (g_mt_stepper) minitaur_kernel<false, true><<<(cfg->n + 2 * EARL_MT_WPB - 1) / (2 * EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
+  MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr, solo_mode(cfg->n)};
+  if (g_mt_stepper) minitaur_kernel<false, true><<<solo_grid(cfg->n, a.solo, EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
   else minitaur_kernel<false, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_rollout");
 }
@@ -3473,12 +3491,17 @@ int earl_minitaur_reset(const void* model24, const earl_collision_model* col, co
   if (!cfg->goal_table || !cfg->reset_qpos || cfg->n_goals < 1 || cfg->settle_steps < 0) return EARL_ERR_ARG;
   if (cfg->n == 0) return EARL_OK;
   if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_reset")) return rc;
-  MinitaurArgs a{model24, col, *cfg, *st, earl_minitaur_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0, mask, obs};
-  if (g_mt_stepper) minitaur_kernel<true, true><<<(cfg->n + 2 * EARL_MT_WPB - 1) / (2 * EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
+  MinitaurArgs a{model24, col, *cfg, *st, earl_minitaur_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0, mask, obs, solo_mode(cfg->n)};
+  if (g_mt_stepper) minitaur_kernel<true, true><<<solo_grid(cfg->n, a.solo, EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
   else minitaur_kernel<true, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_reset");
 }
 int earl_minitaur_cfg_size(void) { return (int)sizeof(earl_minitaur_cfg); }
+int earl_debug_set_solo_mt(int mode) {       // this unit's copy of the small-batch switch (earl_debug_set_solo): the minitaur launches
+  const int prev = g_solo;
+  if (mode >= -1 && mode <= 2) g_solo = mode;
+  return prev;
+}
 int earl_debug_set_minitaur_stepper(int tree) {          // 1 (default): minitaur_stepper.h, 0: the generic substep<22> (comparison / measurement)
   if (tree != 0 && tree != 1) return EARL_ERR_ARG;
   g_mt_stepper = tree;
@@ -3641,11 +3664,16 @@ int earl_kitchen_rollout(const void* model, const earl_collision_model* col, con
   for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
   if (cfg->n == 0 || T == 0) return EARL_OK;
   if (int rc = check_cone(col, false, (hipStream_t)stream, "kitchen_rollout")) return rc;
-  KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T};
-  kitchen_rollout_kernel<<<grid_for<23, 32>(cfg->n), block_for<23>(), 0, (hipStream_t)stream>>>(k);
+  KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T, solo_mode(cfg->n)};
+  kitchen_rollout_kernel<<<solo_grid(cfg->n, k.solo, Lim<23>::WPB), block_for<23>(), 0, (hipStream_t)stream>>>(k);
   return launched("kitchen_rollout");
 }
 
+int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (kitchen / minitaur launches of this unit)
+  const int prev = g_solo;
+  if (mode >= -1 && mode <= 2) g_solo = mode;
+  return prev;
+}
 int earl_debug_set_physics_lanes(int lanes_per_env) {
   if (lanes_per_env != 16 && lanes_per_env != 64) return EARL_ERR_ARG;
   g_lpe = lanes_per_env;

@@ -1,5 +1,7 @@
 """how long does a SHARD of the kitchen / minitaur strong-scaling batches take on one GPU?  reset + one fused launch of the full horizon for
-n = the 8-, 4-, 2- and 1-GPU shard sizes (same seeds per env id: the shard's envs are the batch's first n).   python tools/kitchen_small_batch.py > profiles/r04_kitchen_small_batch.txt"""
+n = the 8-, 4-, 2- and 1-GPU shard sizes (same seeds per env id: the shard's envs are the batch's first n).   python tools/kitchen_small_batch.py > profiles/r05_kitchen_small_batch.txt
+Round 5: every shard size under each small-batch mode of the launch (include/earl_physics.h earl_debug_set_solo: 0 = two envs per wave, 1 = one env per wave, 2 = one env per
+workgroup, -1 = what the launcher picks), and a check that the modes' outputs are bit-identical."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +11,12 @@ from earl_benchmark_amd.envs.minitaur import Minitaur
 from earl_benchmark_amd.wrappers import PersistentStateWrapper
 
 
-def run(make, n, T, adim, reps=2):
+from earl_benchmark_amd import _abi
+LIB = _abi.load()
+
+
+def run(make, n, T, adim, reps=2, mode=-1, keep=None):
+  LIB.earl_debug_set_solo(mode); LIB.earl_debug_set_solo_mt(mode)
   env = PersistentStateWrapper(make(n), T)
   g = torch.Generator(device='cuda').manual_seed(77)
   acts = (torch.rand(T, n, adim, generator=g, device='cuda') * 2 - 1).float()
@@ -21,6 +28,9 @@ def run(make, n, T, adim, reps=2):
     env.reset(); env.unwrapped.rollout(acts, out=out)
     torch.cuda.synchronize()
     best = min(best, time.perf_counter() - t0)
+  LIB.earl_debug_set_solo(-1); LIB.earl_debug_set_solo_mt(-1)
+  if keep is not None:
+    keep.append({k: v.clone() for k, v in out.items() if torch.is_tensor(v)})
   return best
 
 
@@ -30,7 +40,11 @@ for name, make, N, T, adim in (('kitchen', lambda n: Kitchen(num_envs=n, seed=12
   full = None
   for w in (1, 2, 4, 8):
     n = N // w
-    dt = run(make, n, T, adim)
+    keep = []
+    times = {mode: run(make, n, T, adim, mode=mode, keep=keep) for mode in (0, 1, 2, -1)}
+    same = all(all(torch.equal(keep[0][k], o[k]) for k in keep[0]) for o in keep[1:])
+    dt = times[-1]
     full = dt if full is None else full
     print(f'{name}: shard of {w} GPU(s) = {n:5d} envs x {T} steps: {dt * 1e3:8.1f} ms per reset + launch = {dt / full:5.2f} x the {N}-env launch; '
-          f'{w} such GPUs would deliver {N * T / dt / 1e6:6.2f} M env-steps/s ({full / dt:4.2f} x one GPU)')
+          f'{w} such GPUs would deliver {N * T / dt / 1e6:6.2f} M env-steps/s ({full / dt:4.2f} x one GPU) | two envs per wave {times[0] * 1e3:.1f} ms, one env per wave '
+          f'{times[1] * 1e3:.1f} ms, one env per workgroup {times[2] * 1e3:.1f} ms; outputs bit-identical across the modes: {same}', flush=True)
