@@ -1971,26 +1971,30 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           const int p = m.pair[l];
           const double d = s.con.Hc.lo(l, l) + s.con.dl[l], gl = s.con.rc[l] + s.con.rl[l];
           double i0, i1 = 0.0, y;
+          // (y = F^-1 g in the SAME expressions as the uncoupled path below: an env of this wave whose own fingers touch nothing -- its B is zero -- then gets the bits
+          // it would get in a wave without any coupling contact; its result must not depend on which env shares its wave.  Round 5: the small-batch launches pair envs differently)
           if (p >= 0) {
             const int hi = l > p ? l : p, lo_ = l > p ? p : l;
             const double o = s.con.Hc.lo(hi, lo_), dp = s.con.Hc.lo(p, p) + s.con.dl[p], idet = rcp_nr(d * dp - o * o);
             i0 = dp * idet; i1 = -o * idet;
-            y = i0 * gl + i1 * (s.con.rc[p] + s.con.rl[p]);
+            y = (dp * gl - o * (s.con.rc[p] + s.con.rl[p])) * idet;
           } else {
             i0 = rcp_nr(d);
-            y = i0 * gl;
+            y = gl * i0;
           }
           fi0[l] = i0; fi1[l] = i1; fy[l] = y;
         }
         fence();
         if (isl && l < NA) {                              // row l of the Schur complement and of its right-hand side, in place
           double row[NA], g = s.con.rc[l] + s.con.rl[l];
+          bool touched = false;                           // (this env has a contact between the arm and a fixture)
 #pragma unroll
           for (int c = 0; c < NA; ++c) row[c] = c <= l ? s.con.Hc.lo(l, c) : 0.0;
 #pragma unroll
           for (int f = NA; f < NV; ++f) {
             const double bl = s.con.Hc.lo(f, l);
             if (bl != 0.0) {                              // only the fixtures this env's fingers touch have a row in B
+              touched = true;
               const int p = m.pair[f];
               const double w0 = bl * fi0[f], w1 = bl * fi1[f];
               g = fma(-bl, fy[f], g);
@@ -2004,7 +2008,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           }
 #pragma unroll
           for (int c = 0; c < NA; ++c) if (c <= l) s.con.Hc.lo(l, c) = row[c];
-          s.con.rc[l] = g - s.con.rl[l];                  // (a[] below is formed as rc + rl again)
+          if (touched) s.con.rc[l] = g - s.con.rl[l];     // (a[] below is formed as rc + rl again; an untouched row keeps its rc: (rc + rl) - rl + rl is not rc + rl in floating point)
         }
         fence();
 #pragma unroll
@@ -3481,7 +3485,7 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
   if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_rollout")) return rc;
   MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr, solo_mode(cfg->n)};
   if (g_mt_stepper) minitaur_kernel<false, true><<<solo_grid(cfg->n, a.solo, EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
-  else minitaur_kernel<false, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  else minitaur_kernel<false, false><<<solo_grid(cfg->n, a.solo, Lim<22>::WPB), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_rollout");
 }
 int earl_minitaur_reset(const void* model24, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
@@ -3493,7 +3497,7 @@ int earl_minitaur_reset(const void* model24, const earl_collision_model* col, co
   if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_reset")) return rc;
   MinitaurArgs a{model24, col, *cfg, *st, earl_minitaur_out{nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0, mask, obs, solo_mode(cfg->n)};
   if (g_mt_stepper) minitaur_kernel<true, true><<<solo_grid(cfg->n, a.solo, EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
-  else minitaur_kernel<true, false><<<grid_for<22, 32>(cfg->n), block_for<22>(), 0, (hipStream_t)stream>>>(a);
+  else minitaur_kernel<true, false><<<solo_grid(cfg->n, a.solo, Lim<22>::WPB), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_reset");
 }
 int earl_minitaur_cfg_size(void) { return (int)sizeof(earl_minitaur_cfg); }

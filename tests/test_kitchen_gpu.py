@@ -287,6 +287,40 @@ def test_fused_rollout_equals_stepping_bit_for_bit():
     assert torch.equal(info['status'], fused['status'][t])
 
 
+@pytest.mark.parametrize('n', [37, 300])
+def test_small_batch_launch_modes_are_bit_identical(n):
+  """Round 5: the kitchen launch gives every env of a small batch a wave (n <= 4 x CUs) or a whole workgroup (n <= CUs) to itself instead of packing two envs
+  into a wave (include/earl_physics.h earl_debug_set_solo).  Every mode -- and so every pairing of envs in a wave -- returns the same bits, outputs and state, through fixture
+  contacts: an env's result does not depend on which env shares its wave (the solver's coupled path gives an untouched env the bits of the uncoupled one)."""
+  import torch
+  from earl_benchmark_amd import _abi
+  from earl_benchmark_amd.envs.kitchen import Kitchen
+  lib = _abi.load()
+  T = 60
+  g = torch.Generator(device='cuda').manual_seed(9)
+  acts = torch.rand(T, n, 9, generator=g, device='cuda') * 2 - 1
+  acts[:, ::2, 2] -= 0.6                                   # every other hand goes down to the knobs: wave-mates on different solver paths in the packed mode
+  res = {}
+  try:
+    for mode in (0, 1, 2, -1):
+      assert lib.earl_debug_set_solo(mode) in (-1, 0, 1, 2)
+      env = Kitchen(num_envs=n, seed=21)
+      env.reset()
+      out = env.rollout(acts)
+      res[mode] = ({k: v.clone() for k, v in out.items()}, env.qpos.clone(), env.qvel.clone(), env.att.clone())
+  finally:
+    lib.earl_debug_set_solo(-1)
+  ref = res[0]
+  touched = int((ref[0]['obs'][:, :, 9:23] - ref[0]['obs'][0, :, 9:23]).abs().amax(0).amax(1).gt(1e-3).sum())
+  assert touched >= 3, touched                                 # fixtures were moved: contacts happened
+  for mode in (1, 2, -1):
+    for k in ref[0]:
+      a, b = ref[0][k], res[mode][0][k]
+      assert torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a, b.view(torch.int64) if b.dtype == torch.float64 else b), (mode, k)
+    for a, b in zip(ref[1:], res[mode][1:]):
+      assert torch.equal(a.view(torch.int64), b.view(torch.int64)), mode
+
+
 def test_fused_rollout_full_size():
   """2048 envs x 400 steps in one launch: finite, done exactly at the horizon, nobody diverges; the first 64 envs equal a 64-env batch stepped one step at a time"""
   import torch

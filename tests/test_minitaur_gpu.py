@@ -69,6 +69,28 @@ def test_fused_rollout_equals_stepping_bit_for_bit_and_shards_equal_the_batch(to
   assert torch.equal(torch.cat([r0['obs'], r1['obs']], 1), ra['obs'])
 
 
+def test_small_batch_launch_modes_are_bit_identical(torch):
+  """Round 5: two envs per wave / one env per wave / one env per workgroup (include/earl_physics.h earl_debug_set_solo_mt; the launcher picks by batch size): same bits, reset
+  (incl. the settle steps and the randomizer) and rollout, outputs and state"""
+  from earl_benchmark_amd import _abi
+  lib = _abi.load()
+  n, T = 45, 30
+  g = torch.Generator(device='cuda').manual_seed(4)
+  acts = (torch.rand(T, n, 8, generator=g, device='cuda') * 2 - 1)
+  res = {}
+  try:
+    for mode in (0, 1, 2, -1):
+      lib.earl_debug_set_solo_mt(mode)
+      env = make(n, seed=13)
+      out = env.rollout(acts)
+      res[mode] = [out[k].clone() for k in ('obs', 'reward', 'done', 'success', 'status')] + [getattr(env, k).clone() for k in ('qpos', 'qvel', 'overheat', 'observed_torque')]
+  finally:
+    lib.earl_debug_set_solo_mt(-1)
+  for mode in (1, 2, -1):
+    for a, b in zip(res[0], res[mode]):
+      assert torch.equal(a, b), mode
+
+
 def test_tree_stepper_matches_the_generic_stepper(torch):
   """csrc/minitaur_stepper.h (arrow-shaped Hessian, legs eliminated before the root body, DPP exchanges) against the generic nv = 22 instantiation of
   csrc/physics.hip (dense factorisation): same algorithm, so the same numbers to rounding -- reset (100 settle timesteps) and env steps from
