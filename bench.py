@@ -642,19 +642,27 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
           'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
+# one GPU, reset + one fused launch of a SHARD of the strong-scaling batches, relative to the full batch (tools/kitchen_small_batch.py on an MI355X, profiles/r05_kitchen_small_batch.txt):
+# what `world` GPUs would deliver if every shard ran like this one (no collective on the data path; the job's one all-gather is 16 KB)
+MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.95, 4: 0.91, 8: 0.89}, 'minitaur': {1: 1.00, 2: 0.50, 4: 0.46, 8: 0.46}}
+
+
 def predicted_strong_scaling(workload, n_global, world):
   """What the kernels' own layout predicts for the STRONG-scaling lines (configs[3] / [4]: a fixed global batch range-sharded over the GPUs), stated in the
-  line so that nobody reads 'x8' into it.  An env is a serial chain of T x frame_skip timesteps walked by ONE wave; a launch lasts as
-  long as its slowest wave.  Sharding the batch over more GPUs shortens a launch only while a GPU has more waves than wave slots (kitchen: 8 envs per CU x 256
-  CUs = 2048 envs fill exactly one round on ONE GPU; minitaur: 8 envs per CU per round, 4096 envs = two rounds)."""
+  line so that nobody reads 'x8' into it.  An env is a serial chain of T x frame_skip timesteps walked by ONE 32-lane group; a launch lasts as
+  long as its slowest wave.  Sharding the batch over more GPUs shortens a launch while a GPU has more waves than wave slots (kitchen: 2048 envs fill exactly one
+  round on ONE GPU; minitaur: 4096 envs = two rounds), and below that only by what the small-batch launch modes recover (one env per wave / per workgroup: an env no
+  longer waits for its wave-mate's longer branch) -- measured on one GPU per shard size, not extrapolated."""
   per_round = 2048                                      # both kernels: 2 envs per wave, 4 waves per CU, 256 CUs
   rounds_1 = -(-n_global // per_round)
   rounds_w = -(-(-(-n_global // world)) // per_round)
+  rel = MEASURED_SHARD_TIME.get(workload, {}).get(world) if n_global == (2048 if workload == 'kitchen' else 4096) else None
   return {'envs_per_gpu': -(-n_global // world), 'launch_rounds_on_1_gpu': rounds_1, f'launch_rounds_on_{world}_gpus': rounds_w,
-          'predicted_speedup_vs_1_gpu': rounds_1 / rounds_w,
-          'note': (f'{workload}: {n_global} envs = {rounds_1} round(s) of 2048 resident envs on one MI355X; on {world} GPU(s) every shard is {rounds_w} round, so the launch '
-                   f'is predicted {rounds_1 / rounds_w:.1f}x shorter at best (a round lasts as long as its slowest env chain; fewer waves per CU also contend less for '
-                   'LDS and issue slots, measured separately in DESIGN.md section 6).  The scaling lever of these workloads is MORE envs, not more GPUs per env.')}
+          'predicted_speedup_vs_1_gpu': (1.0 / rel) if rel else rounds_1 / rounds_w,
+          'basis': 'measured: one MI355X running one shard of this size (profiles/r05_kitchen_small_batch.txt)' if rel else 'launch rounds',
+          'note': (f'{workload}: {n_global} envs = {rounds_1} round(s) of 2048 resident envs on one MI355X; on {world} GPU(s) a shard of {-(-n_global // world)} envs takes '
+                   + (f'{rel:.2f} x the full-batch launch (measured), so the job is predicted {1.0 / rel:.2f} x faster' if rel else f'{rounds_w} round(s): predicted {rounds_1 / rounds_w:.1f} x at best')
+                   + '.  The chain of an env (T x frame_skip dependent timesteps on one 32-lane group) does not shorten with more GPUs; the scaling lever of these workloads is MORE envs.')}
 
 
 def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=2048, T=400, cpu_seconds=None, env_factory=None):
