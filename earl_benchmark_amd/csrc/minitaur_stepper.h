@@ -121,7 +121,7 @@ struct SharedMTData {
   double qp[NV], qv[NV];
   double bq[4];
   double aprev[NV];                  // solution of the newest solve (warm start of the next timestep; exchange buffer of the row tests)
-  struct { double ext[NV]; double mscale[3], foot_mu; } xt;
+  struct { double ext[NV]; double motor_volt, motor_visc; double mscale[3], foot_mu; } xt;      // (same fields as Shared<NV>::xt)
   double eres[12], eD[12], ear[12];  // closure rows: residual, weight, reference acceleration
   union {
     double ct[MC][8];                // contact records (pair tests -> contact rows)

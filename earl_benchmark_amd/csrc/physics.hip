@@ -370,6 +370,8 @@ template <int NV> struct ConStore<NV, true> {
   double eD[3 * EARL_MAXCONNECT], ear[3 * EARL_MAXCONNECT], eres[3 * EARL_MAXCONNECT];
   double ext[NV];
   signed char crow[EARL_MAXCON][2];      // per contact: the (at most two) dofs beyond the root body's six that its Jacobian touches, -1 = none (K9's column update)
+  double motor_volt, motor_visc;         // the env's battery voltage and motor viscous damping (earl_minitaur_state.motor_param[0..1]): read by ApplyAction in every timestep -- kept here, not in two
+                                         // registers that live across the whole rollout (they were the one spill reloaded inside the timestep loop; tools/scratch_in_loops.py)
   double mscale[3], foot_mu;             // the minitaur's per-env randomisation (earl_minitaur_state.motor_param[2..5]): mass / inertia factor of the root body, the upper links,
                                          // the lower links; friction of the lower links' contacts (<= 0: the classes' own).  Unused (1, 1, 1, -1) elsewhere.
 };
@@ -3226,7 +3228,7 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
     oh = a.st.overheat[(size_t)env * 8 + mi]; en = a.st.motor_enabled[(size_t)env * 8 + mi] != 0; obs_t = a.st.observed_torque[(size_t)env * 8 + mi];
   }
   if (sub < NV) s.xt.ext[sub] = 0.0;
-  if (sub == 0) { s.xt.mscale[0] = ms0; s.xt.mscale[1] = ms1; s.xt.mscale[2] = ms2; s.xt.foot_mu = fmu; }
+  if (sub == 0) { s.xt.mscale[0] = ms0; s.xt.mscale[1] = ms1; s.xt.mscale[2] = ms2; s.xt.foot_mu = fmu; s.xt.motor_volt = voltage; s.xt.motor_visc = viscous; }
   fence();
   // Minitaur.ApplyAction (minitaur.py:326-390) of motor `mi`: the command clipped to what the velocity limit allows in one timestep, the DC-motor
   // model, overheat protection, torque x motor direction -> s.xt.ext[dof]
@@ -3235,7 +3237,7 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
       const double q = s.qp[mdof] * mdir, qd = s.qv[mdof] * mdir;
       const double c = earl::mt_clipd(cmd, q - lim, q + lim);
       double act, obs;
-      earl::mt_motor_torque(cfg.motor_kp, cfg.motor_kd, voltage, viscous, false, c, q, qd, act, obs);
+      earl::mt_motor_torque(cfg.motor_kp, cfg.motor_kd, s.xt.motor_volt, s.xt.motor_visc, false, c, q, qd, act, obs);
       oh = fabs(act) > cfg.overheat_torque ? oh + 1 : 0;
       if (oh > cfg.overheat_steps) en = false;
       obs_t = obs;
@@ -3276,7 +3278,7 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
       if (sub == 0) {
         a.st.goal[(size_t)env * 2] = goal0; a.st.goal[(size_t)env * 2 + 1] = goal1;
         double* mp = a.st.motor_param + (size_t)env * 6;
-        mp[0] = voltage; mp[1] = viscous; mp[2] = s.xt.mscale[0]; mp[3] = s.xt.mscale[1]; mp[4] = s.xt.mscale[2]; mp[5] = s.xt.foot_mu;
+        mp[0] = s.xt.motor_volt; mp[1] = s.xt.motor_visc; mp[2] = s.xt.mscale[0]; mp[3] = s.xt.mscale[1]; mp[4] = s.xt.mscale[2]; mp[5] = s.xt.foot_mu;
         if (a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
         if (a.st.steps_since_goal_change) a.st.steps_since_goal_change[env] = 0;
       }

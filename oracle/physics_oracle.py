@@ -233,13 +233,30 @@ def kbimp(solref, solimp, r, dt):
   return k, b, d
 
 
-def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
-  """rows: J [nc,nv], r [nc], aref [nc], R [nc], is_equality [nc]"""
+WELD_FORM = 'shipped'      # 'shipped' | 'documented' (tools/weld_free_motion_fit.py --forms evaluates both, and six more, on the contact-free prefixes)
+
+
+def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat, weld_form=None):
+  """rows: J [nc,nv], r [nc], aref [nc], R [nc], is_equality [nc]
+
+  The mocap weld's six rows in two FORMS (weld_form, default WELD_FORM):
+  * 'documented' -- MuJoCo's weld as its documentation and mj_instantiateEquality describe it: the mocap body's quaternion NORMALISED (mj_kinematics normalises mocap_quat),
+    translational residual p_mocap - p_hand with the point Jacobian; rotational residual = vector part of the difference quaternion conj(q_hand) q_mocap (~ half the rotation
+    vector) with Jacobian 0.5 x (angular Jacobian in the hand's axes, corrected by the quaternion); regulariser R = (1 - d) / d x body_invweight0[hand] -- its translational
+    component on the first three rows, its rotational one on the last three (diagApprox of an equality row) -- with d the row's own impedance.  Factor 1.0 on everything.
+  * 'shipped' -- the same rows with the mocap quaternion taken AS GIVEN ([1, 0, 1, 0], norm sqrt 2: both the residual and the Jacobian of the rotational rows come out
+    sqrt 2 larger) and the two regularisers multiplied by WELD_TRANSLATION_CALIBRATION / WELD_ROTATION_CALIBRATION (m.weld_calibration).
+  On the contact-free prefixes of the recordings (profiles/r05_weld_forms.json; start state re-fitted per form): 'documented' misses the recorded hand path by 13.4 mm (door) /
+  4.9 mm (peg) RMS, 'shipped' by 0.94 / 0.77 mm.  No documented form needs no factor."""
+  form = weld_form or WELD_FORM
   rows = []
   for w in range(len(m.weld_body1)):
     b1, b2 = int(m.weld_body1[w]), int(m.weld_body2[w])
     assert m.body_mocap[b1], 'weld body1 is the mocap body in these models'
     p1, q1 = mocap_pos, np.asarray(mocap_quat, dtype=np.float64)       # as given: NOT normalised (round 2's rule, see the note above WELD_TRANSLATION_CALIBRATION)
+    cal = np.asarray(m.weld_calibration, float)
+    if form == 'documented':
+      q1, cal = q1 / np.sqrt(q1 @ q1), np.ones(2)
     p2, q2 = kin['xpos'][b2], kin['xquat'][b2]
     Jb = body_jacobian(m, S, b2, p2)
     # mj_instantiateEqual, weld with relpose = identity (metaworld's reset_mocap_welds): position error body1 - body2;
@@ -248,11 +265,11 @@ def constraints(m, kin, S, qpos, qvel, mocap_pos, mocap_quat):
     e = quat_mul(quat_conj(q2), q1)
     R2 = quat_mat(q2)
     for a in range(3):
-      rows.append((-Jb[3 + a], rpos[a], m.weld_solref[w], m.weld_solimp[w], float(m.weld_calibration[0]) * m.body_invweight0[b2, 0], True))
+      rows.append((-Jb[3 + a], rpos[a], m.weld_solref[w], m.weld_solimp[w], float(cal[0]) * m.body_invweight0[b2, 0], True))
     A = R2.T @ Jb[0:3]                                        # 3 x nv, angular Jacobian in body2 axes
     Jq = -0.5 * (e[0] * A + np.cross(A.T, e[1:]).T)
     for a in range(3):
-      rows.append((Jq[a], e[1 + a], m.weld_solref[w], m.weld_solimp[w], float(m.weld_calibration[1]) * m.body_invweight0[b2, 1], True))
+      rows.append((Jq[a], e[1 + a], m.weld_solref[w], m.weld_solimp[w], float(cal[1]) * m.body_invweight0[b2, 1], True))
   for j in range(m.nv):
     if m.jnt_limited[j]:
       lo, hi = m.jnt_range[j]

@@ -152,8 +152,55 @@ def damping_fit(task):
   return out
 
 
+def forms():
+  """candidate FORMS of the weld's rotational rows and regularisers, each at factor 1.0 (nothing fitted but the start state, which every candidate gets
+  re-fitted for itself), on the contact-free prefixes: fit-set RMS and held-out RMS per task -> profiles/r05_weld_forms.json.  The row algebra lives in oracle/physics_oracle.py
+  (constraints()) / oracle/physics_oracle.c; a form is selected here through the restatement's switches: the mocap quaternion as given or normalised, a scale on the rotational
+  rows (rows x s == regulariser / s^2), the two regularisers."""
+  cands = [
+      ('shipped: rows = vec(conj(q_hand) q_mocap) with the mocap quaternion as given [1, 0, 1, 0], R x (3.35, 0.07) [calibrated]', dict(raw=1, ft=he.CAL_T, fr=he.CAL_R, rot_scale=1.0)),
+      ('A  same rows, mocap quaternion as given, derived regularisers (factors 1, 1)', dict(raw=1, ft=1.0, fr=1.0, rot_scale=1.0)),
+      ('B  MuJoCo as documented: mocap quaternion normalised (mj_kinematics), rows = vector part of the difference quaternion (~ theta / 2), Jacobian 0.5 x angular, '
+       'R = (1 - d) / d x body_invweight0[hand] (translational / rotational)', dict(raw=0, ft=1.0, fr=1.0, rot_scale=1.0)),
+      ('C  rotation VECTOR rows (theta x axis, angular Jacobian unscaled) = B with the rotational rows x 2', dict(raw=0, ft=1.0, fr=1.0, rot_scale=2.0)),       # rot_scale = factor on the ROWS (applied below as 1 / s^2 on the regulariser)
+      ('D  B with the inverse weights from J diag(dof_invweight0) J^T at qpos0 (translation x 3.52, rotation x 1.2 of B)', dict(raw=0, ft=3.52, fr=1.2, rot_scale=1.0)),
+      ('E  B with ONE regulariser for all six rows: the translational weight', dict(raw=0, ft=1.0, fr='tran', rot_scale=1.0)),
+      ('F  B with ONE regulariser for all six rows: the rotational weight', dict(raw=0, ft='rot', fr=1.0, rot_scale=1.0)),
+      ('G  rotational rows x 4 of B (regulariser / 16 = 0.0625: what the calibrated 0.07 amounts to as a row scale), translational rows as B', dict(raw=0, ft=1.0, fr=1.0, rot_scale=4.0)),
+      ('H  D for the translational rows (x 3.52) and G for the rotational ones (rows x 4): two RULES, nothing calibrated', dict(raw=0, ft=3.52, fr=1.0, rot_scale=4.0)),
+      ('I  D for the translational rows and C for the rotational ones (rotation vector: rows x 2)', dict(raw=0, ft=3.52, fr=1.0, rot_scale=2.0)),
+      ('J  D for the translational rows, rows x 2 sqrt(2) (rotation vector with the mocap quaternion as given)', dict(raw=0, ft=3.52, fr=1.0, rot_scale=2.8284271247461903)),
+  ]
+  out = {}
+  for name, c in cands:
+    row = {}
+    for task in ('sawyer_door', 'sawyer_peg'):
+      f = FreeMotion(task, 'fit')
+      lib().oracle_set_raw_mocap_quat(C.c_int(c['raw']))
+      rs = 1.0 / c['rot_scale'] ** 2                        # oracle_set_weld_row_scale multiplies the REGULARISER of a row: rows x s == regulariser / s^2
+      sc = (C.c_double * 6)(1, 1, 1, rs, rs, rs)
+      lib().oracle_set_weld_row_scale(sc)
+      dt_, dr_ = f.derived
+      ft = c['ft'] if c['ft'] != 'rot' else dr_ / dt_
+      fr = c['fr'] if c['fr'] != 'tran' else dt_ / dr_
+      try:
+        x, rms = f.fit(ft, fr)
+        h = FreeMotion(task, 'heldout'); h.set(ft, fr)
+        lib().oracle_set_raw_mocap_quat(C.c_int(c['raw'])); lib().oracle_set_weld_row_scale(sc)
+        e = h.residuals(x[:14])[3:]
+        row[task] = dict(fit_rms_mm=round(rms, 2), heldout_rms_mm=round(float(np.sqrt((e ** 2).mean() * 3)), 2))
+      finally:
+        lib().oracle_set_weld_row_scale(None); lib().oracle_set_raw_mocap_quat(C.c_int(1))
+    out[name] = row
+    print(f"{name[:110]:110s} door fit {row['sawyer_door']['fit_rms_mm']:5.2f} held-out {row['sawyer_door']['heldout_rms_mm']:5.2f} | peg fit {row['sawyer_peg']['fit_rms_mm']:5.2f} held-out "
+          f"{row['sawyer_peg']['heldout_rms_mm']:5.2f} mm", flush=True)
+  json.dump(out, open(os.path.join(ROOT, 'profiles', 'r05_weld_forms.json'), 'w'), indent=1)
+
+
 def main():
   physics_c.set_threads(min(8, os.cpu_count() or 1))
+  if '--forms' in sys.argv:
+    return forms()
   if '--damping' in sys.argv:
     task = ([a for a in sys.argv[1:] if not a.startswith('-')] or ['sawyer_door'])[0]
     path = os.path.join(ROOT, 'profiles', 'r04_weld_free_motion_fit.json')
