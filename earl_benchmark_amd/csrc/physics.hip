@@ -39,7 +39,9 @@
 
 // translation units: physics.hip (the main one: nv 10 / 15 / 23 models, every entry point but the two below), physics_w8.hip (the door model's
 // eight-waves-per-CU rollout) and physics_mt.hip (the minitaur: nv = 22) include this file under a variant macro and are compiled side by side
-#if defined(EARL_PHYS_VARIANT_W8) || defined(EARL_PHYS_VARIANT_MT)
+// and physics_l64.hip (round 5: the one-wavefront-per-env instantiations of the Sawyer kernels -- a measurement / test switch, earl_debug_set_physics_lanes(64) -- which were a
+// third of the main unit's 50 s of compile time)
+#if defined(EARL_PHYS_VARIANT_W8) || defined(EARL_PHYS_VARIANT_MT) || defined(EARL_PHYS_UNIT_L64)
 #define EARL_PHYS_NOT_MAIN 1
 #endif
 
@@ -3433,12 +3435,20 @@ int solo_grid(int n, int solo, int wpb) { return solo == 2 ? n : (solo == 1 ? (n
 template <int NV, int LPE> int grid_for(int n) { constexpr int epb = (64 / LPE) * Lim<NV>::WPB; return (n + epb - 1) / epb; }
 template <int NV> constexpr int block_for() { return 64 * Lim<NV>::WPB; }
 
+}  // namespace
+// the 64-lanes-per-env instantiations live in physics_l64.hip (argument structs by address: same source, same layout in both units); not exported from the library
+extern "C" __attribute__((visibility("hidden"))) void earl_unit_l64_physics(const void* pargs, int nv, int integrate, void* stream);
+extern "C" __attribute__((visibility("hidden"))) void earl_unit_l64_sawyer_rollout(const void* sawyer_args, int nv, void* stream);
+namespace {
+
+#ifndef EARL_PHYS_UNIT_L64
 template <int NV, bool INTEGRATE>
 void launch_physics(const PArgs& a, hipStream_t st) {
   if constexpr (NV > 16) physics_kernel<NV, 32, INTEGRATE><<<grid_for<NV, 32>(a.n), block_for<NV>(), 0, st>>>(a);   // 32 lanes per env: two envs per wave
-  else if (g_lpe == 64) physics_kernel<NV, 64, INTEGRATE><<<grid_for<NV, 64>(a.n), block_for<NV>(), 0, st>>>(a);
+  else if (g_lpe == 64) earl_unit_l64_physics(&a, NV, INTEGRATE ? 1 : 0, st);
   else physics_kernel<NV, 16, INTEGRATE><<<grid_for<NV, 16>(a.n), block_for<NV>(), 0, st>>>(a);
 }
+#endif
 
 }  // namespace
 
@@ -3526,6 +3536,21 @@ int earl_debug_read_phys_profile_mt(unsigned long long* out, int reset) {       
   return EARL_OK;
 }
 #endif
+#elif defined(EARL_PHYS_UNIT_L64)
+// This translation unit is physics_l64.hip: one wavefront per env (64 lanes) for the nv = 10 / 15 models -- launched from physics.hip when earl_debug_set_physics_lanes(64) is on
+void earl_unit_l64_physics(const void* pargs, int nv, int integrate, void* stream) {
+  const PArgs& a = *static_cast<const PArgs*>(pargs);
+  const hipStream_t st = (hipStream_t)stream;
+  if (nv == 10 && integrate) physics_kernel<10, 64, true><<<grid_for<10, 64>(a.n), block_for<10>(), 0, st>>>(a);
+  else if (nv == 10) physics_kernel<10, 64, false><<<grid_for<10, 64>(a.n), block_for<10>(), 0, st>>>(a);
+  else if (nv == 15 && integrate) physics_kernel<15, 64, true><<<grid_for<15, 64>(a.n), block_for<15>(), 0, st>>>(a);
+  else if (nv == 15) physics_kernel<15, 64, false><<<grid_for<15, 64>(a.n), block_for<15>(), 0, st>>>(a);
+}
+void earl_unit_l64_sawyer_rollout(const void* sawyer_args, int nv, void* stream) {
+  const SawyerArgs& a = *static_cast<const SawyerArgs*>(sawyer_args);
+  if (nv == 10) sawyer_rollout_kernel<10, 64><<<grid_for<10, 64>(a.cfg.n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
+  else if (nv == 15) sawyer_rollout_kernel<15, 64><<<grid_for<15, 64>(a.cfg.n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
+}
 #elif defined(EARL_PHYS_VARIANT_W8)
 // This translation unit is physics_w8.hip: the door model's rollout kernel built with eight-wave workgroups (EARL_DOOR_WPB 8: 32 envs share one
 // copy of the tables, packed matrices, in-LDS factorisations, 256 registers per wave) = eight waves per CU.  Same arithmetic, bit-identical
@@ -3574,10 +3599,10 @@ int earl_sawyer_rollout(const earl_link_model* model, const earl_collision_model
   if (nv == 10 && g_lpe != 64 && (g_door_variant == 2 || (g_door_variant == 0 && cfg->n > 4096)))
     return earl_sawyer_rollout_door_w8(model, col, cfg, st, action, T, out, stream);      // eight waves per CU: wins from two rounds of 4096 envs on
   if (nv == 10) {
-    if (g_lpe == 64) sawyer_rollout_kernel<10, 64><<<grid_for<10, 64>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
+    if (g_lpe == 64) earl_unit_l64_sawyer_rollout(&a, 10, stream);
     else sawyer_rollout_kernel<10, 16><<<grid_for<10, 16>(cfg->n), block_for<10>(), 0, (hipStream_t)stream>>>(a);
   } else if (nv == 15) {
-    if (g_lpe == 64) sawyer_rollout_kernel<15, 64><<<grid_for<15, 64>(cfg->n), block_for<15>(), 0, (hipStream_t)stream>>>(a);
+    if (g_lpe == 64) earl_unit_l64_sawyer_rollout(&a, 15, stream);
     else {
       // more workgroups than the GPU holds at once (one four-wave workgroup = 16 envs per CU): time-sliced schedule, one persistent workgroup per CU
       int dev = 0, cus = 256;
