@@ -41,7 +41,8 @@
 // eight-waves-per-CU rollout) and physics_mt.hip (the minitaur: nv = 22) include this file under a variant macro and are compiled side by side
 // and physics_l64.hip (round 5: the one-wavefront-per-env instantiations of the Sawyer kernels -- a measurement / test switch, earl_debug_set_physics_lanes(64) -- which were a
 // third of the main unit's 50 s of compile time)
-#if defined(EARL_PHYS_VARIANT_W8) || defined(EARL_PHYS_VARIANT_MT) || defined(EARL_PHYS_UNIT_L64)
+// ... and physics_kitchen.hip (round 5: the nv = 23 instantiation, the kitchen env kernels and their entry points)
+#if defined(EARL_PHYS_VARIANT_W8) || defined(EARL_PHYS_VARIANT_MT) || defined(EARL_PHYS_UNIT_L64) || defined(EARL_PHYS_UNIT_KITCHEN)
 #define EARL_PHYS_NOT_MAIN 1
 #endif
 
@@ -2398,168 +2399,6 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs 
   }
 }
 
-// ------------------------------------------------------------------------------------------------ Sawyer env kernels
-struct SawyerArgs {
-  const void* m;
-  const earl_collision_model* col;
-  earl_sawyer_cfg cfg;
-  earl_sawyer_state st;
-  const float* action; int T;
-  earl_sawyer_out out;
-  const double* reset_qpos; const double* reset_qvel; const uint8_t* mask; double* reset_obs;
-  int observe_only;
-  int slice;                     // SLICED rollout: env steps per work item (0: one item = the whole rollout of a group)
-};
-
-// Work queue of the time-sliced rollout (earl_sawyer_state.sched: progress[G] then lock[G], zero on entry).  An env group's state is in HBM after every env
-// step (the failure guard's "last stable state"), so ANY wave can take the group's next slice of env steps; a wave claims the unlocked group that has come
-// LEAST far.  The groups whose envs are in contact -- the slow chains a statically scheduled launch waits for at the end of its second round -- are then
-// re-claimed the moment they are released and run without a break from the start, while the fast groups share the other wave slots: the launch tends to
-// total work / wave slots instead of (typical wave) + (slowest wave).  Results do not depend on the schedule: an env's arithmetic is its own.
-// `home`: where this wave starts looking among groups that have come equally far (its own index in the launch x 2): at the start every group stands at 0, and
-// a thousand waves going for group 0 at once would fight over every lock in turn
-__device__ __forceinline__ int sched_claim(int32_t* sched, const int G, const int T, const int lane, const int home, int& t0) {
-  int32_t* progress = sched;
-  int32_t* lock = sched + G;
-  for (;;) {
-    unsigned long long best = ~0ull;
-    for (int gi = lane; gi < G; gi += 64) {
-      const int p = __hip_atomic_load(progress + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int l = __hip_atomic_load(lock + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int rot = gi >= home ? gi - home : gi - home + G;                 // distance from `home`, going up and around
-      const unsigned long long key = ((unsigned long long)(unsigned int)p << 32) | (unsigned int)rot;
-      best = (l == 0 && p < T && key < best) ? key : best;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const unsigned long long o = __shfl_xor(best, off);
-      best = o < best ? o : best;
-    }
-    if (best == ~0ull) return -1;                       // every unfinished group is in some wave's hands: nothing to do for this one
-    const int rot_ = (int)(best & 0xFFFFFFFFull);
-    const int gi = rot_ + home < G ? rot_ + home : rot_ + home - G;
-    int ok = 0;
-    if (lane == 0) ok = atomicCAS(lock + gi, 0, 1) == 0 ? 1 : 0;
-    ok = __shfl(ok, 0);
-    if (!ok) continue;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows the previous holder of this group wrote
-    const int p = __hip_atomic_load(progress + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p >= T) {                                       // (finished between the scan and the lock)
-      if (lane == 0) __hip_atomic_store(lock + gi, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
-    t0 = p;
-    return gi;
-  }
-}
-__device__ __forceinline__ void sched_release(int32_t* sched, const int G, const int g, const int t1, const int lane) {
-  fence();
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // state rows, output rows, goal rows of this slice -> visible to the next holder
-  if (lane == 0) {
-    __hip_atomic_store(sched + g, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(sched + G + g, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// metaworld reward_utils.tolerance(x, bounds=(0, hi), margin, sigmoid='gaussian') [UPSTREAM, dm_control semantics; unpinned]
-__device__ __forceinline__ double tolerance_gaussian(double x, double hi, double margin) {
-#pragma clang fp contract(off)
-  if (0.0 <= x && x <= hi) return 1.0;
-  if (margin == 0) return 0.0;
-  const double d = (x < 0.0 ? -x : x - hi) / margin;
-  const double scale = sqrt(-2.0 * log(0.1));
-  return exp(-0.5 * (d * scale) * (d * scale));
-}
-
-// reward + success of one observation row (sawyer_door.py:141-177)
-__device__ __forceinline__ void door_reward(const earl_sawyer_cfg& cfg, const V3 tcp, const V3 obj, const V3 target, double& r, bool& ok, double* info = nullptr) {
-#pragma clang fp contract(off)
-  const V3 d = vsub(obj, target);
-  const double obj_to_target = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);     // np.linalg.norm in f64
-  ok = obj_to_target <= cfg.success_radius;
-  r = ok ? 1.0 : 0.0;
-  if (cfg.reward_type != 0 || info) {
-    const V3 e = vsub(tcp, obj);
-    const V3 oi = vsub(ld3(cfg.obj_init_pos), target), hi = vsub(ld3(cfg.hand_init_pos), obj);
-    const double in_place = tolerance_gaussian(obj_to_target, 0.05, sqrt(oi.x * oi.x + oi.y * oi.y + oi.z * oi.z));
-    const double hand_in_place = tolerance_gaussian(sqrt(e.x * e.x + e.y * e.y + e.z * e.z), 0.25 * 0.05, sqrt(hi.x * hi.x + hi.y * hi.y + hi.z * hi.z) + 0.1);
-    if (cfg.reward_type != 0) {
-      r = 3 * hand_in_place + 6 * in_place;
-      if (obj_to_target < 0.05) r = 10;
-    }
-    if (info) {
-      // SawyerDoorV2.evaluate_state (sawyer_door.py:127-139); compute_reward returns [reward, obj_to_target, hand_in_place] (:171), so the dict's
-      // 'in_place_reward' is the hand's term
-      info[EARL_INFO_SUCCESS] = obj_to_target <= 0.08 ? 1.0 : 0.0;
-      info[EARL_INFO_NEAR_OBJECT] = 0.0; info[EARL_INFO_GRASP_SUCCESS] = 1.0; info[EARL_INFO_GRASP_REWARD] = 1.0;
-      info[EARL_INFO_IN_PLACE_REWARD] = hand_in_place; info[EARL_INFO_OBJ_TO_TARGET] = obj_to_target; info[EARL_INFO_UNSCALED_REWARD] = r;
-      info[7] = 0.0;
-    }
-  }
-}
-
-// ---- metaworld reward_utils / SawyerXYZEnv._gripper_caging_reward [UPSTREAM metaworld, not in the reference tree; UNPINNED]:
-// restated as in oracle/sawyer_oracle.py (tolerance_long_tail, rect_prism_tolerance, hamacher_product, gripper_caging_reward)
-__device__ __forceinline__ double tol_long_tail(double x, double lo, double hi, double margin) {
-#pragma clang fp contract(off)
-  if (lo <= x && x <= hi) return 1.0;
-  if (margin == 0) return 0.0;
-  const double d = (x < lo ? lo - x : x - hi) / margin;
-  const double scale = sqrt(1 / 0.1 - 1);
-  return 1 / ((d * scale) * (d * scale) + 1);
-}
-__device__ __forceinline__ bool in_rng(double a, double b, double c) { return c >= b ? (b <= a && a <= c) : (c <= a && a <= b); }
-__device__ __forceinline__ double rect_prism_tol(const V3 cur, const double* zero, const double* one) {
-#pragma clang fp contract(off)
-  if (in_rng(cur.x, zero[0], one[0]) && in_rng(cur.y, zero[1], one[1]) && in_rng(cur.z, zero[2], one[2]))
-    return (cur.x - zero[0]) / (one[0] - zero[0]) * ((cur.y - zero[1]) / (one[1] - zero[1])) * ((cur.z - zero[2]) / (one[2] - zero[2]));
-  return 1.0;
-}
-__device__ __forceinline__ double hamacher(double a, double b) {
-#pragma clang fp contract(off)
-  const double den = a + b - (a * b);
-  return den > 0 ? (a * b) / den : 0.0;
-}
-// SawyerPegV2.compute_reward, reward_type 'dense' (sawyer_peg.py:231-299); head = obs[4:7] (site pegHead), tcp = obs[:3] (hand)
-// dense = false: reward_type 'sparse' (sawyer_peg.py:284-285: object_grasped = 0 unless lifted); the terms are still worked out, for the info dict (terms[]:
-// tcp_to_obj, obj_to_target (axis-scaled), object_grasped, in_place; may be NULL)
-__device__ __forceinline__ double peg_dense_reward(const earl_sawyer_cfg& cfg, const V3 tcp, const double tcp_opened, const V3 head, const V3 grasp,
-                                                   const V3 lpad, const V3 rpad, const V3 tcpc, const V3 target, const double* __restrict__ oi,
-                                                   const double effort, const bool dense = true, double* terms = nullptr) {
-#pragma clang fp contract(off)
-  const V3 obj = grasp;                                   // obs[4:7] - pegHead + pegGrasp with obs[4:7] == pegHead
-  const V3 e = vsub(obj, tcp);
-  const double tcp_to_obj = sqrt(e.x * e.x + e.y * e.y + e.z * e.z);
-  const V3 ht{(head.x - target.x) * 1.0, (head.y - target.y) * 2.0, (head.z - target.z) * 2.0};
-  const double obj_to_target = sqrt(ht.x * ht.x + ht.y * ht.y + ht.z * ht.z);
-  const V3 hi{(oi[3] - target.x) * 1.0, (oi[4] - target.y) * 2.0, (oi[5] - target.z) * 2.0};
-  double in_place = tol_long_tail(obj_to_target, 0.0, 0.05, sqrt(hi.x * hi.x + hi.y * hi.y + hi.z * hi.z));
-  const double box1 = rect_prism_tol(head, cfg.box_corners[0], cfg.box_corners[1]), box2 = rect_prism_tol(head, cfg.box_corners[2], cfg.box_corners[3]);
-  in_place = hamacher(in_place, hamacher(box2, box1));
-  const bool lifted = tcp_to_obj < 0.08 && tcp_opened > 0 && obj.z - 0.01 > oi[2];
-  double grasped = 1.0;
-  if (!lifted && !dense) grasped = 0.0;
-  if (!lifted && dense) {
-    // _gripper_caging_reward(action, obj, obj_radius 0.0075, pad_success_thresh 0.03, object_reach_radius 0.01, xz_thresh 0.005, high_density)
-    const double pl = fabs(lpad.y - obj.y), pr = fabs(rpad.y - obj.y);
-    const double ml = fabs(fabs(lpad.y - oi[1]) - 0.03), mr = fabs(fabs(rpad.y - oi[1]) - 0.03);
-    const double caging_y = hamacher(tol_long_tail(pl, 0.0075, 0.03, ml), tol_long_tail(pr, 0.0075, 0.03, mr));
-    const double ix = oi[0] - cfg.init_tcp[0], iz = oi[2] - cfg.init_tcp[2];
-    const double dx = tcpc.x - obj.x, dz = tcpc.z - obj.z;
-    const double caging_xz = tol_long_tail(sqrt(dx * dx + dz * dz), 0.0, 0.005, sqrt(ix * ix + iz * iz) - 0.005);
-    const double closed = fmin(fmax(0.0, effort), 1.0) / 1.0;
-    const double caging = hamacher(caging_y, caging_xz);
-    const double gripping = caging > 0.97 ? closed : 0.0;
-    grasped = (hamacher(caging, gripping) + caging) / 2;
-  }
-  double r = hamacher(grasped, in_place);
-  if (lifted) r += 1.0 + 5 * in_place;
-  if (obj_to_target <= 0.05) r = 10.0;
-  if (terms) { terms[0] = tcp_to_obj; terms[1] = obj_to_target; terms[2] = grasped; terms[3] = in_place; }
-  return r;
-}
-
-// any lane of this env's LPE-lane group (the whole wavefront calls it)
 template <int LPE>
 __device__ __forceinline__ bool group_any(const bool pred, const int grp) {
   const unsigned long long bal = __ballot(pred);
@@ -2567,809 +2406,17 @@ __device__ __forceinline__ bool group_any(const bool pred, const int grp) {
   else return ((bal >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull)) != 0ull;
 }
 
-// obs[14] + reward + flags of one env from the kinematics in LDS (sawyer_door.py:86-94, :141-177); the whole group calls it
-template <int NV>
-__device__ __forceinline__ void sawyer_emit(Shared<NV>& s, const typename ModelOf<NV>::T& m, const earl_sawyer_cfg& cfg, const int sub, const bool live,
-                                            const double* __restrict__ goal, double* __restrict__ obs, float* reward, uint8_t* success,
-                                            const double* __restrict__ obj_init = nullptr, const double effort = 0.0, double* __restrict__ obs2 = nullptr,
-                                            double* __restrict__ info = nullptr) {
-#pragma clang fp contract(off)
-  // (compiled into the peg model's kernels only: in the door kernel this code cost 35 more AGPR spills and 10 % of its throughput.  The door's info dict is a
-  // function of the observation alone: earl_sawyer_door_info works it out from the emitted rows.)
-  const bool peg_terms = NV >= 15 && cfg.obj_kind >= 1 && obj_init != nullptr && (cfg.reward_type != 0 || info != nullptr);
-  const bool peg_dense = peg_terms && cfg.reward_type != 0;
-  if (sub < (peg_terms ? 7 : 4)) {
-    const int k = sub == 0 ? cfg.att_hand : (sub == 1 ? cfg.att_right : (sub == 2 ? cfg.att_left : (sub == 3 ? cfg.att_obj :
-                  (sub == 4 ? cfg.att_grasp : (sub == 5 ? cfg.att_lpad : cfg.att_rpad)))));
-    const V3 p = attachment<NV>(s, m, k);
-    s.emit.att[sub][0] = p.x; s.emit.att[sub][1] = p.y; s.emit.att[sub][2] = p.z;
-  }
-  fence();
-  if (sub < 14 && live && (obs || obs2)) {
-    double v;
-    if (sub < 3) v = s.emit.att[0][sub];
-    else if (sub == 3) {
-      const V3 d = vsub(ld3(s.emit.att[1]), ld3(s.emit.att[2]));
-      v = fmin(fmax(sqrt(d.x * d.x + d.y * d.y + d.z * d.z) / 0.1, 0.0), 1.0);
-    } else if (sub < 7) v = s.emit.att[3][sub - 4];
-    else v = goal[sub - 7];
-    if (obs) obs[sub] = v;
-    if (obs2) obs2[sub] = v;
-  }
-  if (sub == 0 && live) {
-    double r; bool ok;
-    door_reward(cfg, ld3(s.emit.att[0]), ld3(s.emit.att[3]), ld3(goal + 4), r, ok);
-    if constexpr (NV >= 15) if (peg_terms) {
-      const V3 rr = ld3(s.emit.att[1]), ll = ld3(s.emit.att[2]), dg = vsub(rr, ll);
-      const double opened = fmin(fmax(sqrt(dg.x * dg.x + dg.y * dg.y + dg.z * dg.z) / 0.1, 0.0), 1.0);      // obs[3]
-      double terms[4];
-      const double rd = peg_dense_reward(cfg, ld3(s.emit.att[0]), opened, ld3(s.emit.att[3]), ld3(s.emit.att[4]), ld3(s.emit.att[5]), ld3(s.emit.att[6]),
-                                         scl(add(rr, ll), 0.5), ld3(goal + 4), obj_init, effort, peg_dense, terms);
-      if (peg_dense) r = rd;
-      if (info) {
-        // SawyerPegV2.evaluate_state (sawyer_peg.py:165-184): tcp_to_obj to the pegGrasp site, obj = the observation's pegHead, TARGET_RADIUS 0.05
-        const double headz = s.emit.att[3][2];
-        info[EARL_INFO_SUCCESS] = terms[1] <= 0.05 ? 1.0 : 0.0;
-        info[EARL_INFO_NEAR_OBJECT] = terms[0] <= 0.03 ? 1.0 : 0.0;
-        info[EARL_INFO_GRASP_SUCCESS] = (terms[0] < 0.02 && opened > 0 && headz - 0.01 > obj_init[2]) ? 1.0 : 0.0;
-        info[EARL_INFO_GRASP_REWARD] = terms[2]; info[EARL_INFO_IN_PLACE_REWARD] = terms[3]; info[EARL_INFO_OBJ_TO_TARGET] = terms[1];
-        info[EARL_INFO_UNSCALED_REWARD] = r; info[7] = 0.0;
-      }
-    }
-    if (reward) *reward = (float)r;
-    if (success) *success = ok ? 1 : 0;
-  }
-  fence();
-}
-
-#ifndef EARL_WAVES_PER_EU
-#define EARL_WAVES_PER_EU 1
-#endif
-// SLICED: the launch's work is a queue of (env group, slice of a.slice env steps) items (sched_claim above) taken by persistent waves, instead of one
-// whole rollout of one group per wave
-template <int NV, int LPE, bool SLICED = false>
-__global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_rollout_kernel(const SawyerArgs a) {
-  static_assert(LPE >= 14, "the observation is written by 14 lanes");
-  constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ Shared<NV> sh[EPW * WPB];
-  stage_blocks(bt, a.col);
-  stage_kb<NV>(bt, a.m, a.col);
-  stage_model(m, a.m);
-  const earl_sawyer_cfg& cfg = a.cfg;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-#ifdef EARL_PHYS_PROF
-  const unsigned long long wave_t0 = __builtin_readcyclecounter();
-#endif
-  Shared<NV>& s = sh[wave * EPW + grp];
-  if constexpr (Lim<NV>::TS < Lim<NV>::NT) {            // the mass-matrix entries between the two trees are never written (K5): zero, once
-    for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
-  }
-  const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
-  const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
-  const float scale = (float)cfg.action_scale;
-  const int G = (n + EPW - 1) / EPW;                     // env groups (one per wave at a time)
-  for (;;) {
-  int group = blockIdx.x * WPB + wave, t_begin = 0, t_end = a.T;
-  if constexpr (SLICED) {
-    group = sched_claim(a.st.sched, G, a.T, lane, (int)(((blockIdx.x * WPB + wave) * 2) % G), t_begin);
-    if (group < 0) break;
-    t_end = t_begin + a.slice < a.T ? t_begin + a.slice : a.T;
-  }
-  const int env_raw = group * EPW + grp;
-  const bool live = env_raw < n;
-  const int env = live ? env_raw : n - 1;
-  load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-  if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
-  fence();
-  int steps = a.st.steps_since_reset ? a.st.steps_since_reset[env] : 0;
-  int sgc = gcf > 0 ? a.st.steps_since_goal_change[env] : 0;
-  RSTART();
-  for (int t = t_begin; t < t_end; ++t) {
-    const float4 act = *reinterpret_cast<const float4*>(a.action + ((size_t)t * n + env) * 4);
-    // set_xyz_action [UPSTREAM]: clip, float32 product with the scale, float64 add, box clip
-    const float cx = fminf(fmaxf(act.x, -1.f), 1.f) * scale, cy = fminf(fmaxf(act.y, -1.f), 1.f) * scale, cz = fminf(fmaxf(act.z, -1.f), 1.f) * scale;
-    if (sub < 3) {                                      // lane k moves coordinate k
-      const float ck = sub == 0 ? cx : (sub == 1 ? cy : cz);
-      s.mocap[sub] = fmin(fmax(s.mocap[sub] + (double)ck, cfg.mocap_low[sub]), cfg.mocap_high[sub]);
-    }
-    fence();
-    const double ctrl[EARL_MAXACT] = {(double)act.w, -(double)act.w, 0, 0};
-    RSTAMP(12);
-    for (int ts = 0; ts < cfg.frame_skip; ++ts) {
-      // The lane's index is passed through an empty asm at the head of every timestep: the per-lane LDS addresses derived from it are then recomputed
-      // inside the timestep (a few integer adds) instead of being hoisted out of the rollout loop, where dozens of them lived across the whole kernel
-      // and went to scratch memory under the register cap -- every reload is a global-memory round trip on the timestep's critical path (scratch per
-      // lane: eight-wave door build 296 -> 212 B, peg 36 -> 0 B).  (Doing the same to the block pointer hides that it is an LDS address: 640 B.)
-      // (Small model only: the peg build, with 512 registers, loses 2 % to the recomputation although its last 36 B of scratch go too.)
-      int sub_ = sub, grp_ = grp;
-      if constexpr (NV <= 10) asm volatile("" : "+v"(sub_));
-      else asm volatile("" : "+v"(grp_));               // (peg: the block's base address was what got spilled, and reloaded six times per timestep)
-      __builtin_assume(sub_ >= 0 && sub_ < LPE);
-      __builtin_assume(grp_ >= 0 && grp_ < EPW);
-      substep<NV, LPE, true>(sh[wave * EPW + grp_], m, bt, a.col, sub_, grp_, mq, ctrl, ts > 0, nullptr, nullptr);   // (every env step starts cold: step() x T == rollout(T))
-    }
-    RSTAMP(13);
-    const size_t row = (size_t)t * n + env;
-    // failure guard (MuJoCo's mj_checkPos / mj_checkVel; metaworld's `except MujocoException` in SawyerXYZEnv.step [UPSTREAM]): an env whose
-    // state went NaN or beyond EARL_BAD_VALUE is rolled back to its last stable state (the rows in HBM) and re-emits its last stable
-    // observation with reward 0; its neighbours in the wavefront never see it (a group only reads its own LDS block)
-    const bool bad_lane = (sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE)) || (sub < 4 && !(fabs(s.bq[sub]) < 2.0));
-    const bool failed = group_any<LPE>(bad_lane, grp);
-    sawyer_emit<NV>(s, m, cfg, sub, live && !failed, a.st.goal + (size_t)env * 7, a.out.obs + row * 14, a.out.reward ? a.out.reward + row : nullptr,
-                    a.out.success ? a.out.success + row : nullptr, a.st.obj_init ? a.st.obj_init + (size_t)env * 6 : nullptr, (double)act.w, nullptr,
-                    (NV >= 15 && a.out.info) ? a.out.info + row * EARL_SAWYER_INFO : nullptr);
-    RSTAMP(14);
-    if (sub == 0 && live && a.out.status) a.out.status[row] = failed ? EARL_STEP_DIVERGED : 0;
-    if (!failed) {
-      // this state is the env's last stable one from here on
-      if (live) {
-        store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-        if (sub < 3) a.st.mocap_pos[(size_t)env * 3 + sub] = s.mocap[sub];
-      }
-      if constexpr (NV >= 15) {
-        // the free body's orientation as load_state would read it back from the row just stored (re-normalised, the same expression): a rollout, its
-        // time slices taken by different waves, and T single-step launches then walk through the same bits (like the minitaur kernel)
-        if (m.ball_dof >= 0) {
-          const double qn = renormalised_quat_entry<NV>(s, sub);
-          fence();
-          if (sub < 4) s.bq[sub] = qn;
-          fence();
-        }
-      }
-    } else {
-      load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-      if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
-      if (live) {
-        const double* prev = t > 0 ? a.out.obs + ((size_t)(t - 1) * n + env) * 14 : (a.st.last_obs ? a.st.last_obs + (size_t)env * 14 : nullptr);
-        if (sub < 14) a.out.obs[row * 14 + sub] = prev ? prev[sub] : __builtin_nan("");
-        if (sub == 0) {
-          if (a.out.reward) a.out.reward[row] = 0.f;
-          if (a.out.success) a.out.success[row] = 0;
-          if (a.st.fail_count) a.st.fail_count[env] += 1;
-        }
-        if (NV >= 15 && a.out.info && sub < EARL_SAWYER_INFO) a.out.info[row * EARL_SAWYER_INFO + sub] = 0.0;
-      }
-    }
-    fence();
-    ++steps;
-    RSTAMP(15);
-    if (sub == 0 && live && a.out.done) a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
-    if (gcf > 0 && ++sgc >= gcf) {
-      // LifelongWrapper.step (lifelong_wrapper.py:36-42): reset_goal() -> get_next_goal(), then the observation is re-read with the new
-      // goal (same simulator state: only the goal block changes); the reward above used the old goal
-      sgc = 0;
-      if (cfg.n_goal_rows > 0 && cfg.goal_table && sub >= 7 && sub < 14 && live) {      // the lanes that wrote the goal block of this row
-        const uint64_t ev = cfg.step_counter + (uint64_t)t;
-        const earl::U4 b = earl::philox4x32_10(earl::U4{0xFFFEu, (uint32_t)(cfg.env_offset + env), (uint32_t)ev, (uint32_t)(ev >> 32)},
-                                               (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
-        int grow = (int)(earl::u01(b.x, b.y) * (double)cfg.n_goal_rows);
-        grow = grow < cfg.n_goal_rows ? grow : cfg.n_goal_rows - 1;
-        const double gv = cfg.goal_table[(size_t)grow * 7 + (sub - 7)];
-        if (NV < 15 && a.out.info && sub >= 11) {
-          // the door's info dict is worked out after the launch from the emitted rows (earl_sawyer_door_info), whose goal block is about to change: this
-          // row's info slots 0-2 carry the target the row's reward was computed with, slot 7 marks it (evaluate_state runs before reset_goal:
-          // lifelong_wrapper.py:30-44; include/earl_physics.h)
-          a.out.info[row * EARL_SAWYER_INFO + (sub - 11)] = a.st.goal[(size_t)env * 7 + (sub - 7)];
-          if (sub == 11) a.out.info[row * EARL_SAWYER_INFO + 7] = 1.0;
-        }
-        a.st.goal[(size_t)env * 7 + (sub - 7)] = gv;
-        a.out.obs[row * 14 + sub] = gv;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next step's observation reads the goal row back through global memory
-    }
-  }
-  if (live) {
-    // (qpos / qvel / mocap_pos were written back after the last stable step)
-    if (t_end == a.T && a.st.last_obs && a.T > 0 && sub < 14) a.st.last_obs[(size_t)env * 14 + sub] = a.out.obs[((size_t)(a.T - 1) * n + env) * 14 + sub];
-    if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
-    if (sub == 0 && gcf > 0) a.st.steps_since_goal_change[env] = sgc;
-  }
-  if constexpr (SLICED) sched_release(a.st.sched, G, group, t_end, lane);
-  else break;
-  }
-#ifdef EARL_PHYS_PROF
-  if (lane == 0 && blockIdx.x * WPB + wave < 4096) g_wave_cycles[blockIdx.x * WPB + wave] = __builtin_readcyclecounter() - wave_t0;
-#endif
-}
-
-// reset (masked) / observe: both end with the kinematics of the current state and the observation
-template <int NV, int LPE>
-__global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const SawyerArgs a) {
-  constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ Shared<NV> sh[EPW * WPB];
-  stage_blocks(bt, a.col);
-  stage_kb<NV>(bt, a.m, a.col);
-  stage_model(m, a.m);
-  const earl_sawyer_cfg& cfg = a.cfg;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE;
-  const int env_raw = (blockIdx.x * WPB + wave) * EPW + grp;
-  const int env = env_raw < cfg.n ? env_raw : cfg.n - 1;
-  Shared<NV>& s = sh[wave * EPW + grp];
-  const bool resetting = !a.observe_only && env_raw < cfg.n && (!a.mask || a.mask[env]);
-  const bool live = env_raw < cfg.n && (a.observe_only || resetting);
-  if constexpr (Lim<NV>::TS < Lim<NV>::NT) {            // (the forward pass below reads the whole mass matrix; K5 leaves the entries between the trees alone)
-    for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;
-  }
-  if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
-  if (resetting) {
-    const uint32_t gid = (uint32_t)(cfg.env_offset + env), c0 = (uint32_t)cfg.counter, c1 = (uint32_t)(cfg.counter >> 32);
-    const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
-    load_state<NV>(s, m, a.reset_qpos, a.reset_qvel, sub);
-    fence();
-    if (cfg.obj_kind == 0) {
-      const earl::U4 b = earl::philox4x32_10(earl::U4{0u, gid, c0, c1}, k0, k1);
-      // np.random.uniform(lo, hi) = lo + (hi - lo) * u   (sawyer_door.py:116-118)
-      double angle;
-      {
-#pragma clang fp contract(off)
-        angle = cfg.obj_init_angle + (cfg.angle_noise[0] + (cfg.angle_noise[1] - cfg.angle_noise[0]) * earl::u01(b.x, b.y));
-      }
-      if (sub == cfg.obj_dof) { s.qp[sub] = angle; s.qv[sub] = 0.0; }
-    } else {
-      // sawyer_peg.py:199-212 / :221-223: xyz ~ U(obj_low, obj_high), redrawn while the xy distance to the hole block is < 0.1;
-      // _set_obj_xyz [UPSTREAM]: qpos[9:12] <- xyz, qvel[9:15] <- 0 (the orientation is left as it is)
-      double px = 0, py = 0, pz = 0;
-      bool wide = false;
-      if (cfg.obj_kind == 2 && cfg.n_wide > 0 && cfg.wide_table) {
-        // wide_init (sawyer_peg.py:200-209): np.random.uniform() < 0.5 keeps the default draw below; otherwise a row of the wide table
-        // (shifted by +0.1 in x: "- np.array([-0.1, 0, 0])") plus U(-0.02, 0.02)^3
-#pragma clang fp contract(off)
-        const earl::U4 c0_ = earl::philox4x32_10(earl::U4{0xFFF0u, gid, c0, c1}, k0, k1);
-        const earl::U4 c1_ = earl::philox4x32_10(earl::U4{0xFFF1u, gid, c0, c1}, k0, k1);
-        wide = !(earl::u01(c0_.x, c0_.y) < 0.5);
-        int wr = (int)(earl::u01(c0_.z, c0_.w) * (double)cfg.n_wide);
-        wr = wr < cfg.n_wide ? wr : cfg.n_wide - 1;
-        const double lo = -cfg.wide_noise, hi = cfg.wide_noise;
-        px = (cfg.wide_table[wr * 3 + 0] + cfg.wide_shift[0]) + (lo + (hi - lo) * earl::u01(c1_.x, c1_.y));
-        py = (cfg.wide_table[wr * 3 + 1] + cfg.wide_shift[1]) + (lo + (hi - lo) * earl::u01(c1_.z, c1_.w));
-        const earl::U4 c2_ = earl::philox4x32_10(earl::U4{0xFFF2u, gid, c0, c1}, k0, k1);
-        pz = (cfg.wide_table[wr * 3 + 2] + cfg.wide_shift[2]) + (lo + (hi - lo) * earl::u01(c2_.x, c2_.y));
-      }
-      for (uint32_t attempt = 0; attempt < 16u && !wide; ++attempt) {
-#pragma clang fp contract(off)
-        const earl::U4 b0 = earl::philox4x32_10(earl::U4{2u * attempt, gid, c0, c1}, k0, k1);
-        const earl::U4 b1 = earl::philox4x32_10(earl::U4{2u * attempt + 1u, gid, c0, c1}, k0, k1);
-        px = cfg.obj_low[0] + (cfg.obj_high[0] - cfg.obj_low[0]) * earl::u01(b0.x, b0.y);
-        py = cfg.obj_low[1] + (cfg.obj_high[1] - cfg.obj_low[1]) * earl::u01(b0.z, b0.w);
-        pz = cfg.obj_low[2] + (cfg.obj_high[2] - cfg.obj_low[2]) * earl::u01(b1.x, b1.y);
-        const double dx = px - cfg.obj_reject_xy[0], dy = py - cfg.obj_reject_xy[1];
-        if (!(sqrt(dx * dx + dy * dy) < cfg.obj_reject_radius)) break;
-      }
-      const int k = sub - cfg.obj_dof;
-      if (k >= 0 && k < 6 && sub < NV) {
-        if (k < 3) s.qp[sub] = k == 0 ? px : (k == 1 ? py : pz);
-        s.qv[sub] = 0.0;
-      }
-    }
-    if (cfg.n_goal_rows > 0 && cfg.goal_table && sub < 7) {
-      // get_next_goal with reset_at_goal (sawyer_peg.py:149-152): np.random.randint(0, rows) -> own Philox draw
-      const earl::U4 b = earl::philox4x32_10(earl::U4{0xFFFFu, gid, c0, c1}, k0, k1);
-      int row = (int)(earl::u01(b.x, b.y) * (double)cfg.n_goal_rows);
-      row = row < cfg.n_goal_rows ? row : cfg.n_goal_rows - 1;
-      a.st.goal[(size_t)env * 7 + sub] = cfg.goal_table[(size_t)row * 7 + sub];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");    // the observation below reads the goal row back through global memory
-    fence();
-    store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-    if (sub < 3) { s.mocap[sub] = cfg.hand_init_pos[sub]; a.st.mocap_pos[(size_t)env * 3 + sub] = cfg.hand_init_pos[sub]; }
-    if (sub == 0 && a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
-    if (sub == 0 && a.st.steps_since_goal_change) a.st.steps_since_goal_change[env] = 0;     // LifelongWrapper.reset (lifelong_wrapper.py:25-28)
-  } else {
-    load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-  }
-  fence();
-  const bool keep = resetting && ((cfg.obj_kind >= 1 && a.st.obj_init) || a.st.last_obs);     // uniform enough: decided per lane, used per lane below
-  if (!a.reset_obs && !__any(keep)) return;
-  // set_state -> sim.forward(): kinematics of the state just written
-  const Q4 mq = ldq(cfg.mocap_quat);                     // as given, NOT normalised (include/earl_physics.h)
-  const double ctrl[EARL_MAXACT] = {0, 0, 0, 0};
-  substep<NV, LPE, false>(s, m, bt, nullptr, sub, grp, mq, ctrl, false, nullptr, nullptr);
-  sawyer_emit<NV>(s, m, cfg, sub, live, a.st.goal + (size_t)env * 7, a.reset_obs ? a.reset_obs + (size_t)env * 14 : nullptr, nullptr, nullptr, nullptr, 0.0,
-                  (resetting && a.st.last_obs) ? a.st.last_obs + (size_t)env * 14 : nullptr);
-  // reset_model keeps obj_init_pos and the pegHead site of the freshly placed peg for the dense reward (sawyer_peg.py:213-215)
-  if (resetting && cfg.obj_kind >= 1 && a.st.obj_init && sub < 6) {
-    double* oi = a.st.obj_init + (size_t)env * 6;
-    oi[sub] = sub < 3 ? s.qp[cfg.obj_dof + sub] : s.emit.att[3][sub - 3];
-  }
-}
-
-#ifndef EARL_PHYS_NOT_MAIN
-// compute_reward / is_successful on given observations (sawyer_door.py:141-177), one lane per row
-__global__ void sawyer_door_reward_kernel(const int n, const double* __restrict__ obs, const earl_sawyer_cfg cfg, float* __restrict__ reward,
-                                          uint8_t* __restrict__ success) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double* o = obs + (size_t)i * 14;
-  double r; bool ok;
-  door_reward(cfg, ld3(o), ld3(o + 4), ld3(o + 11), r, ok);
-  if (reward) reward[i] = (float)r;
-  if (success) success[i] = ok ? 1 : 0;
-}
+#if !defined(EARL_PHYS_VARIANT_MT) && !defined(EARL_PHYS_UNIT_KITCHEN)      // (the minitaur and kitchen units hold no Sawyer kernel)
+#include "physics_env_sawyer.h"
 #endif
 
-#ifndef EARL_PHYS_NOT_MAIN
-// SawyerDoorV2.evaluate_state's info dict (sawyer_door.py:127-139) of given observation rows: every entry is a function of the observation (and of the
-// reward type), so the rollout kernel need not carry it; one lane per row
-__global__ void sawyer_door_info_kernel(const int n, const double* __restrict__ obs, const earl_sawyer_cfg cfg, const uint8_t* __restrict__ status, double* __restrict__ info) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double* o = obs + (size_t)i * 14;
-  double r, row[EARL_SAWYER_INFO]; bool ok;
-  double* mine = info + (size_t)i * EARL_SAWYER_INFO;
-  const V3 target = mine[7] == 1.0 ? ld3(mine) : ld3(o + 11);      // a goal-switch row of a lifelong rollout: the target its reward used (the row's goal block holds the NEW goal)
-  door_reward(cfg, ld3(o), ld3(o + 4), target, r, ok, row);
-  const bool rolled_back = status && status[i] != 0;
-#pragma unroll
-  for (int k = 0; k < EARL_SAWYER_INFO; ++k) info[(size_t)i * EARL_SAWYER_INFO + k] = rolled_back ? 0.0 : row[k];
-}
-#endif
-
-#ifndef EARL_PHYS_NOT_MAIN
-// ------------------------------------------------------------------------------------------------ kitchen env step (include/earl_physics.h)
-// small per-env kernels around the stepper; the numpy glue of the reference (action scaling, observation noise, reward) stays in csrc/glue.hip
-struct KitchenArgs {
-  earl_kitchen_cfg cfg;
-  earl_kitchen_state st;
-  earl_kitchen_out out;
-  const float* action;
-  int n_att;
-};
-// before the stepper: the float32 action promoted to float64 (np.clip keeps float32; the reference's scaling then promotes), the state saved
-__global__ void kitchen_pre_kernel(const KitchenArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.cfg.n * 23) return;
-  const int e = i / 23, j = i % 23;
-  a.st.qpos_bak[i] = a.st.qpos[i];
-  a.st.qvel_bak[i] = a.st.qvel[i];
-  if (j < 9) a.st.action64[e * 9 + j] = (double)a.action[e * 9 + j];
-  if (j < 3) a.st.mocap_bak[e * 3 + j] = a.st.mocap_pos[e * 3 + j];      // (before earl_kitchen_action moves the target)
-  for (int k = j; k < a.n_att * 3; k += 23) a.st.att_bak[(size_t)e * a.n_att * 3 + k] = a.st.att_xpos[(size_t)e * a.n_att * 3 + k];
-}
-// after the stepper: failure guard (roll a diverged env back), the eight task sites gathered for the reward
-__global__ void kitchen_guard_kernel(const KitchenArgs a) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= a.cfg.n) return;
-  bool bad = false;
-  for (int j = 0; j < 23; ++j) bad = bad || !(fabs(a.st.qpos[e * 23 + j]) < EARL_BAD_VALUE) || !(fabs(a.st.qvel[e * 23 + j]) < EARL_BAD_VALUE);
-  if (bad) {
-    // rolled back: state, the mocap target the diverged step was pulled towards, the attachment positions (possibly NaN) the stepper left
-    for (int j = 0; j < 23; ++j) { a.st.qpos[e * 23 + j] = a.st.qpos_bak[e * 23 + j]; a.st.qvel[e * 23 + j] = a.st.qvel_bak[e * 23 + j]; }
-    for (int j = 0; j < 3; ++j) a.st.mocap_pos[e * 3 + j] = a.st.mocap_bak[e * 3 + j];
-    for (int k = 0; k < a.n_att * 3; ++k) a.st.att_xpos[(size_t)e * a.n_att * 3 + k] = a.st.att_bak[(size_t)e * a.n_att * 3 + k];
-    if (a.st.fail_count) a.st.fail_count[e] += 1;
-  }
-  if (a.out.status) a.out.status[e] = bad ? EARL_STEP_DIVERGED : 0;
-  a.st.bad[e] = bad ? 1 : 0;
-  for (int k = 0; k < 8; ++k)
-    for (int c = 0; c < 3; ++c) a.st.sites[(e * 8 + k) * 3 + c] = a.st.att_xpos[(e * a.n_att + a.cfg.site_att[k]) * 3 + c];
-}
-// last: the observation / reward / flags of the step (a rolled-back env returns its last stable observation, reward 0), wrapper bookkeeping
-__global__ void kitchen_finish_kernel(const KitchenArgs a) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= a.cfg.n) return;
-  const bool bad = a.st.bad[e] != 0;
-  for (int k = 0; k < 46; ++k) {
-    const double v = bad ? a.st.last_obs[e * 46 + k] : a.out.obs[e * 46 + k];
-    a.out.obs[e * 46 + k] = v;
-    a.st.last_obs[e * 46 + k] = v;
-    if (k < 9 && !bad) a.st.last_qp_robot[e * 9 + k] = v;          // the newest cached (noisy) robot joint readings
-  }
-  if (bad) { a.out.reward[e] = 0.0; a.out.success[e] = 0; }
-  const int steps = a.st.steps_since_reset[e] + 1;
-  a.st.steps_since_reset[e] = steps;
-  a.out.done[e] = (a.cfg.horizon > 0 && steps >= a.cfg.horizon) ? 1 : 0;
-}
-// The whole env step of earl_kitchen_step, T times, in ONE launch: a wave walks its two envs through action glue -> 40 timesteps -> failure guard ->
-// observation (Philox noise) -> reward -> bookkeeping without ever meeting the other waves.  A launch of the stepper lasts as long as its slowest
-// wave -- the one env with a finger on a fixture -- and between the launches of consecutive env steps every other wave waited for it; here the
-// waves drift apart and only the sum over the rollout counts.  Same arithmetic as the per-step kernels above and csrc/glue.hip (expression by
-// expression: kitchen_action_kernel, kitchen_obs_kernel, uniform_kernel, kitchen_reward_kernel, kitchen_guard / finish): bit-identical outputs.
-struct KitchenRolloutArgs {
-  const void* m;
-  const earl_collision_model* col;
-  earl_kitchen_params p;
-  earl_kitchen_cfg cfg;
-  earl_kitchen_state st;
-  earl_kitchen_out out;          // rows [T, n, ...]
-  const float* action;           // [T, n, 9]
-  int T;
-  int solo;                      // small batches (round 5): 1 = ONE env per wave -- the wave's second 32-lane group shadows the first one's env (same state, same actions, same
-                                 // branches; stores nothing), so the env's chain of timesteps is not held up by a wave-mate on a longer path; 2 = also one wave per workgroup
-                                 // (waves 1-3 leave after the tables are staged): every env has a CU's LDS and issue slots to itself.  Same numbers as the packed launch.
-};
-__device__ __forceinline__ double kit_norm_diff(const double* a, const double* b, const int n) {     // glue.hip norm_diff
-  double d = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const double x = a[i] - b[i];
-    d = fma(x, x, d);
-  }
-  return sqrt(d);
-}
-__global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(const KitchenRolloutArgs a) {
-#pragma clang fp contract(off)
-  constexpr int NV = 23, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ Shared<NV> sh[EPW * WPB];
-  __shared__ earl_kitchen_params kp;
-  stage_blocks(bt, a.col);
-  stage_kb<NV>(bt, a.m, a.col);
-  if (threadIdx.x == 0) kp = a.p;
-  stage_model(m, a.m);                                  // (ends with the workgroup barrier)
-  const earl_kitchen_cfg& cfg = a.cfg;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-  if (a.solo == 2 && wave != 0) return;                 // (after stage_model's barrier, the last one of the kernel)
-  const int env_raw = a.solo == 2 ? (int)blockIdx.x : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
-  const bool live = env_raw < n && (a.solo == 0 || grp == 0);
-  const int env = env_raw < n ? env_raw : n - 1;
-  Shared<NV>& s = sh[wave * EPW + grp];
-  load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
-  for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;      // (entries between different trees are never written, K5)
-  for (int k = sub; k < (int)(sizeof(s.hwst.Hw.v) / sizeof(double)); k += LPE) s.hwst.Hw.v[k] = 0.0;   // (nor the structural zeros of the equality Hessian, K9)
-  if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
-  fence();
-  const Q4 mq = ldq(cfg.mocap_quat_dev);
-  int steps = a.st.steps_since_reset[env];
-  const int kk = sub < 9 ? sub : 8;                     // this lane's action component
-#ifdef EARL_PHYS_PROF
-  const unsigned long long wave_t0 = __builtin_readcyclecounter();
-#endif
-  for (int t = 0; t < a.T; ++t) {
-    const size_t row = (size_t)t * n + env;
-    // ---- KitchenV0.step up to do_simulation (kitchen_action_kernel): mocap target, the nine position targets
-    const double mocap_prev = s.mocap[sub < 3 ? sub : 0];      // the target before this step's action: a diverged step goes back to it
-    {
-      const double x = (double)a.action[row * 9 + kk];
-      const double c = x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x);
-      const double ak = kp.act_mid[kk] + c * kp.act_amp[kk];
-      if (sub < 3) {
-        const double y = s.mocap[sub] + ak * kp.mocap_range[sub];
-        s.mocap[sub] = y < kp.mocap_clip_lower[sub] ? kp.mocap_clip_lower[sub] : (y > kp.mocap_clip_upper[sub] ? kp.mocap_clip_upper[sub] : y);
-      }
-      if (sub < 9) {
-        const double v = ak < kp.vel_bound[sub][0] ? kp.vel_bound[sub][0] : (ak > kp.vel_bound[sub][1] ? kp.vel_bound[sub][1] : ak);
-        const double y = a.st.last_qp_robot[(size_t)env * 9 + sub] + v * kp.step_duration;
-        s.kit.targets[sub] = y < kp.pos_bound[sub][0] ? kp.pos_bound[sub][0] : (y > kp.pos_bound[sub][1] ? kp.pos_bound[sub][1] : y);
-      }
-    }
-    fence();
-    const double ctrl[EARL_MAXACT] = {s.kit.targets[0], s.kit.targets[1], 0, 0};      // do_simulation: ctrl[i] = targets[i] for i < nu = 2
-    if (sub < 3 && live) a.st.mocap_pos[(size_t)env * 3 + sub] = s.mocap[sub];
-    fence();
-    for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);
-    const bool bad_lane = sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE);
-    const bool failed = group_any<LPE>(bad_lane, grp);
-    if (failed) {
-      // rolled back to the last stable state (the rows in HBM); returns its last stable observation, reward 0 (kitchen_guard / finish kernels)
-      load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
-      if (sub < 3) {                                      // ... incl. the mocap target that pulled it there (att_xpos keeps the last stable positions)
-        s.mocap[sub] = mocap_prev;
-        if (live) a.st.mocap_pos[(size_t)env * 3 + sub] = mocap_prev;
-      }
-      if (live) {
-        for (int k = sub; k < 46; k += LPE) a.out.obs[row * 46 + k] = a.st.last_obs[(size_t)env * 46 + k];
-        if (sub == 0) {
-          a.out.reward[row] = 0.0; a.out.success[row] = 0;
-          if (a.st.fail_count) a.st.fail_count[env] += 1;
-        }
-      }
-    } else {
-      if (live) store_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
-      // attachments at the kinematics of the last timestep's start (written only for a step that ended finite); the eight task sites for the reward
-      if (sub < m.n_att && live) {
-        const V3 p = attachment<NV>(s, m, sub);
-        double* o = a.st.att_xpos + ((size_t)env * m.n_att + sub) * 3;
-        o[0] = p.x; o[1] = p.y; o[2] = p.z;
-      }
-      if (sub < 8) {
-        const V3 p = attachment<NV>(s, m, cfg.site_att[sub]);
-        s.kit.sites[sub][0] = p.x; s.kit.sites[sub][1] = p.y; s.kit.sites[sub][2] = p.z;
-      }
-      // Robot.get_obs + KitchenV0._get_obs: 46 draws of U(-1, 1) per env (uniform_kernel: one Philox block = two draws), then kitchen_obs_kernel
-      if (cfg.sensor_noise && sub < 23) {
-        const uint64_t ctr = cfg.counter + (uint64_t)t;
-        const earl::U4 b = earl::philox4x32_10(earl::U4{0x4B00u + (uint32_t)sub, (uint32_t)(cfg.env_offset + env), (uint32_t)ctr, (uint32_t)(ctr >> 32)},
-                                               (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
-        const double lo = -1.0, hi = 1.0;
-        s.kit.noise[2 * sub] = lo + (hi - lo) * earl::u01(b.x, b.y);
-        s.kit.noise[2 * sub + 1] = lo + (hi - lo) * earl::u01(b.z, b.w);
-      }
-      fence();
-      for (int k = sub; k < 46; k += LPE) {
-        double v;
-        if (k < 23) {
-          v = s.qp[k];
-          if (cfg.sensor_noise) v = v + (kp.robot_noise_ratio * kp.pos_noise_amp[k]) * s.kit.noise[k < 9 ? k : k + 9];
-        } else {
-          v = a.st.goal[(size_t)env * 23 + (k - 23)];
-        }
-        s.kit.obs[k] = v;
-        if (live) {
-          a.out.obs[row * 46 + k] = v;
-          a.st.last_obs[(size_t)env * 46 + k] = v;
-          if (k < 9) a.st.last_qp_robot[(size_t)env * 9 + k] = v;
-        }
-      }
-      fence();
-      if (sub == 0 && live) {                           // kitchen.py:141-183 (kitchen_reward_kernel)
-        const double* o = s.kit.obs;
-        const double dist = kit_norm_diff(o + 9, o + 32, 14);
-        double r = -10 * dist;
-        const int start[8] = {9, 11, 13, 15, 17, 19, 20, 22}, len[8] = {2, 2, 2, 2, 2, 1, 2, 1};
-        bool reaching = false;
-        for (int c = 0; c < 8; ++c) {
-          if (kit_norm_diff(o + start[c], o + start[c] + 23, len[c]) < len[c] * 0.01) r += 1;
-          else if (!reaching) {
-            reaching = true;
-            r += -0.5 * kit_norm_diff(s.mocap, s.kit.sites[c], 3);
-          }
-        }
-        a.out.reward[row] = r;
-        a.out.success[row] = dist <= 0.3;
-      }
-    }
-    ++steps;
-    if (sub == 0 && live) {
-      if (a.out.status) a.out.status[row] = failed ? EARL_STEP_DIVERGED : 0;
-      a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");    // the next step reads last_qp_robot (and, after a failure, the state rows) back through global memory
-    fence();
-  }
-#ifdef EARL_PHYS_PROF
-  if (lane == 0 && blockIdx.x * WPB + wave < 4096) g_wave_cycles[blockIdx.x * WPB + wave] = __builtin_readcyclecounter() - wave_t0;
-#endif
-  if (sub == 0 && live) a.st.steps_since_reset[env] = steps;
-}
+#ifdef EARL_PHYS_UNIT_KITCHEN
+#include "physics_env_kitchen.h"
 #endif
 
 #ifdef EARL_PHYS_VARIANT_MT
 #include "minitaur_stepper.h"
-// ------------------------------------------------------------------------------------------------ minitaur env (include/earl_physics.h; physics_mt.hip)
-// One launch = T env steps (or the reset incl. its settle steps) of every env: 32 lanes per env, two envs per wave; lanes 0-7 of a group are also
-// the eight MOTORS (Minitaur.ApplyAction per timestep: velocity-limited command, DC-motor model, overheat protection -- csrc/minitaur_device.h),
-// whose counters and flags live in those lanes' registers between timesteps.  Reference of every expression: oracle/minitaur_oracle.py.
-struct MinitaurArgs {
-  const void* m;
-  const earl_collision_model* col;
-  earl_minitaur_cfg cfg;
-  earl_minitaur_state st;
-  earl_minitaur_out out;
-  const float* action; int T;
-  const uint8_t* mask; double* reset_obs;
-  int solo;                      // as KitchenRolloutArgs::solo
-};
-__device__ __forceinline__ double mt_draw(const earl_minitaur_cfg& cfg, const uint32_t stream, const int env, const uint64_t counter) {
-  const earl::U4 b = earl::philox4x32_10(earl::U4{stream, (uint32_t)(cfg.env_offset + env), (uint32_t)counter, (uint32_t)(counter >> 32)},
-                                         (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32));
-  return earl::u01(b.x, b.y);
-}
-// ARROW: the timestep written on the model's tree (minitaur_stepper.h: substep_mt, the product path) or the generic substep<22> above (kept for
-// comparison: earl_debug_set_minitaur_stepper(0); same numbers to rounding)
-#ifndef EARL_MT_WPB
-#define EARL_MT_WPB 4            // wavefronts per workgroup of the tree-structured kernels
-#endif
-#ifndef EARL_MT_BLOCKS
-#define EARL_MT_BLOCKS 1         // ... and workgroups per CU the register budget is set for (2 = two waves per SIMD, 256 registers each: spills 1.4 KB per lane and runs 1.5 x slower, tools/bench_mt_variant.py)
-#endif
-template <bool ARROW> constexpr int mt_wpb() { return ARROW ? EARL_MT_WPB : Lim<22>::WPB; }
-template <bool RESET, bool ARROW>
-__global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) void minitaur_kernel(const MinitaurArgs a) {
-#pragma clang fp contract(off)
-  constexpr int NV = 22, LPE = 32, EPW = 64 / LPE, WPB = mt_wpb<ARROW>();
-  using SH = std::conditional_t<ARROW, SharedMT, Shared<NV>>;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ SH sh[EPW * WPB];
-  __shared__ std::conditional_t<ARROW, PairTabMT, char> ptab;
-  stage_blocks(bt, a.col);
-  stage_kb<NV>(bt, a.m, a.col);
-  if constexpr (ARROW) stage_pairs_mt(ptab, a.col);
-  stage_model(m, a.m);                                  // (ends with the workgroup barrier)
-  const earl_minitaur_cfg& cfg = a.cfg;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-  if (a.solo == 2 && wave != 0) return;                 // (after stage_model's barrier, the last one of the kernel)
-  const int env_raw = a.solo == 2 ? (int)blockIdx.x : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
-  const bool in_batch = env_raw < n && (a.solo == 0 || grp == 0);
-  const int env = env_raw < n ? env_raw : n - 1;        // idle groups shadow the last env (solo: their wave-mate's) and store nothing
-  const bool live = in_batch && (!RESET || !a.mask || a.mask[env] != 0);      // (a reset leaves the envs outside the mask alone: their groups compute and discard)
-  SH& s = sh[wave * EPW + grp];
-#ifdef EARL_PHYS_PROF
-  const unsigned long long wave_t0 = __builtin_readcyclecounter();
-#endif
-  const double ctrl0[EARL_MAXACT] = {0, 0, 0, 0};
-  auto timestep = [&](const bool warm) {
-    if constexpr (ARROW) {
-      // (the lane index passes through an empty asm: everything derived from it -- the lane's rows of the model tables, its LDS addresses -- is then
-      // read / recomputed inside the timestep instead of being hoisted out of the rollout loop into registers that live across the whole kernel and
-      // end up in scratch memory; see sawyer_rollout_kernel)
-      int sub_ = sub;
-      asm volatile("" : "+v"(sub_));
-      __builtin_assume(sub_ >= 0 && sub_ < LPE);
-      substep_mt<true>(s, m, bt, ptab, sub_, grp, warm, nullptr);
-    }
-    else substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, Q4{1, 0, 0, 0}, ctrl0, warm, nullptr, nullptr);
-  };
-  const int mi = sub < 8 ? sub : 7;                     // this lane's motor
-  const int mdof = cfg.motor_dof[mi];
-  const double mdir = cfg.motor_dir[mi];
-  const double lim = m.dt * cfg.motor_velocity_limit;
-  double voltage, viscous, goal0, goal1;
-  double ms0 = 1.0, ms1 = 1.0, ms2 = 1.0, fmu = -1.0;   // mass factors (root body, upper links, lower links), foot friction: motor_param[2..5]
-  int oh; bool en; double obs_t;                        // motor lanes: overheat counter, enabled flag, observed torque of the newest ApplyAction
-  if constexpr (RESET) {
-    // GoalConditionedMinitaurBulletEnv.reset (minitaur_gym_env.py:476-479, 222-270): goal, [UPSTREAM randomizer] battery voltage and viscous damping, pose
-    int gi = (int)(mt_draw(cfg, 0x4D00u, env, cfg.counter) * (double)cfg.n_goals);
-    gi = gi >= cfg.n_goals ? cfg.n_goals - 1 : gi;
-    goal0 = cfg.goal_table[2 * gi]; goal1 = cfg.goal_table[2 * gi + 1];
-    // MinitaurEnvRandomizer.randomize_env [UPSTREAM] through Minitaur.SetBatteryVoltage / SetMotorViscousDamping / SetBaseMass / SetLegMasses / SetFootFriction
-    // (minitaur.py:468-508); include/earl_physics.h: earl_minitaur_cfg.randomize
-    voltage = (cfg.randomize & 1) ? 14.8 + (16.8 - 14.8) * mt_draw(cfg, 0x4D01u, env, cfg.counter) : 16.0;
-    viscous = (cfg.randomize & 1) ? 0.01 * mt_draw(cfg, 0x4D02u, env, cfg.counter) : 0.0;
-    if (cfg.randomize & 2) {
-      const int root = m.ball_dof + 2;
-      const double leg = cfg.leg_mass * (1.0 + cfg.leg_mass_err[0] + (cfg.leg_mass_err[1] - cfg.leg_mass_err[0]) * mt_draw(cfg, 0x4D04u, env, cfg.counter));
-      const double motor = cfg.motor_mass * (1.0 + cfg.leg_mass_err[0] + (cfg.leg_mass_err[1] - cfg.leg_mass_err[0]) * mt_draw(cfg, 0x4D05u, env, cfg.counter));
-      ms0 = 1.0 + cfg.base_mass_err[0] + (cfg.base_mass_err[1] - cfg.base_mass_err[0]) * mt_draw(cfg, 0x4D03u, env, cfg.counter);
-      ms1 = (motor + leg) / m.mass[root + 1];
-      ms2 = leg / m.mass[root + 2];
-    }
-    if (cfg.randomize & 4) fmu = cfg.foot_friction[0] + (cfg.foot_friction[1] - cfg.foot_friction[0]) * mt_draw(cfg, 0x4D06u, env, cfg.counter);
-    load_state<NV>(s, m, cfg.reset_qpos, a.st.qvel + (size_t)env * NV, sub);
-    if (sub < NV) s.qv[sub] = 0.0;
-    oh = 0; en = true; obs_t = 0.0;
-  } else {
-    goal0 = a.st.goal[(size_t)env * 2]; goal1 = a.st.goal[(size_t)env * 2 + 1];
-    const double* mp = a.st.motor_param + (size_t)env * 6;
-    voltage = mp[0]; viscous = mp[1]; ms0 = mp[2]; ms1 = mp[3]; ms2 = mp[4]; fmu = mp[5];
-    load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-    oh = a.st.overheat[(size_t)env * 8 + mi]; en = a.st.motor_enabled[(size_t)env * 8 + mi] != 0; obs_t = a.st.observed_torque[(size_t)env * 8 + mi];
-  }
-  if (sub < NV) s.xt.ext[sub] = 0.0;
-  if (sub == 0) { s.xt.mscale[0] = ms0; s.xt.mscale[1] = ms1; s.xt.mscale[2] = ms2; s.xt.foot_mu = fmu; s.xt.motor_volt = voltage; s.xt.motor_visc = viscous; }
-  fence();
-  // Minitaur.ApplyAction (minitaur.py:326-390) of motor `mi`: the command clipped to what the velocity limit allows in one timestep, the DC-motor
-  // model, overheat protection, torque x motor direction -> s.xt.ext[dof]
-  auto apply_action = [&](const double cmd) {
-    if (sub < 8) {
-      const double q = s.qp[mdof] * mdir, qd = s.qv[mdof] * mdir;
-      const double c = earl::mt_clipd(cmd, q - lim, q + lim);
-      double act, obs;
-      earl::mt_motor_torque(cfg.motor_kp, cfg.motor_kd, s.xt.motor_volt, s.xt.motor_visc, false, c, q, qd, act, obs);
-      oh = fabs(act) > cfg.overheat_torque ? oh + 1 : 0;
-      if (oh > cfg.overheat_steps) en = false;
-      obs_t = obs;
-      s.xt.ext[mdof] = en ? act * mdir : 0.0;
-    }
-    fence();
-  };
-  // GetObservation + goal (minitaur.py:300-324, minitaur_gym_env.py:541-546): lane k holds entry k of the 32
-  auto observe = [&]() -> double {
-    if (sub < 8) s.kit.obs[16 + sub] = obs_t;
-    fence();
-    double v;
-    if (sub < 8) v = s.qp[mdof] * mdir;
-    else if (sub < 16) v = s.qv[cfg.motor_dof[sub - 8]] * cfg.motor_dir[sub - 8];
-    else if (sub < 24) v = s.kit.obs[sub];
-    else if (sub < 28) v = s.bq[sub == 27 ? 0 : sub - 23];       // Bullet's (x, y, z, w)
-    else if (sub < 30) v = s.qp[sub - 28];
-    else v = sub == 30 ? goal0 : goal1;
-    fence();
-    s.kit.obs[sub] = v;
-    fence();
-    return v;
-  };
-  if constexpr (RESET) {
-    const double half_pi = 3.141592653589793 / 2;
-    for (int ts = 0; ts < cfg.settle_steps; ++ts) {       // minitaur_gym_env.py:265-269
-      apply_action(half_pi);
-      timestep(ts > 0);
-    }
-    const double v = observe();
-    if (live) {
-      store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-      if (a.reset_obs) a.reset_obs[(size_t)env * 32 + sub] = v;
-      if (a.st.last_obs) a.st.last_obs[(size_t)env * 32 + sub] = v;
-      if (sub < 8) {
-        a.st.overheat[(size_t)env * 8 + sub] = oh; a.st.motor_enabled[(size_t)env * 8 + sub] = en ? 1 : 0; a.st.observed_torque[(size_t)env * 8 + sub] = obs_t;
-      }
-      if (sub == 0) {
-        a.st.goal[(size_t)env * 2] = goal0; a.st.goal[(size_t)env * 2 + 1] = goal1;
-        double* mp = a.st.motor_param + (size_t)env * 6;
-        mp[0] = s.xt.motor_volt; mp[1] = s.xt.motor_visc; mp[2] = s.xt.mscale[0]; mp[3] = s.xt.mscale[1]; mp[4] = s.xt.mscale[2]; mp[5] = s.xt.foot_mu;
-        if (a.st.steps_since_reset) a.st.steps_since_reset[env] = 0;
-        if (a.st.steps_since_goal_change) a.st.steps_since_goal_change[env] = 0;
-      }
-    }
-  } else {
-    int steps = a.st.steps_since_reset ? a.st.steps_since_reset[env] : 0;
-    const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
-    int sgc = gcf > 0 ? a.st.steps_since_goal_change[env] : 0;
-    for (int t = 0; t < a.T; ++t) {
-      const size_t row = (size_t)t * n + env;
-      double a64[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) a64[k] = earl::mt_clipd((double)a.action[row * 8 + k], -1.01, 1.01);      // (the front end raises beyond the reference's bound)
-      const double cmd = earl::mt_leg_to_motor(a64, mi);              // ConvertFromLegModel
-      for (int ts = 0; ts < cfg.num_substeps; ++ts) {                  // minitaur_gym_env.py:321-323
-        apply_action(cmd);
-        timestep(ts > 0);
-      }
-      const bool bad_lane = (sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE)) || (sub < 4 && !(fabs(s.bq[sub]) < EARL_BAD_VALUE));
-      const bool failed = group_any<LPE>(bad_lane, grp);
-      ++steps;
-      double v;
-      if (failed) {
-        // rolled back to the env's last stable state (the rows in HBM); the row carries the last stable observation, reward 0
-        load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-        oh = a.st.overheat[(size_t)env * 8 + mi]; en = a.st.motor_enabled[(size_t)env * 8 + mi] != 0; obs_t = a.st.observed_torque[(size_t)env * 8 + mi];
-        v = t > 0 ? a.out.obs[(row - n) * 32 + sub] : (a.st.last_obs ? a.st.last_obs[(size_t)env * 32 + sub] : NAN);
-        if (live) {
-          a.out.obs[row * 32 + sub] = v;
-          if (sub == 0) {
-            a.out.reward[row] = 0.0; a.out.success[row] = 0;
-            if (a.st.fail_count) a.st.fail_count[env] += 1;
-          }
-        }
-        fence();
-      } else {
-        v = observe();
-        {
-          // the orientation quaternion as the next launch's load_state would read it back from the row stored below (re-normalised, the same
-          // expression): a fused rollout and T single-step launches then walk through the same bits
-          const double qn = renormalised_quat_entry<NV>(s, sub);
-          fence();
-          if (live) store_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
-          if (sub < 4) s.bq[sub] = qn;
-          fence();
-        }
-        if (live) {
-          if (sub < 8) {
-            a.st.overheat[(size_t)env * 8 + sub] = oh; a.st.motor_enabled[(size_t)env * 8 + sub] = en ? 1 : 0; a.st.observed_torque[(size_t)env * 8 + sub] = obs_t;
-          }
-          a.out.obs[row * 32 + sub] = v;
-          if (sub == 0) {                                 // _reward (minitaur_gym_env.py:505-521) = compute_reward (:529-535) on this observation; is_successful :495-503
-            const double* o = s.kit.obs;
-            const double xd = o[28] - goal0, yd = o[29] - goal1;
-            double dotp = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) dotp = fma(o[16 + k], o[8 + k], dotp);
-            a.out.reward[row] = cfg.distance_weight * (-fabs(xd) - fabs(yd)) - cfg.energy_weight * (fabs(dotp) * m.dt);
-            a.out.success[row] = sqrt(xd * xd + yd * yd) < cfg.success_radius;
-          }
-        }
-      }
-      if (sub == 0 && live) {
-        if (a.out.status) a.out.status[row] = failed ? EARL_STEP_DIVERGED : 0;
-        a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
-      }
-      if (gcf > 0 && ++sgc >= gcf) {                      // LifelongWrapper.step (lifelong_wrapper.py:36-42): new goal, the observation re-read with it
-        sgc = 0;
-        int gi = (int)(mt_draw(cfg, 0xFFFEu, env, cfg.step_counter + (uint64_t)t) * (double)cfg.n_goals);
-        gi = gi >= cfg.n_goals ? cfg.n_goals - 1 : gi;
-        goal0 = cfg.goal_table[2 * gi]; goal1 = cfg.goal_table[2 * gi + 1];
-        if (live && sub >= 30) a.out.obs[row * 32 + sub] = sub == 30 ? goal0 : goal1;
-        if (live && sub == 0) { a.st.goal[(size_t)env * 2] = goal0; a.st.goal[(size_t)env * 2 + 1] = goal1; }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // a later step of this launch may read this row / the state rows back (failure guard)
-      fence();
-    }
-    if (live) {
-      if (sub == 0) {
-        if (a.st.steps_since_reset) a.st.steps_since_reset[env] = steps;
-        if (gcf > 0) a.st.steps_since_goal_change[env] = sgc;
-      }
-      if (a.st.last_obs && a.T > 0) a.st.last_obs[(size_t)env * 32 + sub] = a.out.obs[((size_t)(a.T - 1) * n + env) * 32 + sub];
-    }
-#ifdef EARL_PHYS_PROF
-    if (lane == 0 && blockIdx.x * WPB + wave < 4096) g_wave_cycles[blockIdx.x * WPB + wave] = __builtin_readcyclecounter() - wave_t0;
-#endif
-  }
-}
+#include "physics_env_minitaur.h"
 #endif   // EARL_PHYS_VARIANT_MT
 
 
@@ -3439,14 +2486,23 @@ template <int NV> constexpr int block_for() { return 64 * Lim<NV>::WPB; }
 // the 64-lanes-per-env instantiations live in physics_l64.hip (argument structs by address: same source, same layout in both units); not exported from the library
 extern "C" __attribute__((visibility("hidden"))) void earl_unit_l64_physics(const void* pargs, int nv, int integrate, void* stream);
 extern "C" __attribute__((visibility("hidden"))) void earl_unit_l64_sawyer_rollout(const void* sawyer_args, int nv, void* stream);
+extern "C" __attribute__((visibility("hidden"))) void earl_unit_kitchen_physics(const void* pargs, int integrate, void* stream);      // physics_kitchen.hip: nv = 23
 namespace {
 
 #ifndef EARL_PHYS_UNIT_L64
 template <int NV, bool INTEGRATE>
 void launch_physics(const PArgs& a, hipStream_t st) {
-  if constexpr (NV > 16) physics_kernel<NV, 32, INTEGRATE><<<grid_for<NV, 32>(a.n), block_for<NV>(), 0, st>>>(a);   // 32 lanes per env: two envs per wave
+  if constexpr (NV > 16) {
+#ifdef EARL_PHYS_UNIT_KITCHEN
+    physics_kernel<NV, 32, INTEGRATE><<<grid_for<NV, 32>(a.n), block_for<NV>(), 0, st>>>(a);   // 32 lanes per env: two envs per wave
+#else
+    earl_unit_kitchen_physics(&a, INTEGRATE ? 1 : 0, st);                                       // (physics_kitchen.hip)
+#endif
+  }
   else if (g_lpe == 64) earl_unit_l64_physics(&a, NV, INTEGRATE ? 1 : 0, st);
+#ifndef EARL_PHYS_UNIT_KITCHEN
   else physics_kernel<NV, 16, INTEGRATE><<<grid_for<NV, 16>(a.n), block_for<NV>(), 0, st>>>(a);
+#endif
 }
 #endif
 
@@ -3528,6 +2584,76 @@ int earl_debug_read_wave_cycles_mt(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_cycles), sizeof(unsigned long long) * 4096) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
 }
 int earl_debug_read_phys_profile_mt(unsigned long long* out, int reset) {          // this unit's own copy of the phase counters (tools/prof_minitaur.py)
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_prof), sizeof(unsigned long long) * 32) != hipSuccess) return EARL_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phys_prof), z, sizeof(z)) != hipSuccess) return EARL_ERR_LAUNCH;
+  }
+  return EARL_OK;
+}
+#endif
+#elif defined(EARL_PHYS_UNIT_KITCHEN)
+// This translation unit is physics_kitchen.hip: the nv = 23 instantiation of the stepper (32 lanes per env), the kitchen env kernels and the kitchen's entry points
+void earl_unit_kitchen_physics(const void* pargs, int integrate, void* stream) {
+  const PArgs& a = *static_cast<const PArgs*>(pargs);
+  if (integrate) launch_physics<23, true>(a, (hipStream_t)stream);
+  else launch_physics<23, false>(a, (hipStream_t)stream);
+}
+int earl_kitchen_step(const void* model, const earl_collision_model* col, const earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
+                      const earl_kitchen_state* st, const float* action, const earl_kitchen_out* out, earl_stream_t stream) {
+  if (!model || !params || !cfg || !st || !action || !out || cfg->n < 0 || cfg->n_att < 10 || cfg->frame_skip < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !st->last_qp_robot || !st->att_xpos || !st->steps_since_reset || !st->last_obs) return EARL_ERR_ARG;
+  if (!st->action64 || !st->ctrl9 || !st->qpos_bak || !st->qvel_bak || !st->sites || !st->bad || !st->mocap_bak || !st->att_bak || (cfg->sensor_noise && !st->noise)) return EARL_ERR_ARG;
+  if (!out->obs || !out->reward || !out->done || !out->success) return EARL_ERR_ARG;
+  for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
+  const int n = cfg->n;
+  if (n == 0) return EARL_OK;
+  const hipStream_t hs = (hipStream_t)stream;
+  if (int rc = check_cone(col, false, hs, "kitchen_step")) return rc;
+  KitchenArgs k{*cfg, *st, *out, action, cfg->n_att};
+  kitchen_pre_kernel<<<(n * 23 + 255) / 256, 256, 0, hs>>>(k);
+  // KitchenV0.step up to do_simulation: mocap target, the nine position targets (csrc/glue.hip)
+  if (int rc = earl_kitchen_action(n, params, st->action64, st->mocap_pos, st->last_qp_robot, st->ctrl9, stream)) return rc;
+  // do_simulation: ctrl[i] = targets[i] for i < nu = 2, frame_skip timesteps (adept_envs/mujoco_env.py:148-157)
+  PArgs a{model, col, n, cfg->frame_skip, st->qpos, st->qvel, st->mocap_pos, cfg->mocap_quat_dev, st->ctrl9, st->att_xpos, nullptr, nullptr, 9, 0};
+  launch_physics<23, true>(a, hs);
+  kitchen_guard_kernel<<<(n + 255) / 256, 256, 0, hs>>>(k);
+  // Robot.get_obs + KitchenV0._get_obs: sensor noise from Philox draws keyed by the global env id
+  if (cfg->sensor_noise)
+    if (int rc = earl_philox_uniform(n, 46, cfg->seed, cfg->counter, cfg->env_offset, 0x4B00u, -1.0, 1.0, st->noise, stream)) return rc;
+  if (int rc = earl_kitchen_obs(n, params, st->qpos, st->goal, cfg->sensor_noise ? st->noise : nullptr, out->obs, stream)) return rc;
+  if (int rc = earl_kitchen_reward(n, out->obs, st->mocap_pos, st->sites, out->reward, out->success, stream)) return rc;
+  kitchen_finish_kernel<<<(n + 255) / 256, 256, 0, hs>>>(k);
+  return launched("kitchen_step");
+}
+
+int earl_kitchen_rollout(const void* model, const earl_collision_model* col, const earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
+                         const earl_kitchen_state* st, const float* action, int32_t T, const earl_kitchen_out* out, earl_stream_t stream) {
+  if (!model || !params || !cfg || !st || !action || !out || cfg->n < 0 || T < 0 || cfg->n_att < 10 || cfg->n_att > 32 || cfg->frame_skip < 0) return EARL_ERR_ARG;
+  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !st->last_qp_robot || !st->att_xpos || !st->steps_since_reset || !st->last_obs) return EARL_ERR_ARG;
+  if (!out->obs || !out->reward || !out->done || !out->success || !cfg->mocap_quat_dev) return EARL_ERR_ARG;
+  for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
+  if (cfg->n == 0 || T == 0) return EARL_OK;
+  if (int rc = check_cone(col, false, (hipStream_t)stream, "kitchen_rollout")) return rc;
+  KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T, solo_mode(cfg->n)};
+  kitchen_rollout_kernel<<<solo_grid(cfg->n, k.solo, Lim<23>::WPB), block_for<23>(), 0, (hipStream_t)stream>>>(k);
+  return launched("kitchen_rollout");
+}
+
+int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (kitchen / minitaur launches of this unit)
+  const int prev = g_solo;
+  if (mode >= -1 && mode <= 2) g_solo = mode;
+  return prev;
+}
+#ifdef EARL_PHYS_PROF
+int earl_debug_set_prof_wave_kitchen(int block, int thread) {     // this unit's copies of the profiling hooks (tools/prof_kitchen_phases.py)
+  const int v[2] = {block, thread};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_sel), v, sizeof(v)) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
+int earl_debug_read_wave_cycles_kitchen(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_cycles), sizeof(unsigned long long) * 4096) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
+int earl_debug_read_phys_profile_kitchen(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phys_prof), sizeof(unsigned long long) * 32) != hipSuccess) return EARL_ERR_LAUNCH;
   if (reset) {
     unsigned long long z[32] = {0};
@@ -3659,52 +2785,8 @@ int earl_sawyer_door_info(const earl_sawyer_cfg* cfg, int32_t n, const double* o
   return launched("sawyer_door_info");
 }
 
-int earl_kitchen_step(const void* model, const earl_collision_model* col, const earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
-                      const earl_kitchen_state* st, const float* action, const earl_kitchen_out* out, earl_stream_t stream) {
-  if (!model || !params || !cfg || !st || !action || !out || cfg->n < 0 || cfg->n_att < 10 || cfg->frame_skip < 0) return EARL_ERR_ARG;
-  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !st->last_qp_robot || !st->att_xpos || !st->steps_since_reset || !st->last_obs) return EARL_ERR_ARG;
-  if (!st->action64 || !st->ctrl9 || !st->qpos_bak || !st->qvel_bak || !st->sites || !st->bad || !st->mocap_bak || !st->att_bak || (cfg->sensor_noise && !st->noise)) return EARL_ERR_ARG;
-  if (!out->obs || !out->reward || !out->done || !out->success) return EARL_ERR_ARG;
-  for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
-  const int n = cfg->n;
-  if (n == 0) return EARL_OK;
-  const hipStream_t hs = (hipStream_t)stream;
-  if (int rc = check_cone(col, false, hs, "kitchen_step")) return rc;
-  KitchenArgs k{*cfg, *st, *out, action, cfg->n_att};
-  kitchen_pre_kernel<<<(n * 23 + 255) / 256, 256, 0, hs>>>(k);
-  // KitchenV0.step up to do_simulation: mocap target, the nine position targets (csrc/glue.hip)
-  if (int rc = earl_kitchen_action(n, params, st->action64, st->mocap_pos, st->last_qp_robot, st->ctrl9, stream)) return rc;
-  // do_simulation: ctrl[i] = targets[i] for i < nu = 2, frame_skip timesteps (adept_envs/mujoco_env.py:148-157)
-  PArgs a{model, col, n, cfg->frame_skip, st->qpos, st->qvel, st->mocap_pos, cfg->mocap_quat_dev, st->ctrl9, st->att_xpos, nullptr, nullptr, 9, 0};
-  launch_physics<23, true>(a, hs);
-  kitchen_guard_kernel<<<(n + 255) / 256, 256, 0, hs>>>(k);
-  // Robot.get_obs + KitchenV0._get_obs: sensor noise from Philox draws keyed by the global env id
-  if (cfg->sensor_noise)
-    if (int rc = earl_philox_uniform(n, 46, cfg->seed, cfg->counter, cfg->env_offset, 0x4B00u, -1.0, 1.0, st->noise, stream)) return rc;
-  if (int rc = earl_kitchen_obs(n, params, st->qpos, st->goal, cfg->sensor_noise ? st->noise : nullptr, out->obs, stream)) return rc;
-  if (int rc = earl_kitchen_reward(n, out->obs, st->mocap_pos, st->sites, out->reward, out->success, stream)) return rc;
-  kitchen_finish_kernel<<<(n + 255) / 256, 256, 0, hs>>>(k);
-  return launched("kitchen_step");
-}
 
-int earl_kitchen_rollout(const void* model, const earl_collision_model* col, const earl_kitchen_params* params, const earl_kitchen_cfg* cfg,
-                         const earl_kitchen_state* st, const float* action, int32_t T, const earl_kitchen_out* out, earl_stream_t stream) {
-  if (!model || !params || !cfg || !st || !action || !out || cfg->n < 0 || T < 0 || cfg->n_att < 10 || cfg->n_att > 32 || cfg->frame_skip < 0) return EARL_ERR_ARG;
-  if (!st->qpos || !st->qvel || !st->mocap_pos || !st->goal || !st->last_qp_robot || !st->att_xpos || !st->steps_since_reset || !st->last_obs) return EARL_ERR_ARG;
-  if (!out->obs || !out->reward || !out->done || !out->success || !cfg->mocap_quat_dev) return EARL_ERR_ARG;
-  for (int k = 0; k < 8; ++k) if (cfg->site_att[k] < 0 || cfg->site_att[k] >= cfg->n_att) return EARL_ERR_ARG;
-  if (cfg->n == 0 || T == 0) return EARL_OK;
-  if (int rc = check_cone(col, false, (hipStream_t)stream, "kitchen_rollout")) return rc;
-  KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T, solo_mode(cfg->n)};
-  kitchen_rollout_kernel<<<solo_grid(cfg->n, k.solo, Lim<23>::WPB), block_for<23>(), 0, (hipStream_t)stream>>>(k);
-  return launched("kitchen_rollout");
-}
 
-int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (kitchen / minitaur launches of this unit)
-  const int prev = g_solo;
-  if (mode >= -1 && mode <= 2) g_solo = mode;
-  return prev;
-}
 int earl_debug_set_physics_lanes(int lanes_per_env) {
   if (lanes_per_env != 16 && lanes_per_env != 64) return EARL_ERR_ARG;
   g_lpe = lanes_per_env;

@@ -14,7 +14,7 @@ if sys.argv[1] == '--build':
   obj = os.path.join(ROOT, 'tools', 'ubench', f'physics_mt_{tag}.o')
   subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + defs + ['-c', '-o', obj, os.path.join(CSRC, 'physics_mt.hip')], check=True)
   subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-shared', '-o', os.path.join(ROOT, 'tools', 'ubench', f'libearl_mt_{tag}.so'), obj] +
-                 [os.path.join(CSRC, f) for f in ('tabletop.o', 'glue.o', 'physics.o', 'physics_w8.o', 'physics_l64.o')], check=True)
+                 [os.path.join(CSRC, f) for f in ('tabletop.o', 'glue.o', 'physics.o', 'physics_w8.o', 'physics_l64.o', 'physics_kitchen.o')], check=True)
   os.remove(obj)
   sys.exit(0)
 sys.path.insert(0, ROOT)

@@ -7,9 +7,9 @@ import numpy as np
 import torch
 from earl_benchmark_amd import _abi
 _abi.LIB_PATH = os.path.join(ROOT, 'tools', 'ubench', 'libearl_physprof.so')
-_abi.SIGNATURES['earl_debug_read_phys_profile'] = [C.c_void_p, C.c_int]
-_abi.SIGNATURES['earl_debug_read_wave_cycles'] = [C.c_void_p]
-_abi.SIGNATURES['earl_debug_set_prof_wave'] = [C.c_int, C.c_int]
+_abi.SIGNATURES['earl_debug_read_phys_profile_kitchen'] = [C.c_void_p, C.c_int]      # (the kitchen's translation unit, csrc/physics_kitchen.hip, has its own counters)
+_abi.SIGNATURES['earl_debug_read_wave_cycles_kitchen'] = [C.c_void_p]
+_abi.SIGNATURES['earl_debug_set_prof_wave_kitchen'] = [C.c_int, C.c_int]
 from earl_benchmark_amd.envs.kitchen import Kitchen
 NAMES = ['K1-2', 'K3', 'C1-2', 'K4', 'K5', 'K6-7', 'C3', 'K8', 'K9b', 'K9a', '-', 'K10']
 nums = [int(x) for x in sys.argv[1:] if x.isdigit()]
@@ -22,14 +22,15 @@ acts = torch.rand(T, n, 9, generator=g, device='cuda') * 2 - 1
 
 def run(block, thread):
   env = Kitchen(num_envs=n, seed=3); env.reset()
-  lib.earl_debug_set_prof_wave(block, thread)
+  lib.earl_debug_set_solo(0)                             # (two envs per wave whatever the batch size: the wave indexing below assumes it)
+  lib.earl_debug_set_prof_wave_kitchen(block, thread)
   torch.cuda.synchronize()
-  lib.earl_debug_read_phys_profile(out, 1)
+  lib.earl_debug_read_phys_profile_kitchen(out, 1)
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record(); env.rollout(acts); e1.record(); torch.cuda.synchronize()
-  lib.earl_debug_read_phys_profile(out, 1)
+  lib.earl_debug_read_phys_profile_kitchen(out, 1)
   wc = (C.c_ulonglong * 4096)()
-  lib.earl_debug_read_wave_cycles(wc)
+  lib.earl_debug_read_wave_cycles_kitchen(wc)
   return e0.elapsed_time(e1), np.array(wc[:(n + 1) // 2], dtype=np.float64) / (T * 40), list(out)
 
 

@@ -15,7 +15,7 @@ NAMES = ['K1-2 joint + world transforms + C0 bounding tests', 'K3 subspace + ine
 if '--build' in sys.argv:
   obj = os.path.join(ROOT, 'tools', 'ubench', 'physics_mt_prof.o')
   subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-DEARL_PHYS_PROF', '-c', '-o', obj, os.path.join(CSRC, 'physics_mt.hip')], check=True)
-  subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-shared', '-o', LIB, obj] + [os.path.join(CSRC, f) for f in ('tabletop.o', 'glue.o', 'physics.o', 'physics_w8.o', 'physics_l64.o')], check=True)
+  subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-shared', '-o', LIB, obj] + [os.path.join(CSRC, f) for f in ('tabletop.o', 'glue.o', 'physics.o', 'physics_w8.o', 'physics_l64.o', 'physics_kitchen.o')], check=True)
   os.remove(obj)
   sys.exit(0)
 sys.path.insert(0, ROOT)

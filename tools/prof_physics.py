@@ -13,7 +13,7 @@ NAMES = ['K1-2 joint + world transforms + C0 bounding tests', 'K3 subspace + ine
 
 
 def build():
-  srcs = [os.path.join(ROOT, 'earl_benchmark_amd', 'csrc', f) for f in ('physics.hip', 'physics_w8.hip', 'physics_mt.hip', 'physics_l64.hip', 'tabletop.hip', 'glue.hip')]
+  srcs = [os.path.join(ROOT, 'earl_benchmark_amd', 'csrc', f) for f in ('physics.hip', 'physics_w8.hip', 'physics_mt.hip', 'physics_l64.hip', 'physics_kitchen.hip', 'tabletop.hip', 'glue.hip')]
   subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS.split() + ['-o', LIB] + srcs, check=True)
 
 
