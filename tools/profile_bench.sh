@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-ARGS="bench.py --no-cpu --no-step-api --no-sawyer --no-kitchen --no-single"   # 20 + 5 launches of 28 episodes each, own actions per episode (the default command = the flags the driver uses)
+ARGS="bench.py --no-cpu --no-step-api --no-sawyer --no-kitchen --no-minitaur --no-single"   # 20 + 5 launches of 28 episodes each, own actions per episode (the default command = the flags the driver uses)
 cd $PWD
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 $ARGS > $OUT/prof_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 $ARGS > $OUT/prof_fetch.log 2>&1
