@@ -88,762 +88,10 @@ __device__ unsigned long long g_wave_cycles[4096];      // duration of every wav
 #define KSTAMP(i) do {} while (0)
 #endif
 
-__device__ __forceinline__ void fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-struct Q4 { double w, x, y, z; };
-struct V3 { double x, y, z; };
-__device__ __forceinline__ Q4 qmul(const Q4& a, const Q4& b) {
-  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
-}
-__device__ __forceinline__ void qmat(const Q4& q, double (&R)[3][3]) {
-  R[0][0] = 1 - 2 * (q.y * q.y + q.z * q.z); R[0][1] = 2 * (q.x * q.y - q.w * q.z); R[0][2] = 2 * (q.x * q.z + q.w * q.y);
-  R[1][0] = 2 * (q.x * q.y + q.w * q.z); R[1][1] = 1 - 2 * (q.x * q.x + q.z * q.z); R[1][2] = 2 * (q.y * q.z - q.w * q.x);
-  R[2][0] = 2 * (q.x * q.z - q.w * q.y); R[2][1] = 2 * (q.y * q.z + q.w * q.x); R[2][2] = 1 - 2 * (q.x * q.x + q.y * q.y);
-}
-__device__ __forceinline__ V3 mulv(const double (&R)[3][3], const V3& v) {
-  return {R[0][0] * v.x + R[0][1] * v.y + R[0][2] * v.z, R[1][0] * v.x + R[1][1] * v.y + R[1][2] * v.z,
-          R[2][0] * v.x + R[2][1] * v.y + R[2][2] * v.z};
-}
-__device__ __forceinline__ V3 mulvT(const double (&R)[3][3], const V3& v) {
-  return {R[0][0] * v.x + R[1][0] * v.y + R[2][0] * v.z, R[0][1] * v.x + R[1][1] * v.y + R[2][1] * v.z,
-          R[0][2] * v.x + R[1][2] * v.y + R[2][2] * v.z};
-}
-__device__ __forceinline__ V3 cross(const V3& a, const V3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ V3 add(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 vsub(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 scl(const V3& a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
-__device__ __forceinline__ Q4 ldq(const double* p) { return {p[0], p[1], p[2], p[3]}; }
-__device__ __forceinline__ double pick3(const V3& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : v.z); }
-// selects of whole vectors, component by component: a `cond ? V3 : V3` on the structs is lowered by hipcc to a select of two
-// stack ADDRESSES and a load through scratch memory (store both, wait, load one) -- seen in the ISA of every phase that had one
-__device__ __forceinline__ V3 selv(const bool c, const V3& a, const V3& b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
-__device__ __forceinline__ Q4 selq(const bool c, const Q4& a, const Q4& b) { return {c ? a.w : b.w, c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
-
-// reciprocal / reciprocal square root: hardware seed + Newton steps (about 1 ulp; not correctly rounded -- fine here)
-__device__ __forceinline__ double rcp_nr(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ double rsq_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  return y;
-}
-
-// the same with TWO Newton steps: the hardware seed is good to 2^-26 or better, so two steps already reach double precision (~1 ulp); used by the
-// factorisations of the bigger models (nv > 10), where fifteen to thirty of these chains stand in a row on the timestep's critical path.  (The
-// door model keeps rsq_nr: its two builds are pinned bit for bit against round 2's outputs.)
-__device__ __forceinline__ double rsq2(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  return y;
-}
-
-// sin / cos for moderate arguments (|x| < ~1e3; joint half-angles are < 3): Cody-Waite reduction by pi/2 and the usual
-// minimax kernels on [-pi/4, pi/4] (the coefficient sets are the classic fdlibm ones), quadrant fix-up by selects
-__device__ __forceinline__ void sincos_mod(double x, double& sn, double& cs) {
-  const double k = rint(x * 6.36619772367581382433e-01);
-  double r = fma(-k, 1.57079632673412561417e+00, x);
-  r = fma(-k, 6.07710050650619224932e-11, r);      // pi/2 = 1.57079632673412561417 + 6.07710050650619224932e-11 (to 1e-27)
-  const double z = r * r;
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
-  const double sr = fma(r * z, ps, r);
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
-  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
-  const int q = (int)k & 3;
-  sn = (q == 0) ? sr : ((q == 1) ? cr : ((q == 2) ? -sr : -cr));
-  cs = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
-}
-
-// compact spatial inertia about the world origin: I10 = {m, h = m c (3), Io xx yy zz xy xz yz}; I [w; v] = [n; f]
-__device__ __forceinline__ void iapply(const double* I, const V3& w, const V3& v, V3& n, V3& f) {
-  const V3 h = ld3(I + 1);
-  n = add(V3{I[4] * w.x + I[7] * w.y + I[8] * w.z, I[7] * w.x + I[5] * w.y + I[9] * w.z, I[8] * w.x + I[9] * w.y + I[6] * w.z}, cross(h, v));
-  f = vsub(scl(v, I[0]), cross(h, w));
-}
-
-// MuJoCo impedance d(r) and (k, b) of a soft constraint row (reference: physics_oracle.kbimp).  (k, b) depend on the row's solref / solimp and the
-// timestep only: the kernels compute them ONCE per launch into the block table (stage_kb) instead of in every timestep -- two reciprocals with their
-// Newton steps, a chain of ~25 dependent operations per row kind
-__device__ __forceinline__ void kb_of(const double* solref, const double* solimp, double dt, double& k, double& b) {
-  const double tc = fmax(solref[0], 2 * dt), dr = solref[1], dw = solimp[1];
-  k = rcp_nr(dw * dw * tc * tc * dr * dr);
-  b = 2.0 * rcp_nr(dw * tc);
-}
-__device__ __forceinline__ void kbimp(const double* solref, const double* solimp, double r, double dt, double& k, double& b, double& d) {   // (all three, per call: the peg build)
-  const double tc = fmax(solref[0], 2 * dt), dr = solref[1];
-  const double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
-  const double x = width > 0 ? fmin(fabs(r) * rcp_nr(width), 1.0) : 1.0;
-  double y;
-  if (power == 1 || d0 == dw) y = x;
-  else if (power == 2) y = x <= mid ? x * x * rcp_nr(mid) : 1 - (1 - x) * (1 - x) * rcp_nr(1 - mid);
-  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
-  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
-  d = d0 + y * (dw - d0);
-  k = rcp_nr(dw * dw * tc * tc * dr * dr);
-  b = 2.0 * rcp_nr(dw * tc);
-}
-__device__ __forceinline__ double imp_of(const double* solimp, double r) {
-  const double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
-  const double x = width > 0 ? fmin(fabs(r) * rcp_nr(width), 1.0) : 1.0;
-  double y;
-  if (power == 1 || d0 == dw) y = x;
-  else if (power == 2) y = x <= mid ? x * x * rcp_nr(mid) : 1 - (1 - x) * (1 - x) * rcp_nr(1 - mid);
-  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
-  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
-  return d0 + y * (dw - d0);
-}
-
-// Symmetric NV x NV matrix in LDS.  Big models (nv > 10) keep the lower triangle packed row-major (row i, column j <= i at
-// i (i + 1) / 2 + j): half the LDS of a square array, and the env block is what limits the number of waves on a CU.  Small models
-// keep the plain square (both triangles written): their workgroup fits four times into a CU either way, and the packed form's index
-// arithmetic cost the door kernel 500 VALU instructions per timestep.
-#ifndef EARL_DOOR_PACKED
-#define EARL_DOOR_PACKED 0
-#endif
-template <int NV>
-struct SymLds {
-  static constexpr bool PACKED = NV > 10 || EARL_DOOR_PACKED;   // (small model: packed only in the eight-waves-per-CU build, where the block size decides)
-  double v[PACKED ? NV * (NV + 1) / 2 : NV * NV];
-  __device__ __forceinline__ double& lo(const int i, const int j) { return v[PACKED ? i * (i + 1) / 2 + j : i * NV + j]; }               // i >= j
-  __device__ __forceinline__ const double& lo(const int i, const int j) const { return v[PACKED ? i * (i + 1) / 2 + j : i * NV + j]; }
-  // entry (i, l) in either order; ltri = l (l + 1) / 2 is kept per lane (i is a compile-time index at every call site)
-  __device__ __forceinline__ double sym(const int i, const int l, const int ltri) const {
-    if constexpr (PACKED) return v[i >= l ? i * (i + 1) / 2 + l : ltri + i];
-    else return v[i * NV + l];
-  }
-  // lane l stores entry (i, l) of its column: the packed form keeps the lower part only, the square form also the mirror image
-  __device__ __forceinline__ void put(const int i, const int l, const double x, const bool mirror) {
-    if constexpr (PACKED) { if (i >= l) v[i * (i + 1) / 2 + l] = x; }
-    else { v[i * NV + l] = x; if (mirror) v[l * NV + i] = x; }
-  }
-  __device__ __forceinline__ double& rowl(const int l, const int ltri, const int j) { return v[PACKED ? ltri + j : l * NV + j]; }        // (l, j), j <= l
-};
-
-// model table type by size: nv <= 16 the compact form, nv = 23 (kitchen) the 24-dof form with the extra joint tables
-template <int NV> struct ModelOf { using T = earl_link_model; };
-template <> struct ModelOf<23> { using T = earl_link_model24; };
-template <> struct ModelOf<22> { using T = earl_link_model24; };   // the minitaur: floating root + 16 hinges
-
-// Static bounds by model size: the door model (nv 10) keeps 8 contact slots and 16 collision blocks, which keeps its workgroup
-// under 40 KB of LDS (four workgroups per CU, one wave per SIMD); the peg model (nv 15) needs 12 / 32.
-template <int NV> struct Lim {
-  static constexpr int MC = NV <= 10 ? 8 : EARL_MAXCON;     // contact slots (runtime cap: earl_collision_model.max_con <= MC)
-  static constexpr int MB = NV <= 10 ? 16 : (NV == 23 ? 64 : (NV == 22 ? 8 : 32));   // collision blocks (<= EARL_MAXBLK; the peg model has 29, the kitchen 56 since round 3: 64-bit near masks, the minitaur 7)
-#ifndef EARL_DOOR_WPB
-#define EARL_DOOR_WPB 1
-#endif
-  static constexpr int WPB = NV <= 10 ? EARL_DOOR_WPB : 4;  // wavefronts per workgroup.  nv 10: 33 KB per single-wave workgroup, four per CU.  nv 15: an
-                                                            // env block is 9.5 KB; a four-wave workgroup (16 envs + the tables once = 163,672 B of the CU's
-                                                            // 163,840) puts one wave on every SIMD where single-wave workgroups would fit two or three.
-                                                            // nv 23: 32 lanes per env, two envs per wave, four waves = 8 envs per workgroup (one per CU)
-#ifndef EARL_DOOR_COOP
-#define EARL_DOOR_COOP 0
-#endif
-  static constexpr bool COOP = (NV <= 10 && EARL_DOOR_COOP) || NV > 16;  // every factorisation shared in LDS instead of per lane in registers: an experiment for
-                                                            // the small model, the only possibility for nv = 23 (a register-resident factor would need 552 VGPRs)
-  static constexpr bool ELLIPTIC = NV <= 16;               // friction cone of the model's MJCF: the Sawyer door and peg (metaworld's basic_scene.xml: cone="elliptic") carry the contact rows
-                                                            // (normal, t1, t2) with MuJoCo's three-zone cost (round 4); the kitchen and the minitaur keep the four pyramid edges.  The host
-                                                            // side refuses tables of the other kind (earl_collision_model.cone, physics/__init__.py)
-  static constexpr bool CAPS = NV <= 10;                    // edge-vs-capsule blocks compiled in (the door model's handle rods; the peg model has none, and
-                                                            // its kernel has no registers to spare: the host side refuses such tables for it)
-  static constexpr int NA = (NV == 15 || NV == 23) ? 9 : NV;              // block split of the factorisations: the peg model's arm (7 hinges + 2 claw slides)
-                                                            // and free peg are separate trees (checked by the host side); the door model
-                                                            // (9 + 1) is factorised densely -- the split did not pay there; the kitchen's arm (7 + 2)
-                                                            // is one tree and each of its 14 fixtures its own (coupled at most in pairs)
-  static constexpr int NT = NV == 23 ? 9 : NV;               // links that can have ancestors / descendants other than themselves: all, except in the kitchen
-                                                            // model, where only the arm's nine do (every fixture is a tree of one link; checked by the host
-                                                            // side).  The masked ancestor / subtree sums run over [0, NT) plus the lane's own link.
-  static constexpr int TS = NV == 15 ? 9 : NT;              // peg model: two trees, links [0, 9) = arm and [9, 15) = the free peg (checked by the host side, like NA): a
-                                                            // lane's ancestor / subtree sums then run over its OWN tree only, 9 terms instead of 15 (the others had weight 0)
-  static constexpr bool KBT = NV != 15;                     // take the rows' (k, b) from the per-launch table (stage_kb) instead of recomputing them in every timestep: door +0.9 %,
-                                                            // kitchen +1.5 %; the peg build (512 registers, one wave per SIMD: the recomputation hides behind LDS latency) -4 %
-  static constexpr bool EXTRAS = NV == 23;                  // dry joint friction, joint springs, force-limited actuators, joint couplings (earl_link_model24), and
-                                                            // the kitchen's structured solver (arm block + fixtures)
-  // the minitaur (nv = 22): ONE tree (a free root body + 16 hinges), no mocap weld, connect constraints (the knee closures), generalized forces
-  // handed in per timestep (the motor model's torques), no joint damping; dense in-LDS factorisations (COOP)
-  static constexpr bool WELD = NV != 22;                    // six weld rows to the mocap body
-  static constexpr bool CONNECT = NV == 22;                 // connect constraints (earl_link_model24.n_con) and the external-force vector s.xt.ext
-  static constexpr bool DAMPED = NV != 22;                  // joint damping (K10's implicit step (M + dt B) a' = M a; without damping a' = a)
-  static constexpr int LPE = NV > 16 ? 32 : 16;             // lanes per env instance (64 = one wavefront per env: measurement switch for nv <= 16)
-  // Models whose first tree is the ARM of these robots -- a serial chain of seven hinges (links 0-6) with the two finger slides (7, 8) on the hand -- and whose
-  // other links are a free body's chain of six (the peg: links 9-14) or single-link trees (the kitchen's fixtures); checked by the host side.  For them the
-  // world frames, velocities, bias accelerations and the two subtree sums (composite inertia, bias force) are SCANS along the chain, done in registers with
-  // DPP row shifts (the arm sits in lanes 0-8 of one 16-lane row) instead of masked sums over every link through LDS: K1-K7 were 20 k cycles per timestep.
-#ifndef EARL_NO_ARMSCAN
-#define EARL_NO_ARMSCAN 0
-#endif
-  static constexpr bool ARMSCAN = (NV == 15 || NV == 23) && !EARL_NO_ARMSCAN;
-#ifndef EARL_NO_PACK
-#define EARL_NO_PACK 0
-#endif
-  static constexpr bool PACK = NV == 23 && !EARL_NO_PACK;   // pair tests: several near blocks per pass (blocks of <= 10 pairs on 32 lanes); results unchanged
-  static constexpr int BODY0 = NV == 15 ? 9 : -100;         // first link of the free body's chain (its six links: three slides, the quaternion link, two rigid ones)
-};
-
-// v = W (j0, j1, j2) for one contact's weight record w (K9).  Pyramid: W = [[w0, w1, w2], [w1, w3, 0], [w2, 0, w4]] (sums over the active edges).  Elliptic cone: the record is
-// (K, m1, m2, q, 1 / mu^2): W = K (1, m1, m2)(1, m1, m2)' + q (I2 - m m' / mu^2) on the tangential block -- the bottom zone is (D, 0, 0, D, .), the top zone all zeros
-// (reference: LinkModel.solve_primal_elliptic)
-template <bool ELL>
-__device__ __forceinline__ void cone_apply(const double* w, const double j0, const double j1, const double j2, double& v0, double& v1, double& v2) {
-  if constexpr (ELL) {
-    const double K = w[0], m1 = w[1], m2 = w[2], q = w[3], i2 = w[4];
-    const double h01 = K * m1, h02 = K * m2, h11 = K * m1 * m1 + q * (1.0 - m1 * m1 * i2), h22 = K * m2 * m2 + q * (1.0 - m2 * m2 * i2), h12 = m1 * m2 * (K - q * i2);
-    v0 = K * j0 + h01 * j1 + h02 * j2; v1 = h01 * j0 + h11 * j1 + h12 * j2; v2 = h02 * j0 + h12 * j1 + h22 * j2;
-  } else {
-    v0 = w[0] * j0 + w[1] * j1 + w[2] * j2; v1 = w[1] * j0 + w[3] * j1; v2 = w[2] * j0 + w[4] * j2;
-  }
-}
-__device__ __forceinline__ int cone_zone(const double r0, const double r1, const double r2, const double mu) {      // 0 top (separating), 1 bottom (sticking), 2 middle (sliding)
-  const double rho = sqrt(r1 * r1 + r2 * r2);
-  return r0 >= mu * rho ? 0 : (rho <= -mu * r0 ? 1 : 2);
-}
-
-// DPP moves within a 16-lane row: lane l reads lane l - K (shr) / l + K (shl) of its row, 0 beyond the row
-template <int CTRL>
-__device__ __forceinline__ double dpp_row(const double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-template <int CTRL> __device__ __forceinline__ V3 dpp_row(const V3& v) { return {dpp_row<CTRL>(v.x), dpp_row<CTRL>(v.y), dpp_row<CTRL>(v.z)}; }
-template <int CTRL> __device__ __forceinline__ Q4 dpp_row(const Q4& q) { return {dpp_row<CTRL>(q.w), dpp_row<CTRL>(q.x), dpp_row<CTRL>(q.y), dpp_row<CTRL>(q.z)}; }
-constexpr int DPP_SHR(int k) { return 0x110 + k; }
-constexpr int DPP_SHL(int k) { return 0x100 + k; }
-// chain membership of a lane: the arm's serial part [0, 6], the free body's chain [BODY0, BODY0 + 5]
-template <int NV> __device__ __forceinline__ bool scan_from_below(const int sub, const int k) {     // lane sub - k is sub's ancestor at distance k
-  return (sub <= 6 && sub >= k) || (Lim<NV>::BODY0 >= 0 && sub >= Lim<NV>::BODY0 + k && sub <= Lim<NV>::BODY0 + 5);
-}
-template <int NV> __device__ __forceinline__ bool scan_from_above(const int sub, const int k) {     // lane sub + k is sub's descendant at distance k
-  return (sub + k <= 6) || (Lim<NV>::BODY0 >= 0 && sub >= Lim<NV>::BODY0 && sub + k <= Lim<NV>::BODY0 + 5);
-}
-// inclusive prefix sums along the chains (ancestors incl. the link itself), then the fingers take the hand's
-template <int NV>
-__device__ __forceinline__ void scan_anc(V3& a, V3& b, const int sub) {
-#define EARL_SCAN_ROUND(K) { const V3 as_ = dpp_row<DPP_SHR(K)>(a), bs_ = dpp_row<DPP_SHR(K)>(b); const bool on = scan_from_below<NV>(sub, K); a = selv(on, add(a, as_), a); b = selv(on, add(b, bs_), b); }
-  EARL_SCAN_ROUND(1) EARL_SCAN_ROUND(2) EARL_SCAN_ROUND(4)
-#undef EARL_SCAN_ROUND
-  const V3 a1 = dpp_row<DPP_SHR(1)>(a), a2 = dpp_row<DPP_SHR(2)>(a), b1 = dpp_row<DPP_SHR(1)>(b), b2 = dpp_row<DPP_SHR(2)>(b);
-  a = selv(sub == 7, add(a1, a), selv(sub == 8, add(a2, a), a));
-  b = selv(sub == 7, add(b1, b), selv(sub == 8, add(b2, b), b));
-}
-// inclusive suffix sums (the link's subtree): the fingers fold into the hand first
-template <int NV, int N>
-__device__ __forceinline__ void scan_desc(double (&x)[N], const int sub) {
-#pragma unroll
-  for (int e = 0; e < N; ++e) {
-    const double f1 = dpp_row<DPP_SHL(1)>(x[e]), f2 = dpp_row<DPP_SHL(2)>(x[e]);
-    x[e] = sub == 6 ? x[e] + f1 + f2 : x[e];
-  }
-#define EARL_SCAN_ROUND(K) { _Pragma("unroll") for (int e = 0; e < N; ++e) { const double xs_ = dpp_row<DPP_SHL(K)>(x[e]); x[e] = scan_from_above<NV>(sub, K) ? x[e] + xs_ : x[e]; } }
-  EARL_SCAN_ROUND(1) EARL_SCAN_ROUND(2) EARL_SCAN_ROUND(4)
-#undef EARL_SCAN_ROUND
-}
-
-// the equality part of the Hessian (M + weld / coupling / drag rows), kept in LDS for the big model: its 23-entry columns would otherwise sit in
-// registers across the whole active-set iteration (the nv = 23 kernel spilled 1.6 KB per lane into scratch)
-template <int NV, bool ON> struct HwStore {};
-template <int NV> struct HwStore<NV, true> { SymLds<NV> Hw; };
-
-// connect constraints (3 rows each) and the generalized forces applied from outside: only in the models that have them (the Sawyer workgroups fill a
-// CU's LDS to the last 200 bytes)
-template <int NV, bool ON> struct ConStore {};
-template <int NV> struct ConStore<NV, true> {
-  double JE[3 * EARL_MAXCONNECT][NV];   // Jacobian rows: Jp(att1) - Jp(att2)
-  double eD[3 * EARL_MAXCONNECT], ear[3 * EARL_MAXCONNECT], eres[3 * EARL_MAXCONNECT];
-  double ext[NV];
-  signed char crow[EARL_MAXCON][2];      // per contact: the (at most two) dofs beyond the root body's six that its Jacobian touches, -1 = none (K9's column update)
-  double motor_volt, motor_visc;         // the env's battery voltage and motor viscous damping (earl_minitaur_state.motor_param[0..1]): read by ApplyAction in every timestep -- kept here, not in two
-                                         // registers that live across the whole rollout (they were the one spill reloaded inside the timestep loop; tools/scratch_in_loops.py)
-  double mscale[3], foot_mu;             // the minitaur's per-env randomisation (earl_minitaur_state.motor_param[2..5]): mass / inertia factor of the root body, the upper links,
-                                         // the lower links; friction of the lower links' contacts (<= 0: the classes' own).  Unused (1, 1, 1, -1) elsewhere.
-};
-
-// Per-env LDS block.  The three phase groups of the union are live at disjoint times.
-template <int NV>
-struct SharedData {
-  static constexpr int MC = Lim<NV>::MC;
-  double qp[NV], qv[NV];
-  double bq[4];                      // orientation of the free body (unit quaternion), identity if the model has none
-  double Xq[NV][4], Xp[NV][3];       // world frame of every link (final buffer of the ancestor doubling)
-  SymLds<NV> M;                      // mass matrix
-  HwStore<NV, (Lim<NV>::EXTRAS || Lim<NV>::CONNECT)> hwst;
-  ConStore<NV, Lim<NV>::CONNECT> xt;
-  union {
-    struct { double Xq1[NV][4], Xp1[NV][3]; } k2;                    // second buffer of the doubling
-    struct { double att[8][3]; } emit;                               // observation epilogue (after the last timestep of an env step)
-    struct { double obs[46], noise[46], sites[8][3], targets[9]; } kit;   // kitchen env step inside the fused rollout (before / after the timesteps)
-    struct {
-      double S[NV][6];                 // motion subspace, world coordinates about the origin: [angular; linear] (every lane keeps its own column in registers)
-      double I10[NV][10];
-      union {
-        struct { double Ic[NV][10], FS[NV][6]; } crb;
-        struct { double V[NV][6], Cc[NV][6], F[NV][6]; } rne;
-      };
-    } dyn;
-    struct {
-      double wD[6], war[6], dl[NV], rl[NV];
-      double CJ[MC][3][NV];            // contact Jacobians: normal, tangent 1, tangent 2
-      union {
-        double ct[MC][8];              // contact records (C2 -> C3): dist, normal (3), point (3), (class, sphere link + 1, box link + 1) packed as class + 64 (ls + 1) + 4096 (lb + 1)
-        double cw[MC][8];              // per-iteration weights of the active pyramid edges (K9)
-      };
-      union {
-        double J6[6][NV];              // weld Jacobian (K8 -> the equality part of K9; dead once every lane holds its Hessian column hw)
-        SymLds<NV> Hc;                 // Hessian of the iteration (written after that); the shared factorisation overwrites it with L
-      };
-      double rc[NV];                   // its right-hand side; then the right-hand side of K10
-    } con;
-  };
-  double mocap[4];                   // mocap position of this env (input of the weld rows; in LDS rather than in six registers that live across the whole rollout)
-  double aprev[(NV + 1) & ~1];       // solution of the previous timestep of this env step: warm start of the active-set iteration (last, even
-                                     // length: the 16-byte alignment of the arrays above decides between ds_read_b128 and two b64)
-};
-// The four env blocks of a wave must not start on the same LDS banks (every broadcast access would conflict 4 ways): the block
-// size is padded to 64 or 192 mod 256 bytes, whichever is nearer
-#ifndef EARL_STRIDE_MOD_10
-#define EARL_STRIDE_MOD_10 -1
-#endif
-#ifndef EARL_STRIDE_MOD_15
-#define EARL_STRIDE_MOD_15 -1
-#endif
-#ifndef EARL_STRIDE_MOD_23
-#define EARL_STRIDE_MOD_23 -1
-#endif
-template <int NV>
-struct Shared : SharedData<NV> {
-  static constexpr int R = (int)(sizeof(SharedData<NV>) % 256);
-  static constexpr int TARGET = NV <= 10 ? (EARL_STRIDE_MOD_10) : (NV <= 15 ? (EARL_STRIDE_MOD_15) : (EARL_STRIDE_MOD_23));   // block size mod 256 (-1: the rule above)
-  static constexpr int PAD = TARGET >= 0 ? (TARGET - R + 256) % 256 : (R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R));
-  char bank_pad[PAD == 0 ? 8 : PAD];
-};
-
-// Cholesky of an SPD matrix held in registers (lower triangle, row-major packed); the diagonal is left INVERTED.
-// NA < NV: the matrix is block diagonal, rows / columns [0, NA) and [NA, NV) -- the arm and the free object are separate
-// trees, so the mass matrix always is, and the Hessian is unless a contact joins the two.  The entries of the off-diagonal block
-// are then never read or written (their registers are dead on that path).
-// (every multiply-subtract is an explicit fma in the same order as chol_coop / solve_lds below: the register-resident and the in-LDS
-// factorisation then produce the same bits, which is what lets earl_sawyer_rollout switch between its two door builds by batch size)
-template <int NV, int NA, bool FAST = false>
-__device__ __forceinline__ void chol_regs(double (&L)[NV * (NV + 1) / 2]) {
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const int p0 = j >= NA ? NA : 0;                  // first column of row j's block
-    double d = L[j * (j + 1) / 2 + j];
-#pragma unroll
-    for (int p = p0; p < j; ++p) d = fma(-L[j * (j + 1) / 2 + p], L[j * (j + 1) / 2 + p], d);
-    const double inv = FAST ? rsq2(d) : rsq_nr(d);       // (FAST: the peg and kitchen models; the door's two builds stay pinned bit for bit)
-    L[j * (j + 1) / 2 + j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < (j < NA ? NA : NV); ++i) {
-      double s = L[i * (i + 1) / 2 + j];
-#pragma unroll
-      for (int p = p0; p < j; ++p) s = fma(-L[i * (i + 1) / 2 + p], L[j * (j + 1) / 2 + p], s);
-      L[i * (i + 1) / 2 + j] = s * inv;
-    }
-  }
-}
-template <int NV, int NA>
-__device__ __forceinline__ void solve_regs(const double (&L)[NV * (NV + 1) / 2], double (&x)[NV]) {   // (L L') x' = x
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double s = x[i];
-#pragma unroll
-    for (int p = (i >= NA ? NA : 0); p < i; ++p) s = fma(-L[i * (i + 1) / 2 + p], x[p], s);
-    x[i] = s * L[i * (i + 1) / 2 + i];
-  }
-#pragma unroll
-  for (int i = NV - 1; i >= 0; --i) {
-    double s = x[i];
-#pragma unroll
-    for (int p = i + 1; p < (i < NA ? NA : NV); ++p) s = fma(-L[p * (p + 1) / 2 + i], x[p], s);
-    x[i] = s * L[i * (i + 1) / 2 + i];
-  }
-}
-// the lower triangle of an LDS matrix (+ a diagonal term) into the packed register form, skipping the off-diagonal block when NA < NV
-template <int NV, int NA, typename D>
-__device__ __forceinline__ void load_tri(double (&L)[NV * (NV + 1) / 2], const SymLds<NV>& H, D diag) {
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-#pragma unroll
-    for (int j = (i >= NA ? NA : 0); j < i; ++j) L[i * (i + 1) / 2 + j] = H.lo(i, j);
-    L[i * (i + 1) / 2 + i] = H.lo(i, i) + diag(i);
-  }
-}
-
-// Dense factorisation for the rare timesteps in which a contact joins the two trees of a big model (gripper plates on the
-// peg): a register-resident 15 x 15 factor would need 240 VGPRs and spills the whole kernel into scratch memory.  Instead the
-// lanes share the work, lane = row, the factor overwrites the lower triangle of H in LDS (diagonal INVERTED): left-looking
-// by columns, every lane recomputes the pivot redundantly from the pivot row it has just read, so a column costs one LDS
-// round trip.  The two triangular solves then read L back from LDS, redundantly per lane (no exchange).
-template <int NV>
-__device__ __forceinline__ void chol_coop(SymLds<NV>& H, const double (&dl)[NV], const int l, const bool isl) {
-  const int ltri = l * (l + 1) / 2;
-  double r[NV];                                        // row l of H, then of L (entries j <= l; the others are never used)
-#pragma unroll
-  for (int j = 0; j < NV; ++j) r[j] = H.sym(j, l, ltri);
-  if (isl) H.rowl(l, ltri, l) = r[l] + dl[l];
-  fence();
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    double sj = H.lo(j, j), si = r[j] + (l == j ? dl[l] : 0.0);
-#pragma unroll
-    for (int p = 0; p < j; ++p) {
-      const double pj = H.lo(j, p);
-      sj = fma(-pj, pj, sj);
-      si = fma(-r[p], pj, si);
-    }
-    const double inv = rsq_nr(sj);
-    r[j] = si * inv;
-    if (isl && l >= j) H.rowl(l, ltri, j) = l == j ? inv : r[j];
-    fence();
-  }
-}
-#ifndef EARL_KITCHEN_DENSE
-#define EARL_KITCHEN_DENSE 0
-#endif
-#if EARL_KITCHEN_DENSE
-#error "EARL_KITCHEN_DENSE: since round 4 the nv = 23 Hessian is stored by its structure only (arm block, fixture rows against the arm, fixture diagonal / pairs); the dense path would read entries nobody writes"
-#endif
-#ifndef EARL_MT_LOOP_SOLVER
-#define EARL_MT_LOOP_SOLVER 0       // nv = 22: the looping in-LDS factorisation / substitution instead of the unrolled ones (measurement switch: 70 k against ~10 k cycles per solve)
-#endif
-// Looping form of the two for the big model (nv = 23): fully unrolled, chol_coop + solve_lds keep two 23-entry vectors in registers and made the
-// kernel spill 1.4 KB per lane into scratch.  Here the lane's row of L stays where it is (in H), the right-hand side / solution stays in LDS
-// (every lane of the env runs the same substitution on the same numbers, so the redundant stores agree), and nothing is indexed dynamically in
-// registers.  Only taken when a contact joins the arm to a fixture.
-template <int NV>
-__device__ __forceinline__ void chol_coop_loop(SymLds<NV>& H, const double (&dl)[NV], const int l, const bool isl) {
-  static_assert(SymLds<NV>::PACKED, "packed storage");
-  const int ltri = l * (l + 1) / 2;
-  if (isl) H.v[ltri + l] += dl[l];
-  fence();
-  for (int j = 0; j < NV; ++j) {
-    const int jtri = j * (j + 1) / 2;
-    double sj = H.v[jtri + j], si = H.v[(l >= j ? ltri : jtri) + j];
-#pragma unroll 4
-    for (int p = 0; p < j; ++p) {
-      const double pj = H.v[jtri + p], rp = H.v[(l >= j ? ltri : jtri) + p];
-      sj = fma(-pj, pj, sj);
-      si = fma(-rp, pj, si);
-    }
-    const double inv = rsq_nr(sj);
-    fence();                                            // every lane has read column j's inputs before the pivot row is overwritten
-    if (isl && l >= j) H.v[ltri + j] = l == j ? inv : si * inv;
-    fence();
-  }
-}
-template <int NV>
-__device__ __forceinline__ void solve_lds_loop(const SymLds<NV>& H, double (&x)[NV]) {   // x in LDS, in place; L as chol_coop_loop leaves it
-  for (int i = 0; i < NV; ++i) {
-    const int itri = i * (i + 1) / 2;
-    double s = x[i];
-#pragma unroll 4
-    for (int p = 0; p < i; ++p) s = fma(-H.v[itri + p], x[p], s);
-    x[i] = s * H.v[itri + i];
-  }
-  for (int i = NV - 1; i >= 0; --i) {
-    double s = x[i];
-#pragma unroll 4
-    for (int p = i + 1; p < NV; ++p) s = fma(-H.v[p * (p + 1) / 2 + i], x[p], s);
-    x[i] = s * H.v[i * (i + 1) / 2 + i];
-  }
-}
-
-// Dense SPD solve for the one-tree model (nv = 22, 32 lanes per env, two envs per wave): H (packed lower triangle in LDS, column l written by lane l)
-// plus dl on the diagonal, right-hand side b_l in this lane -> this lane's entry of the solution.  Lane = row.  The lane keeps ITS ROW of L in
-// registers (r[]); a column of the left-looking factorisation costs one broadcast read of the pivot row from LDS and one cross-lane broadcast of the
-// pivot's inverse root (v_readlane with a constant lane per env group, no LDS round trip); the two substitutions exchange one solution entry per step the
-// same way and read nothing but the lane's own row (forward) / own column (backward, fetched from LDS in one batch).  The unrolled chol_coop +
-// solve_lds pair reads the whole factor back per lane (462 loads the compiler hoists: 1.3 KB of scratch per lane here); their looping forms walk through
-// LDS one dependent round trip at a time (70 k cycles per solve, measured: 57 % of the minitaur's timestep).
-template <int J>
-__device__ __forceinline__ double group_bcast(const double v, const int grp) {      // v of lane J of this lane's 32-lane group
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo0 = __builtin_amdgcn_readlane(lo, J), hi0 = __builtin_amdgcn_readlane(hi, J);
-  const int lo1 = __builtin_amdgcn_readlane(lo, 32 + J), hi1 = __builtin_amdgcn_readlane(hi, 32 + J);
-  return __hiloint2double(grp ? hi1 : hi0, grp ? lo1 : lo0);
-}
-template <int NV, int J>
-struct CholRows {
-  // column J of the factorisation, then the later ones
-  static __device__ __forceinline__ void factor(SymLds<NV>& H, double (&r)[NV], double& inv_l, const int l, const int ltri, const bool isl, const int grp) {
-    // s_l = H[l][J] - sum_{p < J} L[l][p] L[J][p]  (meaningful for l >= J); two partial sums halve the dependent chain
-    double s0 = r[J], s1 = 0.0;
-#pragma unroll
-    for (int p = 0; p < J; ++p) {
-      const double pj = H.v[J * (J + 1) / 2 + p];              // pivot row: the same address in every lane of the env (LDS broadcast)
-      if (p & 1) s1 = fma(-r[p], pj, s1); else s0 = fma(-r[p], pj, s0);
-    }
-    const double sj = s0 + s1;
-    const double inv = group_bcast<J>(rsq_nr(sj), grp);        // 1 / L[J][J], from the pivot's own lane
-    r[J] = sj * inv;                                           // L[l][J] (lane J: L[J][J] itself)
-    inv_l = l == J ? inv : inv_l;
-    if (isl && l > J) H.v[ltri + J] = r[J];                    // my row's entry: lane l's row is the pivot row of column l
-    fence();
-    if constexpr (J + 1 < NV) CholRows<NV, J + 1>::factor(H, r, inv_l, l, ltri, isl, grp);
-  }
-  // forward substitution L y = b: step J hands y_J to the rows below
-  static __device__ __forceinline__ void forward(const double (&r)[NV], const double inv_l, double& t, const int l, const int grp) {
-    const double yj = group_bcast<J>(t * inv_l, grp);
-    t = l > J ? fma(-r[J], yj, t) : (l == J ? yj : t);
-    if constexpr (J + 1 < NV) CholRows<NV, J + 1>::forward(r, inv_l, t, l, grp);
-  }
-  // backward substitution L' x = y: step J (from the last row up) hands x_J to the rows above; c[] = this lane's COLUMN of L
-  static __device__ __forceinline__ void backward(const double (&c)[NV], const double inv_l, double& t, const int l, const int grp) {
-    const double xj = group_bcast<J>(t * inv_l, grp);
-    t = l < J ? fma(-c[J], xj, t) : (l == J ? xj : t);
-    if constexpr (J > 0) CholRows<NV, J - 1>::backward(c, inv_l, t, l, grp);
-  }
-};
-template <int NV>
-__device__ __forceinline__ double chol_solve_rows(SymLds<NV>& H, const double (&dl)[NV], const double b_l, const int l, const bool isl, const int grp) {
-  static_assert(SymLds<NV>::PACKED, "packed storage");
-  const int ltri = l * (l + 1) / 2;
-  double r[NV], inv_l = 1.0;
-#pragma unroll
-  for (int j = 0; j < NV; ++j) r[j] = H.v[(j <= l ? ltri + j : j * (j + 1) / 2 + l)] + (j == l ? dl[l] : 0.0);     // row l of H (symmetric: entry (l, j))
-  fence();
-  CholRows<NV, 0>::factor(H, r, inv_l, l, ltri, isl, grp);
-  double t = b_l;
-  CholRows<NV, 0>::forward(r, inv_l, t, l, grp);
-#pragma unroll
-  for (int k = 0; k < NV; ++k) r[k] = H.v[k * (k + 1) / 2 + (k > l ? l : 0)];     // column l of L: entries (k, l), k > l (the others are not used)
-  CholRows<NV, NV - 1>::backward(r, inv_l, t, l, grp);
-  return t;
-}
-
-// the same on the leading N x N block only (a model whose first N dofs are one tree and whose other dofs are decoupled from it: the kitchen's arm)
-template <int NV, int N>
-__device__ __forceinline__ void chol_coop_lead(SymLds<NV>& H, const double (&dl)[NV], const int l, const bool isl) {
-  const int ltri = l * (l + 1) / 2;
-  const bool mine = isl && l < N;
-  double r[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) r[j] = H.sym(j, l < N ? l : 0, l < N ? ltri : 0);
-  if (mine) H.rowl(l, ltri, l) = r[l] + dl[l];
-  fence();
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    double sj = H.lo(j, j), si = r[j] + (l == j ? dl[l] : 0.0);
-#pragma unroll
-    for (int p = 0; p < j; ++p) {
-      const double pj = H.lo(j, p);
-      sj = fma(-pj, pj, sj);
-      si = fma(-r[p], pj, si);
-    }
-    const double inv = rsq_nr(sj);
-    r[j] = si * inv;
-    if (mine && l >= j) H.rowl(l, ltri, j) = l == j ? inv : r[j];
-    fence();
-  }
-}
-template <int NV, int N>
-__device__ __forceinline__ void solve_lds_lead(const SymLds<NV>& H, double (&x)[NV]) {   // leading block of (L L') x' = x
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    double s = x[i];
-#pragma unroll
-    for (int p = 0; p < i; ++p) s = fma(-H.lo(i, p), x[p], s);
-    x[i] = s * H.lo(i, i);
-  }
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-    double s = x[i];
-#pragma unroll
-    for (int p = i + 1; p < N; ++p) s = fma(-H.lo(p, i), x[p], s);
-    x[i] = s * H.lo(i, i);
-  }
-}
-// the leading N x N block factorised and solved in REGISTERS, redundantly per lane (chol_regs / solve_regs on a copy: same operations in the same order
-// as chol_coop_lead / solve_lds_lead, which cost nine plus eighteen LDS round trips in a row)
-template <int NV, int N, typename D>
-__device__ __forceinline__ void solve_lead_regs(const SymLds<NV>& H, D diag, double (&x)[NV]) {
-  double L[N * (N + 1) / 2], y[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-#pragma unroll
-    for (int j = 0; j < i; ++j) L[i * (i + 1) / 2 + j] = H.lo(i, j);
-    L[i * (i + 1) / 2 + i] = H.lo(i, i) + diag(i);
-    y[i] = x[i];
-  }
-  chol_regs<N, N, true>(L);
-  solve_regs<N, N>(L, y);
-#pragma unroll
-  for (int i = 0; i < N; ++i) x[i] = y[i];
-}
-template <int NV>
-__device__ __forceinline__ void solve_lds(const SymLds<NV>& H, double (&x)[NV]) {   // (L L') x' = x, L in LDS as chol_coop leaves it
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double s = x[i];
-#pragma unroll
-    for (int p = 0; p < i; ++p) s = fma(-H.lo(i, p), x[p], s);
-    x[i] = s * H.lo(i, i);
-  }
-#pragma unroll
-  for (int i = NV - 1; i >= 0; --i) {
-    double s = x[i];
-#pragma unroll
-    for (int p = i + 1; p < NV; ++p) s = fma(-H.lo(p, i), x[p], s);
-    x[i] = s * H.lo(i, i);
-  }
-}
-
-// Two-tree model (arm [0, NA) + free object [NA, NV)) in the timesteps in which a contact JOINS the trees: H = [A B'; B P] is dense.  Instead of the shared
-// in-LDS factorisation of all NV columns (chol_coop + solve_lds: one LDS round trip per column and per substitution step -- 52 k cycles per timestep in the
-// waves whose gripper holds the peg, the waves the launch waits for), eliminate the object's block first, everything in registers and redundantly per lane
-// like the contact-free path: P = Lp Lp', W = B' Lp^-T, S = A - W W' = La La', x_A = S^-1 (b_A - W Lp^-1 b_P), x_P = Lp^-T (Lp^-1 b_P - W' x_A).
-// No exchange between lanes at all: every lane reads the same Hessian from LDS and ends up with the whole solution.
-template <int NV, int NA, typename D>
-__device__ __forceinline__ void solve_schur_regs(const SymLds<NV>& H, D diag, double (&x)[NV]) {
-  constexpr int NP = NV - NA;
-  double Lp[NP * (NP + 1) / 2], yp[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-#pragma unroll
-    for (int j = 0; j < i; ++j) Lp[i * (i + 1) / 2 + j] = H.lo(NA + i, NA + j);
-    Lp[i * (i + 1) / 2 + i] = H.lo(NA + i, NA + i) + diag(NA + i);
-    yp[i] = x[NA + i];
-  }
-  chol_regs<NP, NP, true>(Lp);
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {                        // yp = Lp^-1 b_P
-    double t = yp[i];
-#pragma unroll
-    for (int p = 0; p < i; ++p) t = fma(-Lp[i * (i + 1) / 2 + p], yp[p], t);
-    yp[i] = t * Lp[i * (i + 1) / 2 + i];
-  }
-  double W[NA][NP];                                     // W[i][j] = (B[j][i] - sum_{p < j} W[i][p] Lp[j][p]) / Lp[j][j]
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-      double t = H.lo(NA + j, i);
-#pragma unroll
-      for (int p = 0; p < j; ++p) t = fma(-W[i][p], Lp[j * (j + 1) / 2 + p], t);
-      W[i][j] = t * Lp[j * (j + 1) / 2 + j];
-    }
-  }
-  double La[NA * (NA + 1) / 2], xa[NA];
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-#pragma unroll
-    for (int c = 0; c <= i; ++c) {
-      double t = H.lo(i, c) + (c == i ? diag(i) : 0.0);
-#pragma unroll
-      for (int j = 0; j < NP; ++j) t = fma(-W[i][j], W[c][j], t);
-      La[i * (i + 1) / 2 + c] = t;
-    }
-    double t = x[i];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) t = fma(-W[i][j], yp[j], t);
-    xa[i] = t;
-  }
-  chol_regs<NA, NA, true>(La);
-  solve_regs<NA, NA>(La, xa);
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {                        // z = yp - W' x_A
-    double t = yp[j];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) t = fma(-W[i][j], xa[i], t);
-    yp[j] = t;
-  }
-#pragma unroll
-  for (int j = NP - 1; j >= 0; --j) {                   // x_P = Lp^-T z
-    double t = yp[j];
-#pragma unroll
-    for (int p = j + 1; p < NP; ++p) t = fma(-Lp[p * (p + 1) / 2 + j], yp[p], t);
-    yp[j] = t * Lp[j * (j + 1) / 2 + j];
-  }
-#pragma unroll
-  for (int i = 0; i < NA; ++i) x[i] = xa[i];
-#pragma unroll
-  for (int j = 0; j < NP; ++j) x[NA + j] = yp[j];
-}
-
-// block table of the collision model (bounding tests), staged once per workgroup
-template <int MB, bool KB>
-struct BlkTable {
-  int n_blk, max_con;
-  int begin[MB], end[MB], box[MB], link[MB], box_link[MB], cap[MB];
-  double center[MB][3], reach[MB], box_pos[MB][3], box_quat[MB][4], box_half[MB][3];
-  // second bounding test (include/earl_physics.h blk_obb_*).  Compiled in for the small model only: the door's random-action workload has 2.4 near
-  // blocks per env by the sphere test and 0.5 by both (35.1 -> 36.1 M env-steps/s); the peg lies on the table (that block is always near) and the
-  // kitchen's hands are far from the fixtures, so there the extra test only costs (peg -3.5 %, kitchen 0).  Results do not depend on it.
-  static constexpr bool SAT = MB <= 16;
-  double obb_center[SAT ? MB : 1][3], obb_half[SAT ? MB : 1][3];
-  double cls_mu[EARL_MAXCLS], cls_margin[EARL_MAXCLS], cls_invw[EARL_MAXCLS], cls_solref[EARL_MAXCLS][2], cls_solimp[EARL_MAXCLS][5];   // contact classes
-  // (k, b) of every row kind, once per launch (stage_kb): weld, joint limit / dry friction of dof l, contact class, joint coupling; the dry-friction
-  // rows' regulariser (their residual is always 0, so the whole of it is a constant)
-  // (not in the peg build, Lim<15>::KBT: even unused, the 976 B in front of the env blocks cost it 4 %)
-  double kb_weld[2], kb_lim[KB ? 24 : 1][2], kb_cls[KB ? EARL_MAXCLS : 1][2], kb_jeq[KB ? 8 : 1][2], fr_D[KB ? 24 : 1];
-};
-template <int MB, bool KB>
-__device__ __forceinline__ void stage_blocks(BlkTable<MB, KB>& t, const earl_collision_model* __restrict__ col) {
-  const int i = threadIdx.x;                           // n_blk <= 32 < one wavefront
-  // (bounds are clamped here; the Python / C front ends refuse models that exceed them)
-  const int nb = col ? (col->n_blk < MB ? col->n_blk : MB) : 0;
-  if (i == 0) { t.n_blk = nb; t.max_con = col ? col->max_con : 0; }
-  if (col && i < EARL_MAXCLS) {
-    t.cls_mu[i] = col->cls_mu[i]; t.cls_margin[i] = col->cls_margin[i]; t.cls_invw[i] = col->cls_invw[i];
-    t.cls_solref[i][0] = col->cls_solref[i][0]; t.cls_solref[i][1] = col->cls_solref[i][1];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) t.cls_solimp[i][k] = col->cls_solimp[i][k];
-  }
-  if (i < nb) {
-    const int b = col->blk_box[i];
-    t.begin[i] = col->blk_begin[i]; t.end[i] = col->blk_end[i]; t.box[i] = b; t.link[i] = col->blk_link[i]; t.cap[i] = col->blk_cap[i];
-    t.box_link[i] = col->box_link[b]; t.reach[i] = col->blk_reach[i];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      t.center[i][k] = col->blk_center[i][k]; t.box_pos[i][k] = col->box_pos[b][k]; t.box_half[i][k] = col->box_half[b][k];
-      if constexpr (BlkTable<MB, KB>::SAT) { t.obb_center[i][k] = col->blk_obb_center[i][k]; t.obb_half[i][k] = col->blk_obb_half[i][k]; }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t.box_quat[i][k] = col->box_quat[b][k];
-  }
-}
-
-template <int NV, int MB, bool KB>
-__device__ __forceinline__ void stage_kb(BlkTable<MB, KB>& t, const void* __restrict__ model, const earl_collision_model* __restrict__ col) {
-  if constexpr (!Lim<NV>::KBT) return;
-  const typename ModelOf<NV>::T* mg = reinterpret_cast<const typename ModelOf<NV>::T*>(model);     // (global memory: the LDS copy is not complete yet)
-  const int i = threadIdx.x;
-  const double dt = mg->dt;
-  if (i < NV) {
-    kb_of(mg->jsolref[i], mg->jsolimp[i], dt, t.kb_lim[i][0], t.kb_lim[i][1]);
-    if constexpr (Lim<NV>::EXTRAS) {
-      const double dd = imp_of(mg->jsolimp[i], 0.0);
-      t.fr_D[i] = rcp_nr(fmax((1 - dd) * mg->dof_invweight[i] * rcp_nr(dd), 1e-15));
-    }
-  }
-  if (i == 32) kb_of(mg->weld_solref, mg->weld_solimp, dt, t.kb_weld[0], t.kb_weld[1]);
-  if (col && i >= 33 && i < 33 + EARL_MAXCLS) kb_of(col->cls_solref[i - 33], col->cls_solimp[i - 33], dt, t.kb_cls[i - 33][0], t.kb_cls[i - 33][1]);
-  if constexpr (Lim<NV>::EXTRAS) {
-    if (i >= 56 && i < 64 && i - 56 < mg->n_jeq) kb_of(mg->jeq_solref[i - 56], mg->jeq_solimp[i - 56], dt, t.kb_jeq[i - 56][0], t.kb_jeq[i - 56][1]);
-  }
-}
+#include "physics_math.h"
+#include "physics_lds.h"
+#include "physics_scan.h"
+#include "physics_solve.h"
 
 template <int LPE> __device__ __forceinline__ bool group_any(const bool pred, const int grp);
 
