@@ -258,7 +258,8 @@ static int mpr_box_cylinder(V3 pb, double Rb[3][3], V3 h, V3 c, V3 a, double hl,
 }
 /* diagnostics (single-threaded use): the contacts of the most recent timestep -- pair index, distance, normal, position (tools/door_contact_ablation.py --trace) */
 static double g_dbg_contacts[EARL_MAXCON][8];
-static int g_dbg_ncon = 0;
+static int g_dbg_ncon = 0, g_dbg_on = 0;
+void oracle_debug_trace(int on) { g_dbg_on = on; }      /* off by default: the buffer is shared, a multi-threaded batch must not write it */
 int oracle_debug_contacts(double* out) { for (int c = 0; c < g_dbg_ncon; ++c) for (int k = 0; k < 8; ++k) out[c * 8 + k] = g_dbg_contacts[c][k]; return g_dbg_ncon; }
 /* test hook: the narrow phase alone.  box: centre pb[3], rotation Rb[9] (row major, columns = box axes in the world), half h[3]; cylinder: centre c[3], unit axis a[3] */
 int oracle_mpr_box_cylinder(const double* pb, const double* Rb9, const double* h, const double* c, const double* a, double hl, double r, double margin, double* out7) {
@@ -580,7 +581,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
         n = mulv(Rb, nl);
         p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
         }
-        if (ncon < EARL_MAXCON) { double* dc_ = g_dbg_contacts[ncon]; dc_[0] = pi; dc_[1] = dist; dc_[2] = n.x; dc_[3] = n.y; dc_[4] = n.z; dc_[5] = p.x; dc_[6] = p.y; dc_[7] = p.z; }
+        if (g_dbg_on && ncon < EARL_MAXCON) { double* dc_ = g_dbg_contacts[ncon]; dc_[0] = pi; dc_[1] = dist; dc_[2] = n.x; dc_[3] = n.y; dc_[4] = n.z; dc_[5] = p.x; dc_[6] = p.y; dc_[7] = p.z; }
         /* tangents: n x (the coordinate axis least aligned with n) */
         const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
         const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
@@ -634,7 +635,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       }
     }
     o->ncon = ncon;
-    g_dbg_ncon = ncon;
+    if (g_dbg_on) g_dbg_ncon = ncon;
   }
   /* primal active-set Newton (LinkModel.solve_primal; elliptic models: LinkModel.solve_primal_elliptic) */
   int act[NROWMAX];
