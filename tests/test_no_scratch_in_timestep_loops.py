@@ -1,0 +1,29 @@
+""""no scratch inside any timestep loop".  tools/scratch_in_loops.py compiles the stepper units to gfx950 assembly (device only, no GPU needed) and counts the
+scratch_load / scratch_store instructions of every rollout kernel inside its timestep loop; this test pins the count at zero and the committed report to what the tool prints."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+
+@pytest.mark.skipif(shutil.which('/opt/rocm/bin/hipcc') is None, reason='needs hipcc (cross-compiles without a GPU)')
+def test_timestep_loops_hold_no_scratch_instruction():
+  r = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'scratch_in_loops.py')], capture_output=True, text=True, timeout=1500)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+  assert len(lines) >= 20                                               # every stepper kernel of the five units is listed
+  names = ' '.join(lines)
+  for k in ('sawyer_rollout_kernel<10, 16, false>', 'sawyer_rollout_kernel<15, 16, true>', 'kitchen_rollout_kernel', 'minitaur_kernel<false, true>'):
+    assert k in names, k
+  for ln in lines:
+    if 'timestep loop' in ln:
+      assert ln.rstrip().endswith(': 0'), ln                             # scratch instructions inside the timestep loop
+    else:
+      assert 'no scratch at all' in ln or 'no inner loop' in ln or 'no loop' in ln, ln
+  # the kitchen and door kernels spill nothing at all
+  assert any('kitchen_rollout_kernel' in ln and 'no scratch at all' in ln for ln in lines)
+  assert any(ln.startswith('physics.hip') and 'sawyer_rollout_kernel<10, 16, false>' in ln and 'no scratch at all' in ln for ln in lines)      # (the four-workgroups-per-CU door build; the eight-wave one spills outside the loop)

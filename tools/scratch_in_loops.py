@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""VERDICT r04 item 4 "no scratch inside any timestep loop": where do the rollout kernels' scratch (spill) instructions sit?  Compiles csrc/physics.hip, csrc/physics_kitchen.hip and csrc/physics_mt.hip to
+"""VERDICT r04 item 4 "no scratch inside any timestep loop": where do the rollout kernels' scratch (spill) instructions sit?  Compiles the five stepper units (csrc/physics.hip, physics_kitchen.hip, physics_mt.hip, physics_w8.hip, physics_l64.hip) to
 gfx950 assembly (device only), finds every loop of each rollout kernel (a backward branch to a label), nests them by extent and reports the scratch_load / scratch_store count of the
 kernel, of its env-step loop (the largest loop) and of its TIMESTEP loop (the largest loop strictly inside the env-step loop that holds more than a third of it: the stepper's body).
   python tools/scratch_in_loops.py > profiles/r05_scratch_report.txt          (no GPU needed; ~2 min)"""
@@ -26,7 +26,7 @@ def loops_of(body):
 
 
 def main():
-  for unit in ('physics.hip', 'physics_kitchen.hip', 'physics_mt.hip'):
+  for unit in ('physics.hip', 'physics_kitchen.hip', 'physics_mt.hip', 'physics_w8.hip', 'physics_l64.hip'):
     with tempfile.NamedTemporaryFile(suffix='.s') as f:
       subprocess.run(['/opt/rocm/bin/hipcc'] + FLAGS + ['-o', f.name, os.path.join(CSRC, unit)], check=True, stderr=subprocess.DEVNULL)
       lines = open(f.name).read().split('\n')
