@@ -27,6 +27,41 @@ inline void for_each_env(int n, F&& f) {
   for (int i = 0; i < n; ++i) f(i);
 }
 
+// The fused rollout on the host: a TILE of kTile consecutive envs keeps its state in a small array (the kernels keep it in registers) and walks the T steps time-major,
+// so that every step writes kTile consecutive rows of each output -- the kernels' row order, contiguous in memory -- instead of one row per env per step scattered
+// T * n * 66 bytes apart (rollout_body's loop order, made for a lane that owns one env).  Same wrapped_step, same counters: the same bits.
+constexpr int kTile = 64;
+template <int NOBJ, bool GENERAL>
+void rollout_tiles(const KArgs& a) {
+  const int n = a.cfg.n, tiles = (n + kTile - 1) / kTile;
+#pragma omp parallel for schedule(static) if (tiles >= 4)
+  for (int tile = 0; tile < tiles; ++tile) {
+    const int i0 = tile * kTile, m = n - i0 < kTile ? n - i0 : kTile;
+    Lane<NOBJ> L[kTile];
+    float g[kTile][Dims<NOBJ>::NG];
+    for (int k = 0; k < m; ++k) {
+      load_lane<NOBJ>(a, i0 + k, L[k]);
+      load_goal<NOBJ>(a.st.goal_table, L[k].goal_idx, g[k]);
+    }
+    for (int t = 0; t < a.T; ++t) {
+      const float* ap = a.act + ((size_t)t * n + i0) * 3;
+      const size_t row0 = (size_t)t * n + i0;
+      for (int k = 0; k < m; ++k) {
+        float o[Dims<NOBJ>::NOBS];
+        float reward;
+        bool done, succ;
+        wrapped_step<NOBJ, GENERAL>(a, i0 + k, a.cfg.counter + (uint64_t)t, L[k], g[k], ap[3 * k], ap[3 * k + 1], ap[3 * k + 2], o, reward, done, succ);
+        const size_t row = row0 + k;
+        if (a.out.obs) store_obs<NOBJ>(a.out.obs + row * Dims<NOBJ>::NOBS, o);
+        if (a.out.reward) a.out.reward[row] = reward;
+        if (a.out.done) a.out.done[row] = done;
+        if (a.out.success) a.out.success[row] = succ;
+      }
+    }
+    for (int k = 0; k < m; ++k) store_lane<NOBJ>(a, i0 + k, L[k]);
+  }
+}
+
 template <int NOBJ>
 int do_step(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, const float* act, const int32_t* ngi, const earl_tabletop_out* out) {
   if (int rc = check_common(cfg, st, NOBJ)) return rc;
@@ -60,8 +95,8 @@ int do_rollout(const earl_tabletop_cfg* cfg, const earl_tabletop_state* st, int3
   }
   if (T == 0) return EARL_OK;
   const KArgs a{c2, *st, *out, act, nullptr, nullptr, nullptr, T, thresholds()};
-  if (cfg->goal_change_frequency > 0 || cfg->auto_reset) for_each_env(cfg->n, [&](int i) { rollout_body<NOBJ, true>(a, i); });
-  else for_each_env(cfg->n, [&](int i) { rollout_body<NOBJ, false>(a, i); });
+  if (cfg->goal_change_frequency > 0 || cfg->auto_reset) rollout_tiles<NOBJ, true>(a);
+  else rollout_tiles<NOBJ, false>(a);
   return EARL_OK;
 }
 
