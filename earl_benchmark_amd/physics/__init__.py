@@ -269,6 +269,10 @@ class DeviceModel:
     check_layouts(self.lib)
     self.struct, self.tables = load_link_model(name)
     self.col_struct = load_collision_model(self.tables) if contacts else None
+    if self.col_struct is not None and (any(self.col_struct.pair_kind[i] == 2 for i in range(self.col_struct.n_pair)) or any(self.col_struct.cls_mu_tor[:])):
+      # include/earl_physics.h: cylinder-vs-box pairs (pair_kind 2) and torsional rows (cls_mu_tor) exist in the C restatement's experimental tables only;
+      # the kernels would read a cylinder record as a sphere of the cylinder's radius
+      raise _abi.EarlHipError(f'{name}: this collision table uses cylinder pairs / torsional rows, which the HIP kernels do not implement (experimental tables of the restatement)')
     if not contacts:
       _fill(self.struct.drag_G, np.zeros(self.struct.nv))
     self.nv, self.n_att, self.n_act, self.nq = self.struct.nv, self.struct.n_att, self.struct.n_act, self.struct.nq

@@ -81,3 +81,17 @@ def test_the_ablation_numbers_are_what_profiles_holds():
       np.testing.assert_allclose(got[d]['obj_rms_mm'], want[v][d]['obj_rms_mm'], atol=0.35)
       assert got[d]['reached'] == want[v][d]['reached']
   assert want['chains']['reverse']['reached'] == 1 and all(want[v]['reverse']['reached'] == 0 for v in ('cyl', 'cyl+split', 'cyl+split+tor'))
+
+
+def test_the_product_refuses_the_experimental_tables():
+  """the kernels implement neither cylinder pairs nor torsional rows: the device-side loader must refuse such tables rather than read a cylinder as a sphere (no GPU needed:
+  the check precedes every device call)"""
+  from earl_benchmark_amd import _abi, physics
+  _, tables = physics.load_link_model('sawyer_door_cyl_split_tor')
+  col = physics.load_collision_model(tables)
+  assert any(col.pair_kind[i] == 2 for i in range(col.n_pair)) and any(col.cls_mu_tor[:])
+  with pytest.raises(_abi.EarlHipError, match='cylinder pairs'):
+    physics.DeviceModel('sawyer_door_cyl_split_tor', device='cpu')
+  _, shipped = physics.load_link_model('sawyer_door')
+  c0 = physics.load_collision_model(shipped)
+  assert not any(c0.pair_kind[i] == 2 for i in range(c0.n_pair)) and not any(c0.cls_mu_tor[:])
