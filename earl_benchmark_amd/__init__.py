@@ -10,7 +10,8 @@ Public surface mirrors the reference's loader (reference: earl_benchmark/__init_
 
 Extra keyword arguments of this build: `num_envs` (batch of independent env instances stepped by one HIP
 kernel launch), `device`, `seed`, `env_offset` (global id of env 0 when sharding over GPUs), `auto_reset`.
-Environment arithmetic runs only in the HIP library (csrc/); there is no CPU fallback.
+Environment arithmetic runs only in this build's own native code (csrc/): the HIP library on MI355X; there is no CPU fallback.  (The tabletop's per-env
+functions also exist as a host build, csrc/libearl_host.so -- used only when a caller asks for device='cpu'.)
 """
 import os
 

@@ -5,8 +5,9 @@ constructor arguments, same method names (`reset`, `step`, `reset_goal`, `get_ne
 `compute_reward`, `is_successful`, `get_obs`/`_get_obs`, `set_state`), same observation layout -- but
 every call acts on `num_envs` independent env instances whose state lives in HBM as torch tensors,
 and all arithmetic runs in the hand-written HIP kernels behind include/earl_tabletop.h
-(csrc/tabletop.hip).  There is no CPU path: constructing an env without the HIP library or without a
-GPU raises.
+(csrc/tabletop.hip).  There is no CPU FALLBACK: constructing an env on the default device without the HIP library
+or without a GPU raises.  device='cpu', asked for by name, runs the same per-env functions compiled for the host
+(csrc/libearl_host.so, the `_cpu` entry points of include/earl_tabletop.h; BASELINE configs[0]).
 
 Batched conventions: observations `[N, 12] float32`, rewards `[N] float32`, done / success `[N] bool`
 torch tensors on the env's device.  With `num_envs == 1` and `scalar_api=True` the env returns what
