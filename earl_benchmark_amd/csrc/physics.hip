@@ -76,7 +76,7 @@ __device__ unsigned long long g_wave_cycles[4096];      // duration of every wav
 #define RSTAMP(i) do {} while (0)
 #define RSTART() do {} while (0)
 #define KSTART() do {} while (0)
-#define KSTAMP(i) do {} while (0)
+#define KSTAMP(i) asm volatile("; EARL_PHASE_END K" #i ::: "memory")
 #else
 #define PCOUNT(i, v) do {} while (0)
 #define PSTAMP(i) do {} while (0)
@@ -97,10 +97,14 @@ template <int LPE> __device__ __forceinline__ bool group_any(const bool pred, co
 
 // One timestep of one env by its LPE-lane group (`sub` = lane within the group; every lane of the wave runs this, the
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
-template <int NV, int LPE, bool INTEGRATE>
+// ROLE (round 5, the kitchen's one-env-per-workgroup launches): 0 = the whole timestep in one wave (every other launch).  1 / 2 = the timestep split over TWO waves of the
+// workgroup that work on the same env, each in its own LDS block: wave A (ROLE 1) runs the dynamics -- K1-K3, composite inertia, mass matrix, bias forces (K4-K7) -- and puts
+// the mass matrix and its lane's generalized force into wave B's block (`peer`); wave B (ROLE 2) meanwhile runs K1-K3, the collision phases and the constraint rows (C0-C3, K8),
+// meets A at a workgroup barrier, and goes on alone with the Hessian, the active-set iteration and the integration (K9, K10).  Same expressions, same inputs: same bits.
+template <int NV, int LPE, bool INTEGRATE, int ROLE = 0>
 __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV>::T& m, const BlkTable<Lim<NV>::MB, Lim<NV>::KBT>& bt, const earl_collision_model* __restrict__ col, const int sub,
                                         const int grp, const Q4 mq, const double (&ctrl)[EARL_MAXACT], const bool warm, double* qacc_out,
-                                        double* efc_out) {
+                                        double* efc_out, Shared<NV>* peer = nullptr) {
   // warm (uniform): s.aprev holds the solution of the previous timestep of the same env step / call, and the active-set iteration of K9 starts
   // from the set the new rows take AT it (MuJoCo warm-starts its solver from the previous qacc likewise) instead of from "every row active".
   // The fixed point is the same and so are the bits of the result (the last iteration builds the same Hessian from the same set); what changes is
@@ -192,7 +196,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   using BlkMask = std::conditional_t<(Lim<NV>::MB > 32), unsigned long long, unsigned int>;
   BlkMask nearw = 0;                                   // blocks with a near bounding test in ANY env of the wave
   BlkMask nearg = 0;                                   // ... in this env
-  for (int cb = 0; cb < bt.n_blk; cb += LPE) {
+  for (int cb = 0; ROLE != 1 && cb < bt.n_blk; cb += LPE) {
     // C0: bounding test per block, lane = block (LPE blocks per pass)
     const int b = cb + sub < bt.n_blk ? cb + sub : 0;
     const int bl = bt.link[b], xl = bt.box_link[b];
@@ -323,6 +327,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   // the links this lane's masked sums visit: [tbase, tend), KT of them at most (all of [0, NT) unless the model has two multi-link trees)
   constexpr int TS = Lim<NV>::TS, KT = TS < NT ? (TS > NT - TS ? TS : NT - TS) : NT;
   const int tbase = (TS < NT && l >= TS) ? TS : 0, tend = (TS < NT && l < TS) ? TS : NT;
+  double tau_l = 0.0;                                  // this lane's applied + passive - bias force (K7; ROLE 2: handed over by wave A)
+  SymLds<NV>& Mw = ROLE == 1 ? peer->M : s.M;          // where K5 puts the mass matrix
+  if constexpr (ROLE != 2) {
   // ------------------------------------------------------------------ K4: composite inertia = masked subtree sum; FS = Ic S
   if constexpr (Lim<NV>::ARMSCAN) {
     double acc[10];
@@ -359,26 +366,44 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   fence();
   PSTAMP(3);
   // ------------------------------------------------------------------ K5: mass matrix, lane = column j
+  double arm_l = 0.0;
+  if constexpr (Lim<NV>::EXTRAS) arm_l = m.armature[l];
+  double fsr[Lim<NV>::EXTRAS ? KT : 1][6];               // structured model: every row's FS first, the products after -- one LDS latency instead of one per row
+  if constexpr (Lim<NV>::EXTRAS) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) fsr[k][e] = s.dyn.crb.FS[k][e];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     const bool in = TS == NT || tbase + k < tend;
     const int i = TS < NT ? (in ? tbase + k : tend - 1) : k;
-    const double* fs = s.dyn.crb.FS[i];
+    const double* fs = Lim<NV>::EXTRAS ? fsr[Lim<NV>::EXTRAS ? k : 0] : s.dyn.crb.FS[i];
     double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
     v = ((dmask >> i) & 1u) ? v : 0.0;                  // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
-    if (i == l) v += m.armature[l];
-    if (isl && l <= i && in) s.M.put(i, l, v, true);    // (the entries between the two trees were zeroed when the kernel started and are never written)
+    if constexpr (Lim<NV>::EXTRAS) v = i == l ? v + arm_l : v;      // (a select, not a branch around a load)
+    else if (i == l) v += m.armature[l];
+    if constexpr (Lim<NV>::EXTRAS) {
+      // (no branch around the store: a lane without an entry in this row stores into the block's padding -- with a conditional store per row the loop was nine LDS
+      // round trips one after the other)
+      static_assert(!Lim<NV>::EXTRAS || SymLds<NV>::PACKED, "packed lower triangle");
+      double* const dst = (isl && l <= i && in) ? &Mw.v[i * (i + 1) / 2 + l] : reinterpret_cast<double*>(s.bank_pad);
+      *dst = v;
+    } else {
+    if (isl && l <= i && in) Mw.put(i, l, v, true);    // (the entries between the two trees were zeroed when the kernel started and are never written)
+    }
   }
   if constexpr (NT < NV) {                               // single-link trees: a diagonal entry each; the entries that join them to anything else were
     if (isl && l >= NT) {                                // zeroed when the kernel started and are never written
       const double* fs = s.dyn.crb.FS[l];
-      s.M.put(l, l, Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5] + m.armature[l], true);
+      Mw.put(l, l, Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5] + m.armature[l], true);
     }
   }
   fence();
   PSTAMP(4);
   // ------------------------------------------------------------------ K6: bias forces (RNE by masked sums)
-  double tau_l;                                        // this lane's applied + passive - bias force
   if constexpr (Lim<NV>::ARMSCAN) {
     // velocities V_l = sum over the ancestors of S_a qd_a, bias accelerations A_l = -g + sum of crossm(V) S_a qd_a, and the subtree sums of the bias forces:
     // prefix / suffix scans along the chains in registers (no LDS, no fence)
@@ -504,8 +529,53 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     if constexpr (Lim<NV>::CONNECT) t += s.xt.ext[l];      // generalized force handed in for this timestep (the minitaur's motor torques)
     tau_l = t;
   }
+  }                                                    // (ROLE != 2)
   fence();                                             // dyn.* is dead from here on; col.* then con.* take its place
   PSTAMP(5);
+  // The structured models' equality Hessian (K9) as a function: wave A of a split timestep builds it in wave B's block.
+  // hw_extras: the equality part has the model's structure (checked by the host side): the arm's NT x NT block (mass matrix + weld rows), one diagonal entry per
+  // fixture, one off-diagonal entry per coupled pair of fixtures.  Only those entries of Hw are ever written; the others were zeroed when the
+  // kernel started.  (The earlier form built all 23 rows of every column in registers and ran every coupling over all of them with selects: 14 k of
+  // the timestep's 62 k cycles.)  Same values, same order of additions per entry.  `o`: the block that holds the mass matrix, the weld rows and the couplings' records and takes Hw.
+  // Loads first, stores after, no branch in between: with a conditional store per row the loop was nine LDS round trips one after the other.
+  auto hw_extras = [&](Shared<NV>& o, const double (&DJ)[6]) {
+    if constexpr (Lim<NV>::EXTRAS) {
+      double h[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        h[i] = o.M.sym(i, l, ltri);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) h[i] = fma(o.con.J6[r][i], DJ[r], h[i]);
+        if (i == l) h[i] += m.drag_G[l];
+      }
+      // fixture lanes: the diagonal entry, the entry shared with the coupled partner (a coupling q[j1] - c0 - c1 q[j2] = 0 is a soft equality row with two non-zeros,
+      // 1 at j1 and -c1 at j2: rows j1 and j2 of column l get D J_l and -c1 D J_l -- for lane j1 that is its diagonal and its partner's row, for lane j2 the other way round)
+      const int pl = m.pair[l];
+      const double* const rec = o.jeq.rec[l >= NT ? l - NT : 0];
+      const double hd = o.M.sym(l, l, ltri) + m.drag_G[l] + (pl >= 0 ? rec[2] : 0.0), ho = pl >= 0 ? rec[3] : 0.0;
+      double* const dump = reinterpret_cast<double*>(s.bank_pad);      // (a lane without an entry stores into its own block's padding: no branch per row)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) *((isl && l < NT && i >= l) ? &o.hwst.Hw.lo(i, l) : dump) = h[i];
+      *((isl && l >= NT) ? &o.hwst.Hw.lo(l, l) : dump) = hd;
+      *((isl && l >= NT && pl > l) ? &o.hwst.Hw.lo(pl > l ? pl : l, l) : dump) = ho;      // (the lower triangle: the lane with the smaller index of a pair stores the shared entry)
+    }
+  };
+  if constexpr (ROLE == 1) {
+    // wave A: the mass matrix went straight to the peer's block; when wave B's weld rows are there (barrier X) build the equality Hessian from both, in the peer's block; leave
+    static_assert(ROLE != 1 || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
+    if (isl) peer->tau[l] = tau_l;
+    __syncthreads();                                   // barrier X
+    PSTAMP(10);
+    double DJ[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) DJ[r] = peer->con.wD[r] * peer->con.J6[r][l];      // (J6[r][l] is lane l's Jc[r])
+    hw_extras(*peer, DJ);
+    fence();
+    PSTAMP(9);
+    __syncthreads();                                   // barrier Y
+    PSTAMP(12);
+    return;
+  }
   // ------------------------------------------------------------------ C1-C2: collision (reference: LinkModel.collide)
   int nct = 0;                                         // contacts of this env (same value in every lane of the group)
   if constexpr (Lim<NV>::PACK) {
@@ -754,6 +824,25 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     const double Rg = fmax((1 - dd) * m.weld_invweight[r < 3 ? 0 : 1] * rcp_nr(dd), 1e-15);
     if (sub < 6) { s.con.wD[r] = rcp_nr(Rg); s.con.war[r] = -bb * Jv - kk * dd * res; }
   }
+  if constexpr (Lim<NV>::EXTRAS) {
+    // joint couplings q[j1] - c0 - c1 q[j2] = 0: soft equality rows with two non-zeros (1 at j1, -c1 at j2).  Lane e works out coupling e's regulariser and reference
+    // acceleration (a chain of dependent operations incl. three reciprocals) and leaves, for each of its two dofs, what that dof's lane adds in K9: D J_l, aref, the
+    // term of its diagonal entry, the term of the entry it shares with its partner.  (Until round 5 every lane walked all couplings in K9, twice five LDS round trips.)
+    static_assert(NT < NV || !Lim<NV>::EXTRAS, "coupled dofs lie behind the first tree (checked by the host side)");
+    if (sub < m.n_jeq) {
+      const int e = sub, j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
+      const double c0 = m.jeq_coef[e][0], c1 = m.jeq_coef[e][1];
+      const double res = s.qp[j1] - c0 - c1 * s.qp[j2], Jv = s.qv[j1] - c1 * s.qv[j2];
+      const double kk = bt.kb_jeq[e][0], bb = bt.kb_jeq[e][1], dd = imp_of(m.jeq_solimp[e], res);
+      const double D = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
+      const double ar = -bb * Jv - kk * dd * res;
+      const double DJ1 = D * 1.0, DJ2 = D * -c1;
+      double* const r1 = s.jeq.rec[j1 - NT];
+      double* const r2 = s.jeq.rec[j2 - NT];
+      r1[0] = DJ1; r1[1] = ar; r1[2] = DJ1; r1[3] = -c1 * DJ1;
+      r2[0] = DJ2; r2[1] = ar; r2[2] = -c1 * DJ2; r2[3] = DJ2;
+    }
+  }
   // connect constraints (reference: LinkModel.forward): attachments con_att1[e] / con_att2[e] coincide; rows 3 e + c, residual (p1 - p2)[c],
   // Jacobian Jp(link1, p1) - Jp(link2, p2); this lane's column first, then lane = row for the reference accelerations
   if constexpr (Lim<NV>::CONNECT) {
@@ -927,6 +1016,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   }
   fence();
   PSTAMP(6);
+  if constexpr (ROLE == 2) {                           // wave B: the weld rows are in place for wave A (barrier X), and so are wave A's generalized forces
+    static_assert(ROLE != 2 || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
+    __syncthreads();
+    PSTAMP(10);
+    tau_l = s.tau[l];
+  }
   // ------------------------------------------------------------------ K9: Hessian of the equality part, then the active-set Newton
   double hw[(Lim<NV>::EXTRAS || Lim<NV>::CONNECT) ? 1 : NV], rw;             // this lane's column of M + J6' D J6 (+ drag) and its right-hand side: registers, all iterations
                                                        // (big model: the column goes straight to LDS, s.hwst.Hw)
@@ -967,52 +1062,16 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
     g -= m.drag_G[l] * m.drag_b[l] * s.qv[l];
     if constexpr (Lim<NV>::EXTRAS) {
-      // The equality part has the model's structure (checked by the host side): the arm's NT x NT block (mass matrix + weld rows), one diagonal entry per
-      // fixture, one off-diagonal entry per coupled pair of fixtures.  Only those entries of s.hwst.Hw are ever written; the others were zeroed when the
-      // kernel started.  (The earlier form built all 23 rows of every column in registers and ran every coupling over all of them with selects: 14 k of
-      // the timestep's 62 k cycles.)  Same values, same order of additions per entry.
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        double h = s.M.sym(i, l, ltri);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) h = fma(s.con.J6[r][i], DJ[r], h);
-        if (i == l) h += m.drag_G[l];
-        if (isl && l < NT && i >= l) s.hwst.Hw.lo(i, l) = h;
+      if (m.pair[l] >= 0) {                             // (every other coupling's term in this lane's sum was D . 0 . aref)
+        const double* const rec = s.jeq.rec[l >= NT ? l - NT : 0];
+        g = fma(rec[0], rec[1], g);
       }
-      double hd = s.M.sym(l, l, ltri) + m.drag_G[l], ho = 0.0;        // fixture lanes: the diagonal entry, the entry shared with the coupled partner
-      const int pl = m.pair[l];
-      // joint couplings q[j1] - c0 - c1 q[j2] = 0: soft equality rows with two non-zeros (1 at j1, -c1 at j2).  Lane e works out coupling e's
-      // regulariser and reference acceleration (a chain of dependent operations incl. three reciprocals: five of them in a row, in every lane, were
-      // 5 k cycles of the timestep); the lanes of the pair pick them up from LDS (the edge-weight block is free until the first pass of K9)
-      double* const jq = &s.con.cw[0][0];
-      static_assert(2 * EARL_MAXJEQ <= MC * 8, "coupling terms fit the edge-weight block");
-      if (sub < m.n_jeq) {
-        const int e = sub, j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
-        const double c0 = m.jeq_coef[e][0], c1 = m.jeq_coef[e][1];
-        const double res = s.qp[j1] - c0 - c1 * s.qp[j2], Jv = s.qv[j1] - c1 * s.qv[j2];
-        const double kk = bt.kb_jeq[e][0], bb = bt.kb_jeq[e][1], dd = imp_of(m.jeq_solimp[e], res);
-        jq[2 * e] = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
-        jq[2 * e + 1] = -bb * Jv - kk * dd * res;
-      }
-      fence();
-      for (int e = 0; e < m.n_jeq; ++e) {
-        const int j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
-        const double c1 = m.jeq_coef[e][1];
-        const double D = jq[2 * e];
-        const double Jl = l == j1 ? 1.0 : (l == j2 ? -c1 : 0.0), DJl = D * Jl;
-        g = fma(DJl, jq[2 * e + 1], g);
-        // rows j1 and j2 of column l get DJl and -c1 DJl: for lane j1 that is its diagonal and its partner's row, for lane j2 the other way round
-        hd += l == j1 ? DJl : (l == j2 ? -c1 * DJl : 0.0);
-        ho += l == j1 ? -c1 * DJl : (l == j2 ? DJl : 0.0);
-      }
-      if (isl && l >= NT) {
-        s.hwst.Hw.lo(l, l) = hd;
-        if (pl > l) s.hwst.Hw.lo(pl, l) = ho;              // (the lower triangle: the lane with the smaller index of a pair stores the shared entry)
-      }
+      if constexpr (ROLE != 2) hw_extras(s, DJ);        // (split timestep: wave A's, in place at barrier Y)
     }
     rw = g;
   }
   PSTAMP(9);
+  if constexpr (ROLE == 2) { __syncthreads(); PSTAMP(12); }      // barrier Y: mass matrix and equality Hessian are wave A's
   coupled = __any(coupled);
   if constexpr (NV > 10) { if (warm) lim_start = lim_inst && ((lim_lo ? s.aprev[l] : -s.aprev[l]) - lim_aref < 0); }
   bool act = lim_start;                                // (dry-friction rows keep their cold start, the quadratic zone: from a_prev's zones the
@@ -1076,10 +1135,21 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       // J_i . v: an arm lane keeps rows i >= l of its column, a fixture lane f gets its row (f, i) against the arm (its own J entry is zero unless the
       // contact touches it) and its diagonal.  (The earlier form walked all NV rows of the column per contact with a read-modify-write in LDS each:
       // 20 k cycles per timestep in the wave whose fingers are on a fixture -- the wave the launch waits for.)
+      // No contact in any env of the wave (most timesteps of most waves): the iteration's Hessian IS the equality part -- K9's solver reads it where it lies
+      // (Hs below) instead of from a copy made with nine LDS round trips in a row (x + 0.0 = x: the same bits)
+      if (ncmax == 0) {
+        if (isl) s.con.rc[l] = rw;
+      } else {
       double rr = rw, acc[NA], accd = 0.0;
 #pragma unroll
       for (int i = 0; i < NA; ++i) acc[i] = 0.0;
       static_assert(MC % 2 == 0, "contact slots in pairs");
+      // this lane's entries of the equality part, loaded before the contact loop (independent of it): an arm lane's column, a fixture lane's diagonal and shared entry
+      double hwv[NA];
+      const int plh = m.pair[l];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) hwv[i] = s.hwst.Hw.lo(i >= l ? i : NA - 1, l < NA ? l : 0);
+      const double hwd = s.hwst.Hw.lo(l, l), hwo = s.hwst.Hw.lo(plh > l ? plh : l, l);
       for (int c2 = 0; c2 < ncmax; c2 += 2) {               // two contacts per iteration, their loads side by side (a slot beyond the count is selected away, not multiplied)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1096,18 +1166,20 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           accd += cv ? j0 * v0 + j1 * v1 + j2 * v2 : 0.0;
         }
       }
-      if (isl) {
-        if (l < NA) {
+      {
+        // an arm lane stores rows i >= l of its column, a fixture lane its row against the arm, its diagonal and the entry it shares with its partner: the same
+        // nine + two stores in every lane, the ones a lane does not have go to the block's padding (no branch per row)
+        double* const dump = reinterpret_cast<double*>(s.bank_pad);
+        const bool arm = l < NA;
 #pragma unroll
-          for (int i = 0; i < NA; ++i) if (i >= l) s.con.Hc.lo(i, l) = s.hwst.Hw.lo(i, l) + acc[i];
-        } else {
-#pragma unroll
-          for (int i = 0; i < NA; ++i) s.con.Hc.lo(l, i) = acc[i];                 // (the equality part has no entries between the arm and a fixture)
-          s.con.Hc.lo(l, l) = s.hwst.Hw.lo(l, l) + accd;
-          const int pl = m.pair[l];
-          if (pl > l) s.con.Hc.lo(pl, l) = s.hwst.Hw.lo(pl, l);
+        for (int i = 0; i < NA; ++i) {
+          const double v = arm ? hwv[i] + acc[i] : acc[i];                       // (the equality part has no entries between the arm and a fixture)
+          *(!isl ? dump : (arm ? (i >= l ? &s.con.Hc.lo(i >= l ? i : l, l) : dump) : &s.con.Hc.lo(l, i))) = v;
         }
-        s.con.rc[l] = rr;
+        *((isl && !arm) ? &s.con.Hc.lo(l, l) : dump) = hwd + accd;
+        *((isl && !arm && plh > l) ? &s.con.Hc.lo(plh > l ? plh : l, l) : dump) = hwo;
+        if (isl) s.con.rc[l] = rr;
+      }
       }
     } else if constexpr (Lim<NV>::CONNECT) {
       // column l of the iteration's Hessian: the stored equality part + the active contact edges, summed in registers, stored once (lower part)
@@ -1243,9 +1315,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           bool touched = false;                           // (this env has a contact between the arm and a fixture)
 #pragma unroll
           for (int c = 0; c < NA; ++c) row[c] = c <= l ? s.con.Hc.lo(l, c) : 0.0;
+          double blv[NV - NA];                            // (all of column l of B first: one LDS latency, not one per fixture)
+#pragma unroll
+          for (int f = NA; f < NV; ++f) blv[f - NA] = s.con.Hc.lo(f, l);
 #pragma unroll
           for (int f = NA; f < NV; ++f) {
-            const double bl = s.con.Hc.lo(f, l);
+            const double bl = blv[f - NA];
             if (bl != 0.0) {                              // only the fixtures this env's fingers touch have a row in B
               touched = true;
               const int p = m.pair[f];
@@ -1286,26 +1361,23 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       } else {
         // no contact joins the arm and the fixtures: the Hessian is the arm's NA x NA block plus, per fixture, a scalar or -- for the
         // knob / burner and switch / light couplings -- a 2 x 2 block with its partner (earl_link_model24.pair)
-        if (isl && l >= NA) {
-          const int p = m.pair[l];
-          const double d = s.con.Hc.lo(l, l) + s.con.dl[l];
-          double x;
-          if (p >= 0) {
-            const int hi = l > p ? l : p, lo_ = l > p ? p : l;
-            const double o = s.con.Hc.lo(hi, lo_), dp = s.con.Hc.lo(p, p) + s.con.dl[p];
-            double gl = 0, gp = 0;
+        const SymLds<NV>& Hs = ncmax == 0 ? s.hwst.Hw : s.con.Hc;
+        {
+          // the fixtures' scalars / 2 x 2 blocks: no branch (an arm lane works on fixture NA and stores into the block's padding), so that this chain of LDS round
+          // trips and a reciprocal overlaps the arm block's factorisation below instead of preceding it
+          const int lf = l >= NA ? l : NA;
+          const int p = m.pair[lf], pc = p >= 0 ? p : lf;
+          const double d = Hs.lo(lf, lf) + s.con.dl[lf];
+          const int hi = lf > pc ? lf : pc, lo_ = lf > pc ? pc : lf;
+          const double o = Hs.lo(hi, lo_), dp = Hs.lo(pc, pc) + s.con.dl[pc];
+          double gl = 0, gp = 0;
 #pragma unroll
-            for (int i = NA; i < NV; ++i) { gl = i == l ? a[i] : gl; gp = i == p ? a[i] : gp; }
-            x = (dp * gl - o * gp) * rcp_nr(d * dp - o * o);
-          } else {
-            double gl = 0;
-#pragma unroll
-            for (int i = NA; i < NV; ++i) gl = i == l ? a[i] : gl;
-            x = gl * rcp_nr(d);
-          }
-          s.con.rc[l] = x;                              // (every lane already holds the right-hand side in a[])
+          for (int i = NA; i < NV; ++i) { gl = i == lf ? a[i] : gl; gp = i == p ? a[i] : gp; }
+          const double r = rcp_nr(p >= 0 ? d * dp - o * o : d);
+          const double x = p >= 0 ? (dp * gl - o * gp) * r : gl * r;
+          *((isl && l >= NA) ? &s.con.rc[l] : reinterpret_cast<double*>(s.bank_pad)) = x;      // (every lane already holds the right-hand side in a[])
         }
-        solve_lead_regs<NV, NA>(s.con.Hc, [&](int i) { return s.con.dl[i]; }, a);
+        solve_lead_regs<NV, NA>(Hs, [&](int i) { return s.con.dl[i]; }, a);
         fence();
 #pragma unroll
         for (int i = NA; i < NV; ++i) a[i] = s.con.rc[i];
@@ -1483,11 +1555,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     if (isl) s.con.dl[l] = dt * m.damping[l];
     fence();
     if constexpr (Lim<NV>::EXTRAS) {                   // the mass matrix is ALWAYS the arm's block + one scalar per fixture
-      if (isl && l >= NA) {
+      {
+        const int lf = l >= NA ? l : NA;                 // (no branch: see K9's fixtures)
         double gl = 0;
 #pragma unroll
-        for (int i = NA; i < NV; ++i) gl = i == l ? a[i] : gl;
-        s.con.rc[l] = gl * rcp_nr(s.M.lo(l, l) + s.con.dl[l]);
+        for (int i = NA; i < NV; ++i) gl = i == lf ? a[i] : gl;
+        *((isl && l >= NA) ? &s.con.rc[l] : reinterpret_cast<double*>(s.bank_pad)) = gl * rcp_nr(s.M.lo(lf, lf) + s.con.dl[lf]);
       }
       solve_lead_regs<NV, NA>(s.M, [&](int i) { return s.con.dl[i]; }, a);
       fence();
@@ -1716,7 +1789,8 @@ int g_lpe = 16;   // lanes per env (earl_debug_set_physics_lanes): 16 = four env
 
 // Small batches of the 32-lanes-per-env kernels (kitchen, minitaur): an env is a serial chain of T x frame_skip timesteps walked by one wave, so a batch that leaves
 // wave slots empty gains nothing from them -- except by giving every env a wave (solo 1: up to 4 x CUs envs) or a whole CU (solo 2: up to CUs envs) to itself.
-// earl_debug_set_solo: -1 = by batch size (default), 0 / 1 / 2 = forced (measurement, tests)
+// earl_debug_set_solo: -1 = by batch size (default), 0 / 1 / 2 = forced (measurement, tests); the kitchen's fused rollout runs its one-env-per-workgroup launches with
+// TWO waves per env (solo 3: by default, or forced; 2 forces the one-wave form)
 int g_solo = -1;
 int solo_mode(int n) {
   if (g_solo >= 0) return g_solo;
@@ -1884,13 +1958,15 @@ int earl_kitchen_rollout(const void* model, const earl_collision_model* col, con
   if (cfg->n == 0 || T == 0) return EARL_OK;
   if (int rc = check_cone(col, false, (hipStream_t)stream, "kitchen_rollout")) return rc;
   KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T, solo_mode(cfg->n)};
-  kitchen_rollout_kernel<<<solo_grid(cfg->n, k.solo, Lim<23>::WPB), block_for<23>(), 0, (hipStream_t)stream>>>(k);
+  if (k.solo == 2 && g_solo < 0) k.solo = 3;   // one env per workgroup: two waves per env (the dynamics half of a timestep beside the collision / rows half)
+  if (k.solo == 3) kitchen_rollout_kernel<true><<<cfg->n, block_for<23>(), 0, (hipStream_t)stream>>>(k);
+  else kitchen_rollout_kernel<false><<<solo_grid(cfg->n, k.solo, Lim<23>::WPB), block_for<23>(), 0, (hipStream_t)stream>>>(k);
   return launched("kitchen_rollout");
 }
 
-int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (kitchen / minitaur launches of this unit)
+int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (one wave), 3 = one env per workgroup, two waves (kitchen launches)
   const int prev = g_solo;
-  if (mode >= -1 && mode <= 2) g_solo = mode;
+  if (mode >= -1 && mode <= 3) g_solo = mode;
   return prev;
 }
 #ifdef EARL_PHYS_PROF

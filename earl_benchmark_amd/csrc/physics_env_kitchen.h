@@ -82,6 +82,12 @@ __device__ __forceinline__ double kit_norm_diff(const double* a, const double* b
   }
   return sqrt(d);
 }
+// DUO (solo == 3, round 5): TWO waves of the workgroup work on its one env.  Per timestep (substep's ROLE 1 / 2): both run the kinematics; wave 1 then builds the mass matrix
+// in wave 0's LDS block and works out the bias forces while wave 0 runs the collision phases and the constraint rows; barrier X; wave 1 builds the equality Hessian (mass
+// matrix + weld + coupling rows) in wave 0's block; barrier Y; wave 0 iterates on the active set and integrates; barrier 2; wave 1 copies the new state.  Barrier 0, once per
+// env step, keeps wave 1 off the state while wave 0 does the env step's bookkeeping and hands it the step's actuator targets.  Wave 1 keeps no env state of its own and
+// stores nothing outside LDS.
+template <bool DUO>
 __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(const KitchenRolloutArgs a) {
 #pragma clang fp contract(off)
   constexpr int NV = 23, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
@@ -95,17 +101,35 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
   stage_model(m, a.m);                                  // (ends with the workgroup barrier)
   const earl_kitchen_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-  if (a.solo == 2 && wave != 0) return;                 // (after stage_model's barrier, the last one of the kernel)
-  const int env_raw = a.solo == 2 ? (int)blockIdx.x : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
-  const bool live = env_raw < n && (a.solo == 0 || grp == 0);
+  if (a.solo >= 2 && wave > (DUO ? 1 : 0)) return;      // (after stage_model's barrier; the waves that stay are the only ones the later barriers of the DUO form count)
+  const bool role_a = DUO && wave == 1;                 // the dynamics wave: computes, stores nothing outside LDS
+  const int env_raw = a.solo >= 2 ? (int)blockIdx.x : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
+  const bool live = env_raw < n && (a.solo == 0 || grp == 0) && !role_a;
   const int env = env_raw < n ? env_raw : n - 1;
   Shared<NV>& s = sh[wave * EPW + grp];
+  Shared<NV>* const peer = DUO ? &sh[grp] : nullptr;    // wave 0's block of the same 32-lane group
   load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
   for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;      // (entries between different trees are never written, K5)
   for (int k = sub; k < (int)(sizeof(s.hwst.Hw.v) / sizeof(double)); k += LPE) s.hwst.Hw.v[k] = 0.0;   // (nor the structural zeros of the equality Hessian, K9)
   if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
   fence();
   const Q4 mq = ldq(cfg.mocap_quat_dev);
+  if constexpr (DUO) {
+    __syncthreads();                                    // wave 0's mass matrix is zeroed before wave 1 writes into it
+    if (role_a) {
+      for (int t = 0; t < a.T; ++t) {
+        __syncthreads();                                // barrier 0: wave 0 is through the env step's bookkeeping (a diverged env went back to its stored state); the step's targets are published
+        const double ctrl_a[EARL_MAXACT] = {peer->duo_ctrl[0], peer->duo_ctrl[1], 0, 0};
+        for (int ts = 0; ts < cfg.frame_skip; ++ts) {
+          if (sub < NV) { s.qp[sub] = peer->qp[sub]; s.qv[sub] = peer->qv[sub]; }
+          fence();
+          substep<NV, LPE, true, 1>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);      // (barriers X, Y inside)
+          __syncthreads();                              // barrier 2: wave 0 has integrated
+        }
+      }
+      return;
+    }
+  }
   int steps = a.st.steps_since_reset[env];
   const int kk = sub < 9 ? sub : 8;                     // this lane's action component
 #ifdef EARL_PHYS_PROF
@@ -133,6 +157,14 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
     const double ctrl[EARL_MAXACT] = {s.kit.targets[0], s.kit.targets[1], 0, 0};      // do_simulation: ctrl[i] = targets[i] for i < nu = 2
     if (sub < 3 && live) a.st.mocap_pos[(size_t)env * 3 + sub] = s.mocap[sub];
     fence();
+    if constexpr (DUO) {
+      if (sub < 2) s.duo_ctrl[sub] = ctrl[sub];
+      __syncthreads();                                  // barrier 0
+      for (int ts = 0; ts < cfg.frame_skip; ++ts) {
+        substep<NV, LPE, true, 2>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);                // (barriers X, Y inside)
+        __syncthreads();                                // barrier 2
+      }
+    } else
     for (int ts = 0; ts < cfg.frame_skip; ++ts) substep<NV, LPE, true>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);
     const bool bad_lane = sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE);
     const bool failed = group_any<LPE>(bad_lane, grp);

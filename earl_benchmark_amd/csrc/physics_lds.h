@@ -177,9 +177,20 @@ struct SharedData {
 #ifndef EARL_STRIDE_MOD_23
 #define EARL_STRIDE_MOD_23 -1
 #endif
+// What only the kitchen model's block holds (an empty base class elsewhere: the other models' blocks keep their size and the 16-byte alignment of their arrays).
+// jeq.rec: joint couplings -- per coupled dof l >= NT the four numbers lane l's part of the equality Hessian takes: D J_l, the coupling's reference acceleration, the
+// term of its diagonal entry, the term of the entry it shares with its partner (K8 writes, K9 reads).  duo_ctrl, tau: two waves per env (substep's ROLE 1 / 2) -- the
+// env step's two actuator targets, published by wave B for wave A (whose K7 applies them); the generalized forces wave A computed, read by wave B after barrier X.
+template <int NV, bool ON> struct KitchenStore { static constexpr int SIZE = 0; };
+template <int NV> struct KitchenStore<NV, true> {
+  struct { double rec[NV - Lim<NV>::NT][4]; } jeq;
+  double duo_ctrl[2];
+  double tau[NV];
+  static constexpr int SIZE = (int)sizeof(double) * ((NV - Lim<NV>::NT) * 4 + 2 + NV);
+};
 template <int NV>
-struct Shared : SharedData<NV> {
-  static constexpr int R = (int)(sizeof(SharedData<NV>) % 256);
+struct Shared : SharedData<NV>, KitchenStore<NV, Lim<NV>::EXTRAS> {
+  static constexpr int R = (int)((sizeof(SharedData<NV>) + KitchenStore<NV, Lim<NV>::EXTRAS>::SIZE) % 256);
   static constexpr int TARGET = NV <= 10 ? (EARL_STRIDE_MOD_10) : (NV <= 15 ? (EARL_STRIDE_MOD_15) : (EARL_STRIDE_MOD_23));   // block size mod 256 (-1: the rule above)
   static constexpr int PAD = TARGET >= 0 ? (TARGET - R + 256) % 256 : (R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R));
   char bank_pad[PAD == 0 ? 8 : PAD];

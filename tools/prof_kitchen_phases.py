@@ -11,7 +11,8 @@ _abi.SIGNATURES['earl_debug_read_phys_profile_kitchen'] = [C.c_void_p, C.c_int] 
 _abi.SIGNATURES['earl_debug_read_wave_cycles_kitchen'] = [C.c_void_p]
 _abi.SIGNATURES['earl_debug_set_prof_wave_kitchen'] = [C.c_int, C.c_int]
 from earl_benchmark_amd.envs.kitchen import Kitchen
-NAMES = ['K1-2', 'K3', 'C1-2', 'K4', 'K5', 'K6-7', 'C3', 'K8', 'K9b', 'K9a', '-', 'K10']
+NAMES = ['K1-2', 'K3', 'C1-2', 'K4', 'K5', 'K6-7', 'C3', 'K8', 'K9b', 'K9a', 'wait X', 'K10', 'wait Y', 'K9a:g', 'K9a:jq', 'K9a:loop']
+DUO = '--duo' in sys.argv                               # two waves per env (n <= CUs): the phases of both waves of workgroup 0, incl. their waits at the timestep's barriers
 nums = [int(x) for x in sys.argv[1:] if x.isdigit()]
 n, T = (nums + [2048, 100])[:2] if len(nums) < 2 else nums[:2]
 lib = _abi.load()
@@ -22,7 +23,7 @@ acts = torch.rand(T, n, 9, generator=g, device='cuda') * 2 - 1
 
 def run(block, thread):
   env = Kitchen(num_envs=n, seed=3); env.reset()
-  lib.earl_debug_set_solo(0)                             # (two envs per wave whatever the batch size: the wave indexing below assumes it)
+  lib.earl_debug_set_solo(3 if DUO else 0)               # (two envs per wave whatever the batch size: the wave indexing below assumes it)
   lib.earl_debug_set_prof_wave_kitchen(block, thread)
   torch.cuda.synchronize()
   lib.earl_debug_read_phys_profile_kitchen(out, 1)
@@ -35,13 +36,23 @@ def run(block, thread):
 
 
 def show(tag, o):
-  ts = max(1, o[20]); tot = sum(o[:12])
+  ts = max(1, o[20]) if not DUO else T * 40; tot = sum(o[:16])
   print(f'{tag}: timesteps {o[20]}; near block {o[21] / ts:.3f}; with contacts {o[23] / ts:.3f} (max per env, mean {o[24] / ts:.2f}); passes per timestep {o[25] / ts:.2f}; coupled {o[26] / ts:.3f}')
-  print(f'  cycles per timestep {tot / ts:.0f}: ' + ', '.join(f'{NAMES[i]} {o[i] / ts:.0f}' for i in range(12) if NAMES[i] != '-'))
+  print(f'  cycles per timestep {tot / ts:.0f}: ' + ', '.join(f'{NAMES[i]} {o[i] / ts:.0f}' for i in range(16) if NAMES[i] != '-' and (DUO or i not in (10, 12))))
   print(f'  active-set pass: edge weights {o[16] / ts:.0f}, Hessian columns {o[17] / ts:.0f}, factor + solve {o[18] / ts:.0f}, row test {o[19] / ts:.0f}; '
         f'K9b in coupled timesteps {o[27] / max(1, o[26]):.0f}, in the others {o[28] / max(1, ts - o[26]):.0f}')
 
 
+if DUO:
+  n = min(n, 256)
+  acts = acts[:, :n].contiguous()
+  for blk in (0, 1, 100):
+    ms, w, o = run(blk, 0)
+    print(f'kitchen rollout N={n} T={T}, two waves per env: launch {ms:.1f} ms = {ms * 1e-3 * 2.4e9 / (T * 40):.0f} cycles per timestep at 2.4 GHz')
+    show(f'workgroup {blk} wave B (rows, bias forces, active set, integration)', o)
+    ms, w, o = run(blk, 64)
+    show(f'workgroup {blk} wave A (mass matrix, equality Hessian)', o)
+  sys.exit(0)
 ms, w, o = run(0, 0)
 print(f'kitchen rollout N={n} T={T}: launch {ms:.1f} ms = {n * T / ms / 1e3:.3f} M env-steps/s')
 print(f'  wave durations, cycles per timestep: min {w.min():.0f}  p10 {np.percentile(w, 10):.0f}  median {np.median(w):.0f}  mean {w.mean():.0f}  p90 {np.percentile(w, 90):.0f}  '
