@@ -366,34 +366,53 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   fence();
   PSTAMP(3);
   // ------------------------------------------------------------------ K5: mass matrix, lane = column j
-  double arm_l = 0.0;
-  if constexpr (Lim<NV>::EXTRAS) arm_l = m.armature[l];
-  double fsr[Lim<NV>::EXTRAS ? KT : 1][6];               // structured model: every row's FS first, the products after -- one LDS latency instead of one per row
-  if constexpr (Lim<NV>::EXTRAS) {
+#ifndef EARL_PEG_K5_BATCH
+#define EARL_PEG_K5_BATCH 3
+#endif
+  // Batched form (kitchen: all nine rows at once; peg: EARL_PEG_K5_BATCH rows at a time -- its kernel has no registers for more): the rows' FS first, the products
+  // after, a select instead of a branch around the armature's load, and no branch around the store -- a lane without an entry in a row stores into the block's
+  // padding.  With a conditional store per row the loop was one LDS round trip per row, one after the other (kitchen: 3.0 k -> 1.8 k cycles per timestep).
+  constexpr int K5B = Lim<NV>::EXTRAS ? KT : (NV == 15 ? EARL_PEG_K5_BATCH : 0);
+  if constexpr (K5B > 0) {
+    static_assert(K5B == 0 || SymLds<NV>::PACKED, "packed lower triangle");
+    const double arm_l = m.armature[l];
+    double* const dump = reinterpret_cast<double*>(s.bank_pad);
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
+    for (int k0 = 0; k0 < KT; k0 += (K5B > 0 ? K5B : 1)) {
+      double fsr[K5B > 0 ? K5B : 1][6];
 #pragma unroll
-      for (int e = 0; e < 6; ++e) fsr[k][e] = s.dyn.crb.FS[k][e];
+      for (int u = 0; u < K5B; ++u) {
+        const int k = k0 + u < KT ? k0 + u : KT - 1;
+        const bool in = TS == NT || tbase + k < tend;
+        const int i = TS < NT ? (in ? tbase + k : tend - 1) : k;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) fsr[u][e] = s.dyn.crb.FS[i][e];
+      }
+#pragma unroll
+      for (int u = 0; u < K5B; ++u) {
+        if (k0 + u < KT) {
+          const int k = k0 + u;
+          const bool in = TS == NT || tbase + k < tend;
+          const int i = TS < NT ? (in ? tbase + k : tend - 1) : k;
+          const double* fs = fsr[u];
+          double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
+          v = ((dmask >> i) & 1u) ? v : 0.0;            // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
+          v = i == l ? v + arm_l : v;
+          *((isl && l <= i && in) ? &Mw.v[i * (i + 1) / 2 + l] : dump) = v;
+        }
+      }
     }
-  }
+  } else {
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     const bool in = TS == NT || tbase + k < tend;
     const int i = TS < NT ? (in ? tbase + k : tend - 1) : k;
-    const double* fs = Lim<NV>::EXTRAS ? fsr[Lim<NV>::EXTRAS ? k : 0] : s.dyn.crb.FS[i];
+    const double* fs = s.dyn.crb.FS[i];
     double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
     v = ((dmask >> i) & 1u) ? v : 0.0;                  // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
-    if constexpr (Lim<NV>::EXTRAS) v = i == l ? v + arm_l : v;      // (a select, not a branch around a load)
-    else if (i == l) v += m.armature[l];
-    if constexpr (Lim<NV>::EXTRAS) {
-      // (no branch around the store: a lane without an entry in this row stores into the block's padding -- with a conditional store per row the loop was nine LDS
-      // round trips one after the other)
-      static_assert(!Lim<NV>::EXTRAS || SymLds<NV>::PACKED, "packed lower triangle");
-      double* const dst = (isl && l <= i && in) ? &Mw.v[i * (i + 1) / 2 + l] : reinterpret_cast<double*>(s.bank_pad);
-      *dst = v;
-    } else {
+    if (i == l) v += m.armature[l];
     if (isl && l <= i && in) Mw.put(i, l, v, true);    // (the entries between the two trees were zeroed when the kernel started and are never written)
-    }
+  }
   }
   if constexpr (NT < NV) {                               // single-link trees: a diagonal entry each; the entries that join them to anything else were
     if (isl && l >= NT) {                                // zeroed when the kernel started and are never written
@@ -1310,6 +1329,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           fi0[l] = i0; fi1[l] = i1; fy[l] = y;
         }
         fence();
+        KSTAMP(13);
         if (isl && l < NA) {                              // row l of the Schur complement and of its right-hand side, in place
           double row[NA], g = s.con.rc[l] + s.con.rl[l];
           bool touched = false;                           // (this env has a contact between the arm and a fixture)
@@ -1339,11 +1359,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           if (touched) s.con.rc[l] = g - s.con.rl[l];     // (a[] below is formed as rc + rl again; an untouched row keeps its rc: (rc + rl) - rl + rl is not rc + rl in floating point)
         }
         fence();
+        KSTAMP(14);
 #pragma unroll
         for (int i = 0; i < NA; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
         // (the Schur complement is factorised and solved in registers, redundantly per lane, like the arm's block without contacts: the lane-cooperative
         // in-LDS form -- chol_coop_lead + solve_lds_lead, nine plus eighteen dependent LDS round trips -- was a third of this path)
         solve_lead_regs<NV, NA>(s.con.Hc, [&](int i) { return s.con.dl[i]; }, a);
+        KSTAMP(15);
         if (isl && l >= NA) {                             // t_f = B_f . x_arm
           double t = 0;
 #pragma unroll

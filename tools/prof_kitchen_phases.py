@@ -11,7 +11,7 @@ _abi.SIGNATURES['earl_debug_read_phys_profile_kitchen'] = [C.c_void_p, C.c_int] 
 _abi.SIGNATURES['earl_debug_read_wave_cycles_kitchen'] = [C.c_void_p]
 _abi.SIGNATURES['earl_debug_set_prof_wave_kitchen'] = [C.c_int, C.c_int]
 from earl_benchmark_amd.envs.kitchen import Kitchen
-NAMES = ['K1-2', 'K3', 'C1-2', 'K4', 'K5', 'K6-7', 'C3', 'K8', 'K9b', 'K9a', 'wait X', 'K10', 'wait Y', 'K9a:g', 'K9a:jq', 'K9a:loop']
+NAMES = ['K1-2', 'K3', 'C1-2', 'K4', 'K5', 'K6-7', 'C3', 'K8', 'K9b', 'K9a', 'wait X', 'K10', 'wait Y', '-', '-', '-']
 DUO = '--duo' in sys.argv                               # two waves per env (n <= CUs): the phases of both waves of workgroup 0, incl. their waits at the timestep's barriers
 nums = [int(x) for x in sys.argv[1:] if x.isdigit()]
 n, T = (nums + [2048, 100])[:2] if len(nums) < 2 else nums[:2]
@@ -36,11 +36,11 @@ def run(block, thread):
 
 
 def show(tag, o):
-  ts = max(1, o[20]) if not DUO else T * 40; tot = sum(o[:16])
+  ts = max(1, o[20]) if not DUO else T * 40; tot = sum(o[:13])
   print(f'{tag}: timesteps {o[20]}; near block {o[21] / ts:.3f}; with contacts {o[23] / ts:.3f} (max per env, mean {o[24] / ts:.2f}); passes per timestep {o[25] / ts:.2f}; coupled {o[26] / ts:.3f}')
   print(f'  cycles per timestep {tot / ts:.0f}: ' + ', '.join(f'{NAMES[i]} {o[i] / ts:.0f}' for i in range(16) if NAMES[i] != '-' and (DUO or i not in (10, 12))))
   print(f'  active-set pass: edge weights {o[16] / ts:.0f}, Hessian columns {o[17] / ts:.0f}, factor + solve {o[18] / ts:.0f}, row test {o[19] / ts:.0f}; '
-        f'K9b in coupled timesteps {o[27] / max(1, o[26]):.0f}, in the others {o[28] / max(1, ts - o[26]):.0f}')
+        f'K9b in coupled timesteps {o[27] / max(1, o[26]):.0f}, in the others {o[28] / max(1, ts - o[26]):.0f}; per coupled timestep: fixtures inverse {o[13] / max(1, o[26]):.0f}, Schur rows {o[14] / max(1, o[26]):.0f}, arm solve {o[15] / max(1, o[26]):.0f}')
 
 
 if DUO:
