@@ -85,15 +85,6 @@ __device__ __forceinline__ void stage_pairs_mt(PairTabMT& t, const earl_collisio
     t.link[i] = col->pair_rec[i].sph_link; t.cls[i] = col->pair_rec[i].cls;
   }
 }
-// MuJoCo's impedance for solimp powers 1 and 2 only (this model's; checked by the host side): imp_of / kbimp of physics.hip without their pow() branches,
-// which are never taken here but are a quarter of the timestep's code
-__device__ __forceinline__ double imp_p2(const double* solimp, double r) {
-  const double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
-  const double x = width > 0 ? fmin(fabs(r) * rcp_nr(width), 1.0) : 1.0;
-  const double y2 = x <= mid ? x * x * rcp_nr(mid) : 1 - (1 - x) * (1 - x) * rcp_nr(1 - mid);
-  const double y = (power == 1 || d0 == dw) ? x : y2;
-  return d0 + y * (dw - d0);
-}
 // chol_regs of physics.hip (dense, diagonal left inverted) with the two-step reciprocal root
 template <int N>
 __device__ __forceinline__ void chol_small(double (&L)[N * (N + 1) / 2]) {
@@ -150,6 +141,7 @@ struct SharedMTData {
       double Y[16];                      // y = L^-1 b of the legs
       double LL[MTDims::NLEG][10];       // the legs' Cholesky factors (diagonal inverted)
       double SS[22];                     // Schur complement of the root block, packed lower triangle (21)
+      double xr0[6];                     // the root block's right-hand side: rc - sum of the legs' parts (six lanes of the Schur stage work it out, every lane reads it)
     } pas;
   };
 };
@@ -590,12 +582,13 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
           const double* w = s.cw[c];
           const int d1 = s.crow[c][0], d2 = s.crow[c][1];
           const int slot = l == d2 ? 1 : 0;
-          const bool touch = isroot || l == d1 || l == d2;
+          const double tmask = (isroot || l == d1 || l == d2) ? 1.0 : 0.0, cmask = l == d1 ? 1.0 : 0.0;
           double j[3], jc[3];
   #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const double jr = s.CJr[c][k][isroot ? l : 0], jh = s.CJh[c][k][slot];
-            j[k] = touch ? (isroot ? jr : jh) : 0.0;
+            // (ONE load per entry, used unconditionally -- times 1 or 0, exact: slots beyond the count hold zero rows.  Selected by `touch`, the compiler put each of
+            // these loads under a branch with its own s_waitcnt: twelve LDS round trips one after the other per group of four contacts)
+            j[k] = *(isroot ? &s.CJr[c][k][l] : &s.CJh[c][k][slot]) * tmask;
             jc[k] = s.CJh[c][k][1];
           }
           const double v0 = w[0] * j[0] + w[1] * j[1] + w[2] * j[2], v1 = w[1] * j[0] + w[3] * j[1], v2 = w[2] * j[0] + w[4] * j[2];
@@ -603,7 +596,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   #pragma unroll
           for (int i = 0; i < 6; ++i) acc6[i] += s.CJr[c][0][i] * v0 + s.CJr[c][1][i] * v1 + s.CJr[c][2][i] * v2;
           accd += j[0] * v0 + j[1] * v1 + j[2] * v2;
-          accc += (l == d1) ? jc[0] * v0 + jc[1] * v1 + jc[2] * v2 : 0.0;
+          accc += (jc[0] * v0 + jc[1] * v1 + jc[2] * v2) * cmask;
         }
       }
       if (isroot) {
@@ -667,6 +660,11 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
         s2 = fma(-s.pas.Wl[i][p + 2], s.pas.Wl[c][p + 2], s2); s3 = fma(-s.pas.Wl[i][p + 3], s.pas.Wl[c][p + 3], s3);
       }
       if (sub < 21) s.pas.SS[e] = (s0 + s1) + (s2 + s3);
+      // ... and the root block's right-hand side, lane 21 + i = root dof i (until round 5 every lane formed all six in the next stage: 30 loads into the same
+      // registers, twelve LDS round trips one after the other)
+      const int ri = sub >= 21 && sub < 27 ? sub - 21 : 0;
+      const double x0 = s.pas.rc[ri] - ((s.pas.part[ri][0] + s.pas.part[ri][1]) + (s.pas.part[ri][2] + s.pas.part[ri][3]));
+      if (sub >= 21 && sub < 27) s.pas.xr0[ri] = x0;
     }
     fence();
     {
@@ -675,7 +673,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
 #pragma unroll
       for (int e = 0; e < 21; ++e) Lr[e] = s.pas.SS[e];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) xr[i] = s.pas.rc[i] - ((s.pas.part[i][0] + s.pas.part[i][1]) + (s.pas.part[i][2] + s.pas.part[i][3]));
+      for (int i = 0; i < 6; ++i) xr[i] = s.pas.xr0[i];
       chol_small<6>(Lr);
       solve_regs<6, 6>(Lr, xr);
       // hinge lanes: back-substitution of their leg, x_k = L_k^-T (y_k - W_k' x_root)

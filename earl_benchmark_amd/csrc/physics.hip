@@ -838,7 +838,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     for (int j = 0; j < (TS < NT ? TS : NT); ++j) Jv = fma(s.con.J6[r][j], s.qv[j], Jv);          // (the weld's chain lies within the first tree)
     const double res = r < 3 ? pick3(rpos, r) : pick3(rrot, r - 3);
     double kk = bt.kb_weld[0], bb = bt.kb_weld[1], dd;
-    if constexpr (Lim<NV>::KBT) dd = imp_of(m.weld_solimp, res);
+    if constexpr (Lim<NV>::EXTRAS) dd = imp_p2(m.weld_solimp, res);
+    else if constexpr (Lim<NV>::KBT) dd = imp_of(m.weld_solimp, res);
     else kbimp(m.weld_solref, m.weld_solimp, res, dt, kk, bb, dd);
     const double Rg = fmax((1 - dd) * m.weld_invweight[r < 3 ? 0 : 1] * rcp_nr(dd), 1e-15);
     if (sub < 6) { s.con.wD[r] = rcp_nr(Rg); s.con.war[r] = -bb * Jv - kk * dd * res; }
@@ -848,18 +849,21 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     // acceleration (a chain of dependent operations incl. three reciprocals) and leaves, for each of its two dofs, what that dof's lane adds in K9: D J_l, aref, the
     // term of its diagonal entry, the term of the entry it shares with its partner.  (Until round 5 every lane walked all couplings in K9, twice five LDS round trips.)
     static_assert(NT < NV || !Lim<NV>::EXTRAS, "coupled dofs lie behind the first tree (checked by the host side)");
-    if (sub < m.n_jeq) {
-      const int e = sub, j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
+    {
+      // (no branch: every lane runs the chain -- for coupling 0 beyond the count -- and only lanes e < n_jeq store: the scheduler runs it beside the weld rows' chain above)
+      const bool mine = sub < m.n_jeq;
+      const int e = mine ? sub : 0, j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
       const double c0 = m.jeq_coef[e][0], c1 = m.jeq_coef[e][1];
       const double res = s.qp[j1] - c0 - c1 * s.qp[j2], Jv = s.qv[j1] - c1 * s.qv[j2];
-      const double kk = bt.kb_jeq[e][0], bb = bt.kb_jeq[e][1], dd = imp_of(m.jeq_solimp[e], res);
+      const double kk = bt.kb_jeq[e][0], bb = bt.kb_jeq[e][1], dd = imp_p2(m.jeq_solimp[e], res);
       const double D = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
       const double ar = -bb * Jv - kk * dd * res;
       const double DJ1 = D * 1.0, DJ2 = D * -c1;
-      double* const r1 = s.jeq.rec[j1 - NT];
-      double* const r2 = s.jeq.rec[j2 - NT];
-      r1[0] = DJ1; r1[1] = ar; r1[2] = DJ1; r1[3] = -c1 * DJ1;
-      r2[0] = DJ2; r2[1] = ar; r2[2] = -c1 * DJ2; r2[3] = DJ2;
+      double* const dump = reinterpret_cast<double*>(s.bank_pad);
+      double* const r1 = s.jeq.rec[j1 >= NT ? j1 - NT : 0];
+      double* const r2 = s.jeq.rec[j2 >= NT ? j2 - NT : 0];
+      *(mine ? &r1[0] : dump) = DJ1; *(mine ? &r1[1] : dump) = ar; *(mine ? &r1[2] : dump) = DJ1; *(mine ? &r1[3] : dump) = -c1 * DJ1;
+      *(mine ? &r2[0] : dump) = DJ2; *(mine ? &r2[1] : dump) = ar; *(mine ? &r2[2] : dump) = -c1 * DJ2; *(mine ? &r2[3] : dump) = DJ2;
     }
   }
   // connect constraints (reference: LinkModel.forward): attachments con_att1[e] / con_att2[e] coincide; rows 3 e + c, residual (p1 - p2)[c],
@@ -907,7 +911,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     lim_inst = isl && m.limited[l] && res < 0;
     double kk = bt.kb_lim[Lim<NV>::KBT ? l : 0][0], bb = bt.kb_lim[Lim<NV>::KBT ? l : 0][1];
     double dd;
-    if constexpr (Lim<NV>::KBT) dd = imp_of(m.jsolimp[l], res);
+    if constexpr (Lim<NV>::EXTRAS) dd = imp_p2(m.jsolimp[l], res);
+    else if constexpr (Lim<NV>::KBT) dd = imp_of(m.jsolimp[l], res);
     else kbimp(m.jsolref[l], m.jsolimp[l], res, dt, kk, bb, dd);
     lim_D = rcp_nr(fmax((1 - dd) * m.dof_invweight[l] * rcp_nr(dd), 1e-15));
     lim_aref = -bb * (lim_lo ? s.qv[l] : -s.qv[l]) - kk * dd * res;
@@ -934,7 +939,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   bool ctA = true, ctP = true;                         // ... and of the contact this lane owns
   unsigned int armmask = 0, pegmask = 0;               // two-tree model: contact slots whose Jacobian has entries in the first / second tree in SOME env of the wave
   if (ncmax > 0) {
-    for (int c = 0; c < ncmax; ++c) {
+    auto contact_jac = [&](const int c) {
       const double* rec = s.con.ct[c];
       const bool cv = c < nct;
       const V3 n = selv(cv, ld3(rec + 1), V3{0, 0, 1}), p = selv(cv, ld3(rec + 4), V3{0, 0, 0});
@@ -954,11 +959,24 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const V3 t2 = cross(n, t1);
       const double w = ((ls >= 0 && ((m.anc_mask[ls < 0 ? 0 : ls] >> l) & 1u)) ? 1.0 : 0.0) - ((lb >= 0 && ((m.anc_mask[lb < 0 ? 0 : lb] >> l) & 1u)) ? 1.0 : 0.0);
       const V3 Jp = scl(add(Sv, cross(Sw, p)), w);
+      if constexpr (Lim<NV>::EXTRAS) {                    // (no branch: two contacts' chains of LDS round trips run side by side below)
+        double* const dump = reinterpret_cast<double*>(s.bank_pad);
+        *((isl && cv) ? &s.con.CJ[c][0][l] : dump) = dot(n, Jp);
+        *((isl && cv) ? &s.con.CJ[c][1][l] : dump) = dot(t1, Jp);
+        *((isl && cv) ? &s.con.CJ[c][2][l] : dump) = dot(t2, Jp);
+      } else {
       if (isl && cv) {
         s.con.CJ[c][0][l] = dot(n, Jp);
         s.con.CJ[c][1][l] = dot(t1, Jp);
         s.con.CJ[c][2][l] = dot(t2, Jp);
       }
+      }
+    };
+    if constexpr (Lim<NV>::EXTRAS) {
+      static_assert(MC % 2 == 0, "contact slots in pairs");
+      for (int c2 = 0; c2 < ncmax; c2 += 2) { contact_jac(c2); contact_jac(c2 + 1); }      // (a slot beyond the env's count is selected away inside)
+    } else {
+      for (int c = 0; c < ncmax; ++c) contact_jac(c);
     }
     fence();
     {
@@ -1009,7 +1027,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       }
       double kk = bt.kb_cls[Lim<NV>::KBT ? cls : 0][0], bb = bt.kb_cls[Lim<NV>::KBT ? cls : 0][1];
       double dd;
-      if constexpr (Lim<NV>::KBT) dd = imp_of(bt.cls_solimp[cls], rec[0] - margin);
+      if constexpr (Lim<NV>::EXTRAS) dd = imp_p2(bt.cls_solimp[cls], rec[0] - margin);
+      else if constexpr (Lim<NV>::KBT) dd = imp_of(bt.cls_solimp[cls], rec[0] - margin);
       else kbimp(bt.cls_solref[cls], bt.cls_solimp[cls], rec[0] - margin, dt, kk, bb, dd);
       const double R0 = fmax((1 - dd) * bt.cls_invw[cls] * rcp_nr(dd), 1e-15);
       const double basea = -kk * dd * (rec[0] - margin);
@@ -1334,7 +1353,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           double row[NA], g = s.con.rc[l] + s.con.rl[l];
           bool touched = false;                           // (this env has a contact between the arm and a fixture)
 #pragma unroll
-          for (int c = 0; c < NA; ++c) row[c] = c <= l ? s.con.Hc.lo(l, c) : 0.0;
+          for (int c = 0; c < NA; ++c) { const double hv = s.con.Hc.lo(l, c <= l ? c : l); row[c] = c <= l ? hv : 0.0; }      // (loads without a branch per entry)
           double blv[NV - NA];                            // (all of column l of B first: one LDS latency, not one per fixture)
 #pragma unroll
           for (int f = NA; f < NV; ++f) blv[f - NA] = s.con.Hc.lo(f, l);
@@ -1343,19 +1362,19 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
             const double bl = blv[f - NA];
             if (bl != 0.0) {                              // only the fixtures this env's fingers touch have a row in B
               touched = true;
-              const int p = m.pair[f];
+              const int p = m.pair[f], pc = p >= 0 ? p : f;
               const double w0 = bl * fi0[f], w1 = bl * fi1[f];
               g = fma(-bl, fy[f], g);
 #pragma unroll
               for (int c = 0; c < NA; ++c) {
-                double t = w0 * s.con.Hc.lo(f, c);
-                if (p >= 0) t = fma(w1, s.con.Hc.lo(p, c), t);
+                const double t0 = w0 * s.con.Hc.lo(f, c), t1 = fma(w1, s.con.Hc.lo(pc, c), t0);      // (both rows loaded, no branch per entry)
+                const double t = p >= 0 ? t1 : t0;
                 row[c] -= c <= l ? t : 0.0;
               }
             }
           }
 #pragma unroll
-          for (int c = 0; c < NA; ++c) if (c <= l) s.con.Hc.lo(l, c) = row[c];
+          for (int c = 0; c < NA; ++c) *(c <= l ? &s.con.Hc.lo(l, c <= l ? c : l) : reinterpret_cast<double*>(s.bank_pad)) = row[c];      // (... and stores)
           if (touched) s.con.rc[l] = g - s.con.rl[l];     // (a[] below is formed as rc + rl again; an untouched row keeps its rc: (rc + rl) - rl + rl is not rc + rl in floating point)
         }
         fence();

@@ -40,6 +40,12 @@ __device__ __forceinline__ V3 selv(const bool c, const V3& a, const V3& b) { ret
 __device__ __forceinline__ Q4 selq(const bool c, const Q4& a, const Q4& b) { return {c ? a.w : b.w, c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 
 // reciprocal / reciprocal square root: hardware seed + Newton steps (about 1 ulp; not correctly rounded -- fine here)
+// a value the compiler must hold in a register HERE: keeps an LDS load out of a branch the optimiser would otherwise sink it into (a conditional load has its own
+// s_waitcnt; in a one-wave-per-SIMD kernel every such wait is a full LDS round trip)
+__device__ __forceinline__ double pinned(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ double rcp_nr(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
@@ -124,6 +130,16 @@ __device__ __forceinline__ double imp_of(const double* solimp, double r) {
   else if (power == 2) y = x <= mid ? x * x * rcp_nr(mid) : 1 - (1 - x) * (1 - x) * rcp_nr(1 - mid);
   else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
   else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  return d0 + y * (dw - d0);
+}
+// MuJoCo's impedance for solimp powers 1 and 2 only -- the kitchen's and the minitaur's tables (the host side refuses others for them: physics/__init__.py
+// check_impedance_powers): imp_of without its pow() branches, which are never taken there, are a quarter of the timestep's code and stand between chains of
+// dependent operations the scheduler could otherwise run side by side
+__device__ __forceinline__ double imp_p2(const double* solimp, double r) {
+  const double d0 = solimp[0], dw = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  const double x = width > 0 ? fmin(fabs(r) * rcp_nr(width), 1.0) : 1.0;
+  const double y2 = x <= mid ? x * x * rcp_nr(mid) : 1 - (1 - x) * (1 - x) * rcp_nr(1 - mid);
+  const double y = (power == 1 || d0 == dw) ? x : y2;
   return d0 + y * (dw - d0);
 }
 

@@ -82,6 +82,17 @@ def _fill(dst, src):
   a[tuple(slice(0, k) for k in src.shape)] = src
 
 
+def check_impedance_powers(d, keys, what):
+  """csrc/physics_math.h imp_p2 -- the impedance of the kitchen's and the minitaur's kernels -- knows MuJoCo's solimp powers 1 and 2 (a constant impedance, d0 == dwidth,
+  needs none): refuse any other here rather than compute a wrong impedance there"""
+  for k in keys:
+    if k in d and len(d[k]):
+      a = np.asarray(d[k], float).reshape(-1, 5)
+      ok = (a[:, 4] == 1) | (a[:, 4] == 2) | (a[:, 0] == a[:, 1])
+      if not ok.all():
+        raise _abi.EarlHipError(f'{what}: {k} row {int(np.flatnonzero(~ok)[0])} has solimp power {a[~ok][0, 4]:g}; the nv > 16 kernels implement powers 1 and 2 only')
+
+
 def load_link_model(name):
   """-> (LinkModelStruct, dict of the npz arrays)"""
   with np.load(os.path.join(MODEL_DIR, name + '_links.npz')) as z:
@@ -139,6 +150,8 @@ def load_link_model(name):
   if 'dof_drag_G' in d:
     _fill(s.drag_G, d['dof_drag_G'])
     _fill(s.drag_b, d['dof_drag_b'])
+  if big:
+    check_impedance_powers(d, ('jnt_solimp', 'weld_solimp', 'jeq_solimp', 'con_solimp'), name)
   if big and nv == 22:
     # the minitaur: floating root + 16 hinges, no mocap weld, four connect constraints (csrc/physics.hip Lim<22>: dense factorisations)
     s.n_jeq, s.n_con = 0, len(d['con_att1'])
@@ -206,6 +219,8 @@ def load_collision_model(d):
   c.cone = int(d['cone_elliptic']) if 'cone_elliptic' in d else 0
   assert c.cone == (1 if len(d['parent']) <= 16 else 0), 'csrc/physics.hip Lim<NV>::ELLIPTIC: the Sawyer models (nv 10, 15) are compiled with the elliptic cone, the others with the pyramid'
   small = len(d['parent']) <= 10                # csrc/physics.hip Lim<NV>: 8 contact slots / 16 blocks for nv <= 10
+  if len(d['parent']) > 16:
+    check_impedance_powers(d, ('col_cls_solimp',), 'collision classes')
   assert c.n_sph <= MAXSPH and c.n_box <= MAXBOX and c.n_pair <= MAXPAIR and c.n_cls <= MAXCLS
   nvm = len(d['parent'])
   assert c.n_blk <= (16 if small else (64 if nvm == 23 else (8 if nvm == 22 else 32))) and 0 < c.max_con <= (8 if small else MAXCON)      # Lim<NV>::MB, ::MC
