@@ -549,6 +549,19 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     wbits |= (jp[0] - cmu * jp[2] - car[3] < 0) ? 8u : 0u;
     cact = cv ? (warm ? wbits : 0xFu) : 0u;
   }
+  // which contact slots this lane's dof takes part in (bit c: it is the root's, or one of the two hinges of contact c's chain), which of the chain's two entries is
+  // its own, whether it is the upper hinge: from the slots' chain records, ONCE per timestep (every pass read them again, a round trip before each contact's rows)
+  unsigned int tbits = 0, sbits = 0, cbits = 0;
+  if (ncmax > 0) {
+    fence();
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      const int d1 = s.crow[c][0], d2 = s.crow[c][1];
+      tbits |= (isroot || l == d1 || l == d2) ? (1u << c) : 0u;
+      sbits |= l == d2 ? (1u << c) : 0u;
+      cbits |= l == d1 ? (1u << c) : 0u;
+    }
+  }
   PSTAMP(6);
   PSTAMP(9);
   // ------------------------------------------------------------------ K9: active-set Newton on the arrow-shaped Hessian
@@ -580,21 +593,30 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
         for (int u = 0; u < 4; ++u) {
           const int c = c4 + u;
           const double* w = s.cw[c];
-          const int d1 = s.crow[c][0], d2 = s.crow[c][1];
-          const int slot = l == d2 ? 1 : 0;
-          const double tmask = (isroot || l == d1 || l == d2) ? 1.0 : 0.0, cmask = l == d1 ? 1.0 : 0.0;
-          double j[3], jc[3];
+          const int slot = (sbits >> c) & 1u;
+          const double tmask = ((tbits >> c) & 1u) ? 1.0 : 0.0, cmask = ((cbits >> c) & 1u) ? 1.0 : 0.0;
+          // The contact's rows and weights: ALL loads first (pin6 / pin_batch: one s_waitcnt), then the arithmetic.  Left to the scheduler they came two at a time, each
+          // pair with its own wait; and this lane's own entries -- ONE load each, used unconditionally (times 1 or 0, exact: slots beyond the count hold zero rows) --
+          // selected by `touch` ended up under a branch per load: twenty LDS round trips one after the other per group of four contacts
+          double j[3], jc[3], wv[8], jr[18];
   #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            // (ONE load per entry, used unconditionally -- times 1 or 0, exact: slots beyond the count hold zero rows.  Selected by `touch`, the compiler put each of
-            // these loads under a branch with its own s_waitcnt: twelve LDS round trips one after the other per group of four contacts)
-            j[k] = *(isroot ? &s.CJr[c][k][l] : &s.CJh[c][k][slot]) * tmask;
+            j[k] = *(isroot ? &s.CJr[c][k][l] : &s.CJh[c][k][slot]);
             jc[k] = s.CJh[c][k][1];
           }
-          const double v0 = w[0] * j[0] + w[1] * j[1] + w[2] * j[2], v1 = w[1] * j[0] + w[3] * j[1], v2 = w[2] * j[0] + w[4] * j[2];
-          rr += w[5] * j[0] + w[6] * j[1] + w[7] * j[2];
   #pragma unroll
-          for (int i = 0; i < 6; ++i) acc6[i] += s.CJr[c][0][i] * v0 + s.CJr[c][1][i] * v1 + s.CJr[c][2][i] * v2;
+          for (int k = 0; k < 8; ++k) wv[k] = w[k];
+  #pragma unroll
+          for (int k = 0; k < 3; ++k)
+  #pragma unroll
+            for (int i = 0; i < 6; ++i) jr[6 * k + i] = s.CJr[c][k][i];
+          pin6(j[0], j[1], j[2], jc[0], jc[1], jc[2]); pin_batch(wv); pin_batch(jr);
+  #pragma unroll
+          for (int k = 0; k < 3; ++k) j[k] *= tmask;
+          const double v0 = wv[0] * j[0] + wv[1] * j[1] + wv[2] * j[2], v1 = wv[1] * j[0] + wv[3] * j[1], v2 = wv[2] * j[0] + wv[4] * j[2];
+          rr += wv[5] * j[0] + wv[6] * j[1] + wv[7] * j[2];
+  #pragma unroll
+          for (int i = 0; i < 6; ++i) acc6[i] += jr[i] * v0 + jr[6 + i] * v1 + jr[12 + i] * v2;
           accd += j[0] * v0 + j[1] * v1 + j[2] * v2;
           accc += (jc[0] * v0 + jc[1] * v1 + jc[2] * v2) * cmask;
         }
@@ -624,6 +646,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       for (int e = 0; e < 10; ++e) L[e] = s.pas.HA[k][e];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { Bc[j] = s.pas.HB[4 * k + j][i]; bk[j] = s.pas.rc[6 + 4 * k + j]; }
+      pin_batch(L); pin_batch(Bc); pin_batch(bk);         // (all of the stage's loads before its first use: physics_math.h pin_batch)
       chol_small<4>(L);
       double W[4], y[4], pt = 0.0;
 #pragma unroll
@@ -654,10 +677,14 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       const int i = e >= 15 ? 5 : (e >= 10 ? 4 : (e >= 6 ? 3 : (e >= 3 ? 2 : (e >= 1 ? 1 : 0))));
       const int c = e - i * (i + 1) / 2;
       double s0 = s.pas.HR[i][c], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      double wi[16], wc[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) { wi[p] = s.pas.Wl[i][p]; wc[p] = s.pas.Wl[c][p]; }
+      s0 = pinned(s0); pin_batch(wi); pin_batch(wc);
 #pragma unroll
       for (int p = 0; p < 16; p += 4) {
-        s0 = fma(-s.pas.Wl[i][p], s.pas.Wl[c][p], s0); s1 = fma(-s.pas.Wl[i][p + 1], s.pas.Wl[c][p + 1], s1);
-        s2 = fma(-s.pas.Wl[i][p + 2], s.pas.Wl[c][p + 2], s2); s3 = fma(-s.pas.Wl[i][p + 3], s.pas.Wl[c][p + 3], s3);
+        s0 = fma(-wi[p], wc[p], s0); s1 = fma(-wi[p + 1], wc[p + 1], s1);
+        s2 = fma(-wi[p + 2], wc[p + 2], s2); s3 = fma(-wi[p + 3], wc[p + 3], s3);
       }
       if (sub < 21) s.pas.SS[e] = (s0 + s1) + (s2 + s3);
       // ... and the root block's right-hand side, lane 21 + i = root dof i (until round 5 every lane formed all six in the next stage: 30 loads into the same
@@ -674,17 +701,25 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       for (int e = 0; e < 21; ++e) Lr[e] = s.pas.SS[e];
 #pragma unroll
       for (int i = 0; i < 6; ++i) xr[i] = s.pas.xr0[i];
-      chol_small<6>(Lr);
-      solve_regs<6, 6>(Lr, xr);
-      // hinge lanes: back-substitution of their leg, x_k = L_k^-T (y_k - W_k' x_root)
-      double Lk[10], z[4];
+      // (the back-substitution's operands too: everything this stage reads is on its way before the factorisation starts -- physics_math.h pin_batch)
+      double Lk[10], z[4], wl[24];
 #pragma unroll
       for (int e = 0; e < 10; ++e) Lk[e] = s.pas.LL[leg][e];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        double zz = s.pas.Y[4 * leg + j];
+        z[j] = s.pas.Y[4 * leg + j];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) zz = fma(-s.pas.Wl[i][4 * leg + j], xr[i], zz);
+        for (int i = 0; i < 6; ++i) wl[6 * j + i] = s.pas.Wl[i][4 * leg + j];
+      }
+      pin_batch(Lr); pin_batch(xr); pin_batch(Lk); pin_batch(z); pin_batch(wl);
+      chol_small<6>(Lr);
+      solve_regs<6, 6>(Lr, xr);
+      // hinge lanes: back-substitution of their leg, x_k = L_k^-T (y_k - W_k' x_root)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        double zz = z[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) zz = fma(-wl[6 * j + i], xr[i], zz);
         z[j] = zz;
       }
 #pragma unroll

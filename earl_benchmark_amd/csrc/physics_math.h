@@ -46,6 +46,18 @@ __device__ __forceinline__ double pinned(double v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// ... and a whole batch of loaded values at once: every load of the batch is issued before the first use, ONE s_waitcnt instead of one per pair of loads (the
+// scheduler, minimising register pressure, otherwise interleaves "read two, wait, use": in a one-wave-per-SIMD kernel a chain of full LDS round trips)
+__device__ __forceinline__ void pin6(double& a, double& b, double& c, double& d, double& e, double& f) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+template <int N>
+__device__ __forceinline__ void pin_batch(double (&x)[N]) {
+#pragma unroll
+  for (int i = 0; i + 6 <= N; i += 6) pin6(x[i], x[i + 1], x[i + 2], x[i + 3], x[i + 4], x[i + 5]);
+#pragma unroll
+  for (int i = N - N % 6; i < N; ++i) asm volatile("" : "+v"(x[i]));
+}
 __device__ __forceinline__ double rcp_nr(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
