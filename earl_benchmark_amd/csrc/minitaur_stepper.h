@@ -474,7 +474,12 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     const bool cv = sub < nct;
     double rec[8];                                        // (a lane reads its own record only, and later writes its own edge weights over it: no exchange.  Slots
 #pragma unroll                                            // beyond the env's count hold whatever LDS held: taken as zeros -- tests/test_lds_hygiene_gpu.py)
-    for (int k = 0; k < 8; ++k) rec[k] = cv ? s.ct[c][k] : 0.0;
+    for (int k = 0; k < 8; ++k) rec[k] = s.ct[c][k];
+    // (loads in three batches, by what their addresses depend on -- the record; the chain's parent and the class's tables; the chain's motion subspaces and velocities --
+    // each batch one LDS round trip: physics_math.h pin_batch.  Selected per load, they were eleven round trips one after the other)
+    pin_batch(rec);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rec[k] = cv ? rec[k] : 0.0;
     const V3 n = selv(cv, V3{rec[1], rec[2], rec[3]}, V3{0, 0, 1}), p = selv(cv, V3{rec[4], rec[5], rec[6]}, V3{0, 0, 0});
     const int pk = cv ? (int)rec[7] : 0;
     const int cls = pk & 63, ls = ((pk >> 6) & 63) - 1;
@@ -485,13 +490,27 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     t1 = scl(t1, rsq2(dot(t1, t1)));
     const V3 t2 = cross(n, t1);
     cd2 = ls >= 6 ? ls : -1;
-    cd1 = (cd2 >= 0 && m.parent[cd2] >= 6) ? m.parent[cd2] : -1;
+    double ctab[6] = {bt.cls_margin[cls], bt.cls_mu[cls], bt.kb_cls[cls][0], bt.kb_cls[cls][1], bt.cls_invw[cls], s.xt.foot_mu};
+    double simp[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) simp[k] = bt.cls_solimp[cls][k];
+    int par2 = m.parent[cd2 >= 0 ? cd2 : 0], parls = m.parent[ls > 0 ? ls : 0];
+    asm volatile("" : "+v"(par2), "+v"(parls));
+    pin_batch(ctab); pin_batch(simp);
+    cd1 = (cd2 >= 0 && par2 >= 6) ? par2 : -1;
     // Jacobian of the contact point, direction t: root dofs [t ; Rb' ((p - Pb) x t)], hinge d: t . (Sv_d + Sw_d x p)
     const V3 rp = vsub(p, Pb);
     const V3 dirs[3] = {n, t1, t2};
     double Jr[3][6], Jh[3][2];
-    const double* s1 = s.dyn.Sh[cd1 >= 0 ? cd1 - 6 : 0];
-    const double* s2 = s.dyn.Sh[cd2 >= 0 ? cd2 - 6 : 0];
+    double sh1[6], sh2[6], qa[4] = {s.qv[cd1 >= 0 ? cd1 : 0], s.qv[cd2 >= 0 ? cd2 : 0], s.aprev[cd1 >= 0 ? cd1 : 0], s.aprev[cd2 >= 0 ? cd2 : 0]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { sh1[k] = s.dyn.Sh[cd1 >= 0 ? cd1 - 6 : 0][k]; sh2[k] = s.dyn.Sh[cd2 >= 0 ? cd2 - 6 : 0][k]; }
+    double qr[6], ar[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { qr[r] = s.qv[r]; ar[r] = s.aprev[r]; }
+    pin_batch(sh1); pin_batch(sh2); pin_batch(qa); pin_batch(qr); pin_batch(ar);
+    const double* s1 = sh1;
+    const double* s2 = sh2;
     const V3 jp1 = add(ld3(s1 + 3), cross(ld3(s1), p)), jp2 = add(ld3(s2 + 3), cross(ld3(s2), p));
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -514,11 +533,8 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     // J qvel and J a_prev (warm start)
     double jv[3], jp[3];
     {
-      const double q1 = cd1 >= 0 ? s.qv[cd1 >= 0 ? cd1 : 0] : 0.0, q2 = cd2 >= 0 ? s.qv[cd2 >= 0 ? cd2 : 0] : 0.0;
-      const double a1 = cd1 >= 0 ? s.aprev[cd1 >= 0 ? cd1 : 0] : 0.0, a2 = cd2 >= 0 ? s.aprev[cd2 >= 0 ? cd2 : 0] : 0.0;
-      double qr[6], ar[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) { qr[r] = s.qv[r]; ar[r] = s.aprev[r]; }
+      const double q1 = cd1 >= 0 ? qa[0] : 0.0, q2 = cd2 >= 0 ? qa[1] : 0.0;
+      const double a1 = cd1 >= 0 ? qa[2] : 0.0, a2 = cd2 >= 0 ? qa[3] : 0.0;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         double a_ = 0, b_ = 0;
@@ -529,15 +545,15 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
         jv[k] = a_; jp[k] = b_;
       }
     }
-    const double margin = bt.cls_margin[cls];
-    cmu = bt.cls_mu[cls];
+    const double margin = ctab[0];
+    cmu = ctab[1];
     {
       const int root = m.ball_dof + 2;                    // Minitaur.SetFootFriction: every contact of a lower-leg link
-      if (s.xt.foot_mu > 0 && ls > root && m.parent[ls > 0 ? ls : 0] != root) cmu = s.xt.foot_mu;
+      cmu = (ctab[5] > 0 && ls > root && parls != root) ? ctab[5] : cmu;
     }
-    const double kk = bt.kb_cls[cls][0], bb = bt.kb_cls[cls][1];
-    const double dd = imp_p2(bt.cls_solimp[cls], rec[0] - margin);
-    const double R0 = fmax((1 - dd) * bt.cls_invw[cls] * rcp_nr(dd), 1e-15);
+    const double kk = ctab[2], bb = ctab[3];
+    const double dd = imp_p2(simp, rec[0] - margin);
+    const double R0 = fmax((1 - dd) * ctab[4] * rcp_nr(dd), 1e-15);
     cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
     const double basea = -kk * dd * (rec[0] - margin);
     car[0] = -bb * (jv[0] + cmu * jv[1]) + basea; car[1] = -bb * (jv[0] - cmu * jv[1]) + basea;
@@ -711,7 +727,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
 #pragma unroll
         for (int i = 0; i < 6; ++i) wl[6 * j + i] = s.pas.Wl[i][4 * leg + j];
       }
-      pin_batch(Lr); pin_batch(xr); pin_batch(Lk); pin_batch(z); pin_batch(wl);
+      pin_batch(Lr); pin_batch(xr); pin_batch(Lk); pin_batch(z);
       chol_small<6>(Lr);
       solve_regs<6, 6>(Lr, xr);
       // hinge lanes: back-substitution of their leg, x_k = L_k^-T (y_k - W_k' x_root)
@@ -741,14 +757,22 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     if (ncmax > 0) {
       fence();                                            // the hinges' entries of the solution
       const int c = sub < MC ? sub : MC - 1;
-      const double a1 = cd1 >= 0 ? s.aprev[cd1 >= 0 ? cd1 : 0] : 0.0, a2 = cd2 >= 0 ? s.aprev[cd2 >= 0 ? cd2 : 0] : 0.0;
+      double cj[18], ch[6], ah[2] = {s.aprev[cd1 >= 0 ? cd1 : 0], s.aprev[cd2 >= 0 ? cd2 : 0]};      // (one batch of loads: physics_math.h pin_batch)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) cj[6 * k + r] = s.CJr[c][k][r];
+        ch[2 * k] = s.CJh[c][k][0]; ch[2 * k + 1] = s.CJh[c][k][1];
+      }
+      pin_batch(ah); pin_batch(ch); pin_batch(cj);
+      const double a1 = cd1 >= 0 ? ah[0] : 0.0, a2 = cd2 >= 0 ? ah[1] : 0.0;
       double an[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         double a_ = 0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) a_ = fma(s.CJr[c][k][r], xr[r], a_);
-        a_ = fma(s.CJh[c][k][0], a1, a_); a_ = fma(s.CJh[c][k][1], a2, a_);
+        for (int r = 0; r < 6; ++r) a_ = fma(cj[6 * k + r], xr[r], a_);
+        a_ = fma(ch[2 * k], a1, a_); a_ = fma(ch[2 * k + 1], a2, a_);
         an[k] = a_;
       }
       unsigned int nb = 0;
