@@ -1291,13 +1291,36 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         if constexpr (TS < NT) {
           // the rows of a tree that slot c touches in no env of the wave hold exact zeros (C3 wrote them): skipped.  A peg lying on the table gives
           // four contacts with entries in the peg's six rows only -- 18 of the 45 reads and multiply-adds per contact
+          // (a tree's rows as ONE batch of loads -- physics_math.h pin_batch -- and the select on the sums: with the loads inside the select every row was a branch
+          // around three loads with a wait of their own, 77 LDS round trips one after the other per pass)
+#ifndef EARL_PEG_ROW_BATCH
+#define EARL_PEG_ROW_BATCH 1
+#endif
           if ((armmask >> c) & 1u) {
+            if constexpr (EARL_PEG_ROW_BATCH) {
+              double cj[3 * TS];
+#pragma unroll
+              for (int i = 0; i < TS; ++i) { cj[3 * i] = s.con.CJ[c][0][i]; cj[3 * i + 1] = s.con.CJ[c][1][i]; cj[3 * i + 2] = s.con.CJ[c][2][i]; }
+              pin_batch(cj);
+#pragma unroll
+              for (int i = 0; i < TS; ++i) hcol[i] += cv ? cj[3 * i] * v0 + cj[3 * i + 1] * v1 + cj[3 * i + 2] * v2 : 0.0;
+            } else {
 #pragma unroll
             for (int i = 0; i < TS; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+            }
           }
           if ((pegmask >> c) & 1u) {
+            if constexpr (EARL_PEG_ROW_BATCH) {
+              double cj[3 * (NV - TS)];
+#pragma unroll
+              for (int i = TS; i < NV; ++i) { cj[3 * (i - TS)] = s.con.CJ[c][0][i]; cj[3 * (i - TS) + 1] = s.con.CJ[c][1][i]; cj[3 * (i - TS) + 2] = s.con.CJ[c][2][i]; }
+              pin_batch(cj);
+#pragma unroll
+              for (int i = TS; i < NV; ++i) hcol[i] += cv ? cj[3 * (i - TS)] * v0 + cj[3 * (i - TS) + 1] * v1 + cj[3 * (i - TS) + 2] * v2 : 0.0;
+            } else {
 #pragma unroll
             for (int i = TS; i < NV; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+            }
           }
         } else {
 #pragma unroll
