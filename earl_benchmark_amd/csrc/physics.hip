@@ -1323,8 +1323,20 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
             }
           }
         } else {
+#ifndef EARL_DOOR_ROW_BATCH
+#define EARL_DOOR_ROW_BATCH 1
+#endif
+          if constexpr (EARL_DOOR_ROW_BATCH) {
+            double cj[3 * NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { cj[3 * i] = s.con.CJ[c][0][i]; cj[3 * i + 1] = s.con.CJ[c][1][i]; cj[3 * i + 2] = s.con.CJ[c][2][i]; }
+            pin_batch(cj);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) hcol[i] += cv ? cj[3 * i] * v0 + cj[3 * i + 1] * v1 + cj[3 * i + 2] * v2 : 0.0;
+          } else {
 #pragma unroll
           for (int i = 0; i < NV; ++i) hcol[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+          }
         }
       }
       if (isl) {
