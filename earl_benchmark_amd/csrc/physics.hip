@@ -1192,15 +1192,24 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int c = c2 + u;
-          const double* w = s.con.cw[c];
-          const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
+          // (the contact's weights, this lane's entries and the arm's rows as ONE batch of loads -- physics_math.h pin_batch -- and the selects on the sums: with the
+          // loads inside the selects every row was a branch around three loads with a wait of their own)
+          double w[8], jl[3], cj[3 * NA];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w[k] = s.con.cw[c][k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) jl[k] = s.con.CJ[c][k][l];
+#pragma unroll
+          for (int i = 0; i < NA; ++i) { cj[3 * i] = s.con.CJ[c][0][i]; cj[3 * i + 1] = s.con.CJ[c][1][i]; cj[3 * i + 2] = s.con.CJ[c][2][i]; }
+          pin_batch(w); pin_batch(jl); pin_batch(cj);
+          const double j0 = jl[0], j1 = jl[1], j2 = jl[2];
           const bool cv = c < nct;
           double v0, v1, v2;
         cone_apply<Lim<NV>::ELLIPTIC>(w, j0, j1, j2, v0, v1, v2);
         v0 = cv ? v0 : 0.0; v1 = cv ? v1 : 0.0; v2 = cv ? v2 : 0.0;
           rr += cv ? w[5] * j0 + w[6] * j1 + w[7] * j2 : 0.0;
 #pragma unroll
-          for (int i = 0; i < NA; ++i) acc[i] += cv ? s.con.CJ[c][0][i] * v0 + s.con.CJ[c][1][i] * v1 + s.con.CJ[c][2][i] * v2 : 0.0;
+          for (int i = 0; i < NA; ++i) acc[i] += cv ? cj[3 * i] * v0 + cj[3 * i + 1] * v1 + cj[3 * i + 2] * v2 : 0.0;
           accd += cv ? j0 * v0 + j1 * v1 + j2 * v2 : 0.0;
         }
       }
@@ -1524,6 +1533,25 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
           for (int j = TS; j < NV; ++j) { an = fma(s.con.CJ[c][0][j], a[j], an); at1 = fma(s.con.CJ[c][1][j], a[j], at1); at2 = fma(s.con.CJ[c][2][j], a[j], at2); }
         }
+      } else if constexpr (Lim<NV>::EXTRAS) {
+        // (a row of the contact's Jacobian as one batch of loads -- physics_math.h pin_batch: left to the scheduler the 69 loads came one or two at a time, 40 LDS
+        // round trips one after the other; the three sums keep their order of additions)
+        double row[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) row[j] = s.con.CJ[c][0][j];
+        pin_batch(row);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) an = fma(row[j], a[j], an);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) row[j] = s.con.CJ[c][1][j];
+        pin_batch(row);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) at1 = fma(row[j], a[j], at1);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) row[j] = s.con.CJ[c][2][j];
+        pin_batch(row);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) at2 = fma(row[j], a[j], at2);
       } else {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
