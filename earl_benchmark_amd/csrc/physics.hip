@@ -990,24 +990,34 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         ctP = cv && (ls >= TS || lb >= TS);
       }
       double vn = 0, vt1 = 0, vt2 = 0, pn = 0, pt1 = 0, pt2 = 0;      // J qvel; J a_prev (warm start)
-      auto rows = [&](const int j) {
-        const double qd = s.qv[j], ap = s.aprev[j];
-        const double jn = s.con.CJ[c][0][j], j1 = s.con.CJ[c][1][j], j2 = s.con.CJ[c][2][j];
-        vn = fma(jn, qd, vn); vt1 = fma(j1, qd, vt1); vt2 = fma(j2, qd, vt2);
-        pn = fma(jn, ap, pn); pt1 = fma(j1, ap, pt1); pt2 = fma(j2, ap, pt2);
+      // dofs [J0, J0 + N): their entries of the three rows, velocities and previous accelerations as ONE batch of loads (physics_math.h pin_batch), then the six sums in
+      // their order of additions -- left to the scheduler the loads came a row at a time, each with its own wait
+      auto rows = [&](auto j0c, auto nc) {
+        constexpr int J0 = decltype(j0c)::value, N = decltype(nc)::value;
+        double cj[3 * N], qa[2 * N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          cj[3 * j] = s.con.CJ[c][0][J0 + j]; cj[3 * j + 1] = s.con.CJ[c][1][J0 + j]; cj[3 * j + 2] = s.con.CJ[c][2][J0 + j];
+          qa[2 * j] = s.qv[J0 + j]; qa[2 * j + 1] = s.aprev[J0 + j];
+        }
+        pin_batch(cj); pin_batch(qa);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const double qd = qa[2 * j], ap = qa[2 * j + 1], jn = cj[3 * j], j1 = cj[3 * j + 1], j2 = cj[3 * j + 2];
+          vn = fma(jn, qd, vn); vt1 = fma(j1, qd, vt1); vt2 = fma(j2, qd, vt2);
+          pn = fma(jn, ap, pn); pt1 = fma(j1, ap, pt1); pt2 = fma(j2, ap, pt2);
+        }
       };
+      using std::integral_constant;
       if constexpr (TS < NT) {
-        if (ctA) {
-#pragma unroll
-          for (int j = 0; j < TS; ++j) rows(j);
-        }
-        if (ctP) {
-#pragma unroll
-          for (int j = TS; j < NV; ++j) rows(j);
-        }
+        if (ctA) rows(integral_constant<int, 0>{}, integral_constant<int, TS>{});
+        if (ctP) rows(integral_constant<int, TS>{}, integral_constant<int, NV - TS>{});
+      } else if constexpr (NV <= 12) {
+        rows(integral_constant<int, 0>{}, integral_constant<int, NV>{});
       } else {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) rows(j);
+        rows(integral_constant<int, 0>{}, integral_constant<int, 8>{});
+        rows(integral_constant<int, 8>{}, integral_constant<int, 8>{});
+        rows(integral_constant<int, 16>{}, integral_constant<int, NV - 16>{});
       }
       const int cls = cv ? ((int)rec[7] & 63) : 0;
       if constexpr (Lim<NV>::CONNECT) {
@@ -1525,13 +1535,21 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const int c = sub < MC ? sub : MC - 1;
       double an = 0, at1 = 0, at2 = 0;
       if constexpr (TS < NT) {
-        if (ctA) {
+        if (ctA) {                                        // (a tree's entries of the three rows as one batch of loads: physics_math.h pin_batch)
+          double cj[3 * TS];
 #pragma unroll
-          for (int j = 0; j < TS; ++j) { an = fma(s.con.CJ[c][0][j], a[j], an); at1 = fma(s.con.CJ[c][1][j], a[j], at1); at2 = fma(s.con.CJ[c][2][j], a[j], at2); }
+          for (int j = 0; j < TS; ++j) { cj[3 * j] = s.con.CJ[c][0][j]; cj[3 * j + 1] = s.con.CJ[c][1][j]; cj[3 * j + 2] = s.con.CJ[c][2][j]; }
+          pin_batch(cj);
+#pragma unroll
+          for (int j = 0; j < TS; ++j) { an = fma(cj[3 * j], a[j], an); at1 = fma(cj[3 * j + 1], a[j], at1); at2 = fma(cj[3 * j + 2], a[j], at2); }
         }
         if (ctP) {
+          double cj[3 * (NV - TS)];
 #pragma unroll
-          for (int j = TS; j < NV; ++j) { an = fma(s.con.CJ[c][0][j], a[j], an); at1 = fma(s.con.CJ[c][1][j], a[j], at1); at2 = fma(s.con.CJ[c][2][j], a[j], at2); }
+          for (int j = TS; j < NV; ++j) { cj[3 * (j - TS)] = s.con.CJ[c][0][j]; cj[3 * (j - TS) + 1] = s.con.CJ[c][1][j]; cj[3 * (j - TS) + 2] = s.con.CJ[c][2][j]; }
+          pin_batch(cj);
+#pragma unroll
+          for (int j = TS; j < NV; ++j) { an = fma(cj[3 * (j - TS)], a[j], an); at1 = fma(cj[3 * (j - TS) + 1], a[j], at1); at2 = fma(cj[3 * (j - TS) + 2], a[j], at2); }
         }
       } else if constexpr (Lim<NV>::EXTRAS) {
         // (a row of the contact's Jacobian as one batch of loads -- physics_math.h pin_batch: left to the scheduler the 69 loads came one or two at a time, 40 LDS
