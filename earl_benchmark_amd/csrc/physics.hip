@@ -199,15 +199,38 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   for (int cb = 0; ROLE != 1 && cb < bt.n_blk; cb += LPE) {
     // C0: bounding test per block, lane = block (LPE blocks per pass)
     const int b = cb + sub < bt.n_blk ? cb + sub : 0;
-    const int bl = bt.link[b], xl = bt.box_link[b];
+    // (two batches of loads -- the block's table entries, then the frames of the two links they name -- each ONE LDS round trip: physics_math.h pin_batch.  Left to
+    // the scheduler they were a dozen round trips one after the other)
+    int bl = bt.link[b], xl = bt.box_link[b];
     constexpr bool SAT = BlkTable<Lim<NV>::MB, Lim<NV>::KBT>::SAT;
-    V3 cs = ld3(bt.center[b]), cb_ = ld3(bt.box_pos[b]), ca = ld3(bt.obb_center[SAT ? b : 0]);
-    Q4 qb = ldq(bt.box_quat[b]);
+    double tb[14 + (SAT ? 6 : 0)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { tb[k] = bt.center[b][k]; tb[3 + k] = bt.box_pos[b][k]; tb[10 + k] = bt.box_half[b][k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tb[6 + k] = bt.box_quat[b][k];
+    tb[13] = bt.reach[b];
+    if constexpr (SAT) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { tb[14 + k] = bt.obb_center[b][k]; tb[17 + k] = bt.obb_half[b][k]; }
+    }
+    asm volatile("" : "+v"(bl), "+v"(xl));
+    pin_batch(tb);
+    double fr[14];
+    {
+      const int blc = bl < 0 ? 0 : bl, xlc = xl < 0 ? 0 : xl;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { fr[k] = s.Xq[blc][k]; fr[7 + k] = s.Xq[xlc][k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { fr[4 + k] = s.Xp[blc][k]; fr[11 + k] = s.Xp[xlc][k]; }
+    }
+    pin_batch(fr);
+    V3 cs{tb[0], tb[1], tb[2]}, cb_{tb[3], tb[4], tb[5]}, ca{tb[SAT ? 14 : 0], tb[SAT ? 15 : 1], tb[SAT ? 16 : 2]};
+    Q4 qb{tb[6], tb[7], tb[8], tb[9]};
     double RA[3][3];                                   // frame of the set's link (identity: world)
     {
       double R[3][3];
-      qmat(ldq(s.Xq[bl < 0 ? 0 : bl]), R);
-      const V3 xa = ld3(s.Xp[bl < 0 ? 0 : bl]);
+      qmat(Q4{fr[0], fr[1], fr[2], fr[3]}, R);
+      const V3 xa{fr[4], fr[5], fr[6]};
       const V3 w = add(xa, mulv(R, cs));
       cs = selv(bl < 0, cs, w);
       ca = selv(bl < 0, ca, add(xa, mulv(R, ca)));
@@ -215,9 +238,9 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) RA[i][j] = bl < 0 ? (i == j ? 1.0 : 0.0) : R[i][j];
-      const Q4 ql = ldq(s.Xq[xl < 0 ? 0 : xl]);
+      const Q4 ql{fr[7], fr[8], fr[9], fr[10]};
       qmat(ql, R);
-      const V3 w2 = add(ld3(s.Xp[xl < 0 ? 0 : xl]), mulv(R, cb_));
+      const V3 w2 = add(V3{fr[11], fr[12], fr[13]}, mulv(R, cb_));
       const Q4 q2 = qmul(ql, qb);
       cb_ = selv(xl < 0, cb_, w2);
       qb = selq(xl < 0, qb, q2);
@@ -225,12 +248,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     // distance from the set's bounding-sphere centre to the box (in the box frame) against the set radius + margin
     double Rb[3][3];
     qmat(qb, Rb);
-    const V3 x = mulvT(Rb, vsub(cs, cb_)), h = ld3(bt.box_half[b]);
+    const V3 x = mulvT(Rb, vsub(cs, cb_)), h{tb[10], tb[11], tb[12]};
     const V3 d{x.x - fmin(fmax(x.x, -h.x), h.x), x.y - fmin(fmax(x.y, -h.y), h.y), x.z - fmin(fmax(x.z, -h.z), h.z)};
     // second test: a face axis of the set's box (frame RA, centre ca, half extents incl. radii and margin) or of the block's box separates them
     bool separated = false;
     if constexpr (SAT) {
-      const V3 t = mulvT(RA, vsub(cb_, ca)), ha = ld3(bt.obb_half[b]);
+      const V3 t = mulvT(RA, vsub(cb_, ca)), ha{tb[SAT ? 17 : 0], tb[SAT ? 18 : 1], tb[SAT ? 19 : 2]};
       const double tt[3] = {t.x, t.y, t.z}, hA[3] = {ha.x, ha.y, ha.z}, hB[3] = {h.x, h.y, h.z};
       double Rm[3][3], aR[3][3];
 #pragma unroll
@@ -246,7 +269,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       for (int j = 0; j < 3; ++j)
         separated |= fabs(tt[0] * Rm[0][j] + tt[1] * Rm[1][j] + tt[2] * Rm[2][j]) > hB[j] + (hA[0] * aR[0][j] + hA[1] * aR[1][j] + hA[2] * aR[2][j]);
     }
-    const bool nearb = cb + sub < bt.n_blk && dot(d, d) < bt.reach[b] * bt.reach[b] && !separated;
+    const bool nearb = cb + sub < bt.n_blk && dot(d, d) < tb[13] * tb[13] && !separated;
     const unsigned long long bal = __ballot(nearb);
     if constexpr (LPE == 64) {
       nearg |= (BlkMask)bal; nearw |= (BlkMask)bal;
@@ -1366,8 +1389,14 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
     fence();
     KSTAMP(17);
+    {                                                    // (both vectors as one batch of loads: physics_math.h pin_batch -- they came a pair at a time, each with its own wait)
+      double rlv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i] + s.con.rl[i];
+      for (int i = 0; i < NV; ++i) { a[i] = s.con.rc[i]; rlv[i] = s.con.rl[i]; }
+      pin_batch(a); pin_batch(rlv);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) a[i] = a[i] + rlv[i];
+    }
     if constexpr (Lim<NV>::EXTRAS) {
       if (coupled && EARL_KITCHEN_DENSE) {             // (measurement switch: the generic dense factorisation in its looping form)
         if (isl) s.con.rc[l] += s.con.rl[l];
