@@ -473,14 +473,36 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     double nf[6] = {n.x, n.y, n.z, f.x, f.y, f.z};
     scan_desc<NV, 6>(nf, sub);
     double t = -m.damping[l] * qdl - (Sw.x * nf[0] + Sw.y * nf[1] + Sw.z * nf[2] + Sv.x * nf[3] + Sv.y * nf[4] + Sv.z * nf[5]);
-    if constexpr (Lim<NV>::EXTRAS) t -= m.stiffness[l] * (s.qp[l] - m.springref[l]);
+    if constexpr (Lim<NV>::EXTRAS) {
+      t -= m.stiffness[l] * (s.qp[l] - m.springref[l]);
+      // the actuators' tables as one batch of loads (physics_math.h pin_batch), their forces added under a select: the loop with a branch per actuator was a chain of
+      // LDS round trips (its joint, then its ranges and gain)
+      int aj[EARL_MAXACT];
+      double at[5 * EARL_MAXACT];
+#pragma unroll
+      for (int ac = 0; ac < EARL_MAXACT; ++ac) {
+        aj[ac] = m.act_joint[ac];
+        at[5 * ac] = m.act_ctrlrange[ac][0]; at[5 * ac + 1] = m.act_ctrlrange[ac][1]; at[5 * ac + 2] = m.act_kp[ac];
+        at[5 * ac + 3] = m.act_forcerange[ac][0]; at[5 * ac + 4] = m.act_forcerange[ac][1];
+      }
+      static_assert(EARL_MAXACT == 4, "four actuator slots");
+      asm volatile("" : "+v"(aj[0]), "+v"(aj[1]), "+v"(aj[2]), "+v"(aj[3]));
+      pin_batch(at);
+      const double qpl = s.qp[l];
+#pragma unroll
+      for (int ac = 0; ac < EARL_MAXACT; ++ac) {
+        const double c = fmin(fmax(ctrl[ac], at[5 * ac]), at[5 * ac + 1]);
+        const double frc = fmin(fmax(at[5 * ac + 2] * (c - qpl), at[5 * ac + 3]), at[5 * ac + 4]);
+        t = (ac < m.n_act && aj[ac] == l) ? t + frc : t;
+      }
+    } else {
     for (int ac = 0; ac < m.n_act; ++ac)
       if (m.act_joint[ac] == l) {
         const double c = fmin(fmax(ctrl[ac], m.act_ctrlrange[ac][0]), m.act_ctrlrange[ac][1]);
         double frc = m.act_kp[ac] * (c - s.qp[l]);
-        if constexpr (Lim<NV>::EXTRAS) frc = fmin(fmax(frc, m.act_forcerange[ac][0]), m.act_forcerange[ac][1]);
         t += frc;
       }
+    }
     tau_l = t;
   } else {
     V3 w{0, 0, 0}, v{0, 0, 0};
@@ -1694,13 +1716,23 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     if constexpr (Lim<NV>::DAMPED) {
     {
       double acc = 0;
+      if constexpr (Lim<NV>::EXTRAS) {                   // (this lane's column of M as one batch of loads: physics_math.h pin_batch; the peg build measured 2 % slower with it)
+        double mc[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) mc[j] = s.M.sym(j, l, ltri);
+        pin_batch(mc);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc = fma(mc[j], a[j], acc);
+      } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j) acc = fma(s.M.sym(j, l, ltri), a[j], acc);
+      }
       if (isl) s.con.rc[l] = acc;
     }
     fence();
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i];
+    if constexpr (Lim<NV>::EXTRAS) pin_batch(a);
     // the implicit-damping diagonal dt * B goes through LDS in both forms: as an operand of the add in load_tri the product would be contracted
     // into an fma, in chol_coop it is a rounded product -- the two door builds must agree to the bit
     if (isl) s.con.dl[l] = dt * m.damping[l];

@@ -250,6 +250,7 @@ __device__ __forceinline__ void solve_lead_regs(const SymLds<NV>& H, D diag, dou
     L[i * (i + 1) / 2 + i] = H.lo(i, i) + diag(i);
     y[i] = x[i];
   }
+  pin_batch(L);                                          // (the block as one batch of loads, ahead of the factorisation's first use)
   chol_regs<N, N, true>(L);
   solve_regs<N, N>(L, y);
 #pragma unroll
