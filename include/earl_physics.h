@@ -80,7 +80,8 @@ typedef struct earl_link_model24 {
   double jaxis[EARL_MAXV24][3], jpos[EARL_MAXV24][3];
   double mass[EARL_MAXV24], com[EARL_MAXV24][3], inertia[EARL_MAXV24][6];
   double range[EARL_MAXV24][2], damping[EARL_MAXV24], armature[EARL_MAXV24];
-  double jsolref[EARL_MAXV24][2], jsolimp[EARL_MAXV24][5], dof_invweight[EARL_MAXV24];
+  double jsolref[EARL_MAXV24][2], jsolimp[EARL_MAXV24][5], dof_invweight[EARL_MAXV24];   /* every solimp of this struct (and of the collision classes used with it): power 1 or 2, or d0 == dwidth -- the
+                                                                                           * nv > 16 kernels evaluate the impedance without pow() (csrc/physics_math.h imp_p2; the Python host side refuses other tables) */
   double att_pos[EARL_MAXATT24][3], att_quat[EARL_MAXATT24][4];
   double act_kp[EARL_MAXACT], act_ctrlrange[EARL_MAXACT][2];
   double weld_solref[2], weld_solimp[5], weld_invweight[2];
