@@ -1462,20 +1462,33 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           double blv[NV - NA];                            // (all of column l of B first: one LDS latency, not one per fixture)
 #pragma unroll
           for (int f = NA; f < NV; ++f) blv[f - NA] = s.con.Hc.lo(f, l);
+          // only the fixtures a finger touches have a row in B: the set of them over the wave's arm lanes (uniform), one pass of the loop per fixture of the set,
+          // ascending -- a lane whose own entry is zero subtracts exact zeros.  (Until round 5: fourteen unrolled tests, each body under its own branch with its loads
+          // and waits inside; 68 LDS round trips one after the other in the listing.)
+          unsigned int tset = 0;
 #pragma unroll
-          for (int f = NA; f < NV; ++f) {
-            const double bl = blv[f - NA];
-            if (bl != 0.0) {                              // only the fixtures this env's fingers touch have a row in B
-              touched = true;
-              const int p = m.pair[f], pc = p >= 0 ? p : f;
-              const double w0 = bl * fi0[f], w1 = bl * fi1[f];
-              g = fma(-bl, fy[f], g);
+          for (int f = NA; f < NV; ++f) tset |= __ballot(blv[f - NA] != 0.0) ? (1u << (f - NA)) : 0u;
+          for (unsigned int r = tset; r; r &= r - 1u) {
+            const int f = NA + __builtin_ctz(r);
+            int p = m.pair[f];
+            double fv[4] = {s.con.Hc.lo(f, l), fi0[f], fi1[f], fy[f]}, hf[NA], hp[NA];
 #pragma unroll
-              for (int c = 0; c < NA; ++c) {
-                const double t0 = w0 * s.con.Hc.lo(f, c), t1 = fma(w1, s.con.Hc.lo(pc, c), t0);      // (both rows loaded, no branch per entry)
-                const double t = p >= 0 ? t1 : t0;
-                row[c] -= c <= l ? t : 0.0;
-              }
+            for (int c = 0; c < NA; ++c) hf[c] = s.con.Hc.lo(f, c);
+            asm volatile("" : "+v"(p));
+            pin_batch(fv); pin_batch(hf);
+            const int pc = p >= 0 ? p : f;
+#pragma unroll
+            for (int c = 0; c < NA; ++c) hp[c] = s.con.Hc.lo(pc, c);
+            pin_batch(hp);
+            const double bl = fv[0];
+            touched = touched || bl != 0.0;
+            const double w0 = bl * fv[1], w1 = bl * fv[2];
+            g = fma(-bl, fv[3], g);
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+              const double t0 = w0 * hf[c], t1 = fma(w1, hp[c], t0);
+              const double t = p >= 0 ? t1 : t0;
+              row[c] -= c <= l ? t : 0.0;
             }
           }
 #pragma unroll
