@@ -395,9 +395,11 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   // Batched form (kitchen: all nine rows at once; peg: EARL_PEG_K5_BATCH rows at a time -- its kernel has no registers for more): the rows' FS first, the products
   // after, a select instead of a branch around the armature's load, and no branch around the store -- a lane without an entry in a row stores into the block's
   // padding.  With a conditional store per row the loop was one LDS round trip per row, one after the other (kitchen: 3.0 k -> 1.8 k cycles per timestep).
-  constexpr int K5B = Lim<NV>::EXTRAS ? KT : (NV == 15 ? EARL_PEG_K5_BATCH : 0);
+#ifndef EARL_DOOR_K5_BATCH
+#define EARL_DOOR_K5_BATCH 5
+#endif
+  constexpr int K5B = Lim<NV>::EXTRAS ? KT : (NV == 15 ? EARL_PEG_K5_BATCH : (NV <= 10 ? EARL_DOOR_K5_BATCH : 0));
   if constexpr (K5B > 0) {
-    static_assert(K5B == 0 || SymLds<NV>::PACKED, "packed lower triangle");
     const double arm_l = m.armature[l];
     double* const dump = reinterpret_cast<double*>(s.bank_pad);
 #pragma unroll
@@ -421,7 +423,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
           double v = Sw.x * fs[0] + Sw.y * fs[1] + Sw.z * fs[2] + Sv.x * fs[3] + Sv.y * fs[4] + Sv.z * fs[5];
           v = ((dmask >> i) & 1u) ? v : 0.0;            // j = l is an ancestor of (or is) i  <=>  i is in l's subtree
           v = i == l ? v + arm_l : v;
-          *((isl && l <= i && in) ? &Mw.v[i * (i + 1) / 2 + l] : dump) = v;
+          if constexpr (SymLds<NV>::PACKED) {
+            *((isl && l <= i && in) ? &Mw.v[i * (i + 1) / 2 + l] : dump) = v;
+          } else {                                        // (square form: the entry and its mirror image)
+            *((isl && l <= i && in) ? &Mw.v[i * NV + l] : dump) = v;
+            *((isl && l <= i && in) ? &Mw.v[l * NV + i] : dump) = v;
+          }
         }
       }
     }
@@ -506,6 +513,35 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     tau_l = t;
   } else {
     V3 w{0, 0, 0}, v{0, 0, 0};
+#ifndef EARL_K6_BATCH
+#define EARL_K6_BATCH 5
+#endif
+    if constexpr (NV <= 10 && EARL_K6_BATCH > 0) {
+      // (the door build: the ancestors' subspaces and velocities in batches of loads -- physics_math.h pin_batch; the velocity under a select was a branch around its
+      // load per row, each with a wait of its own)
+      constexpr int KB = EARL_K6_BATCH > 0 ? EARL_K6_BATCH : 1;
+#pragma unroll
+      for (int k0 = 0; k0 < KT; k0 += KB) {
+        double sv[6 * KB], qv_[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          const int a = k0 + u < KT ? k0 + u : KT - 1;
+          qv_[u] = s.qv[a];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) sv[6 * u + e] = s.dyn.S[a][e];
+        }
+        pin_batch(sv); pin_batch(qv_);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          if (k0 + u < KT) {
+            const int a = k0 + u;
+            const double qd = ((amask >> a) & 1u) ? qv_[u] : 0.0;
+            w = add(w, scl(V3{sv[6 * u], sv[6 * u + 1], sv[6 * u + 2]}, qd));
+            v = add(v, scl(V3{sv[6 * u + 3], sv[6 * u + 4], sv[6 * u + 5]}, qd));
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const bool in = TS == NT || tbase + k < tend;
@@ -514,6 +550,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const double* sa = s.dyn.S[a];
       w = add(w, scl(ld3(sa), qd));
       v = add(v, scl(ld3(sa + 3), qd));
+    }
     }
     if constexpr (NT < NV) {                             // single-link tree: only its own joint moves it
       const double qd = l >= NT ? s.qv[l] : 0.0;
@@ -541,6 +578,26 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
     fence();
     V3 aw{0, 0, 0}, av{-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    if constexpr (NV <= 10 && EARL_K6_BATCH > 0) {
+      constexpr int KB = EARL_K6_BATCH > 0 ? EARL_K6_BATCH : 1;
+#pragma unroll
+      for (int k0 = 0; k0 < KT; k0 += KB) {
+        double cv_[6 * KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+#pragma unroll
+          for (int e = 0; e < 6; ++e) cv_[6 * u + e] = s.dyn.rne.Cc[k0 + u < KT ? k0 + u : KT - 1][e];
+        pin_batch(cv_);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          if (k0 + u < KT) {
+            const double wgt = ((amask >> (k0 + u)) & 1u) ? 1.0 : 0.0;
+            aw = add(aw, scl(V3{cv_[6 * u], cv_[6 * u + 1], cv_[6 * u + 2]}, wgt));
+            av = add(av, scl(V3{cv_[6 * u + 3], cv_[6 * u + 4], cv_[6 * u + 5]}, wgt));
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const bool in = TS == NT || tbase + k < tend;
@@ -549,6 +606,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const double* ca = s.dyn.rne.Cc[a];
       aw = add(aw, scl(ld3(ca), wgt));
       av = add(av, scl(ld3(ca + 3), wgt));
+    }
     }
     if constexpr (NT < NV) {
       const double wgt = l >= NT ? 1.0 : 0.0;
@@ -566,6 +624,26 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
     fence();
     V3 ns{0, 0, 0}, fs{0, 0, 0};
+    if constexpr (NV <= 10 && EARL_K6_BATCH > 0) {
+      constexpr int KB = EARL_K6_BATCH > 0 ? EARL_K6_BATCH : 1;
+#pragma unroll
+      for (int k0 = 0; k0 < KT; k0 += KB) {
+        double fv_[6 * KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+#pragma unroll
+          for (int e = 0; e < 6; ++e) fv_[6 * u + e] = s.dyn.rne.F[k0 + u < KT ? k0 + u : KT - 1][e];
+        pin_batch(fv_);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          if (k0 + u < KT) {
+            const double wgt = ((dmask >> (k0 + u)) & 1u) ? 1.0 : 0.0;
+            ns = add(ns, scl(V3{fv_[6 * u], fv_[6 * u + 1], fv_[6 * u + 2]}, wgt));
+            fs = add(fs, scl(V3{fv_[6 * u + 3], fv_[6 * u + 4], fv_[6 * u + 5]}, wgt));
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       const bool in = TS == NT || tbase + k < tend;
@@ -574,6 +652,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const double* fd = s.dyn.rne.F[d];
       ns = add(ns, scl(ld3(fd), wgt));
       fs = add(fs, scl(ld3(fd + 3), wgt));
+    }
     }
     if constexpr (NT < NV) {
       const double wgt = l >= NT ? 1.0 : 0.0;
