@@ -644,7 +644,7 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
 
 # one GPU, reset + one fused launch of a SHARD of the strong-scaling batches, relative to the full batch (tools/kitchen_small_batch.py on an MI355X, profiles/r05_kitchen_small_batch.txt):
 # what `world` GPUs would deliver if every shard ran like this one (no collective on the data path; the job's one all-gather is 16 KB)
-MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.95, 4: 0.90, 8: 0.74}, 'minitaur': {1: 1.00, 2: 0.50, 4: 0.47, 8: 0.46}}      # (kitchen at 256 envs: two waves per env)
+MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.96, 4: 0.90, 8: 0.65}, 'minitaur': {1: 1.00, 2: 0.50, 4: 0.47, 8: 0.46}}      # (kitchen at 256 envs: four waves per env)
 
 
 def predicted_strong_scaling(workload, n_global, world):
@@ -652,7 +652,7 @@ def predicted_strong_scaling(workload, n_global, world):
   line so that nobody reads 'x8' into it.  An env is a serial chain of T x frame_skip timesteps walked by ONE 32-lane group; a launch lasts as
   long as its slowest wave.  Sharding the batch over more GPUs shortens a launch while a GPU has more waves than wave slots (kitchen: 2048 envs fill exactly one
   round on ONE GPU; minitaur: 4096 envs = two rounds), and below that only by what the small-batch launch modes recover (one env per wave / per workgroup -- an env no
-  longer waits for its wave-mate's longer branch -- and, kitchen, two waves per env) -- measured on one GPU per shard size, not extrapolated."""
+  longer waits for its wave-mate's longer branch -- and, kitchen, four waves per env) -- measured on one GPU per shard size, not extrapolated."""
   per_round = 2048                                      # both kernels: 2 envs per wave, 4 waves per CU, 256 CUs
   rounds_1 = -(-n_global // per_round)
   rounds_w = -(-(-(-n_global // world)) // per_round)

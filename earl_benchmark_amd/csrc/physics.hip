@@ -97,10 +97,11 @@ template <int LPE> __device__ __forceinline__ bool group_any(const bool pred, co
 
 // One timestep of one env by its LPE-lane group (`sub` = lane within the group; every lane of the wave runs this, the
 // groups working on their own Shared block).  INTEGRATE=false stops after qacc (mj_forward); outputs may be NULL.
-// ROLE (round 5, the kitchen's one-env-per-workgroup launches): 0 = the whole timestep in one wave (every other launch).  1 / 2 = the timestep split over TWO waves of the
-// workgroup that work on the same env, each in its own LDS block: wave A (ROLE 1) runs the dynamics -- K1-K3, composite inertia, mass matrix, bias forces (K4-K7) -- and puts
-// the mass matrix and its lane's generalized force into wave B's block (`peer`); wave B (ROLE 2) meanwhile runs K1-K3, the collision phases and the constraint rows (C0-C3, K8),
-// meets A at a workgroup barrier, and goes on alone with the Hessian, the active-set iteration and the integration (K9, K10).  Same expressions, same inputs: same bits.
+// ROLE (round 5, the kitchen's one-env-per-workgroup launches): 0 = the whole timestep in one wave (every other launch).  1 - 4 = the timestep split over the FOUR waves of the
+// workgroup, one per SIMD, that work on the same env, each in its own LDS block; all run the kinematics (K1 - K3).  Wave B (ROLE 2) owns the env: constraint rows (K8) before
+// barrier X, then the contact rows (C3), the active-set iteration and the integration (K9, K10).  Before barrier X: wave A (ROLE 1) builds the mass matrix into B's block (K4, K5),
+// ROLE 3 works out the bias forces (K6, K7) and hands B its lanes' generalized forces, ROLE 4 runs the bounding tests and the collision phases (C0 - C2) and leaves the contact
+// records and their count in B's block.  Between X and Y wave A builds the equality Hessian in B's block.  Same expressions, same inputs, same order: same bits.
 template <int NV, int LPE, bool INTEGRATE, int ROLE = 0>
 __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV>::T& m, const BlkTable<Lim<NV>::MB, Lim<NV>::KBT>& bt, const earl_collision_model* __restrict__ col, const int sub,
                                         const int grp, const Q4 mq, const double (&ctrl)[EARL_MAXACT], const bool warm, double* qacc_out,
@@ -158,6 +159,11 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const bool on = sub == 7 || sub == 8;
       Q = selq(on, qn_, Q); P = selv(on, pn_, P);
     }
+    if constexpr (Lim<NV>::EXTRAS) {
+      // the phase's results held in registers HERE, whatever consumes them: a product that ends a phase is otherwise contracted into its consumer's add (fp contract fast)
+      // or not depending on what else the instantiation does with it -- the waves of a split timestep (ROLE 1 - 4) must compute the bits of the one-wave form
+      asm volatile("" : "+v"(Q.w), "+v"(Q.x), "+v"(Q.y), "+v"(Q.z), "+v"(P.x), "+v"(P.y), "+v"(P.z));
+    }
     if (isl) {
       double* oq = s.Xq[l];
       double* op = s.Xp[l];
@@ -196,7 +202,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   using BlkMask = std::conditional_t<(Lim<NV>::MB > 32), unsigned long long, unsigned int>;
   BlkMask nearw = 0;                                   // blocks with a near bounding test in ANY env of the wave
   BlkMask nearg = 0;                                   // ... in this env
-  for (int cb = 0; ROLE != 1 && cb < bt.n_blk; cb += LPE) {
+  for (int cb = 0; (ROLE == 0 || ROLE == 4) && cb < bt.n_blk; cb += LPE) {
     // C0: bounding test per block, lane = block (LPE blocks per pass)
     const int b = cb + sub < bt.n_blk ? cb + sub : 0;
     // (two batches of loads -- the block's table entries, then the frames of the two links they name -- each ONE LDS round trip: physics_math.h pin_batch.  Left to
@@ -352,7 +358,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   const int tbase = (TS < NT && l >= TS) ? TS : 0, tend = (TS < NT && l < TS) ? TS : NT;
   double tau_l = 0.0;                                  // this lane's applied + passive - bias force (K7; ROLE 2: handed over by wave A)
   SymLds<NV>& Mw = ROLE == 1 ? peer->M : s.M;          // where K5 puts the mass matrix
-  if constexpr (ROLE != 2) {
+  if constexpr (ROLE == 0 || ROLE == 1) {
   // ------------------------------------------------------------------ K4: composite inertia = masked subtree sum; FS = Ic S
   if constexpr (Lim<NV>::ARMSCAN) {
     double acc[10];
@@ -452,6 +458,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   }
   fence();
   PSTAMP(4);
+  }                                                    // (ROLE 0 / 1)
+  if constexpr (ROLE == 0 || ROLE == 3) {
   // ------------------------------------------------------------------ K6: bias forces (RNE by masked sums)
   if constexpr (Lim<NV>::ARMSCAN) {
     // velocities V_l = sum over the ancestors of S_a qd_a, bias accelerations A_l = -g + sum of crossm(V) S_a qd_a, and the subtree sums of the bias forces:
@@ -672,7 +680,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     if constexpr (Lim<NV>::CONNECT) t += s.xt.ext[l];      // generalized force handed in for this timestep (the minitaur's motor torques)
     tau_l = t;
   }
-  }                                                    // (ROLE != 2)
+  }                                                    // (ROLE 0 / 3)
   fence();                                             // dyn.* is dead from here on; col.* then con.* take its place
   PSTAMP(5);
   // The structured models' equality Hessian (K9) as a function: wave A of a split timestep builds it in wave B's block.
@@ -706,7 +714,6 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   if constexpr (ROLE == 1) {
     // wave A: the mass matrix went straight to the peer's block; when wave B's weld rows are there (barrier X) build the equality Hessian from both, in the peer's block; leave
     static_assert(ROLE != 1 || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
-    if (isl) peer->tau[l] = tau_l;
     __syncthreads();                                   // barrier X
     PSTAMP(10);
     double DJ[6];
@@ -719,8 +726,42 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     PSTAMP(12);
     return;
   }
+  auto jeq_records = [&](Shared<NV>& o) {      // (`o`: the block that takes the records -- wave B's when the collision wave of a split timestep works them out)
+  if constexpr (Lim<NV>::EXTRAS) {
+    // joint couplings q[j1] - c0 - c1 q[j2] = 0: soft equality rows with two non-zeros (1 at j1, -c1 at j2).  Lane e works out coupling e's regulariser and reference
+    // acceleration (a chain of dependent operations incl. three reciprocals) and leaves, for each of its two dofs, what that dof's lane adds in K9: D J_l, aref, the
+    // term of its diagonal entry, the term of the entry it shares with its partner.  (Until round 5 every lane walked all couplings in K9, twice five LDS round trips.)
+    static_assert(NT < NV || !Lim<NV>::EXTRAS, "coupled dofs lie behind the first tree (checked by the host side)");
+    {
+      // (no branch: every lane runs the chain -- for coupling 0 beyond the count -- and only lanes e < n_jeq store: the scheduler runs it beside the weld rows' chain above)
+      const bool mine = sub < m.n_jeq;
+      const int e = mine ? sub : 0, j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
+      const double c0 = m.jeq_coef[e][0], c1 = m.jeq_coef[e][1];
+      const double res = s.qp[j1] - c0 - c1 * s.qp[j2], Jv = s.qv[j1] - c1 * s.qv[j2];
+      const double kk = bt.kb_jeq[e][0], bb = bt.kb_jeq[e][1], dd = imp_p2(m.jeq_solimp[e], res);
+      const double D = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
+      const double ar = -bb * Jv - kk * dd * res;
+      const double DJ1 = D * 1.0, DJ2 = D * -c1;
+      double* const dump = reinterpret_cast<double*>(s.bank_pad);
+      double* const r1 = o.jeq.rec[j1 >= NT ? j1 - NT : 0];
+      double* const r2 = o.jeq.rec[j2 >= NT ? j2 - NT : 0];
+      *(mine ? &r1[0] : dump) = DJ1; *(mine ? &r1[1] : dump) = ar; *(mine ? &r1[2] : dump) = DJ1; *(mine ? &r1[3] : dump) = -c1 * DJ1;
+      *(mine ? &r2[0] : dump) = DJ2; *(mine ? &r2[1] : dump) = ar; *(mine ? &r2[2] : dump) = -c1 * DJ2; *(mine ? &r2[3] : dump) = DJ2;
+    }
+  }
+  };
+  if constexpr (ROLE == 3) {                           // the bias-force wave: hand the generalized forces over and leave
+    if (isl) peer->tau[l] = tau_l;
+    __syncthreads();                                   // barrier X
+    PSTAMP(10);
+    __syncthreads();                                   // barrier Y
+    PSTAMP(12);
+    return;
+  }
   // ------------------------------------------------------------------ C1-C2: collision (reference: LinkModel.collide)
   int nct = 0;                                         // contacts of this env (same value in every lane of the group)
+  double (*const ctw)[8] = ROLE == 4 ? peer->con.ct : s.con.ct;      // where the contact records go (the collision wave of a split timestep: into wave B's block)
+  if constexpr (ROLE == 0 || ROLE == 4) {
   if constexpr (Lim<NV>::PACK) {
     // C2, PACKED (the kitchen: blocks of 2 - 10 pairs on 32 lanes per env): consecutive near blocks of the wave share a pass as long as their pairs fit the
     // group's LPE lanes -- lane -> (block, pair) by a walk over the pass's blocks, the block's box frame per lane.  Contacts keep the sequential order (blocks
@@ -792,7 +833,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       if (accept && slot < maxcon) {
         const V3 n = mulv(Rb, nl);
         const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
-        double* o = s.con.ct[slot];
+        double* o = ctw[slot];
         o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
         o[7] = (double)(cls + 64 * (lk + 1) + 4096 * (xl + 1));
       }
@@ -889,7 +930,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         if (hit && slot < maxcon && before < room) {
           const V3 n = mulv(Rb, nl);
           const V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
-          double* o = s.con.ct[slot];
+          double* o = ctw[slot];
           o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
           o[7] = (double)(cls + 64 * (lk + 1) + 4096 * (xl + 1));
         }
@@ -900,11 +941,21 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     }
     fence();
   }
+  }                                                    // (ROLE 0 / 4)
   PSTAMP(2);
+  if constexpr (ROLE == 4) {                           // the collision wave: the records are in wave B's block; leave their count there and go
+    fence();
+    if (sub == 0) peer->duo_nct = nct;
+    __syncthreads();                                   // barrier X
+    PSTAMP(10);
+    __syncthreads();                                   // barrier Y
+    PSTAMP(12);
+    return;
+  }
   // most over the wave (uniform loop bound for the contact phases)
   PCOUNT(20, 1); PCOUNT(21, nearw ? 1 : 0); PCOUNT(22, __popcll((unsigned long long)nearw));
   int ncmax = 0;
-  if (nearw && __any(nct > 0)) {
+  if (ROLE != 2 && nearw && __any(nct > 0)) {          // (wave B of a split timestep: after barrier X, from the count the collision wave left)
 #pragma unroll
     for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
   }
@@ -968,28 +1019,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     const double Rg = fmax((1 - dd) * m.weld_invweight[r < 3 ? 0 : 1] * rcp_nr(dd), 1e-15);
     if (sub < 6) { s.con.wD[r] = rcp_nr(Rg); s.con.war[r] = -bb * Jv - kk * dd * res; }
   }
-  if constexpr (Lim<NV>::EXTRAS) {
-    // joint couplings q[j1] - c0 - c1 q[j2] = 0: soft equality rows with two non-zeros (1 at j1, -c1 at j2).  Lane e works out coupling e's regulariser and reference
-    // acceleration (a chain of dependent operations incl. three reciprocals) and leaves, for each of its two dofs, what that dof's lane adds in K9: D J_l, aref, the
-    // term of its diagonal entry, the term of the entry it shares with its partner.  (Until round 5 every lane walked all couplings in K9, twice five LDS round trips.)
-    static_assert(NT < NV || !Lim<NV>::EXTRAS, "coupled dofs lie behind the first tree (checked by the host side)");
-    {
-      // (no branch: every lane runs the chain -- for coupling 0 beyond the count -- and only lanes e < n_jeq store: the scheduler runs it beside the weld rows' chain above)
-      const bool mine = sub < m.n_jeq;
-      const int e = mine ? sub : 0, j1 = m.jeq_joint1[e], j2 = m.jeq_joint2[e];
-      const double c0 = m.jeq_coef[e][0], c1 = m.jeq_coef[e][1];
-      const double res = s.qp[j1] - c0 - c1 * s.qp[j2], Jv = s.qv[j1] - c1 * s.qv[j2];
-      const double kk = bt.kb_jeq[e][0], bb = bt.kb_jeq[e][1], dd = imp_p2(m.jeq_solimp[e], res);
-      const double D = rcp_nr(fmax((1 - dd) * m.jeq_invweight[e] * rcp_nr(dd), 1e-15));
-      const double ar = -bb * Jv - kk * dd * res;
-      const double DJ1 = D * 1.0, DJ2 = D * -c1;
-      double* const dump = reinterpret_cast<double*>(s.bank_pad);
-      double* const r1 = s.jeq.rec[j1 >= NT ? j1 - NT : 0];
-      double* const r2 = s.jeq.rec[j2 >= NT ? j2 - NT : 0];
-      *(mine ? &r1[0] : dump) = DJ1; *(mine ? &r1[1] : dump) = ar; *(mine ? &r1[2] : dump) = DJ1; *(mine ? &r1[3] : dump) = -c1 * DJ1;
-      *(mine ? &r2[0] : dump) = DJ2; *(mine ? &r2[1] : dump) = ar; *(mine ? &r2[2] : dump) = -c1 * DJ2; *(mine ? &r2[3] : dump) = DJ2;
-    }
-  }
+  if constexpr (ROLE == 0 || ROLE == 2) jeq_records(s);      // (measured on the collision wave of a split timestep instead: 190 -> 193 ms per 256-env launch -- in the envs the launch waits for,
+                                                             // the ones in contact, that wave is the longest before barrier X)
   // connect constraints (reference: LinkModel.forward): attachments con_att1[e] / con_att2[e] coincide; rows 3 e + c, residual (p1 - p2)[c],
   // Jacobian Jp(link1, p1) - Jp(link2, p2); this lane's column first, then lane = row for the reference accelerations
   if constexpr (Lim<NV>::CONNECT) {
@@ -1055,6 +1086,18 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fr_aref = -bt.kb_lim[l][1] * s.qv[l];
   }
   PSTAMP(7);
+  if constexpr (ROLE == 2) {                           // wave B: its weld rows and coupling records are in place for wave A; mass matrix, generalized forces and contact records are in its block
+    static_assert(ROLE != 2 || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
+    fence();
+    __syncthreads();                                   // barrier X
+    PSTAMP(10);
+    tau_l = s.tau[l];
+    nct = s.duo_nct;
+    if (__any(nct > 0)) {
+#pragma unroll
+      for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
+    }
+  }
   // ------------------------------------------------------------------ C3: contact rows (reference: LinkModel.contact_rows)
   double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};       // lane c (< nct) owns contact c: edge weights and reference accelerations
   unsigned int cact = 0;                               // active pyramid edges of that contact (bits 0..3); elliptic models: its zone
@@ -1188,12 +1231,6 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   }
   fence();
   PSTAMP(6);
-  if constexpr (ROLE == 2) {                           // wave B: the weld rows are in place for wave A (barrier X), and so are wave A's generalized forces
-    static_assert(ROLE != 2 || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
-    __syncthreads();
-    PSTAMP(10);
-    tau_l = s.tau[l];
-  }
   // ------------------------------------------------------------------ K9: Hessian of the equality part, then the active-set Newton
   double hw[(Lim<NV>::EXTRAS || Lim<NV>::CONNECT) ? 1 : NV], rw;             // this lane's column of M + J6' D J6 (+ drag) and its right-hand side: registers, all iterations
                                                        // (big model: the column goes straight to LDS, s.hwst.Hw)
@@ -2065,7 +2102,7 @@ int g_lpe = 16;   // lanes per env (earl_debug_set_physics_lanes): 16 = four env
 // Small batches of the 32-lanes-per-env kernels (kitchen, minitaur): an env is a serial chain of T x frame_skip timesteps walked by one wave, so a batch that leaves
 // wave slots empty gains nothing from them -- except by giving every env a wave (solo 1: up to 4 x CUs envs) or a whole CU (solo 2: up to CUs envs) to itself.
 // earl_debug_set_solo: -1 = by batch size (default), 0 / 1 / 2 = forced (measurement, tests); the kitchen's fused rollout runs its one-env-per-workgroup launches with
-// TWO waves per env (solo 3: by default, or forced; 2 forces the one-wave form)
+// all FOUR waves on the env (solo 3: by default, or forced; 2 forces the one-wave form)
 int g_solo = -1;
 int solo_mode(int n) {
   if (g_solo >= 0) return g_solo;
@@ -2233,13 +2270,13 @@ int earl_kitchen_rollout(const void* model, const earl_collision_model* col, con
   if (cfg->n == 0 || T == 0) return EARL_OK;
   if (int rc = check_cone(col, false, (hipStream_t)stream, "kitchen_rollout")) return rc;
   KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T, solo_mode(cfg->n)};
-  if (k.solo == 2 && g_solo < 0) k.solo = 3;   // one env per workgroup: two waves per env (the dynamics half of a timestep beside the collision / rows half)
+  if (k.solo == 2 && g_solo < 0) k.solo = 3;   // one env per workgroup: four waves per env (rows | mass matrix | bias forces | collision, then one wave's active set)
   if (k.solo == 3) kitchen_rollout_kernel<true><<<cfg->n, block_for<23>(), 0, (hipStream_t)stream>>>(k);
   else kitchen_rollout_kernel<false><<<solo_grid(cfg->n, k.solo, Lim<23>::WPB), block_for<23>(), 0, (hipStream_t)stream>>>(k);
   return launched("kitchen_rollout");
 }
 
-int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (one wave), 3 = one env per workgroup, two waves (kitchen launches)
+int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (one wave), 3 = one env per workgroup, four waves (kitchen launches)
   const int prev = g_solo;
   if (mode >= -1 && mode <= 3) g_solo = mode;
   return prev;

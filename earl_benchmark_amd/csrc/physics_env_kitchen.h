@@ -82,11 +82,11 @@ __device__ __forceinline__ double kit_norm_diff(const double* a, const double* b
   }
   return sqrt(d);
 }
-// DUO (solo == 3, round 5): TWO waves of the workgroup work on its one env.  Per timestep (substep's ROLE 1 / 2): both run the kinematics; wave 1 then builds the mass matrix
-// in wave 0's LDS block and works out the bias forces while wave 0 runs the collision phases and the constraint rows; barrier X; wave 1 builds the equality Hessian (mass
-// matrix + weld + coupling rows) in wave 0's block; barrier Y; wave 0 iterates on the active set and integrates; barrier 2; wave 1 copies the new state.  Barrier 0, once per
-// env step, keeps wave 1 off the state while wave 0 does the env step's bookkeeping and hands it the step's actuator targets.  Wave 1 keeps no env state of its own and
-// stores nothing outside LDS.
+// DUO (solo == 3, round 5): the FOUR waves of the workgroup, one per SIMD, work on its one env (substep's ROLE 1 - 4).  Per timestep all run the kinematics; then, side by
+// side: wave 0 (B, owns the env) the constraint rows, wave 1 (A) the mass matrix into wave 0's LDS block, wave 2 the bias forces, wave 3 the bounding tests and the collision
+// phases (contact records into wave 0's block); barrier X; wave 1 builds the equality Hessian in wave 0's block while wave 0 does the contact rows and its right-hand side;
+// barrier Y; wave 0 iterates on the active set and integrates; barrier 2; waves 1 - 3 copy the new state.  Barrier 0, once per env step, keeps them off the state while wave 0
+// does the env step's bookkeeping and hands over the step's actuator targets.  Waves 1 - 3 keep no env state of their own and store nothing outside LDS.
 template <bool DUO>
 __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(const KitchenRolloutArgs a) {
 #pragma clang fp contract(off)
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
   stage_model(m, a.m);                                  // (ends with the workgroup barrier)
   const earl_kitchen_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-  if (a.solo >= 2 && wave > (DUO ? 1 : 0)) return;      // (after stage_model's barrier; the waves that stay are the only ones the later barriers of the DUO form count)
-  const bool role_a = DUO && wave == 1;                 // the dynamics wave: computes, stores nothing outside LDS
+  if (a.solo >= 2 && !DUO && wave > 0) return;          // (after stage_model's barrier; the DUO form keeps all four waves: its later barriers count them)
+  const bool role_a = DUO && wave >= 1;                 // the helper waves: compute, store nothing outside LDS
   const int env_raw = a.solo >= 2 ? (int)blockIdx.x : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
   const bool live = env_raw < n && (a.solo == 0 || grp == 0) && !role_a;
   const int env = env_raw < n ? env_raw : n - 1;
@@ -123,7 +123,9 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
         for (int ts = 0; ts < cfg.frame_skip; ++ts) {
           if (sub < NV) { s.qp[sub] = peer->qp[sub]; s.qv[sub] = peer->qv[sub]; }
           fence();
-          substep<NV, LPE, true, 1>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);      // (barriers X, Y inside)
+          if (wave == 1) substep<NV, LPE, true, 1>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);      // (barriers X, Y inside)
+          else if (wave == 2) substep<NV, LPE, true, 3>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);
+          else substep<NV, LPE, true, 4>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);
           __syncthreads();                              // barrier 2: wave 0 has integrated
         }
       }

@@ -179,14 +179,16 @@ struct SharedData {
 #endif
 // What only the kitchen model's block holds (an empty base class elsewhere: the other models' blocks keep their size and the 16-byte alignment of their arrays).
 // jeq.rec: joint couplings -- per coupled dof l >= NT the four numbers lane l's part of the equality Hessian takes: D J_l, the coupling's reference acceleration, the
-// term of its diagonal entry, the term of the entry it shares with its partner (K8 writes, K9 reads).  duo_ctrl, tau: two waves per env (substep's ROLE 1 / 2) -- the
-// env step's two actuator targets, published by wave B for wave A (whose K7 applies them); the generalized forces wave A computed, read by wave B after barrier X.
+// term of its diagonal entry, the term of the entry it shares with its partner (K8 writes, K9 reads).  duo_ctrl, tau, duo_nct: four waves per env (substep's ROLE 1 - 4) --
+// the env step's two actuator targets, published by wave B for the bias-force wave (whose K7 applies them); the generalized forces that wave computed and the contact
+// count the collision wave found, both read by wave B after barrier X.
 template <int NV, bool ON> struct KitchenStore { static constexpr int SIZE = 0; };
 template <int NV> struct KitchenStore<NV, true> {
   struct { double rec[NV - Lim<NV>::NT][4]; } jeq;
   double duo_ctrl[2];
   double tau[NV];
-  static constexpr int SIZE = (int)sizeof(double) * ((NV - Lim<NV>::NT) * 4 + 2 + NV);
+  int duo_nct, duo_pad_;               // the env's contact count, left by the collision wave for wave B
+  static constexpr int SIZE = (int)sizeof(double) * ((NV - Lim<NV>::NT) * 4 + 2 + NV + 1);
 };
 template <int NV>
 struct Shared : SharedData<NV>, KitchenStore<NV, Lim<NV>::EXTRAS> {

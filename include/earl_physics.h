@@ -434,9 +434,10 @@ int earl_minitaur_cfg_size(void);
 int earl_debug_set_minitaur_stepper(int tree);
 /* Small batches of the kitchen / minitaur launches (round 5; BASELINE configs[3] / [4] shard 2048 / 4096 envs over 8 GPUs: 256 / 512 per GPU).  An env is a serial chain of
  * T x frame_skip timesteps walked by one 32-lane group; the launch lasts as long as its slowest wave, and a wave's two envs wait for each other's longer branch in every
- * timestep.  -1 (default) = by batch size: n <= CUs: one env per WORKGROUP -- the kitchen with TWO waves per env (mode 3: a timestep's dynamics half and its collision /
- * constraint-row half side by side on two SIMDs, csrc/physics_env_kitchen.h), the minitaur with one; n <= 4 x CUs: one env per WAVE (the second group shadows the first
- * one's env and stores nothing); otherwise two envs per wave.  0 / 1 / 2 force a mode (2 = one env per workgroup, one wave), 3 (kitchen only) forces the two-wave form.  Results are bit-identical in every mode
+ * timestep.  -1 (default) = by batch size: n <= CUs: one env per WORKGROUP -- the kitchen with all FOUR waves on the env (mode 3: a timestep's constraint rows, mass matrix,
+ * bias forces and collision phases side by side on the CU's four SIMDs, then one wave's active set and integration; csrc/physics_env_kitchen.h), the minitaur with one; n <= 4 x CUs:
+ * one env per WAVE (the second group shadows the first one's env and stores nothing); otherwise two envs per wave.  0 / 1 / 2 force a mode (2 = one env per workgroup, one wave),
+ * 3 (kitchen only) forces the four-wave form.  Results are bit-identical in every mode
  * (tests/test_kitchen_gpu.py, tests/test_minitaur_gpu.py).  earl_debug_set_solo: kitchen launches; earl_debug_set_solo_mt: minitaur launches.  Returns the previous setting. */
 int earl_debug_set_solo(int mode);
 int earl_debug_set_solo_mt(int mode);

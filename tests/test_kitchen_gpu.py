@@ -289,8 +289,8 @@ def test_fused_rollout_equals_stepping_bit_for_bit():
 
 @pytest.mark.parametrize('n', [37, 300])
 def test_small_batch_launch_modes_are_bit_identical(n):
-  """Round 5: the kitchen launch gives every env of a small batch a wave (n <= 4 x CUs) or a whole workgroup (n <= CUs) to itself instead of packing two envs
-  into a wave (include/earl_physics.h earl_debug_set_solo).  Every mode -- and so every pairing of envs in a wave -- returns the same bits, outputs and state, through fixture
+  """Round 5: the kitchen launch gives every env of a small batch a wave (n <= 4 x CUs) or a whole workgroup (n <= CUs: one wave, or all four waves on the
+  env's timestep -- mode 3, the default there) to itself instead of packing two envs into a wave (include/earl_physics.h earl_debug_set_solo).  Every mode -- and so every pairing of envs in a wave -- returns the same bits, outputs and state, through fixture
   contacts: an env's result does not depend on which env shares its wave (the solver's coupled path gives an untouched env the bits of the uncoupled one)."""
   import torch
   from earl_benchmark_amd import _abi

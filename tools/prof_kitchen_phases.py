@@ -12,7 +12,7 @@ _abi.SIGNATURES['earl_debug_read_wave_cycles_kitchen'] = [C.c_void_p]
 _abi.SIGNATURES['earl_debug_set_prof_wave_kitchen'] = [C.c_int, C.c_int]
 from earl_benchmark_amd.envs.kitchen import Kitchen
 NAMES = ['K1-2', 'K3', 'C1-2', 'K4', 'K5', 'K6-7', 'C3', 'K8', 'K9b', 'K9a', 'wait X', 'K10', 'wait Y', '-', '-', '-']
-DUO = '--duo' in sys.argv                               # two waves per env (n <= CUs): the phases of both waves of workgroup 0, incl. their waits at the timestep's barriers
+DUO = '--duo' in sys.argv                               # four waves per env (n <= CUs): the phases of every wave of a workgroup, incl. their waits at the timestep's barriers
 nums = [int(x) for x in sys.argv[1:] if x.isdigit()]
 n, T = (nums + [2048, 100])[:2] if len(nums) < 2 else nums[:2]
 lib = _abi.load()
@@ -46,12 +46,13 @@ def show(tag, o):
 if DUO:
   n = min(n, 256)
   acts = acts[:, :n].contiguous()
-  for blk in (0, 1, 100):
+  for blk in (0, 100):
     ms, w, o = run(blk, 0)
-    print(f'kitchen rollout N={n} T={T}, two waves per env: launch {ms:.1f} ms = {ms * 1e-3 * 2.4e9 / (T * 40):.0f} cycles per timestep at 2.4 GHz')
-    show(f'workgroup {blk} wave B (rows, bias forces, active set, integration)', o)
-    ms, w, o = run(blk, 64)
-    show(f'workgroup {blk} wave A (mass matrix, equality Hessian)', o)
+    print(f'kitchen rollout N={n} T={T}, four waves per env: launch {ms:.1f} ms = {ms * 1e-3 * 2.4e9 / (T * 40):.0f} cycles per timestep at 2.4 GHz')
+    show(f'workgroup {blk} wave 0 = B (constraint rows | contact rows, active set, integration)', o)
+    for wv, what in ((1, 'A (mass matrix | equality Hessian)'), (2, 'bias forces'), (3, 'bounding tests + collision')):
+      ms, w, o = run(blk, 64 * wv)
+      show(f'workgroup {blk} wave {wv} = {what}; "wait X" / "wait Y" = its time in the two barriers of a timestep', o)
   sys.exit(0)
 ms, w, o = run(0, 0)
 print(f'kitchen rollout N={n} T={T}: launch {ms:.1f} ms = {n * T / ms / 1e3:.3f} M env-steps/s')
