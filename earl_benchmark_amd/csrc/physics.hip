@@ -488,17 +488,18 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     double nf[6] = {n.x, n.y, n.z, f.x, f.y, f.z};
     scan_desc<NV, 6>(nf, sub);
     double t = -m.damping[l] * qdl - (Sw.x * nf[0] + Sw.y * nf[1] + Sw.z * nf[2] + Sv.x * nf[3] + Sv.y * nf[4] + Sv.z * nf[5]);
-    if constexpr (Lim<NV>::EXTRAS) {
-      t -= m.stiffness[l] * (s.qp[l] - m.springref[l]);
+    if constexpr (Lim<NV>::EXTRAS) t -= m.stiffness[l] * (s.qp[l] - m.springref[l]);
+    {
       // the actuators' tables as one batch of loads (physics_math.h pin_batch), their forces added under a select: the loop with a branch per actuator was a chain of
       // LDS round trips (its joint, then its ranges and gain)
       int aj[EARL_MAXACT];
-      double at[5 * EARL_MAXACT];
+      double at[(Lim<NV>::EXTRAS ? 5 : 3) * EARL_MAXACT];
+      constexpr int AS = Lim<NV>::EXTRAS ? 5 : 3;
 #pragma unroll
       for (int ac = 0; ac < EARL_MAXACT; ++ac) {
         aj[ac] = m.act_joint[ac];
-        at[5 * ac] = m.act_ctrlrange[ac][0]; at[5 * ac + 1] = m.act_ctrlrange[ac][1]; at[5 * ac + 2] = m.act_kp[ac];
-        at[5 * ac + 3] = m.act_forcerange[ac][0]; at[5 * ac + 4] = m.act_forcerange[ac][1];
+        at[AS * ac] = m.act_ctrlrange[ac][0]; at[AS * ac + 1] = m.act_ctrlrange[ac][1]; at[AS * ac + 2] = m.act_kp[ac];
+        if constexpr (Lim<NV>::EXTRAS) { at[AS * ac + 3] = m.act_forcerange[ac][0]; at[AS * ac + 4] = m.act_forcerange[ac][1]; }      // (forcelimited actuators: the 24-dof model form)
       }
       static_assert(EARL_MAXACT == 4, "four actuator slots");
       asm volatile("" : "+v"(aj[0]), "+v"(aj[1]), "+v"(aj[2]), "+v"(aj[3]));
@@ -506,16 +507,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       const double qpl = s.qp[l];
 #pragma unroll
       for (int ac = 0; ac < EARL_MAXACT; ++ac) {
-        const double c = fmin(fmax(ctrl[ac], at[5 * ac]), at[5 * ac + 1]);
-        const double frc = fmin(fmax(at[5 * ac + 2] * (c - qpl), at[5 * ac + 3]), at[5 * ac + 4]);
+        const double c = fmin(fmax(ctrl[ac], at[AS * ac]), at[AS * ac + 1]);
+        double frc = at[AS * ac + 2] * (c - qpl);
+        if constexpr (Lim<NV>::EXTRAS) frc = fmin(fmax(frc, at[AS * ac + 3]), at[AS * ac + 4]);
         t = (ac < m.n_act && aj[ac] == l) ? t + frc : t;
-      }
-    } else {
-    for (int ac = 0; ac < m.n_act; ++ac)
-      if (m.act_joint[ac] == l) {
-        const double c = fmin(fmax(ctrl[ac], m.act_ctrlrange[ac][0]), m.act_ctrlrange[ac][1]);
-        double frc = m.act_kp[ac] * (c - s.qp[l]);
-        t += frc;
       }
     }
     tau_l = t;
