@@ -1102,11 +1102,18 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   unsigned int armmask = 0, pegmask = 0;               // two-tree model: contact slots whose Jacobian has entries in the first / second tree in SOME env of the wave
   if (ncmax > 0) {
     auto contact_jac = [&](const int c) {
-      const double* rec = s.con.ct[c];
+      // (the record as one batch of loads, then the two links' ancestor masks as another -- physics_math.h pin_batch; selected per load, the packed entry and the masks
+      // each sat under a branch with a wait of its own: four LDS round trips per contact, one after the other)
+      double rec[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) rec[k] = s.con.ct[c][k];
+      pin_batch(rec);
       const bool cv = c < nct;
-      const V3 n = selv(cv, ld3(rec + 1), V3{0, 0, 1}), p = selv(cv, ld3(rec + 4), V3{0, 0, 0});
+      const V3 n = selv(cv, V3{rec[1], rec[2], rec[3]}, V3{0, 0, 1}), p = selv(cv, V3{rec[4], rec[5], rec[6]}, V3{0, 0, 0});
       const int pk = cv ? (int)rec[7] : 0;
       const int ls = ((pk >> 6) & 63) - 1, lb = (pk >> 12) - 1;
+      unsigned int am_s = m.anc_mask[ls < 0 ? 0 : ls], am_b = m.anc_mask[lb < 0 ? 0 : lb];
+      asm volatile("" : "+v"(am_s), "+v"(am_b));
       coupled = coupled || (ls >= 0 && lb >= 0 && ((ls < NA) != (lb < NA)));
       if constexpr (TS < NT) {
         armmask |= __any(cv && ((ls >= 0 && ls < TS) || (lb >= 0 && lb < TS))) ? (1u << c) : 0u;
@@ -1119,7 +1126,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       V3 t1 = cross(n, e);
       t1 = scl(t1, rsq_nr(dot(t1, t1)));
       const V3 t2 = cross(n, t1);
-      const double w = ((ls >= 0 && ((m.anc_mask[ls < 0 ? 0 : ls] >> l) & 1u)) ? 1.0 : 0.0) - ((lb >= 0 && ((m.anc_mask[lb < 0 ? 0 : lb] >> l) & 1u)) ? 1.0 : 0.0);
+      const double w = ((ls >= 0 && ((am_s >> l) & 1u)) ? 1.0 : 0.0) - ((lb >= 0 && ((am_b >> l) & 1u)) ? 1.0 : 0.0);
       const V3 Jp = scl(add(Sv, cross(Sw, p)), w);
       if constexpr (Lim<NV>::EXTRAS) {                    // (no branch: two contacts' chains of LDS round trips run side by side below)
         double* const dump = reinterpret_cast<double*>(s.bank_pad);
