@@ -21,16 +21,25 @@ __device__ __forceinline__ double mt_leg_to_motor(const double* a, const int i) 
   return (pi + fb) + ext;
 }
 
+// motor.py's current / torque table, in constant memory: read with compile-time indices these are scalar loads into SGPRs.  As literals in the code they were
+// 64-bit constants in VGPR pairs, hoisted out of the minitaur kernel's timestep loop and -- that kernel has no register to spare -- spilled: the one scratch reload
+// inside its timestep loop (tests/test_no_scratch_in_timestep_loops.py)
+static __device__ __constant__ const double MT_CURRENT_TABLE[7] = {0, 10, 20, 30, 40, 50, 60};
+static __device__ __constant__ const double MT_TORQUE_TABLE[7] = {0, 1, 1.9, 2.45, 3.0, 3.25, 3.5};
+
 __device__ __forceinline__ double mt_interp7(double x) {   // np.interp on motor.py's current / torque table
 #pragma clang fp contract(off)
-  const double xp[7] = {0, 10, 20, 30, 40, 50, 60}, fp[7] = {0, 1, 1.9, 2.45, 3.0, 3.25, 3.5};
-  if (x >= 60.0) return 3.5;
-  double x0 = 0, f0 = 0, x1 = 10, f1 = 1;
+  const double* const xp = MT_CURRENT_TABLE;
+  const double* const fp = MT_TORQUE_TABLE;
+  double x0 = xp[0], f0 = fp[0], x1 = xp[1], f1 = fp[1];
 #pragma unroll
-  for (int j = 1; j < 6; ++j)
-    if (x >= xp[j]) { x0 = xp[j]; f0 = fp[j]; x1 = xp[j + 1]; f1 = fp[j + 1]; }
+  for (int j = 1; j < 6; ++j) {
+    const bool ge = x >= xp[j];
+    x0 = ge ? xp[j] : x0; f0 = ge ? fp[j] : f0; x1 = ge ? xp[j + 1] : x1; f1 = ge ? fp[j + 1] : f1;
+  }
   const double slope = (f1 - f0) / (x1 - x0);
-  return slope * (x - x0) + f0;
+  const double y = slope * (x - x0) + f0;
+  return x >= xp[6] ? fp[6] : y;
 }
 
 // one motor: command (desired angle, or the pwm itself in torque control), angle, velocity -> actual torque, observed torque  (motor.py:49-94)

@@ -344,57 +344,74 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   // ------------------------------------------------------------------ C1-C2: pair tests of the near blocks (lane = pair; spheres vs world-fixed boxes)
   int nct = 0;
   if (nearw) {
-    for (unsigned int rest = nearw; rest; rest &= rest - 1u) {
-      const int b = __builtin_ctz(rest);
-      const bool mine = (nearg >> b) & 1u;
-      const int pend = bt.end[b];
+    // PACKED (round 5; the form of the kitchen's C2 in physics.hip): consecutive near blocks of the wave share a pass as long as their pairs fit the group's 32 lanes --
+    // lane -> (block, pair) by a walk over the pass's blocks, the block's box frame per lane.  Contacts keep the sequential order (blocks ascending on the lanes, pairs
+    // ascending within a block) and the per-block caps, so the contact list is the one a block-per-pass loop builds.  The model's seven blocks hold 4 + 6 x 8 pairs: the
+    // three blocks under the feet, near in almost every timestep, were three passes of two LDS round trips each (5.9 k cycles per timestep) and are one now.
+    unsigned int rest = nearw;
+    while (rest) {
+      int myb = -1, myoff = 0, used = 0;
+      unsigned int taken = 0;
+      for (unsigned int r2 = rest; r2; r2 &= r2 - 1u) {
+        const int b = __builtin_ctz(r2);
+        const int sz = bt.end[b] - bt.begin[b];
+        if (used + sz > LPE) { if (used == 0) { taken = 1u << b; used = sz; if (sub < sz) { myb = b; myoff = 0; } } break; }      // (a block of more than 32 pairs goes alone; its tail is not tested: the host side refuses such tables)
+        if (sub >= used && sub < used + sz) { myb = b; myoff = used; }
+        used += sz;
+        taken |= 1u << b;
+      }
+      rest &= ~taken;
+      const bool has = myb >= 0;
+      const int b = has ? myb : 0;
+      const bool mine = has && ((nearg >> b) & 1u);
+      const int bsz = bt.end[b] - bt.begin[b];
       const V3 pb = ld3(bt.box_pos[b]);
       double Rbx[3][3];
       qmat(ldq(bt.box_quat[b]), Rbx);
       const V3 h = ld3(bt.box_half[b]);
-      int room = bt.cap[b] & 255;
-      for (int base = bt.begin[b]; base < pend; base += LPE) {
-        const int pi = base + sub < pend ? base + sub : pend - 1;
-        const bool valid = mine && base + sub < pend;
-        const int lk = pt.link[pi], cls = pt.cls[pi];
-        const double r = pt.r[pi], margin = pt.margin[pi];
-        V3 c = ld3(pt.pos[pi]);
-        {
-          double Rl[3][3];
-          qmat(ldq(s.dyn.Xq[lk < 0 ? 0 : lk]), Rl);
-          c = selv(lk < 0, c, add(ld3(s.dyn.Xp[lk < 0 ? 0 : lk]), mulv(Rl, c)));
-        }
-        const V3 x = mulvT(Rbx, vsub(c, pb));
-        V3 q{fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z)};
-        const bool outside = fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z;
-        const V3 dd = vsub(x, q);
-        const double d2 = dot(dd, dd);
-        const double inv = rsq2(outside ? d2 : 1.0);
-        const double gx = h.x - fabs(x.x), gy = h.y - fabs(x.y), gz = h.z - fabs(x.z);
-        const int axn = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
-        const double xa = pick3(x, axn), ha = pick3(h, axn), sg = xa >= 0 ? 1.0 : -1.0;
-        const V3 ni{axn == 0 ? sg : 0.0, axn == 1 ? sg : 0.0, axn == 2 ? sg : 0.0};
-        const V3 qi{axn == 0 ? sg * ha : x.x, axn == 1 ? sg * ha : x.y, axn == 2 ? sg * ha : x.z};
-        const double dist = outside ? d2 * inv - r : -(ha - fabs(xa)) - r;
-        const V3 nl = selv(outside, scl(dd, inv), ni);
-        q = selv(outside, q, qi);
-        const bool hit = valid && dist < margin;
-        const unsigned long long bal = __ballot(hit);
-        const unsigned int gb = (unsigned int)((bal >> (grp * 32)) & 0xFFFFFFFFull);
-        const int before = __popc(gb & ((1u << sub) - 1u));
-        const int total = __popc(gb);
-        const int slot = nct + before;
-        if (hit && slot < maxcon && before < room) {
-          const V3 n = mulv(Rbx, nl);
-          const V3 p = add(add(pb, mulv(Rbx, q)), scl(n, 0.5 * dist));
-          double* o = s.ct[slot];
-          o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
-          o[7] = (double)(cls + 64 * (lk + 1));
-        }
-        const int took = total < room ? total : room;
-        room -= took;
-        nct = nct + took < maxcon ? nct + took : maxcon;
+      const int room = bt.cap[b] & 255;
+      const int pi = has ? bt.begin[b] + (sub - myoff < bsz ? sub - myoff : bsz - 1) : 0;
+      const bool valid = mine && sub - myoff < bsz;
+      const int lk = pt.link[pi], cls = pt.cls[pi];
+      const double r = pt.r[pi], margin = pt.margin[pi];
+      V3 c = ld3(pt.pos[pi]);
+      {
+        double Rl[3][3];
+        qmat(ldq(s.dyn.Xq[lk < 0 ? 0 : lk]), Rl);
+        c = selv(lk < 0, c, add(ld3(s.dyn.Xp[lk < 0 ? 0 : lk]), mulv(Rl, c)));
       }
+      const V3 x = mulvT(Rbx, vsub(c, pb));
+      V3 q{fmin(fmax(x.x, -h.x), h.x), fmin(fmax(x.y, -h.y), h.y), fmin(fmax(x.z, -h.z), h.z)};
+      const bool outside = fabs(x.x) > h.x || fabs(x.y) > h.y || fabs(x.z) > h.z;
+      const V3 dd = vsub(x, q);
+      const double d2 = dot(dd, dd);
+      const double inv = rsq2(outside ? d2 : 1.0);
+      const double gx = h.x - fabs(x.x), gy = h.y - fabs(x.y), gz = h.z - fabs(x.z);
+      const int axn = (gx <= gy && gx <= gz) ? 0 : (gy <= gz ? 1 : 2);
+      const double xa = pick3(x, axn), ha = pick3(h, axn), sg = xa >= 0 ? 1.0 : -1.0;
+      const V3 ni{axn == 0 ? sg : 0.0, axn == 1 ? sg : 0.0, axn == 2 ? sg : 0.0};
+      const V3 qi{axn == 0 ? sg * ha : x.x, axn == 1 ? sg * ha : x.y, axn == 2 ? sg * ha : x.z};
+      const double dist = outside ? d2 * inv - r : -(ha - fabs(xa)) - r;
+      const V3 nl = selv(outside, scl(dd, inv), ni);
+      q = selv(outside, q, qi);
+      const bool hit = valid && dist < margin;
+      const unsigned long long bal = __ballot(hit);
+      const unsigned int gb = (unsigned int)((bal >> (grp * 32)) & 0xFFFFFFFFull);
+      const unsigned int seg = has ? (unsigned int)(((1ull << bsz) - 1ull) << myoff) : 0u;      // the lanes of this lane's block
+      const int before_blk = __popc(gb & seg & ((1u << sub) - 1u));
+      const bool accept = hit && before_blk < room;
+      const unsigned long long bal2 = __ballot(accept);
+      const unsigned int ga = (unsigned int)((bal2 >> (grp * 32)) & 0xFFFFFFFFull);
+      const int slot = nct + __popc(ga & ((1u << sub) - 1u));
+      if (accept && slot < maxcon) {
+        const V3 n = mulv(Rbx, nl);
+        const V3 p = add(add(pb, mulv(Rbx, q)), scl(n, 0.5 * dist));
+        double* o = s.ct[slot];
+        o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
+        o[7] = (double)(cls + 64 * (lk + 1));
+      }
+      const int took = __popc(ga);
+      nct = nct + took < maxcon ? nct + took : maxcon;
     }
     fence();
   }
