@@ -101,7 +101,8 @@ template <int LPE> __device__ __forceinline__ bool group_any(const bool pred, co
 // workgroup, one per SIMD, that work on the same env, each in its own LDS block; all run the kinematics (K1 - K3).  Wave B (ROLE 2) owns the env: constraint rows (K8) before
 // barrier X, then the contact rows (C3), the active-set iteration and the integration (K9, K10).  Before barrier X: wave A (ROLE 1) builds the mass matrix into B's block (K4, K5),
 // ROLE 3 works out the bias forces (K6, K7) and hands B its lanes' generalized forces, ROLE 4 runs the bounding tests and the collision phases (C0 - C2) and leaves the contact
-// records and their count in B's block.  Between X and Y wave A builds the equality Hessian in B's block.  Same expressions, same inputs, same order: same bits.
+// records and their count in B's block.  Between X and Y wave A builds the equality Hessian in B's block; after Y, while B iterates on the active set, A factorises the arm's
+// block of M + dt B and inverts the fixtures' scalars for K10 (barrier Z: B picks them up from A's block).  Same expressions, same inputs, same order: same bits.
 template <int NV, int LPE, bool INTEGRATE, int ROLE = 0>
 __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV>::T& m, const BlkTable<Lim<NV>::MB, Lim<NV>::KBT>& bt, const earl_collision_model* __restrict__ col, const int sub,
                                         const int grp, const Q4 mq, const double (&ctrl)[EARL_MAXACT], const bool warm, double* qacc_out,
@@ -719,6 +720,28 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     PSTAMP(9);
     __syncthreads();                                   // barrier Y
     PSTAMP(12);
+    // ... and, while wave B iterates on the active set, K10's factorisation -- the arm's block of M + dt B and the fixtures' reciprocals depend on nothing B still has to work
+    // out -- left in THIS wave's block (its equality-Hessian store is otherwise unused; wave B holds a pointer to it).  The same chol_regs on the same entries: the same factor.
+    {
+      constexpr int NL = NA * (NA + 1) / 2;
+      static_assert(NL + (NV - NA) <= (int)(sizeof(s.hwst.Hw.v) / sizeof(double)), "factor and reciprocals fit the store");
+      double Lk[NL];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) Lk[i * (i + 1) / 2 + j] = peer->M.lo(i, j);
+        Lk[i * (i + 1) / 2 + i] = peer->M.lo(i, i) + pinned(dt * m.damping[i]);      // (the rounded product K10 sends through LDS)
+      }
+      pin_batch(Lk);
+      chol_regs<NA, NA, true>(Lk);
+      double* const dump = reinterpret_cast<double*>(s.bank_pad);
+#pragma unroll
+      for (int e = 0; e < NL; ++e) *(sub == (e % LPE) ? &s.hwst.Hw.v[e] : dump) = Lk[e];
+      const int lf = l >= NA ? l : NA;
+      *((isl && l >= NA) ? &s.hwst.Hw.v[NL + lf - NA] : dump) = rcp_nr(peer->M.lo(lf, lf) + pinned(dt * m.damping[lf]));
+      fence();
+    }
+    __syncthreads();                                   // barrier Z
     return;
   }
   auto jeq_records = [&](Shared<NV>& o) {      // (`o`: the block that takes the records -- wave B's when the collision wave of a split timestep works them out)
@@ -751,6 +774,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     PSTAMP(10);
     __syncthreads();                                   // barrier Y
     PSTAMP(12);
+    __syncthreads();                                   // barrier Z
     return;
   }
   // ------------------------------------------------------------------ C1-C2: collision (reference: LinkModel.collide)
@@ -945,6 +969,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     PSTAMP(10);
     __syncthreads();                                   // barrier Y
     PSTAMP(12);
+    __syncthreads();                                   // barrier Z
     return;
   }
   // most over the wave (uniform loop bound for the contact phases)
@@ -1864,6 +1889,30 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i];
     if constexpr (Lim<NV>::EXTRAS) pin_batch(a);
+    if constexpr (ROLE == 2) {
+      // split timestep: wave A factorised the arm's block and inverted the fixtures' scalars while this wave iterated (barrier Z: they are in its block, `peer`)
+      constexpr int NL = NA * (NA + 1) / 2;
+      __syncthreads();                                 // barrier Z
+      const double* const kf = peer->hwst.Hw.v;
+      double Lk[NL], y[NA];
+#pragma unroll
+      for (int e = 0; e < NL; ++e) Lk[e] = kf[e];
+      const int lf = l >= NA ? l : NA;
+      const double ki = kf[NL + lf - NA];
+      pin_batch(Lk);
+      double gl = 0;
+#pragma unroll
+      for (int i = NA; i < NV; ++i) gl = i == lf ? a[i] : gl;
+      *((isl && l >= NA) ? &s.con.rc[l] : reinterpret_cast<double*>(s.bank_pad)) = gl * ki;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) y[i] = a[i];
+      solve_regs<NA, NA>(Lk, y);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[i] = y[i];
+      fence();
+#pragma unroll
+      for (int i = NA; i < NV; ++i) a[i] = s.con.rc[i];
+    } else {
     // the implicit-damping diagonal dt * B goes through LDS in both forms: as an operand of the add in load_tri the product would be contracted
     // into an fma, in chol_coop it is a rounded product -- the two door builds must agree to the bit
     if (isl) s.con.dl[l] = dt * m.damping[l];
@@ -1888,6 +1937,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       chol_regs<NV, NA, (NV > 10)>(L);
       solve_regs<NV, NA>(L, a);
     }
+    }                                                  // (ROLE != 2)
     }
     double al = 0;
 #pragma unroll

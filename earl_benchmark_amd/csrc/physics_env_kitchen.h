@@ -85,7 +85,8 @@ __device__ __forceinline__ double kit_norm_diff(const double* a, const double* b
 // DUO (solo == 3, round 5): the FOUR waves of the workgroup, one per SIMD, work on its one env (substep's ROLE 1 - 4).  Per timestep all run the kinematics; then, side by
 // side: wave 0 (B, owns the env) the constraint rows, wave 1 (A) the mass matrix into wave 0's LDS block, wave 2 the bias forces, wave 3 the bounding tests and the collision
 // phases (contact records into wave 0's block); barrier X; wave 1 builds the equality Hessian in wave 0's block while wave 0 does the contact rows and its right-hand side;
-// barrier Y; wave 0 iterates on the active set and integrates; barrier 2; waves 1 - 3 copy the new state.  Barrier 0, once per env step, keeps them off the state while wave 0
+// barrier Y; wave 0 iterates on the active set while wave 1 factorises for the integration (K10's arm block and fixture scalars: barrier Z); wave 0 integrates; barrier 2;
+// waves 1 - 3 copy the new state.  Barrier 0, once per env step, keeps them off the state while wave 0
 // does the env step's bookkeeping and hands over the step's actuator targets.  Waves 1 - 3 keep no env state of their own and store nothing outside LDS.
 template <bool DUO>
 __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(const KitchenRolloutArgs a) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
         for (int ts = 0; ts < cfg.frame_skip; ++ts) {
           if (sub < NV) { s.qp[sub] = peer->qp[sub]; s.qv[sub] = peer->qv[sub]; }
           fence();
-          if (wave == 1) substep<NV, LPE, true, 1>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);      // (barriers X, Y inside)
+          if (wave == 1) substep<NV, LPE, true, 1>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);      // (barriers X, Y, Z inside)
           else if (wave == 2) substep<NV, LPE, true, 3>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);
           else substep<NV, LPE, true, 4>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);
           __syncthreads();                              // barrier 2: wave 0 has integrated
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
       if (sub < 2) s.duo_ctrl[sub] = ctrl[sub];
       __syncthreads();                                  // barrier 0
       for (int ts = 0; ts < cfg.frame_skip; ++ts) {
-        substep<NV, LPE, true, 2>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr);                // (barriers X, Y inside)
+        substep<NV, LPE, true, 2>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr, &sh[EPW + grp]);     // (barriers X, Y, Z inside; `peer`: wave 1's block, where it leaves K10's factor)
         __syncthreads();                                // barrier 2
       }
     } else

@@ -270,6 +270,6 @@ def test_two_rank_strong_scaling_lines(tmp_path, which, n_global):
   # what the kernels' layout predicts for the real shapes (one round of 2048 resident envs per GPU): stated in the line
   # the line says what the kernels' layout gives, from MEASURED shard launches (profiles/r05_kitchen_small_batch.txt), never 'x8'
   k8, m8 = bench.predicted_strong_scaling('kitchen', 2048, 8), bench.predicted_strong_scaling('minitaur', 4096, 8)
-  assert 1.0 <= k8['predicted_speedup_vs_1_gpu'] < 1.7 and 2.0 <= m8['predicted_speedup_vs_1_gpu'] < 2.5 and k8['basis'].startswith('measured')
+  assert 1.0 <= k8['predicted_speedup_vs_1_gpu'] < 1.9 and 2.0 <= m8['predicted_speedup_vs_1_gpu'] < 2.5 and k8['basis'].startswith('measured')
   assert bench.predicted_strong_scaling('kitchen', 8192, 2)['predicted_speedup_vs_1_gpu'] == 2.0       # other batch sizes: by launch rounds
   assert cfg['predicted_scaling']['envs_per_gpu'] == -(-n_global // world)
