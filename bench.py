@@ -644,7 +644,7 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
 
 # one GPU, reset + one fused launch of a SHARD of the strong-scaling batches, relative to the full batch (tools/kitchen_small_batch.py on an MI355X, profiles/r05_kitchen_small_batch.txt):
 # what `world` GPUs would deliver if every shard ran like this one (no collective on the data path; the job's one all-gather is 16 KB)
-MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.96, 4: 0.90, 8: 0.61}, 'minitaur': {1: 1.00, 2: 0.50, 4: 0.47, 8: 0.46}}      # (kitchen at 256 envs: four waves per env)
+MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.95, 4: 0.77, 8: 0.61}, 'minitaur': {1: 1.00, 2: 0.50, 4: 0.47, 8: 0.46}}      # (kitchen at 256 envs: four waves per env; at 512: two)
 
 
 def predicted_strong_scaling(workload, n_global, world):

@@ -112,6 +112,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   // The fixed point is the same and so are the bits of the result (the last iteration builds the same Hessian from the same set); what changes is
   // the number of iterations: 1.81 -> 1.38 per timestep in contact for the door under random actions (oracle/physics_oracle.c g_newton_stats).
   static_assert(NV <= LPE, "one lane per link");
+  // which parts of the timestep this instantiation runs (ROLE 5 / 6: the TWO-wave split of batches with two envs per CU -- 5 = mass matrix + bias forces + equality
+  // Hessian + K10's factor, 6 = the owner incl. the collision phases)
+  constexpr bool R_OWNER = ROLE == 2 || ROLE == 6;                     // constraint rows, contact rows, active set, integration
+  constexpr bool R_COL = ROLE == 0 || ROLE == 4 || ROLE == 6;           // C0 - C2
+  constexpr bool R_MASS = ROLE == 0 || ROLE == 1 || ROLE == 5;          // K4, K5
+  constexpr bool R_BIAS = ROLE == 0 || ROLE == 3 || ROLE == 5;          // K6, K7
+  constexpr bool R_HELPS_HW = ROLE == 1 || ROLE == 5;                   // builds the equality Hessian and K10's factor for the owner
   constexpr int MC = Lim<NV>::MC, NA = Lim<NV>::NA, NT = Lim<NV>::NT;
   static_assert(MC <= LPE, "one lane per contact");
   const int maxcon = bt.max_con < MC ? bt.max_con : MC;
@@ -203,7 +210,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   using BlkMask = std::conditional_t<(Lim<NV>::MB > 32), unsigned long long, unsigned int>;
   BlkMask nearw = 0;                                   // blocks with a near bounding test in ANY env of the wave
   BlkMask nearg = 0;                                   // ... in this env
-  for (int cb = 0; (ROLE == 0 || ROLE == 4) && cb < bt.n_blk; cb += LPE) {
+  for (int cb = 0; R_COL && cb < bt.n_blk; cb += LPE) {
     // C0: bounding test per block, lane = block (LPE blocks per pass)
     const int b = cb + sub < bt.n_blk ? cb + sub : 0;
     // (two batches of loads -- the block's table entries, then the frames of the two links they name -- each ONE LDS round trip: physics_math.h pin_batch.  Left to
@@ -358,8 +365,8 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   constexpr int TS = Lim<NV>::TS, KT = TS < NT ? (TS > NT - TS ? TS : NT - TS) : NT;
   const int tbase = (TS < NT && l >= TS) ? TS : 0, tend = (TS < NT && l < TS) ? TS : NT;
   double tau_l = 0.0;                                  // this lane's applied + passive - bias force (K7; ROLE 2: handed over by wave A)
-  SymLds<NV>& Mw = ROLE == 1 ? peer->M : s.M;          // where K5 puts the mass matrix
-  if constexpr (ROLE == 0 || ROLE == 1) {
+  SymLds<NV>& Mw = R_HELPS_HW ? peer->M : s.M;         // where K5 puts the mass matrix
+  if constexpr (R_MASS) {
   // ------------------------------------------------------------------ K4: composite inertia = masked subtree sum; FS = Ic S
   if constexpr (Lim<NV>::ARMSCAN) {
     double acc[10];
@@ -460,7 +467,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   fence();
   PSTAMP(4);
   }                                                    // (ROLE 0 / 1)
-  if constexpr (ROLE == 0 || ROLE == 3) {
+  if constexpr (R_BIAS) {
   // ------------------------------------------------------------------ K6: bias forces (RNE by masked sums)
   if constexpr (Lim<NV>::ARMSCAN) {
     // velocities V_l = sum over the ancestors of S_a qd_a, bias accelerations A_l = -g + sum of crossm(V) S_a qd_a, and the subtree sums of the bias forces:
@@ -707,9 +714,10 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       *((isl && l >= NT && pl > l) ? &o.hwst.Hw.lo(pl > l ? pl : l, l) : dump) = ho;      // (the lower triangle: the lane with the smaller index of a pair stores the shared entry)
     }
   };
-  if constexpr (ROLE == 1) {
+  if constexpr (R_HELPS_HW) {
     // wave A: the mass matrix went straight to the peer's block; when wave B's weld rows are there (barrier X) build the equality Hessian from both, in the peer's block; leave
-    static_assert(ROLE != 1 || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
+    static_assert(!R_HELPS_HW || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
+    if constexpr (ROLE == 5) { if (isl) peer->tau[l] = tau_l; }      // (two-wave split: the bias forces are this wave's too)
     __syncthreads();                                   // barrier X
     PSTAMP(10);
     double DJ[6];
@@ -780,7 +788,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   // ------------------------------------------------------------------ C1-C2: collision (reference: LinkModel.collide)
   int nct = 0;                                         // contacts of this env (same value in every lane of the group)
   double (*const ctw)[8] = ROLE == 4 ? peer->con.ct : s.con.ct;      // where the contact records go (the collision wave of a split timestep: into wave B's block)
-  if constexpr (ROLE == 0 || ROLE == 4) {
+  if constexpr (R_COL) {
   if constexpr (Lim<NV>::PACK) {
     // C2, PACKED (the kitchen: blocks of 2 - 10 pairs on 32 lanes per env): consecutive near blocks of the wave share a pass as long as their pairs fit the
     // group's LPE lanes -- lane -> (block, pair) by a walk over the pass's blocks, the block's box frame per lane.  Contacts keep the sequential order (blocks
@@ -1039,7 +1047,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     const double Rg = fmax((1 - dd) * m.weld_invweight[r < 3 ? 0 : 1] * rcp_nr(dd), 1e-15);
     if (sub < 6) { s.con.wD[r] = rcp_nr(Rg); s.con.war[r] = -bb * Jv - kk * dd * res; }
   }
-  if constexpr (ROLE == 0 || ROLE == 2) jeq_records(s);      // (measured on the collision wave of a split timestep instead: 190 -> 193 ms per 256-env launch -- in the envs the launch waits for,
+  if constexpr (ROLE == 0 || R_OWNER) jeq_records(s);      // (measured on the collision wave of a split timestep instead: 190 -> 193 ms per 256-env launch -- in the envs the launch waits for,
                                                              // the ones in contact, that wave is the longest before barrier X)
   // connect constraints (reference: LinkModel.forward): attachments con_att1[e] / con_att2[e] coincide; rows 3 e + c, residual (p1 - p2)[c],
   // Jacobian Jp(link1, p1) - Jp(link2, p2); this lane's column first, then lane = row for the reference accelerations
@@ -1106,16 +1114,18 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
     fr_aref = -bt.kb_lim[l][1] * s.qv[l];
   }
   PSTAMP(7);
-  if constexpr (ROLE == 2) {                           // wave B: its weld rows and coupling records are in place for wave A; mass matrix, generalized forces and contact records are in its block
-    static_assert(ROLE != 2 || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
+  if constexpr (R_OWNER) {                             // wave B: its weld rows and coupling records are in place for wave A; mass matrix, generalized forces and contact records are in its block
+    static_assert(!R_OWNER || (Lim<NV>::EXTRAS && Lim<NV>::ARMSCAN), "the split timestep is the kitchen model's");
     fence();
     __syncthreads();                                   // barrier X
     PSTAMP(10);
     tau_l = s.tau[l];
-    nct = s.duo_nct;
-    if (__any(nct > 0)) {
+    if constexpr (ROLE == 2) {                         // (four-wave split: the collision wave's count; the two-wave split's owner ran the collision itself)
+      nct = s.duo_nct;
+      if (__any(nct > 0)) {
 #pragma unroll
-      for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
+        for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
+      }
     }
   }
   // ------------------------------------------------------------------ C3: contact rows (reference: LinkModel.contact_rows)
@@ -1302,12 +1312,12 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
         const double* const rec = s.jeq.rec[l >= NT ? l - NT : 0];
         g = fma(rec[0], rec[1], g);
       }
-      if constexpr (ROLE != 2) hw_extras(s, DJ);        // (split timestep: wave A's, in place at barrier Y)
+      if constexpr (!R_OWNER) hw_extras(s, DJ);         // (split timestep: wave A's, in place at barrier Y)
     }
     rw = g;
   }
   PSTAMP(9);
-  if constexpr (ROLE == 2) { __syncthreads(); PSTAMP(12); }      // barrier Y: mass matrix and equality Hessian are wave A's
+  if constexpr (R_OWNER) { __syncthreads(); PSTAMP(12); }       // barrier Y: mass matrix and equality Hessian are wave A's
   coupled = __any(coupled);
   if constexpr (NV > 10) { if (warm) lim_start = lim_inst && ((lim_lo ? s.aprev[l] : -s.aprev[l]) - lim_aref < 0); }
   bool act = lim_start;                                // (dry-friction rows keep their cold start, the quadratic zone: from a_prev's zones the
@@ -1889,7 +1899,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #pragma unroll
     for (int i = 0; i < NV; ++i) a[i] = s.con.rc[i];
     if constexpr (Lim<NV>::EXTRAS) pin_batch(a);
-    if constexpr (ROLE == 2) {
+    if constexpr (R_OWNER) {
       // split timestep: wave A factorised the arm's block and inverted the fixtures' scalars while this wave iterated (barrier Z: they are in its block, `peer`)
       constexpr int NL = NA * (NA + 1) / 2;
       __syncthreads();                                 // barrier Z
@@ -2323,14 +2333,20 @@ int earl_kitchen_rollout(const void* model, const earl_collision_model* col, con
   if (int rc = check_cone(col, false, (hipStream_t)stream, "kitchen_rollout")) return rc;
   KitchenRolloutArgs k{model, col, *params, *cfg, *st, *out, action, T, solo_mode(cfg->n)};
   if (k.solo == 2 && g_solo < 0) k.solo = 3;   // one env per workgroup: four waves per env (rows | mass matrix | bias forces | collision, then one wave's active set)
-  if (k.solo == 3) kitchen_rollout_kernel<true><<<cfg->n, block_for<23>(), 0, (hipStream_t)stream>>>(k);
-  else kitchen_rollout_kernel<false><<<solo_grid(cfg->n, k.solo, Lim<23>::WPB), block_for<23>(), 0, (hipStream_t)stream>>>(k);
+  if (g_solo < 0 && k.solo == 1) {               // at most two envs per CU: two envs per workgroup, two waves per env
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cfg->n <= 2 * cus) k.solo = 4;
+  }
+  if (k.solo == 3) kitchen_rollout_kernel<1><<<cfg->n, block_for<23>(), 0, (hipStream_t)stream>>>(k);
+  else if (k.solo == 4) kitchen_rollout_kernel<2><<<(cfg->n + 1) / 2, block_for<23>(), 0, (hipStream_t)stream>>>(k);
+  else kitchen_rollout_kernel<0><<<solo_grid(cfg->n, k.solo, Lim<23>::WPB), block_for<23>(), 0, (hipStream_t)stream>>>(k);
   return launched("kitchen_rollout");
 }
 
-int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (one wave), 3 = one env per workgroup, four waves (kitchen launches)
+int earl_debug_set_solo(int mode) {          // -1 = by batch size, 0 = two envs per wave, 1 = one env per wave, 2 = one env per workgroup (one wave), 3 = one env per workgroup, four waves, 4 = two envs per workgroup, two waves each (kitchen launches)
   const int prev = g_solo;
-  if (mode >= -1 && mode <= 3) g_solo = mode;
+  if (mode >= -1 && mode <= 4) g_solo = mode;
   return prev;
 }
 #ifdef EARL_PHYS_PROF

@@ -88,7 +88,9 @@ __device__ __forceinline__ double kit_norm_diff(const double* a, const double* b
 // barrier Y; wave 0 iterates on the active set while wave 1 factorises for the integration (K10's arm block and fixture scalars: barrier Z); wave 0 integrates; barrier 2;
 // waves 1 - 3 copy the new state.  Barrier 0, once per env step, keeps them off the state while wave 0
 // does the env step's bookkeeping and hands over the step's actuator targets.  Waves 1 - 3 keep no env state of their own and store nothing outside LDS.
-template <bool DUO>
+// DUO == 2 (solo == 4: batches of at most TWO envs per CU): two envs per workgroup, two waves each -- waves 0 / 2 own an env and run its collision phases too (ROLE 6), waves
+// 1 / 3 do its mass matrix, bias forces, equality Hessian and K10's factor (ROLE 5); the same barriers, shared by the workgroup's two envs.
+template <int DUO>
 __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(const KitchenRolloutArgs a) {
 #pragma clang fp contract(off)
   constexpr int NV = 23, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
@@ -102,20 +104,20 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
   stage_model(m, a.m);                                  // (ends with the workgroup barrier)
   const earl_kitchen_cfg& cfg = a.cfg;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
-  if (a.solo >= 2 && !DUO && wave > 0) return;          // (after stage_model's barrier; the DUO form keeps all four waves: its later barriers count them)
-  const bool role_a = DUO && wave >= 1;                 // the helper waves: compute, store nothing outside LDS
-  const int env_raw = a.solo >= 2 ? (int)blockIdx.x : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
+  if (a.solo >= 2 && DUO == 0 && wave > 0) return;          // (after stage_model's barrier; the DUO form keeps all four waves: its later barriers count them)
+  const bool role_a = DUO == 1 ? wave >= 1 : (DUO == 2 && (wave & 1));      // the helper waves: compute, store nothing outside LDS
+  const int env_raw = a.solo >= 2 ? (DUO == 2 ? (int)(blockIdx.x * 2 + (wave >> 1)) : (int)blockIdx.x) : (a.solo == 1 ? (int)(blockIdx.x * WPB + wave) : (int)((blockIdx.x * WPB + wave) * EPW + grp));
   const bool live = env_raw < n && (a.solo == 0 || grp == 0) && !role_a;
   const int env = env_raw < n ? env_raw : n - 1;
   Shared<NV>& s = sh[wave * EPW + grp];
-  Shared<NV>* const peer = DUO ? &sh[grp] : nullptr;    // wave 0's block of the same 32-lane group
+  Shared<NV>* const peer = DUO == 1 ? &sh[grp] : (DUO == 2 ? &sh[(wave ^ 1) * EPW + grp] : nullptr);      // helpers: the owner's block of the same 32-lane group; owners: their helper's (wave 1 of the four-wave form)
   load_state<NV>(s, m, a.st.qpos + (size_t)env * NV, a.st.qvel + (size_t)env * NV, sub);
   for (int k = sub; k < (int)(sizeof(s.M.v) / sizeof(double)); k += LPE) s.M.v[k] = 0.0;      // (entries between different trees are never written, K5)
   for (int k = sub; k < (int)(sizeof(s.hwst.Hw.v) / sizeof(double)); k += LPE) s.hwst.Hw.v[k] = 0.0;   // (nor the structural zeros of the equality Hessian, K9)
   if (sub < 3) s.mocap[sub] = a.st.mocap_pos[(size_t)env * 3 + sub];
   fence();
   const Q4 mq = ldq(cfg.mocap_quat_dev);
-  if constexpr (DUO) {
+  if constexpr (DUO != 0) {
     __syncthreads();                                    // wave 0's mass matrix is zeroed before wave 1 writes into it
     if (role_a) {
       for (int t = 0; t < a.T; ++t) {
@@ -124,7 +126,8 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
         for (int ts = 0; ts < cfg.frame_skip; ++ts) {
           if (sub < NV) { s.qp[sub] = peer->qp[sub]; s.qv[sub] = peer->qv[sub]; }
           fence();
-          if (wave == 1) substep<NV, LPE, true, 1>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);      // (barriers X, Y, Z inside)
+          if constexpr (DUO == 2) substep<NV, LPE, true, 5>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);      // (barriers X, Y, Z inside)
+          else if (wave == 1) substep<NV, LPE, true, 1>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);
           else if (wave == 2) substep<NV, LPE, true, 3>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);
           else substep<NV, LPE, true, 4>(s, m, bt, a.col, sub, grp, mq, ctrl_a, false, nullptr, nullptr, peer);
           __syncthreads();                              // barrier 2: wave 0 has integrated
@@ -160,11 +163,12 @@ __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(cons
     const double ctrl[EARL_MAXACT] = {s.kit.targets[0], s.kit.targets[1], 0, 0};      // do_simulation: ctrl[i] = targets[i] for i < nu = 2
     if (sub < 3 && live) a.st.mocap_pos[(size_t)env * 3 + sub] = s.mocap[sub];
     fence();
-    if constexpr (DUO) {
+    if constexpr (DUO != 0) {
       if (sub < 2) s.duo_ctrl[sub] = ctrl[sub];
       __syncthreads();                                  // barrier 0
       for (int ts = 0; ts < cfg.frame_skip; ++ts) {
-        substep<NV, LPE, true, 2>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr, &sh[EPW + grp]);     // (barriers X, Y, Z inside; `peer`: wave 1's block, where it leaves K10's factor)
+        if constexpr (DUO == 2) substep<NV, LPE, true, 6>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr, peer);     // (barriers X, Y, Z inside; `peer`: its helper's block, where that leaves K10's factor)
+        else substep<NV, LPE, true, 2>(s, m, bt, a.col, sub, grp, mq, ctrl, ts > 0, nullptr, nullptr, &sh[EPW + grp]);
         __syncthreads();                                // barrier 2
       }
     } else

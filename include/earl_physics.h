@@ -436,8 +436,9 @@ int earl_debug_set_minitaur_stepper(int tree);
  * T x frame_skip timesteps walked by one 32-lane group; the launch lasts as long as its slowest wave, and a wave's two envs wait for each other's longer branch in every
  * timestep.  -1 (default) = by batch size: n <= CUs: one env per WORKGROUP -- the kitchen with all FOUR waves on the env (mode 3: a timestep's constraint rows, mass matrix,
  * bias forces and collision phases side by side on the CU's four SIMDs, then one wave's active set and integration; csrc/physics_env_kitchen.h), the minitaur with one; n <= 4 x CUs:
- * one env per WAVE (the second group shadows the first one's env and stores nothing); otherwise two envs per wave.  0 / 1 / 2 force a mode (2 = one env per workgroup, one wave),
- * 3 (kitchen only) forces the four-wave form.  Results are bit-identical in every mode
+ * one env per WAVE (the second group shadows the first one's env and stores nothing) -- the kitchen, for n <= 2 x CUs, with TWO waves per env, two envs per workgroup (mode 4: the
+ * owner wave runs collision, rows, active set and integration, its helper the mass matrix, bias forces, equality Hessian and the integration's factor); otherwise two envs per wave.
+ * 0 / 1 / 2 force a mode (2 = one env per workgroup, one wave), 3 / 4 (kitchen only) force the four-wave / two-wave form.  Results are bit-identical in every mode
  * (tests/test_kitchen_gpu.py, tests/test_minitaur_gpu.py).  earl_debug_set_solo: kitchen launches; earl_debug_set_solo_mt: minitaur launches.  Returns the previous setting. */
 int earl_debug_set_solo(int mode);
 int earl_debug_set_solo_mt(int mode);

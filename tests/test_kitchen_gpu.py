@@ -302,8 +302,8 @@ def test_small_batch_launch_modes_are_bit_identical(n):
   acts[:, ::2, 2] -= 0.6                                   # every other hand goes down to the knobs: wave-mates on different solver paths in the packed mode
   res = {}
   try:
-    for mode in (0, 1, 2, 3, -1):
-      assert lib.earl_debug_set_solo(mode) in (-1, 0, 1, 2, 3)
+    for mode in (0, 1, 2, 3, 4, -1):
+      assert lib.earl_debug_set_solo(mode) in (-1, 0, 1, 2, 3, 4)
       env = Kitchen(num_envs=n, seed=21)
       env.reset()
       out = env.rollout(acts)
@@ -313,7 +313,7 @@ def test_small_batch_launch_modes_are_bit_identical(n):
   ref = res[0]
   touched = int((ref[0]['obs'][:, :, 9:23] - ref[0]['obs'][0, :, 9:23]).abs().amax(0).amax(1).gt(1e-3).sum())
   assert touched >= 3, touched                                 # fixtures were moved: contacts happened
-  for mode in (1, 2, 3, -1):
+  for mode in (1, 2, 3, 4, -1):
     for k in ref[0]:
       a, b = ref[0][k], res[mode][0][k]
       assert torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a, b.view(torch.int64) if b.dtype == torch.float64 else b), (mode, k)

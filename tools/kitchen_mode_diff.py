@@ -17,14 +17,14 @@ acts = torch.rand(T, n, 9, generator=g, device='cuda') * 2 - 1
 acts[:, :40, 2] -= 0.6
 res = {}
 try:
-  for mode in (0, 1, 2, 3):
+  for mode in (0, 1, 2, 3, 4):
     lib.earl_debug_set_solo(mode)
     env = Kitchen(num_envs=n, seed=21)
     env.reset()
     res[mode] = torch.nan_to_num(env.rollout(acts)['obs'].clone(), nan=123.0)
 finally:
   lib.earl_debug_set_solo(-1)
-for mode, name in ((1, 'one env per wave'), (2, 'one env per workgroup'), (3, 'four waves per env')):
+for mode, name in ((1, 'one env per wave'), (2, 'one env per workgroup'), (3, 'four waves per env'), (4, 'two waves per env, two envs per workgroup')):
   bad = (res[mode].view(torch.int64) != res[0].view(torch.int64)).nonzero()
   if len(bad) == 0:
     print(f'{name}: the bits of the packed launch ({n} envs x {T} env steps)')

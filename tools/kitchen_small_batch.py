@@ -41,11 +41,11 @@ for name, make, N, T, adim in (('kitchen', lambda n: Kitchen(num_envs=n, seed=12
   for w in (1, 2, 4, 8):
     n = N // w
     keep = []
-    times = {mode: run(make, n, T, adim, mode=mode, keep=keep) for mode in ((0, 1, 2, 3, -1) if name == 'kitchen' and n <= 256 else (0, 1, 2, -1))}
+    times = {mode: run(make, n, T, adim, mode=mode, keep=keep) for mode in ((0, 1, 2, 3, 4, -1) if name == 'kitchen' and n <= 256 else ((0, 1, 2, 4, -1) if name == 'kitchen' and n <= 512 else (0, 1, 2, -1)))}
     same = all(all(torch.equal(keep[0][k], o[k]) for k in keep[0]) for o in keep[1:])
     dt = times[-1]
     full = dt if full is None else full
-    duo = f', four waves per env {times[3] * 1e3:.1f} ms' if 3 in times else ''
+    duo = (f', four waves per env {times[3] * 1e3:.1f} ms' if 3 in times else '') + (f', two waves per env (two envs per workgroup) {times[4] * 1e3:.1f} ms' if 4 in times else '')
     print(f'{name}: shard of {w} GPU(s) = {n:5d} envs x {T} steps: {dt * 1e3:8.1f} ms per reset + launch = {dt / full:5.2f} x the {N}-env launch; '
           f'{w} such GPUs would deliver {N * T / dt / 1e6:6.2f} M env-steps/s ({full / dt:4.2f} x one GPU) | two envs per wave {times[0] * 1e3:.1f} ms, one env per wave '
           f'{times[1] * 1e3:.1f} ms, one env per workgroup {times[2] * 1e3:.1f} ms{duo}; outputs bit-identical across the modes: {same}', flush=True)
