@@ -1498,8 +1498,13 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
       for (int i = 0; i < NV; ++i) hcol[i] = hw[i];
 #pragma unroll 2
       for (int c = 0; c < ncmax; ++c) {
-        const double* w = s.con.cw[c];
-        const double j0 = s.con.CJ[c][0][l], j1 = s.con.CJ[c][1][l], j2 = s.con.CJ[c][2][l];
+        double w[8], jl[3];                               // (the contact's weights and this lane's entries as one batch of loads: physics_math.h pin_batch)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = s.con.cw[c][k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) jl[k] = s.con.CJ[c][k][l];
+        pin_batch(w); pin_batch(jl);
+        const double j0 = jl[0], j1 = jl[1], j2 = jl[2];
         const bool cv = c < nct;
         double v0, v1, v2;
         cone_apply<Lim<NV>::ELLIPTIC>(w, j0, j1, j2, v0, v1, v2);
