@@ -643,27 +643,36 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
           'single_core': sweep[1], 'by_threads': {str(k): v for k, v in sweep.items()}, 'runs': {str(k): v for k, v in detail.items()}, 'host': host_cpu_info()}
 
 
-# one GPU, reset + one fused launch of a SHARD of the strong-scaling batches, relative to the full batch (tools/kitchen_small_batch.py on an MI355X, profiles/r05_kitchen_small_batch.txt):
-# what `world` GPUs would deliver if every shard ran like this one (no collective on the data path; the job's one all-gather is 16 KB)
-MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.95, 4: 0.77, 8: 0.61}, 'minitaur': {1: 1.00, 2: 0.50, 4: 0.47, 8: 0.46}}      # (kitchen at 256 envs: four waves per env; at 512: two)
+# STATIC figures (not measured in this run): one MI355X, reset + one fused launch of a SHARD of the strong-scaling batches, relative to the full batch -- copied from
+# profiles/r05_kitchen_small_batch.txt (tools/kitchen_small_batch.py on an MI355X, round 5; kitchen at 256 envs: four waves per env; at 512: two).  What `world` GPUs
+# would deliver if every shard ran like this one (no collective on the data path; the job's one all-gather is 16 KB)
+SHARD_PROFILE = 'profiles/r05_kitchen_small_batch.txt'
+MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.95, 4: 0.76, 8: 0.61}, 'minitaur': {1: 1.00, 2: 0.50, 4: 0.47, 8: 0.46}}
 
 
-def predicted_strong_scaling(workload, n_global, world):
-  """What the kernels' own layout predicts for the STRONG-scaling lines (configs[3] / [4]: a fixed global batch range-sharded over the GPUs), stated in the
-  line so that nobody reads 'x8' into it.  An env is a serial chain of T x frame_skip timesteps walked by ONE 32-lane group; a launch lasts as
-  long as its slowest wave.  Sharding the batch over more GPUs shortens a launch while a GPU has more waves than wave slots (kitchen: 2048 envs fill exactly one
-  round on ONE GPU; minitaur: 4096 envs = two rounds), and below that only by what the small-batch launch modes recover (one env per wave / per workgroup -- an env no
-  longer waits for its wave-mate's longer branch -- and, kitchen, four waves per env) -- measured on one GPU per shard size, not extrapolated."""
+def predicted_scaling(workload, n_global, world):
+  """What the kernels' own layout predicts for configs[3] / [4] on `world` GPUs, both ways, stated in the line so that nobody reads 'x8' into the strong-scaling job
+  (VERDICT r03 item 5a, r05 item 7).  An env is a serial chain of T x frame_skip timesteps walked by ONE 32-lane group; a launch lasts as long as its slowest wave.
+    strong: the config as BASELINE.json words it -- a FIXED global batch range-sharded over the GPUs.  Sharding shortens a launch while a GPU has more waves than wave
+            slots (kitchen: 2048 envs fill exactly one round on ONE GPU; minitaur: 4096 envs = two rounds), and below that only by what the small-batch launch modes
+            recover (one env per wave / per workgroup, and, kitchen, two or four waves per env) -- STATIC ratios measured on one GPU per shard size, not extrapolated.
+    weak:   the regime the design scales in -- the config's batch PER GPU (2048 / 4096 envs each): every rank runs the one-GPU launch on its own env range, no
+            data-path collective, one all-gather of the [N, 2] evaluation summary per job (16-32 KB per rank: microseconds over xGMI), so the prediction is `world` x
+            the one-GPU figure.  Nothing here is a measured multi-GPU number."""
   per_round = 2048                                      # both kernels: 2 envs per wave, 4 waves per CU, 256 CUs
   rounds_1 = -(-n_global // per_round)
   rounds_w = -(-(-(-n_global // world)) // per_round)
   rel = MEASURED_SHARD_TIME.get(workload, {}).get(world) if n_global == (2048 if workload == 'kitchen' else 4096) else None
-  return {'envs_per_gpu': -(-n_global // world), 'launch_rounds_on_1_gpu': rounds_1, f'launch_rounds_on_{world}_gpus': rounds_w,
-          'predicted_speedup_vs_1_gpu': (1.0 / rel) if rel else rounds_1 / rounds_w,
-          'basis': 'measured: one MI355X running one shard of this size (profiles/r05_kitchen_small_batch.txt)' if rel else 'launch rounds',
-          'note': (f'{workload}: {n_global} envs = {rounds_1} round(s) of 2048 resident envs on one MI355X; on {world} GPU(s) a shard of {-(-n_global // world)} envs takes '
-                   + (f'{rel:.2f} x the full-batch launch (measured), so the job is predicted {1.0 / rel:.2f} x faster' if rel else f'{rounds_w} round(s): predicted {rounds_1 / rounds_w:.1f} x at best')
-                   + '.  The chain of an env (T x frame_skip dependent timesteps on one 32-lane group) does not shorten with more GPUs; the scaling lever of these workloads is MORE envs.')}
+  strong = {'envs_per_gpu': -(-n_global // world), 'launch_rounds_on_1_gpu': rounds_1, f'launch_rounds_on_{world}_gpus': rounds_w,
+            'predicted_speedup_vs_1_gpu': (1.0 / rel) if rel else rounds_1 / rounds_w,
+            'basis': f'static: one MI355X running one shard of this size ({SHARD_PROFILE}, round 5; not measured in this run)' if rel else 'launch rounds',
+            'note': (f'{workload}: {n_global} envs = {rounds_1} round(s) of 2048 resident envs on one MI355X; on {world} GPU(s) a shard of {-(-n_global // world)} envs takes '
+                     + (f'{rel:.2f} x the full-batch launch, so the job is predicted {1.0 / rel:.2f} x faster' if rel else f'{rounds_w} round(s): predicted {rounds_1 / rounds_w:.1f} x at best')
+                     + '.  The chain of an env (T x frame_skip dependent timesteps on one 32-lane group) does not shorten with more GPUs; the scaling lever of these workloads is MORE envs.')}
+  weak = {'envs_per_gpu': n_global, 'envs_global': n_global * world, 'predicted_speedup_vs_1_gpu': float(world),
+          'basis': 'design: independent env ranges, no data-path collective, one [N, 2] all-gather per job; every rank runs the one-GPU launch of this line',
+          'all_gather_bytes_per_rank': n_global * 2 * 4}
+  return {'strong': strong, 'weak': weak, 'predicted_speedup_vs_1_gpu': strong['predicted_speedup_vs_1_gpu'], 'basis': strong['basis']}
 
 
 def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=2048, T=400, cpu_seconds=None, env_factory=None):
@@ -743,7 +752,7 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
                                  'timesteps per bench step; own stepper (nv = 23, 32 lanes per env), reduced collision set, parity with MuJoCo unpinned',
                      'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 40, 'launches_per_episode': 1,
                      'parallelism': f'env-range shard x{world} of a FIXED {n_global}-env batch (strong scaling), no per-step collective, one all-gather of the [N, 2] '
-                                    'evaluation summary per job', 'predicted_scaling': predicted_strong_scaling('kitchen', n_global, world)},
+                                    'evaluation summary per job', 'predicted_scaling': predicted_scaling('kitchen', n_global, world)},
           'gathered_rows': None if gathered is None else int(gathered.shape[0]),
           'cpu_baseline': CPU_RESULTS.get('kitchen') if cpu_seconds is not None else None}
 
@@ -842,7 +851,7 @@ def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=40
                                  'timesteps per bench step; own robot model (nv = 22, four loop closures) and tree-structured stepper (csrc/minitaur_stepper.h), parity with PyBullet unpinned and model-less',
                      'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'launches_per_episode': 2,
                      'parallelism': f'env-range shard x{world} of a FIXED {n_global}-env batch (strong scaling), no per-step collective, one all-gather of the [N, 2] '
-                                    'evaluation summary per job', 'predicted_scaling': predicted_strong_scaling('minitaur', n_global, world)},
+                                    'evaluation summary per job', 'predicted_scaling': predicted_scaling('minitaur', n_global, world)},
           'gathered_rows': None if gathered is None else int(gathered.shape[0]),
           'cpu_baseline': CPU_RESULTS.get('minitaur') if cpu_seconds is not None else None}
 
@@ -905,7 +914,8 @@ def compact_line(res):
     cfg['other_workloads'] = {k: {kk: v.get(kk) for kk in ('value', 'ms', 'valu_x_lanes', 'cpu')} for k, v in ow.items()}
   ps = c.get('predicted_scaling')
   if ps:
-    cfg['predicted_scaling'] = {k: ps[k] for k in ('strong', 'weak', 'predicted_speedup_vs_1_gpu', 'basis') if k in ps}
+    cfg['predicted_scaling'] = {'strong_speedup_vs_1_gpu': (ps.get('strong') or {}).get('predicted_speedup_vs_1_gpu'), 'strong_basis': (ps.get('strong') or {}).get('basis', '')[:110],
+                                'weak_speedup_vs_1_gpu': (ps.get('weak') or {}).get('predicted_speedup_vs_1_gpu'), 'weak_envs_per_gpu': (ps.get('weak') or {}).get('envs_per_gpu')}
   out['config'] = cfg
   r = res.get('roofline') or {}
   keep_r = ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_min', 'frac_max', 'traffic', 'kernel', 'kernel_ms_median', 'kernel_ms_mean', 'strict_frac', 'strict_value',

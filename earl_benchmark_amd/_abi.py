@@ -140,6 +140,7 @@ SIGNATURES = {
     'earl_physics_model24_size': [],
     'earl_collision_model_size': [],
     'earl_sawyer_cfg_size': [],
+    'earl_physics_forget_table': [C.c_void_p],
     'earl_debug_set_physics_lanes': [C.c_int],
     'earl_debug_set_door_variant': [C.c_int],
     'earl_debug_set_peg_schedule': [C.c_int],

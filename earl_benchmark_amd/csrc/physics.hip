@@ -35,7 +35,9 @@
 #include "../../include/earl_glue.h"
 #include "philox.h"
 
+#ifndef EARL_PHYS_NO_CONTRACT      // (-DEARL_PHYS_NO_CONTRACT: the units under the command line's -ffp-contract=off, as the tabletop path is built -- the measurement of DESIGN.md "contraction")
 #pragma clang fp contract(fast)
+#endif
 
 // translation units: physics.hip (the main one: nv 10 / 15 / 23 models, every entry point but the two below), physics_w8.hip (the door model's
 // eight-waves-per-CU rollout) and physics_mt.hip (the minitaur: nv = 22) include this file under a variant macro and are compiled side by side
@@ -45,6 +47,9 @@
 #if defined(EARL_PHYS_VARIANT_W8) || defined(EARL_PHYS_VARIANT_MT) || defined(EARL_PHYS_UNIT_L64) || defined(EARL_PHYS_UNIT_KITCHEN)
 #define EARL_PHYS_NOT_MAIN 1
 #endif
+
+// cone word of a device collision table, cached per address (defined in the main unit; -1 = unknown); see check_cone
+extern "C" __attribute__((visibility("hidden"))) int earl_unit_table_cone(const void* col, void* stream);
 
 namespace {
 
@@ -2131,23 +2136,14 @@ int launched(const char* what) {
 
 // The kernels compile the friction cone per model size (Lim<NV>::ELLIPTIC) and the two cones lay the contact arrays out differently, so a collision table
 // compiled for the other cone must be refused (include/earl_physics.h: earl_collision_model.cone).  `col` is a DEVICE table: its cone word is copied to the
-// host ONCE per device address (4 bytes, a blocking copy -- never while the stream is being captured into a graph: the check is then skipped for an address
-// not yet seen) and remembered.  A caller that rewrites a table in place with the other cone must use a new allocation.
+// host once per device address (4 bytes, a blocking copy -- never while the stream is being captured into a graph: the check is then skipped for an address
+// not yet seen) and remembered in ONE cache for all translation units (earl_unit_table_cone, main unit) until its owner announces that the block is gone:
+// earl_physics_forget_table (the Python front end calls it when a DeviceModel is freed -- a caching allocator hands the block to the next table, which may be of
+// the other cone: ADVICE r05).
 int check_cone(const earl_collision_model* col, const bool want_elliptic, hipStream_t st, const char* what) {
   if (!col) return EARL_OK;
-  static std::mutex mu;
-  static std::unordered_map<const void*, int> seen;
-  std::lock_guard<std::mutex> lock(mu);
-  int cone = -1;
-  const auto it = seen.find(col);
-  if (it != seen.end()) cone = it->second;
-  else {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return EARL_OK; }
-    if (cs != hipStreamCaptureStatusNone) return EARL_OK;
-    if (hipMemcpy(&cone, &col->cone, sizeof cone, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return EARL_OK; }   // (not a device table: the launch reports it)
-    seen[col] = cone;
-  }
+  const int cone = earl_unit_table_cone(col, st);
+  if (cone < 0) return EARL_OK;            // (unknown: a capture in progress, or not a device table -- the launch reports that)
   if (cone != (want_elliptic ? 1 : 0)) {
     fprintf(stderr, "earl_physics: %s: the collision table is compiled for the %s friction cone, this model size runs the %s one (earl_collision_model.cone)\n", what,
             cone == 1 ? "elliptic" : "pyramidal", want_elliptic ? "elliptic" : "pyramidal");
@@ -2209,9 +2205,34 @@ void launch_physics(const PArgs& a, hipStream_t st) {
 
 }  // namespace
 
+#ifndef EARL_PHYS_NOT_MAIN
+namespace {
+std::mutex g_cone_mu;
+std::unordered_map<const void*, int> g_cone_seen;
+}  // namespace
+extern "C" __attribute__((visibility("hidden"))) int earl_unit_table_cone(const void* col, void* stream) {
+  std::lock_guard<std::mutex> lock(g_cone_mu);
+  const auto it = g_cone_seen.find(col);
+  if (it != g_cone_seen.end()) return it->second;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  if (cs != hipStreamCaptureStatusNone) return -1;
+  int cone = -1;
+  if (hipMemcpy(&cone, &static_cast<const earl_collision_model*>(col)->cone, sizeof cone, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  g_cone_seen[col] = cone;
+  return cone;
+}
+#endif
+
 extern "C" {
 
 #ifndef EARL_PHYS_NOT_MAIN
+// include/earl_physics.h: the owner of a device collision table announces that the block is freed / rewritten (NULL: every table)
+int earl_physics_forget_table(const void* col) {
+  std::lock_guard<std::mutex> lock(g_cone_mu);
+  if (!col) { const int k = (int)g_cone_seen.size(); g_cone_seen.clear(); return k; }
+  return (int)g_cone_seen.erase(col);
+}
 int earl_physics_step(const void* model, const earl_collision_model* col, int32_t nv, int32_t n, int32_t nsub, double* qpos, double* qvel,
                       const double* mocap_pos, const double* mocap_quat, const double* ctrl, double* att_xpos,
                       earl_stream_t stream) {

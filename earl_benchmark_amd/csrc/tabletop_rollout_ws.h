@@ -961,7 +961,9 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         // as ordinary stores they went through the L2 write-back path and, with four episodes in flight, held the kernel at 5.1-5.7 TB/s;
         // streamed past it the launch runs at 7.3 TB/s algorithmic = 6.3 TB/s at the HBM interface (the actions hit the cache), which is what
         // MI355X_MICROARCH.md gives as the achievable HBM bandwidth.  (EARL_WS_TEMPORAL_STORES: the ordinary stores, for comparison.)
-#ifdef EARL_WS_ST_AUX
+#ifdef EARL_WS_NO_STORES      // measurement only (WRONG results): the storers keep their LDS reads and arithmetic but write one row in 64 -- what the launch costs without its stores
+        if ((t & 63) == 0) { dst[lane] = rw.v0; dst[lane + 64] = rw.v1; dst[lane + 128] = rw.v2; }
+#elif defined(EARL_WS_ST_AUX)
         {
           const __amdgpu_buffer_rsrc_t rs = ws_rsrc(dst);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_v4i, ws_v4f{rw.v0.x, rw.v0.y, rw.v0.z, rw.v0.w}), rs, lane * 16, 0, EARL_WS_ST_AUX);
@@ -982,13 +984,19 @@ __global__ __launch_bounds__(64 * ((NC == 3 ? 2 : NC) + NL + NS)) void rollout_w
         float rew;
         if constexpr (RT == EARL_REWARD_SPARSE) rew = succ ? 1.0f : 0.0f;
         else rew = (float)dense1(o);
-#ifdef EARL_WS_SMALL_NT
+#ifdef EARL_WS_NO_STORES
+        if ((t & 63) == 0) a.reward[row0 + lane] = rew;
+#elif defined(EARL_WS_SMALL_NT)
         __builtin_nontemporal_store(rew, a.reward + row0 + lane);
 #else
         a.reward[row0 + lane] = rew;
 #endif
         const unsigned long long ms = __ballot(succ), md = __ballot(t - t_ep0 >= t_done);
+#ifdef EARL_WS_NO_STORES
+        if (lane < 16 && (t & 63) == 0) {
+#else
         if (lane < 16) {
+#endif
           const uint32_t ns = (uint32_t)(ms >> (4 * lane)) & 0xFu, nd = (uint32_t)(md >> (4 * lane)) & 0xFu;
 #ifdef EARL_WS_SMALL_NT
           __builtin_nontemporal_store((ns * 0x00204081u) & 0x01010101u, reinterpret_cast<uint32_t*>(a.success + row0) + lane);

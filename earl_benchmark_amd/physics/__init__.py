@@ -7,6 +7,8 @@ tools/mjcf_compile.py into earl_benchmark_amd/models/*.npz.
 import ctypes as C
 import os
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -297,6 +299,10 @@ class DeviceModel:
     self.col_buf = None
     if self.col_struct is not None:
       self.col_buf = torch.from_numpy(np.frombuffer(bytes(self.col_struct), dtype=np.uint8).copy()).to(self.device)
+      # the library remembers a table's friction cone per device address (include/earl_physics.h: earl_physics_forget_table): this block may have been another
+      # table's before (torch's caching allocator), and will be again after this model is gone
+      self.lib.earl_physics_forget_table(self.col_buf.data_ptr())
+      weakref.finalize(self, self.lib.earl_physics_forget_table, self.col_buf.data_ptr())
     self.att_names = [str(x) for x in self.tables['att_names']]
 
   def _stream(self):

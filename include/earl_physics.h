@@ -301,6 +301,11 @@ int earl_sawyer_door_info(const earl_sawyer_cfg* cfg, int32_t n, const double* o
 
 /* measurement switch: lanes of a wavefront that work on one env instance -- 16 (default: four envs per wavefront) or 64 (one
  * wavefront per env).  Results are identical; DESIGN.md quotes both timings. */
+/* The entry points that take a collision table check its friction cone against the kernels' (earl_collision_model.cone) by reading the cone word of the DEVICE table
+ * once per address and remembering it.  The owner of a table must announce that its block is freed or rewritten -- a caching allocator hands the same address to the
+ * next table, which may be of the other cone: col = the table's device address, or NULL for every table.  Returns the number of entries dropped.  (The Python front end:
+ * earl_benchmark_amd.physics.DeviceModel.__del__; nothing in the reference corresponds -- MuJoCo reads `opt.cone` from the one model it holds.) */
+int earl_physics_forget_table(const void* col);
 int earl_debug_set_physics_lanes(int lanes_per_env);
 
 /* ---------------------------------------------------------------------------------------------------------------------

@@ -126,6 +126,9 @@ typedef struct {
  * the order of the sums -- is the same; the iteration count is what changes.  0 = always the cold start (round 1 / early round 2). */
 static int g_warm_start = 1;
 int oracle_set_warm_start(int w) { const int prev = g_warm_start; g_warm_start = w; return prev; }
+/* experiment switch (tools/minitaur_passes.py): 1 = the minitaur rollout keeps the warm start ACROSS env steps of one call (the product rule is: every env step starts cold) */
+static int g_warm_across_steps = 0;
+int oracle_set_warm_across_steps(int w) { const int prev = g_warm_across_steps; g_warm_across_steps = w; return prev; }
 static long long g_newton_stats[5];       /* timesteps, Newton iterations, timesteps with contacts, iterations in those, timesteps that used all 8 iterations without reaching a fixed point */
 void oracle_newton_stats(long long* out, int reset) {
   for (int i = 0; i < 5; ++i) { out[i] = g_newton_stats[i]; if (reset) g_newton_stats[i] = 0; }
@@ -1093,7 +1096,7 @@ int oracle_minitaur_rollout(const earl_link_model24* m0, const earl_collision_mo
       memcpy(q2, qp, sizeof(double) * m->nq); memcpy(v2, qv, sizeof(double) * nv);
       memcpy(obs2, st->observed_torque + (size_t)e * 8, sizeof(obs2)); memcpy(oh2, st->overheat + (size_t)e * 8, sizeof(oh2)); memcpy(en2, st->motor_enabled + (size_t)e * 8, sizeof(en2));
       MtMotors mt = {mp[0], mp[1], obs2, oh2, en2};
-      o.warm = 0;
+      if (!(g_warm_across_steps && t > 0)) o.warm = 0;
       for (int s = 0; s < cfg->num_substeps; ++s) {                                           /* minitaur_gym_env.py:321-323 */
         mt_apply_action(m, cfg, q2, v2, cmd, &mt, qfrc);
         substep(m, col, q2, v2, v3(0, 0, 0), mq, NULL, 1, &o, qfrc);

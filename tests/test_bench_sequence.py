@@ -269,7 +269,56 @@ def test_two_rank_strong_scaling_lines(tmp_path, which, n_global):
   assert cfg['envs_global'] == n_global and cfg['envs_per_gpu'] == -(-n_global // world) and 'strong scaling' in cfg['parallelism']
   # what the kernels' layout predicts for the real shapes (one round of 2048 resident envs per GPU): stated in the line
   # the line says what the kernels' layout gives, from MEASURED shard launches (profiles/r05_kitchen_small_batch.txt), never 'x8'
-  k8, m8 = bench.predicted_strong_scaling('kitchen', 2048, 8), bench.predicted_strong_scaling('minitaur', 4096, 8)
-  assert 1.0 <= k8['predicted_speedup_vs_1_gpu'] < 1.9 and 2.0 <= m8['predicted_speedup_vs_1_gpu'] < 2.5 and k8['basis'].startswith('measured')
-  assert bench.predicted_strong_scaling('kitchen', 8192, 2)['predicted_speedup_vs_1_gpu'] == 2.0       # other batch sizes: by launch rounds
-  assert cfg['predicted_scaling']['envs_per_gpu'] == -(-n_global // world)
+  k8, m8 = bench.predicted_scaling('kitchen', 2048, 8), bench.predicted_scaling('minitaur', 4096, 8)
+  assert 1.0 <= k8['strong']['predicted_speedup_vs_1_gpu'] < 1.9 and 2.0 <= m8['strong']['predicted_speedup_vs_1_gpu'] < 2.5
+  for p8 in (k8, m8):                                            # static figures, labelled so, with the file they come from -- which exists and holds this workload
+    assert p8['strong']['basis'].startswith('static') and bench.SHARD_PROFILE in p8['strong']['basis'] and os.path.exists(os.path.join(REPO, bench.SHARD_PROFILE))
+  prof = open(os.path.join(REPO, bench.SHARD_PROFILE)).read()
+  for wl, shard in (('kitchen', 256), ('minitaur', 512)):
+    row = [ln for ln in prof.splitlines() if ln.startswith(wl + ': shard of 8 GPU(s)')][0]
+    assert f'{shard} envs' in row and f'{bench.MEASURED_SHARD_TIME[wl][8]:.2f} x the' in row
+  # ... and the WEAK-scaling entry next to it: the config's batch PER GPU, predicted `world` x -- the regime the design scales in
+  assert k8['weak'] == {**k8['weak'], 'envs_per_gpu': 2048, 'envs_global': 16384, 'predicted_speedup_vs_1_gpu': 8.0} and m8['weak']['envs_global'] == 32768
+  assert bench.predicted_scaling('kitchen', 8192, 2)['strong']['predicted_speedup_vs_1_gpu'] == 2.0       # other batch sizes: by launch rounds
+  assert cfg['predicted_scaling']['strong']['envs_per_gpu'] == -(-n_global // world) and cfg['predicted_scaling']['weak']['envs_per_gpu'] == n_global
+
+
+def _ragged_trajectory_worker(rank, world, port, n_global, T, D, out_dir):
+  sys.path.insert(0, REPO)
+  import torch.distributed as dist
+  from earl_benchmark_amd import sharding
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    lo, hi = sharding.shard_range(n_global, rank, world)
+    g = torch.Generator().manual_seed(5)
+    obs = torch.randn(T, n_global, D, generator=g)[:, lo:hi].contiguous()              # this rank's columns of ONE global trajectory buffer
+    g2 = torch.Generator().manual_seed(6)
+    rew = torch.randn(T, n_global, generator=g2)[:, lo:hi].contiguous()
+    done = (torch.arange(T)[:, None] == T - 1).expand(T, hi - lo).contiguous()
+    succ = ((torch.arange(lo, hi)[None, :] + torch.arange(T)[:, None]) % 3 == 0)
+    for sizes in (None, [sharding.shard_range(n_global, r, world)[1] - sharding.shard_range(n_global, r, world)[0] for r in range(world)]):
+      full = sharding.gather_rollout(sharding.pack_rollout(obs, rew, done, succ), sizes=sizes)     # with and without the size exchange
+      torch.save(full, os.path.join(out_dir, f'r{rank}_{0 if sizes is None else 1}.pt'))
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world, n_global', [(2, 21), (3, 8)])      # ragged: 11 + 10, and 3 + 3 + 2
+def test_gather_rollout_of_ragged_shards_reproduces_the_one_batch_trajectory_buffer(tmp_path, world, n_global):
+  """the job's trajectory-collecting collective on shards whose sizes differ -- every rank ends up holding [T, N_global, D + 2] equal, entry by
+  entry, to the buffer ONE batch of all the envs would have packed (env order = rank order; padding dropped)."""
+  from earl_benchmark_amd import sharding
+  T, D = 5, 12
+  mp.spawn(_ragged_trajectory_worker, args=(world, _free_port(), n_global, T, D, str(tmp_path)), nprocs=world, join=True)
+  obs = torch.randn(T, n_global, D, generator=torch.Generator().manual_seed(5))
+  rew = torch.randn(T, n_global, generator=torch.Generator().manual_seed(6))
+  done = (torch.arange(T)[:, None] == T - 1).expand(T, n_global).contiguous()
+  succ = ((torch.arange(n_global)[None, :] + torch.arange(T)[:, None]) % 3 == 0)
+  one_batch = sharding.pack_rollout(obs, rew, done, succ)
+  for rank in range(world):
+    for k in (0, 1):
+      got = torch.load(tmp_path / f'r{rank}_{k}.pt')
+      assert got.shape == (T, n_global, D + 2) and torch.equal(got, one_batch)
+  o, r, d, sc = sharding.unpack_rollout(one_batch)
+  assert torch.equal(o, obs) and torch.equal(r, rew) and torch.equal(d, done) and torch.equal(sc, succ)

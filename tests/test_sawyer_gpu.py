@@ -206,6 +206,36 @@ def test_a_collision_table_of_the_other_cone_is_refused_by_the_c_abi():
   rc = lib.earl_sawyer_rollout(u.model.buf.data_ptr(), u.model.col_ptr, u.nv, u._cfg_ref, u._st_ref, acts.data_ptr(), 1, C.byref(o), None)
   assert rc == 0
   torch.cuda.synchronize()
+  # the cone word is remembered per device ADDRESS.  The same block rewritten with the right cone is still refused (stale entry) until its owner
+  # announces the change -- earl_physics_forget_table -- and accepted afterwards; a freed table's entry must not outlive it either (DeviceModel does this on free)
+  cm.cone = 1
+  raw.copy_(torch.frombuffer(bytearray(bytes(cm)), dtype=torch.uint8))
+  torch.cuda.synchronize()
+  assert lib.earl_sawyer_rollout(u.model.buf.data_ptr(), raw.data_ptr(), u.nv, u._cfg_ref, u._st_ref, acts.data_ptr(), 1, C.byref(o), None) == -1
+  assert lib.earl_physics_forget_table(raw.data_ptr()) == 1 and lib.earl_physics_forget_table(raw.data_ptr()) == 0
+  assert lib.earl_sawyer_rollout(u.model.buf.data_ptr(), raw.data_ptr(), u.nv, u._cfg_ref, u._st_ref, acts.data_ptr(), 1, C.byref(o), None) == 0
+  torch.cuda.synchronize()
+  lib.earl_physics_forget_table(raw.data_ptr())
+
+
+def test_envs_of_both_cones_built_and_dropped_in_turn_never_meet_a_stale_cone_entry():
+  """every collision table is 55,648 B, so torch's caching allocator hands a freed Sawyer table's block (elliptic) to the next kitchen / minitaur table
+  (pyramidal).  DeviceModel announces both ends of a table's life to the library; ten envs of alternating kinds in one process all run."""
+  import gc
+  import torch
+  from earl_benchmark_amd.envs.sawyer_door import SawyerDoor
+  from earl_benchmark_amd.envs.minitaur import Minitaur
+  seen = set()
+  for k in range(10):
+    env = SawyerDoor(num_envs=4, seed=k) if k % 2 == 0 else Minitaur(num_envs=4, seed=k, scalar_api=False)
+    seen.add((k % 2, env.model.col_ptr))
+    env.reset()
+    a = torch.zeros(2, 4, 4 if k % 2 == 0 else 8, device='cuda')
+    env.rollout(a)
+    torch.cuda.synchronize()
+    del env, a
+    gc.collect()
+  assert len({p for _, p in seen}) < len(seen) or len(seen) == 10      # (informational: whether the allocator did reuse a block is up to it; the loop must simply pass)
 
 
 def test_loader_builds_the_door_env():
