@@ -141,6 +141,10 @@ int oracle_set_raw_mocap_quat(int raw) { const int prev = g_raw_mocap_quat; g_ra
 /* experiment hook (tools/weld_free_motion_fit.py): per-row factors on the six weld regularisers, 1 = the tables' value */
 static double g_weld_row_scale[6] = {1, 1, 1, 1, 1, 1};
 void oracle_set_weld_row_scale(const double* s6) { for (int r = 0; r < 6; ++r) g_weld_row_scale[r] = s6 ? s6[r] : 1.0; }
+/* experiment switch (tools/weld_free_motion_fit.py --forms, tools/heldout_eval.py): 1 = the impedance of the weld's six rows is ONE number, read at the NORM of the six residuals
+ * (MuJoCo's engine_core_constraint.c getposdim: a weld is one 6-dimensional constraint); 0 = every row its own (what the kernels implement) */
+static int g_weld_norm_imp = 0;
+int oracle_set_weld_norm_imp(int on) { const int prev = g_weld_norm_imp; g_weld_norm_imp = on; return prev; }
 static Q4 qnormalize(Q4 q) {
   const double s = 1.0 / sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   Q4 r = {q.w * s, q.x * s, q.y * s, q.z * s};
@@ -415,11 +419,12 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       J[0][j] = -pv.x; J[1][j] = -pv.y; J[2][j] = -pv.z;
       J[3][j] = -0.5 * jq.x; J[4][j] = -0.5 * jq.y; J[5][j] = -0.5 * jq.z;
     }
+    const double res_norm = sqrt(dot(rpos, rpos) + dot(ev, ev));
     for (int r = 0; r < 6; ++r) {
       const double res = r < 3 ? pick(rpos, r) : pick(ev, r - 3);
       double Jv = 0, kk, bb, dd;
       for (int j = 0; j < nv; ++j) Jv += J[r][j] * qv[j];
-      kbimp(m->weld_solref, m->weld_solimp, res, dt, &kk, &bb, &dd);
+      kbimp(m->weld_solref, m->weld_solimp, g_weld_norm_imp ? res_norm : res, dt, &kk, &bb, &dd);
       aref[r] = -bb * Jv - kk * dd * res;
       D[r] = 1.0 / fmax((1 - dd) / dd * m->weld_invweight[r < 3 ? 0 : 1] * g_weld_row_scale[r], 1e-15);
       iseq[r] = 1; rowid[r] = r;

@@ -235,7 +235,7 @@ def test_envs_of_both_cones_built_and_dropped_in_turn_never_meet_a_stale_cone_en
     torch.cuda.synchronize()
     del env, a
     gc.collect()
-  assert len({p for _, p in seen}) < len(seen) or len(seen) == 10      # (informational: whether the allocator did reuse a block is up to it; the loop must simply pass)
+  assert len(seen) >= 2                                                 # (whether the allocator reuses a block across kinds is up to it: the loop must simply pass)
 
 
 def test_loader_builds_the_door_env():

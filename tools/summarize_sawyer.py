@@ -33,6 +33,10 @@ if 'SQ_WAVE_CYCLES' in c:
                                              ('valu', 'SQ_ACTIVE_INST_VALU'), ('lds', 'SQ_ACTIVE_INST_LDS'), ('scalar', 'SQ_ACTIVE_INST_SCA')) if n in c}
   if 'SQ_LDS_BANK_CONFLICT' in c and 'SQ_LDS_IDX_ACTIVE' in c:
     res['derived']['lds_bank_conflict_share'] = c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_LDS_IDX_ACTIVE'], 1.0)
+if 'SQ_THREAD_CYCLES_VALU' in c and 'derived' in res:
+  # lanes active per VALU instruction / 64 (SQ_THREAD_CYCLES_VALU counts thread-cycles of VALU work; SQ_INSTS_VALU the instructions)
+  res['derived']['lane_occupancy'] = c['SQ_THREAD_CYCLES_VALU'] / (64.0 * max(c.get('SQ_ACTIVE_INST_VALU', 1.0), 1.0))
+  res['derived']['lane_occupancy_per_inst'] = c['SQ_THREAD_CYCLES_VALU'] / (64.0 * max(c.get('SQ_INSTS_VALU', 1.0), 1.0))
 if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
   # HBM bytes per launch as MI355X_MICROARCH.md prescribes for gfx950 (both counters in KiB; FETCH_SIZE reports half the bytes of streaming reads)
   res['hbm_bytes_per_launch'] = (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024
@@ -41,9 +45,5 @@ if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
   tj[w] = {"hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": f"profiles/{tag}_{w}_rollout_pmc.json", "rocprof_kernel_average_ns": float(kern["AverageNs"]), "issue": res.get("derived"),
            "waves_per_simd": 2 if w == "sawyer_door" else 1}      # the bench batch (8192 envs) runs the door's eight-waves-per-CU build: two waves per SIMD; the peg has one
   json.dump(tj, open(tp, 'w'), indent=1)
-if 'SQ_THREAD_CYCLES_VALU' in c and 'derived' in res:
-  # lanes active per VALU instruction / 64 (SQ_THREAD_CYCLES_VALU counts thread-cycles of VALU work; SQ_INSTS_VALU the instructions)
-  res['derived']['lane_occupancy'] = c['SQ_THREAD_CYCLES_VALU'] / (64.0 * max(c.get('SQ_ACTIVE_INST_VALU', 1.0), 1.0))
-  res['derived']['lane_occupancy_per_inst'] = c['SQ_THREAD_CYCLES_VALU'] / (64.0 * max(c.get('SQ_INSTS_VALU', 1.0), 1.0))
 json.dump(res, open(os.path.join(PROF, f'{tag}_{w}_rollout_pmc.json'), 'w'), indent=1)
 print(json.dumps(res, indent=1))
