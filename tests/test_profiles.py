@@ -12,7 +12,7 @@ from conftest import REPO
 
 PROF = os.path.join(REPO, 'profiles')
 LIB = os.path.join(REPO, 'earl_benchmark_amd', 'csrc', 'libearl_hip.so')
-OURS = re.compile(r'(earl::|\(anonymous namespace\)::)\w*kernel')      # kernels of this library (torch's own kernels in the same traces are not ours to check)
+OURS = re.compile(r'^(void )?(earl::|\(anonymous namespace\)::)\w*kernel')      # kernels of this library: the name STARTS in its namespaces (torch's own kernels in the same traces are not ours to check)
 
 
 def newest_round():
