@@ -151,6 +151,7 @@ SIGNATURES = {
     'earl_minitaur_reset': [C.c_void_p, C.c_void_p, _P(MinitaurCfg), _P(MinitaurState), C.c_void_p, C.c_void_p, C.c_void_p],
     'earl_minitaur_cfg_size': [],
     'earl_debug_set_minitaur_stepper': [C.c_int],
+    'earl_debug_set_minitaur_duo': [C.c_int],
     'earl_debug_set_solo': [C.c_int],
     'earl_debug_set_solo_mt': [C.c_int],
     'earl_sawyer_reset': [C.c_void_p, C.c_int32, _P(SawyerCfg), _P(SawyerState)] + [C.c_void_p] * 5,

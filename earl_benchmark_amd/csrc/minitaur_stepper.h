@@ -114,6 +114,12 @@ struct SharedMTData {
   double aprev[NV];                  // solution of the newest solve (warm start of the next timestep; exchange buffer of the row tests)
   struct { double ext[NV]; double motor_volt, motor_visc; double mscale[3], foot_mu; } xt;      // (same fields as Shared<NV>::xt)
   double eres[12], eD[12], ear[12];  // closure rows: residual, weight, reference acceleration
+  // minitaur_duo_kernel: what an env's step keeps between the visits of its wave (the one-wave kernel holds these in registers): motors 0 - 7 -- observed torque, the env step's
+  // command, overheat counter, enabled flag --, the goal, the wrappers' counters
+  struct { double obs_t[8], cmd[8]; int oh[8], en[8]; double goal[2]; int steps, sgc; } ev;
+  // ... and what the contact rows (C3, wave A's half) leave in the contact's LANE for the passes (wave B's half): weight, friction, the four edges' reference accelerations,
+  // the warm-started active edges, the chain's hinges
+  struct { double cD, cmu, car[4]; unsigned int cact; int cd1, cd2, pad_; } c3[MC];
   union {
     double ct[MC][8];                // contact records (pair tests -> contact rows)
     double cw[MC][8];                // per-pass edge weights
@@ -130,6 +136,16 @@ struct SharedMTData {
       double redF[9][6];                 // the same for the bias forces
     } dyn;
     struct {
+      // ROLE-split timestep (the two-waves-per-SIMD launch, physics_env_minitaur.h minitaur_duo_kernel): what wave A's half of the timestep (frames ... closure rows) hands
+      // to wave B's half (contact rows, active-set passes, integration) besides what already lives in LDS -- this lane's entries of the equality Hessian and right-hand side.
+      // It lies where the frames (dead after the pair tests) and the subtree sums (dead after K7) lay and leaves the motion subspaces alone, which the contact rows read.
+      double Bw[NV][6];
+      double rw[NV];
+      double sh_keep[MTDims::NH][6];
+      double Aw[MTDims::NH][4];
+      int nct;
+    } hand;
+    struct {
       // the pass's Hessian, by blocks, and right-hand side
       double HA[MTDims::NLEG][10];       // leg blocks, packed lower triangle (p, q) at p (p + 1) / 2 + q
       double HB[MTDims::NH][6];          // couplings: row = hinge, column = root dof
@@ -145,6 +161,8 @@ struct SharedMTData {
     } pas;
   };
 };
+static_assert(offsetof(SharedMTData, hand.sh_keep) == offsetof(SharedMTData, dyn.Sh) && offsetof(SharedMTData, hand.Aw) == offsetof(SharedMTData, dyn.redI) &&
+              sizeof(((SharedMTData*)nullptr)->hand) <= sizeof(((SharedMTData*)nullptr)->dyn), "the hand-over block keeps clear of the motion subspaces and fits the dynamics block");
 struct SharedMT : SharedMTData {
   static constexpr int R = (int)(sizeof(SharedMTData) % 256);
   static constexpr int PAD = R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R);      // the two env blocks of a wave on different banks (physics.hip Shared<NV>)
@@ -153,7 +171,10 @@ struct SharedMT : SharedMTData {
 
 // One timestep of one env by its 32-lane group.  Lane roles: sub 0-5 = the root body's dofs, sub 8 + 4 k + j = hinge j of leg k (dof 6 + 4 k + j),
 // the other lanes idle (they shadow a hinge and store nothing).  INTEGRATE = false stops after qacc.
-template <bool INTEGRATE>
+// ROLE 0: the whole timestep in this wave.  ROLE 1 / 2 (minitaur_duo_kernel): the timestep in two halves run by two waves, one after the other on the same LDS block --
+// 1 = frames, bounding and pair tests, mass matrix, bias forces, closure rows, contact rows (K1 - K8, C0 - C3), handing over this lane's equality entries (s.hand) and
+// its contact's row data (s.c3); 2 = active-set passes and integration (K9, K10), beginning with that hand-over.  Same expressions on the same values in the same order: same results.
+template <bool INTEGRATE, int ROLE = 0>
 __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24& m, const BlkTable<MTDims::MB, true>& bt, const PairTabMT& pt,
                                            const int sub, const int grp, const bool warm, double* qacc_out) {
   constexpr int NV = MTDims::NV, MC = MTDims::MC, LPE = MTDims::LPE;
@@ -174,6 +195,9 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   const V3 ax = ld3(m.jaxis[l]);
   const int jt = m.jtype[l];
   const double ql_ = s.qp[l], qd = s.qv[l];
+  double Bw[6], Aw[4], rw;                                // this lane's entries of the equality Hessian and right-hand side (K8 -> K9)
+  int nct = 0, ncmax = 0;                                 // contacts of this lane's env, of the wave's two envs at most (C1-2 -> C3, K9)
+  if constexpr (ROLE != 2) {
   {
     const Q4 tq = ldq(m.tquat[l]);
     const V3 tp = ld3(m.tpos[l]);
@@ -279,10 +303,26 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     double tot[10];
 #pragma unroll
     for (int e = 0; e < 10; ++e) tot[e] = s.dyn.redI[8][e];
+    if constexpr (ROLE == 0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int e = 0; e < 10; ++e) tot[e] += s.dyn.redI[u][e];
+        for (int e = 0; e < 10; ++e) tot[e] += s.dyn.redI[u][e];
+    } else {
+      // (256 registers: all ninety loads at once -- what the scheduler does with the loop above -- end in scratch memory; two subtrees per LDS round trip, same sums in the same order)
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        double part[20];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) { part[e] = s.dyn.redI[u][e]; part[10 + e] = s.dyn.redI[u + 1][e]; }
+        pin_batch(part);
+#pragma unroll
+        for (int e = 0; e < 10; ++e) tot[e] += part[e];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) tot[e] += part[10 + e];
+        pin_batch(tot);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 10; ++e) Ic[e] = isroot ? tot[e] : Ic[e];
   }
@@ -335,14 +375,27 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     }
     fence();
     V3 nt = ld3(s.dyn.redF[8]), ft = ld3(s.dyn.redF[8] + 3);
+    if constexpr (ROLE == 0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { nt = add(nt, ld3(s.dyn.redF[u])); ft = add(ft, ld3(s.dyn.redF[u] + 3)); }
+      for (int u = 0; u < 8; ++u) { nt = add(nt, ld3(s.dyn.redF[u])); ft = add(ft, ld3(s.dyn.redF[u] + 3)); }
+    } else {
+      // (256 registers: four subtrees per LDS round trip instead of all eight loaded at once and spilled; same sums in the same order)
+#pragma unroll
+      for (int u = 0; u < 8; u += 4) {
+        double part[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) part[k] = s.dyn.redF[u + k / 6][k % 6];
+        pin_batch(part);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { nt = add(nt, V3{part[6 * w], part[6 * w + 1], part[6 * w + 2]}); ft = add(ft, V3{part[6 * w + 3], part[6 * w + 4], part[6 * w + 5]}); }
+        nt = V3{pinned(nt.x), pinned(nt.y), pinned(nt.z)}; ft = V3{pinned(ft.x), pinned(ft.y), pinned(ft.z)};
+      }
+    }
     ns = selv(isroot, nt, ns); fs = selv(isroot, ft, fs);
     tau_l = -m.damping[l] * qd - (dot(Sw, ns) + dot(Sv, fs)) + s.xt.ext[l];
   }
   PSTAMP(5);
   // ------------------------------------------------------------------ C1-C2: pair tests of the near blocks (lane = pair; spheres vs world-fixed boxes)
-  int nct = 0;
   if (nearw) {
     // PACKED (round 5; the form of the kitchen's C2 in physics.hip): consecutive near blocks of the wave share a pass as long as their pairs fit the group's 32 lanes --
     // lane -> (block, pair) by a walk over the pass's blocks, the block's box frame per lane.  Contacts keep the sequential order (blocks ascending on the lanes, pairs
@@ -417,14 +470,12 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   }
   PSTAMP(2);
   PCOUNT(20, 1); PCOUNT(21, nearw ? 1 : 0); PCOUNT(22, __popc(nearw));
-  int ncmax = 0;
   if (nearw && __any(nct > 0)) {
 #pragma unroll
     for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
   }
   // ------------------------------------------------------------------ K8: closure rows (connect constraints; leg k carries constraint k: attachment 1 on its
   // hinge 3, attachment 2 on its hinge 1) and the equality part of the Hessian -- this lane's entries, kept in registers over the passes
-  double Bw[6], Aw[4], rw;
   {
     const int k1 = m.con_att1[leg], k2 = m.con_att2[leg];
     const V3 pa = add(P, mulv(R, ld3(m.att_pos[hq == 3 ? k1 : k2])));
@@ -482,11 +533,44 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     rw = isroot ? gr : gh;
   }
   PSTAMP(7);
+  }   // ROLE != 2
+  if constexpr (ROLE == 1) {
+    // hand-over to the wave that runs the second half (it waits at a workgroup barrier): this lane's dof's entries, the env's contact count
+    if (isl) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) s.hand.Bw[l][i] = Bw[i];
+      s.hand.rw[l] = rw;
+    }
+    if (ishinge) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s.hand.Aw[l - 6][p] = Aw[p];
+    }
+    if (sub == 0) s.hand.nct = nct;
+  }
+  if constexpr (ROLE == 0) {
+    // the one-wave form holds the same values in registers HERE, opaque to the optimiser as a hand-over through LDS is: what the compiler may fuse or share across this point
+    // (fp contract(fast)) is then the same in the one-wave and the two-wave forms -- they walk through the same bits
+    pin_batch(Bw); pin_batch(Aw); rw = pinned(rw);
+  }
+  if constexpr (ROLE == 2) {
+    nct = s.hand.nct;
+    if (__any(nct > 0)) {
+#pragma unroll
+      for (int k = 0; k < MC; ++k) ncmax = __any(nct > k) ? k + 1 : ncmax;
+    }
+  }
   // ------------------------------------------------------------------ C3: contact rows, lane = contact (all contacts of the env at once)
   double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};
   unsigned int cact = 0;
   int cd1 = -1, cd2 = -1;                               // lane c: the hinges of its contact's chain
-  if (ncmax > 0) {
+  if constexpr (ROLE == 2) {
+    const int c = sub < MC ? sub : MC - 1;
+    cD = s.c3[c].cD; cmu = s.c3[c].cmu;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) car[k] = s.c3[c].car[k];
+    cact = s.c3[c].cact; cd1 = s.c3[c].cd1; cd2 = s.c3[c].cd2;
+  }
+  if (ROLE != 2 && ncmax > 0) {
     const int c = sub < MC ? sub : MC - 1;
     const bool cv = sub < nct;
     double rec[8];                                        // (a lane reads its own record only, and later writes its own edge weights over it: no exchange.  Slots
@@ -582,6 +666,19 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     wbits |= (jp[0] - cmu * jp[2] - car[3] < 0) ? 8u : 0u;
     cact = cv ? (warm ? wbits : 0xFu) : 0u;
   }
+  if constexpr (ROLE == 0) {                             // (as above: the contact rows' results as the two-wave form hands them over)
+    cD = pinned(cD); cmu = pinned(cmu); pin_batch(car);
+    asm volatile("" : "+v"(cact), "+v"(cd1), "+v"(cd2));
+  }
+  if constexpr (ROLE == 1) {
+    if (sub < MC) {
+      s.c3[sub].cD = cD; s.c3[sub].cmu = cmu;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s.c3[sub].car[k] = car[k];
+      s.c3[sub].cact = cact; s.c3[sub].cd1 = cd1; s.c3[sub].cd2 = cd2;
+    }
+    return;
+  }
   // which contact slots this lane's dof takes part in (bit c: it is the root's, or one of the two hinges of contact c's chain), which of the chain's two entries is
   // its own, whether it is the upper hinge: from the slots' chain records, ONCE per timestep (every pass read them again, a round trip before each contact's rows)
   unsigned int tbits = 0, sbits = 0, cbits = 0;
@@ -597,6 +694,17 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   }
   PSTAMP(6);
   PSTAMP(9);
+  if constexpr (ROLE == 2) {
+    // (after the contact rows, which need none of it; before the first pass writes s.pas, which lies over it)
+    const int hl = ishinge ? l - 6 : 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Bw[i] = s.hand.Bw[l][i];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Aw[p] = s.hand.Aw[hl][p];
+    rw = s.hand.rw[l];
+    pin_batch(Bw); pin_batch(Aw); rw = pinned(rw);
+    fence();
+  }
   // ------------------------------------------------------------------ K9: active-set Newton on the arrow-shaped Hessian
   double al = 0.0;                                       // this lane's entry of the solution
   PCOUNT(23, ncmax > 0 ? 1 : 0); PCOUNT(24, ncmax);

@@ -2154,6 +2154,7 @@ int check_cone(const earl_collision_model* col, const bool want_elliptic, hipStr
 
 #ifdef EARL_PHYS_VARIANT_MT
 int g_mt_stepper = 1;     // earl_debug_set_minitaur_stepper: 1 = the tree-structured timestep (minitaur_stepper.h), 0 = the generic substep<22>
+int g_mt_duo = EARL_MT_DUO_DEFAULT;   // earl_debug_set_minitaur_duo: 1 = the two-waves-per-SIMD rollout (minitaur_duo_kernel), 0 = the one-wave kernel, -1 = by batch size
 #endif
 #ifndef EARL_PEG_SLICE
 #define EARL_PEG_SLICE 10   // env steps per work item (tools/bench_peg_schedule.py: 5 and 10: 43.1 ms, 20: 44.3, 40: 47.0, 100: 50.9, one group per wave: 54.8) of the peg's time-sliced schedule (a slice is ~1 ms; claiming one costs a scan of the queue: microseconds)
@@ -2274,6 +2275,11 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
   if (cfg->n == 0 || T == 0) return EARL_OK;
   if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_rollout")) return rc;
   MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr, solo_mode(cfg->n)};
+  // two waves per SIMD by role (minitaur_duo_kernel: 16 envs per workgroup of eight waves) for batches that fill the chip's wave slots in the packed form anyway
+  if (g_mt_stepper && a.solo == 0 && (g_mt_duo > 0 || (g_mt_duo < 0 && cfg->n >= EARL_MT_DUO_MIN_ENVS))) {
+    minitaur_duo_kernel<<<(unsigned)((cfg->n + 16 * MT_DUO_PAIRS / 4 - 1) / (4 * MT_DUO_PAIRS)), 128 * MT_DUO_PAIRS, 0, (hipStream_t)stream>>>(a);
+    return launched("minitaur_rollout (two waves per SIMD)");
+  }
   if (g_mt_stepper) minitaur_kernel<false, true><<<solo_grid(cfg->n, a.solo, EARL_MT_WPB), 64 * EARL_MT_WPB, 0, (hipStream_t)stream>>>(a);
   else minitaur_kernel<false, false><<<solo_grid(cfg->n, a.solo, Lim<22>::WPB), block_for<22>(), 0, (hipStream_t)stream>>>(a);
   return launched("minitaur_rollout");
@@ -2301,7 +2307,16 @@ int earl_debug_set_minitaur_stepper(int tree) {          // 1 (default): minitau
   g_mt_stepper = tree;
   return EARL_OK;
 }
+int earl_debug_set_minitaur_duo(int mode) {              // 1: the two-waves-per-SIMD rollout kernel for every packed launch, 0: never, -1: by batch size (default).  Returns the previous setting
+  const int prev = g_mt_duo;
+  if (mode >= -1 && mode <= 1) g_mt_duo = mode;
+  return prev;
+}
 #ifdef EARL_PHYS_PROF
+int earl_debug_set_prof_wave_mt(int block, int thread) {     // this unit's copy of earl_debug_set_prof_wave (minitaur_duo_kernel: thread 0 = a first-half wave, thread 256 = its partner)
+  const int v[2] = {block, thread};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_sel), v, sizeof(v)) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
 int earl_debug_read_wave_cycles_mt(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_cycles), sizeof(unsigned long long) * 4096) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
 }

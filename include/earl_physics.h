@@ -437,6 +437,9 @@ int earl_minitaur_cfg_size(void);
  * constraint Hessian eliminated legs -> root body, parent / child exchanges by DPP), 0 = the generic nv = 22 instantiation of the stepper (dense
  * factorisation).  Same algorithm; results agree to rounding (tests/test_minitaur_gpu.py). */
 int earl_debug_set_minitaur_stepper(int tree);
+/* The minitaur's fused rollout in its two-waves-per-SIMD form (csrc/physics_env_minitaur.h minitaur_duo_kernel: a timestep in two halves run by two waves; same results):
+ * 1 = every packed launch, 0 = never, -1 = by batch size (the default).  Returns the previous setting.  Measurement / test switch. */
+int earl_debug_set_minitaur_duo(int mode);
 /* Small batches of the kitchen / minitaur launches (round 5; BASELINE configs[3] / [4] shard 2048 / 4096 envs over 8 GPUs: 256 / 512 per GPU).  An env is a serial chain of
  * T x frame_skip timesteps walked by one 32-lane group; the launch lasts as long as its slowest wave, and a wave's two envs wait for each other's longer branch in every
  * timestep.  -1 (default) = by batch size: n <= CUs: one env per WORKGROUP -- the kitchen with all FOUR waves on the env (mode 3: a timestep's constraint rows, mass matrix,

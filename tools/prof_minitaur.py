@@ -27,8 +27,12 @@ _abi.SIGNATURES['earl_debug_read_wave_cycles_mt'] = [C.c_void_p]
 from earl_benchmark_amd.envs.minitaur import Minitaur
 args = [int(x) for x in sys.argv[1:] if x.isdigit()]
 n, T = (args + [4096, 100])[:2] if len(args) < 2 else args[:2]
+_abi.SIGNATURES['earl_debug_set_prof_wave_mt'] = [C.c_int, C.c_int]
 env = Minitaur(num_envs=n, seed=1234, scalar_api=False)
 lib = _abi.load()
+if os.environ.get('PROF_DUO'):          # the two-waves-per-SIMD kernel: PROF_THREAD = 0 clocks a first-half wave, 256 its partner
+  lib.earl_debug_set_minitaur_duo(1)
+  lib.earl_debug_set_prof_wave_mt(int(os.environ.get('PROF_BLOCK', '0')), int(os.environ.get('PROF_THREAD', '0')))
 out = (C.c_ulonglong * 32)()
 torch.manual_seed(0)
 acts = torch.rand(T, n, 8, device='cuda') * 2 - 1
@@ -51,5 +55,7 @@ print(f'minitaur N={n} T={T}: launch {ms:.1f} ms = {n * T / ms / 1e3:.2f} M env-
       f'(max contacts per env, mean {out[24] / ts:.2f}), Newton iterations per timestep {out[25] / ts:.2f}')
 print(f'  timesteps with more than three passes {out[10] / ts:.3f}, with all eight {out[12] / ts:.4f}')
 print(f'  active-set pass, cycles per timestep: edge weights {out[16] / ts:.0f}, Hessian columns {out[17] / ts:.0f}, factor + solve {out[18] / ts:.0f}, row test {out[19] / ts:.0f}')
+if out[28]:
+  print(f'  two-waves-per-SIMD kernel, this wave: {out[28]} slots, work {out[26] / out[28]:.0f} cycles per slot, barrier wait {out[27] / out[28]:.0f}')
 tot = sum(out[i] for i in range(12) if NAMES[i] != '-')   # slot 10 holds a pass-count tally, not cycles
 print(f'  cycles per timestep {tot / ts:.0f}: ' + ', '.join(f'{NAMES[i].split()[0]} {out[i] / ts:.0f}' for i in range(12) if NAMES[i] != '-'))
