@@ -644,10 +644,11 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
 
 
 # STATIC figures (not measured in this run): one MI355X, reset + one fused launch of a SHARD of the strong-scaling batches, relative to the full batch -- copied from
-# profiles/r05_kitchen_small_batch.txt (tools/kitchen_small_batch.py on an MI355X, round 5; kitchen at 256 envs: four waves per env; at 512: two).  What `world` GPUs
+# profiles/r06_kitchen_small_batch.txt (tools/kitchen_small_batch.py on an MI355X, round 6; kitchen at 256 envs: four waves per env; at 512: two; minitaur: the 4096-env
+# launch takes the two-waves-per-SIMD kernel, 139 ms, the shards the one-wave kernel, 80 - 87 ms).  What `world` GPUs
 # would deliver if every shard ran like this one (no collective on the data path; the job's one all-gather is 16 KB)
-SHARD_PROFILE = 'profiles/r05_kitchen_small_batch.txt'
-MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.95, 4: 0.76, 8: 0.61}, 'minitaur': {1: 1.00, 2: 0.50, 4: 0.47, 8: 0.46}}
+SHARD_PROFILE = 'profiles/r06_kitchen_small_batch.txt'
+MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.96, 4: 0.77, 8: 0.62}, 'minitaur': {1: 1.00, 2: 0.62, 4: 0.58, 8: 0.58}}
 
 
 def predicted_scaling(workload, n_global, world):
@@ -659,13 +660,13 @@ def predicted_scaling(workload, n_global, world):
     weak:   the regime the design scales in -- the config's batch PER GPU (2048 / 4096 envs each): every rank runs the one-GPU launch on its own env range, no
             data-path collective, one all-gather of the [N, 2] evaluation summary per job (16-32 KB per rank: microseconds over xGMI), so the prediction is `world` x
             the one-GPU figure.  Nothing here is a measured multi-GPU number."""
-  per_round = 2048                                      # both kernels: 2 envs per wave, 4 waves per CU, 256 CUs
+  per_round = 2048                                      # the one-wave kernels: 2 envs per wave, 4 waves per CU, 256 CUs (the minitaur's two-wave kernel: 4096)
   rounds_1 = -(-n_global // per_round)
   rounds_w = -(-(-(-n_global // world)) // per_round)
   rel = MEASURED_SHARD_TIME.get(workload, {}).get(world) if n_global == (2048 if workload == 'kitchen' else 4096) else None
   strong = {'envs_per_gpu': -(-n_global // world), 'launch_rounds_on_1_gpu': rounds_1, f'launch_rounds_on_{world}_gpus': rounds_w,
             'predicted_speedup_vs_1_gpu': (1.0 / rel) if rel else rounds_1 / rounds_w,
-            'basis': f'static: one MI355X running one shard of this size ({SHARD_PROFILE}, round 5; not measured in this run)' if rel else 'launch rounds',
+            'basis': f'static: one MI355X running one shard of this size ({SHARD_PROFILE}, round 6; not measured in this run)' if rel else 'launch rounds',
             'note': (f'{workload}: {n_global} envs = {rounds_1} round(s) of 2048 resident envs on one MI355X; on {world} GPU(s) a shard of {-(-n_global // world)} envs takes '
                      + (f'{rel:.2f} x the full-batch launch, so the job is predicted {1.0 / rel:.2f} x faster' if rel else f'{rounds_w} round(s): predicted {rounds_1 / rounds_w:.1f} x at best')
                      + '.  The chain of an env (T x frame_skip dependent timesteps on one 32-lane group) does not shorten with more GPUs; the scaling lever of these workloads is MORE envs.')}
@@ -844,12 +845,13 @@ def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=40
   tpath = os.path.join(REPO, 'profiles', 'traffic.json')
   if os.path.exists(tpath) and (n_global, T, world) == (4096, 1000, 1):
     prof = json.load(open(tpath)).get('minitaur', {})
-  roof = pipe_roofline(prof, 'minitaur_kernel', clk.elapsed_ms() / steps)
+  roof = pipe_roofline(prof, 'minitaur_duo_kernel (two waves per SIMD)' if (n >= 2049 and world == 1 and prof.get('waves_per_simd') == 2) else 'minitaur_kernel', clk.elapsed_ms() / steps)
   return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
           'valu_frac': roof['frac'], 'roofline': roof, 'timesteps_per_s': steps * n_global * T * 5 / dt, 'scaling': 'strong', 'diverged_env_steps': fails,
           'config': {'workload': f'minitaur dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 5 '
                                  'timesteps per bench step; own robot model (nv = 22, four loop closures) and tree-structured stepper (csrc/minitaur_stepper.h), parity with PyBullet unpinned and model-less',
                      'envs_global': n_global, 'envs_per_gpu': n, 'horizon': T, 'frame_skip': 5, 'launches_per_episode': 2,
+                     'launch_form': 'by batch size: the two-waves-per-SIMD rollout kernel when it needs less time for the batch (16 envs per CU: 4096 envs are one round), else the one-wave kernel; same bits',
                      'parallelism': f'env-range shard x{world} of a FIXED {n_global}-env batch (strong scaling), no per-step collective, one all-gather of the [N, 2] '
                                     'evaluation summary per job', 'predicted_scaling': predicted_scaling('minitaur', n_global, world)},
           'gathered_rows': None if gathered is None else int(gathered.shape[0]),

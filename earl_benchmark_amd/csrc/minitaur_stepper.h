@@ -66,6 +66,15 @@ __device__ __forceinline__ void sincos_kc(double x, double& sn, double& cs) {
   cs = (q == 0) ? cr : ((q == 1) ? -sr : ((q == 2) ? -cr : sr));
 }
 
+#ifdef EARL_MT_DEBUG
+__device__ int g_mt_dbg[4096 * 8 * 32];          // per env, timestep (mod 8): [0] contacts, [1] warm, [2] passes, [4..15] the contacts' edge sets before the passes, [16..27] after
+__device__ double g_mt_dbg_al[4096 * 8 * 32];    // ... and the solution
+__device__ double g_mt_dbg_x[5][4096 * 8 * 32];  // per dof: 0 rw, 1 a weighted sum of Bw, 2 of Aw, 3 qv after the integration, 4 the external force of the timestep
+__device__ double g_mt_dbg_ph[8][4096 * 8 * 32]; // per dof, a weighted sum of what each phase of the dynamics half leaves: 0 frames, 1 subspace + inertia, 2 composite inertia, 3 mass-matrix entries, 4 tau, 5 closure rows
+#define DBG_PH(k, v) do { if (isl) g_mt_dbg_ph[k][((size_t)s.dbg_env * 8 + (s.dbg_ts & 7)) * 32 + l] = (v); } while (0)
+#else
+#define DBG_PH(k, v) do {} while (0)
+#endif
 struct MTDims {
   static constexpr int NV = 22, NR = 6, NLEG = 4, LS = 4, NH = 16, LPE = 32, MC = EARL_MAXCON, MB = 8;
 };
@@ -116,10 +125,14 @@ struct SharedMTData {
   double eres[12], eD[12], ear[12];  // closure rows: residual, weight, reference acceleration
   // minitaur_duo_kernel: what an env's step keeps between the visits of its wave (the one-wave kernel holds these in registers): motors 0 - 7 -- observed torque, the env step's
   // command, overheat counter, enabled flag --, the goal, the wrappers' counters
-  struct { double obs_t[8], cmd[8]; int oh[8], en[8]; double goal[2]; int steps, sgc; } ev;
+  struct { double obs_t[8], cmd[8]; int oh[8], en[8]; double goal[2]; int steps, sgc, pad_[2]; } ev;      // (a multiple of 16 bytes: what follows keeps its 16-byte alignment --
+                                                                                                           // without it 220 of the kernel's 255 ds_read_b128 became ds_read2_b64, twice the LDS cycles: 178 -> 212 ms per bench launch)
   // ... and what the contact rows (C3, wave A's half) leave in the contact's LANE for the passes (wave B's half): weight, friction, the four edges' reference accelerations,
   // the warm-started active edges, the chain's hinges
   struct { double cD, cmu, car[4]; unsigned int cact; int cd1, cd2, pad_; } c3[MC];
+#ifdef EARL_MT_DEBUG
+  int dbg_env, dbg_ts, dbg_pad[2];   // (tools/mt_duo_bisect.py, debug builds only: which env this block holds, timesteps since the launch began)
+#endif
   union {
     double ct[MC][8];                // contact records (pair tests -> contact rows)
     double cw[MC][8];                // per-pass edge weights
@@ -161,6 +174,7 @@ struct SharedMTData {
     } pas;
   };
 };
+static_assert(sizeof(((SharedMTData*)nullptr)->ev) % 16 == 0 && sizeof(((SharedMTData*)nullptr)->c3) % 16 == 0 && offsetof(SharedMTData, dyn) % 16 == 0, "16-byte alignment of the blocks the kernels read as b128");
 static_assert(offsetof(SharedMTData, hand.sh_keep) == offsetof(SharedMTData, dyn.Sh) && offsetof(SharedMTData, hand.Aw) == offsetof(SharedMTData, dyn.redI) &&
               sizeof(((SharedMTData*)nullptr)->hand) <= sizeof(((SharedMTData*)nullptr)->dyn), "the hand-over block keeps clear of the motion subspaces and fits the dynamics block");
 struct SharedMT : SharedMTData {
@@ -218,6 +232,12 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     Q = selq(isroot, Qr, selq(lower, Qw, Qu));
     P = selv(isroot, Pr, selv(lower, Pw, Pu));
   }
+#ifdef EARL_MT_DEBUG_FRAMES
+  DBG_PH(0, Q.w); DBG_PH(1, Q.x); DBG_PH(2, Q.y); DBG_PH(3, Q.z); DBG_PH(4, P.x); DBG_PH(5, P.y); DBG_PH(6, P.z); DBG_PH(7, ql_);
+#else
+  DBG_PH(0, Q.w + 2 * Q.x + 3 * Q.y + 5 * Q.z + 7 * P.x + 11 * P.y + 13 * P.z);
+  DBG_PH(5, ql_); DBG_PH(6, Qb.w + 2 * Qb.x + 3 * Qb.y + 5 * Qb.z + 7 * Pb.x + 11 * Pb.y + 13 * Pb.z); DBG_PH(7, qd);
+#endif
   if (isl) {
     double* oq = s.dyn.Xq[l];
     double* op = s.dyn.Xp[l];
@@ -285,6 +305,10 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       o[0] = Sw.x; o[1] = Sw.y; o[2] = Sw.z; o[3] = Sv.x; o[4] = Sv.y; o[5] = Sv.z;
     }
   }
+  
+#ifndef EARL_MT_DEBUG_FRAMES
+  DBG_PH(1, Sw.x + 2 * Sw.y + 3 * Sw.z + 5 * Sv.x + 7 * Sv.y + 11 * Sv.z + 13 * I10[0] + 17 * I10[1] + 19 * I10[2] + 23 * I10[3] + 29 * I10[4] + 31 * I10[5] + 37 * I10[6] + 41 * I10[7] + 43 * I10[8] + 47 * I10[9]);
+#endif
   PSTAMP(1);
   // ------------------------------------------------------------------ K4: composite inertia (own + child by DPP; the root body: everything, through LDS)
   double Ic[10];
@@ -303,7 +327,10 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     double tot[10];
 #pragma unroll
     for (int e = 0; e < 10; ++e) tot[e] = s.dyn.redI[8][e];
-    if constexpr (ROLE == 0) {
+#ifndef EARL_MT_NO_CHUNK
+#define EARL_MT_NO_CHUNK 0       // (measurement: 1 = the role builds sum the subtrees like the one-wave build and spill)
+#endif
+    if constexpr (ROLE == 0 || EARL_MT_NO_CHUNK) {
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -326,6 +353,10 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
 #pragma unroll
     for (int e = 0; e < 10; ++e) Ic[e] = isroot ? tot[e] : Ic[e];
   }
+  
+#ifndef EARL_MT_DEBUG_FRAMES
+  DBG_PH(2, Ic[0] + 2 * Ic[1] + 3 * Ic[2] + 5 * Ic[3] + 7 * Ic[4] + 11 * Ic[5] + 13 * Ic[6] + 17 * Ic[7] + 19 * Ic[8] + 23 * Ic[9]);
+#endif
   PSTAMP(3);
   // ------------------------------------------------------------------ K5: this lane's entries of the mass matrix
   // g6 = row l of the six root columns: M[l][r] = S_r . (Ic_l S_l) = [f ; Rb' (n + f x Pb)] with [n; f] = Ic_l S_l  (hinge: its row of B; root dof: its row of R);
@@ -340,6 +371,10 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     const V3 nc = dpp_quad<QP_CHILD>(n), fc = dpp_quad<QP_CHILD>(f);
     Ach = dot(Sw, nc) + dot(Sv, fc);
   }
+  
+#ifndef EARL_MT_DEBUG_FRAMES
+  DBG_PH(3, g6[0] + 2 * g6[1] + 3 * g6[2] + 5 * g6[3] + 7 * g6[4] + 11 * g6[5] + 13 * Add + 17 * Ach);
+#endif
   PSTAMP(4);
   // ------------------------------------------------------------------ K6-K7: bias forces
   const V3 vlin = ld3(s.qv), om = ld3(s.qv + 3);
@@ -375,7 +410,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     }
     fence();
     V3 nt = ld3(s.dyn.redF[8]), ft = ld3(s.dyn.redF[8] + 3);
-    if constexpr (ROLE == 0) {
+    if constexpr (ROLE == 0 || EARL_MT_NO_CHUNK) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) { nt = add(nt, ld3(s.dyn.redF[u])); ft = add(ft, ld3(s.dyn.redF[u] + 3)); }
     } else {
@@ -394,6 +429,10 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     ns = selv(isroot, nt, ns); fs = selv(isroot, ft, fs);
     tau_l = -m.damping[l] * qd - (dot(Sw, ns) + dot(Sv, fs)) + s.xt.ext[l];
   }
+  
+#ifndef EARL_MT_DEBUG_FRAMES
+  DBG_PH(4, tau_l);
+#endif
   PSTAMP(5);
   // ------------------------------------------------------------------ C1-C2: pair tests of the near blocks (lane = pair; spheres vs world-fixed boxes)
   if (nearw) {
@@ -657,15 +696,25 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     const double R0 = fmax((1 - dd) * ctab[4] * rcp_nr(dd), 1e-15);
     cD = cv ? rcp_nr(2 * cmu * cmu * R0) : 0.0;
     const double basea = -kk * dd * (rec[0] - margin);
-    car[0] = -bb * (jv[0] + cmu * jv[1]) + basea; car[1] = -bb * (jv[0] - cmu * jv[1]) + basea;
-    car[2] = -bb * (jv[0] + cmu * jv[2]) + basea; car[3] = -bb * (jv[0] - cmu * jv[2]) + basea;
+    // (the edges' combinations as EXPLICIT fused multiply-adds, here, in the warm-start test below and in the passes' row test: left to fp contract(fast) the one-wave and
+    // the two-wave instantiations fused them differently, the warm-started edge set of a row within rounding of zero differed, and with it -- about once in 10^4 env steps --
+    // the pass sequence and the last bits of the solution)
+    car[0] = fma(-bb, fma(cmu, jv[1], jv[0]), basea); car[1] = fma(-bb, fma(-cmu, jv[1], jv[0]), basea);
+    car[2] = fma(-bb, fma(cmu, jv[2], jv[0]), basea); car[3] = fma(-bb, fma(-cmu, jv[2], jv[0]), basea);
     unsigned int wbits = 0;
-    wbits |= (jp[0] + cmu * jp[1] - car[0] < 0) ? 1u : 0u;
-    wbits |= (jp[0] - cmu * jp[1] - car[1] < 0) ? 2u : 0u;
-    wbits |= (jp[0] + cmu * jp[2] - car[2] < 0) ? 4u : 0u;
-    wbits |= (jp[0] - cmu * jp[2] - car[3] < 0) ? 8u : 0u;
+    wbits |= (fma(cmu, jp[1], jp[0]) - car[0] < 0) ? 1u : 0u;
+    wbits |= (fma(-cmu, jp[1], jp[0]) - car[1] < 0) ? 2u : 0u;
+    wbits |= (fma(cmu, jp[2], jp[0]) - car[2] < 0) ? 4u : 0u;
+    wbits |= (fma(-cmu, jp[2], jp[0]) - car[3] < 0) ? 8u : 0u;
     cact = cv ? (warm ? wbits : 0xFu) : 0u;
   }
+#ifdef EARL_MT_DEBUG
+  if constexpr (ROLE != 2) {
+    int* row = g_mt_dbg + ((size_t)s.dbg_env * 8 + (s.dbg_ts & 7)) * 32;
+    if (sub < MC) row[4 + sub] = (int)cact;
+    if (sub == 0) { row[0] = nct; row[1] = warm ? 1 : 0; }
+  }
+#endif
   if constexpr (ROLE == 0) {                             // (as above: the contact rows' results as the two-wave form hands them over)
     cD = pinned(cD); cmu = pinned(cmu); pin_batch(car);
     asm volatile("" : "+v"(cact), "+v"(cd1), "+v"(cd2));
@@ -705,11 +754,23 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     pin_batch(Bw); pin_batch(Aw); rw = pinned(rw);
     fence();
   }
+#ifdef EARL_MT_DEBUG
+  if (isl) {
+    const size_t o_ = ((size_t)s.dbg_env * 8 + (s.dbg_ts & 7)) * 32 + l;
+    g_mt_dbg_x[0][o_] = rw;
+    g_mt_dbg_x[1][o_] = Bw[0] + 2 * Bw[1] + 3 * Bw[2] + 5 * Bw[3] + 7 * Bw[4] + 11 * Bw[5];
+    g_mt_dbg_x[2][o_] = Aw[0] + 2 * Aw[1] + 3 * Aw[2] + 5 * Aw[3];
+    g_mt_dbg_x[4][o_] = s.xt.ext[l];
+  }
+#endif
   // ------------------------------------------------------------------ K9: active-set Newton on the arrow-shaped Hessian
   double al = 0.0;                                       // this lane's entry of the solution
   PCOUNT(23, ncmax > 0 ? 1 : 0); PCOUNT(24, ncmax);
   for (int it = 0; it < 8; ++it) {
     PCOUNT(25, 1);
+#ifdef EARL_MT_DEBUG
+    if (sub == 0) g_mt_dbg[((size_t)s.dbg_env * 8 + (s.dbg_ts & 7)) * 32 + 2] = it + 1;
+#endif
     KSTART();
     if (ncmax > 0) {
       if (sub < MC) {
@@ -901,10 +962,10 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
         an[k] = a_;
       }
       unsigned int nb = 0;
-      nb |= (an[0] + cmu * an[1] - car[0] < 0) ? 1u : 0u;
-      nb |= (an[0] - cmu * an[1] - car[1] < 0) ? 2u : 0u;
-      nb |= (an[0] + cmu * an[2] - car[2] < 0) ? 4u : 0u;
-      nb |= (an[0] - cmu * an[2] - car[3] < 0) ? 8u : 0u;
+      nb |= (fma(cmu, an[1], an[0]) - car[0] < 0) ? 1u : 0u;
+      nb |= (fma(-cmu, an[1], an[0]) - car[1] < 0) ? 2u : 0u;
+      nb |= (fma(cmu, an[2], an[0]) - car[2] < 0) ? 4u : 0u;
+      nb |= (fma(-cmu, an[2], an[0]) - car[3] < 0) ? 8u : 0u;
       nb = sub < nct ? nb : 0u;
       changed = nb != cact;
       cact = nb;
@@ -914,6 +975,16 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     PCOUNT(10, it == 2 ? 1 : 0);                          // (profiling build: timesteps that go beyond three passes ...
     PCOUNT(12, it == 6 ? 1 : 0);                          //  ... and those that use all eight)
   }
+#ifdef EARL_MT_DEBUG
+  {
+    int* row = g_mt_dbg + ((size_t)s.dbg_env * 8 + (s.dbg_ts & 7)) * 32;
+    if (sub < MC) row[16 + sub] = (int)cact;
+    if (isl) reinterpret_cast<double*>(g_mt_dbg_al)[((size_t)s.dbg_env * 8 + (s.dbg_ts & 7)) * 32 + l] = al;
+    fence();
+    if (sub == 0) s.dbg_ts = s.dbg_ts + 1;
+    fence();
+  }
+#endif
   PSTAMP(8);
   if constexpr (!INTEGRATE) {
     if (qacc_out && isl) qacc_out[l] = al;
@@ -921,26 +992,39 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     // ---------------------------------------------------------------- K10: semi-implicit Euler (no joint damping in this model: checked by the host side)
     fence();
     if (isl) {
-      const double nv_ = qd + dt * al;
+      // (explicit fused multiply-adds: left to fp contract(fast) the one-wave and the two-wave instantiations of this function chose differently here -- a position that
+      // differs in its last bit about once in 10^4 env steps was the only thing that told them apart: tools/mt_duo_bisect.py)
+      const double nv_ = fma(dt, al, qd);
       s.qv[l] = nv_;
-      s.qp[l] = ql_ + dt * nv_;                           // (unused for the rotation dofs of the root body)
+      s.qp[l] = fma(dt, nv_, ql_);                        // (unused for the rotation dofs of the root body)
     }
     fence();
     {
       const int bd = m.ball_dof;
       const V3 wbd{s.qv[bd], s.qv[bd + 1], s.qv[bd + 2]};
+      // The orientation update with every sum of products written as an EXPLICIT chain of fused multiply-adds (norm2, mul4 below): left to fp contract(fast), the one-wave
+      // and the two-wave instantiations of this function fused these sums differently, and the base quaternion's last bit -- about once in 10^4 env steps -- was all that told
+      // their results apart (tools/mt_duo_bisect.py: located phase by phase, then component by component).
+      auto norm2 = [](const Q4& q) { return fma(q.z, q.z, fma(q.y, q.y, fma(q.x, q.x, q.w * q.w))); };
+      auto mul4 = [](const Q4& a, const Q4& b) {
+        return Q4{fma(-a.z, b.z, fma(-a.y, b.y, fma(-a.x, b.x, a.w * b.w))), fma(-a.z, b.y, fma(a.y, b.z, fma(a.x, b.w, a.w * b.x))),
+                  fma(a.z, b.x, fma(a.y, b.w, fma(-a.x, b.z, a.w * b.y))), fma(a.z, b.w, fma(-a.y, b.x, fma(a.x, b.y, a.w * b.z)))};
+      };
       Q4 q0 = Qb;
-      const double n0 = rsq2(q0.w * q0.w + q0.x * q0.x + q0.y * q0.y + q0.z * q0.z);
+      const double n0 = rsq2(norm2(q0));
       q0 = Q4{q0.w * n0, q0.x * n0, q0.y * n0, q0.z * n0};
-      const double w2 = dot(wbd, wbd);
+      const double w2 = fma(wbd.z, wbd.z, fma(wbd.y, wbd.y, wbd.x * wbd.x));
       const double iw = w2 > 0 ? rsq2(w2 > 0 ? w2 : 1.0) : 0.0;
       double sn, cs;
       sincos_kc(0.5 * dt * (w2 * iw), sn, cs);
-      const Q4 q1 = qmul(q0, Q4{cs, sn * wbd.x * iw, sn * wbd.y * iw, sn * wbd.z * iw});
-      const double n1 = rsq2(q1.w * q1.w + q1.x * q1.x + q1.y * q1.y + q1.z * q1.z);
+      const Q4 q1 = mul4(q0, Q4{cs, sn * wbd.x * iw, sn * wbd.y * iw, sn * wbd.z * iw});
+      const double n1 = rsq2(norm2(q1));
       if (sub == 0) { s.bq[0] = q1.w * n1; s.bq[1] = q1.x * n1; s.bq[2] = q1.y * n1; s.bq[3] = q1.z * n1; }
       fence();
     }
+#ifdef EARL_MT_DEBUG
+    if (isl) g_mt_dbg_x[3][((size_t)s.dbg_env * 8 + ((s.dbg_ts - 1) & 7)) * 32 + l] = s.qv[l];
+#endif
     PSTAMP(11);
   }
 }

@@ -2174,6 +2174,14 @@ int solo_mode(int n) {
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   return n <= cus ? 2 : (n <= 4 * cus ? 1 : 0);
 }
+// minitaur rollout, packed launches: the one-wave kernel holds 8 envs per CU, the two-wave kernel 16 at 1.6 x the time per round (measured: 4096 x 1000 in 174 ms = two rounds of
+// 87 against one round of 139): whichever needs less time for the batch's rounds
+bool mt_use_duo(int n) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long rounds_one = (n + 8L * cus - 1) / (8L * cus), rounds_two = (n + 16L * cus - 1) / (16L * cus);
+  return 16 * rounds_two < 10 * rounds_one;
+}
 int solo_grid(int n, int solo, int wpb) { return solo == 2 ? n : (solo == 1 ? (n + wpb - 1) / wpb : (n + 2 * wpb - 1) / (2 * wpb)); }
 
 // launch geometry: Lim<NV>::WPB wavefronts per workgroup, 64 / LPE envs per wavefront
@@ -2276,7 +2284,7 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
   if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_rollout")) return rc;
   MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr, solo_mode(cfg->n)};
   // two waves per SIMD by role (minitaur_duo_kernel: 16 envs per workgroup of eight waves) for batches that fill the chip's wave slots in the packed form anyway
-  if (g_mt_stepper && a.solo == 0 && (g_mt_duo > 0 || (g_mt_duo < 0 && cfg->n >= EARL_MT_DUO_MIN_ENVS))) {
+  if (g_mt_stepper && a.solo == 0 && (g_mt_duo > 0 || (g_mt_duo < 0 && mt_use_duo(cfg->n)))) {
     minitaur_duo_kernel<<<(unsigned)((cfg->n + 16 * MT_DUO_PAIRS / 4 - 1) / (4 * MT_DUO_PAIRS)), 128 * MT_DUO_PAIRS, 0, (hipStream_t)stream>>>(a);
     return launched("minitaur_rollout (two waves per SIMD)");
   }
@@ -2312,6 +2320,14 @@ int earl_debug_set_minitaur_duo(int mode) {              // 1: the two-waves-per
   if (mode >= -1 && mode <= 1) g_mt_duo = mode;
   return prev;
 }
+#ifdef EARL_MT_DEBUG
+int earl_debug_read_mt_dbg(int* out_i, double* out_d) {
+  if (hipMemcpyFromSymbol(out_i, HIP_SYMBOL(g_mt_dbg), sizeof(int) * 4096 * 8 * 32) != hipSuccess) return EARL_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out_d, HIP_SYMBOL(g_mt_dbg_al), sizeof(double) * 4096 * 8 * 32) != hipSuccess) return EARL_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out_d + 4096 * 8 * 32, HIP_SYMBOL(g_mt_dbg_x), sizeof(double) * 5 * 4096 * 8 * 32) != hipSuccess) return EARL_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(out_d + 6 * 4096 * 8 * 32, HIP_SYMBOL(g_mt_dbg_ph), sizeof(double) * 8 * 4096 * 8 * 32) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
+#endif
 #ifdef EARL_PHYS_PROF
 int earl_debug_set_prof_wave_mt(int block, int thread) {     // this unit's copy of earl_debug_set_prof_wave (minitaur_duo_kernel: thread 0 = a first-half wave, thread 256 = its partner)
   const int v[2] = {block, thread};

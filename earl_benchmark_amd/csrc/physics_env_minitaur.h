@@ -30,13 +30,9 @@ __device__ __forceinline__ double mt_draw(const earl_minitaur_cfg& cfg, const ui
 #define EARL_MT_BLOCKS 1         // ... and workgroups per CU the register budget is set for (2 = two waves per SIMD, 256 registers each: spills 1.4 KB per lane and runs 1.5 x slower, tools/bench_mt_variant.py)
 #endif
 #ifndef EARL_MT_DUO_DEFAULT
-#define EARL_MT_DUO_DEFAULT 0    // g_mt_duo at start-up: 0 = the one-wave kernel for every batch.  The two-waves-per-SIMD kernel (minitaur_duo_kernel below; 1 = always, -1 = by batch
-                                 // size) is OPT-IN: its results equal the one-wave kernel's to rounding, not bit for bit (another context under fp contract(fast): about one env step in 10^4 rounds
-                                 // differently), so a batch and its shards would part ways; and it pays only on short launches (+22 % on the first 200 env steps after a reset, +3 % on the
-                                 // bench's 1000-step launch: profiles/r06_minitaur_two_waves_per_simd.txt)
-#endif
-#ifndef EARL_MT_DUO_MIN_ENVS
-#define EARL_MT_DUO_MIN_ENVS 3072   // mode -1: batches of at least this many envs take the two-waves-per-SIMD kernel (16 envs per CU: 4096 envs fill the chip once)
+#define EARL_MT_DUO_DEFAULT -1   // g_mt_duo at start-up: -1 = the launcher picks the rollout kernel by batch size (mt_use_duo), 0 = always the one-wave kernel, 1 = the two-waves-per-SIMD
+                                 // kernel (minitaur_duo_kernel below) for every packed launch.  The two kernels return the same bits (tests/test_minitaur_gpu.py), so the choice is
+                                 // about speed only: 16 resident envs per CU against 8, a round of the two-wave kernel taking 1.6 x a round of the one-wave kernel
 #endif
 template <bool ARROW> constexpr int mt_wpb() { return ARROW ? EARL_MT_WPB : Lim<22>::WPB; }
 template <bool RESET, bool ARROW>
@@ -60,6 +56,9 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
   const int env = env_raw < n ? env_raw : n - 1;        // idle groups shadow the last env (solo: their wave-mate's) and store nothing
   const bool live = in_batch && (!RESET || !a.mask || a.mask[env] != 0);      // (a reset leaves the envs outside the mask alone: their groups compute and discard)
   SH& s = sh[wave * EPW + grp];
+#ifdef EARL_MT_DEBUG
+  if constexpr (ARROW) { if (sub == 0) { s.dbg_env = env < 4096 ? env : 4095; s.dbg_ts = 0; } }
+#endif
 #ifdef EARL_PHYS_PROF
   const unsigned long long wave_t0 = __builtin_readcyclecounter();
 #endif
@@ -292,6 +291,9 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
       SharedMT& s = sh[(pair * 2 + q) * EPW + grp];
       const double* mp = a.st.motor_param + (size_t)env * 6;
       load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
+#ifdef EARL_MT_DEBUG
+      if (sub == 0) { s.dbg_env = env < 4096 ? env : 4095; s.dbg_ts = 0; }
+#endif
       if (sub < NV) s.xt.ext[sub] = 0.0;
       if (sub < 8) {
         s.ev.oh[sub] = a.st.overheat[(size_t)env * 8 + sub]; s.ev.en[sub] = a.st.motor_enabled[(size_t)env * 8 + sub] != 0 ? 1 : 0;

@@ -270,7 +270,7 @@ def test_two_rank_strong_scaling_lines(tmp_path, which, n_global):
   # what the kernels' layout predicts for the real shapes (one round of 2048 resident envs per GPU): stated in the line
   # the line says what the kernels' layout gives, from MEASURED shard launches (profiles/r05_kitchen_small_batch.txt), never 'x8'
   k8, m8 = bench.predicted_scaling('kitchen', 2048, 8), bench.predicted_scaling('minitaur', 4096, 8)
-  assert 1.0 <= k8['strong']['predicted_speedup_vs_1_gpu'] < 1.9 and 2.0 <= m8['strong']['predicted_speedup_vs_1_gpu'] < 2.5
+  assert 1.0 <= k8['strong']['predicted_speedup_vs_1_gpu'] < 1.9 and 1.5 <= m8['strong']['predicted_speedup_vs_1_gpu'] < 2.0
   for p8 in (k8, m8):                                            # static figures, labelled so, with the file they come from -- which exists and holds this workload
     assert p8['strong']['basis'].startswith('static') and bench.SHARD_PROFILE in p8['strong']['basis'] and os.path.exists(os.path.join(REPO, bench.SHARD_PROFILE))
   prof = open(os.path.join(REPO, bench.SHARD_PROFILE)).read()

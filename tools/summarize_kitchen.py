@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, 'gpurun_out'), os.path.join(ROOT, 'profiles')
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 w = sys.argv[2] if len(sys.argv) > 2 else 'kitchen'
-KERNEL = {'kitchen': 'kitchen_rollout_kernel', 'minitaur': 'minitaur_kernel'}[w]      # (kitchen: the fused rollout; its step_api leg launches physics_kernel<23, 32>)
+KERNEL = {'kitchen': 'kitchen_rollout_kernel', 'minitaur': 'minitaur_'}[w]      # (minitaur: minitaur_kernel<..> or minitaur_duo_kernel, whichever the launch took)      # (kitchen: the fused rollout; its step_api leg launches physics_kernel<23, 32>)
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
 stats = newest(os.path.join(OUT, f'prof_{w}_stats', '*', '*_kernel_stats.csv'))
 shutil.copy(stats, os.path.join(PROF, f'{tag}_bench_{w}_kernel_stats.csv'))
@@ -36,6 +36,6 @@ if 'SQ_WAVE_CYCLES' in c:
 json.dump(res, open(os.path.join(PROF, f'{tag}_{w}_rollout_pmc.json'), 'w'), indent=1)
 tp = os.path.join(PROF, 'traffic.json')
 tj = json.load(open(tp)) if os.path.exists(tp) else {}
-tj[w] = {'source': f'profiles/{tag}_{w}_rollout_pmc.json', 'rocprof_kernel_average_ns': float(kern['AverageNs']), 'issue': res.get('derived'), 'waves_per_simd': 1}
+tj[w] = {'source': f'profiles/{tag}_{w}_rollout_pmc.json', 'rocprof_kernel_average_ns': float(kern['AverageNs']), 'issue': res.get('derived'), 'waves_per_simd': 2 if 'duo' in kern['Name'] else 1}
 json.dump(tj, open(tp, 'w'), indent=1)
 print(json.dumps(res, indent=1))
