@@ -279,6 +279,7 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), sub = lane % LPE, grp = lane / LPE, n = cfg.n;
   const int pair = wave & (NP - 1);
   const bool role_b = wave >= NP;                       // (waves w and w + 4 of a workgroup land on the same SIMD: every SIMD hosts one wave of each role)
+  // (measured and left out: issue priority for the solver half -- the longer one -- 138.7 -> 147.5 ms per bench launch, for the dynamics half 139.9; s_sleep 1 / 32 in the pair barrier 139.3 / 140.2)
   // (this lane's motor constants are re-read where they are used, from a lane index the compiler cannot follow: hoisted out of the slot loop they sat in registers across both
   // halves of the timestep and were spilled around them)
   const int NS = cfg.num_substeps, TT = a.T * NS;       // timesteps per env of this launch
