@@ -259,3 +259,33 @@ def test_two_waves_per_simd_rollout_is_bit_identical_to_the_one_wave_kernel(torc
     assert float(np.abs(rc['obs'][0] - rg['obs'][0].cpu().numpy()).max()) < 1e-6
   finally:
     lib.earl_debug_set_minitaur_duo(prev)
+
+
+def test_two_waves_kernel_failure_guard_goal_switch_and_horizon_match_the_one_wave_kernel(torch):
+  """the two-wave kernel's env-level paths against the one-wave kernel's, bit for bit, on a packed batch (1,100 envs; the kernel forced): a poisoned env is rolled back and flagged
+  (its neighbours untouched), the lifelong wrapper's goal switch inside the launch (goal_change_frequency), the horizon's done flag and the wrappers' counters"""
+  from earl_benchmark_amd import _abi
+  lib = _abi.load()
+  n, T = 1100, 7
+  g = torch.Generator(device='cuda').manual_seed(12)
+  acts = (torch.rand(T, n, 8, generator=g, device='cuda') * 2 - 1)
+  prev = lib.earl_debug_set_minitaur_duo(0)
+  try:
+    res = {}
+    for mode in (0, 1):
+      lib.earl_debug_set_minitaur_duo(mode)
+      env = make(n, seed=41)
+      env.qvel[5, 7] = float('nan')                                             # poison one env
+      env._cfg.goal_change_frequency = 3                                        # LifelongWrapper.step's switch, every third env step
+      env._cfg.horizon = 5
+      out = env.rollout(acts)
+      torch.cuda.synchronize()
+      res[mode] = [out[k].clone() for k in ('obs', 'reward', 'done', 'success', 'status')] + \
+                  [getattr(env, k).clone() for k in ('qpos', 'qvel', 'goal_t', 'fail_count', 'steps_since_reset', 'steps_since_goal_change', 'overheat', 'observed_torque', 'last_obs')]
+    st = res[1][4]
+    assert st[:, 5].tolist() == [1] * T and int(st.sum()) == T and int(res[1][8][5]) == T         # the poisoned env: every step rolled back and counted
+    assert bool(res[1][2][4:].all()) and not bool(res[1][2][:4].any())                             # done from the horizon's step on
+    for a, b in zip(res[0], res[1]):
+      assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a.double()), torch.nan_to_num(b.double()))
+  finally:
+    lib.earl_debug_set_minitaur_duo(prev)
