@@ -130,6 +130,7 @@ struct SharedMTData {
   // ... and what the contact rows (C3, wave A's half) leave in the contact's LANE for the passes (wave B's half): weight, friction, the four edges' reference accelerations,
   // the warm-started active edges, the chain's hinges
   struct { double cD, cmu, car[4]; unsigned int cact; int cd1, cd2, pad_; } c3[MC];
+  unsigned int tb[NV][4];             // ... and per dof: which contact slots it takes part in (tbits, sbits, cbits of K9), worked out once per timestep by the first half
 #ifdef EARL_MT_DEBUG
   int dbg_env, dbg_ts, dbg_pad[2];   // (tools/mt_duo_bisect.py, debug builds only: which env this block holds, timesteps since the launch began)
 #endif
@@ -174,14 +175,55 @@ struct SharedMTData {
     } pas;
   };
 };
-static_assert(sizeof(((SharedMTData*)nullptr)->ev) % 16 == 0 && sizeof(((SharedMTData*)nullptr)->c3) % 16 == 0 && offsetof(SharedMTData, dyn) % 16 == 0, "16-byte alignment of the blocks the kernels read as b128");
+static_assert(sizeof(((SharedMTData*)nullptr)->ev) % 16 == 0 && sizeof(((SharedMTData*)nullptr)->c3) % 16 == 0 && sizeof(((SharedMTData*)nullptr)->tb) % 16 == 0 && offsetof(SharedMTData, dyn) % 16 == 0, "16-byte alignment of the blocks the kernels read as b128");
 static_assert(offsetof(SharedMTData, hand.sh_keep) == offsetof(SharedMTData, dyn.Sh) && offsetof(SharedMTData, hand.Aw) == offsetof(SharedMTData, dyn.redI) &&
               sizeof(((SharedMTData*)nullptr)->hand) <= sizeof(((SharedMTData*)nullptr)->dyn), "the hand-over block keeps clear of the motion subspaces and fits the dynamics block");
 struct SharedMT : SharedMTData {
   static constexpr int R = (int)(sizeof(SharedMTData) % 256);
   static constexpr int PAD = R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R);      // the two env blocks of a wave on different banks (physics.hip Shared<NV>)
-  char bank_pad[PAD == 0 ? 8 : PAD];
+  char bank_pad[PAD == 0 ? 16 : PAD];        // (never 8: a block size that is no multiple of 16 bytes turns every ds_read_b128 of the odd blocks into ds_read2_b64 -- twice the LDS cycles, 20 % of the kernel)
 };
+static_assert(sizeof(SharedMT) % 16 == 0, "an env block is a whole number of 16-byte words: the blocks of one wave all keep the alignment ds_read_b128 needs");
+
+// K10 of the timestep: semi-implicit Euler from the solution `al` (no joint damping in this model: checked by the host side).  A function of its own since round 6: the one-wave
+// form calls it at the end of the timestep, the two-wave form's FIRST-half wave calls it for the timestep before, at the head of its next visit of the env (the solution waits in
+// s.aprev): 1.7 k cycles off the longer half.  Same expressions on the same values either way.
+__device__ __forceinline__ void integrate_mt(SharedMT& s, const earl_link_model24& m, const int sub, const bool isl, const int l, const double dt, const double al,
+                                             const double qd, const double ql_, const Q4 Qb) {
+  // ---------------------------------------------------------------- K10: semi-implicit Euler (no joint damping in this model: checked by the host side)
+  fence();
+  if (isl) {
+    // (explicit fused multiply-adds: left to fp contract(fast) the one-wave and the two-wave instantiations of this function chose differently here -- a position that
+    // differs in its last bit about once in 10^4 env steps was the only thing that told them apart: tools/mt_duo_bisect.py)
+    const double nv_ = fma(dt, al, qd);
+    s.qv[l] = nv_;
+    s.qp[l] = fma(dt, nv_, ql_);                        // (unused for the rotation dofs of the root body)
+  }
+  fence();
+  {
+    const int bd = m.ball_dof;
+    const V3 wbd{s.qv[bd], s.qv[bd + 1], s.qv[bd + 2]};
+    // The orientation update with every sum of products written as an EXPLICIT chain of fused multiply-adds (norm2, mul4 below): left to fp contract(fast), the one-wave
+    // and the two-wave instantiations of this function fused these sums differently, and the base quaternion's last bit -- about once in 10^4 env steps -- was all that told
+    // their results apart (tools/mt_duo_bisect.py: located phase by phase, then component by component).
+    auto norm2 = [](const Q4& q) { return fma(q.z, q.z, fma(q.y, q.y, fma(q.x, q.x, q.w * q.w))); };
+    auto mul4 = [](const Q4& a, const Q4& b) {
+      return Q4{fma(-a.z, b.z, fma(-a.y, b.y, fma(-a.x, b.x, a.w * b.w))), fma(-a.z, b.y, fma(a.y, b.z, fma(a.x, b.w, a.w * b.x))),
+                fma(a.z, b.x, fma(a.y, b.w, fma(-a.x, b.z, a.w * b.y))), fma(a.z, b.w, fma(-a.y, b.x, fma(a.x, b.y, a.w * b.z)))};
+    };
+    Q4 q0 = Qb;
+    const double n0 = rsq2(norm2(q0));
+    q0 = Q4{q0.w * n0, q0.x * n0, q0.y * n0, q0.z * n0};
+    const double w2 = fma(wbd.z, wbd.z, fma(wbd.y, wbd.y, wbd.x * wbd.x));
+    const double iw = w2 > 0 ? rsq2(w2 > 0 ? w2 : 1.0) : 0.0;
+    double sn, cs;
+    sincos_kc(0.5 * dt * (w2 * iw), sn, cs);
+    const Q4 q1 = mul4(q0, Q4{cs, sn * wbd.x * iw, sn * wbd.y * iw, sn * wbd.z * iw});
+    const double n1 = rsq2(norm2(q1));
+    if (sub == 0) { s.bq[0] = q1.w * n1; s.bq[1] = q1.x * n1; s.bq[2] = q1.y * n1; s.bq[3] = q1.z * n1; }
+    fence();
+  }
+}
 
 // One timestep of one env by its 32-lane group.  Lane roles: sub 0-5 = the root body's dofs, sub 8 + 4 k + j = hinge j of leg k (dof 6 + 4 k + j),
 // the other lanes idle (they shadow a hinge and store nothing).  INTEGRATE = false stops after qacc.
@@ -726,12 +768,14 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       for (int k = 0; k < 4; ++k) s.c3[sub].car[k] = car[k];
       s.c3[sub].cact = cact; s.c3[sub].cd1 = cd1; s.c3[sub].cd2 = cd2;
     }
-    return;
   }
   // which contact slots this lane's dof takes part in (bit c: it is the root's, or one of the two hinges of contact c's chain), which of the chain's two entries is
   // its own, whether it is the upper hinge: from the slots' chain records, ONCE per timestep (every pass read them again, a round trip before each contact's rows)
   unsigned int tbits = 0, sbits = 0, cbits = 0;
-  if (ncmax > 0) {
+  if constexpr (ROLE == 2) {
+    tbits = s.tb[l][0]; sbits = s.tb[l][1]; cbits = s.tb[l][2];
+  }
+  if (ROLE != 2 && ncmax > 0) {
     fence();
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
@@ -740,6 +784,10 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       sbits |= l == d2 ? (1u << c) : 0u;
       cbits |= l == d1 ? (1u << c) : 0u;
     }
+  }
+  if constexpr (ROLE == 1) {
+    if (isl) { s.tb[l][0] = tbits; s.tb[l][1] = sbits; s.tb[l][2] = cbits; }
+    return;
   }
   PSTAMP(6);
   PSTAMP(9);
@@ -986,42 +1034,11 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   }
 #endif
   PSTAMP(8);
+  if constexpr (ROLE == 2) return;                       // (the two-wave form integrates at the head of the first-half wave's next visit: integrate_mt from s.aprev)
   if constexpr (!INTEGRATE) {
     if (qacc_out && isl) qacc_out[l] = al;
   } else {
-    // ---------------------------------------------------------------- K10: semi-implicit Euler (no joint damping in this model: checked by the host side)
-    fence();
-    if (isl) {
-      // (explicit fused multiply-adds: left to fp contract(fast) the one-wave and the two-wave instantiations of this function chose differently here -- a position that
-      // differs in its last bit about once in 10^4 env steps was the only thing that told them apart: tools/mt_duo_bisect.py)
-      const double nv_ = fma(dt, al, qd);
-      s.qv[l] = nv_;
-      s.qp[l] = fma(dt, nv_, ql_);                        // (unused for the rotation dofs of the root body)
-    }
-    fence();
-    {
-      const int bd = m.ball_dof;
-      const V3 wbd{s.qv[bd], s.qv[bd + 1], s.qv[bd + 2]};
-      // The orientation update with every sum of products written as an EXPLICIT chain of fused multiply-adds (norm2, mul4 below): left to fp contract(fast), the one-wave
-      // and the two-wave instantiations of this function fused these sums differently, and the base quaternion's last bit -- about once in 10^4 env steps -- was all that told
-      // their results apart (tools/mt_duo_bisect.py: located phase by phase, then component by component).
-      auto norm2 = [](const Q4& q) { return fma(q.z, q.z, fma(q.y, q.y, fma(q.x, q.x, q.w * q.w))); };
-      auto mul4 = [](const Q4& a, const Q4& b) {
-        return Q4{fma(-a.z, b.z, fma(-a.y, b.y, fma(-a.x, b.x, a.w * b.w))), fma(-a.z, b.y, fma(a.y, b.z, fma(a.x, b.w, a.w * b.x))),
-                  fma(a.z, b.x, fma(a.y, b.w, fma(-a.x, b.z, a.w * b.y))), fma(a.z, b.w, fma(-a.y, b.x, fma(a.x, b.y, a.w * b.z)))};
-      };
-      Q4 q0 = Qb;
-      const double n0 = rsq2(norm2(q0));
-      q0 = Q4{q0.w * n0, q0.x * n0, q0.y * n0, q0.z * n0};
-      const double w2 = fma(wbd.z, wbd.z, fma(wbd.y, wbd.y, wbd.x * wbd.x));
-      const double iw = w2 > 0 ? rsq2(w2 > 0 ? w2 : 1.0) : 0.0;
-      double sn, cs;
-      sincos_kc(0.5 * dt * (w2 * iw), sn, cs);
-      const Q4 q1 = mul4(q0, Q4{cs, sn * wbd.x * iw, sn * wbd.y * iw, sn * wbd.z * iw});
-      const double n1 = rsq2(norm2(q1));
-      if (sub == 0) { s.bq[0] = q1.w * n1; s.bq[1] = q1.x * n1; s.bq[2] = q1.y * n1; s.bq[3] = q1.z * n1; }
-      fence();
-    }
+    integrate_mt(s, m, sub, isl, l, dt, al, qd, ql_, Qb);
 #ifdef EARL_MT_DEBUG
     if (isl) g_mt_dbg_x[3][((size_t)s.dbg_env * 8 + ((s.dbg_ts - 1) & 7)) * 32 + l] = s.qv[l];
 #endif

@@ -2066,9 +2066,9 @@ struct PArgs {
 template <int NV, int LPE, bool INTEGRATE>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB) void physics_kernel(const PArgs a) {
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ Shared<NV> sh[EPW * WPB];
+  __shared__ alignas(16) typename ModelOf<NV>::T m;
+  __shared__ alignas(16) BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
+  __shared__ alignas(16) Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
   stage_kb<NV>(bt, a.m, a.col);
   stage_model(m, a.m);

@@ -94,9 +94,9 @@ template <int DUO>
 __global__ __launch_bounds__(64 * Lim<23>::WPB) void kitchen_rollout_kernel(const KitchenRolloutArgs a) {
 #pragma clang fp contract(off)
   constexpr int NV = 23, LPE = 32, EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ Shared<NV> sh[EPW * WPB];
+  __shared__ alignas(16) typename ModelOf<NV>::T m;
+  __shared__ alignas(16) BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
+  __shared__ alignas(16) Shared<NV> sh[EPW * WPB];
   __shared__ earl_kitchen_params kp;
   stage_blocks(bt, a.col);
   stage_kb<NV>(bt, a.m, a.col);

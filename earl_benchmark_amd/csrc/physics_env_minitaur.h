@@ -40,10 +40,10 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
 #pragma clang fp contract(off)
   constexpr int NV = 22, LPE = 32, EPW = 64 / LPE, WPB = mt_wpb<ARROW>();
   using SH = std::conditional_t<ARROW, SharedMT, Shared<NV>>;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ SH sh[EPW * WPB];
-  __shared__ std::conditional_t<ARROW, PairTabMT, char> ptab;
+  __shared__ alignas(16) typename ModelOf<NV>::T m;
+  __shared__ alignas(16) BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
+  __shared__ alignas(16) SH sh[EPW * WPB];
+  __shared__ alignas(16) std::conditional_t<ARROW, PairTabMT, char> ptab;
   stage_blocks(bt, a.col);
   stage_kb<NV>(bt, a.m, a.col);
   if constexpr (ARROW) stage_pairs_mt(ptab, a.col);
@@ -255,8 +255,7 @@ __global__ __launch_bounds__(64 * mt_wpb<ARROW>(), ARROW ? EARL_MT_BLOCKS : 1) v
 // ------------------------------------------------------------------------------------------------ two waves per SIMD by ROLE (round 6)
 // The one-wave kernel above needs all 512 registers of a SIMD lane (256 + 256 accumulation registers used as spill space): one wave per SIMD, the vector ALU issuing in
 // half of its cycles.  Capped at 256 registers it spills 1.2 KB per lane and runs 1.7 x slower (profiles/r06_minitaur_two_waves_per_simd.txt).  What does fit 256 registers is
-// HALF a timestep: the dynamics half (frames, bounding and pair tests, mass matrix, bias forces, closure rows: substep_mt<.., 1>) and the solver half (contact rows, active-set
-// passes, integration: substep_mt<.., 2>) are each other's only long-lived register state.  So a workgroup is EIGHT waves, two per SIMD: waves 0 - 3 run first halves, waves
+// HALF a timestep: the dynamics half (frames, bounding and pair tests, mass matrix, bias forces, closure rows: substep_mt<.., 1>) and the solver half (active-set passes: substep_mt<.., 2>; the integration runs at the head of the first-half wave's next visit) are each other's only long-lived register state.  So a workgroup is EIGHT waves, two per SIMD: waves 0 - 3 run first halves, waves
 // 4 - 7 second halves, wave p and wave p + 4 work as a pair on TWO env pairs (four envs) alternately -- while A runs the first half of timestep k of env pair X, B runs the
 // second half of timestep k of env pair Y (whose first half A finished in the slot before); one barrier of the PAIR per slot (a flag each in LDS).  16 envs per CU: 4096 envs are ONE round of the
 // chip instead of two.  An env's per-step state (motor counters, command, goal, wrapper counters) lives in its LDS block (SharedMTData::ev) between the visits of wave A,
@@ -265,10 +264,10 @@ constexpr int MT_DUO_PAIRS = 4;
 __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(const MinitaurArgs a) {
 #pragma clang fp contract(off)
   constexpr int NV = 22, LPE = 32, EPW = 64 / LPE, NP = MT_DUO_PAIRS;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ SharedMT sh[NP * 2 * EPW];
-  __shared__ PairTabMT ptab;
+  __shared__ alignas(16) typename ModelOf<NV>::T m;
+  __shared__ alignas(16) BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
+  __shared__ alignas(16) SharedMT sh[NP * 2 * EPW];
+  __shared__ alignas(16) PairTabMT ptab;
   __shared__ int slots_done[NP][2];                     // per pair and role: slots finished (the pair's own barrier; see the slot loop)
   if (threadIdx.x < 2 * NP) (&slots_done[0][0])[threadIdx.x] = 0;
   stage_blocks(bt, a.col);
@@ -395,6 +394,13 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
       const int env_raw = env_of(q), env = env_raw < n ? env_raw : n - 1;       // idle groups shadow the last env and store nothing
       const bool live = env_raw < n;
       SharedMT& s = sh[(pair * 2 + q) * EPW + grp];
+      if (ts > 0) {                                     // K10 of this slot's timestep before: wave B left the solution in s.aprev (1.7 k cycles off the longer half)
+        const bool isroot = sub < 6, ishinge = sub >= 8 && sub < 24, isl = isroot || ishinge;
+        const int l = isroot ? sub : (ishinge ? sub - 2 : NV - 1);
+        const double al = s.aprev[l], qd = s.qv[l], ql = s.qp[l];
+        const Q4 Qb = ldq(s.bq);
+        integrate_mt(s, m, sub, isl, l, m.dt, al, qd, ql, Qb);
+      }
       if (k == 0) {
         if (t > 0) finish_step(s, env, live, t - 1);
         if (t < a.T) {                                  // ConvertFromLegModel of env step t's action -> this motor's command, kept for the step's timesteps

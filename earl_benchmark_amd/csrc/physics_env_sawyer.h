@@ -229,9 +229,9 @@ template <int NV, int LPE, bool SLICED = false>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_rollout_kernel(const SawyerArgs a) {
   static_assert(LPE >= 14, "the observation is written by 14 lanes");
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ Shared<NV> sh[EPW * WPB];
+  __shared__ alignas(16) typename ModelOf<NV>::T m;
+  __shared__ alignas(16) BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
+  __shared__ alignas(16) Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
   stage_kb<NV>(bt, a.m, a.col);
   stage_model(m, a.m);
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
 template <int NV, int LPE>
 __global__ __launch_bounds__(64 * Lim<NV>::WPB) void sawyer_reset_kernel(const SawyerArgs a) {
   constexpr int EPW = 64 / LPE, WPB = Lim<NV>::WPB;
-  __shared__ typename ModelOf<NV>::T m;
-  __shared__ BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
-  __shared__ Shared<NV> sh[EPW * WPB];
+  __shared__ alignas(16) typename ModelOf<NV>::T m;
+  __shared__ alignas(16) BlkTable<Lim<NV>::MB, Lim<NV>::KBT> bt;
+  __shared__ alignas(16) Shared<NV> sh[EPW * WPB];
   stage_blocks(bt, a.col);
   stage_kb<NV>(bt, a.m, a.col);
   stage_model(m, a.m);

@@ -195,8 +195,9 @@ struct Shared : SharedData<NV>, KitchenStore<NV, Lim<NV>::EXTRAS> {
   static constexpr int R = (int)((sizeof(SharedData<NV>) + KitchenStore<NV, Lim<NV>::EXTRAS>::SIZE) % 256);
   static constexpr int TARGET = NV <= 10 ? (EARL_STRIDE_MOD_10) : (NV <= 15 ? (EARL_STRIDE_MOD_15) : (EARL_STRIDE_MOD_23));   // block size mod 256 (-1: the rule above)
   static constexpr int PAD = TARGET >= 0 ? (TARGET - R + 256) % 256 : (R <= 64 ? 64 - R : (R <= 192 ? 192 - R : 320 - R));
-  char bank_pad[PAD == 0 ? 8 : PAD];
+  char bank_pad[PAD == 0 ? 16 : PAD];        // (never 8: see SharedMT)
 };
+static_assert(sizeof(Shared<10>) % 16 == 0 && sizeof(Shared<15>) % 16 == 0 && sizeof(Shared<22>) % 16 == 0 && sizeof(Shared<23>) % 16 == 0, "env blocks are whole numbers of 16-byte words");
 
 
 // block table of the collision model (bounding tests), staged once per workgroup
