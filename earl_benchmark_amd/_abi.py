@@ -226,6 +226,13 @@ def load_host():
   if _host is None:
     if not os.path.exists(HOST_LIB_PATH):
       raise EarlHipError(f'{HOST_LIB_PATH} not found: build it with `make -C earl_benchmark_amd/csrc libearl_host.so`')
+    try:                                                                       # the library is compiled with -mavx2 -mfma: on a CPU without them it would die with SIGILL
+      flags = next((ln for ln in open('/proc/cpuinfo') if ln.startswith('flags')), '')
+    except OSError:
+      flags = 'avx2 fma'                                                       # (no /proc: nothing to check against)
+    missing = [f for f in ('avx2', 'fma') if f not in flags.split()]
+    if missing:
+      raise EarlHipError(f'{HOST_LIB_PATH} needs a CPU with {" and ".join(missing)} (built with -mavx2 -mfma); this one has neither the HIP path (device="cpu" was asked for) nor those')
     _host = HostLib(C.CDLL(HOST_LIB_PATH))
   return _host
 

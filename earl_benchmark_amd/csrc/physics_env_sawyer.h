@@ -334,6 +334,9 @@ __global__ __launch_bounds__(64 * Lim<NV>::WPB, EARL_WAVES_PER_EU) void sawyer_r
     ++steps;
     RSTAMP(15);
     if (sub == 0 && live && a.out.done) a.out.done[row] = (cfg.horizon > 0 && steps >= cfg.horizon) ? 1 : 0;
+    // door with goal switching: slot 7 of EVERY row's info block is this kernel's to write -- 0, or 1 on a goal-switch row (below) -- so that earl_sawyer_door_info never reads
+    // a marker the caller left behind (the Python side used to zero the column with a launch of its own before every call)
+    if (NV < 15 && gcf > 0 && a.out.info && sub == 11 && live) a.out.info[row * EARL_SAWYER_INFO + 7] = 0.0;
     if (gcf > 0 && ++sgc >= gcf) {
       // LifelongWrapper.step (lifelong_wrapper.py:36-42): reset_goal() -> get_next_goal(), then the observation is re-read with the new
       // goal (same simulator state: only the goal block changes); the reward above used the old goal
@@ -498,7 +501,9 @@ __global__ void sawyer_door_info_kernel(const int n, const double* __restrict__ 
   const double* o = obs + (size_t)i * 14;
   double r, row[EARL_SAWYER_INFO]; bool ok;
   double* mine = info + (size_t)i * EARL_SAWYER_INFO;
-  const V3 target = mine[7] == 1.0 ? ld3(mine) : ld3(o + 11);      // a goal-switch row of a lifelong rollout: the target its reward used (the row's goal block holds the NEW goal)
+  // a goal-switch row of a lifelong rollout (cfg.goal_change_frequency > 0: only then has the rollout kernel written the marker, for every row): the target its reward used
+  // (the row's goal block holds the NEW goal).  Without goal switching the slot is output only.
+  const V3 target = (cfg.goal_change_frequency > 0 && mine[7] == 1.0) ? ld3(mine) : ld3(o + 11);
   door_reward(cfg, ld3(o), ld3(o + 4), target, r, ok, row);
   const bool rolled_back = status && status[i] != 0;
 #pragma unroll

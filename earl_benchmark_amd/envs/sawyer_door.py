@@ -213,8 +213,6 @@ class SawyerDoor:
                        success=_ptr(out.get('success')), status=_ptr(out.get('status')), info=_ptr(info) if (in_kernel or stash) else None)
     self._cfg.step_counter = self.total_step_count
     with torch.cuda.device(self.device):
-      if info is not None and not in_kernel:
-        info[..., 7] = 0.0                                 # (input column of earl_sawyer_door_info: no row marked)
       if self.sched is not None and T > 1 and self._uses_queue(T):
         self.sched.zero_()                                 # (the queue of the time-sliced schedule: zero on entry)
       _abi.check(self._lib.earl_sawyer_rollout(self.model.buf.data_ptr(), self.model.col_ptr, self.nv, self._cfg_ref, self._st_ref, actions.data_ptr(),

@@ -292,10 +292,11 @@ int earl_sawyer_door_reward(const earl_sawyer_cfg* cfg, int32_t n, const double*
                             earl_stream_t stream);
 /* the info dict of SawyerDoorV2.step (evaluate_state, earl_benchmark/envs/sawyer_door.py:127-139) for n observation rows [n, 14] -> info [n, EARL_SAWYER_INFO]
  * (slots EARL_INFO_*); every entry is a function of the observation and the reward type.  status (may be NULL): rows of rolled-back steps get zeros.
- * info[.][7] is also an INPUT: 1.0 marks a row whose slots 0-2 hold the target to evaluate against instead of the row's own goal block.  earl_sawyer_rollout
- * (nv = 10, lifelong goal switching on, out->info given) leaves exactly that on goal-switch rows -- the reward of such a row was computed with the goal
- * in force BEFORE the switch (wrappers/lifelong_wrapper.py:30-44: step(), i.e. evaluate_state, then reset_goal), while its observation already carries the new
- * goal --; the caller zeroes column 7 before the rollout.  Any other value: the row's own goal block.
+ * With cfg->goal_change_frequency > 0 -- and only then -- info[.][7] is also an INPUT: 1.0 marks a row whose slots 0-2 hold the target to evaluate against instead of
+ * the row's own goal block.  earl_sawyer_rollout (nv = 10, goal switching on, out->info given) writes that slot for EVERY row it emits: 1.0 and the old target on
+ * goal-switch rows -- the reward of such a row was computed with the goal in force BEFORE the switch (wrappers/lifelong_wrapper.py:30-44: step(), i.e.
+ * evaluate_state, then reset_goal), while its observation already carries the new goal --, 0.0 on all others; the caller prepares nothing.  Without goal switching
+ * the slot is output only (whatever the buffer held is ignored).
  * (The peg's dict needs simulator state -- the pegGrasp site, the pads: earl_sawyer_out.info of earl_sawyer_rollout carries it.) */
 int earl_sawyer_door_info(const earl_sawyer_cfg* cfg, int32_t n, const double* obs, const uint8_t* status, double* info, earl_stream_t stream);
 
