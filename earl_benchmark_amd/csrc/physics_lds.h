@@ -129,14 +129,23 @@ template <int NV> struct ConStore<NV, true> {
 // Per-env LDS block.  The three phase groups of the union are live at disjoint times.
 template <int NV>
 struct SharedData {
+#ifndef EARL_PAD_ROWS
+#define EARL_PAD_ROWS 0             // (experiment: rows of NV doubles padded to an even length for odd NV, so that every row starts on a 16-byte boundary)
+#endif
   static constexpr int MC = Lim<NV>::MC;
+  static constexpr int NVP = (EARL_PAD_ROWS && NV <= 16) ? ((NV + 1) & ~1) : NV;
   double qp[NV], qv[NV];
   double bq[4];                      // orientation of the free body (unit quaternion), identity if the model has none
   double Xq[NV][4], Xp[NV][3];       // world frame of every link (final buffer of the ancestor doubling)
-  SymLds<NV> M;                      // mass matrix
+#if EARL_PAD_ROWS
+#define EARL_A16 alignas(16)
+#else
+#define EARL_A16
+#endif
+  EARL_A16 SymLds<NV> M;             // mass matrix
   HwStore<NV, (Lim<NV>::EXTRAS || Lim<NV>::CONNECT)> hwst;
   ConStore<NV, Lim<NV>::CONNECT> xt;
-  union {
+  EARL_A16 union {
     struct { double Xq1[NV][4], Xp1[NV][3]; } k2;                    // second buffer of the doubling
     struct { double att[8][3]; } emit;                               // observation epilogue (after the last timestep of an env step)
     struct { double obs[46], noise[46], sites[8][3], targets[9]; } kit;   // kitchen env step inside the fused rollout (before / after the timesteps)
@@ -150,19 +159,19 @@ struct SharedData {
     } dyn;
     struct {
       double wD[6], war[6], dl[NV], rl[NV];
-      double CJ[MC][3][NV];            // contact Jacobians: normal, tangent 1, tangent 2
+      double CJ[MC][3][NVP];           // contact Jacobians: normal, tangent 1, tangent 2
       union {
         double ct[MC][8];              // contact records (C2 -> C3): dist, normal (3), point (3), (class, sphere link + 1, box link + 1) packed as class + 64 (ls + 1) + 4096 (lb + 1)
         double cw[MC][8];              // per-iteration weights of the active pyramid edges (K9)
       };
       union {
-        double J6[6][NV];              // weld Jacobian (K8 -> the equality part of K9; dead once every lane holds its Hessian column hw)
+        double J6[6][NVP];             // weld Jacobian (K8 -> the equality part of K9; dead once every lane holds its Hessian column hw)
         SymLds<NV> Hc;                 // Hessian of the iteration (written after that); the shared factorisation overwrites it with L
       };
-      double rc[NV];                   // its right-hand side; then the right-hand side of K10
+      EARL_A16 double rc[NV];          // its right-hand side; then the right-hand side of K10
     } con;
   };
-  double mocap[4];                   // mocap position of this env (input of the weld rows; in LDS rather than in six registers that live across the whole rollout)
+  EARL_A16 double mocap[4];          // mocap position of this env (input of the weld rows; in LDS rather than in six registers that live across the whole rollout)
   double aprev[(NV + 1) & ~1];       // solution of the previous timestep of this env step: warm start of the active-set iteration (last, even
                                      // length: the 16-byte alignment of the arrays above decides between ds_read_b128 and two b64)
 };
