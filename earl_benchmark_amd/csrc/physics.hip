@@ -2284,7 +2284,7 @@ int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, 
   if (int rc = check_cone(col, false, (hipStream_t)stream, "minitaur_rollout")) return rc;
   MinitaurArgs a{model24, col, *cfg, *st, *out, action, T, nullptr, nullptr, solo_mode(cfg->n)};
   // two waves per SIMD by role (minitaur_duo_kernel: 16 envs per workgroup of eight waves) for batches that fill the chip's wave slots in the packed form anyway
-  if (g_mt_stepper && a.solo == 0 && (g_mt_duo > 0 || (g_mt_duo < 0 && mt_use_duo(cfg->n)))) {
+  if (g_mt_stepper && a.solo == 0 && cfg->num_substeps > 0 && (g_mt_duo > 0 || (g_mt_duo < 0 && mt_use_duo(cfg->n)))) {      // (num_substeps = 0: nothing to split)
     minitaur_duo_kernel<<<(unsigned)((cfg->n + 16 * MT_DUO_PAIRS / 4 - 1) / (4 * MT_DUO_PAIRS)), 128 * MT_DUO_PAIRS, 0, (hipStream_t)stream>>>(a);
     return launched("minitaur_rollout (two waves per SIMD)");
   }
