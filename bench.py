@@ -644,10 +644,10 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
 
 
 # STATIC figures (not measured in this run): one MI355X, reset + one fused launch of a SHARD of the strong-scaling batches, relative to the full batch -- copied from
-# profiles/r06_kitchen_small_batch.txt (tools/kitchen_small_batch.py on an MI355X, round 6; kitchen at 256 envs: four waves per env; at 512: two; minitaur: the 4096-env
+# profiles/r06_shard_launches.txt (tools/kitchen_small_batch.py on an MI355X, round 6; kitchen at 256 envs: four waves per env; at 512: two; minitaur: the 4096-env
 # launch takes the two-waves-per-SIMD kernel, 139 ms, the shards the one-wave kernel, 80 - 87 ms).  What `world` GPUs
 # would deliver if every shard ran like this one (no collective on the data path; the job's one all-gather is 16 KB)
-SHARD_PROFILE = 'profiles/r06_kitchen_small_batch.txt'
+SHARD_PROFILE = 'profiles/r06_shard_launches.txt'
 MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.96, 4: 0.77, 8: 0.62}, 'minitaur': {1: 1.00, 2: 0.62, 4: 0.58, 8: 0.58}}
 
 
