@@ -132,7 +132,7 @@ struct SharedData {
 #ifndef EARL_PAD_ROWS
 #define EARL_PAD_ROWS 0             // (measurement switch, round 6: rows of NV doubles padded to an even length for the peg's odd NV and M / the phase union / rc / mocap aligned
                                     // to 16 bytes: ds_read_b128 221 -> 307, ds_read2_b64 199 -> 113, LDS 152 -> 158 kB, outputs identical -- and 42.4 -> 42.8 ms per launch: the peg is not bound by
-                                    // LDS-array cycles, unlike the minitaur; profiles/r06_peg_lds_alignment_experiment.txt)
+                                    // LDS-array cycles, unlike the minitaur; profiles/r06_stepper_build_experiments.txt)
 #endif
   static constexpr int MC = Lim<NV>::MC;
   static constexpr int NVP = (EARL_PAD_ROWS && NV <= 16) ? ((NV + 1) & ~1) : NV;
