@@ -741,7 +741,13 @@ def run_kitchen(a, torch, dist, world, rank, device, steps, warmup, n_global=204
   tpath = os.path.join(REPO, 'profiles', 'traffic.json')
   if os.path.exists(tpath) and (n_global, T, world) == (2048, 400, 1):
     prof = json.load(open(tpath)).get('kitchen', {})
-  roof = pipe_roofline(prof, 'kitchen_rollout_kernel', clk.elapsed_ms() / steps)
+  # algorithmic HBM bytes per env step: action 9 x 4 in; observation 46 x 8 + reward 8 + done 1 + success 1 + status 1 out; the last-stable state row (qpos, qvel: 2 x 23 x 8)
+  # written after every env step.  Not what bounds the kernel (a few GB/s): reported because BASELINE.json asks for the achieved HBM fraction of every workload.
+  kb = 36 + 46 * 8 + 8 + 3 + 2 * 23 * 8
+  kms = clk.elapsed_ms() / steps
+  khbm = {'achieved_GBs': n * T * kb / (kms * 1e-3) / 1e9, 'frac_of_8TBs': n * T * kb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'bytes_per_env_step': kb,
+          'algorithmic_bytes_per_launch': n * T * kb, 'traffic': prof.get('hbm_bytes_per_launch'), 'traffic_source': (prof.get('source', '') + ' (static)') if prof.get('hbm_bytes_per_launch') else None}
+  roof = pipe_roofline(prof, 'kitchen_rollout_kernel', kms, hbm=khbm)
   return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
           'valu_frac': roof['frac'], 'roofline': roof,
           'timesteps_per_s': steps * n_global * T * 40 / dt, 'gpu_ms_per_env_step': clk.elapsed_ms() / (steps * T), 'scaling': 'strong',
@@ -845,7 +851,13 @@ def run_minitaur(a, torch, dist, world, rank, device, steps, warmup, n_global=40
   tpath = os.path.join(REPO, 'profiles', 'traffic.json')
   if os.path.exists(tpath) and (n_global, T, world) == (4096, 1000, 1):
     prof = json.load(open(tpath)).get('minitaur', {})
-  roof = pipe_roofline(prof, 'minitaur_duo_kernel (two waves per SIMD)' if (n >= 2049 and world == 1 and prof.get('waves_per_simd') == 2) else 'minitaur_kernel', clk.elapsed_ms() / steps)
+  # algorithmic HBM bytes per env step: action 8 x 4 in; observation 32 x 8 + reward 8 + done 1 + success 1 + status 1 out; the state row (qpos 23 + qvel 22 doubles) and the
+  # motors' row (8 x (8 + 4 + 1)) written after every env step
+  mb = 32 + 32 * 8 + 8 + 3 + (23 + 22) * 8 + 8 * 13
+  mms = clk.elapsed_ms() / steps
+  mhbm = {'achieved_GBs': n * T * mb / (mms * 1e-3) / 1e9, 'frac_of_8TBs': n * T * mb / (mms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'bytes_per_env_step': mb,
+          'algorithmic_bytes_per_launch': n * T * mb, 'traffic': prof.get('hbm_bytes_per_launch'), 'traffic_source': (prof.get('source', '') + ' (static)') if prof.get('hbm_bytes_per_launch') else None}
+  roof = pipe_roofline(prof, 'minitaur_duo_kernel (two waves per SIMD)' if (n >= 2049 and world == 1 and prof.get('waves_per_simd') == 2) else 'minitaur_kernel', mms, hbm=mhbm)
   return {'value': steps * n_global * T / dt, 'unit': 'env-steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': dt / steps * 1e3,
           'valu_frac': roof['frac'], 'roofline': roof, 'timesteps_per_s': steps * n_global * T * 5 / dt, 'scaling': 'strong', 'diverged_env_steps': fails,
           'config': {'workload': f'minitaur dense reward, {n_global} envs range-sharded over {world} MI355X ({n} per GPU), reset + one fused launch of {T} env steps of 5 '
@@ -923,6 +935,8 @@ def compact_line(res):
   keep_r = ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_min', 'frac_max', 'traffic', 'kernel', 'kernel_ms_median', 'kernel_ms_mean', 'strict_frac', 'strict_value',
             'bytes_per_env_step', 'algorithmic_bytes_per_launch', 'windows', 'waves_per_simd', 'lane_occupancy', 'valu_x_lane_occupancy')
   roof = {k: r[k] for k in keep_r if k in r}
+  if isinstance(r.get('hbm'), dict):                        # the stepper lines: the VALU roofline is the bound; the HBM side rides along (BASELINE.json asks for it)
+    roof['hbm'] = {k: r['hbm'].get(k) for k in ('achieved_GBs', 'frac_of_8TBs', 'bytes_per_env_step', 'traffic')}
   if isinstance(roof.get('unit'), str):
     roof['unit'] = roof['unit'][:80]
   cmpf = r.get('compare_with_profile')

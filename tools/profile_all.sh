@@ -35,9 +35,9 @@ for W in $WORKLOADS; do
     sawyer_door|sawyer_peg)
       PASSES="$SQ1"$'\n'"$SQ2"$'\n'"$SQ3"$'\n'"$SQ4"$'\nFETCH_SIZE\nWRITE_SIZE' prof $W --workload $W --steps 3 --warmup 1 --no-cpu ;;
     kitchen)
-      PASSES="$SQ1"$'\n'"$SQ2"$'\n'"$SQ3" prof kitchen --workload kitchen --steps 1 --warmup 1 --no-cpu --no-step-api ;;
+      PASSES="$SQ1"$'\n'"$SQ2"$'\n'"$SQ3"$'\nFETCH_SIZE\nWRITE_SIZE' prof kitchen --workload kitchen --steps 1 --warmup 1 --no-cpu --no-step-api ;;
     minitaur)
-      PASSES="$SQ1"$'\n'"$SQ2"$'\n'"$SQ3" prof minitaur --workload minitaur --steps 1 --warmup 1 --no-cpu ;;
+      PASSES="$SQ1"$'\n'"$SQ2"$'\n'"$SQ3"$'\nFETCH_SIZE\nWRITE_SIZE' prof minitaur --workload minitaur --steps 1 --warmup 1 --no-cpu ;;
   esac
 done
 # keep what travels back small: the per-dispatch traces are not needed, the stats and counter CSVs are
