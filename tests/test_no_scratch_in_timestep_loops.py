@@ -1,5 +1,5 @@
 """"no scratch inside any timestep loop".  tools/scratch_in_loops.py compiles the stepper units to gfx950 assembly (device only, no GPU needed) and counts the
-scratch_load / scratch_store instructions of every rollout kernel inside its timestep loop; this test pins the count at zero and the committed report to what the tool prints."""
+scratch_load / scratch_store instructions of every rollout kernel inside its timestep loop; this test pins the count at zero (the one-wave kernels) or bounds it (the minitaur's two-wave kernel)."""
 import os
 import shutil
 import subprocess
@@ -19,6 +19,12 @@ def test_timestep_loops_hold_no_scratch_instruction():
   names = ' '.join(lines)
   for k in ('sawyer_rollout_kernel<10, 16, false>', 'sawyer_rollout_kernel<15, 16, true>', 'kitchen_rollout_kernel', 'minitaur_kernel<false, true>'):
     assert k in names, k
+  duo = [ln for ln in lines if 'minitaur_duo_kernel' in ln]
+  assert len(duo) == 1 and 'slot loop' in duo[0]                        # the two-waves-per-SIMD kernel (round 6): at the 256-register cap its dynamics half keeps a few spills -- bounded here,
+  import re                                                             # stated in DESIGN.md 4.5 (their write-through is the launch's extra HBM traffic)
+  m = re.search(r': (\d+) loads, (\d+) stores$', duo[0].rstrip())
+  assert m and int(m.group(1)) <= 64 and int(m.group(2)) <= 8, duo[0]
+  lines = [ln for ln in lines if 'minitaur_duo_kernel' not in ln]
   for ln in lines:
     if 'timestep loop' in ln:
       assert ln.rstrip().endswith(': 0'), ln                             # scratch instructions inside the timestep loop
