@@ -283,11 +283,11 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
   // halves of the timestep and were spilled around them)
   const int NS = cfg.num_substeps, TT = a.T * NS;       // timesteps per env of this launch
   const int gcf = a.st.steps_since_goal_change ? cfg.goal_change_frequency : 0;
-  auto env_of = [&](const int q) { return (int)((blockIdx.x * NP + pair) * 2 + q) * EPW + grp; };
+  auto env_of = [&](const int q, const int grp_) { return (int)((blockIdx.x * NP + pair) * 2 + q) * EPW + grp_; };
   // ---- both slots of this pair: state rows -> LDS (wave A; wave B waits at the first barrier)
   if (!role_b) {
     for (int q = 0; q < 2; ++q) {
-      const int env_raw = env_of(q), env = env_raw < n ? env_raw : n - 1;
+      const int env_raw = env_of(q, grp), env = env_raw < n ? env_raw : n - 1;
       SharedMT& s = sh[(pair * 2 + q) * EPW + grp];
       const double* mp = a.st.motor_param + (size_t)env * 6;
       load_state<NV>(s, m, a.st.qpos + (size_t)env * m.nq, a.st.qvel + (size_t)env * NV, sub);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
     fence();
   }
   // (wave A) what stands between the last timestep of env step t and the first of env step t + 1 of slot q: the tail of minitaur_kernel's step loop
-  auto finish_step = [&](SharedMT& s, const int env, const bool live, const int t) {
+  auto finish_step = [&](SharedMT& s, const int env, const bool live, const int t, const int sub, const int grp) {      // (sub, grp: the caller's laundered lane indices, see the slot loop)
     const size_t row = (size_t)t * n + env;
     const bool bad_lane = (sub < NV && !(fabs(s.qp[sub]) < EARL_BAD_VALUE && fabs(s.qv[sub]) < EARL_BAD_VALUE)) || (sub < 4 && !(fabs(s.bq[sub]) < EARL_BAD_VALUE));
     const bool failed = group_any<LPE>(bad_lane, grp);
@@ -390,8 +390,14 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
     const unsigned long long slot_t0 = __builtin_readcyclecounter();
 #endif
     if (!role_b) {
+      // (the lane's indices pass through an empty asm once per slot: everything derived from them in the code around the timesteps -- rows of the kernel's tables, addresses of
+      // the env's rows in HBM -- is then worked out where it is used instead of being hoisted out of the slot loop, held across both halves of the timestep, spilled, and reloaded
+      // from scratch memory with a wait each: 33 reloads per slot)
+      int lane_ = lane;
+      asm volatile("" : "+v"(lane_));
+      const int sub = lane_ % LPE, grp = lane_ / LPE;
       const int q = j & 1, ts = j >> 1, t = ts / NS, k = ts - t * NS;
-      const int env_raw = env_of(q), env = env_raw < n ? env_raw : n - 1;       // idle groups shadow the last env and store nothing
+      const int env_raw = env_of(q, grp), env = env_raw < n ? env_raw : n - 1;  // idle groups shadow the last env and store nothing
       const bool live = env_raw < n;
       SharedMT& s = sh[(pair * 2 + q) * EPW + grp];
       if (ts > 0) {                                     // K10 of this slot's timestep before: wave B left the solution in s.aprev (1.7 k cycles off the longer half)
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
         integrate_mt(s, m, sub, isl, l, m.dt, al, qd, ql, Qb);
       }
       if (k == 0) {
-        if (t > 0) finish_step(s, env, live, t - 1);
+        if (t > 0) finish_step(s, env, live, t - 1, sub, grp);
         if (t < a.T) {                                  // ConvertFromLegModel of env step t's action -> this motor's command, kept for the step's timesteps
           const size_t row = (size_t)t * n + env;
           double a64[8];
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
   }
   if (!role_b) {
     for (int q = 0; q < 2; ++q) {
-      const int env_raw = env_of(q), env = env_raw < n ? env_raw : n - 1;
+      const int env_raw = env_of(q, grp), env = env_raw < n ? env_raw : n - 1;
       SharedMT& s = sh[(pair * 2 + q) * EPW + grp];
       if (env_raw < n) {
         if (sub == 0) {
