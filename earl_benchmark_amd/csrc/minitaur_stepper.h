@@ -129,7 +129,7 @@ struct SharedMTData {
                                                                                                            // without it 220 of the kernel's 255 ds_read_b128 became ds_read2_b64, twice the LDS cycles: 178 -> 212 ms per bench launch)
   // ... and what the contact rows (C3, wave A's half) leave in the contact's LANE for the passes (wave B's half): weight, friction, the four edges' reference accelerations,
   // the warm-started active edges, the chain's hinges
-  struct { double cD, cmu, car[4]; unsigned int cact; int cd1, cd2, pad_; } c3[MC];
+  struct { double cD, cmu, car[4]; unsigned int cact; int cd1, cd2, pid; } c3[MC];
   unsigned int tb[NV][4];             // ... and per dof: which contact slots it takes part in (tbits, sbits, cbits of K9), worked out once per timestep by the first half
 #ifdef EARL_MT_DEBUG
   int dbg_env, dbg_ts, dbg_pad[2];   // (tools/mt_duo_bisect.py, debug builds only: which env this block holds, timesteps since the launch began)
@@ -542,7 +542,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
         const V3 p = add(add(pb, mulv(Rbx, q)), scl(n, 0.5 * dist));
         double* o = s.ct[slot];
         o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
-        o[7] = (double)(cls + 64 * (lk + 1));
+        o[7] = (double)(cls + 64 * (lk + 1) + 4096 * pi);      // (+ the collision pair: what C3 recognises a slot's contact of the previous timestep by)
       }
       const int took = __popc(ga);
       nct = nct + took < maxcon ? nct + took : maxcon;
@@ -644,6 +644,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   double cD = 0, cmu = 0, car[4] = {0, 0, 0, 0};
   unsigned int cact = 0;
   int cd1 = -1, cd2 = -1;                               // lane c: the hinges of its contact's chain
+  int cpid = -1;                                        // ... and its collision pair (-1: the slot is empty)
   if constexpr (ROLE == 2) {
     const int c = sub < MC ? sub : MC - 1;
     cD = s.c3[c].cD; cmu = s.c3[c].cmu;
@@ -654,17 +655,22 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
   if (ROLE != 2 && ncmax > 0) {
     const int c = sub < MC ? sub : MC - 1;
     const bool cv = sub < nct;
+    // the slot's record of the timestep before (its pair, the edge set its passes ENDED with): s.c3 keeps them between the timesteps of an env step
+    unsigned int pact = s.c3[c].cact;
+    int ppid = s.c3[c].pid;
     double rec[8];                                        // (a lane reads its own record only, and later writes its own edge weights over it: no exchange.  Slots
 #pragma unroll                                            // beyond the env's count hold whatever LDS held: taken as zeros -- tests/test_lds_hygiene_gpu.py)
     for (int k = 0; k < 8; ++k) rec[k] = s.ct[c][k];
     // (loads in three batches, by what their addresses depend on -- the record; the chain's parent and the class's tables; the chain's motion subspaces and velocities --
     // each batch one LDS round trip: physics_math.h pin_batch.  Selected per load, they were eleven round trips one after the other)
     pin_batch(rec);
+    asm volatile("" : "+v"(pact), "+v"(ppid));
 #pragma unroll
     for (int k = 0; k < 8; ++k) rec[k] = cv ? rec[k] : 0.0;
     const V3 n = selv(cv, V3{rec[1], rec[2], rec[3]}, V3{0, 0, 1}), p = selv(cv, V3{rec[4], rec[5], rec[6]}, V3{0, 0, 0});
     const int pk = cv ? (int)rec[7] : 0;
     const int cls = pk & 63, ls = ((pk >> 6) & 63) - 1;
+    cpid = cv ? (pk >> 12) : -1;
     const double ax_ = fabs(n.x), ay_ = fabs(n.y), az_ = fabs(n.z);
     const int ia = (ax_ <= ay_ && ax_ <= az_) ? 0 : (ay_ <= az_ ? 1 : 2);
     const V3 e{ia == 0 ? 1.0 : 0.0, ia == 1 ? 1.0 : 0.0, ia == 2 ? 1.0 : 0.0};
@@ -748,7 +754,14 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     wbits |= (fma(-cmu, jp[1], jp[0]) - car[1] < 0) ? 2u : 0u;
     wbits |= (fma(cmu, jp[2], jp[0]) - car[2] < 0) ? 4u : 0u;
     wbits |= (fma(-cmu, jp[2], jp[0]) - car[3] < 0) ? 8u : 0u;
+    // Start of the active-set passes: the first timestep of an env step from "every edge active"; later ones from the set this slot's passes ended with at the timestep before if
+    // the slot holds the same collision pair again, else from the set the previous solution predicts for the new rows.  (The fixed point does not depend on the start; the
+    // number of passes does: 2.05 -> 1.66 per timestep on random actions with the carried sets -- oracle/physics_oracle.c StepOut.pact.)
+#ifndef EARL_MT_NO_CARRY                                  // (measurement switch: the start rule of rounds 2 - 5, for same-build comparisons -- tools/bench_mt_variant.py)
+    cact = cv ? (warm ? ((ppid == cpid) ? pact : wbits) : 0xFu) : 0u;
+#else
     cact = cv ? (warm ? wbits : 0xFu) : 0u;
+#endif
   }
 #ifdef EARL_MT_DEBUG
   if constexpr (ROLE != 2) {
@@ -766,7 +779,7 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
       s.c3[sub].cD = cD; s.c3[sub].cmu = cmu;
 #pragma unroll
       for (int k = 0; k < 4; ++k) s.c3[sub].car[k] = car[k];
-      s.c3[sub].cact = cact; s.c3[sub].cd1 = cd1; s.c3[sub].cd2 = cd2;
+      s.c3[sub].cact = cact; s.c3[sub].cd1 = cd1; s.c3[sub].cd2 = cd2; s.c3[sub].pid = cpid;
     }
   }
   // which contact slots this lane's dof takes part in (bit c: it is the root's, or one of the two hinges of contact c's chain), which of the chain's two entries is
@@ -1033,6 +1046,12 @@ __device__ __forceinline__ void substep_mt(SharedMT& s, const earl_link_model24&
     fence();
   }
 #endif
+  // what the next timestep's C3 starts from (above): the slot's final edge set, and -- in the one-wave form, which hands nothing over through s.c3 -- its pair
+  if constexpr (ROLE == 2) {
+    if (ncmax > 0 && sub < MC) s.c3[sub].cact = cact;
+  } else {
+    if (sub < MC) { s.c3[sub].cact = cact; s.c3[sub].pid = cpid; }
+  }
   PSTAMP(8);
   if constexpr (ROLE == 2) return;                       // (the two-wave form integrates at the head of the first-half wave's next visit: integrate_mt from s.aprev)
   if constexpr (!INTEGRATE) {

@@ -118,6 +118,9 @@ typedef struct {
   double efc[6 + 2 * NVMAX];
   int ncon;
   int warm;                               /* qacc holds the previous timestep's solution of the SAME call (env step): the active-set iteration starts from it */
+  /* minitaur (round 6): the edge sets the previous timestep of the same env step ENDED with, per contact slot, and the collision pair each slot held.  A slot that holds the
+   * same pair again starts from that set instead of the one a_prev predicts (csrc/minitaur_stepper.h C3): 2.05 -> 1.66 passes per timestep on random actions, same fixed point */
+  int carry, pncon, ppair[EARL_MAXCON], pact[EARL_MAXCON][4];
 } StepOut;
 
 /* Warm start of the active-set iteration (the rule the kernels implement): the first timestep of a call / of an env step starts from "every
@@ -127,6 +130,9 @@ typedef struct {
 static int g_warm_start = 1;
 int oracle_set_warm_start(int w) { const int prev = g_warm_start; g_warm_start = w; return prev; }
 /* experiment switch (tools/minitaur_passes.py): 1 = the minitaur rollout keeps the warm start ACROSS env steps of one call (the product rule is: every env step starts cold) */
+/* test switch (tests/test_minitaur.py): 0 = the minitaur's contact slots never start from the set their passes ended with at the timestep before (the start rule of rounds 2 - 5) */
+static int g_carry_sets = 1;
+int oracle_set_carry_sets(int w) { const int prev = g_carry_sets; g_carry_sets = w; return prev; }
 static int g_warm_across_steps = 0;
 int oracle_set_warm_across_steps(int w) { const int prev = g_warm_across_steps; g_warm_across_steps = w; return prev; }
 static long long g_newton_stats[5];       /* timesteps, Newton iterations, timesteps with contacts, iterations in those, timesteps that used all 8 iterations without reaching a fixed point */
@@ -397,6 +403,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
   }
   /* constraint rows */
   double J[NROWMAX][NVMAX], aref[NROWMAX], D[NROWMAX];
+  int cpair[EARL_MAXCON];                          /* collision pair of contact slot c */
   int iseq[NROWMAX], rowid[NROWMAX], nr = 0;       /* rowid: position in the efc output (weld 0..5, limits 6 + 2 j + side), -1 otherwise */
   memset(J, 0, sizeof(J));
   if (m->weld_att >= 0) {                            /* (the minitaur model has no mocap weld) */
@@ -639,6 +646,7 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
           iseq[nr] = 0; rowid[nr] = -1;
           ++nr;
         }
+        cpair[ncon] = pi;
         ++ncon; ++btaken;
       }
     }
@@ -674,6 +682,11 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
       zone[c] = CONE_ZONE(q[0], CONE_RHO(q, cdim[c]), cone_mu[c]);
     }
   }
+  const int carry = g_carry_sets && o->carry && col && col->cone != 1, ncs = carry ? o->ncon : 0, cbase = nr_contacts0;      /* (pyramid contacts: four rows each, slot c at cbase + 4 c) */
+  if (carry && g_warm_start && o->warm)
+    for (int c = 0; c < ncs && c < o->pncon; ++c)
+      if (o->ppair[c] == cpair[c])
+        for (int e = 0; e < 4; ++e) act[cbase + 4 * c + e] = o->pact[c][e];
   int iters = 0, converged = 0;
   for (int it = 0; it < 8; ++it) {
     ++iters;
@@ -773,6 +786,10 @@ static void substep(const LM* m, const earl_collision_model* col, double* qp, do
 #pragma omp atomic
     g_newton_stats[3] += hasc ? iters : 0;
   }
+  if (carry) {
+    o->pncon = ncs;
+    for (int c = 0; c < ncs; ++c) { o->ppair[c] = cpair[c]; for (int e = 0; e < 4; ++e) o->pact[c][e] = act[cbase + 4 * c + e]; }
+  }
   o->warm = integrate ? 1 : 0;
   for (int i = 0; i < nv; ++i) o->qacc[i] = a[i];
   memset(o->efc, 0, sizeof(o->efc));
@@ -831,7 +848,7 @@ static int physics24(const LM* m, const earl_collision_model* col, int32_t n, in
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < n; ++e) {
     StepOut o;
-    o.warm = 0;
+    o.warm = 0; o.carry = 0;
     const V3 mpos = ld3(mocap_pos + 3 * (size_t)e);
     const Q4 mq = g_raw_mocap_quat ? ldq(mocap_quat + 4 * (size_t)e) : qnormalize(ldq(mocap_quat + 4 * (size_t)e));
     for (int ts = 0; ts < (integrate ? nsub : 1); ++ts)
@@ -882,6 +899,7 @@ int oracle_sawyer_rollout(const earl_link_model* m16, const earl_collision_model
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < n; ++e) {
     StepOut o;
+    o.carry = 0;
     double* qp = st->qpos + (size_t)e * m->nq;
     double* qv = st->qvel + (size_t)e * nv;
     double* mp = st->mocap_pos + (size_t)e * 3;
@@ -1053,7 +1071,7 @@ int oracle_minitaur_reset(const earl_link_model24* m0, const earl_collision_mode
     MtMotors mt = {mp[0], mp[1], st->observed_torque + (size_t)e * 8, st->overheat + (size_t)e * 8, st->motor_enabled + (size_t)e * 8};
     for (int i = 0; i < 8; ++i) { mt.observed[i] = 0; mt.overheat[i] = 0; mt.enabled[i] = 1; }
     StepOut o;
-    o.warm = 0;
+    o.warm = 0; o.carry = 1; o.pncon = 0;
     double cmd[8], qfrc[NVMAX];
     for (int i = 0; i < 8; ++i) cmd[i] = 3.141592653589793 / 2;
     const Q4 mq = {1, 0, 0, 0};
@@ -1078,6 +1096,7 @@ int oracle_minitaur_rollout(const earl_link_model24* m0, const earl_collision_mo
 #pragma omp parallel for schedule(static)
   for (int e = 0; e < n; ++e) {
     StepOut o;
+    o.carry = 1; o.pncon = 0;
     double* qp = st->qpos + (size_t)e * m0->nq;
     double* qv = st->qvel + (size_t)e * nv;
     double* goal = st->goal + (size_t)e * 2;
