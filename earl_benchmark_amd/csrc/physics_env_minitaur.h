@@ -385,6 +385,10 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
     fence();
   };
   // Slot j: wave A works on (slot q = j & 1, timestep j >> 1), wave B on the slot-timestep A finished in slot j - 1.  One barrier per slot.
+#ifdef EARL_PHYS_PROF
+  const unsigned long long duo_t0 = __builtin_readcyclecounter();
+  unsigned long long duo_wait = 0;
+#endif
   for (int j = 0; j <= 2 * TT + 1; ++j) {
 #ifdef EARL_PHYS_PROF
     const unsigned long long slot_t0 = __builtin_readcyclecounter();
@@ -466,8 +470,15 @@ __global__ __launch_bounds__(128 * MT_DUO_PAIRS, 1) void minitaur_duo_kernel(con
     }
 #ifdef EARL_PHYS_PROF
     PCOUNT(26, slot_t1 - slot_t0); PCOUNT(27, __builtin_readcyclecounter() - slot_t1); PCOUNT(28, 1);      // this wave's work and wait per slot
+    duo_wait += __builtin_readcyclecounter() - slot_t1;
 #endif
   }
+#ifdef EARL_PHYS_PROF
+  if (lane == 0 && blockIdx.x * 2 * NP + wave < 2048) {      // every wave's duration and the part of it spent at the pair's barrier (load balance: tools/prof_minitaur.py)
+    g_wave_cycles[blockIdx.x * 2 * NP + wave] = __builtin_readcyclecounter() - duo_t0;
+    g_wave_cycles[2048 + blockIdx.x * 2 * NP + wave] = duo_wait;
+  }
+#endif
   if (!role_b) {
     for (int q = 0; q < 2; ++q) {
       const int env_raw = env_of(q, grp), env = env_raw < n ? env_raw : n - 1;

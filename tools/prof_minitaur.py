@@ -49,6 +49,16 @@ import numpy as np
 wc = (C.c_ulonglong * 4096)()
 lib.earl_debug_read_wave_cycles_mt(wc)
 w = np.array(wc[:min(4096, (n + 1) // 2)], dtype=np.float64) / (T * 5)
+if os.environ.get('PROF_DUO'):
+  nw = min(2048, (n + 15) // 16 * 8)
+  tot, wait = np.array(wc[:nw], dtype=np.float64).reshape(-1, 2, 4) / (T * 5 * 2), np.array(wc[2048:2048 + nw], dtype=np.float64).reshape(-1, 2, 4) / (T * 5 * 2)     # [workgroup, role, pair]; per slot
+  work = tot - wait
+  pct = lambda x: f'min {x.min():.0f}  p10 {np.percentile(x, 10):.0f}  median {np.median(x):.0f}  mean {x.mean():.0f}  p90 {np.percentile(x, 90):.0f}  p99 {np.percentile(x, 99):.0f}  max {x.max():.0f}'
+  print('  two-wave kernel, cycles per slot over all wave pairs: duration ' + pct(tot[:, 0]))
+  print('    first-half waves, own work ' + pct(work[:, 0]) + '\n    second-half waves, own work ' + pct(work[:, 1]))
+  k = int(tot[:, 0].reshape(-1).argmax())
+  print(f'    slowest pair: workgroup {k // 4} pair {k % 4} (PROF_BLOCK={k // 4} PROF_THREAD={(k % 4) * 64} / {256 + (k % 4) * 64}): first half {work[k // 4, 0, k % 4]:.0f}, second half {work[k // 4, 1, k % 4]:.0f}')
+  w = tot[:, 0].reshape(-1) * 2
 print(f'  wave durations, cycles per timestep: min {w.min():.0f}  p10 {np.percentile(w, 10):.0f}  median {np.median(w):.0f}  mean {w.mean():.0f}  p90 {np.percentile(w, 90):.0f}  p99 {np.percentile(w, 99):.0f}  max {w.max():.0f}')
 ts = max(1, out[20])
 print(f'minitaur N={n} T={T}: launch {ms:.1f} ms = {n * T / ms / 1e3:.2f} M env-steps/s; wave 0: {out[20]} timesteps, with contacts {out[23] / ts:.3f} '
