@@ -427,7 +427,8 @@ typedef struct earl_minitaur_out {
   uint8_t* status;                 /* [T, n] may be NULL: EARL_STEP_DIVERGED as in earl_sawyer_out (state rolled back, last stable observation, reward 0) */
 } earl_minitaur_out;
 /* T env steps of every env in ONE launch; action float32 [T, n, 8] in [-1, 1] (the reference raises ValueError beyond +-1.01: the Python front end
- * checks; the kernel clips to +-1.01). */
+ * checks; the kernel clips to +-1.01).  Solver start: as earl_physics_step states it, every env step starting cold; within an env step a contact slot that holds the
+ * same collision pair as at the timestep before starts from the edge set its passes ENDED with (same fixed point, fewer passes: 2.05 -> 1.66 per timestep on random actions). */
 int earl_minitaur_rollout(const void* model24, const earl_collision_model* col, const earl_minitaur_cfg* cfg, const earl_minitaur_state* st,
                           const float* action, int32_t T, const earl_minitaur_out* out, earl_stream_t stream);
 /* reset the envs with mask[i] != 0 (NULL = all); obs [n, 32] (may be NULL) is written for the reset envs only */
