@@ -2449,6 +2449,10 @@ int earl_sawyer_rollout_door_w8(const earl_link_model* model, const earl_collisi
   return launched("sawyer_rollout (door, 8 waves per CU)");
 }
 #ifdef EARL_PHYS_PROF
+int earl_debug_set_prof_wave_w8(int block, int thread) {     // this unit's copy of earl_debug_set_prof_wave (eight-wave workgroups: thread = 64 x the wave)
+  const int v[2] = {block, thread};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_sel), v, sizeof(v)) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
+}
 int earl_debug_read_wave_cycles_w8(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_cycles), sizeof(unsigned long long) * 4096) == hipSuccess ? EARL_OK : EARL_ERR_LAUNCH;
 }

@@ -34,6 +34,8 @@ def rollout_counters(n, T, sel=None):
   lib = _abi.load()
   if w8:
     lib.earl_debug_set_door_variant(2)
+    if sel is not None:
+      lib.earl_debug_set_prof_wave_w8(C.c_int(sel // 8), C.c_int((sel % 8) * 64))      # (eight-wave workgroups)
   elif sel is not None:
     lib.earl_debug_set_prof_wave(sel // 4, (sel % 4) * 64)       # (four-wave workgroups: the peg build; the door's single-wave build has one wave per workgroup)
   read = getattr(lib, reader)
@@ -80,7 +82,7 @@ def main():
   if '--rollout' in sys.argv:
     n, T = 8192 if ('--w8' in sys.argv or '--full' in sys.argv) else 1024, 200 if '--peg' in sys.argv else 300
     slow = rollout_counters(n, T)
-    if '--slowest' in sys.argv and '--peg' in sys.argv:     # the same launch again, clocking the wave that took longest
+    if '--slowest' in sys.argv and ('--peg' in sys.argv or '--w8' in sys.argv):     # the same launch again, clocking the wave that took longest
       print(f'--- slowest wave: #{slow}')
       rollout_counters(n, T, sel=slow)
     return
