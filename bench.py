@@ -648,7 +648,7 @@ def kitchen_cpu_baseline(seconds, n=2048, reps=2):
 # launch takes the two-waves-per-SIMD kernel, 139 ms, the shards the one-wave kernel, 80 - 87 ms).  What `world` GPUs
 # would deliver if every shard ran like this one (no collective on the data path; the job's one all-gather is 16 KB)
 SHARD_PROFILE = 'profiles/r06_shard_launches.txt'
-MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.96, 4: 0.76, 8: 0.60}, 'minitaur': {1: 1.00, 2: 0.66, 4: 0.62, 8: 0.62}}
+MEASURED_SHARD_TIME = {'kitchen': {1: 1.00, 2: 0.95, 4: 0.76, 8: 0.60}, 'minitaur': {1: 1.00, 2: 0.66, 4: 0.62, 8: 0.62}}
 
 
 def predicted_scaling(workload, n_global, world):

@@ -305,9 +305,33 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
 #ifndef EARL_NO_PREFETCH
 #define EARL_NO_PREFETCH 0
 #endif
+  // Edge-vs-capsule blocks (the door's handle rods: 4 pairs each on 16 lanes per env) share a pass: a run of consecutive near capsule blocks is tested side by side, lane ->
+  // (block, pair) as in the kitchen's packed C2 below.  cp_b / cp_off: this lane's block of the FIRST such pass and where its lanes begin (the run that starts at the first
+  // near block, if that is a capsule block) -- worked out here so that the prefetch below fetches the record this lane will test.  (Round 6: the wave the door's launch waits
+  // for has 5.3 near blocks per timestep, 3.3 of them capsule blocks: one pass instead of three.)
+  int cp_b = -1, cp_off = 0;
+  BlkMask cp_taken = 0;
+  auto capsule_run = [&](const BlkMask from, int& myb, int& myoff) -> BlkMask {     // the leading run of capsule blocks of `from` that fits the group's lanes
+    BlkMask taken = 0;
+    int used = 0;
+    myb = -1; myoff = 0;
+    for (BlkMask r2 = from; r2; r2 &= r2 - 1u) {
+      const int b = sizeof(BlkMask) == 8 ? __builtin_ctzll((unsigned long long)r2) : __builtin_ctz((unsigned int)r2);
+      const int sz = bt.end[b] - bt.begin[b];
+      if (!((bt.cap[b] >> 8) & 1) || used + sz > LPE) break;      // (a capsule block of more than LPE pairs is left to the block-per-pass loop)
+      if (sub >= used && sub < used + sz) { myb = b; myoff = used; }
+      used += sz;
+      taken |= (BlkMask)1 << b;
+    }
+    return taken;
+  };
+  if constexpr (Lim<NV>::CAPS && !Lim<NV>::PACK) {
+    if (nearw) cp_taken = capsule_run(nearw, cp_b, cp_off);
+  }
   if (nearw && !(EARL_NO_PREFETCH && NV <= 10) && !Lim<NV>::PACK) {      // (two waves per SIMD hide that latency themselves; the registers are worth more there)
     pf_blk = sizeof(BlkMask) == 8 ? __builtin_ctzll((unsigned long long)nearw) : __builtin_ctz((unsigned int)nearw);
-    const int pend = bt.end[pf_blk], pi0 = bt.begin[pf_blk] + sub;
+    const int pb_ = cp_taken ? (cp_b >= 0 ? cp_b : pf_blk) : pf_blk;
+    const int pend = bt.end[pb_], pi0 = bt.begin[pb_] + sub - (cp_taken && cp_b >= 0 ? cp_off : 0);
     const int pi = pi0 < pend ? pi0 : pend - 1;
     pf_link = col->pair_rec[pi].sph_link; pf_cls = col->pair_rec[pi].cls;
     pf_r = col->pair_rec[pi].r; pf_margin = col->pair_rec[pi].margin;
@@ -876,8 +900,98 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   } else
   if (nearw) {
     // C2: pair tests of the near blocks, in pair order; the box frame once per block, the sphere centre per test
-    for (BlkMask rest = nearw; rest; rest &= rest - 1u) {
+    BlkMask rest = nearw;
+    while (rest) {
+      if constexpr (Lim<NV>::CAPS) {
+        // a run of capsule blocks at the head of `rest`: ONE pass, lane -> (block, pair); contacts keep the sequential order and the per-block caps
+        int myb, myoff;
+        const bool first = rest == nearw;
+        const BlkMask taken = first ? cp_taken : capsule_run(rest, myb, myoff);
+        if (first) { myb = cp_b; myoff = cp_off; }
+        if (taken) {
+          const bool has = myb >= 0;
+          const int b = has ? myb : (sizeof(BlkMask) == 8 ? __builtin_ctzll((unsigned long long)taken) : __builtin_ctz((unsigned int)taken));
+          const bool mine = has && ((nearg >> b) & 1u);
+          const int bsz = bt.end[b] - bt.begin[b], xl = bt.box_link[b];
+          V3 pb = ld3(bt.box_pos[b]);
+          Q4 qb = ldq(bt.box_quat[b]);
+          {
+            const Q4 ql = ldq(s.Xq[xl < 0 ? 0 : xl]);
+            double R[3][3];
+            qmat(ql, R);
+            pb = selv(xl < 0, pb, add(ld3(s.Xp[xl < 0 ? 0 : xl]), mulv(R, pb)));
+            qb = selq(xl < 0, qb, qmul(ql, qb));
+          }
+          double Rb[3][3];
+          qmat(qb, Rb);
+          const V3 h = ld3(bt.box_half[b]);
+          const int room = bt.cap[b] & 255;
+          int lk, cls;
+          double r, margin, hl;
+          V3 c, ed;
+          if (first && pf_blk >= 0) {                     // uniform: the records prefetched after C0 (not in the eight-wave build: EARL_NO_PREFETCH)
+            lk = pf_link; cls = pf_cls; r = pf_r; margin = pf_margin; c = pf_pos; ed = pf_dir; hl = pf_hl;
+          } else {
+            const int pi = has ? bt.begin[b] + (sub - myoff) : bt.begin[b];
+            lk = col->pair_rec[pi].sph_link; cls = col->pair_rec[pi].cls;
+            r = col->pair_rec[pi].r; margin = col->pair_rec[pi].margin;
+            c = ld3(col->pair_rec[pi].pos); ed = ld3(col->pair_rec[pi].dir); hl = col->pair_rec[pi].hl;
+          }
+          (void)r;
+          {
+            double R[3][3];
+            qmat(ldq(s.Xq[lk < 0 ? 0 : lk]), R);
+            const V3 w = add(ld3(s.Xp[lk < 0 ? 0 : lk]), mulv(R, c));
+            c = selv(lk < 0, c, w);
+            ed = selv(lk < 0, ed, mulv(R, ed));
+          }
+          // (the pass's inputs held in registers HERE and its results below, whatever else the instantiation does around them: under fp contract(fast) the door's two builds
+          // -- four and eight waves per workgroup, the latter for batches beyond 4096 envs -- otherwise fused these sums differently, and a shard of 4096 envs no longer
+          // returned the bits of the same envs in a batch of 8192: tests/test_sawyer_full_gpu.py)
+          pin6(c.x, c.y, c.z, ed.x, ed.y, ed.z); pin6(pb.x, pb.y, pb.z, Rb[0][0], Rb[0][1], Rb[0][2]); pin6(Rb[1][0], Rb[1][1], Rb[1][2], Rb[2][0], Rb[2][1], Rb[2][2]);
+          // closest points of the edge (c +- hl ed) and the capsule's axis segment (pb +- hc cd); normal from the axis to the edge
+          const V3 cd{Rb[0][2], Rb[1][2], Rb[2][2]}, rr = vsub(c, pb);
+          const double hc = h.z - h.x, rad = h.x;
+          const double b_ = dot(ed, cd), c_ = dot(ed, rr), f_ = dot(cd, rr), den = 1.0 - b_ * b_;
+          double s_ = den > 1e-12 ? fmin(fmax((b_ * f_ - c_) / den, -hl), hl) : 0.0;
+          const double t_ = fmin(fmax(fma(b_, s_, f_), -hc), hc);
+          s_ = fmin(fmax(fma(b_, t_, -c_), -hl), hl);
+          const V3 d = vsub(add(rr, scl(ed, s_)), scl(cd, t_));
+          const double d2 = dot(d, d);
+          const bool sane = d2 > 1e-18;
+          const double inv = rsq_nr(sane ? d2 : 1.0);
+          double dist = d2 * inv - rad;
+          const V3 nw = scl(d, inv);
+          V3 nl = mulvT(Rb, nw);
+          V3 q{nl.x * rad, nl.y * rad, t_ + nl.z * rad};   // surface point of the capsule in its own frame (axis = z)
+          dist = pinned(dist); pin6(nl.x, nl.y, nl.z, q.x, q.y, q.z);
+          const bool hit = mine && sub - myoff < bsz && sane && dist < margin;
+          auto of_group = [&](const unsigned long long bits) { return LPE == 64 ? bits : ((bits >> (grp * (LPE & 63))) & ((1ull << (LPE & 63)) - 1ull)); };
+          const unsigned long long below = (1ull << sub) - 1ull;
+          const unsigned long long gb = of_group(__ballot(hit));
+          const unsigned long long seg = has ? (bsz >= 64 ? ~0ull : ((1ull << bsz) - 1ull) << myoff) : 0ull;      // the lanes of this lane's block
+          const int before_blk = __popcll(gb & seg & below);
+          const bool accept = hit && before_blk < room;
+          const unsigned long long ga = of_group(__ballot(accept));
+          const int slot = nct + __popcll(ga & below);
+          {
+            V3 n = mulv(Rb, nl);
+            V3 p = add(add(pb, mulv(Rb, q)), scl(n, 0.5 * dist));
+            pin6(n.x, n.y, n.z, p.x, p.y, p.z);
+            if (accept && slot < maxcon) {
+              double* o = ctw[slot];
+              o[0] = dist; o[1] = n.x; o[2] = n.y; o[3] = n.z; o[4] = p.x; o[5] = p.y; o[6] = p.z;
+              o[7] = (double)(cls + 64 * (lk + 1) + 4096 * (xl + 1));
+            }
+          }
+          const int took = __popcll(ga);
+          nct = nct + took < maxcon ? nct + took : maxcon;
+          rest &= ~taken;
+          continue;
+        }
+      }
       const int b = sizeof(BlkMask) == 8 ? __builtin_ctzll((unsigned long long)rest) : __builtin_ctz((unsigned int)rest);
+      rest &= rest - 1u;
       const bool mine = (nearg >> b) & 1u;
       const int pend = bt.end[b], xl = bt.box_link[b];
       V3 pb = ld3(bt.box_pos[b]);
@@ -987,6 +1101,7 @@ __device__ __forceinline__ void substep(Shared<NV>& s, const typename ModelOf<NV
   }
   // most over the wave (uniform loop bound for the contact phases)
   PCOUNT(20, 1); PCOUNT(21, nearw ? 1 : 0); PCOUNT(22, __popcll((unsigned long long)nearw));
+  PCOUNT(31, __popcll((unsigned long long)nearw & 0x3Full));      // (the door's six 4-pair capsule blocks among them)
   int ncmax = 0;
   if (ROLE != 2 && nearw && __any(nct > 0)) {          // (wave B of a split timestep: after barrier X, from the count the collision wave left)
 #pragma unroll

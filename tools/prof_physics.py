@@ -62,6 +62,7 @@ def rollout_counters(n, T, sel=None):
   ts = max(1, out[20])
   print(f'rollout N={n} T={T}: timesteps of wave {sel or 0}: {out[20]}; with a near block {out[21] / ts:.3f} (blocks per timestep {out[22] / ts:.2f}); '
         f'with contacts {out[23] / ts:.3f} (max contacts per env, mean {out[24] / ts:.2f}); Newton iterations per timestep {out[25] / ts:.2f}')
+  print(f'  near blocks among the first six of the table (the door\'s 4-pair capsule blocks) per timestep: {out[31] / ts:.2f}')
   nc = out[26]
   print(f'  timesteps in which a contact joins the arm and the object (shared dense factorisation): {nc / ts:.3f}; active-set phase: {out[27] / max(1, nc):.0f} cycles in those, '
         f'{out[28] / max(1, ts - nc):.0f} in the others')
